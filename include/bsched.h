@@ -1,0 +1,296 @@
+/*
+ * bsched.h — C ABI of the MI355X gang-feasibility core.
+ *
+ * This is the drop-in boundary for ONE hot path of tenstack/batch-scheduler: the
+ * PreFilter / Filter / Permit resource-fit arithmetic of
+ * /root/reference/pkg/scheduler/core/core.go.  The reference has no FFI today
+ * (CGO_ENABLED=0, Makefile:28); the Go plugin keeps its framework surface
+ * (batchscheduler.go:102 PreFilter, :151 Filter, :165 Permit, :214 Less) and binds the
+ * entry points below through cgo (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *  - Only flat arrays of scalars cross the boundary: no strings, no pointers to
+ *    pointers.  Strings the reference compares (group full names, OwnerReferences UIDs,
+ *    resource names, node names) are interned to integers by the Go shim.
+ *  - A "resource vector" (upstream nodeinfo.Resource) is L = 4 + S int64 lanes:
+ *      lane 0 MilliCPU, 1 Memory, 2 EphemeralStorage, 3 AllowedPodNumber,
+ *      lane 4+s = ScalarResources[name_s]  with a presence bit s (Go map key exists).
+ *    S (scalar lanes) is fixed per context (bs_config.scalar_lanes <= BS_MAX_SCALARS).
+ *  - 2-D arrays are lane-major SoA: x[lane * count + index].
+ *  - The caller owns every buffer it passes; the library copies during the call and
+ *    keeps no caller pointer after return (cgo pointer rules).  The library owns device
+ *    memory, its HIP stream and events.
+ *  - Every function returns BS_OK (0) or a negative bs_status; nothing throws or aborts
+ *    across the ABI.  Reference panics (uint32 divide by zero core.go:716-717, nil
+ *    maxPGStatus core.go:525) are reported as decision codes, not crashes.
+ *  - Mutating calls on one bs_ctx must be serialised by the caller.
+ */
+#ifndef BSCHED_H
+#define BSCHED_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BS_ABI_VERSION 1u
+
+enum {
+  BS_LANE_CPU = 0,       /* Resource.MilliCPU          */
+  BS_LANE_MEM = 1,       /* Resource.Memory            */
+  BS_LANE_EPH = 2,       /* Resource.EphemeralStorage  */
+  BS_LANE_PODS = 3,      /* Resource.AllowedPodNumber  */
+  BS_FIXED_LANES = 4,
+  BS_MAX_SCALARS = 12,
+  BS_MAX_LANES = 16
+};
+
+typedef enum bs_status {
+  BS_OK = 0,
+  BS_ERR_INVALID = -1,   /* bad argument / inconsistent sizes                         */
+  BS_ERR_NO_DEVICE = -2, /* no gfx950 device, or HIP runtime failure at create time   */
+  BS_ERR_HIP = -3,       /* a HIP call failed (bs_last_error has the text)            */
+  BS_ERR_STATE = -4,     /* call order: nodes / fit / groups / pods not loaded yet    */
+  BS_ERR_CAPACITY = -5,  /* exceeds configured or addressable capacity                */
+  BS_ERR_NOMEM = -6,
+  BS_ERR_COMM = -7       /* RCCL failure                                              */
+} bs_status;
+
+/* ---- node flags (per NodeInfo in list order) -------------------------------------- */
+#define BS_NODE_NIL            0x01u /* list entry is nil           core.go:606 (skip); Filter: core.go:447 -> error */
+#define BS_NODE_NO_NODE        0x02u /* info.Node() == nil          core.go:610 (skip); Filter: Get() fails core.go:443 */
+#define BS_NODE_UNSCHEDULABLE  0x04u /* Spec.Unschedulable          core.go:615 (skip); NOT consulted by Filter */
+#define BS_NODE_TAINT_ERR      0x08u /* info.Taints() returned err  core.go:639 (adds zeros, still compared) */
+#define BS_NODE_SKIP_MASK      0x07u
+
+/* ---- group flags (cache.PodGroupMatchStatus, cache.go:52-67) ---------------------- */
+#define BS_GROUP_SCHEDULED_LATCH 0x01u /* pgs.Scheduled (set core.go:305, never cleared) */
+#define BS_GROUP_HAS_POD         0x02u /* pgs.Pod != nil (first pod seen, core.go:486-488) */
+#define BS_GROUP_HAS_MINRES      0x04u /* Spec.MinResources != nil (core.go:489-493)      */
+#define BS_GROUP_DENIED          0x08u /* live entry in lastDeniedPG (core.go:105-110)    */
+
+/* ---- pod flags / group sentinels -------------------------------------------------- */
+#define BS_POD_LAST_PERMITTED 0x01u   /* live entry in lastPermittedPod (core.go:95-98) */
+#define BS_POD_NOT_GROUPED   (-1)     /* no PodGroupLabel (util/k8s.go:62-70)           */
+#define BS_POD_GROUP_MISSING (-2)     /* label set but podGroupStatusCache.Get == nil   */
+
+/* ---- PreFilter decision codes (which `return` of core.go:88-167 fired) ------------ */
+#define BS_PF_PASS_NOT_GROUPED    0u  /* core.go:89-92   */
+#define BS_PF_PASS_LAST_PERMITTED 1u  /* core.go:95-98   */
+#define BS_PF_PASS_NO_MAX         2u  /* core.go:127-130 */
+#define BS_PF_PASS_FIRST_FITS     3u  /* core.go:136-146 */
+#define BS_PF_PASS_IS_MAX         4u  /* core.go:150-155 */
+#define BS_PF_PASS_RESERVE_FITS   5u  /* core.go:157-166 */
+#define BS_PF_ERR_PG_NOT_FOUND   16u  /* core.go:100-103 */
+#define BS_PF_ERR_DENIED         17u  /* core.go:105-110 */
+#define BS_PF_ERR_OCCUPIED       18u  /* core.go:113-115 <- :503-510 */
+#define BS_PF_REJECT_FIRST       19u  /* core.go:140-144 (+AddToDenyCache) */
+#define BS_PF_REJECT_RESERVE     20u  /* core.go:161-165 (+AddToDenyCache) */
+#define BS_PF_PANIC_DIV0         32u  /* findMaxPG uint32 divide by zero, core.go:716-717 */
+#define BS_PF_IS_PASS(code) ((code) < 16u)
+
+/* ---- Filter per-pod codes (core.go:170-191, :514-564) ----------------------------- */
+#define BS_FL_PASS_NOT_GROUPED    0u  /* core.go:171-174: every node passes */
+#define BS_FL_PASS_IS_MAX         1u  /* case 1, core.go:531-535            */
+#define BS_FL_PASS_NO_MINRES      2u  /* maxSingleRequired == nil, :542-544 */
+#define BS_FL_EVALUATED           3u  /* per node: case 2 / case 3 / ErrorResourceNotEnough */
+#define BS_FL_ERR_PG_NOT_FOUND   16u  /* core.go:177-180 */
+#define BS_FL_PANIC_NIL_MAX      32u  /* sop.maxPGStatus == nil deref, core.go:525 */
+#define BS_FL_NOT_RUN            64u  /* PreFilter did not pass: framework never calls Filter */
+
+/* Filter per-(pod,node) codes, bs_filter_one */
+#define BS_FN_PASS_CASE2          0u  /* left >= pod + maxSingle, core.go:551-555 */
+#define BS_FN_PASS_CASE3          1u  /* node cannot hold a leader member, :557-561 */
+#define BS_FN_ERR_NOT_ENOUGH     16u  /* ErrorResourceNotEnough, :562-563 */
+#define BS_FN_ERR_SNAPSHOT       17u  /* "SnapShot not initialized", :545-548 */
+
+#define BS_K_NONE        0xFFFFFFFFu  /* scan ran over every node, no prefix satisfied */
+#define BS_K_NOT_SCANNED 0xFFFFFFFEu  /* decision taken without a node scan            */
+
+typedef struct bs_ctx bs_ctx;
+
+typedef struct bs_config {
+  uint32_t abi_version;   /* BS_ABI_VERSION */
+  int32_t  device;        /* HIP device ordinal */
+  uint32_t scalar_lanes;  /* S */
+  uint32_t eph_gate;      /* upstream feature gate LocalStorageCapacityIsolation (default 1):
+                             Resource.Add counts ephemeral-storage only when on */
+  uint32_t enable_timing; /* record hipEvents around every kernel (bs_timing_get) */
+  uint32_t reserved[3];
+} bs_config;
+
+/* Node snapshot, in SnapshotSharedLister().NodeInfos().List() order (core.go:597). */
+typedef struct bs_nodes_soa {
+  uint32_t n;
+  const int64_t*  allocatable;        /* [L][n] info.AllocatableResource()                   */
+  const int64_t*  requested;          /* [L][n] info.RequestedResource(); pods lane = podCount
+                                         exactly as core.go:650-653 / :455-458 resolve it      */
+  const uint32_t* allocatable_present;/* [n] bit s: allocatable.ScalarResources has key s     */
+  const uint32_t* requested_present;  /* [n] bit s: requested.ScalarResources has key s       */
+  const uint8_t*  flags;              /* [n] BS_NODE_*                                        */
+} bs_nodes_soa;
+
+/* PodGroup cache state, in the iteration order findMaxPG is to use (core.go:703; Go map
+ * order is random, so the caller fixes one and parity is defined given that order). */
+typedef struct bs_groups_soa {
+  uint32_t g;
+  uint32_t* min_member;            /* [g] Spec.MinMember        (types.go:79-101)  */
+  uint32_t* status_scheduled;      /* [g] Status.Scheduled      (types.go:104-130) */
+  uint32_t* matched;               /* [g] len(MatchedPodNodes.Items()) (cache.go:57) */
+  uint8_t*  flags;                 /* [g] BS_GROUP_*                                */
+  uint32_t* cls;                   /* [g] fit class of pgs.Pod (valid iff HAS_POD)  */
+  int64_t*  min_resources;         /* [L][g] Spec.MinResources (valid iff HAS_MINRES) */
+  uint32_t* min_resources_present; /* [g] scalar keys in MinResources               */
+  uint64_t* occupied_by;           /* [g] interned Status.OccupiedBy, 0 == ""       */
+} bs_groups_soa;
+
+/* Pending pods in scheduling-queue order. */
+typedef struct bs_pods_soa {
+  uint32_t p;
+  const int32_t*  group;       /* [p] group index, BS_POD_NOT_GROUPED or BS_POD_GROUP_MISSING */
+  const int64_t*  req;         /* [L][p] getPodResourceRequire(pod), core.go:761-772          */
+  const uint32_t* req_present; /* [p] scalar keys in that Resource                            */
+  const uint32_t* cls;         /* [p] fit class the pod defines if it becomes pgs.Pod         */
+  const uint64_t* owner;       /* [p] interned sorted+joined OwnerReferences UIDs, 0 = none   */
+  const uint8_t*  flags;       /* [p] BS_POD_*                                                */
+} bs_pods_soa;
+
+/* Outputs of one batch (any pointer may be NULL = not wanted). */
+typedef struct bs_batch_out {
+  uint8_t*  pf_code;       /* [p] BS_PF_*                                                     */
+  uint32_t* pf_first_k;    /* [p] list index of the node whose prefix first satisfied the
+                              request (reference `count`-1, core.go:605,623), BS_K_NONE,
+                              or BS_K_NOT_SCANNED                                             */
+  int32_t*  pf_leader;     /* [p] group index findMaxPG returned for this pod (sop.maxPGStatus,
+                              core.go:120-122), -1 none                                       */
+  uint8_t*  fl_code;       /* [p] BS_FL_*                                                     */
+  uint32_t* fl_feasible;   /* [p] nodes on which Filter returns nil                           */
+  uint64_t* fl_bitmap;     /* [ceil(n/64)][p] word-major: bit (node&63) of word node>>6       */
+  uint32_t* group_admit;   /* [g] pods of the group that pass PreFilter and (if Filter ran)
+                              have >=1 feasible node; summed over ranks when sharded          */
+  uint8_t*  group_ready;   /* [g] quorum predicate core.go:303 with matched+admit             */
+} bs_batch_out;
+
+/* bs_batch_run stage bits */
+#define BS_STAGE_PREFILTER 0x1u
+#define BS_STAGE_FILTER    0x2u
+#define BS_STAGE_TALLY     0x4u   /* per-group admit counts + ready bits */
+#define BS_STAGE_ALL       0x7u
+#define BS_BATCH_COMMIT    0x100u /* persist first-pod capture / occupancy / deny into the ctx
+                                     group state (bs_groups_read), as sequential PreFilter would */
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+uint32_t    bs_abi_version(void);
+const char* bs_strerror(int status);
+const char* bs_last_error(const bs_ctx* ctx);           /* text of the last BS_ERR_HIP/COMM */
+int bs_create(const bs_config* cfg, bs_ctx** out);
+int bs_destroy(bs_ctx* ctx);
+
+/* ---- snapshot / state loads (replaces frameworkHandler.SnapshotSharedLister() reads,
+ *      core.go:437,567,597, and the cache reads of cache.go:94-102) ------------------ */
+int bs_nodes_load(bs_ctx* ctx, const bs_nodes_soa* nodes);
+/* fit[c][n] = checkFit(rep pod of class c, node n), core.go:741-759; bit n&31 of word n>>5 */
+int bs_fit_load(bs_ctx* ctx, uint32_t n_classes, const uint32_t* fit_bits);
+int bs_groups_load(bs_ctx* ctx, const bs_groups_soa* groups);
+int bs_groups_read(bs_ctx* ctx, bs_groups_soa* groups_out); /* caller-sized arrays, g must match */
+int bs_pods_load(bs_ctx* ctx, const bs_pods_soa* pods);
+
+/* node churn (BASELINE config 5): stable delete / append / requested-update */
+#define BS_DELTA_UPDATE 0u   /* replace node `index` (all lanes, presence, flags, fit column) */
+#define BS_DELTA_APPEND 1u   /* append at the end of the list                                 */
+#define BS_DELTA_REMOVE 2u   /* stable delete of node `index`                                 */
+typedef struct bs_node_delta {
+  uint32_t kind, index;
+  int64_t  allocatable[BS_MAX_LANES];
+  int64_t  requested[BS_MAX_LANES];
+  uint32_t allocatable_present, requested_present;
+  uint32_t flags;
+  uint32_t fit_default;      /* 1: node fits every class except those listed in ...        */
+  uint32_t n_fit_exceptions; /* ... fit_exceptions (classes whose bit is !fit_default)      */
+  uint32_t fit_exceptions[8];
+} bs_node_delta;
+int bs_nodes_apply(bs_ctx* ctx, const bs_node_delta* deltas, uint32_t count);
+int bs_nodes_count(const bs_ctx* ctx, uint32_t* n_out);
+
+/* ---- single queries: 1:1 drop-ins ------------------------------------------------- */
+/* compareClusterResourceAndRequire(pod of class `cls`, req, percent), core.go:595-632.
+ * *fits = its bool; *first_k as in bs_batch_out.pf_first_k (BS_K_NONE when false). */
+int bs_cluster_fits(bs_ctx* ctx, uint32_t cls, float percent, const int64_t* req /*[L]*/,
+                    uint32_t req_present, uint8_t* fits, uint32_t* first_k);
+/* singleNodeResource for every node (core.go:634-670): left[L][n] and presence[n];
+ * flagged-skip nodes are still evaluated (the skip lives in the callers). */
+int bs_node_left(bs_ctx* ctx, uint32_t cls, float percent, int64_t* left, uint32_t* present);
+/* The running sums compareClusterResourceAndRequire forms (core.go:602,621): one row per
+ * non-skipped node in list order.  prefix[L][n], present[n], node_index[n]; *rows = count. */
+int bs_scan_prefix(bs_ctx* ctx, uint32_t cls, float percent, int64_t* prefix, uint32_t* present,
+                   uint32_t* node_index, uint32_t* rows);
+/* computeClusterResource(pod of class cls), core.go:566-593 (log-only in the reference). */
+int bs_cluster_total(bs_ctx* ctx, uint32_t cls, int64_t* total /*[L]*/, uint32_t* present);
+/* computeResourceSatisfied for one (pod, node) given leader group (core.go:514-564);
+ * leader < 0 reports BS_FL_PANIC_NIL_MAX in *fl_code.  *fn_code valid iff *fl_code == BS_FL_EVALUATED. */
+int bs_filter_one(bs_ctx* ctx, int32_t pod_group, const int64_t* pod_req, uint32_t pod_req_present,
+                  int32_t leader, uint32_t node, uint8_t* fl_code, uint8_t* fn_code);
+/* findMaxPG over the loaded group state (core.go:701-739): *leader = index or -1;
+ * *finished = maxFinished; returns BS_OK and sets *panic=1 on the divide-by-zero case. */
+int bs_find_max_pg(bs_ctx* ctx, int32_t* leader, uint32_t* finished, uint8_t* panic);
+
+/* ---- the batched hot path --------------------------------------------------------- */
+/* Decisions equal to calling the reference's PreFilter for pods 0..p-1 in order against the
+ * frozen snapshot and group counters, with the in-batch side effects of core.go:113
+ * (first-pod capture, MinResources default, occupancy) and :142,:163 (deny cache) replayed
+ * in queue order.  Filter is evaluated for pods that passed, with sop.maxPGStatus as that
+ * pod's PreFilter left it; Filter's own TTL side effects (core.go:184,188) are not replayed
+ * (the shipped config does not enable Filter: deploy/scheduler/config/batch_scheduler_config.json).
+ * Asynchronous on the context stream; bs_batch_sync waits. */
+int bs_batch_run(bs_ctx* ctx, uint32_t stages);
+int bs_batch_sync(bs_ctx* ctx);
+int bs_batch_read(bs_ctx* ctx, const bs_batch_out* out);
+
+/* ---- pod-axis sharding (one process per GPU) -------------------------------------- */
+/* Only pods [lo,hi) of the loaded batch are evaluated by this context; deny replay stays
+ * exact because each rank replays the PreFilter codes of ALL pods of a group it owns pods of
+ * (groups never straddle ranks when the caller cuts at group boundaries; otherwise the
+ * straddling group's earlier pods are re-evaluated locally). */
+int bs_shard_set(bs_ctx* ctx, uint32_t rank, uint32_t nranks);
+/* Device address of the per-group admit counters (uint32[g]) so the caller's collective
+ * (torch.distributed / RCCL all-reduce, sum) can run in place between the two halves. */
+int bs_group_admit_devptr(bs_ctx* ctx, void** dptr, uint32_t* count);
+/* HIP stream (hipStream_t) the context launches on, for event timing / stream ordering. */
+int bs_stream(bs_ctx* ctx, void** stream);
+/* Native RCCL path for hosts without torch (the Go shim): unique id is 128 bytes. */
+int bs_comm_unique_id(uint8_t id[128]);
+int bs_comm_init(bs_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t nranks);
+/* Second half after the all-reduce: ready bits from the (reduced) admit counters. */
+int bs_batch_finish(bs_ctx* ctx);
+
+/* ---- measurement ------------------------------------------------------------------ */
+#define BS_KERNEL_PREPASS   0u
+#define BS_KERNEL_LEADER    1u
+#define BS_KERNEL_QUERY     2u
+#define BS_KERNEL_TABLES    3u
+#define BS_KERNEL_SCAN      4u   /* the dominant kernel: pods x nodes prefix compare */
+#define BS_KERNEL_RESOLVE   5u
+#define BS_KERNEL_FILTER    6u
+#define BS_KERNEL_TALLY     7u
+#define BS_KERNEL_COUNT     8u
+typedef struct bs_timing {
+  double   total_ms[BS_KERNEL_COUNT];   /* hipEvent elapsed, summed over launches */
+  uint64_t launches[BS_KERNEL_COUNT];
+} bs_timing;
+int bs_timing_reset(bs_ctx* ctx);
+int bs_timing_get(bs_ctx* ctx, bs_timing* out);   /* synchronises the stream */
+const char* bs_kernel_name(uint32_t kernel_id);
+/* Work counters of the last batch: evals the scan kernel executed (node rows visited x 64-lane
+ * tiles), logical pods x nodes, scan queries, tables built. */
+typedef struct bs_batch_stats {
+  uint64_t scan_queries, scan_rows_executed, scan_evals_executed, tables_built, logical_evals;
+  uint64_t filter_evals;
+} bs_batch_stats;
+int bs_batch_stats_get(bs_ctx* ctx, bs_batch_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSCHED_H */

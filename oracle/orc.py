@@ -1,0 +1,254 @@
+"""ctypes binding of the CPU oracle (oracle/libbs_oracle.so).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+soa = importlib.import_module("batch-scheduler_amd.soa")
+
+LIB_PATH = os.path.join(_HERE, "libbs_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("bs_oracle.c", "bs_oracle.h")] + [os.path.join(_ROOT, "include", "bsched.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libbs_oracle.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+class Resource(C.Structure):
+    _fields_ = [("v", C.c_int64 * soa.MAX_LANES), ("present", C.c_uint32)]
+
+    @staticmethod
+    def make(lanes, present=0) -> "Resource":
+        r = Resource()
+        for j, x in enumerate(lanes):
+            r.v[j] = int(x)
+        r.present = int(present)
+        return r
+
+    def lanes(self, L: int):
+        return [int(self.v[j]) for j in range(L)]
+
+
+class SnapshotStruct(C.Structure):
+    _fields_ = [("nodes", soa.NodesStruct), ("fit", C.POINTER(C.c_uint32)), ("n_classes", C.c_uint32),
+                ("S", C.c_uint32), ("eph_gate", C.c_uint32)]
+
+
+class SopStruct(C.Structure):
+    _fields_ = [("snap", SnapshotStruct), ("groups", soa.GroupsStruct), ("max_finished_pg", C.c_int32),
+                ("has_max_status", C.c_int), ("faithful_cost", C.c_int), ("iters", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_scale.restype = C.c_int64
+        L.orc_scale.argtypes = [C.c_int64, C.c_float]
+        L.orc_compare_resource_and_require.restype = C.c_int
+        L.orc_compare_resource_and_require.argtypes = [C.POINTER(Resource), C.POINTER(Resource), C.c_uint32]
+        L.orc_single_node_resource.restype = None
+        L.orc_single_node_resource.argtypes = [C.POINTER(SnapshotStruct), C.c_uint32, C.c_uint32, C.c_float, C.POINTER(Resource)]
+        L.orc_compare_cluster.restype = C.c_int
+        L.orc_compare_cluster.argtypes = [C.POINTER(SnapshotStruct), C.c_uint32, C.POINTER(Resource), C.c_float,
+                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.orc_compute_cluster_resource.restype = None
+        L.orc_compute_cluster_resource.argtypes = [C.POINTER(SnapshotStruct), C.c_uint32, C.POINTER(Resource), C.POINTER(C.c_uint64)]
+        L.orc_get_left_resource.restype = C.c_int
+        L.orc_get_left_resource.argtypes = [C.POINTER(SnapshotStruct), C.c_uint32, C.POINTER(Resource)]
+        L.orc_scan_prefix.restype = C.c_uint32
+        L.orc_scan_prefix.argtypes = [C.POINTER(SnapshotStruct), C.c_uint32, C.c_float, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_node_left.restype = None
+        L.orc_node_left.argtypes = [C.POINTER(SnapshotStruct), C.c_uint32, C.c_float, C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]
+        L.orc_find_max_pg.restype = C.c_int32
+        L.orc_find_max_pg.argtypes = [C.POINTER(soa.GroupsStruct), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+        L.orc_get_pre_allocated.restype = None
+        L.orc_get_pre_allocated.argtypes = [C.POINTER(soa.GroupsStruct), C.c_uint32, C.c_int64, C.c_uint32, C.c_uint32, C.POINTER(Resource)]
+        L.orc_permit_ready.restype = C.c_int
+        L.orc_permit_ready.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_prefilter.restype = C.c_uint8
+        L.orc_prefilter.argtypes = [C.POINTER(SopStruct), C.POINTER(soa.PodsStruct), C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_filter_node.restype = C.c_uint8
+        L.orc_filter_node.argtypes = [C.POINTER(SopStruct), C.POINTER(soa.PodsStruct), C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint8)]
+        L.orc_batch.restype = None
+        L.orc_batch.argtypes = [C.POINTER(SopStruct), C.POINTER(soa.PodsStruct), C.c_uint32, C.POINTER(soa.BatchOutStruct)]
+        L.orc_ttl_new.restype = C.c_void_p
+        L.orc_ttl_free.argtypes = [C.c_void_p]
+        L.orc_ttl_set.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64]
+        L.orc_ttl_add.restype = C.c_int
+        L.orc_ttl_add.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64]
+        L.orc_ttl_get.restype = C.c_int
+        L.orc_ttl_get.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_uint64)]
+        L.orc_ttl_delete.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_ttl_count.restype = C.c_uint32
+        L.orc_ttl_count.argtypes = [C.c_void_p, C.c_int64]
+        _lib = L
+    return _lib
+
+
+def scale(a: int, pct: float) -> int:
+    return int(lib().orc_scale(int(a), float(np.float32(pct))))
+
+
+class Snapshot:
+    """Node snapshot + fit masks, as the oracle sees them."""
+
+    def __init__(self, nodes, fit, scalar_lanes: int | None = None, eph_gate: int = 1):
+        self.nodes, self.fit = nodes, fit
+        self.S = nodes.lanes - soa.FIXED_LANES if scalar_lanes is None else scalar_lanes
+        assert nodes.lanes == soa.FIXED_LANES + self.S
+        assert fit.n == nodes.n
+        self.eph_gate = eph_gate
+        self.struct = SnapshotStruct(nodes.as_struct(), fit.bits.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                     fit.n_classes, self.S, eph_gate)
+
+    @property
+    def L(self) -> int:
+        return soa.FIXED_LANES + self.S
+
+    def single_node_resource(self, cls: int, node: int, pct: float):
+        r = Resource()
+        lib().orc_single_node_resource(C.byref(self.struct), cls, node, float(np.float32(pct)), C.byref(r))
+        return r.lanes(self.L), int(r.present)
+
+    def compare_cluster(self, cls: int, req, present: int, pct: float):
+        r = Resource.make(req, present)
+        fk, it = C.c_uint32(0), C.c_uint64(0)
+        ok = lib().orc_compare_cluster(C.byref(self.struct), cls, C.byref(r), float(np.float32(pct)), C.byref(fk), C.byref(it))
+        return bool(ok), int(fk.value), int(it.value)
+
+    def cluster_total(self, cls: int):
+        r = Resource()
+        it = C.c_uint64(0)
+        lib().orc_compute_cluster_resource(C.byref(self.struct), cls, C.byref(r), C.byref(it))
+        return r.lanes(self.L), int(r.present)
+
+    def left_resource(self, node: int):
+        r = Resource()
+        ok = lib().orc_get_left_resource(C.byref(self.struct), node, C.byref(r))
+        return (r.lanes(self.L), int(r.present)) if ok else None
+
+    def scan_prefix(self, cls: int, pct: float):
+        n = self.nodes.n
+        prefix = np.zeros((self.L, n), np.int64)
+        present = np.zeros(n, np.uint32)
+        idx = np.zeros(n, np.uint32)
+        rows = lib().orc_scan_prefix(C.byref(self.struct), cls, float(np.float32(pct)),
+                                     prefix.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     present.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                     idx.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return prefix[:, :rows].copy(), present[:rows].copy(), idx[:rows].copy()
+
+    def node_left(self, cls: int, pct: float):
+        n = self.nodes.n
+        left = np.zeros((self.L, n), np.int64)
+        present = np.zeros(n, np.uint32)
+        lib().orc_node_left(C.byref(self.struct), cls, float(np.float32(pct)),
+                            left.ctypes.data_as(C.POINTER(C.c_int64)), present.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return left, present
+
+
+def compare_resource_and_require(left, left_present, req, req_present, S: int) -> bool:
+    a, b = Resource.make(left, left_present), Resource.make(req, req_present)
+    return bool(lib().orc_compare_resource_and_require(C.byref(a), C.byref(b), S))
+
+
+def find_max_pg(groups):
+    gs = groups.as_struct()
+    fin, pan = C.c_uint32(0), C.c_uint8(0)
+    leader = lib().orc_find_max_pg(C.byref(gs), C.byref(fin), C.byref(pan))
+    return int(leader), int(fin.value), bool(pan.value)
+
+
+def pre_allocated(groups, g: int, matched: int, S: int, eph_gate: int = 1):
+    gs = groups.as_struct()
+    r = Resource()
+    lib().orc_get_pre_allocated(C.byref(gs), g, matched, S, eph_gate, C.byref(r))
+    return r.lanes(soa.FIXED_LANES + S), int(r.present)
+
+
+def permit_ready(matched: int, min_member: int, scheduled: int) -> bool:
+    return bool(lib().orc_permit_ready(matched & 0xFFFFFFFF, min_member & 0xFFFFFFFF, scheduled & 0xFFFFFFFF))
+
+
+class Sop:
+    """ScheduleOperation mirror over mutable flattened group state (sequential reference order)."""
+
+    def __init__(self, snap: Snapshot, groups, faithful_cost: bool = False):
+        self.snap = snap
+        self.groups = groups.copy()       # mutated in place by the oracle
+        self.struct = SopStruct(snap.struct, self.groups.as_struct(), -1, 0, int(faithful_cost), 0)
+
+    @property
+    def iters(self) -> int:
+        return int(self.struct.iters)
+
+    @property
+    def leader(self) -> int:
+        return int(self.struct.max_finished_pg) if self.struct.has_max_status else -1
+
+    def prefilter(self, pods, i: int):
+        ps = pods.as_struct()
+        fk = C.c_uint32(0)
+        code = lib().orc_prefilter(C.byref(self.struct), C.byref(ps), i, C.byref(fk))
+        return int(code), int(fk.value)
+
+    def filter_node(self, pods, i: int, leader: int, node: int):
+        ps = pods.as_struct()
+        fn = C.c_uint8(0)
+        fl = lib().orc_filter_node(C.byref(self.struct), C.byref(ps), i, leader, node, C.byref(fn))
+        return int(fl), int(fn.value)
+
+    def batch(self, pods, stages: int = soa.STAGE_ALL, bitmap: bool = True):
+        out = soa.BatchOut.alloc(pods.p, self.groups.g, self.snap.nodes.n, bitmap=bitmap)
+        ps, os_ = pods.as_struct(), out.as_struct()
+        lib().orc_batch(C.byref(self.struct), C.byref(ps), stages, C.byref(os_))
+        return out
+
+
+class TTL:
+    def __init__(self):
+        self.h = lib().orc_ttl_new()
+
+    def __del__(self):
+        try:
+            lib().orc_ttl_free(self.h)
+        except Exception:
+            pass
+
+    def set(self, key, val, now, ttl):
+        lib().orc_ttl_set(self.h, key, val, now, ttl)
+
+    def add(self, key, val, now, ttl) -> bool:
+        return lib().orc_ttl_add(self.h, key, val, now, ttl) == 0
+
+    def get(self, key, now):
+        v = C.c_uint64(0)
+        return int(v.value) if lib().orc_ttl_get(self.h, key, now, C.byref(v)) else None
+
+    def delete(self, key):
+        lib().orc_ttl_delete(self.h, key)
+
+    def count(self, now) -> int:
+        return int(lib().orc_ttl_count(self.h, now))
