@@ -1,0 +1,51 @@
+"""Builds the in-tree HIP shared library (gfx950 only) with hipcc.
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.  There is no JIT and no
+fallback: if hipcc is missing or the build fails this raises.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libbsched.so")
+SOURCES = ["bsched.hip"]
+HEADERS = ["bs_common.hpp", "bs_kernels.hpp", os.path.join("..", "..", "include", "bsched.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the gfx950 library cannot be built")
+    return exe
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [hipcc(), *FLAGS, *(extra_flags or []), "-o", LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES], "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    if verbose and res.stderr:
+        print(res.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

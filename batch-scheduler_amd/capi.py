@@ -1,0 +1,317 @@
+"""ctypes binding of the C ABI (include/bsched.h) implemented by libbsched.so (HIP, gfx950).
+
+This is what a host language does at the boundary: hand flat SoA buffers in, get decision arrays
+out.  No torch types cross it.  There is deliberately NO fallback: a missing library, a missing
+GPU or a failing HIP call raises BsError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import soa
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbsched.so")
+
+KERNEL_COUNT = 8
+KERNEL_PREPASS, KERNEL_LEADER, KERNEL_QUERY, KERNEL_TABLES, KERNEL_SCAN, KERNEL_RESOLVE, KERNEL_FILTER, KERNEL_TALLY = range(8)
+
+# every symbol include/bsched.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "bs_abi_version", "bs_strerror", "bs_last_error", "bs_create", "bs_destroy",
+    "bs_nodes_load", "bs_fit_load", "bs_groups_load", "bs_groups_read", "bs_pods_load",
+    "bs_nodes_apply", "bs_nodes_count",
+    "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
+    "bs_batch_run", "bs_batch_sync", "bs_batch_read",
+    "bs_shard_set", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
+    "bs_timing_reset", "bs_timing_get", "bs_kernel_name", "bs_batch_stats_get",
+]
+
+
+class BsError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: status {status}" + (f" ({detail})" if detail else ""))
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("scalar_lanes", C.c_uint32),
+                ("eph_gate", C.c_uint32), ("enable_timing", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class NodeDelta(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32),
+                ("allocatable", C.c_int64 * soa.MAX_LANES), ("requested", C.c_int64 * soa.MAX_LANES),
+                ("allocatable_present", C.c_uint32), ("requested_present", C.c_uint32), ("flags", C.c_uint32),
+                ("fit_default", C.c_uint32), ("n_fit_exceptions", C.c_uint32), ("fit_exceptions", C.c_uint32 * 8)]
+
+
+DELTA_UPDATE, DELTA_APPEND, DELTA_REMOVE = 0, 1, 2
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_double * KERNEL_COUNT), ("launches", C.c_uint64 * KERNEL_COUNT)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("scan_queries", C.c_uint64), ("scan_rows_executed", C.c_uint64), ("scan_evals_executed", C.c_uint64),
+                ("tables_built", C.c_uint64), ("logical_evals", C.c_uint64), ("filter_evals", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen libbsched.so and declare prototypes.  Raises if the HIP library is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise BsError(-2, "load_library", f"{p} not built: run `python __graft_entry__.py build` (hipcc, gfx950)")
+    L = C.CDLL(p)
+    vp, u32, i32, u8 = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint8
+    P = C.POINTER
+    L.bs_abi_version.restype = u32
+    L.bs_strerror.restype = C.c_char_p
+    L.bs_strerror.argtypes = [C.c_int]
+    L.bs_last_error.restype = C.c_char_p
+    L.bs_last_error.argtypes = [vp]
+    L.bs_kernel_name.restype = C.c_char_p
+    L.bs_kernel_name.argtypes = [u32]
+    L.bs_create.argtypes = [P(Config), P(vp)]
+    L.bs_destroy.argtypes = [vp]
+    L.bs_nodes_load.argtypes = [vp, P(soa.NodesStruct)]
+    L.bs_fit_load.argtypes = [vp, u32, P(u32)]
+    L.bs_groups_load.argtypes = [vp, P(soa.GroupsStruct)]
+    L.bs_groups_read.argtypes = [vp, P(soa.GroupsStruct)]
+    L.bs_pods_load.argtypes = [vp, P(soa.PodsStruct)]
+    L.bs_nodes_apply.argtypes = [vp, P(NodeDelta), u32]
+    L.bs_nodes_count.argtypes = [vp, P(u32)]
+    L.bs_cluster_fits.argtypes = [vp, u32, C.c_float, P(C.c_int64), u32, P(u8), P(u32)]
+    L.bs_node_left.argtypes = [vp, u32, C.c_float, P(C.c_int64), P(u32)]
+    L.bs_scan_prefix.argtypes = [vp, u32, C.c_float, P(C.c_int64), P(u32), P(u32), P(u32)]
+    L.bs_cluster_total.argtypes = [vp, u32, P(C.c_int64), P(u32)]
+    L.bs_filter_one.argtypes = [vp, i32, P(C.c_int64), u32, i32, u32, P(u8), P(u8)]
+    L.bs_find_max_pg.argtypes = [vp, P(i32), P(u32), P(u8)]
+    L.bs_batch_run.argtypes = [vp, u32]
+    L.bs_batch_sync.argtypes = [vp]
+    L.bs_batch_read.argtypes = [vp, P(soa.BatchOutStruct)]
+    L.bs_shard_set.argtypes = [vp, u32, u32]
+    L.bs_group_admit_devptr.argtypes = [vp, P(vp), P(u32)]
+    L.bs_group_admit_bind.argtypes = [vp, vp]
+    L.bs_stream.argtypes = [vp, P(vp)]
+    L.bs_comm_unique_id.argtypes = [P(u8)]
+    L.bs_comm_init.argtypes = [vp, P(u8), u32, u32]
+    L.bs_batch_finish.argtypes = [vp]
+    L.bs_timing_reset.argtypes = [vp]
+    L.bs_timing_get.argtypes = [vp, P(Timing)]
+    L.bs_batch_stats_get.argtypes = [vp, P(BatchStats)]
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:
+            fn.restype = C.c_int
+    if path is None:
+        _lib = L
+    return L
+
+
+def _i64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Context:
+    """One bs_ctx: a HIP device, its stream and the resident snapshot / group / pod state."""
+
+    def __init__(self, scalar_lanes: int = 0, eph_gate: int = 1, device: int = 0, enable_timing: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.S = scalar_lanes
+        self.L = soa.FIXED_LANES + scalar_lanes
+        cfg = Config(self._lib.bs_abi_version(), device, scalar_lanes, eph_gate, enable_timing)
+        rc = self._lib.bs_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise BsError(rc, "bs_create", self._lib.bs_strerror(rc).decode())
+        self.n = self.g = self.p = 0
+
+    # -- plumbing
+    def _chk(self, rc: int, where: str):
+        if rc != 0:
+            raise BsError(rc, where, self._lib.bs_strerror(rc).decode() + ": " + self._lib.bs_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._lib.bs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- loads
+    def load_nodes(self, nodes: soa.Nodes, fit: soa.FitMasks | None = None):
+        assert nodes.lanes == self.L, f"context has {self.L} lanes, nodes have {nodes.lanes}"
+        st = nodes.as_struct()
+        self._chk(self._lib.bs_nodes_load(self._h, C.byref(st)), "bs_nodes_load")
+        self.n = nodes.n
+        if fit is not None:
+            self.load_fit(fit)
+
+    def load_fit(self, fit: soa.FitMasks):
+        assert fit.n == self.n
+        bits = np.ascontiguousarray(fit.bits, dtype=np.uint32)
+        if bits.size == 0:
+            bits = np.zeros((fit.n_classes, 1), np.uint32)
+        self._chk(self._lib.bs_fit_load(self._h, fit.n_classes, _u32p(bits)), "bs_fit_load")
+        self.n_classes = fit.n_classes
+
+    def load_groups(self, groups: soa.Groups):
+        assert groups.min_resources.shape[0] == self.L
+        st = groups.as_struct()
+        self._chk(self._lib.bs_groups_load(self._h, C.byref(st)), "bs_groups_load")
+        self.g = groups.g
+
+    def read_groups(self) -> soa.Groups:
+        out = soa.Groups.empty(self.g, self.L)
+        st = out.as_struct()
+        self._chk(self._lib.bs_groups_read(self._h, C.byref(st)), "bs_groups_read")
+        return out
+
+    def load_pods(self, pods: soa.Pods):
+        assert pods.req.shape[0] == self.L
+        st = pods.as_struct()
+        self._chk(self._lib.bs_pods_load(self._h, C.byref(st)), "bs_pods_load")
+        self.p = pods.p
+
+    def apply_node_deltas(self, deltas: list):
+        arr = (NodeDelta * len(deltas))(*deltas)
+        self._chk(self._lib.bs_nodes_apply(self._h, arr, len(deltas)), "bs_nodes_apply")
+        n = C.c_uint32(0)
+        self._chk(self._lib.bs_nodes_count(self._h, C.byref(n)), "bs_nodes_count")
+        self.n = int(n.value)
+
+    # -- single queries
+    def cluster_fits(self, cls: int, pct: float, req, present: int = 0):
+        r = np.zeros(soa.MAX_LANES, np.int64)
+        r[: len(req)] = req
+        fits, fk = C.c_uint8(0), C.c_uint32(0)
+        self._chk(self._lib.bs_cluster_fits(self._h, cls, float(np.float32(pct)), _i64p(r), present, C.byref(fits), C.byref(fk)),
+                  "bs_cluster_fits")
+        return bool(fits.value), int(fk.value)
+
+    def node_left(self, cls: int, pct: float):
+        left = np.zeros((self.L, self.n), np.int64)
+        present = np.zeros(max(self.n, 1), np.uint32)
+        self._chk(self._lib.bs_node_left(self._h, cls, float(np.float32(pct)), _i64p(left), _u32p(present)), "bs_node_left")
+        return left, present[: self.n]
+
+    def scan_prefix(self, cls: int, pct: float):
+        n = max(self.n, 1)
+        prefix = np.zeros((self.L, n), np.int64)
+        present, idx = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        rows = C.c_uint32(0)
+        self._chk(self._lib.bs_scan_prefix(self._h, cls, float(np.float32(pct)), _i64p(prefix), _u32p(present), _u32p(idx), C.byref(rows)),
+                  "bs_scan_prefix")
+        r = int(rows.value)
+        return prefix[:, :r].copy(), present[:r].copy(), idx[:r].copy()
+
+    def cluster_total(self, cls: int):
+        tot = np.zeros(soa.MAX_LANES, np.int64)
+        pr = C.c_uint32(0)
+        self._chk(self._lib.bs_cluster_total(self._h, cls, _i64p(tot), C.byref(pr)), "bs_cluster_total")
+        return tot[: self.L].tolist(), int(pr.value)
+
+    def filter_one(self, pod_group: int, req, present: int, leader: int, node: int):
+        r = np.zeros(soa.MAX_LANES, np.int64)
+        r[: len(req)] = req
+        fl, fn = C.c_uint8(0), C.c_uint8(0)
+        self._chk(self._lib.bs_filter_one(self._h, pod_group, _i64p(r), present, leader, node, C.byref(fl), C.byref(fn)), "bs_filter_one")
+        return int(fl.value), int(fn.value)
+
+    def find_max_pg(self):
+        leader, fin, pan = C.c_int32(0), C.c_uint32(0), C.c_uint8(0)
+        self._chk(self._lib.bs_find_max_pg(self._h, C.byref(leader), C.byref(fin), C.byref(pan)), "bs_find_max_pg")
+        return int(leader.value), bool(pan.value)
+
+    # -- batch
+    def run(self, stages: int = soa.STAGE_ALL):
+        self._chk(self._lib.bs_batch_run(self._h, stages), "bs_batch_run")
+
+    def sync(self):
+        self._chk(self._lib.bs_batch_sync(self._h), "bs_batch_sync")
+
+    def finish(self):
+        self._chk(self._lib.bs_batch_finish(self._h), "bs_batch_finish")
+
+    def read(self, bitmap: bool = True) -> soa.BatchOut:
+        out = soa.BatchOut.alloc(self.p, self.g, self.n, bitmap=bitmap)
+        st = out.as_struct()
+        self._chk(self._lib.bs_batch_read(self._h, C.byref(st)), "bs_batch_read")
+        return out
+
+    def batch(self, stages: int = soa.STAGE_ALL, bitmap: bool = True) -> soa.BatchOut:
+        self.run(stages)
+        return self.read(bitmap=bitmap)
+
+    # -- sharding / measurement
+    def set_shard(self, rank: int, nranks: int):
+        self._chk(self._lib.bs_shard_set(self._h, rank, nranks), "bs_shard_set")
+
+    def admit_devptr(self):
+        p, n = C.c_void_p(), C.c_uint32(0)
+        self._chk(self._lib.bs_group_admit_devptr(self._h, C.byref(p), C.byref(n)), "bs_group_admit_devptr")
+        return int(p.value or 0), int(n.value)
+
+    def bind_admit(self, dptr: int | None):
+        self._chk(self._lib.bs_group_admit_bind(self._h, C.c_void_p(dptr or 0)), "bs_group_admit_bind")
+
+    def stream(self) -> int:
+        p = C.c_void_p()
+        self._chk(self._lib.bs_stream(self._h, C.byref(p)), "bs_stream")
+        return int(p.value or 0)
+
+    def comm_init(self, uid: bytes, rank: int, nranks: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._chk(self._lib.bs_comm_init(self._h, buf, rank, nranks), "bs_comm_init")
+
+    def timing_reset(self):
+        self._chk(self._lib.bs_timing_reset(self._h), "bs_timing_reset")
+
+    def timing(self) -> dict:
+        t = Timing()
+        self._chk(self._lib.bs_timing_get(self._h, C.byref(t)), "bs_timing_get")
+        return {self._lib.bs_kernel_name(i).decode(): (float(t.total_ms[i]), int(t.launches[i])) for i in range(KERNEL_COUNT)}
+
+    def stats_arm(self):
+        s = BatchStats()
+        self._chk(self._lib.bs_batch_stats_get(self._h, C.byref(s)), "bs_batch_stats_get")
+
+    def stats_read(self) -> dict:
+        s = BatchStats()
+        self._chk(self._lib.bs_batch_stats_get(self._h, C.byref(s)), "bs_batch_stats_get")
+        return {k: int(getattr(s, k)) for k, _ in BatchStats._fields_}
+
+
+def comm_unique_id() -> bytes:
+    lib = load_library()
+    buf = (C.c_uint8 * 128)()
+    rc = lib.bs_comm_unique_id(buf)
+    if rc != 0:
+        raise BsError(rc, "bs_comm_unique_id")
+    return bytes(buf)

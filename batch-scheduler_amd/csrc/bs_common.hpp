@@ -1,0 +1,133 @@
+// bs_common.hpp — shared device helpers for the gfx950 gang-feasibility kernels.
+//
+// Wave = 64 lanes everywhere (CDNA4).  All resource arithmetic is int64 with two's-complement
+// wrap (Go semantics), done in uint64 to stay defined in C++.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bsched.h"
+
+#define BS_INF 0xFFFFFFFFu
+#define BS_PF_NOT_OWNED 0xFFu
+
+namespace bs {
+
+constexpr int kWave = 64;
+constexpr int kScanBlock = 1024;   // single-block sequential-chunk scans
+
+__device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+__device__ __forceinline__ int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+__device__ __forceinline__ int64_t wmul(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// int64(float32(a) * pct) exactly as Go/amd64 computes it (core.go:656-659,667):
+// i64 -> f32 round-to-nearest-even (CVTSQ2SS), one f32 multiply (MULSS, no contraction),
+// truncation toward zero (CVTTSS2SQ; out of range / NaN -> 0x8000000000000000).
+__device__ __forceinline__ int64_t scale_f32(int64_t a, float pct) {
+  float f = __ll2float_rn((long long)a);
+  float m = __fmul_rn(f, pct);
+  if (!(m < 9223372036854775808.0f) || m < -9223372036854775808.0f) return INT64_MIN;
+  return (int64_t)m;
+}
+
+// Put a wave-uniform value into one (wave-uniform) lane of a VGPR.  gfx9 v_writelane_b32 accepts only
+// one SGPR source (constant-bus limit), so this is the select form: v_cmp_eq + v_cndmask.
+__device__ __forceinline__ uint32_t writelane_u32(uint32_t value, uint32_t lane, uint32_t old) {
+  return ((uint32_t)lane_id() == lane) ? value : old;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan_add(T v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T u = __shfl_up(v, o);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Block-wide reductions for up to 1024 threads; `lds` needs 16 uint32.  All threads get the result.
+__device__ __forceinline__ uint32_t block_min_u32(uint32_t v, uint32_t* lds) {
+  v = wave_min_u32(v);
+  __syncthreads();
+  if (lane_id() == 0) lds[wave_id()] = v;
+  __syncthreads();
+  const int nw = (int)(blockDim.x >> 6);
+  uint32_t r = BS_INF;
+  for (int w = 0; w < nw; ++w) r = min(r, lds[w]);
+  return r;
+}
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* lds) {
+  v = wave_max_u32(v);
+  __syncthreads();
+  if (lane_id() == 0) lds[wave_id()] = v;
+  __syncthreads();
+  const int nw = (int)(blockDim.x >> 6);
+  uint32_t r = 0;
+  for (int w = 0; w < nw; ++w) r = max(r, lds[w]);
+  return r;
+}
+
+// Block inclusive scan (sum) for T in {uint32_t, unsigned long long}; `lds` needs 16 T.
+// Returns the inclusive value; `total` = block total.
+template <typename T>
+__device__ __forceinline__ T block_incl_scan_add(T v, T* lds, T& total) {
+  T s = wave_incl_scan_add<T>(v);
+  __syncthreads();
+  if (lane_id() == 63) lds[wave_id()] = s;
+  __syncthreads();
+  const int nw = (int)(blockDim.x >> 6), w = wave_id();
+  T off = 0, tot = 0;
+  for (int i = 0; i < nw; ++i) {
+    T x = lds[i];
+    if (i < w) off += x;
+    tot += x;
+  }
+  total = tot;
+  return s + off;
+}
+
+// One atomicAdd per distinct key per wave: lanes with `active` contribute 1 to counters[key];
+// returns this lane's slot (old counter value + rank among same-key lanes).  The reduction uses
+// readfirstlane + ballot + mbcnt — no LDS.
+__device__ __forceinline__ uint32_t wave_aggregated_inc(uint32_t* counters, uint32_t key, bool active) {
+  uint32_t slot = 0;
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+    const unsigned long long same = __ballot(active && key == k0) & todo;
+    uint32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(&counters[k0], (uint32_t)__popcll(same));
+    base = (uint32_t)__shfl((int)base, leader);
+    if (active && key == k0) {
+      const unsigned long long below = same & ((1ull << lane_id()) - 1ull);
+      slot = base + (uint32_t)__popcll(below);
+    }
+    todo &= ~same;
+  }
+  return slot;
+}
+
+}  // namespace bs

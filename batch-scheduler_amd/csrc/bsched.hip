@@ -1,0 +1,1133 @@
+// bsched.hip — C ABI of include/bsched.h on top of the gfx950 kernels in bs_kernels.hpp.
+//
+// Host responsibilities only: device memory, one HIP stream, launch geometry, event timing,
+// H2D/D2H staging.  Every decision is computed on the GPU; there is no CPU evaluation path here
+// (the CPU restatement lives in oracle/ and is test infrastructure).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bs_kernels.hpp"
+
+using namespace bs;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = std::max<size_t>(bytes, 256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct EventPair { hipEvent_t a, b; uint32_t id; };
+
+}  // namespace
+
+struct bs_ctx {
+  bs_config cfg{};
+  uint32_t L = 4, S = 0, LP = 4;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+
+  // ---- nodes
+  bool have_nodes = false, have_fit = false, have_groups = false, have_pods = false;
+  uint32_t N = 0, Ncap = 0, M = 0, C = 0, fit_words = 0;
+  DevBuf d_alloc, d_nreq, d_apres, d_rpres, d_nflags, d_fit, d_kmap, d_m, d_left4;
+  std::vector<int64_t> h_alloc, h_nreq;          // [L][N] mirrors (churn + read-back)
+  std::vector<uint32_t> h_apres, h_rpres, h_kmap;
+  std::vector<uint8_t> h_nflags;
+  std::vector<uint32_t> h_fit;                   // [C][fit_words]
+
+  // ---- groups
+  uint32_t G = 0, n_uncaptured = 0;
+  DevBuf d_gmm, d_gsc, d_gmatched, d_gflags, d_gcls, d_gminres, d_gmrpres, d_gocc;
+
+  // ---- pods
+  uint32_t P = 0;
+  DevBuf d_pgroup, d_preq, d_ppres, d_pcls, d_powner, d_pflags;
+
+  // ---- batch scratch / outputs
+  DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
+  DevBuf d_epoch, d_nepochs, d_leader_epoch, d_panic_epoch;
+  DevBuf d_tcode, d_stage, d_leader_raw, d_qtable, d_qreq, d_qflags, d_first_row;
+  DevBuf d_tbl_count, d_tbl_off, d_tbl_cursor, d_tbl_slot, d_desc, d_ntables, d_tiles, d_ntiles, d_qlist;
+  DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags;
+  DevBuf d_pf_code, d_pf_first_k, d_pf_leader, d_fl_code, d_fl_feasible, d_fl_bitmap, d_admit, d_ready;
+  // single-query scratch
+  DevBuf d_sq;
+  uint32_t table_slots = 0, table_mcap = 0;
+
+  uint32_t rank = 0, nranks = 1;
+  uint32_t* ext_admit = nullptr;     // caller-owned device memory for the admit counters
+  int32_t sop_leader0 = -1;
+  uint32_t last_stages = 0;
+  bool batch_pending_finish = false;
+  uint32_t seg_len_override = 0, collect_stats = 0;
+  bs_batch_stats stats{};
+
+  // ---- timing
+  std::vector<EventPair> events;
+  size_t events_used = 0;
+  bs_timing timing{};
+
+  // ---- native RCCL (dlopen'ed on demand)
+  void* rccl_handle = nullptr;
+  void* comm = nullptr;
+};
+
+namespace {
+
+const char* kKernelNames[BS_KERNEL_COUNT] = {"prepass", "leader", "query", "tables", "scan", "resolve", "filter", "tally"};
+
+#define HIPCHK(ctx, call)                                                                         \
+  do {                                                                                            \
+    hipError_t _e = (call);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(_e);                      \
+      return BS_ERR_HIP;                                                                          \
+    }                                                                                             \
+  } while (0)
+
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+int timer_begin(bs_ctx* c, uint32_t id, size_t* slot) {
+  *slot = (size_t)-1;
+  if (!c->cfg.enable_timing) return BS_OK;
+  if (c->cfg.enable_timing == 1 && id != BS_KERNEL_SCAN && id != BS_KERNEL_FILTER) return BS_OK;
+  if (c->events_used == c->events.size()) {
+    EventPair ep{};
+    HIPCHK(c, hipEventCreate(&ep.a));
+    HIPCHK(c, hipEventCreate(&ep.b));
+    c->events.push_back(ep);
+  }
+  *slot = c->events_used++;
+  c->events[*slot].id = id;
+  HIPCHK(c, hipEventRecord(c->events[*slot].a, c->stream));
+  return BS_OK;
+}
+int timer_end(bs_ctx* c, size_t slot) {
+  if (slot == (size_t)-1) return BS_OK;
+  HIPCHK(c, hipEventRecord(c->events[slot].b, c->stream));
+  return BS_OK;
+}
+int timer_collect(bs_ctx* c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < c->events_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b));
+    c->timing.total_ms[c->events[i].id] += ms;
+    c->timing.launches[c->events[i].id] += 1;
+  }
+  c->events_used = 0;
+  return BS_OK;
+}
+
+#define TIMED(ctx, id, ...)                                    \
+  do {                                                         \
+    size_t _slot;                                              \
+    int _rc = timer_begin(ctx, id, &_slot);                    \
+    if (_rc) return _rc;                                       \
+    __VA_ARGS__;                                               \
+    HIPCHK(ctx, hipGetLastError());                            \
+    _rc = timer_end(ctx, _slot);                               \
+    if (_rc) return _rc;                                       \
+  } while (0)
+
+int use_device(bs_ctx* c) {
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  return BS_OK;
+}
+
+NodesDev nodes_dev(const bs_ctx* c) {
+  NodesDev nd{};
+  nd.n = c->N;
+  nd.stride = c->Ncap;
+  nd.alloc = c->d_alloc.as<int64_t>();
+  nd.req = c->d_nreq.as<int64_t>();
+  nd.apres = c->d_apres.as<uint32_t>();
+  nd.rpres = c->d_rpres.as<uint32_t>();
+  nd.flags = c->d_nflags.as<uint8_t>();
+  nd.fit = c->d_fit.as<uint32_t>();
+  nd.fit_words = c->fit_words;
+  nd.n_classes = c->C;
+  nd.kmap = c->d_kmap.as<uint32_t>();
+  nd.m = c->M;
+  nd.left4 = c->d_left4.as<int64_t>();
+  return nd;
+}
+GroupsDev groups_dev(const bs_ctx* c) {
+  GroupsDev g{};
+  g.g = c->G;
+  g.min_member = c->d_gmm.as<uint32_t>();
+  g.status_scheduled = c->d_gsc.as<uint32_t>();
+  g.matched = c->d_gmatched.as<uint32_t>();
+  g.flags = c->d_gflags.as<uint8_t>();
+  g.cls = c->d_gcls.as<uint32_t>();
+  g.minres = c->d_gminres.as<int64_t>();
+  g.mrpres = c->d_gmrpres.as<uint32_t>();
+  g.occupied = c->d_gocc.as<uint64_t>();
+  return g;
+}
+PodsDev pods_dev(const bs_ctx* c) {
+  PodsDev p{};
+  p.p = c->P;
+  p.group = c->d_pgroup.as<int32_t>();
+  p.req = c->d_preq.as<int64_t>();
+  p.pres = c->d_ppres.as<uint32_t>();
+  p.cls = c->d_pcls.as<uint32_t>();
+  p.owner = c->d_powner.as<uint64_t>();
+  p.flags = c->d_pflags.as<uint8_t>();
+  return p;
+}
+BatchDev batch_dev(const bs_ctx* c) {
+  BatchDev b{};
+  b.first_elig = c->d_first_elig.as<uint32_t>();
+  b.first_owner = c->d_first_owner.as<uint32_t>();
+  b.first_reject = c->d_first_reject.as<uint32_t>();
+  b.first_pod = c->d_first_pod.as<uint32_t>();
+  b.cap_epoch = c->d_cap_epoch.as<uint32_t>();
+  b.epoch = c->d_epoch.as<uint32_t>();
+  b.nepochs = c->d_nepochs.as<uint32_t>();
+  b.leader_epoch = c->d_leader_epoch.as<int32_t>();
+  b.panic_epoch = c->d_panic_epoch.as<uint8_t>();
+  b.tcode = c->d_tcode.as<uint8_t>();
+  b.stage = c->d_stage.as<uint8_t>();
+  b.leader_raw = c->d_leader_raw.as<int32_t>();
+  b.qtable = c->d_qtable.as<int32_t>();
+  b.qreq = c->d_qreq.as<int64_t>();
+  b.qflags = c->d_qflags.as<uint32_t>();
+  b.first_row = c->d_first_row.as<uint32_t>();
+  b.tbl_count = c->d_tbl_count.as<uint32_t>();
+  b.tbl_off = c->d_tbl_off.as<uint32_t>();
+  b.tbl_cursor = c->d_tbl_cursor.as<uint32_t>();
+  b.tbl_slot = c->d_tbl_slot.as<int32_t>();
+  b.desc = c->d_desc.as<TableDesc>();
+  b.ntables = c->d_ntables.as<uint32_t>();
+  b.tiles = c->d_tiles.as<Tile>();
+  b.ntiles = c->d_ntiles.as<uint32_t>();
+  b.qlist = c->d_qlist.as<uint32_t>();
+  b.tables = c->d_tables.as<int64_t>();
+  b.kp = c->d_kp.as<uint32_t>();
+  b.stats = c->d_stats.as<uint64_t>();
+  b.fparams = c->d_fparams.as<int64_t>();
+  b.fflags = c->d_fflags.as<uint32_t>();
+  b.pf_code = c->d_pf_code.as<uint8_t>();
+  b.pf_first_k = c->d_pf_first_k.as<uint32_t>();
+  b.pf_leader = c->d_pf_leader.as<int32_t>();
+  b.fl_code = c->d_fl_code.as<uint8_t>();
+  b.fl_feasible = c->d_fl_feasible.as<uint32_t>();
+  b.fl_bitmap = c->d_fl_bitmap.as<uint64_t>();
+  b.admit = c->ext_admit ? c->ext_admit : c->d_admit.as<uint32_t>();
+  b.ready = c->d_ready.as<uint8_t>();
+  return b;
+}
+BatchParams batch_params(const bs_ctx* c) {
+  BatchParams p{};
+  p.L = c->L; p.S = c->S; p.LP = c->LP; p.C = c->C;
+  p.eph_gate = c->cfg.eph_gate;
+  p.rank = c->rank; p.nranks = c->nranks;
+  p.sop_leader0 = c->sop_leader0;
+  p.run_filter = 0;
+  p.collect_stats = c->collect_stats;
+  p.mcap = c->table_mcap;
+  p.seg_len = 0;
+  return p;
+}
+
+// (re)allocate table storage once classes and node capacity are known
+int ensure_tables(bs_ctx* c) {
+  if (!c->have_nodes || !c->have_fit) return BS_OK;
+  const uint32_t slots = 2 * c->C + 1;
+  const size_t bytes = (size_t)slots * c->Ncap * c->LP * sizeof(int64_t);
+  if (bytes > ((size_t)64 << 30)) { c->last_error = "table storage exceeds 64 GiB"; return BS_ERR_CAPACITY; }
+  HIPCHK(c, c->d_tables.reserve(bytes));
+  HIPCHK(c, c->d_kp.reserve((size_t)slots * 16 * sizeof(uint32_t)));
+  HIPCHK(c, c->d_desc.reserve((size_t)slots * sizeof(TableDesc)));
+  HIPCHK(c, c->d_tbl_count.reserve((size_t)(2 * c->C + 1) * 4));
+  HIPCHK(c, c->d_tbl_off.reserve((size_t)(2 * c->C + 2) * 4));
+  HIPCHK(c, c->d_tbl_cursor.reserve((size_t)(2 * c->C + 1) * 4));
+  HIPCHK(c, c->d_tbl_slot.reserve((size_t)(2 * c->C + 1) * 4));
+  HIPCHK(c, c->d_ntables.reserve(16));
+  HIPCHK(c, c->d_ntiles.reserve(16));
+  HIPCHK(c, c->d_stats.reserve(8 * sizeof(uint64_t)));
+  HIPCHK(c, c->d_sq.reserve(4096));
+  c->table_slots = slots;
+  c->table_mcap = c->Ncap;
+  return BS_OK;
+}
+
+int upload_nodes(bs_ctx* c) {
+  const uint32_t N = c->N, L = c->L;
+  if (N > c->Ncap || c->Ncap == 0) {
+    c->Ncap = std::max<uint32_t>(64, N + N / 4 + 64);
+    c->d_tables.release();   // row capacity changed: tables are re-reserved in ensure_tables
+  }
+  const size_t cap = c->Ncap;
+  HIPCHK(c, c->d_alloc.reserve(cap * L * 8));
+  HIPCHK(c, c->d_nreq.reserve(cap * L * 8));
+  HIPCHK(c, c->d_left4.reserve(cap * 4 * 8));
+  HIPCHK(c, c->d_apres.reserve(cap * 4));
+  HIPCHK(c, c->d_rpres.reserve(cap * 4));
+  HIPCHK(c, c->d_nflags.reserve(cap));
+  HIPCHK(c, c->d_kmap.reserve(cap * 4));
+  HIPCHK(c, c->d_m.reserve(16));
+  if (N) {
+    for (uint32_t j = 0; j < L; ++j) {
+      HIPCHK(c, hipMemcpyAsync(c->d_alloc.as<int64_t>() + j * cap, c->h_alloc.data() + (size_t)j * N, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->d_nreq.as<int64_t>() + j * cap, c->h_nreq.data() + (size_t)j * N, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_apres.p, c->h_apres.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_rpres.p, c->h_rpres.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_nflags.p, c->h_nflags.data(), (size_t)N, hipMemcpyHostToDevice, c->stream));
+  }
+  NodesDev nd = nodes_dev(c);
+  hipLaunchKernelGGL(k_nodes_derive, dim3(1), dim3(kScanBlock), 0, c->stream, nd, c->d_kmap.as<uint32_t>(), c->d_m.as<uint32_t>(), c->d_left4.as<int64_t>());
+  HIPCHK(c, hipGetLastError());
+  uint32_t m = 0;
+  HIPCHK(c, hipMemcpyAsync(&m, c->d_m.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->M = m;
+  c->h_kmap.resize(m);
+  if (m) HIPCHK(c, hipMemcpy(c->h_kmap.data(), c->d_kmap.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+  c->have_nodes = true;
+  return ensure_tables(c);
+}
+
+int upload_fit(bs_ctx* c) {
+  HIPCHK(c, c->d_fit.reserve(std::max<size_t>(4, c->h_fit.size() * 4)));
+  if (!c->h_fit.empty())
+    HIPCHK(c, hipMemcpyAsync(c->d_fit.p, c->h_fit.data(), c->h_fit.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_fit = true;
+  return ensure_tables(c);
+}
+
+template <int S>
+void launch_scan_s(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S>), grid, dim3(256), 0, c->stream, b, p, m);
+}
+void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m) {
+  switch (c->S) {
+    case 0: launch_scan_s<0>(c, grid, b, p, m); break;
+    case 1: launch_scan_s<1>(c, grid, b, p, m); break;
+    case 2: launch_scan_s<2>(c, grid, b, p, m); break;
+    case 3: launch_scan_s<3>(c, grid, b, p, m); break;
+    case 4: launch_scan_s<4>(c, grid, b, p, m); break;
+    case 5: launch_scan_s<5>(c, grid, b, p, m); break;
+    case 6: launch_scan_s<6>(c, grid, b, p, m); break;
+    case 7: launch_scan_s<7>(c, grid, b, p, m); break;
+    case 8: launch_scan_s<8>(c, grid, b, p, m); break;
+    case 9: launch_scan_s<9>(c, grid, b, p, m); break;
+    case 10: launch_scan_s<10>(c, grid, b, p, m); break;
+    case 11: launch_scan_s<11>(c, grid, b, p, m); break;
+    default: launch_scan_s<12>(c, grid, b, p, m); break;
+  }
+}
+
+uint32_t pick_seg_len(const bs_ctx* c, uint32_t tiles, uint32_t m) {
+  if (c->seg_len_override) return c->seg_len_override;
+  if (m == 0) return 64;
+  const uint32_t target_waves = 4096;                         // ~4 waves per SIMD on 256 CUs
+  uint32_t nseg = std::max<uint32_t>(1, target_waves / std::max<uint32_t>(1, tiles));
+  nseg = std::min<uint32_t>(nseg, cdiv(m, 64));
+  uint32_t seg = cdiv(m, nseg);
+  seg = cdiv(seg, 32) * 32;
+  return std::max<uint32_t>(seg, 32);
+}
+
+// Build the running-sum table for (cls, pct) in the scratch slot (last one) — single queries.
+int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) {
+  if (!c->have_nodes || !c->have_fit) { c->last_error = "nodes / fit not loaded"; return BS_ERR_STATE; }
+  if (cls >= c->C) { c->last_error = "class out of range"; return BS_ERR_INVALID; }
+  const uint32_t slot = c->table_slots - 1;
+  BatchDev b = batch_dev(c);
+  BatchParams p = batch_params(c);
+  TableDesc d{cls, pct};
+  // scratch layout in d_sq: [0] ntables(u32)=slot+1 ... we run k_tables with a descriptor copy per slot
+  HIPCHK(c, hipMemcpyAsync(b.desc + slot, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
+  uint32_t nt = slot + 1;
+  uint32_t* d_nt = c->d_sq.as<uint32_t>();
+  HIPCHK(c, hipMemcpyAsync(d_nt, &nt, 4, hipMemcpyHostToDevice, c->stream));
+  BatchDev b2 = b;
+  b2.ntables = d_nt;
+  // launch only the one block: shift the table / kp / desc bases so that blockIdx 0 == slot
+  b2.tables = b.tables + (size_t)slot * p.mcap * p.LP;
+  b2.kp = b.kp + (size_t)slot * 16;
+  b2.desc = b.desc + slot;
+  hipLaunchKernelGGL(k_tables, dim3(1), dim3(kScanBlock), 0, c->stream, nodes_dev(c), b2, p);
+  HIPCHK(c, hipGetLastError());
+  *slot_out = slot;
+  return BS_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+uint32_t bs_abi_version(void) { return BS_ABI_VERSION; }
+
+const char* bs_strerror(int status) {
+  switch (status) {
+    case BS_OK: return "ok";
+    case BS_ERR_INVALID: return "invalid argument";
+    case BS_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case BS_ERR_HIP: return "HIP runtime error";
+    case BS_ERR_STATE: return "call order: snapshot / groups / pods not loaded";
+    case BS_ERR_CAPACITY: return "capacity exceeded";
+    case BS_ERR_NOMEM: return "out of memory";
+    case BS_ERR_COMM: return "RCCL error";
+    default: return "unknown status";
+  }
+}
+
+const char* bs_last_error(const bs_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char* bs_kernel_name(uint32_t id) { return id < BS_KERNEL_COUNT ? kKernelNames[id] : "?"; }
+
+int bs_create(const bs_config* cfg, bs_ctx** out) {
+  if (!cfg || !out) return BS_ERR_INVALID;
+  *out = nullptr;
+  if (cfg->abi_version != BS_ABI_VERSION || cfg->scalar_lanes > BS_MAX_SCALARS) return BS_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return BS_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return BS_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BS_ERR_NO_DEVICE;   // gfx950-only code object
+  bs_ctx* c = new (std::nothrow) bs_ctx();
+  if (!c) return BS_ERR_NOMEM;
+  c->cfg = *cfg;
+  c->S = cfg->scalar_lanes;
+  c->L = BS_FIXED_LANES + c->S;
+  c->LP = c->S == 0 ? 4 : (c->S <= 4 ? 8 : 16);
+  if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return BS_ERR_NO_DEVICE;
+  }
+  if (const char* e = std::getenv("BS_SEG_LEN")) c->seg_len_override = (uint32_t)std::atoi(e);
+  *out = c;
+  return BS_OK;
+}
+
+int bs_destroy(bs_ctx* c) {
+  if (!c) return BS_OK;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+  for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (c->comm && c->rccl_handle) {
+    typedef int (*destroy_t)(void*);
+    destroy_t f = (destroy_t)dlsym(c->rccl_handle, "ncclCommDestroy");
+    if (f) f(c->comm);
+  }
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return BS_OK;
+}
+
+int bs_nodes_load(bs_ctx* c, const bs_nodes_soa* nodes) {
+  if (!c || !nodes) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t N = nodes->n, L = c->L;
+  if (N && (!nodes->allocatable || !nodes->requested || !nodes->allocatable_present || !nodes->requested_present || !nodes->flags))
+    return BS_ERR_INVALID;
+  if (N > 0x7FFFFFF0u) return BS_ERR_CAPACITY;
+  c->N = N;
+  c->h_alloc.assign(nodes->allocatable, nodes->allocatable + (size_t)L * N);
+  c->h_nreq.assign(nodes->requested, nodes->requested + (size_t)L * N);
+  c->h_apres.assign(nodes->allocatable_present, nodes->allocatable_present + N);
+  c->h_rpres.assign(nodes->requested_present, nodes->requested_present + N);
+  c->h_nflags.assign(nodes->flags, nodes->flags + N);
+  c->have_fit = false;      // fit columns belong to a node list
+  return upload_nodes(c);
+}
+
+int bs_nodes_count(const bs_ctx* c, uint32_t* n_out) {
+  if (!c || !n_out) return BS_ERR_INVALID;
+  *n_out = c->N;
+  return BS_OK;
+}
+
+int bs_fit_load(bs_ctx* c, uint32_t n_classes, const uint32_t* fit_bits) {
+  if (!c || n_classes == 0 || !fit_bits) return BS_ERR_INVALID;
+  if (!c->have_nodes) { c->last_error = "bs_fit_load before bs_nodes_load"; return BS_ERR_STATE; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  c->C = n_classes;
+  c->fit_words = cdiv(c->N, 32);
+  c->h_fit.assign(fit_bits, fit_bits + (size_t)n_classes * c->fit_words);
+  return upload_fit(c);
+}
+
+int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
+  if (!c || !g) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t G = g->g, L = c->L;
+  const size_t n = std::max<uint32_t>(G, 1);
+  HIPCHK(c, c->d_gmm.reserve(n * 4));
+  HIPCHK(c, c->d_gsc.reserve(n * 4));
+  HIPCHK(c, c->d_gmatched.reserve(n * 4));
+  HIPCHK(c, c->d_gflags.reserve(n));
+  HIPCHK(c, c->d_gcls.reserve(n * 4));
+  HIPCHK(c, c->d_gminres.reserve(n * L * 8));
+  HIPCHK(c, c->d_gmrpres.reserve(n * 4));
+  HIPCHK(c, c->d_gocc.reserve(n * 8));
+  HIPCHK(c, c->d_first_elig.reserve(n * 4));
+  HIPCHK(c, c->d_first_owner.reserve(n * 4));
+  HIPCHK(c, c->d_first_reject.reserve(n * 4));
+  HIPCHK(c, c->d_first_pod.reserve(n * 4));
+  HIPCHK(c, c->d_cap_epoch.reserve(n * 4));
+  HIPCHK(c, c->d_admit.reserve(n * 4));
+  HIPCHK(c, c->d_ready.reserve(n));
+  HIPCHK(c, c->d_leader_epoch.reserve((n + 1) * 4));
+  HIPCHK(c, c->d_panic_epoch.reserve(n + 1));
+  HIPCHK(c, c->d_nepochs.reserve(16));
+  c->G = G;
+  c->n_uncaptured = 0;
+  if (G) {
+    HIPCHK(c, hipMemcpyAsync(c->d_gmm.p, g->min_member, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_gsc.p, g->status_scheduled, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_gmatched.p, g->matched, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_gflags.p, g->flags, (size_t)G, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_gcls.p, g->cls, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_gminres.p, g->min_resources, (size_t)G * L * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_gmrpres.p, g->min_resources_present, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_gocc.p, g->occupied_by, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
+    for (uint32_t i = 0; i < G; ++i)
+      if (!(g->flags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_groups = true;
+  return BS_OK;
+}
+
+int bs_groups_read(bs_ctx* c, bs_groups_soa* g) {
+  if (!c || !g) return BS_ERR_INVALID;
+  if (!c->have_groups) return BS_ERR_STATE;
+  if (g->g != c->G) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t G = c->G, L = c->L;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (G) {
+    HIPCHK(c, hipMemcpy(g->min_member, c->d_gmm.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->status_scheduled, c->d_gsc.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->matched, c->d_gmatched.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->flags, c->d_gflags.p, (size_t)G, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->cls, c->d_gcls.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->min_resources, c->d_gminres.p, (size_t)G * L * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->min_resources_present, c->d_gmrpres.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->occupied_by, c->d_gocc.p, (size_t)G * 8, hipMemcpyDeviceToHost));
+  }
+  return BS_OK;
+}
+
+int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
+  if (!c || !pods) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t P = pods->p, L = c->L;
+  const size_t n = std::max<uint32_t>(P, 1);
+  HIPCHK(c, c->d_pgroup.reserve(n * 4));
+  HIPCHK(c, c->d_preq.reserve(n * L * 8));
+  HIPCHK(c, c->d_ppres.reserve(n * 4));
+  HIPCHK(c, c->d_pcls.reserve(n * 4));
+  HIPCHK(c, c->d_powner.reserve(n * 8));
+  HIPCHK(c, c->d_pflags.reserve(n));
+  HIPCHK(c, c->d_epoch.reserve(n * 4));
+  HIPCHK(c, c->d_tcode.reserve(n));
+  HIPCHK(c, c->d_stage.reserve(n));
+  HIPCHK(c, c->d_leader_raw.reserve(n * 4));
+  HIPCHK(c, c->d_qtable.reserve(n * 4));
+  HIPCHK(c, c->d_qreq.reserve(n * c->LP * 8));
+  HIPCHK(c, c->d_qflags.reserve(n * 4));
+  HIPCHK(c, c->d_first_row.reserve(n * 4));
+  HIPCHK(c, c->d_qlist.reserve(n * 4));
+  HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
+  HIPCHK(c, c->d_fflags.reserve(n * 4));
+  HIPCHK(c, c->d_pf_code.reserve(n));
+  HIPCHK(c, c->d_pf_first_k.reserve(n * 4));
+  HIPCHK(c, c->d_pf_leader.reserve(n * 4));
+  HIPCHK(c, c->d_fl_code.reserve(n));
+  HIPCHK(c, c->d_fl_feasible.reserve(n * 4));
+  c->P = P;
+  if (P) {
+    HIPCHK(c, hipMemcpyAsync(c->d_pgroup.p, pods->group, (size_t)P * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_preq.p, pods->req, (size_t)P * L * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ppres.p, pods->req_present, (size_t)P * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pcls.p, pods->cls, (size_t)P * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_powner.p, pods->owner, (size_t)P * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pflags.p, pods->flags, (size_t)P, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_pods = true;
+  return BS_OK;
+}
+
+int bs_shard_set(bs_ctx* c, uint32_t rank, uint32_t nranks) {
+  if (!c || nranks == 0 || rank >= nranks) return BS_ERR_INVALID;
+  c->rank = rank;
+  c->nranks = nranks;
+  return BS_OK;
+}
+
+int bs_stream(bs_ctx* c, void** stream) {
+  if (!c || !stream) return BS_ERR_INVALID;
+  *stream = (void*)c->stream;
+  return BS_OK;
+}
+
+int bs_group_admit_bind(bs_ctx* c, void* dptr) {
+  if (!c) return BS_ERR_INVALID;
+  c->ext_admit = reinterpret_cast<uint32_t*>(dptr);
+  return BS_OK;
+}
+
+int bs_group_admit_devptr(bs_ctx* c, void** dptr, uint32_t* count) {
+  if (!c || !dptr || !count) return BS_ERR_INVALID;
+  if (!c->have_groups) return BS_ERR_STATE;
+  *dptr = c->ext_admit ? (void*)c->ext_admit : c->d_admit.p;
+  *count = c->G;
+  return BS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int bs_batch_run(bs_ctx* c, uint32_t stages) {
+  if (!c) return BS_ERR_INVALID;
+  if (!c->have_nodes || !c->have_fit || !c->have_groups || !c->have_pods) {
+    c->last_error = "bs_batch_run needs nodes, fit, groups and pods loaded";
+    return BS_ERR_STATE;
+  }
+  if (!(stages & BS_STAGE_PREFILTER)) { c->last_error = "PREFILTER stage is mandatory"; return BS_ERR_INVALID; }
+  if ((stages & BS_BATCH_COMMIT) && c->nranks > 1) { c->last_error = "COMMIT is single-rank only"; return BS_ERR_STATE; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t P = c->P, G = c->G, N = c->N, C = c->C;
+  const uint32_t W = cdiv(N, 64);
+  const bool run_filter = stages & BS_STAGE_FILTER;
+  if (run_filter) HIPCHK(c, c->d_fl_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
+  const uint32_t max_tiles = cdiv(P, 64) + 2 * C;
+  HIPCHK(c, c->d_tiles.reserve((size_t)(max_tiles + 1) * sizeof(Tile)));
+
+  NodesDev nd = nodes_dev(c);
+  GroupsDev gr = groups_dev(c);
+  PodsDev pd = pods_dev(c);
+  BatchDev b = batch_dev(c);
+  BatchParams prm = batch_params(c);
+  prm.run_filter = run_filter;
+  prm.seg_len = pick_seg_len(c, cdiv(std::max<uint32_t>(P, 1), 64), c->M);
+
+  const uint32_t init_n = std::max(std::max(G, 2 * C), std::max(P, 8u));
+  const dim3 blk(256);
+  TIMED(c, BS_KERNEL_PREPASS, {
+    hipLaunchKernelGGL(k_init, dim3(cdiv(init_n, 256)), blk, 0, c->stream, gr, b, prm, P);
+    if (run_filter && P) (void)hipMemsetAsync(b.fl_feasible, 0, (size_t)P * 4, c->stream);
+    if (P) hipLaunchKernelGGL(k_prepass, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, gr, b);
+    hipLaunchKernelGGL(k_epochs, dim3(1), dim3(kScanBlock), 0, c->stream, pd, gr, b);
+  });
+  const uint32_t max_epochs = std::min(c->n_uncaptured, P) + 1;
+  TIMED(c, BS_KERNEL_LEADER, hipLaunchKernelGGL(k_leader, dim3(max_epochs), blk, 0, c->stream, gr, b));
+  TIMED(c, BS_KERNEL_QUERY, {
+    if (P) hipLaunchKernelGGL(k_query, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, gr, b, prm);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(kScanBlock), 0, c->stream, b, prm);
+    if (P) hipLaunchKernelGGL(k_scatter, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b);
+  });
+  TIMED(c, BS_KERNEL_TABLES, hipLaunchKernelGGL(k_tables, dim3(2 * C), dim3(kScanBlock), 0, c->stream, nd, b, prm));
+  if (c->M && P) {
+    const dim3 grid(cdiv(max_tiles, 4), cdiv(c->M, prm.seg_len));
+    TIMED(c, BS_KERNEL_SCAN, launch_scan(c, grid, b, prm, c->M));
+  }
+  TIMED(c, BS_KERNEL_RESOLVE, {
+    if (P) hipLaunchKernelGGL(k_reject, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b);
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(kScanBlock), 0, c->stream, pd, nd, b, prm);
+  });
+  if (run_filter && P) {
+    const uint32_t ptiles = cdiv(P, 64);
+    uint32_t nsplit = std::max<uint32_t>(1, 4096 / ptiles);
+    nsplit = std::min<uint32_t>(nsplit, std::max<uint32_t>(W, 1));
+    const uint32_t bpw = std::max<uint32_t>(1, cdiv(std::max<uint32_t>(W, 1), nsplit));
+    TIMED(c, BS_KERNEL_FILTER, {
+      hipLaunchKernelGGL(k_filter_params, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, gr, b, prm);
+      if (W) hipLaunchKernelGGL(k_filter, dim3(cdiv(ptiles, 4), cdiv(W, bpw)), blk, 0, c->stream, pd, nd, b, bpw, 1u);
+    });
+  } else if (P) {
+    HIPCHK(c, hipMemsetAsync(b.fl_code, BS_FL_NOT_RUN, P, c->stream));
+    HIPCHK(c, hipMemsetAsync(b.fl_feasible, 0, (size_t)P * 4, c->stream));
+  }
+  if (stages & BS_BATCH_COMMIT) {
+    if (G) hipLaunchKernelGGL(k_commit, dim3(cdiv(G, 256)), blk, 0, c->stream, pd, b, prm, c->d_gflags.as<uint8_t>(), c->d_gcls.as<uint32_t>(),
+                              c->d_gminres.as<int64_t>(), c->d_gmrpres.as<uint32_t>(), c->d_gocc.as<uint64_t>(), G);
+    if (P) {
+      int32_t last = -1;
+      HIPCHK(c, hipMemcpyAsync(&last, b.pf_leader + (P - 1), 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->sop_leader0 = last;
+    }
+    // the committed capture may have given every group a pod
+    std::vector<uint8_t> fl(G);
+    if (G) HIPCHK(c, hipMemcpy(fl.data(), c->d_gflags.p, G, hipMemcpyDeviceToHost));
+    c->n_uncaptured = 0;
+    for (uint32_t i = 0; i < G; ++i) if (!(fl[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+  }
+  c->last_stages = stages;
+  c->batch_pending_finish = false;
+  if (stages & BS_STAGE_TALLY) {
+    TIMED(c, BS_KERNEL_TALLY, {
+      if (P) hipLaunchKernelGGL(k_tally, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, gr, b, run_filter ? 1u : 0u);
+    });
+    if (c->nranks > 1) {
+      if (c->comm) {
+        // native RCCL: one all-reduce(sum) of the per-group admit counters on the context stream
+        typedef int (*allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+        allreduce_t ar = (allreduce_t)dlsym(c->rccl_handle, "ncclAllReduce");
+        if (!ar || ar(b.admit, b.admit, G, /*ncclUint32*/ 3, /*ncclSum*/ 0, c->comm, c->stream) != 0) {
+          c->last_error = "ncclAllReduce failed";
+          return BS_ERR_COMM;
+        }
+        if (G) hipLaunchKernelGGL(k_ready, dim3(cdiv(G, 256)), blk, 0, c->stream, gr, b);
+      } else {
+        c->batch_pending_finish = true;   // caller reduces bs_group_admit_devptr, then bs_batch_finish
+      }
+    } else if (G) {
+      hipLaunchKernelGGL(k_ready, dim3(cdiv(G, 256)), blk, 0, c->stream, gr, b);
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return BS_OK;
+}
+
+int bs_batch_finish(bs_ctx* c) {
+  if (!c) return BS_ERR_INVALID;
+  if (!c->have_groups) return BS_ERR_STATE;
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->G) hipLaunchKernelGGL(k_ready, dim3(cdiv(c->G, 256)), dim3(256), 0, c->stream, groups_dev(c), batch_dev(c));
+  HIPCHK(c, hipGetLastError());
+  c->batch_pending_finish = false;
+  return BS_OK;
+}
+
+int bs_batch_sync(bs_ctx* c) {
+  if (!c) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return BS_OK;
+}
+
+int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
+  if (!c || !out) return BS_ERR_INVALID;
+  if (!c->have_pods || !c->have_groups) return BS_ERR_STATE;
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint32_t P = c->P, G = c->G, W = cdiv(c->N, 64);
+  if (P) {
+    if (out->pf_code) HIPCHK(c, hipMemcpy(out->pf_code, c->d_pf_code.p, P, hipMemcpyDeviceToHost));
+    if (out->pf_first_k) HIPCHK(c, hipMemcpy(out->pf_first_k, c->d_pf_first_k.p, (size_t)P * 4, hipMemcpyDeviceToHost));
+    if (out->pf_leader) HIPCHK(c, hipMemcpy(out->pf_leader, c->d_pf_leader.p, (size_t)P * 4, hipMemcpyDeviceToHost));
+    if (out->fl_code) HIPCHK(c, hipMemcpy(out->fl_code, c->d_fl_code.p, P, hipMemcpyDeviceToHost));
+    if (out->fl_feasible) HIPCHK(c, hipMemcpy(out->fl_feasible, c->d_fl_feasible.p, (size_t)P * 4, hipMemcpyDeviceToHost));
+    if (out->fl_bitmap && W) {
+      if (c->last_stages & BS_STAGE_FILTER) HIPCHK(c, hipMemcpy(out->fl_bitmap, c->d_fl_bitmap.p, (size_t)W * P * 8, hipMemcpyDeviceToHost));
+      else std::memset(out->fl_bitmap, 0, (size_t)W * P * 8);
+    }
+  }
+  if (G && (c->last_stages & BS_STAGE_TALLY)) {
+    if (out->group_admit) HIPCHK(c, hipMemcpy(out->group_admit, c->ext_admit ? (void*)c->ext_admit : c->d_admit.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+    if (out->group_ready) HIPCHK(c, hipMemcpy(out->group_ready, c->d_ready.p, G, hipMemcpyDeviceToHost));
+  }
+  return BS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// single queries
+// -------------------------------------------------------------------------------------------------
+int bs_node_left(bs_ctx* c, uint32_t cls, float percent, int64_t* left, uint32_t* present) {
+  if (!c || !left || !present) return BS_ERR_INVALID;
+  if (!c->have_nodes || !c->have_fit) return BS_ERR_STATE;
+  if (cls >= c->C) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t N = c->N, L = c->L;
+  if (!N) return BS_OK;
+  DevBuf d_left, d_pres;
+  HIPCHK(c, d_left.reserve((size_t)N * L * 8));
+  HIPCHK(c, d_pres.reserve((size_t)N * 4));
+  hipLaunchKernelGGL(k_node_left, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, nodes_dev(c), cls, percent, L, d_left.as<int64_t>(), d_pres.as<uint32_t>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(left, d_left.p, (size_t)N * L * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(present, d_pres.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+  return BS_OK;
+}
+
+int bs_scan_prefix(bs_ctx* c, uint32_t cls, float percent, int64_t* prefix, uint32_t* present, uint32_t* node_index, uint32_t* rows) {
+  if (!c || !prefix || !present || !node_index || !rows) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  uint32_t slot;
+  rc = build_scratch_table(c, cls, percent, &slot);
+  if (rc) return rc;
+  const uint32_t M = c->M, L = c->L, LP = c->LP, N = c->N;
+  std::vector<int64_t> t((size_t)M * LP);
+  uint32_t kp[16];
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (M) HIPCHK(c, hipMemcpy(t.data(), c->d_tables.as<int64_t>() + (size_t)slot * c->table_mcap * LP, (size_t)M * LP * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(kp, c->d_kp.as<uint32_t>() + (size_t)slot * 16, sizeof(kp), hipMemcpyDeviceToHost));
+  for (uint32_t k = 0; k < M; ++k) {
+    for (uint32_t j = 0; j < L; ++j) prefix[(size_t)j * N + k] = t[(size_t)k * LP + j];
+    uint32_t pr = 0;
+    for (uint32_t s = 0; s < c->S; ++s) if (k >= kp[s]) pr |= 1u << s;
+    present[k] = pr;
+    node_index[k] = c->h_kmap[k];
+  }
+  *rows = M;
+  return BS_OK;
+}
+
+int bs_cluster_total(bs_ctx* c, uint32_t cls, int64_t* total, uint32_t* present) {
+  if (!c || !total || !present) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  uint32_t slot;
+  rc = build_scratch_table(c, cls, 1.0f, &slot);
+  if (rc) return rc;
+  const uint32_t M = c->M, L = c->L, LP = c->LP;
+  std::vector<int64_t> row(LP, 0);
+  uint32_t kp[16];
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (M) HIPCHK(c, hipMemcpy(row.data(), c->d_tables.as<int64_t>() + ((size_t)slot * c->table_mcap + (M - 1)) * LP, (size_t)LP * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(kp, c->d_kp.as<uint32_t>() + (size_t)slot * 16, sizeof(kp), hipMemcpyDeviceToHost));
+  uint32_t pr = 0;
+  for (uint32_t j = 0; j < L; ++j) total[j] = M ? row[j] : 0;
+  for (uint32_t s = 0; s < c->S; ++s) if (M && kp[s] != BS_INF) pr |= 1u << s;
+  *present = pr;
+  return BS_OK;
+}
+
+int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, uint32_t req_present, uint8_t* fits, uint32_t* first_k) {
+  if (!c || !req || !fits) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  uint32_t slot;
+  rc = build_scratch_table(c, cls, percent, &slot);
+  if (rc) return rc;
+  const uint32_t L = c->L, LP = c->LP, S = c->S, M = c->M;
+  // scratch layout (bytes): 0 ntables | 64 ntiles | 128 Tile | 192 qlist | 256 qflags | 320 first_row | 512 qreq[LP]
+  uint8_t* sq = c->d_sq.as<uint8_t>();
+  struct { uint32_t ntiles; } h_nt{1};
+  Tile tl{slot, 0, 1, 0};
+  uint32_t zero = 0, inf = BS_INF, qflags = 0;
+  int64_t q[BS_MAX_LANES];
+  for (uint32_t j = 0; j < LP; ++j) q[j] = INT64_MIN;
+  for (uint32_t j = 0; j < 4; ++j) q[j] = req[j];
+  if (!c->cfg.eph_gate) q[BS_LANE_EPH] = 0;    // a Resource built by Add never carries ephemeral-storage with the gate off
+  uint32_t absok = 0;
+  for (uint32_t s = 0; s < S; ++s) {
+    const bool pres = req_present & (1u << s);
+    if (!pres || req[4 + s] == 0) absok |= 1u << s;
+    q[4 + s] = pres ? req[4 + s] : INT64_MIN;
+  }
+  qflags = (req_present & 0xFFFu) | (absok << 16);
+  HIPCHK(c, hipMemcpyAsync(sq + 64, &h_nt, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sq + 128, &tl, sizeof(tl), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sq + 192, &zero, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sq + 256, &qflags, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sq + 320, &inf, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sq + 512, q, (size_t)LP * 8, hipMemcpyHostToDevice, c->stream));
+  BatchDev b = batch_dev(c);
+  b.ntiles = reinterpret_cast<uint32_t*>(sq + 64);
+  b.tiles = reinterpret_cast<Tile*>(sq + 128);
+  b.qlist = reinterpret_cast<uint32_t*>(sq + 192);
+  b.qflags = reinterpret_cast<uint32_t*>(sq + 256);
+  b.first_row = reinterpret_cast<uint32_t*>(sq + 320);
+  b.qreq = reinterpret_cast<int64_t*>(sq + 512);
+  BatchParams prm = batch_params(c);
+  prm.collect_stats = 0;
+  prm.seg_len = pick_seg_len(c, 1, M);
+  if (M) {
+    launch_scan(c, dim3(1, cdiv(M, prm.seg_len)), b, prm, M);
+    HIPCHK(c, hipGetLastError());
+  }
+  uint32_t row = BS_INF;
+  HIPCHK(c, hipMemcpyAsync(&row, sq + 320, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *fits = row != BS_INF;
+  if (first_k) *first_k = row == BS_INF ? BS_K_NONE : c->h_kmap[row];
+  (void)L;
+  return BS_OK;
+}
+
+int bs_find_max_pg(bs_ctx* c, int32_t* leader, uint32_t* finished, uint8_t* panic) {
+  if (!c || !leader || !panic) return BS_ERR_INVALID;
+  if (!c->have_groups) return BS_ERR_STATE;
+  int rc = use_device(c);
+  if (rc) return rc;
+  GroupsDev gr = groups_dev(c);
+  BatchDev b = batch_dev(c);
+  BatchParams prm = batch_params(c);
+  prm.C = 0;
+  prm.collect_stats = 0;
+  const uint32_t one = 1;
+  hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(c->G, 8), 256)), dim3(256), 0, c->stream, gr, b, prm, 0u);
+  HIPCHK(c, hipMemcpyAsync(b.nepochs, &one, 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_leader, dim3(1), dim3(256), 0, c->stream, gr, b);
+  HIPCHK(c, hipGetLastError());
+  int32_t l = -1;
+  uint8_t pn = 0;
+  HIPCHK(c, hipMemcpyAsync(&l, b.leader_epoch, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&pn, b.panic_epoch, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *leader = l;
+  *panic = pn;
+  if (finished) *finished = 0;   // maxFinished is unused by every caller in the reference (core.go:120 discards it)
+  return BS_OK;
+}
+
+int bs_filter_one(bs_ctx* c, int32_t pod_group, const int64_t* pod_req, uint32_t pod_req_present, int32_t leader,
+                  uint32_t node, uint8_t* fl_code, uint8_t* fn_code) {
+  // Implemented on top of the batch path: a one-pod batch whose PreFilter is forced to pass is not
+  // expressible, so this entry point evaluates through k_filter_params/k_filter with a one-pod view.
+  if (!c || !pod_req || !fl_code || !fn_code) return BS_ERR_INVALID;
+  if (!c->have_nodes || !c->have_groups) return BS_ERR_STATE;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t L = c->L, N = c->N;
+  // one-pod SoA in scratch device memory
+  DevBuf d;
+  HIPCHK(c, d.reserve(4096 + (size_t)cdiv(std::max<uint32_t>(N, 1), 64) * 8));
+  uint8_t* base = d.as<uint8_t>();
+  int32_t grp = pod_group;
+  uint8_t pf = BS_PF_PASS_NO_MAX, zero8 = 0;
+  uint32_t zero32 = 0;
+  uint64_t zero64 = 0;
+  HIPCHK(c, hipMemcpyAsync(base + 0, &grp, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + 64, pod_req, (size_t)L * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + 256, &pod_req_present, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + 320, &zero32, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + 384, &zero64, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + 448, &zero8, 1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + 512, &pf, 1, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + 576, &leader, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(base + 640, 0, 256, c->stream));
+  PodsDev pd{};
+  pd.p = 1;
+  pd.group = reinterpret_cast<int32_t*>(base + 0);
+  pd.req = reinterpret_cast<int64_t*>(base + 64);
+  pd.pres = reinterpret_cast<uint32_t*>(base + 256);
+  pd.cls = reinterpret_cast<uint32_t*>(base + 320);
+  pd.owner = reinterpret_cast<uint64_t*>(base + 384);
+  pd.flags = base + 448;
+  BatchDev b = batch_dev(c);
+  b.pf_code = base + 512;
+  b.pf_leader = reinterpret_cast<int32_t*>(base + 576);
+  b.fl_code = base + 640;
+  b.fflags = reinterpret_cast<uint32_t*>(base + 704);
+  b.fl_feasible = reinterpret_cast<uint32_t*>(base + 768);
+  b.fparams = reinterpret_cast<int64_t*>(base + 832);
+  b.fl_bitmap = reinterpret_cast<uint64_t*>(base + 4096);
+  // first_elig must not redirect MinResources for a stand-alone query: use INF for every group
+  DevBuf fe;
+  HIPCHK(c, fe.reserve(std::max<size_t>(4, (size_t)c->G * 4)));
+  HIPCHK(c, hipMemsetAsync(fe.p, 0xFF, std::max<size_t>(4, (size_t)c->G * 4), c->stream));
+  b.first_elig = fe.as<uint32_t>();
+  BatchParams prm = batch_params(c);
+  GroupsDev gr = groups_dev(c);
+  NodesDev nd = nodes_dev(c);
+  hipLaunchKernelGGL(k_filter_params, dim3(1), dim3(256), 0, c->stream, pd, gr, b, prm);
+  const uint32_t W = cdiv(N, 64);
+  if (W) hipLaunchKernelGGL(k_filter, dim3(1, 1), dim3(256), 0, c->stream, pd, nd, b, W, 1u);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_filter_one, dim3(1), dim3(64), 0, c->stream, nd, b, node, base + 768 + 16);
+  HIPCHK(c, hipGetLastError());
+  uint8_t fl = 0, fn = 0;
+  uint64_t word = 0;
+  HIPCHK(c, hipMemcpyAsync(&fl, base + 640, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&fn, base + 768 + 16, 1, hipMemcpyDeviceToHost, c->stream));
+  if (node < N) HIPCHK(c, hipMemcpyAsync(&word, base + 4096 + (size_t)(node >> 6) * 8, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *fl_code = fl;
+  *fn_code = fn;
+  if (fl == BS_FL_EVALUATED) {
+    // the batched bitmap and the per-pair kernel must agree on pass / fail
+    const bool pass = node < N && ((word >> (node & 63)) & 1ull);
+    if (pass != (fn < 16u)) { c->last_error = "bitmap / filter_one disagreement"; return BS_ERR_HIP; }
+  }
+  return BS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// churn (BASELINE config 5): list edits on the host mirror, then a suffix re-upload
+// -------------------------------------------------------------------------------------------------
+int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
+  if (!c || (count && !deltas)) return BS_ERR_INVALID;
+  if (!c->have_nodes || !c->have_fit) return BS_ERR_STATE;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t L = c->L, C = c->C;
+  // unpack fit bits to one byte vector per class for easy insert/erase
+  uint32_t N = c->N;
+  std::vector<std::vector<uint8_t>> fit(C, std::vector<uint8_t>(N));
+  for (uint32_t cl = 0; cl < C; ++cl)
+    for (uint32_t n = 0; n < N; ++n) fit[cl][n] = (c->h_fit[(size_t)cl * c->fit_words + (n >> 5)] >> (n & 31)) & 1u;
+  std::vector<std::vector<int64_t>> al(L), rq(L);
+  for (uint32_t j = 0; j < L; ++j) {
+    al[j].assign(c->h_alloc.begin() + (size_t)j * N, c->h_alloc.begin() + (size_t)(j + 1) * N);
+    rq[j].assign(c->h_nreq.begin() + (size_t)j * N, c->h_nreq.begin() + (size_t)(j + 1) * N);
+  }
+  for (uint32_t d = 0; d < count; ++d) {
+    const bs_node_delta& x = deltas[d];
+    if (x.kind == BS_DELTA_REMOVE) {
+      if (x.index >= N) return BS_ERR_INVALID;
+      for (uint32_t j = 0; j < L; ++j) { al[j].erase(al[j].begin() + x.index); rq[j].erase(rq[j].begin() + x.index); }
+      c->h_apres.erase(c->h_apres.begin() + x.index);
+      c->h_rpres.erase(c->h_rpres.begin() + x.index);
+      c->h_nflags.erase(c->h_nflags.begin() + x.index);
+      for (uint32_t cl = 0; cl < C; ++cl) fit[cl].erase(fit[cl].begin() + x.index);
+      --N;
+      continue;
+    }
+    uint32_t at = x.index;
+    if (x.kind == BS_DELTA_APPEND) {
+      at = N++;
+      for (uint32_t j = 0; j < L; ++j) { al[j].push_back(0); rq[j].push_back(0); }
+      c->h_apres.push_back(0); c->h_rpres.push_back(0); c->h_nflags.push_back(0);
+      for (uint32_t cl = 0; cl < C; ++cl) fit[cl].push_back(0);
+    } else if (x.kind != BS_DELTA_UPDATE || at >= N) {
+      return BS_ERR_INVALID;
+    }
+    for (uint32_t j = 0; j < L; ++j) { al[j][at] = x.allocatable[j]; rq[j][at] = x.requested[j]; }
+    c->h_apres[at] = x.allocatable_present;
+    c->h_rpres[at] = x.requested_present;
+    c->h_nflags[at] = (uint8_t)x.flags;
+    if (x.n_fit_exceptions > 8) return BS_ERR_INVALID;
+    for (uint32_t cl = 0; cl < C; ++cl) fit[cl][at] = x.fit_default ? 1 : 0;
+    for (uint32_t e = 0; e < x.n_fit_exceptions; ++e) {
+      if (x.fit_exceptions[e] >= C) return BS_ERR_INVALID;
+      fit[x.fit_exceptions[e]][at] = x.fit_default ? 0 : 1;
+    }
+  }
+  c->N = N;
+  c->h_alloc.resize((size_t)L * N);
+  c->h_nreq.resize((size_t)L * N);
+  for (uint32_t j = 0; j < L; ++j) {
+    std::copy(al[j].begin(), al[j].end(), c->h_alloc.begin() + (size_t)j * N);
+    std::copy(rq[j].begin(), rq[j].end(), c->h_nreq.begin() + (size_t)j * N);
+  }
+  c->fit_words = cdiv(N, 32);
+  c->h_fit.assign((size_t)C * c->fit_words, 0);
+  for (uint32_t cl = 0; cl < C; ++cl)
+    for (uint32_t n = 0; n < N; ++n)
+      if (fit[cl][n]) c->h_fit[(size_t)cl * c->fit_words + (n >> 5)] |= 1u << (n & 31);
+  rc = upload_nodes(c);
+  if (rc) return rc;
+  return upload_fit(c);
+}
+
+// -------------------------------------------------------------------------------------------------
+// native RCCL (for hosts without torch): librccl is dlopen'ed on first use
+// -------------------------------------------------------------------------------------------------
+static void* open_rccl() {
+  static void* h = nullptr;
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  return h;
+}
+
+int bs_comm_unique_id(uint8_t id[128]) {
+  if (!id) return BS_ERR_INVALID;
+  void* h = open_rccl();
+  if (!h) return BS_ERR_COMM;
+  typedef int (*getid_t)(void*);
+  getid_t f = (getid_t)dlsym(h, "ncclGetUniqueId");
+  if (!f || f(id) != 0) return BS_ERR_COMM;
+  return BS_OK;
+}
+
+int bs_comm_init(bs_ctx* c, const uint8_t id[128], uint32_t rank, uint32_t nranks) {
+  if (!c || !id || nranks == 0 || rank >= nranks) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  void* h = open_rccl();
+  if (!h) { c->last_error = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "?"); return BS_ERR_COMM; }
+  struct uid { char internal[128]; } u;
+  std::memcpy(u.internal, id, 128);
+  typedef int (*init_t)(void**, int, uid, int);
+  init_t f = (init_t)dlsym(h, "ncclCommInitRank");
+  void* comm = nullptr;
+  if (!f || f(&comm, (int)nranks, u, (int)rank) != 0) { c->last_error = "ncclCommInitRank failed"; return BS_ERR_COMM; }
+  c->rccl_handle = h;
+  c->comm = comm;
+  c->rank = rank;
+  c->nranks = nranks;
+  return BS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int bs_timing_reset(bs_ctx* c) {
+  if (!c) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  rc = timer_collect(c);
+  std::memset(&c->timing, 0, sizeof(c->timing));
+  return rc;
+}
+
+int bs_timing_get(bs_ctx* c, bs_timing* out) {
+  if (!c || !out) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  rc = timer_collect(c);
+  *out = c->timing;
+  return rc;
+}
+
+int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {
+  // Re-runs nothing: the counters are filled by the next bs_batch_run after this call arms them, and
+  // read back here.  Usage: bs_batch_stats_get(arm) -> bs_batch_run -> bs_batch_stats_get(read).
+  if (!c || !out) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  std::memset(out, 0, sizeof(*out));
+  if (!c->collect_stats) {
+    c->collect_stats = 1;
+    return BS_OK;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  uint64_t raw[8] = {0};
+  uint32_t nt = 0, ntl = 0;
+  if (c->d_stats.p) HIPCHK(c, hipMemcpy(raw, c->d_stats.p, sizeof(raw), hipMemcpyDeviceToHost));
+  if (c->d_ntables.p) HIPCHK(c, hipMemcpy(&nt, c->d_ntables.p, 4, hipMemcpyDeviceToHost));
+  if (c->d_ntiles.p) HIPCHK(c, hipMemcpy(&ntl, c->d_ntiles.p, 4, hipMemcpyDeviceToHost));
+  uint32_t nq = 0;
+  if (c->d_tbl_off.p && c->C) HIPCHK(c, hipMemcpy(&nq, c->d_tbl_off.as<uint32_t>() + 2 * c->C, 4, hipMemcpyDeviceToHost));
+  out->scan_rows_executed = raw[0];
+  out->scan_evals_executed = raw[1];
+  out->scan_queries = nq;
+  out->tables_built = nt;
+  out->logical_evals = (uint64_t)c->P * c->N;
+  out->filter_evals = (c->last_stages & BS_STAGE_FILTER) ? (uint64_t)c->P * c->N : 0;
+  c->collect_stats = 0;
+  (void)ntl;
+  return BS_OK;
+}
+
+}  // extern "C"

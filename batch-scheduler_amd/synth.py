@@ -1,0 +1,210 @@
+"""Seeded synthetic cluster snapshots for the configurations of BASELINE.json.
+
+Counter-based SplitMix64 (vectorised with numpy) so that any element is a pure function of
+(seed, stream, index): the same snapshot is produced on the build container and on the GPU box.
+
+Configs (BASELINE.json `configs`):
+  cfg2  1k pods / 200 groups / 500 nodes, cpu+mem (S=0)
+  cfg3  10k pods / 2k groups / 5k nodes, cpu/mem/eph/gpu (S=1)     <- the bench workload
+  cfg4  50k pods / 5k groups / 20k nodes (S=1), pod axis sharded over GPUs
+Scenarios:
+  cold  nothing seen yet: matched = 0, no representative pods -> core.go:136-147 for every group
+  warm  steady state: every group has its pod/MinResources; one leader one pod short of quorum
+        (core.go:157-166 for everybody else)
+  busy  warm on a saturated cluster with a leader that still needs most of its gang: most
+        reservations fail after a full scan (REJECT + deny-cache)
+  tail  saturated cluster whose free capacity sits in freshly appended nodes at the END of the node
+        list (what a cluster autoscaler produces): every pod has to walk almost the whole list
+        before the running sum covers it.  Worst case for the reference's early exit, and the
+        workload bench.py quotes.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import soa
+
+GI = 1 << 30
+KI = 1 << 10
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+CONFIGS = {
+    "cfg2": dict(pods=1000, groups=200, nodes=500, scalars=0, classes=8),
+    "cfg3": dict(pods=10000, groups=2000, nodes=5000, scalars=1, classes=32),
+    "cfg4": dict(pods=50000, groups=5000, nodes=20000, scalars=1, classes=64),
+    "tiny": dict(pods=96, groups=12, nodes=150, scalars=1, classes=3),
+}
+
+
+def _mix(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+class Stream:
+    """SplitMix64 in counter mode: element i of stream s under seed."""
+
+    def __init__(self, seed: int, stream: int):
+        with np.errstate(over="ignore"):
+            self.base = _mix(np.array([np.uint64(seed & 0xFFFFFFFFFFFFFFFF)]) + _GAMMA * np.uint64(stream + 1))[0]
+
+    def u64(self, n: int) -> np.ndarray:
+        with np.errstate(over="ignore"):
+            idx = np.arange(1, n + 1, dtype=np.uint64)
+            return _mix(self.base + idx * _GAMMA)
+
+    def uniform(self, n: int) -> np.ndarray:
+        return (self.u64(n) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+    def integers(self, n: int, lo: int, hi: int) -> np.ndarray:
+        """inclusive range"""
+        return (lo + (self.u64(n) % np.uint64(hi - lo + 1)).astype(np.int64)).astype(np.int64)
+
+    def choice(self, n: int, values, probs=None) -> np.ndarray:
+        values = np.asarray(values)
+        if probs is None:
+            return values[self.integers(n, 0, len(values) - 1)]
+        cdf = np.cumsum(probs)
+        return values[np.minimum(np.searchsorted(cdf, self.uniform(n), side="right"), len(values) - 1)]
+
+
+def make_nodes(seed: int, n: int, scalars: int, scenario: str):
+    L = 4 + scalars
+    sku = Stream(seed, 1).choice(n, [0, 1, 2], [0.5, 0.3, 0.2])
+    cap_cpu = np.array([32000, 64000, 96000])[sku]
+    cap_mem = np.array([128, 256, 512])[sku] * GI
+    cap_eph = np.array([500, 1024, 2048])[sku] * GI
+    cap_pods = np.array([110, 110, 250])[sku]
+    is_gpu = sku == 2
+    alloc = np.zeros((L, n), np.int64)
+    alloc[0] = cap_cpu - Stream(seed, 2).integers(n, 100, 500)
+    # reserved memory in odd-KiB steps: allocatable is NOT float32-representable
+    alloc[1] = cap_mem - (Stream(seed, 3).integers(n, GI // KI, 4 * GI // KI) | 1) * KI
+    alloc[2] = cap_eph - Stream(seed, 4).integers(n, 0, 64) * GI
+    alloc[3] = cap_pods
+    u = Stream(seed, 5).uniform(n)
+    v = Stream(seed, 6).uniform(n)
+    if scenario in ("cold", "warm"):
+        util = np.where(u < 0.6, 0.1 + 0.5 * v, np.where(u < 0.9, 0.6 + 0.3 * v, 0.9 + 0.1 * v))
+    elif scenario == "busy":
+        util = np.where(u < 0.85, 0.72 + 0.26 * v, 0.05 + 0.4 * v)
+    elif scenario == "tail":
+        tail0 = n - max(1, n // 12)
+        util = np.where(np.arange(n) >= tail0, 0.02 + 0.18 * v, 0.70 + 0.03 * v)
+    else:
+        raise ValueError(scenario)
+    req = np.zeros((L, n), np.int64)
+    jitter = Stream(seed, 7).uniform(3 * n).reshape(3, n)
+    req[0] = np.floor(alloc[0] * np.clip(util + 0.04 * (jitter[0] - 0.5), 0, 1.05)).astype(np.int64)
+    req[1] = np.floor(alloc[1] * np.clip(util + 0.04 * (jitter[1] - 0.5), 0, 1.05)).astype(np.int64)
+    req[2] = np.floor(alloc[2] * np.clip(0.5 * util + 0.04 * (jitter[2] - 0.5), 0, 1.0)).astype(np.int64)
+    req[3] = Stream(seed, 8).integers(n, 5, 60)            # podCount
+    ap = np.zeros(n, np.uint32)
+    rp = np.zeros(n, np.uint32)
+    if scalars >= 1:
+        alloc[4] = np.where(is_gpu, 8, 0)
+        ap |= np.where(is_gpu, 1, 0).astype(np.uint32)
+        has_req = is_gpu & (Stream(seed, 9).uniform(n) < 0.7)      # Q3: key present on 70 % of GPU nodes
+        rp |= np.where(has_req, 1, 0).astype(np.uint32)
+        gpu_used = np.minimum(8, np.floor(8 * util + Stream(seed, 10).uniform(n)).astype(np.int64))
+        req[4] = np.where(has_req, gpu_used, 0)
+    for s in range(1, scalars):                                     # further extended resources
+        present = Stream(seed, 20 + s).uniform(n) < 0.5
+        alloc[4 + s] = np.where(present, 16, 0)
+        ap |= (np.where(present, 1, 0) << s).astype(np.uint32)
+        hr = present & (Stream(seed, 40 + s).uniform(n) < 0.6)
+        rp |= (np.where(hr, 1, 0) << s).astype(np.uint32)
+        req[4 + s] = np.where(hr, Stream(seed, 60 + s).integers(n, 0, 12), 0)
+    flags = np.zeros(n, np.uint8)
+    f = Stream(seed, 11).uniform(n)
+    flags[f < 0.02] = soa.NODE_UNSCHEDULABLE
+    flags[(f >= 0.02) & (f < 0.025)] = soa.NODE_TAINT_ERR
+    flags[(f >= 0.025) & (f < 0.027)] = soa.NODE_NO_NODE
+    return soa.Nodes(alloc, req, ap, rp, flags)
+
+
+def make_fit(seed: int, n: int, classes: int) -> soa.FitMasks:
+    fit = Stream(seed, 12).uniform(classes * n).reshape(classes, n) < 0.95
+    return soa.FitMasks.from_bool(fit)
+
+
+def make_groups_and_pods(seed: int, p: int, g: int, scalars: int, classes: int, scenario: str):
+    L = 4 + scalars
+    size = max(1, p // g)
+    # group templates
+    t_cpu = Stream(seed, 13).choice(g, [500, 1000, 2000, 4000])
+    t_mem = Stream(seed, 14).choice(g, [1, 2, 4, 8]) * GI
+    t_eph = Stream(seed, 15).choice(g, [0, 10 * GI])
+    t_gpu = Stream(seed, 16).choice(g, [0, 1, 8], [0.8, 0.12, 0.08])
+    t_cls = Stream(seed, 17).integers(g, 0, classes - 1)
+    hetero = Stream(seed, 18).uniform(g) < 0.10
+
+    groups = soa.Groups.empty(g, L)
+    groups.min_member[:] = size
+    pgroup = np.minimum(np.arange(p) // size, g - 1).astype(np.int32)
+    # interleave the queue a little: pods of neighbouring groups arrive mixed, as a real queue does
+    order = np.argsort(np.arange(p) // (4 * size) * (4 * size) + Stream(seed, 19).integers(p, 0, 4 * size - 1), kind="stable")
+    pgroup = pgroup[order]
+    preq = np.zeros((L, p), np.int64)
+    het_scale = np.where(hetero[pgroup], Stream(seed, 21).choice(p, [1, 2]), 1)
+    preq[0] = t_cpu[pgroup] * het_scale
+    preq[1] = t_mem[pgroup] * het_scale
+    preq[2] = t_eph[pgroup]
+    ppres = np.zeros(p, np.uint32)
+    if scalars >= 1:
+        preq[4] = t_gpu[pgroup]
+        ppres |= np.where(t_gpu[pgroup] > 0, 1, 0).astype(np.uint32)
+    pcls = t_cls[pgroup].astype(np.uint32)
+    powner = (pgroup.astype(np.uint64) + np.uint64(1))            # one owner (job) per gang
+    pflags = np.zeros(p, np.uint8)
+    stray = Stream(seed, 22).uniform(p)
+    pgroup = np.where(stray < 0.01, soa.POD_NOT_GROUPED, pgroup).astype(np.int32)    # 1 % ordinary pods
+    pods = soa.Pods(pgroup, preq, ppres, pcls, powner, pflags)
+
+    if scenario != "cold":
+        groups.flags[:] = soa.GROUP_HAS_POD | soa.GROUP_HAS_MINRES
+        groups.cls[:] = t_cls
+        groups.min_resources[0] = t_cpu
+        groups.min_resources[1] = t_mem
+        groups.min_resources[2] = t_eph
+        if scalars >= 1:
+            groups.min_resources[4] = t_gpu
+            groups.min_resources_present[:] = np.where(t_gpu > 0, 1, 0)
+        groups.occupied_by[:] = np.arange(g, dtype=np.uint64) + np.uint64(1)
+        groups.matched[:] = Stream(seed, 23).integers(g, 0, max(0, size - 2))
+        leader = int(Stream(seed, 24).integers(1, 0, g - 1)[0])
+        if scenario == "warm":
+            groups.matched[leader] = max(1, size - 1)
+        elif scenario == "busy":
+            groups.min_member[leader] = 64
+            groups.matched[leader] = 8
+            groups.min_resources[0, leader] = 4000
+            groups.min_resources[1, leader] = 8 * GI
+        elif scenario == "tail":
+            groups.min_member[leader] = 48
+            groups.matched[leader] = 40
+            groups.min_resources[0, leader] = 4000
+            groups.min_resources[1, leader] = 8 * GI
+            if scalars >= 1:
+                groups.min_resources[4, leader] = 0
+                groups.min_resources_present[leader] = 0
+        done = Stream(seed, 25).uniform(g) < 0.05                  # a few gangs already latched
+        done[leader] = False
+        groups.flags[done] |= soa.GROUP_SCHEDULED_LATCH
+    return groups, pods
+
+
+def make(config: str = "cfg3", scenario: str = "tail", seed: int = 20260921, **overrides):
+    """-> (Nodes, FitMasks, Groups, Pods, meta)"""
+    cfg = dict(CONFIGS[config])
+    cfg.update(overrides)
+    nodes = make_nodes(seed, cfg["nodes"], cfg["scalars"], scenario)
+    fit = make_fit(seed, cfg["nodes"], cfg["classes"])
+    groups, pods = make_groups_and_pods(seed, cfg["pods"], cfg["groups"], cfg["scalars"], cfg["classes"], scenario)
+    meta = dict(config=config, scenario=scenario, seed=seed, **cfg)
+    return nodes, fit, groups, pods, meta

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — pod x node fit evaluations / s of the batched gang-feasibility path on MI355X.
+
+One "step" = one pass of the hot path over one batch that is already resident in HBM:
+PreFilter (core.go:88-167) for every pending pod against the node snapshot, Filter
+(core.go:514-564) for every (pod, node), per-group admit counts and the Permit quorum
+(core.go:303).  Workload at N=1: BASELINE.json's metric configuration "10k pods x 5k nodes"
+(configs[2]: 10k pods / 2k groups / 5k nodes, 4 resource dims), scenario "tail" (synth.py).
+For N>1 the pod axis is sharded over ranks (weak scaling: N x 10k pods, N x 2k groups, the same
+5k nodes replicated) with ONE all-reduce of the per-group admit counters per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--scenario", default="tail")
+    ap.add_argument("--seed", type=int, default=20260921)
+    ap.add_argument("--stages", default="all", choices=["all", "prefilter"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(bsa, nodes, fit, groups, pods, stages, reps):
+    """The oracle (C port of the Go path, 1 core — upstream runs PreFilter on the single scheduling
+    goroutine) on the rank-0 share of the same workload.  Checker code, timed as the baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    snap = orc.Snapshot(nodes, fit)
+    best, iters = None, 0
+    for _ in range(reps):
+        sop = orc.Sop(snap, groups)
+        t0 = time.perf_counter()
+        sop.batch(pods, stages, bitmap=bool(stages & bsa.soa.STAGE_FILTER))
+        dt = time.perf_counter() - t0
+        iters = sop.iters
+        best = dt if best is None else min(best, dt)
+    logical = pods.p * nodes.n
+    return {"value": logical / best, "unit": "pod x node fit evals/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x one full batch ({pods.p} pods x {nodes.n} nodes, same seeded inputs, same stages), best of {reps}; "
+                      f"reference node-loop iterations executed (core.go:604) = {iters} of {logical} logical",
+            "seconds_per_batch": best, "reference_loop_iterations": iters}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    if world != n_gpus:
+        if world == 1 and n_gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        n_gpus = world
+
+    import torch
+    bsa = importlib.import_module("batch-scheduler_amd")
+    soa, synth = bsa.soa, bsa.synth
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    base = synth.CONFIGS[args.config]
+    nodes, fit, groups, pods, meta = synth.make(args.config, args.scenario, seed=args.seed,
+                                                pods=base["pods"] * world, groups=base["groups"] * world)
+    stages = soa.STAGE_ALL if args.stages == "all" else (soa.STAGE_PREFILTER | soa.STAGE_TALLY)
+    L = nodes.lanes
+
+    ctx = bsa.Context(scalar_lanes=L - 4, device=local_rank, enable_timing=1)
+    ctx.load_nodes(nodes, fit)
+    ctx.load_groups(groups)
+    ctx.load_pods(pods)
+    admit_t = None
+    if world > 1:
+        ctx.set_shard(rank, world)
+        admit_t = torch.zeros(groups.g, dtype=torch.int32, device=f"cuda:{local_rank}")
+        ctx.bind_admit(admit_t.data_ptr())
+
+    def step():
+        ctx.run(stages)
+        if world > 1:
+            ctx.sync()                         # counters complete on the library stream
+            dist.all_reduce(admit_t)           # ONE RCCL all-reduce (sum) of per-group admit counts
+            torch.cuda.current_stream().synchronize()
+            ctx.finish()                       # quorum bits from the reduced counters
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = ctx.timing()
+
+    # executed-work counters from one extra, untimed, instrumented batch
+    ctx.stats_arm()
+    step()
+    ctx.sync()
+    stats = ctx.stats_read()
+    out = ctx.read(bitmap=False)
+
+    logical = pods.p * nodes.n                        # whole job: every pending pod against every node
+    ms_per_step = elapsed / args.steps * 1e3
+    value = logical * args.steps / elapsed
+
+    # roofline of the dominant kernel (k_scan): algorithmic bytes = (16 L + 2) per executed pod x node
+    # evaluation (alloc[L] + requested[L] int64 + flag byte + fit bit), per launch.
+    scan_ms, scan_launches = timing["scan"]
+    bytes_per_eval = 16 * L + 2
+    roofline = None
+    if scan_launches:
+        avg_s = scan_ms / scan_launches * 1e-3
+        achieved = stats["scan_evals_executed"] * bytes_per_eval / avg_s / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "kernel": "k_scan", "avg_launch_us": avg_s * 1e6, "launches": scan_launches,
+                    "algorithmic_bytes_per_eval": bytes_per_eval, "evals_per_launch": stats["scan_evals_executed"],
+                    "note": "table rows are wave-uniform scalar loads reused by 64 pod lanes, so algorithmic bytes exceed physical HBM traffic (working set < 1 MB); see DESIGN.md"}
+    filt_ms, filt_launches = timing["filter"]
+
+    result = None
+    if rank == 0:
+        # admit latency of one cold call: pods H2D + batch + decisions D2H, host-observed
+        lat = []
+        for _ in range(15 if world == 1 else 0):
+            a = time.perf_counter()
+            ctx.load_pods(pods)
+            step()
+            ctx.sync()
+            ctx.read(bitmap=False)
+            lat.append((time.perf_counter() - a) * 1e3)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(bsa, nodes, fit, groups, pods, stages, args.cpu_reps)
+        codes = np.bincount(out.pf_code, minlength=256)
+        result = {
+            "metric": "pod x node fit evals/sec", "value": value, "unit": "evals/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"{args.config}/{args.scenario}: {pods.p} pods / {groups.g} groups / {nodes.n} nodes, "
+                                   f"{L} int64 lanes (cpu, mem, eph, pods{', gpu' if L > 4 else ''}), seed {args.seed}",
+                       "stages": "prefilter+filter+tally+ready" if args.stages == "all" else "prefilter+tally+ready",
+                       "parallelism": f"pod-axis shard x{world}" if world > 1 else "single GPU",
+                       "logical_evals_per_step": logical,
+                       "scan_evals_executed_per_step": stats["scan_evals_executed"],
+                       "filter_evals_per_step": stats["filter_evals"],
+                       "scan_queries": stats["scan_queries"], "tables_built": stats["tables_built"],
+                       "decisions": {soa.PF_NAMES.get(i, str(i)): int(c) for i, c in enumerate(codes) if c},
+                       "groups_ready": int(out.group_ready.sum())},
+            "gang_admit_latency_ms_p50": float(np.percentile(lat, 50)) if lat else None,
+            "gang_admit_latency_note": "host-observed: pods H2D + one batch + decision D2H; every group of the batch is decided by that call",
+            "roofline": roofline,
+            "kernel_ms_per_step": {"scan": scan_ms / max(1, scan_launches), "filter": filt_ms / max(1, filt_launches)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    return result
+
+
+if __name__ == "__main__":
+    main()

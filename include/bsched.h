@@ -257,6 +257,9 @@ int bs_shard_set(bs_ctx* ctx, uint32_t rank, uint32_t nranks);
 /* Device address of the per-group admit counters (uint32[g]) so the caller's collective
  * (torch.distributed / RCCL all-reduce, sum) can run in place between the two halves. */
 int bs_group_admit_devptr(bs_ctx* ctx, void** dptr, uint32_t* count);
+/* Use caller-owned device memory (uint32[g], e.g. a torch tensor's data_ptr) for the admit counters,
+ * so that a framework collective can reduce it in place.  NULL restores the internal buffer. */
+int bs_group_admit_bind(bs_ctx* ctx, void* dptr);
 /* HIP stream (hipStream_t) the context launches on, for event timing / stream ordering. */
 int bs_stream(bs_ctx* ctx, void** stream);
 /* Native RCCL path for hosts without torch (the Go shim): unique id is 128 bytes. */

@@ -1,0 +1,359 @@
+"""GPU parity: the HIP path (through the C ABI, libbsched.so) against the CPU oracle, bit for bit.
+
+Every test here needs a real MI355X (`-m gpu`).  Nothing falls back to the CPU: Context() raises when
+the library or the device is missing.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import naive_ref as nv
+from scenarios import random_objects
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def assert_batch_equal(got, exp, what="", bitmap=True):
+    for name in ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible", "group_admit", "group_ready"):
+        a, b = getattr(got, name), getattr(exp, name)
+        if not np.array_equal(a, b):
+            bad = np.nonzero(a != b)[0]
+            raise AssertionError(f"{what}: {name} differs at {bad[:8].tolist()} ({len(bad)} total): got {a[bad[:8]].tolist()} exp {b[bad[:8]].tolist()}")
+    if bitmap and exp.fl_bitmap is not None:
+        assert np.array_equal(got.fl_bitmap, exp.fl_bitmap), f"{what}: fl_bitmap differs"
+
+
+def load_ctx(bsa, nodes, fit, groups, pods, **kw):
+    ctx = bsa.Context(scalar_lanes=nodes.lanes - 4, **kw)
+    ctx.load_nodes(nodes, fit)
+    ctx.load_groups(groups)
+    ctx.load_pods(pods)
+    return ctx
+
+
+def test_scale_kat_on_device(bsa, soa, orc):
+    """int64(float32(a)*pct) on gfx950 == x86 golden vectors (core.go:656-659), via bs_node_left."""
+    kat = json.load(open(os.path.join(GOLD, "f32_scale_kat.json")))["vectors"]
+    by_pct = {}
+    for v in kat:
+        by_pct.setdefault(v["pct_bits"], []).append(v)
+    rng = np.random.default_rng(99)
+    extra = rng.integers(-(2 ** 62), 2 ** 62, size=20000)
+    for pct_bits, vs in by_pct.items():
+        pct = float(np.uint32(pct_bits).view(np.float32))
+        a = np.array([v["a"] for v in vs] + extra.tolist() + [2 ** 63 - 1, -(2 ** 63), 2 ** 63 - 2 ** 38, 0], dtype=np.int64)
+        n = len(a)
+        alloc = np.stack([a, a[::-1], a, a[::-1]])
+        nodes = soa.Nodes(alloc, np.zeros((4, n), np.int64), np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint8))
+        fit = soa.FitMasks.from_bool(np.ones((1, n), bool))
+        with bsa.Context(scalar_lanes=0) as ctx:
+            ctx.load_nodes(nodes, fit)
+            left, _ = ctx.node_left(0, pct)
+        exp = np.array([v["out"] for v in vs], dtype=np.int64)
+        assert np.array_equal(left[0, : len(vs)], exp)
+        exp_all = np.array([orc.scale(int(x), pct) for x in a], dtype=np.int64)
+        assert np.array_equal(left[0], exp_all)
+        assert np.array_equal(left[1], exp_all[::-1])
+
+
+def test_reference_core_test_vectors_on_device(bsa, soa, orc):
+    v = json.load(open(os.path.join(GOLD, "core_test_vectors.json")))
+    nd = v["node"]
+    alloc, reqd = nv.Resource(), nv.Resource()
+    alloc.Add(nd["allocatable"])
+    reqd.Add(nd["requested"])
+    info = nv.NodeInfo(alloc, reqd, nd["pod_count"])
+    names = v["scalar_names"]
+    for case in v["cases"]:
+        pod = nv.Pod("u", None, case["req"])
+        nodes, fit, groups, pods, _ = nv.to_soa([info], {}, [pod], names, 1)
+        with bsa.Context(scalar_lanes=2) as ctx:
+            ctx.load_nodes(nodes, fit)
+            left, present = ctx.node_left(0, v["percent"])
+            exp = v["expected_left"]
+            assert left[:, 0].tolist() == [exp["cpu"], exp["memory"], exp["ephemeral-storage"], exp["pods"], exp[names[0]], exp[names[1]]]
+            assert int(present[0]) == 3
+            ok, fk = ctx.cluster_fits(0, v["percent"], pods.req[:, 0].tolist(), int(pods.req_present[0]))
+            assert ok is case["desire"]
+            assert fk == (0 if ok else soa.K_NONE)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_single_queries_random(seed, bsa, soa, orc):
+    sc = random_objects(seed + 700, n_nodes=int(np.random.default_rng(seed).integers(1, 200)))
+    nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"])
+    snap = orc.Snapshot(nodes, fit)
+    S = len(sc["names"])
+    with bsa.Context(scalar_lanes=S) as ctx:
+        ctx.load_nodes(nodes, fit)
+        for cls in range(sc["n_classes"]):
+            for pct in (1.0, 0.7, 0.35):
+                l_g, p_g = ctx.node_left(cls, pct)
+                l_o, p_o = snap.node_left(cls, pct)
+                assert np.array_equal(l_g, l_o) and np.array_equal(p_g, p_o)
+                pre_g, pp_g, idx_g = ctx.scan_prefix(cls, pct)
+                pre_o, pp_o, idx_o = snap.scan_prefix(cls, pct)
+                assert np.array_equal(idx_g, idx_o)
+                assert np.array_equal(pre_g, pre_o), "every prefix element must match exactly"
+                assert np.array_equal(pp_g, pp_o)
+            assert ctx.cluster_total(cls) == snap.cluster_total(cls)
+        rng = np.random.default_rng(seed)
+        for i in range(min(pods.p, 12)):
+            cls = int(rng.integers(0, sc["n_classes"]))
+            pct = float(rng.choice([1.0, 0.7]))
+            req = (pods.req[:, i] * int(rng.integers(0, 40))).tolist()
+            pres = int(pods.req_present[i])
+            ok_o, fk_o, _ = snap.compare_cluster(cls, req, pres, pct)
+            assert ctx.cluster_fits(cls, pct, req, pres) == (ok_o, fk_o)
+
+
+def _batch_case(sc, bsa, soa, orc, commit=True, eph_gate=1):
+    nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"],
+                                            denied=sc["denied"], permitted=sc["permitted"])
+    snap = orc.Snapshot(nodes, fit, eph_gate=eph_gate)
+    sop = orc.Sop(snap, groups)
+    exp = sop.batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods, eph_gate=eph_gate) as ctx:
+        got = ctx.batch(soa.STAGE_ALL)
+        assert_batch_equal(got, exp)
+        # what-if runs leave the loaded group state alone
+        assert ctx.read_groups().state_equal(groups)
+        if commit:
+            got2 = ctx.batch(soa.STAGE_ALL | soa.BATCH_COMMIT)
+            assert_batch_equal(got2, exp)
+            after = ctx.read_groups()
+            assert after.state_equal(sop.groups), "committed group state must equal the sequential reference's"
+    return got
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_batch_random_small(seed, bsa, soa, orc):
+    _batch_case(random_objects(seed), bsa, soa, orc)
+
+
+@pytest.mark.parametrize("seed", range(3000, 3040))
+def test_batch_random_medium(seed, bsa, soa, orc):
+    _batch_case(random_objects(seed, n_nodes=300, n_groups=20, n_pods=400, n_scalars=seed % 3, n_classes=4), bsa, soa, orc)
+
+
+@pytest.mark.parametrize("seed", range(4000, 4010))
+def test_batch_eph_gate_off(seed, bsa, soa, orc):
+    _batch_case(random_objects(seed, n_nodes=60, n_groups=8, n_pods=80), bsa, soa, orc, eph_gate=0)
+
+
+@pytest.mark.parametrize("scenario", ["cold", "warm", "busy", "tail"])
+def test_batch_cfg2_all_scenarios(scenario, bsa, soa, orc):
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", scenario)
+    sop = orc.Sop(orc.Snapshot(nodes, fit), groups)
+    exp = sop.batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, scenario)
+
+
+@pytest.mark.parametrize("scenario,seed", [("cold", 1), ("warm", 2), ("busy", 3), ("tail", 20260921)])
+def test_batch_cfg3_prefilter(scenario, seed, bsa, soa, orc):
+    """BASELINE config 3 (10k pods / 2k groups / 5k nodes, 4 resource dims): admit/reject bit-identical."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg3", scenario, seed=seed)
+    sop = orc.Sop(orc.Snapshot(nodes, fit), groups)
+    st = soa.STAGE_PREFILTER | soa.STAGE_TALLY
+    exp = sop.batch(pods, st, bitmap=False)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        got = ctx.batch(st, bitmap=False)
+        assert_batch_equal(got, exp, scenario, bitmap=False)
+
+
+def test_batch_cfg3_tail_with_filter(bsa, soa, orc):
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg3", "tail")
+    sop = orc.Sop(orc.Snapshot(nodes, fit), groups)
+    exp = sop.batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "cfg3 tail")
+
+
+def test_find_max_pg_and_filter_one(bsa, soa, orc):
+    for seed in range(40):
+        sc = random_objects(seed + 9000, n_nodes=20)
+        nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"])
+        snap = orc.Snapshot(nodes, fit)
+        sop = orc.Sop(snap, groups)
+        with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+            leader, fin, panic = orc.find_max_pg(groups)
+            gl, gp = ctx.find_max_pg()
+            assert gp == panic
+            if not panic:
+                assert gl == leader
+            rng = np.random.default_rng(seed)
+            for _ in range(10):
+                i = int(rng.integers(0, pods.p))
+                ld = int(rng.integers(-1, groups.g))
+                k = int(rng.integers(0, nodes.n))
+                if pods.group[i] == soa.POD_GROUP_MISSING:
+                    continue
+                exp = sop.filter_node(pods, i, ld, k)
+                got = ctx.filter_one(int(pods.group[i]), pods.req[:, i].tolist(), int(pods.req_present[i]), ld, k)
+                assert got[0] == exp[0]
+                if exp[0] == soa.FL_EVALUATED:
+                    assert got[1] == exp[1]
+
+
+def test_edge_sizes(bsa, soa, orc):
+    """empty and ragged inputs: zero pods, zero nodes, one node, 63/64/65 pods and nodes."""
+    for n_nodes, n_pods in [(0, 5), (1, 1), (63, 65), (64, 64), (65, 63), (129, 1), (5, 0)]:
+        sc = random_objects(n_nodes * 131 + n_pods, n_nodes=n_nodes, n_pods=max(n_pods, 1), n_groups=3)
+        if n_pods == 0:
+            sc["pods"] = []
+        _batch_case(sc, bsa, soa, orc, commit=False)
+
+
+def test_max_scalar_lanes(bsa, soa, orc):
+    """S = 12 (BS_MAX_SCALARS): the widest row layout."""
+    rng = np.random.default_rng(5)
+    S, n, L = 12, 300, 16
+    alloc = rng.integers(0, 1000, size=(L, n)).astype(np.int64)
+    req = rng.integers(0, 800, size=(L, n)).astype(np.int64)
+    ap = rng.integers(0, 1 << S, size=n).astype(np.uint32)
+    rp = rng.integers(0, 1 << S, size=n).astype(np.uint32)
+    nodes = soa.Nodes(alloc, req, ap, rp, np.zeros(n, np.uint8))
+    fit = soa.FitMasks.from_bool(rng.random((2, n)) < 0.9)
+    snap = orc.Snapshot(nodes, fit)
+    with bsa.Context(scalar_lanes=S) as ctx:
+        ctx.load_nodes(nodes, fit)
+        for cls in (0, 1):
+            a, b, c = ctx.scan_prefix(cls, 0.7)
+            x, y, z = snap.scan_prefix(cls, 0.7)
+            assert np.array_equal(a, x) and np.array_equal(b, y) and np.array_equal(c, z)
+            for _ in range(30):
+                reqv = rng.integers(-50, 4000, size=L).tolist()
+                pres = int(rng.integers(0, 1 << S))
+                ok, fk, _ = snap.compare_cluster(cls, reqv, pres, 0.7)
+                assert ctx.cluster_fits(cls, 0.7, reqv, pres) == (ok, fk)
+
+
+def test_churn_apply_equals_reload(bsa, soa, orc):
+    """BASELINE config 5 in miniature: a stream of update / append / stable-remove edits."""
+    capi = bsa.capi
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "warm", seed=5)
+    rng = np.random.default_rng(11)
+    alloc, req = nodes.allocatable.copy(), nodes.requested.copy()
+    ap, rp, fl = nodes.allocatable_present.copy(), nodes.requested_present.copy(), nodes.flags.copy()
+    fitb = fit.to_bool()
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        for rnd in range(6):
+            deltas = []
+            for _ in range(25):
+                kind = int(rng.choice([capi.DELTA_UPDATE, capi.DELTA_APPEND, capi.DELTA_REMOVE], p=[0.4, 0.3, 0.3]))
+                n = alloc.shape[1]
+                d = capi.NodeDelta()
+                d.kind = kind
+                if kind == capi.DELTA_REMOVE:
+                    idx = int(rng.integers(0, n))
+                    d.index = idx
+                    alloc, req = np.delete(alloc, idx, 1), np.delete(req, idx, 1)
+                    ap, rp, fl = np.delete(ap, idx), np.delete(rp, idx), np.delete(fl, idx)
+                    fitb = np.delete(fitb, idx, 1)
+                else:
+                    src = int(rng.integers(0, n))
+                    col_a, col_r = alloc[:, src].copy(), req[:, src].copy()
+                    col_r[0] = int(col_a[0] * rng.random())
+                    col_r[1] = int(col_a[1] * rng.random())
+                    for j in range(4):
+                        d.allocatable[j], d.requested[j] = int(col_a[j]), int(col_r[j])
+                    d.fit_default, d.n_fit_exceptions = 1, 1
+                    exc = int(rng.integers(0, fitb.shape[0]))
+                    d.fit_exceptions[0] = exc
+                    fcol = np.ones(fitb.shape[0], bool)
+                    fcol[exc] = False
+                    if kind == capi.DELTA_UPDATE:
+                        idx = int(rng.integers(0, n))
+                        d.index = idx
+                        alloc[:, idx], req[:, idx], ap[idx], rp[idx], fl[idx] = col_a, col_r, 0, 0, 0
+                        fitb[:, idx] = fcol
+                    else:
+                        alloc, req = np.concatenate([alloc, col_a[:, None]], 1), np.concatenate([req, col_r[:, None]], 1)
+                        ap, rp, fl = np.append(ap, 0).astype(np.uint32), np.append(rp, 0).astype(np.uint32), np.append(fl, 0).astype(np.uint8)
+                        fitb = np.concatenate([fitb, fcol[:, None]], 1)
+                deltas.append(d)
+            ctx.apply_node_deltas(deltas)
+            cur_nodes = soa.Nodes(alloc, req, ap, rp, fl)
+            cur_fit = soa.FitMasks.from_bool(fitb)
+            assert ctx.n == cur_nodes.n
+            sop = orc.Sop(orc.Snapshot(cur_nodes, cur_fit), groups)
+            exp = sop.batch(pods, soa.STAGE_ALL)
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"churn round {rnd}")
+
+
+def test_sharded_union_equals_single(bsa, soa, orc):
+    """Pod-axis sharding: ranks own whole groups, per-group admit counters are disjoint, their sum (what
+    the RCCL all-reduce produces) equals the single-GPU counters and the decisions agree pod by pod."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "busy", seed=3)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        single = ctx.batch(soa.STAGE_ALL)
+        for nranks in (2, 3, 8):
+            admit = np.zeros(groups.g, np.uint32)
+            owned = np.zeros(pods.p, np.int32)
+            for r in range(nranks):
+                ctx.set_shard(r, nranks)
+                ctx.run(soa.STAGE_ALL)
+                part = ctx.read()
+                mine = part.pf_code != 0xFF
+                owned += mine
+                assert np.array_equal(part.pf_code[mine], single.pf_code[mine])
+                assert np.array_equal(part.pf_first_k[mine], single.pf_first_k[mine])
+                assert np.array_equal(part.fl_feasible[mine], single.fl_feasible[mine])
+                assert np.array_equal(part.fl_bitmap[:, mine], single.fl_bitmap[:, mine])
+                admit += part.group_admit
+            assert np.all(owned == 1), "every pod is evaluated by exactly one rank"
+            assert np.array_equal(admit, single.group_admit)
+        ctx.set_shard(0, 1)
+
+
+def test_native_rccl_single_rank(bsa, soa, orc):
+    """bs_comm_init + in-library ncclAllReduce at world size 1 (the only size one GPU allows)."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("tiny", "warm")
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        ctx.comm_init(bsa.capi.comm_unique_id(), 0, 1)
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp)
+
+
+def test_full_size_properties_cfg4(bsa, soa, orc):
+    """BASELINE config 4 sizes (50k pods / 5k groups / 20k nodes): size-independent properties."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg4", "tail", seed=4)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        a = ctx.batch(soa.STAGE_ALL)
+        b = ctx.batch(soa.STAGE_ALL)
+        assert_batch_equal(a, b, "determinism")                      # idempotent / deterministic
+        # feasible count == popcount of the pod's bitmap column
+        lut = np.array([bin(i).count("1") for i in range(256)], dtype=np.uint8)
+        pop = lut[a.fl_bitmap.view(np.uint8)].reshape(a.fl_bitmap.shape[0], pods.p, 8).sum(axis=(0, 2), dtype=np.uint32)
+        assert np.array_equal(pop, a.fl_feasible)
+        # admit counters == per-group count of admitted pods; ready == quorum predicate core.go:303
+        passed = (a.pf_code < 16) & (a.fl_feasible > 0) & (pods.group >= 0)
+        cnt = np.bincount(pods.group[passed], minlength=groups.g).astype(np.uint32)
+        assert np.array_equal(cnt, a.group_admit)
+        ready = (groups.matched + cnt).astype(np.uint32) >= (groups.min_member - groups.status_scheduled).astype(np.uint32)
+        assert np.array_equal(ready.astype(np.uint8), a.group_ready)
+        # deny replay: behind a group's first REJECT every later pod of the group is ERR_DENIED
+        rej = np.isin(a.pf_code, [soa.PF_REJECT_FIRST, soa.PF_REJECT_RESERVE])
+        first_rej = np.full(groups.g, pods.p, np.int64)
+        idx = np.nonzero(rej)[0]
+        np.minimum.at(first_rej, pods.group[idx], idx)
+        grouped = pods.group >= 0
+        later = grouped & (np.arange(pods.p) > first_rej[np.maximum(pods.group, 0)])
+        assert np.all(a.pf_code[later] == soa.PF_ERR_DENIED)
+        assert rej.sum() == (first_rej < pods.p).sum(), "exactly one REJECT per denied group"
+        # spot-check decisions against the oracle's single-query path (finishes in seconds)
+        snap = orc.Snapshot(nodes, fit)
+        sop = orc.Sop(snap, groups)
+        rng = np.random.default_rng(0)
+        for i in rng.choice(pods.p, 40, replace=False):
+            code = int(a.pf_code[i])
+            if code in (soa.PF_PASS_RESERVE_FITS, soa.PF_REJECT_RESERVE):
+                ld = int(a.pf_leader[i])
+                pre, pres = orc.pre_allocated(groups, ld, int(groups.matched[ld]), 1)
+                req = [pre[j] + int(pods.req[j, i]) for j in range(5)]
+                ok, fk, _ = snap.compare_cluster(int(groups.cls[ld]), req, pres | int(pods.req_present[i]), 0.7)
+                assert ok == (code == soa.PF_PASS_RESERVE_FITS) and fk == int(a.pf_first_k[i])
