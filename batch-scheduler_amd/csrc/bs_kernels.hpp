@@ -102,6 +102,8 @@ struct BatchDev {
   int64_t* tables;          // [slots][mcap][LP] running sums, row-major (one s_load per row)
   uint32_t* kp;             // [slots][16] first row at which scalar key s exists in the running sum
   uint64_t* stats;          // [8] counters (only touched when collect_stats)
+  unsigned long long* chunk_tot;   // [slots][nchunks][16] chunk totals of the two-level table scan
+  uint32_t* blk_scratch;    // per-block summaries of the two-level pod scans
   // filter
   int64_t* fparams;         // [P][8]: R[4] = pod + maxSingle, M[4] = maxSingle  (fixed lanes)
   uint32_t* fflags;         // [P] bit0 scalar_block (case 2 impossible), bit1 leader_block, bits 8.. fl_code
@@ -125,6 +127,7 @@ struct BatchParams {
   uint32_t collect_stats;
   uint32_t mcap;               // table row capacity
   uint32_t seg_len;            // rows per scan segment
+  uint32_t tile_queries;       // queries per scan tile (64 x Q)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -156,9 +159,9 @@ __global__ __launch_bounds__(kScanBlock) void k_nodes_derive(NodesDev nd, uint32
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_init
+// k_init: reset per-batch scratch
 // ------------------------------------------------------------------------------------------------
-__global__ void k_init(GroupsDev gr, BatchDev b, BatchParams prm, uint32_t P) {
+__global__ void k_init(GroupsDev gr, BatchDev b, BatchParams prm, uint32_t P, uint32_t no_capture) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < gr.g) {
     b.first_elig[t] = BS_INF;
@@ -172,7 +175,12 @@ __global__ void k_init(GroupsDev gr, BatchDev b, BatchParams prm, uint32_t P) {
     b.tbl_count[t] = 0;
     b.tbl_cursor[t] = 0;
   }
-  if (t < P) b.first_row[t] = BS_INF;
+  if (t < P) {
+    b.first_row[t] = BS_INF;
+    b.fl_feasible[t] = 0;
+    if (no_capture) b.epoch[t] = 0;
+  }
+  if (t == 0 && no_capture) *b.nepochs = 1;      // every group already has its pod: one epoch
   if (t < 8 && prm.collect_stats) b.stats[t] = 0;
 }
 
@@ -198,29 +206,42 @@ __global__ void k_prepass(PodsDev pods, GroupsDev gr, BatchDev b) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_epochs: epoch[i] = number of first-pod captures (pgs.Pod = pod, core.go:486-488) at queue
-// positions <= i.  findMaxPG skips groups without a pod (core.go:709-711), so its candidate set —
-// and therefore the leader — can only change at these positions.  Single block, ordered chunks.
+// k_epochs_a / k_epochs_b: epoch[i] = number of first-pod captures (pgs.Pod = pod, core.go:486-488)
+// at queue positions <= i.  findMaxPG skips groups without a pod (core.go:709-711), so its candidate
+// set — and therefore the leader — can only change at these positions.  Two-level ordered scan:
+// per-block counts, then block prefix + in-block scan.  Skipped entirely when every group already
+// has its pod (k_init writes epoch = 0).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kScanBlock) void k_epochs(PodsDev pods, GroupsDev gr, BatchDev b) {
-  __shared__ uint32_t lds[16];
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < pods.p; base += kScanBlock) {
-    const uint32_t i = base + threadIdx.x;
-    uint32_t cap = 0;
-    int32_t gi = -1;
-    if (i < pods.p && (b.stage[i] & ST_ELIG)) {
-      gi = pods.group[i];
-      cap = (b.first_elig[gi] == i && !(gr.flags[gi] & BS_GROUP_HAS_POD)) ? 1u : 0u;
-    }
-    uint32_t total;
-    const uint32_t incl = block_incl_scan_add<uint32_t>(cap, lds, total);
-    if (i < pods.p) b.epoch[i] = carry + incl;
-    if (cap) b.cap_epoch[gi] = carry + incl;
-    carry += total;
-    __syncthreads();
+__device__ __forceinline__ uint32_t capture_flag(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, uint32_t i, int32_t& gi) {
+  gi = -1;
+  if (i < pods.p && (b.stage[i] & ST_ELIG)) {
+    gi = pods.group[i];
+    return (b.first_elig[gi] == i && !(gr.flags[gi] & BS_GROUP_HAS_POD)) ? 1u : 0u;
   }
-  if (threadIdx.x == 0) *b.nepochs = carry + 1;
+  return 0u;
+}
+__global__ __launch_bounds__(kScanBlock) void k_epochs_a(PodsDev pods, GroupsDev gr, BatchDev b) {
+  __shared__ uint32_t lds[16];
+  int32_t gi;
+  const uint32_t cap = capture_flag(pods, gr, b, blockIdx.x * kScanBlock + threadIdx.x, gi);
+  uint32_t total;
+  (void)block_incl_scan_add<uint32_t>(cap, lds, total);
+  if (threadIdx.x == 0) b.blk_scratch[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanBlock) void k_epochs_b(PodsDev pods, GroupsDev gr, BatchDev b) {
+  __shared__ uint32_t lds[16];
+  uint32_t part = 0;
+  for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kScanBlock) part += b.blk_scratch[j];
+  uint32_t prev;
+  (void)block_incl_scan_add<uint32_t>(part, lds, prev);
+  const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
+  int32_t gi;
+  const uint32_t cap = capture_flag(pods, gr, b, i, gi);
+  uint32_t total;
+  const uint32_t incl = block_incl_scan_add<uint32_t>(cap, lds, total);
+  if (i < pods.p) b.epoch[i] = prev + incl;
+  if (cap) b.cap_epoch[gi] = prev + incl;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *b.nepochs = prev + total + 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,6 +254,7 @@ __global__ __launch_bounds__(kScanBlock) void k_epochs(PodsDev pods, GroupsDev g
 // them is taken unconditionally, and from then on the holder `cur` is replaced by the next tied
 // candidate with Scheduled == 0 while `cur` itself is fully scheduled.  That chain is walked with
 // block-wide min reductions (it has length <= 2 unless MinMember == 0 groups exist).
+// One 64-bit max reduction carries {panic, any candidate, F}.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool leader_candidate(const GroupsDev& gr, const BatchDev& b, uint32_t g, uint32_t e) {
   return !(gr.flags[g] & BS_GROUP_SCHEDULED_LATCH) && b.cap_epoch[g] <= e;
@@ -243,43 +265,79 @@ __device__ __forceinline__ uint32_t leader_finished(const GroupsDev& gr, uint32_
   if (mm == 0u) { panic = true; return 0u; }
   return (uint32_t)((uint32_t)(gr.matched[g] + sc) * 1000u) / mm;
 }
+__device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, unsigned long long* lds) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long u = __shfl_xor(v, o);
+    v = u > v ? u : v;
+  }
+  __syncthreads();
+  if (lane_id() == 0) lds[wave_id()] = v;
+  __syncthreads();
+  unsigned long long r = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r = lds[w] > r ? lds[w] : r;
+  return r;
+}
 
-__global__ __launch_bounds__(256) void k_leader(GroupsDev gr, BatchDev b) {
+constexpr int kLeaderBlock = 512;
+constexpr int kLeaderPerThread = 16;     // groups cached in registers per thread (G <= 8192), else recomputed
+
+__global__ __launch_bounds__(kLeaderBlock) void k_leader(GroupsDev gr, BatchDev b) {
+  __shared__ unsigned long long lds64[16];
   __shared__ uint32_t lds[16];
   const uint32_t e = blockIdx.x;
   if (e >= *b.nepochs) return;
+  // per thread: up to kLeaderPerThread groups cached in registers (candidate bit + finished)
+  uint32_t fin[kLeaderPerThread];
+  uint32_t cand = 0;
   bool panic = false;
-  uint32_t fmax = 0, any = 0;
-  for (uint32_t g = threadIdx.x; g < gr.g; g += blockDim.x) {
-    if (!leader_candidate(gr, b, g, e)) continue;
-    any = 1;
-    fmax = max(fmax, leader_finished(gr, g, panic));
+  unsigned long long best = 0;                     // max of finished + 1 over candidates, 0 = none
+#pragma unroll
+  for (int it = 0; it < kLeaderPerThread; ++it) {
+    const uint32_t g = threadIdx.x + (uint32_t)it * kLeaderBlock;
+    fin[it] = 0;
+    if (g < gr.g && leader_candidate(gr, b, g, e)) {
+      cand |= 1u << it;
+      fin[it] = leader_finished(gr, g, panic);
+      const unsigned long long k64 = (unsigned long long)fin[it] + 1ull;
+      best = k64 > best ? k64 : best;
+    }
   }
-  const uint32_t any_panic = block_max_u32(panic ? 1u : 0u, lds);
-  const uint32_t any_cand = block_max_u32(any, lds);
-  const uint32_t F = block_max_u32(fmax, lds);
-  if (any_panic) {
+  for (uint32_t g = threadIdx.x + kLeaderBlock * kLeaderPerThread; g < gr.g; g += kLeaderBlock) {   // G > 8192
+    if (!leader_candidate(gr, b, g, e)) continue;
+    const unsigned long long k64 = (unsigned long long)leader_finished(gr, g, panic) + 1ull;
+    best = k64 > best ? k64 : best;
+  }
+  if (panic) best |= 1ull << 63;
+  const unsigned long long top = block_max_u64(best, lds64);
+  if (top >> 63) {
     if (threadIdx.x == 0) { b.leader_epoch[e] = -1; b.panic_epoch[e] = 1; }
     return;
   }
-  if (!any_cand) {
+  if (top == 0) {
     if (threadIdx.x == 0) { b.leader_epoch[e] = -1; b.panic_epoch[e] = 0; }
     return;
   }
-  // first candidate tied at F
-  uint32_t first = BS_INF;
-  for (uint32_t g = threadIdx.x; g < gr.g; g += blockDim.x) {
+  const uint32_t F = (uint32_t)(top - 1ull);
+  auto tied = [&](uint32_t g) -> bool {
+    if (!leader_candidate(gr, b, g, e)) return false;
     bool p2 = false;
-    if (leader_candidate(gr, b, g, e) && leader_finished(gr, g, p2) == F) { first = g; break; }
-  }
+    return leader_finished(gr, g, p2) == F;
+  };
+  // first candidate tied at F (group indices grow with `it`, so scan downwards and keep the last hit)
+  uint32_t first = BS_INF;
+  for (uint32_t g = threadIdx.x + kLeaderBlock * kLeaderPerThread; g < gr.g; g += kLeaderBlock)
+    if (tied(g)) { first = g; break; }
+#pragma unroll
+  for (int it = kLeaderPerThread - 1; it >= 0; --it)
+    if (((cand >> it) & 1u) && fin[it] == F) first = threadIdx.x + (uint32_t)it * kLeaderBlock;
   uint32_t cur = block_min_u32(first, lds);
   for (;;) {
     if (!(gr.status_scheduled[cur] >= gr.min_member[cur])) break;   // holder not fully scheduled: stays
     uint32_t nxt = BS_INF;
-    for (uint32_t g = threadIdx.x; g < gr.g; g += blockDim.x) {
+    for (uint32_t g = threadIdx.x; g < gr.g; g += kLeaderBlock) {
       if (g <= cur) continue;
-      bool p2 = false;
-      if (leader_candidate(gr, b, g, e) && gr.status_scheduled[g] == 0u && leader_finished(gr, g, p2) == F) { nxt = g; break; }
+      if (gr.status_scheduled[g] == 0u && tied(g)) { nxt = g; break; }
     }
     nxt = block_min_u32(nxt, lds);
     if (nxt == BS_INF) break;
@@ -296,38 +354,58 @@ struct Res {            // upstream nodeinfo.Resource flattened
   uint32_t present;
 };
 
-__device__ __forceinline__ void res_zero(Res& r, uint32_t L) {
-  for (uint32_t j = 0; j < L; ++j) r.v[j] = 0;
+// TS >= 0: scalar-lane count known at compile time (arrays stay in registers); TS < 0: runtime S.
+template <int TS>
+struct Shape {
+  uint32_t rtS;
+  __device__ __forceinline__ explicit Shape(uint32_t s) : rtS(s) {}
+  __device__ __forceinline__ uint32_t S() const { return TS >= 0 ? (uint32_t)TS : rtS; }
+  __device__ __forceinline__ uint32_t L() const { return 4u + S(); }
+};
+
+template <int TS>
+__device__ __forceinline__ void res_zero(Res& r, Shape<TS> sh) {
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+    if (j < sh.L()) r.v[j] = 0;
   r.present = 0;
 }
 // Resource.Add(ResourceList): ephemeral-storage only behind the feature gate; scalar keys are created.
-__device__ __forceinline__ void res_add(Res& r, const Res& rl, uint32_t S, uint32_t gate) {
+template <int TS>
+__device__ __forceinline__ void res_add(Res& r, const Res& rl, Shape<TS> sh, uint32_t gate) {
   r.v[0] = wadd(r.v[0], rl.v[0]);
   r.v[1] = wadd(r.v[1], rl.v[1]);
   if (gate) r.v[2] = wadd(r.v[2], rl.v[2]);
   r.v[3] = wadd(r.v[3], rl.v[3]);
-  for (uint32_t s = 0; s < S; ++s)
-    if (rl.present & (1u << s)) { r.v[4 + s] = wadd(r.v[4 + s], rl.v[4 + s]); r.present |= 1u << s; }
+#pragma unroll
+  for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s)
+    if (s < sh.S() && (rl.present & (1u << s))) { r.v[4 + s] = wadd(r.v[4 + s], rl.v[4 + s]); r.present |= 1u << s; }
 }
 // getPodResourceRequire(pod): lanes handed over by the shim, normalised through Add
-__device__ __forceinline__ void pod_require(const PodsDev& pods, uint32_t i, uint32_t L, uint32_t S, uint32_t gate, Res& out) {
+template <int TS>
+__device__ __forceinline__ void pod_require(const PodsDev& pods, uint32_t i, Shape<TS> sh, uint32_t gate, Res& out) {
   Res raw;
-  for (uint32_t j = 0; j < L; ++j) raw.v[j] = pods.req[(size_t)j * pods.p + i];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+    if (j < sh.L()) raw.v[j] = pods.req[(size_t)j * pods.p + i];
   raw.present = pods.pres[i];
-  res_zero(out, L);
-  res_add(out, raw, S, gate);
+  res_zero(out, sh);
+  res_add(out, raw, sh, gate);
 }
 // Spec.MinResources of group g as pod i sees it: the loaded value, or (MinResources == nil at load)
 // the request of the first pod that reached fillOccupiedObj (core.go:489-493), or nil.
+template <int TS>
 __device__ __forceinline__ bool group_minres_at(const GroupsDev& gr, const PodsDev& pods, const BatchDev& b, uint32_t g,
-                                                uint32_t i, uint32_t L, uint32_t S, uint32_t gate, Res& out) {
+                                                uint32_t i, Shape<TS> sh, uint32_t gate, Res& out) {
   if (gr.flags[g] & BS_GROUP_HAS_MINRES) {
-    for (uint32_t j = 0; j < L; ++j) out.v[j] = gr.minres[(size_t)j * gr.g + g];
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < sh.L()) out.v[j] = gr.minres[(size_t)j * gr.g + g];
     out.present = gr.mrpres[g];
     return true;
   }
   const uint32_t fe = b.first_elig[g];
-  if (fe <= i) { pod_require(pods, fe, L, S, gate, out); return true; }
+  if (fe <= i) { pod_require(pods, fe, sh, gate, out); return true; }
   return false;
 }
 __device__ __forceinline__ uint32_t group_cls_at(const GroupsDev& gr, const PodsDev& pods, const BatchDev& b, uint32_t g) {
@@ -335,28 +413,33 @@ __device__ __forceinline__ uint32_t group_cls_at(const GroupsDev& gr, const Pods
   return pods.cls[b.first_elig[g]];
 }
 // getPreAllocatedResource, core.go:774-793 (repeated Add == wrapping multiply)
+template <int TS>
 __device__ __forceinline__ void pre_allocated(const GroupsDev& gr, uint32_t g, int64_t matched, bool have_mr, const Res& mr,
-                                              uint32_t L, uint32_t S, uint32_t gate, Res& out) {
-  res_zero(out, L);
+                                              Shape<TS> sh, uint32_t gate, Res& out) {
+  res_zero(out, sh);
   const int64_t mm = (int64_t)gr.min_member[g];
   const int64_t not_finished = matched != 0 ? mm - matched : mm - (int64_t)gr.status_scheduled[g];
   if (not_finished > 0 && have_mr) {
     Res times;
-    for (uint32_t j = 0; j < L; ++j) times.v[j] = wmul(mr.v[j], not_finished);
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < sh.L()) times.v[j] = wmul(mr.v[j], not_finished);
     times.present = mr.present;
-    res_add(out, times, S, gate);
+    res_add(out, times, sh, gate);
   }
   if (out.v[BS_LANE_PODS] == 0) out.v[BS_LANE_PODS] = mm + 1;
 }
 
+template <int TS>
 __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
+  const Shape<TS> sh(prm.S);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < pods.p;
-  const uint32_t L = prm.L, S = prm.S, gate = prm.eph_gate;
+  const uint32_t gate = prm.eph_gate;
   uint8_t code = BS_PF_PASS_NOT_GROUPED, st = 0;
   int32_t leader = -1, table = -1;
   Res q;
-  res_zero(q, L);
+  res_zero(q, sh);
   if (valid) {
     st = b.stage[i];
     const int32_t gi = pods.group[i];
@@ -393,18 +476,18 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
             const int64_t matched = (int64_t)gr.matched[leader];                         // :132-135
             Res mr;
             if (matched == 0) {                                                          // :136-147
-              const bool have = group_minres_at(gr, pods, b, g, i, L, S, gate, mr);
-              pre_allocated(gr, g, 0, have, mr, L, S, gate, q);
+              const bool have = group_minres_at(gr, pods, b, g, i, sh, gate, mr);
+              pre_allocated(gr, g, 0, have, mr, sh, gate, q);
               table = (int32_t)group_cls_at(gr, pods, b, g);                             // pct 1
               code = BS_PF_PASS_FIRST_FITS;                                              // tentative
             } else if (leader == gi) {
               code = BS_PF_PASS_IS_MAX;                                                  // :150-155
             } else {                                                                     // :157-166
-              const bool have = group_minres_at(gr, pods, b, (uint32_t)leader, i, L, S, gate, mr);
-              pre_allocated(gr, (uint32_t)leader, matched, have, mr, L, S, gate, q);
+              const bool have = group_minres_at(gr, pods, b, (uint32_t)leader, i, sh, gate, mr);
+              pre_allocated(gr, (uint32_t)leader, matched, have, mr, sh, gate, q);
               Res cur;
-              pod_require(pods, i, L, S, gate, cur);
-              res_add(q, cur, S, gate);
+              pod_require(pods, i, sh, gate, cur);
+              res_add(q, cur, sh, gate);
               table = (int32_t)(prm.C + group_cls_at(gr, pods, b, (uint32_t)leader));    // pct 0.7
               code = BS_PF_PASS_RESERVE_FITS;                                            // tentative
             }
@@ -416,14 +499,18 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
     if (table >= 0) {
       st |= ST_QUERY;
       uint32_t absok = 0;
-      for (uint32_t s = 0; s < S; ++s) {
-        const bool pres = q.present & (1u << s);
-        if (!pres || q.v[4 + s] == 0) absok |= 1u << s;       // core.go:688-692
-        if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
+#pragma unroll
+      for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+        if (s < sh.S()) {
+          const bool pres = q.present & (1u << s);
+          if (!pres || q.v[4 + s] == 0) absok |= 1u << s;       // core.go:688-692
+          if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
+        }
       }
       int64_t* dst = b.qreq + (size_t)i * prm.LP;
-      for (uint32_t j = 0; j < L; ++j) dst[j] = q.v[j];
-      for (uint32_t j = L; j < prm.LP; ++j) dst[j] = INT64_MIN;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+        if (j < prm.LP) dst[j] = j < sh.L() ? q.v[j] : INT64_MIN;
       b.qflags[i] = q.present | (absok << 16);
     }
     b.tcode[i] = code;
@@ -436,46 +523,65 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_plan: offsets per table, table slots + descriptors, 64-query tiles.  Single block.
+// k_plan: offsets per table, table slots + descriptors, scan tiles.  Single block.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kScanBlock) void k_plan(BatchDev b, BatchParams prm) {
   __shared__ uint32_t lds[16];
   __shared__ uint32_t s_carry[3];
+  __shared__ uint32_t s_tile0[kScanBlock + 1], s_off[kScanBlock], s_cnt[kScanBlock], s_slot[kScanBlock];
   const uint32_t T = 2 * prm.C;
+  const uint32_t tq = prm.tile_queries;
   if (threadIdx.x == 0) { s_carry[0] = 0; s_carry[1] = 0; s_carry[2] = 0; }
   __syncthreads();
   for (uint32_t base = 0; base < T; base += kScanBlock) {
     const uint32_t t = base + threadIdx.x;
     const uint32_t cnt = t < T ? b.tbl_count[t] : 0u;
     const uint32_t need = cnt ? 1u : 0u;
-    const uint32_t ntile = (cnt + 63u) / 64u;
+    const uint32_t ntile = (cnt + tq - 1u) / tq;
     uint32_t tot_c, tot_n, tot_t;
     const uint32_t inc_c = block_incl_scan_add<uint32_t>(cnt, lds, tot_c);
     const uint32_t inc_n = block_incl_scan_add<uint32_t>(need, lds, tot_n);
     const uint32_t inc_t = block_incl_scan_add<uint32_t>(ntile, lds, tot_t);
     const uint32_t c0 = s_carry[0], n0 = s_carry[1], t0 = s_carry[2];
+    const uint32_t off = c0 + inc_c - cnt;
+    const uint32_t slot = n0 + inc_n - 1;
+    s_tile0[threadIdx.x] = inc_t - ntile;              // exclusive, relative to t0
+    s_off[threadIdx.x] = off;
+    s_cnt[threadIdx.x] = cnt;
+    s_slot[threadIdx.x] = slot;
+    if (threadIdx.x == kScanBlock - 1) s_tile0[kScanBlock] = inc_t;
     if (t < T) {
-      const uint32_t off = c0 + inc_c - cnt;
       b.tbl_off[t] = off;
       if (need) {
-        const uint32_t slot = n0 + inc_n - 1;
         b.tbl_slot[t] = (int32_t)slot;
         TableDesc d;
         d.cls = t % prm.C;
         d.pct = t < prm.C ? 1.0f : 0.7f;        // core.go:140 (percent 1) / :161 (percent 0.7)
         b.desc[slot] = d;
-        const uint32_t tile0 = t0 + inc_t - ntile;
-        for (uint32_t k = 0; k < ntile; ++k) {
-          Tile tl;
-          tl.slot = slot;
-          tl.q0 = off + 64u * k;
-          tl.count = min(64u, cnt - 64u * k);
-          tl.pad = 0;
-          b.tiles[tile0 + k] = tl;
-        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b.kp[slot * 16 + s] = BS_INF;
       } else {
         b.tbl_slot[t] = -1;
       }
+    }
+    __syncthreads();
+    // all threads write this chunk's tiles: tile x belongs to the table whose exclusive offset is the
+    // last one <= x (binary search over the 1024 offsets in LDS)
+    for (uint32_t x = threadIdx.x; x < tot_t; x += kScanBlock) {
+      uint32_t lo = 0, hi = kScanBlock - 1;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (s_tile0[mid] <= x) lo = mid; else hi = mid - 1;
+      }
+      // skip empty tables that share the same offset: advance to the one that really owns x
+      while (lo + 1 < kScanBlock && s_tile0[lo + 1] <= x) ++lo;
+      const uint32_t k = x - s_tile0[lo];
+      Tile tl;
+      tl.slot = s_slot[lo];
+      tl.q0 = s_off[lo] + tq * k;
+      tl.count = min(tq, s_cnt[lo] - tq * k);
+      tl.pad = 0;
+      b.tiles[t0 + x] = tl;
     }
     __syncthreads();
     if (threadIdx.x == 0) { s_carry[0] = c0 + tot_c; s_carry[1] = n0 + tot_n; s_carry[2] = t0 + tot_t; }
@@ -497,71 +603,163 @@ __global__ void k_scatter(PodsDev pods, BatchDev b) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tables: one block per table slot.  Row k (k-th non-skipped node in list order) holds the running
-// sum leftResources after that node (core.go:602,621):
+// k_tables_local / k_tables_fix: running sums per table, two-level.
+// Row k (k-th non-skipped node in list order) holds leftResources after that node (core.go:602,621):
 //   left = fit && !taint_err ? int64(float32(alloc)*pct) - requested : 0         (core.go:634-670)
 //   scalar lane s contributes only when both allocatable and requested carry the key (:662-668)
-// kp[s] = first row at which the running sum owns scalar key s.
+// Block (slot, chunk) scans its 256 rows and records the chunk totals; the fix-up pass adds the sum
+// of the preceding chunks.  kp[s] = first row at which the running sum owns scalar key s.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kScanBlock) void k_tables(NodesDev nd, BatchDev b, BatchParams prm) {
+constexpr int kTblChunk = 256;
+
+__global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDev b, BatchParams prm, uint32_t nslots_host) {
   __shared__ unsigned long long lds64[16];
-  __shared__ uint32_t s_kp[BS_MAX_SCALARS];
   const uint32_t slot = blockIdx.x;
-  if (slot >= *b.ntables) return;
+  if (nslots_host == 0 ? slot >= *b.ntables : slot >= nslots_host) return;
+  const uint32_t chunk = blockIdx.y, nchunks = gridDim.y;
+  const uint32_t k = chunk * kTblChunk + threadIdx.x;
+  if (chunk * kTblChunk >= nd.m) return;
   const TableDesc d = b.desc[slot];
   const uint32_t L = prm.L, S = prm.S, LP = prm.LP;
   int64_t* T = b.tables + (size_t)slot * prm.mcap * LP;
-  if (threadIdx.x < BS_MAX_SCALARS) s_kp[threadIdx.x] = BS_INF;
-  __syncthreads();
-  unsigned long long carry[BS_MAX_LANES];
-  for (uint32_t j = 0; j < L; ++j) carry[j] = 0;
-  const uint32_t* fitrow = nd.fit + (size_t)d.cls * nd.fit_words;
-  for (uint32_t base = 0; base < nd.m; base += kScanBlock) {
-    const uint32_t k = base + threadIdx.x;
-    const bool valid = k < nd.m;
-    uint32_t n = 0, pres = 0;
-    bool fit = false;
-    if (valid) {
-      n = nd.kmap[k];
-      fit = ((fitrow[n >> 5] >> (n & 31u)) & 1u) && !(nd.flags[n] & BS_NODE_TAINT_ERR);
-      if (fit) pres = nd.apres[n] & nd.rpres[n];
-    }
-    for (uint32_t j = 0; j < L; ++j) {
-      unsigned long long left = 0;
-      const bool lane_live = fit && (j < 4 || (pres & (1u << (j - 4))));
-      if (lane_live && !(j == BS_LANE_EPH && !prm.eph_gate))
-        left = (unsigned long long)wsub(scale_f32(nd.alloc[(size_t)j * nd.stride + n], d.pct), nd.req[(size_t)j * nd.stride + n]);
-      unsigned long long total;
-      const unsigned long long incl = block_incl_scan_add<unsigned long long>(left, lds64, total);
-      if (valid) T[(size_t)k * LP + j] = (int64_t)(carry[j] + incl);
-      carry[j] += total;
-    }
-    if (valid) {
-      for (uint32_t j = L; j < LP; ++j) T[(size_t)k * LP + j] = INT64_MAX;
-      for (uint32_t s = 0; s < S; ++s)
-        if (pres & (1u << s)) atomicMin(&s_kp[s], k);
-    }
-    __syncthreads();
+  const bool valid = k < nd.m;
+  uint32_t n = 0, pres = 0;
+  bool fit = false;
+  if (valid) {
+    n = nd.kmap[k];
+    const uint32_t* fitrow = nd.fit + (size_t)d.cls * nd.fit_words;
+    fit = ((fitrow[n >> 5] >> (n & 31u)) & 1u) && !(nd.flags[n] & BS_NODE_TAINT_ERR);
+    if (fit) pres = nd.apres[n] & nd.rpres[n];
   }
-  if (threadIdx.x < BS_MAX_SCALARS) b.kp[slot * 16 + threadIdx.x] = s_kp[threadIdx.x];
+  for (uint32_t j = 0; j < L; ++j) {
+    unsigned long long left = 0;
+    const bool lane_live = fit && (j < 4 || (pres & (1u << (j - 4))));
+    if (lane_live && !(j == BS_LANE_EPH && !prm.eph_gate))
+      left = (unsigned long long)wsub(scale_f32(nd.alloc[(size_t)j * nd.stride + n], d.pct), nd.req[(size_t)j * nd.stride + n]);
+    unsigned long long total;
+    const unsigned long long incl = block_incl_scan_add<unsigned long long>(left, lds64, total);
+    if (valid) T[(size_t)k * LP + j] = (int64_t)incl;
+    if (threadIdx.x == 0) b.chunk_tot[((size_t)slot * nchunks + chunk) * 16 + j] = total;
+  }
+  if (valid)
+    for (uint32_t j = L; j < LP; ++j) T[(size_t)k * LP + j] = INT64_MAX;
+  for (uint32_t s = 0; s < S; ++s) {
+    const unsigned long long m = __ballot(valid && (pres & (1u << s)));
+    if (m && lane_id() == 0) atomicMin(&b.kp[slot * 16 + s], chunk * kTblChunk + (uint32_t)(threadIdx.x & ~63u) + (uint32_t)(__ffsll((long long)m) - 1));
+  }
+}
+
+__global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev b, BatchParams prm, uint32_t nslots_host) {
+  __shared__ unsigned long long off[BS_MAX_LANES];
+  const uint32_t slot = blockIdx.x;
+  if (nslots_host == 0 ? slot >= *b.ntables : slot >= nslots_host) return;
+  const uint32_t chunk = blockIdx.y + 1, nchunks = gridDim.y + 1;      // chunk 0 needs no fix-up
+  if (chunk * kTblChunk >= nd.m) return;
+  const uint32_t L = prm.L, LP = prm.LP;
+  if (threadIdx.x < L) {
+    unsigned long long s = 0;
+    for (uint32_t c = 0; c < chunk; ++c) s += b.chunk_tot[((size_t)slot * nchunks + c) * 16 + threadIdx.x];
+    off[threadIdx.x] = s;
+  }
+  __syncthreads();
+  const uint32_t k = chunk * kTblChunk + threadIdx.x;
+  if (k >= nd.m) return;
+  int64_t* row = b.tables + ((size_t)slot * prm.mcap + k) * LP;
+  for (uint32_t j = 0; j < L; ++j) row[j] = (int64_t)((unsigned long long)row[j] + off[j]);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_scan — the dominant kernel.
-// One wave = one tile of <=64 queries (pods) that share a table, x one segment of table rows.
-// Lane l holds query l's request lanes in VGPRs; the loop walks rows k (wave-uniform), whose running
-// sums arrive as scalar loads; per resource lane ONE v_cmp_ge_i64 (VGPR vs SGPR) decides 64 pod x
-// node pairs and lands as a 64-bit lane mask in SGPRs; masks are ANDed on the scalar unit
-// (compareResourceAndRequire core.go:672-699).  A lane records the first row whose mask bit is set
-// (the reference's early exit, core.go:623-627); the wave leaves when every lane has one.
-// Scalar key rule (core.go:686-697): for rows before kp[s] the running sum has no key s, the lane
-// passes iff it requests nothing of s (precomputed bit); from kp[s] on it is a plain compare.
-// Segments of one tile combine through atomicMin on first_row.
+// k_scan — the dominant kernel: "exists k : running_sum_k >= request" (core.go:602-631) for every
+// query, and the first such k (the reference's early exit, core.go:623-627).
+//
+// Geometry.  One wave = one tile of up to 64*Q queries (pods) that share a table x one segment of
+// table rows.  Lane l holds the request lanes of Q queries in VGPRs.  Rows are wave-uniform: a row
+// (LP int64) arrives through the scalar cache with one s_load and is shared by all 64*Q queries.
+//
+// Inner step (one row x 64 queries), hand-written because the compiler's form costs ~20 SALU
+// instructions per row (mask ANDs, selects, branches) around 5 compares:
+//     s_mov_b64   exec, nf            ; lanes still looking for their first row
+//     v_cmpx_ge_i64 vcc, row[0], r0   ; EXEC narrows: each compare only keeps lanes that also
+//     ...                             ; satisfied the previous ones  (compareResourceAndRequire,
+//     v_cmpx_ge_i64 vcc, row[L-1], r  ;  core.go:672-699, is an AND over lanes)
+//     v_mov_b32   myk, k              ; surviving lanes record k — their FIRST satisfying row
+//     s_andn2_b64 nf, nf, exec        ; ... and stop looking
+//     s_mov_b64   exec, -1
+// = 3 SALU + (L+1) VALU per 64 pod x node evaluations, no branch.  v_cmpx on a lane outside EXEC
+// yields 0, so the chain is the AND; one v_cmp_*_i64 decides 64 pairs.
+//
+// Scalar keys (core.go:686-697).  Before row kp[s] the running sum has no key s: a lane passes iff
+// it requests nothing of s (bit precomputed in qflags); from kp[s] on it is an ordinary compare.  k
+// is wave-uniform, so a segment is cut at the kp[s] that fall inside it and each piece runs the
+// same branch-free loop with the lanes that cannot pass masked out of EXEC (their padded request
+// INT64_MIN / 0 makes the absent-key compare trivially true for the others).
+//
+// Rows are double-buffered in SGPRs: the s_loads of the next U rows are in flight while the current U
+// rows are compared.  Table and request pointers are address-space-4 (constant) so that the loads
+// are scalar by construction.  Segments of one tile combine through atomicMin on first_row.
 // ------------------------------------------------------------------------------------------------
-template <int S>
+typedef const __attribute__((address_space(4))) int64_t* crow_t;
+__device__ __forceinline__ crow_t as_const_rows(const int64_t* p) { return (crow_t)(uintptr_t)p; }
+
+#define BS_S_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)   /* lgkmcnt(0), vmcnt/expcnt untouched */
+
+#define BS_CX(j) "v_cmpx_ge_i64 vcc, %[a" #j "], %[r" #j "]\n\t"
+#define BS_ROW_HEAD "s_mov_b64 exec, %[nf]\n\t"
+#define BS_ROW_TAIL "v_mov_b32 %[myk], %[k]\n\ts_andn2_b64 %[nf], %[nf], exec\n\ts_mov_b64 exec, -1"
+#define BS_OPS4 [a0] "s"(a[0]), [r0] "v"(r[0]), [a1] "s"(a[1]), [r1] "v"(r[1]), [a2] "s"(a[2]), [r2] "v"(r[2]), [a3] "s"(a[3]), [r3] "v"(r[3])
+
+template <int L>
+__device__ __forceinline__ void row_step(unsigned long long& nf, uint32_t& myk, uint32_t k, const int64_t (&a)[L], const int64_t (&r)[L]) {
+  if constexpr (L == 4) {
+    asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_ROW_TAIL
+                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4 : "vcc");
+  } else if constexpr (L == 5) {
+    asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_ROW_TAIL
+                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]) : "vcc");
+  } else if constexpr (L == 6) {
+    asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_ROW_TAIL
+                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]) : "vcc");
+  } else if constexpr (L == 7) {
+    asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_CX(6) BS_ROW_TAIL
+                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]),
+                   [a6] "s"(a[6]), [r6] "v"(r[6]) : "vcc");
+  } else if constexpr (L == 8) {
+    asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_CX(6) BS_CX(7) BS_ROW_TAIL
+                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]),
+                   [a6] "s"(a[6]), [r6] "v"(r[6]), [a7] "s"(a[7]), [r7] "v"(r[7]) : "vcc");
+  } else {
+    // wide rows (S > 4): two chained statements; the surviving-lane mask travels in an SGPR pair
+    static_assert(L > 8 && L <= 16, "row width");
+    unsigned long long m = nf;
+    {
+      const int64_t(&a0)[8] = reinterpret_cast<const int64_t(&)[8]>(a[0]);
+      const int64_t(&r0)[8] = reinterpret_cast<const int64_t(&)[8]>(r[0]);
+      asm volatile("s_mov_b64 exec, %[m]\n\t"
+                   "v_cmpx_ge_i64 vcc, %[a0], %[r0]\n\tv_cmpx_ge_i64 vcc, %[a1], %[r1]\n\tv_cmpx_ge_i64 vcc, %[a2], %[r2]\n\t"
+                   "v_cmpx_ge_i64 vcc, %[a3], %[r3]\n\tv_cmpx_ge_i64 vcc, %[a4], %[r4]\n\tv_cmpx_ge_i64 vcc, %[a5], %[r5]\n\t"
+                   "v_cmpx_ge_i64 vcc, %[a6], %[r6]\n\tv_cmpx_ge_i64 vcc, %[a7], %[r7]\n\t"
+                   "s_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
+                   : [m] "+s"(m)
+                   : [a0] "s"(a0[0]), [r0] "v"(r0[0]), [a1] "s"(a0[1]), [r1] "v"(r0[1]), [a2] "s"(a0[2]), [r2] "v"(r0[2]), [a3] "s"(a0[3]),
+                     [r3] "v"(r0[3]), [a4] "s"(a0[4]), [r4] "v"(r0[4]), [a5] "s"(a0[5]), [r5] "v"(r0[5]), [a6] "s"(a0[6]), [r6] "v"(r0[6]),
+                     [a7] "s"(a0[7]), [r7] "v"(r0[7])
+                   : "vcc");
+    }
+#pragma unroll
+    for (int j = 8; j < L; ++j) {
+      asm volatile("s_mov_b64 exec, %[m]\n\tv_cmpx_ge_i64 vcc, %[a], %[r]\n\ts_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
+                   : [m] "+s"(m) : [a] "s"(a[j]), [r] "v"(r[j]) : "vcc");
+    }
+    asm volatile("s_mov_b64 exec, %[m]\n\tv_mov_b32 %[myk], %[k]\n\ts_andn2_b64 %[nf], %[nf], exec\n\ts_mov_b64 exec, -1"
+                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), [m] "s"(m));
+  }
+}
+
+template <int S, int Q>
 __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
+  constexpr int U = (L <= 5) ? 2 : 1;            // rows per buffer (SGPR budget: 2 buffers x U x L pairs)
   const int lane = lane_id();
   const uint32_t tile_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id());
   if (tile_id >= *b.ntiles) return;
@@ -573,62 +771,139 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
   const uint32_t q0 = __builtin_amdgcn_readfirstlane(tl.q0);
   const uint32_t cnt = __builtin_amdgcn_readfirstlane(tl.count);
 
-  const bool valid = (uint32_t)lane < cnt;
-  const uint32_t pod = valid ? b.qlist[q0 + (uint32_t)lane] : 0u;
-  int64_t r[L];
-  uint32_t qf = 0;
-  if (valid) {
-    const int64_t* src = b.qreq + (size_t)pod * LP;
+  int64_t r[Q][L];
+  uint32_t pod[Q], myk[Q], qf[Q];
+  unsigned long long nf[Q];                      // lanes still looking for their first row
 #pragma unroll
-    for (int j = 0; j < L; ++j) r[j] = src[j];
-    qf = b.qflags[pod];
-  } else {
+  for (int q = 0; q < Q; ++q) {
+    const uint32_t qi = (uint32_t)q * 64u + (uint32_t)lane;
+    const bool valid = qi < cnt;
+    pod[q] = valid ? b.qlist[q0 + qi] : 0u;
+    myk[q] = BS_INF;
+    qf[q] = 0;
+    uint32_t seen = 0;
+    if (valid) {
+      const int64_t* src = b.qreq + (size_t)pod[q] * LP;
 #pragma unroll
-    for (int j = 0; j < L; ++j) r[j] = INT64_MAX;
+      for (int j = 0; j < L; ++j) r[q][j] = src[j];
+      qf[q] = b.qflags[pod[q]];
+      seen = __hip_atomic_load(&b.first_row[pod[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+      for (int j = 0; j < L; ++j) r[q][j] = INT64_MAX;
+    }
+    nf[q] = __ballot(valid && seen >= k0);       // an earlier segment may already own a smaller row
   }
-  // lanes that already have an earlier row from another segment need nothing from this one
-  const uint32_t seen = valid ? __hip_atomic_load(&b.first_row[pod], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  unsigned long long found = __ballot(!valid || seen < k0);
-  if (found == ~0ull) return;
+  unsigned long long any = 0;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) any |= nf[q];
+  if (any == 0) return;
 
-  unsigned long long absok[S > 0 ? S : 1];
   uint32_t kp[S > 0 ? S : 1];
+  unsigned long long absok[Q][S > 0 ? S : 1];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    absok[s] = __ballot((qf >> (16 + s)) & 1u);
     kp[s] = __builtin_amdgcn_readfirstlane(b.kp[slot * 16 + s]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) absok[q][s] = __ballot((qf[q] >> (16 + s)) & 1u);
   }
 
-  const int64_t* __restrict__ T = b.tables + (size_t)slot * prm.mcap * LP;
-  uint32_t myk = BS_INF;
-  uint32_t k = k0;
-  for (; k < k1; ++k) {
-    const int64_t* __restrict__ row = T + (size_t)k * LP;
-    unsigned long long mk = __ballot(row[0] >= r[0]);
-    mk &= __ballot(row[1] >= r[1]);
-    mk &= __ballot(row[2] >= r[2]);
-    mk &= __ballot(row[3] >= r[3]);
+  crow_t T = as_const_rows(b.tables + (size_t)slot * prm.mcap * LP);
+  uint32_t rows_done = 0;
+  uint32_t a = k0;
+  while (a < k1) {
+    // piece [a, e): no kp[s] strictly inside
+    uint32_t e = k1;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const unsigned long long cmp = __ballot(row[4 + s] >= r[4 + s]);
-      mk &= (k >= kp[s]) ? cmp : absok[s];
+    for (int s = 0; s < S; ++s)
+      if (kp[s] > a && kp[s] < e) e = kp[s];
+    // lanes that can pass while key s is absent from the running sum (core.go:688-692)
+    unsigned long long act[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      unsigned long long el = ~0ull;
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+        if (kp[s] > a) el &= absok[q][s];
+      act[q] = nf[q] & el;
+      nf[q] &= ~el;                              // parked until a later piece
     }
-    const unsigned long long fresh = mk & ~found;
-    if (fresh) {
-      if ((fresh >> lane) & 1ull) myk = k;
-      found |= mk;
-      if (found == ~0ull) { ++k; break; }
+    uint32_t k = a;
+    const uint32_t pairs = (e - a) / (2u * U);
+    if (pairs) {
+      int64_t A[U][L], B[U][L];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < L; ++j) A[u][j] = T[(size_t)(k + u) * LP + j];
+      BS_S_WAIT_LGKM0();
+      for (uint32_t it = 0; it < pairs; ++it) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < L; ++j) B[u][j] = T[(size_t)(k + U + u) * LP + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) row_step<L>(act[q], myk[q], k + u, A[u], r[q]);
+        BS_S_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        // rows k+2U.. may lie past the piece (prefetch only; the table has slack rows)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < L; ++j) A[u][j] = T[(size_t)(k + 2 * U + u) * LP + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int q = 0; q < Q; ++q) row_step<L>(act[q], myk[q], k + U + u, B[u], r[q]);
+        BS_S_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        k += 2 * U;
+        unsigned long long left = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) left |= act[q];
+        if (left == 0) break;
+      }
     }
+    {
+      unsigned long long left = 0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) left |= act[q];
+      if (left) {
+        for (; k < e; ++k) {                     // < 2U leftover rows of the piece
+          int64_t R1[L];
+#pragma unroll
+          for (int j = 0; j < L; ++j) R1[j] = T[(size_t)k * LP + j];
+          BS_S_WAIT_LGKM0();
+#pragma unroll
+          for (int q = 0; q < Q; ++q) row_step<L>(act[q], myk[q], k, R1, r[q]);
+        }
+      }
+    }
+    rows_done += k - a;
+    unsigned long long left = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      nf[q] |= act[q];
+      left |= nf[q];
+    }
+    if (left == 0) break;
+    a = e;
   }
-  if (valid && myk != BS_INF) atomicMin(&b.first_row[pod], myk);
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    if (myk[q] != BS_INF) atomicMin(&b.first_row[pod[q]], myk[q]);
   if (prm.collect_stats && lane == 0) {
-    atomicAdd((unsigned long long*)&b.stats[0], (unsigned long long)(k - k0));          // rows visited by this wave
-    atomicAdd((unsigned long long*)&b.stats[1], (unsigned long long)(k - k0) * cnt);    // pod x node pairs evaluated
+    atomicAdd((unsigned long long*)&b.stats[0], (unsigned long long)rows_done);
+    atomicAdd((unsigned long long*)&b.stats[1], (unsigned long long)rows_done * cnt);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_reject / k_final
+// k_reject / k_final_a / k_final_b
 // ------------------------------------------------------------------------------------------------
 __global__ void k_reject(PodsDev pods, BatchDev b) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -642,60 +917,117 @@ __global__ void k_reject(PodsDev pods, BatchDev b) {
 }
 
 // Final codes in queue order.  A pod behind the first rejected pod of its group meets the deny entry
-// at core.go:105-110 and never gets further.  pf_leader = sop.maxFinishedPG after the pod's PreFilter
-// returned: the value findMaxPG produced for it, or — if the call returned before core.go:120 — what
-// the latest earlier pod left there (carried in from before the batch when there is none).
-__global__ __launch_bounds__(kScanBlock) void k_final(PodsDev pods, NodesDev nd, BatchDev b, BatchParams prm) {
+// at core.go:105-110 and never gets further.  Also records, per 256-pod block, the last pod that
+// really reached findMaxPG (for the stale-leader propagation of k_final_b).
+__global__ __launch_bounds__(256) void k_final_a(PodsDev pods, NodesDev nd, BatchDev b) {
   __shared__ uint32_t lds[16];
-  __shared__ int s_carry;
-  if (threadIdx.x == 0) s_carry = -1;
-  __syncthreads();
-  for (uint32_t base = 0; base < pods.p; base += kScanBlock) {
-    const uint32_t i = base + threadIdx.x;
-    int key = -1;
-    uint8_t code = 0, st = 0;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  int key = -1;
+  if (i < pods.p) {
+    uint8_t code = b.tcode[i], st = b.stage[i];
     uint32_t fk = BS_K_NOT_SCANNED;
-    if (i < pods.p) {
-      code = b.tcode[i];
-      st = b.stage[i];
-      bool reach6 = st & ST_REACH6;
-      if (st & ST_OWNED) {
-        if ((st & ST_ELIG) && b.first_reject[pods.group[i]] < i) {
-          code = BS_PF_ERR_DENIED;
-          reach6 = false;
-        } else if (st & ST_QUERY) {
-          const uint32_t row = b.first_row[i];
-          fk = row == BS_INF ? BS_K_NONE : nd.kmap[row];
-        }
-      } else {
-        code = BS_PF_NOT_OWNED;
+    bool reach6 = st & ST_REACH6;
+    if (st & ST_OWNED) {
+      if ((st & ST_ELIG) && b.first_reject[pods.group[i]] < i) {
+        code = BS_PF_ERR_DENIED;
+        reach6 = false;
+      } else if (st & ST_QUERY) {
+        const uint32_t row = b.first_row[i];
+        fk = row == BS_INF ? BS_K_NONE : nd.kmap[row];
       }
-      if (reach6) key = (int)i;
+    } else {
+      code = BS_PF_NOT_OWNED;
     }
-    // inclusive prefix max of key (block), then across chunks
-    int v = key;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(v, o);
-      if (lane_id() >= o) v = max(v, u);
-    }
-    __syncthreads();
-    if (lane_id() == 63) lds[wave_id()] = (uint32_t)v;
-    __syncthreads();
-    int off = s_carry;
-    for (int w = 0; w < wave_id(); ++w) off = max(off, (int)lds[w]);
-    int blockmax = s_carry;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) blockmax = max(blockmax, (int)lds[w]);
-    const int jstar = max(v, off);
-    if (i < pods.p) {
-      b.pf_code[i] = code;
-      b.pf_first_k[i] = fk;
-      b.pf_leader[i] = jstar >= 0 ? b.leader_raw[jstar] : prm.sop_leader0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) s_carry = blockmax;
-    __syncthreads();
+    if (!reach6) st &= (uint8_t)~ST_REACH6;
+    b.stage[i] = st;
+    b.pf_code[i] = code;
+    b.pf_first_k[i] = fk;
+    if (reach6) key = (int)i;
   }
+  const uint32_t m = block_max_u32((uint32_t)(key + 1), lds);      // 0 = none
+  if (threadIdx.x == 0) b.blk_scratch[blockIdx.x] = m;
+}
+
+// Filter per-pod parameters (see the Filter section below); defined here because k_final_b fuses it.
+template <int TS>
+__device__ __forceinline__ void filter_params_for(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm,
+                                                  uint32_t i, uint8_t pf, int32_t leader) {
+  const Shape<TS> sh(prm.S);
+  const uint32_t gate = prm.eph_gate;
+  uint8_t fl = BS_FL_NOT_RUN;
+  uint32_t ff = 0;
+  int64_t R[4] = {0, 0, 0, 0}, M[4] = {0, 0, 0, 0};
+  if (pf != BS_PF_NOT_OWNED && BS_PF_IS_PASS(pf)) {
+    const int32_t gi = pods.group[i];
+    if (gi == BS_POD_NOT_GROUPED) fl = BS_FL_PASS_NOT_GROUPED;                 // core.go:171-174
+    else if (gi < 0 || (uint32_t)gi >= gr.g) fl = BS_FL_ERR_PG_NOT_FOUND;      // :177-180
+    else if (leader < 0) fl = BS_FL_PANIC_NIL_MAX;                             // :525
+    else {
+      Res mr, ms;
+      res_zero(ms, sh);
+      const bool have = group_minres_at(gr, pods, b, (uint32_t)leader, i, sh, gate, mr);
+      if (have) res_add(ms, mr, sh, gate);                                     // :526-527
+      if (leader == gi) fl = BS_FL_PASS_IS_MAX;                                // :531-535
+      else if (!have) fl = BS_FL_PASS_NO_MINRES;                               // :542-544
+      else {
+        fl = BS_FL_EVALUATED;
+        Res cur;
+        pod_require(pods, i, sh, gate, cur);                                   // :551
+        res_add(cur, ms, sh, gate);                                            // :552
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { R[j] = cur.v[j]; M[j] = ms.v[j]; }
+#pragma unroll
+        for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+          if (s < sh.S()) {
+            if ((cur.present & (1u << s)) && cur.v[4 + s] != 0) ff |= 1u;      // case 2 can never hold
+            if ((ms.present & (1u << s)) && ms.v[4 + s] != 0) ff |= 2u;        // node "cannot hold" a leader member
+          }
+        }
+      }
+    }
+  }
+  int64_t* dst = b.fparams + (size_t)i * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dst[j] = R[j]; dst[4 + j] = M[j]; }
+  b.fflags[i] = ff | ((uint32_t)fl << 8);
+  b.fl_code[i] = fl;
+}
+
+// pf_leader = sop.maxFinishedPG after the pod's PreFilter returned: the value findMaxPG produced for
+// it, or — if the call returned before core.go:120 — what the latest earlier pod left there (carried in
+// from before the batch when there is none).  Prefix-max over "last pod that reached findMaxPG":
+// block summaries from k_final_a + in-block scan.  Fused: the Filter parameters of the pod.
+template <int TS>
+__global__ __launch_bounds__(256) void k_final_b(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
+  __shared__ uint32_t lds[16];
+  uint32_t part = 0;
+  for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256u) part = max(part, b.blk_scratch[j]);
+  const uint32_t prev = block_max_u32(part, lds);                  // key+1 of earlier blocks, 0 none
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  uint32_t v = (i < pods.p && (b.stage[i] & ST_REACH6)) ? i + 1u : 0u;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+    if (lane_id() >= o) v = max(v, u);
+  }
+  __syncthreads();
+  if (lane_id() == 63) lds[wave_id()] = v;
+  __syncthreads();
+  uint32_t off = prev;
+  for (int w = 0; w < wave_id(); ++w) off = max(off, lds[w]);
+  const uint32_t jp1 = max(v, off);
+  if (i < pods.p) {
+    const int32_t leader = jp1 ? b.leader_raw[jp1 - 1u] : prm.sop_leader0;
+    b.pf_leader[i] = leader;
+    if (prm.run_filter) filter_params_for<TS>(pods, gr, b, prm, i, b.pf_code[i], leader);
+  }
+}
+
+// stand-alone Filter parameters (bs_filter_one): pf_code / pf_leader given
+__global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pods.p) return;
+  filter_params_for<-1>(pods, gr, b, prm, i, b.pf_code[i], b.pf_leader[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -709,102 +1041,198 @@ __global__ __launch_bounds__(kScanBlock) void k_final(PodsDev pods, NodesDev nd,
 // left has no scalar keys, so any non-zero scalar in a request fails compareResourceAndRequire
 // (core.go:688-691) for every node: that is one per-pod bit (scalar_block / leader_block).
 // ------------------------------------------------------------------------------------------------
-__global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= pods.p) return;
-  const uint32_t L = prm.L, S = prm.S, gate = prm.eph_gate;
-  uint8_t fl = BS_FL_NOT_RUN;
-  uint32_t ff = 0;
-  int64_t R[4] = {0, 0, 0, 0}, M[4] = {0, 0, 0, 0};
-  const uint8_t pf = b.pf_code[i];
-  if (pf != BS_PF_NOT_OWNED && BS_PF_IS_PASS(pf)) {
-    const int32_t gi = pods.group[i];
-    const int32_t leader = b.pf_leader[i];
-    if (gi == BS_POD_NOT_GROUPED) fl = BS_FL_PASS_NOT_GROUPED;                 // core.go:171-174
-    else if (gi < 0 || (uint32_t)gi >= gr.g) fl = BS_FL_ERR_PG_NOT_FOUND;      // :177-180
-    else if (leader < 0) fl = BS_FL_PANIC_NIL_MAX;                             // :525
-    else {
-      Res mr, ms;
-      res_zero(ms, L);
-      const bool have = group_minres_at(gr, pods, b, (uint32_t)leader, i, L, S, gate, mr);
-      if (have) res_add(ms, mr, S, gate);                                      // :526-527
-      if (leader == gi) fl = BS_FL_PASS_IS_MAX;                                // :531-535
-      else if (!have) fl = BS_FL_PASS_NO_MINRES;                               // :542-544
-      else {
-        fl = BS_FL_EVALUATED;
-        Res cur;
-        pod_require(pods, i, L, S, gate, cur);                                 // :551
-        res_add(cur, ms, S, gate);                                             // :552
-        for (int j = 0; j < 4; ++j) { R[j] = cur.v[j]; M[j] = ms.v[j]; }
-        for (uint32_t s = 0; s < S; ++s) {
-          if ((cur.present & (1u << s)) && cur.v[4 + s] != 0) ff |= 1u;        // case 2 can never hold
-          if ((ms.present & (1u << s)) && ms.v[4 + s] != 0) ff |= 2u;          // node "cannot hold" a leader member
-        }
-      }
-    }
-  }
-  int64_t* dst = b.fparams + (size_t)i * 8;
-  for (int j = 0; j < 4; ++j) { dst[j] = R[j]; dst[4 + j] = M[j]; }
-  b.fflags[i] = ff | ((uint32_t)fl << 8);
-  b.fl_code[i] = fl;
+// One wave = 64 consecutive pods x a range of 64-node blocks, NB blocks at a time.
+// Lanes are NODES while comparing: lane n holds left[n] (4 int64) in VGPRs, the pod's request R is
+// wave-uniform (one s_load), and an EXEC-chained
+//     s_mov_b64 exec, ok ; 4 x v_cmpx_le_i64 vcc, R[j], left[j]
+// leaves in EXEC the 64 node-feasibility bits of case 2 for that pod — the compare result IS the
+// bitmap word ("ballot").  OR-ing the pod-independent case-3 mask gives the word; v_writelane (lane
+// select in M0) drops it into lane pp, so that after 64 pods lane pp owns pod pp's word: lanes are
+// PODS for the outputs (coalesced 512-byte bitmap store, popcount -> feasible-node count).
+__device__ __forceinline__ void filter_cmp(uint32_t& wlo, uint32_t& whi, unsigned long long ok, const int64_t (&R)[4],
+                                           const int64_t (&l)[4], uint32_t nlf_lo, uint32_t nlf_hi) {
+  asm volatile("s_mov_b64 exec, %[ok]\n\t"
+               "v_cmpx_le_i64 vcc, %[R0], %[l0]\n\t"
+               "v_cmpx_le_i64 vcc, %[R1], %[l1]\n\t"
+               "v_cmpx_le_i64 vcc, %[R2], %[l2]\n\t"
+               "v_cmpx_le_i64 vcc, %[R3], %[l3]\n\t"
+               "s_or_b32 %[wlo], exec_lo, %[nlo]\n\t"
+               "s_or_b32 %[whi], exec_hi, %[nhi]\n\t"
+               "s_mov_b64 exec, -1"
+               : [wlo] "=&s"(wlo), [whi] "=&s"(whi)
+               : [ok] "s"(ok), [R0] "s"(R[0]), [l0] "v"(l[0]), [R1] "s"(R[1]), [l1] "v"(l[1]), [R2] "s"(R[2]), [l2] "v"(l[2]),
+                 [R3] "s"(R[3]), [l3] "v"(l[3]), [nlo] "s"(nlf_lo), [nhi] "s"(nlf_hi)
+               : "vcc", "scc");
+}
+// v_writelane_b32 with the lane select in M0 (gfx9 allows one SGPR source besides M0)
+__device__ __forceinline__ void put_word(uint32_t& vlo, uint32_t& vhi, uint32_t wlo, uint32_t whi, uint32_t lane_sel) {
+  asm volatile("s_mov_b32 m0, %[sel]\n\t"
+               "s_nop 0\n\t"
+               "v_writelane_b32 %[vlo], %[wlo], m0\n\t"
+               "v_writelane_b32 %[vhi], %[whi], m0"
+               : [vlo] "+v"(vlo), [vhi] "+v"(vhi)
+               : [wlo] "s"(wlo), [whi] "s"(whi), [sel] "s"(lane_sel));
 }
 
-// One wave = 64 consecutive pods x a range of 64-node blocks.  Lanes are NODES while comparing (a
-// v_cmp_ge_i64 against the pod's wave-uniform request yields the 64 node-feasibility bits of that pod
-// directly as an SGPR pair — the "ballot is the bitmap word"), and lanes are PODS for the outputs
-// (v_writelane collects pod pp's word into lane pp; popcount accumulates its feasible-node count).
+template <int NB>
 __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, BatchDev b, uint32_t blocks_per_wave,
                                                 uint32_t want_bitmap) {
+  typedef const __attribute__((address_space(4))) uint32_t* cflag_t;
   const int lane = lane_id();
   const uint32_t ptile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id());
   const uint32_t p0 = ptile * 64u;
   if (p0 >= pods.p) return;
   const uint32_t W = (nd.n + 63u) / 64u;
   const uint32_t w0 = blockIdx.y * blocks_per_wave;
+  if (w0 >= W) return;
   const uint32_t w1 = min(W, w0 + blocks_per_wave);
   const uint32_t np = min(64u, pods.p - p0);
+
+  // Is the leader's single-member request M the same for every evaluated pod of the tile?  (It is,
+  // unless the tile straddles a first-pod capture.)  Then case 3 is one mask per node block.
+  const bool mine = (uint32_t)lane < np;
+  const uint32_t myff = mine ? b.fflags[p0 + lane] : 0u;
+  const bool ev = (myff >> 8) == BS_FL_EVALUATED;
+  int64_t M[4] = {0, 0, 0, 0};
+  if (ev) {
+    const int64_t* src = b.fparams + (size_t)(p0 + lane) * 8 + 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) M[j] = src[j];
+  }
+  const unsigned long long evmask = __ballot(ev);
+  bool uniformM = true;
+  int64_t M0[4] = {0, 0, 0, 0};
+  uint32_t lb0 = 0;
+  if (evmask) {
+    const int first = __ffsll((long long)evmask) - 1;
+    bool same = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      M0[j] = __shfl(M[j], first);
+      same = same && (M[j] == M0[j]);
+    }
+    lb0 = (uint32_t)__shfl((int)(myff & 2u), first);
+    same = same && ((myff & 2u) == lb0);
+    uniformM = __ballot(ev && !same) == 0;
+  }
+
+  crow_t FP = as_const_rows(b.fparams);
+  cflag_t FF = (cflag_t)(uintptr_t)b.fflags;
   uint32_t cnt = 0;
-  for (uint32_t w = w0; w < w1; ++w) {
-    const uint32_t n = w * 64u + (uint32_t)lane;
-    const bool nvalid = n < nd.n;
-    int64_t l0 = INT64_MIN, l1 = INT64_MIN, l2 = INT64_MIN, l3 = INT64_MIN;
-    bool node_ok = false;
-    if (nvalid) {
-      l0 = nd.left4[n];
-      l1 = nd.left4[(size_t)nd.stride + n];
-      l2 = nd.left4[(size_t)2 * nd.stride + n];
-      l3 = nd.left4[(size_t)3 * nd.stride + n];
-      node_ok = !(nd.flags[n] & (BS_NODE_NIL | BS_NODE_NO_NODE));              // core.go:442-449
-    }
-    const unsigned long long in_range = __ballot(nvalid);
-    const unsigned long long okmask = __ballot(node_ok);
-    uint32_t word_lo = 0, word_hi = 0;
-    for (uint32_t pp = 0; pp < np; ++pp) {
-      const uint32_t p = p0 + pp;                                              // wave-uniform
-      const uint32_t ff = b.fflags[p];
-      const uint32_t fl = ff >> 8;
-      unsigned long long word;
-      if (fl == BS_FL_EVALUATED) {
-        const int64_t* __restrict__ prm = b.fparams + (size_t)p * 8;
-        unsigned long long c2 = 0, lf = 0;
-        if (!(ff & 1u)) c2 = __ballot(l0 >= prm[0]) & __ballot(l1 >= prm[1]) & __ballot(l2 >= prm[2]) & __ballot(l3 >= prm[3]);
-        if (!(ff & 2u)) lf = __ballot(l0 >= prm[4]) & __ballot(l1 >= prm[5]) & __ballot(l2 >= prm[6]) & __ballot(l3 >= prm[7]);
-        word = okmask & (c2 | ~lf);
-      } else if (fl < 16u) {
-        word = in_range;              // returned nil before looking at the node
-      } else {
-        word = 0;
+  for (uint32_t w = w0; w < w1; w += NB) {
+    int64_t l[NB][4];
+    unsigned long long okmask[NB], in_range[NB];
+    uint32_t nlf_lo[NB], nlf_hi[NB], vlo[NB], vhi[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const uint32_t n = (w + nb) * 64u + (uint32_t)lane;
+      const bool nvalid = (w + nb) < w1 && n < nd.n;
+      bool node_ok = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) l[nb][j] = INT64_MIN;
+      if (nvalid) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l[nb][j] = nd.left4[(size_t)j * nd.stride + n];
+        node_ok = !(nd.flags[n] & (BS_NODE_NIL | BS_NODE_NO_NODE));              // core.go:442-449
       }
-      word_lo = writelane_u32((uint32_t)word, pp, word_lo);
-      word_hi = writelane_u32((uint32_t)(word >> 32), pp, word_hi);
+      in_range[nb] = __ballot(nvalid);
+      okmask[nb] = __ballot(node_ok);
+      // case 3 for the tile's common leader: nodes that cannot hold one leader member
+      unsigned long long lf = 0;
+      if (!lb0) lf = __ballot(l[nb][0] >= M0[0]) & __ballot(l[nb][1] >= M0[1]) & __ballot(l[nb][2] >= M0[2]) & __ballot(l[nb][3] >= M0[3]);
+      const unsigned long long nlf = okmask[nb] & ~lf;
+      nlf_lo[nb] = __builtin_amdgcn_readfirstlane((uint32_t)nlf);
+      nlf_hi[nb] = __builtin_amdgcn_readfirstlane((uint32_t)(nlf >> 32));
+      vlo[nb] = 0;
+      vhi[nb] = 0;
     }
-    if ((uint32_t)lane < np) {
-      const unsigned long long mine = ((unsigned long long)word_hi << 32) | word_lo;
-      cnt += (uint32_t)__popcll(mine);
-      if (want_bitmap) b.fl_bitmap[(size_t)w * pods.p + p0 + lane] = mine;
+    if (uniformM) {
+      // software-pipelined over pods: the next pod's request is in flight while this one is compared
+      int64_t RA[4], RB[4];
+      uint32_t fa, fb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) RA[j] = FP[(size_t)p0 * 8 + j];
+      fa = FF[p0];
+      BS_S_WAIT_LGKM0();
+      for (uint32_t pp = 0; pp < np; pp += 2) {
+        const uint32_t pn = p0 + min(pp + 1, np - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) RB[j] = FP[(size_t)pn * 8 + j];
+        fb = FF[pn];
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const uint32_t fl = fa >> 8;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            uint32_t wlo, whi;
+            if (fl == BS_FL_EVALUATED) {
+              filter_cmp(wlo, whi, (fa & 1u) ? 0ull : okmask[nb], RA, l[nb], nlf_lo[nb], nlf_hi[nb]);
+            } else {
+              const unsigned long long word = fl < 16u ? in_range[nb] : 0ull;   // nil before any node lookup / error
+              wlo = (uint32_t)word;
+              whi = (uint32_t)(word >> 32);
+            }
+            put_word(vlo[nb], vhi[nb], wlo, whi, pp);
+          }
+        }
+        BS_S_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t pn2 = p0 + min(pp + 2, np - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) RA[j] = FP[(size_t)pn2 * 8 + j];
+        fa = FF[pn2];
+        __builtin_amdgcn_sched_barrier(0);
+        if (pp + 1 < np) {
+          const uint32_t fl = fb >> 8;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            uint32_t wlo, whi;
+            if (fl == BS_FL_EVALUATED) {
+              filter_cmp(wlo, whi, (fb & 1u) ? 0ull : okmask[nb], RB, l[nb], nlf_lo[nb], nlf_hi[nb]);
+            } else {
+              const unsigned long long word = fl < 16u ? in_range[nb] : 0ull;
+              wlo = (uint32_t)word;
+              whi = (uint32_t)(word >> 32);
+            }
+            put_word(vlo[nb], vhi[nb], wlo, whi, pp + 1);
+          }
+        }
+        BS_S_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // generic path: per-pod leader request (tile straddles a capture); plain ballots
+      for (uint32_t pp = 0; pp < np; ++pp) {
+        const uint32_t p = p0 + pp;
+        const uint32_t ff = FF[p];
+        const uint32_t fl = ff >> 8;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          unsigned long long word;
+          if (fl == BS_FL_EVALUATED) {
+            unsigned long long c2 = 0, lf = 0;
+            if (!(ff & 1u)) c2 = __ballot(l[nb][0] >= FP[(size_t)p * 8 + 0]) & __ballot(l[nb][1] >= FP[(size_t)p * 8 + 1]) &
+                                 __ballot(l[nb][2] >= FP[(size_t)p * 8 + 2]) & __ballot(l[nb][3] >= FP[(size_t)p * 8 + 3]);
+            if (!(ff & 2u)) lf = __ballot(l[nb][0] >= FP[(size_t)p * 8 + 4]) & __ballot(l[nb][1] >= FP[(size_t)p * 8 + 5]) &
+                                 __ballot(l[nb][2] >= FP[(size_t)p * 8 + 6]) & __ballot(l[nb][3] >= FP[(size_t)p * 8 + 7]);
+            word = okmask[nb] & (c2 | ~lf);
+          } else {
+            word = fl < 16u ? in_range[nb] : 0ull;
+          }
+          put_word(vlo[nb], vhi[nb], (uint32_t)word, (uint32_t)(word >> 32), pp);
+        }
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if ((w + nb) < w1 && mine) {
+        const unsigned long long word = ((unsigned long long)vhi[nb] << 32) | vlo[nb];
+        cnt += (uint32_t)__popcll(word);
+        if (want_bitmap) b.fl_bitmap[(size_t)(w + nb) * pods.p + p0 + lane] = word;
+      }
     }
   }
-  if ((uint32_t)lane < np && cnt) atomicAdd(&b.fl_feasible[p0 + lane], cnt);
+  if (mine && cnt) atomicAdd(&b.fl_feasible[p0 + lane], cnt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -867,7 +1295,7 @@ __global__ void k_commit(PodsDev pods, BatchDev b, BatchParams prm, uint8_t* gfl
     if (!(fl & BS_GROUP_HAS_POD)) { fl |= BS_GROUP_HAS_POD; gcls[g] = pods.cls[fe]; }
     if (!(fl & BS_GROUP_HAS_MINRES)) {
       Res r;
-      pod_require(pods, fe, prm.L, prm.S, prm.eph_gate, r);
+      pod_require(pods, fe, Shape<-1>(prm.S), prm.eph_gate, r);
       for (uint32_t j = 0; j < prm.L; ++j) gminres[(size_t)j * G + g] = r.v[j];
       gmrpres[g] = r.present;
       fl |= BS_GROUP_HAS_MINRES;

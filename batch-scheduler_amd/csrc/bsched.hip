@@ -68,7 +68,7 @@ struct bs_ctx {
   DevBuf d_epoch, d_nepochs, d_leader_epoch, d_panic_epoch;
   DevBuf d_tcode, d_stage, d_leader_raw, d_qtable, d_qreq, d_qflags, d_first_row;
   DevBuf d_tbl_count, d_tbl_off, d_tbl_cursor, d_tbl_slot, d_desc, d_ntables, d_tiles, d_ntiles, d_qlist;
-  DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags;
+  DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch;
   DevBuf d_pf_code, d_pf_first_k, d_pf_leader, d_fl_code, d_fl_feasible, d_fl_bitmap, d_admit, d_ready;
   // single-query scratch
   DevBuf d_sq;
@@ -79,7 +79,7 @@ struct bs_ctx {
   int32_t sop_leader0 = -1;
   uint32_t last_stages = 0;
   bool batch_pending_finish = false;
-  uint32_t seg_len_override = 0, collect_stats = 0;
+  uint32_t seg_len_override = 0, scan_q_override = 0, target_waves = 8192, collect_stats = 0;
   bs_batch_stats stats{};
 
   // ---- timing
@@ -226,6 +226,8 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.tables = c->d_tables.as<int64_t>();
   b.kp = c->d_kp.as<uint32_t>();
   b.stats = c->d_stats.as<uint64_t>();
+  b.chunk_tot = c->d_chunk_tot.as<unsigned long long>();
+  b.blk_scratch = c->d_blk_scratch.as<uint32_t>();
   b.fparams = c->d_fparams.as<int64_t>();
   b.fflags = c->d_fflags.as<uint32_t>();
   b.pf_code = c->d_pf_code.as<uint8_t>();
@@ -248,6 +250,7 @@ BatchParams batch_params(const bs_ctx* c) {
   p.collect_stats = c->collect_stats;
   p.mcap = c->table_mcap;
   p.seg_len = 0;
+  p.tile_queries = 64;
   return p;
 }
 
@@ -259,6 +262,7 @@ int ensure_tables(bs_ctx* c) {
   if (bytes > ((size_t)64 << 30)) { c->last_error = "table storage exceeds 64 GiB"; return BS_ERR_CAPACITY; }
   HIPCHK(c, c->d_tables.reserve(bytes));
   HIPCHK(c, c->d_kp.reserve((size_t)slots * 16 * sizeof(uint32_t)));
+  HIPCHK(c, c->d_chunk_tot.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
   HIPCHK(c, c->d_desc.reserve((size_t)slots * sizeof(TableDesc)));
   HIPCHK(c, c->d_tbl_count.reserve((size_t)(2 * c->C + 1) * 4));
   HIPCHK(c, c->d_tbl_off.reserve((size_t)(2 * c->C + 2) * 4));
@@ -320,31 +324,32 @@ int upload_fit(bs_ctx* c) {
 }
 
 template <int S>
-void launch_scan_s(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S>), grid, dim3(256), 0, c->stream, b, p, m);
+void launch_scan_s(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, int q) {
+  if (q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S, 2>), grid, dim3(256), 0, c->stream, b, p, m);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S, 1>), grid, dim3(256), 0, c->stream, b, p, m);
 }
-void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m) {
+void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, int q) {
   switch (c->S) {
-    case 0: launch_scan_s<0>(c, grid, b, p, m); break;
-    case 1: launch_scan_s<1>(c, grid, b, p, m); break;
-    case 2: launch_scan_s<2>(c, grid, b, p, m); break;
-    case 3: launch_scan_s<3>(c, grid, b, p, m); break;
-    case 4: launch_scan_s<4>(c, grid, b, p, m); break;
-    case 5: launch_scan_s<5>(c, grid, b, p, m); break;
-    case 6: launch_scan_s<6>(c, grid, b, p, m); break;
-    case 7: launch_scan_s<7>(c, grid, b, p, m); break;
-    case 8: launch_scan_s<8>(c, grid, b, p, m); break;
-    case 9: launch_scan_s<9>(c, grid, b, p, m); break;
-    case 10: launch_scan_s<10>(c, grid, b, p, m); break;
-    case 11: launch_scan_s<11>(c, grid, b, p, m); break;
-    default: launch_scan_s<12>(c, grid, b, p, m); break;
+    case 0: launch_scan_s<0>(c, grid, b, p, m, q); break;
+    case 1: launch_scan_s<1>(c, grid, b, p, m, q); break;
+    case 2: launch_scan_s<2>(c, grid, b, p, m, q); break;
+    case 3: launch_scan_s<3>(c, grid, b, p, m, q); break;
+    case 4: launch_scan_s<4>(c, grid, b, p, m, q); break;
+    case 5: launch_scan_s<5>(c, grid, b, p, m, q); break;
+    case 6: launch_scan_s<6>(c, grid, b, p, m, q); break;
+    case 7: launch_scan_s<7>(c, grid, b, p, m, q); break;
+    case 8: launch_scan_s<8>(c, grid, b, p, m, q); break;
+    case 9: launch_scan_s<9>(c, grid, b, p, m, q); break;
+    case 10: launch_scan_s<10>(c, grid, b, p, m, q); break;
+    case 11: launch_scan_s<11>(c, grid, b, p, m, q); break;
+    default: launch_scan_s<12>(c, grid, b, p, m, q); break;
   }
 }
 
 uint32_t pick_seg_len(const bs_ctx* c, uint32_t tiles, uint32_t m) {
   if (c->seg_len_override) return c->seg_len_override;
   if (m == 0) return 64;
-  const uint32_t target_waves = 4096;                         // ~4 waves per SIMD on 256 CUs
+  const uint32_t target_waves = c->target_waves;              // waves in flight wanted (1024 SIMDs x 8)
   uint32_t nseg = std::max<uint32_t>(1, target_waves / std::max<uint32_t>(1, tiles));
   nseg = std::min<uint32_t>(nseg, cdiv(m, 64));
   uint32_t seg = cdiv(m, nseg);
@@ -360,18 +365,17 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
   BatchDev b = batch_dev(c);
   BatchParams p = batch_params(c);
   TableDesc d{cls, pct};
-  // scratch layout in d_sq: [0] ntables(u32)=slot+1 ... we run k_tables with a descriptor copy per slot
   HIPCHK(c, hipMemcpyAsync(b.desc + slot, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
-  uint32_t nt = slot + 1;
-  uint32_t* d_nt = c->d_sq.as<uint32_t>();
-  HIPCHK(c, hipMemcpyAsync(d_nt, &nt, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(b.kp + (size_t)slot * 16, 0xFF, 16 * sizeof(uint32_t), c->stream));
+  const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
+  // one slot: shift the table / kp / desc / chunk-total bases so that blockIdx.x 0 == slot
   BatchDev b2 = b;
-  b2.ntables = d_nt;
-  // launch only the one block: shift the table / kp / desc bases so that blockIdx 0 == slot
   b2.tables = b.tables + (size_t)slot * p.mcap * p.LP;
   b2.kp = b.kp + (size_t)slot * 16;
   b2.desc = b.desc + slot;
-  hipLaunchKernelGGL(k_tables, dim3(1), dim3(kScanBlock), 0, c->stream, nodes_dev(c), b2, p);
+  b2.chunk_tot = b.chunk_tot + (size_t)slot * cdiv(c->Ncap, 256) * 16;
+  hipLaunchKernelGGL(k_tables_local, dim3(1, nchunks), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, 1u);
+  if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(1, nchunks - 1), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, 1u);
   HIPCHK(c, hipGetLastError());
   *slot_out = slot;
   return BS_OK;
@@ -421,6 +425,8 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     return BS_ERR_NO_DEVICE;
   }
   if (const char* e = std::getenv("BS_SEG_LEN")) c->seg_len_override = (uint32_t)std::atoi(e);
+  if (const char* e = std::getenv("BS_SCAN_Q")) { int q = std::atoi(e); c->scan_q_override = (q == 1 || q == 2) ? (uint32_t)q : 0; }
+  if (const char* e = std::getenv("BS_TARGET_WAVES")) c->target_waves = std::max(1, std::atoi(e));
   *out = c;
   return BS_OK;
 }
@@ -562,6 +568,7 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, c->d_qlist.reserve(n * 4));
   HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
   HIPCHK(c, c->d_fflags.reserve(n * 4));
+  HIPCHK(c, c->d_blk_scratch.reserve((n / 256 + 2) * 4));
   HIPCHK(c, c->d_pf_code.reserve(n));
   HIPCHK(c, c->d_pf_first_k.reserve(n * 4));
   HIPCHK(c, c->d_pf_leader.reserve(n * 4));
@@ -623,7 +630,8 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const uint32_t W = cdiv(N, 64);
   const bool run_filter = stages & BS_STAGE_FILTER;
   if (run_filter) HIPCHK(c, c->d_fl_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
-  const uint32_t max_tiles = cdiv(P, 64) + 2 * C;
+  const int scan_q = (c->scan_q_override ? (int)c->scan_q_override : (P >= 4096 ? 2 : 1));
+  const uint32_t max_tiles = cdiv(P, 64 * scan_q) + 2 * C;
   HIPCHK(c, c->d_tiles.reserve((size_t)(max_tiles + 1) * sizeof(Tile)));
 
   NodesDev nd = nodes_dev(c);
@@ -632,44 +640,75 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   BatchDev b = batch_dev(c);
   BatchParams prm = batch_params(c);
   prm.run_filter = run_filter;
-  prm.seg_len = pick_seg_len(c, cdiv(std::max<uint32_t>(P, 1), 64), c->M);
+  prm.tile_queries = 64u * (uint32_t)scan_q;
+  prm.seg_len = pick_seg_len(c, cdiv(std::max<uint32_t>(P, 1), prm.tile_queries), c->M);
 
   const uint32_t init_n = std::max(std::max(G, 2 * C), std::max(P, 8u));
   const dim3 blk(256);
+  const bool captures_possible = c->n_uncaptured > 0 && P > 0;
+  const int ts = c->S <= 4 ? (int)c->S : -1;
   TIMED(c, BS_KERNEL_PREPASS, {
-    hipLaunchKernelGGL(k_init, dim3(cdiv(init_n, 256)), blk, 0, c->stream, gr, b, prm, P);
-    if (run_filter && P) (void)hipMemsetAsync(b.fl_feasible, 0, (size_t)P * 4, c->stream);
+    hipLaunchKernelGGL(k_init, dim3(cdiv(init_n, 256)), blk, 0, c->stream, gr, b, prm, P, captures_possible ? 0u : 1u);
     if (P) hipLaunchKernelGGL(k_prepass, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, gr, b);
-    hipLaunchKernelGGL(k_epochs, dim3(1), dim3(kScanBlock), 0, c->stream, pd, gr, b);
+    if (captures_possible) {
+      hipLaunchKernelGGL(k_epochs_a, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
+      hipLaunchKernelGGL(k_epochs_b, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
+    }
   });
   const uint32_t max_epochs = std::min(c->n_uncaptured, P) + 1;
-  TIMED(c, BS_KERNEL_LEADER, hipLaunchKernelGGL(k_leader, dim3(max_epochs), blk, 0, c->stream, gr, b));
+  TIMED(c, BS_KERNEL_LEADER, hipLaunchKernelGGL(k_leader, dim3(max_epochs), dim3(kLeaderBlock), 0, c->stream, gr, b));
   TIMED(c, BS_KERNEL_QUERY, {
-    if (P) hipLaunchKernelGGL(k_query, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, gr, b, prm);
+    if (P) {
+      const dim3 qg(cdiv(P, 256));
+      switch (ts) {
+        case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<0>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<1>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<2>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
+        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<3>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
+        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<4>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<-1>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
+      }
+    }
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(kScanBlock), 0, c->stream, b, prm);
     if (P) hipLaunchKernelGGL(k_scatter, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b);
   });
-  TIMED(c, BS_KERNEL_TABLES, hipLaunchKernelGGL(k_tables, dim3(2 * C), dim3(kScanBlock), 0, c->stream, nd, b, prm));
+  {
+    const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
+    // chunk totals are indexed [slot][nchunks_cap]: pass the capacity as gridDim.y only when it equals nchunks
+    TIMED(c, BS_KERNEL_TABLES, {
+      hipLaunchKernelGGL(k_tables_local, dim3(2 * C, nchunks), dim3(kTblChunk), 0, c->stream, nd, b, prm, 0u);
+      if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, 0u);
+    });
+  }
   if (c->M && P) {
     const dim3 grid(cdiv(max_tiles, 4), cdiv(c->M, prm.seg_len));
-    TIMED(c, BS_KERNEL_SCAN, launch_scan(c, grid, b, prm, c->M));
+    TIMED(c, BS_KERNEL_SCAN, launch_scan(c, grid, b, prm, c->M, scan_q));
   }
   TIMED(c, BS_KERNEL_RESOLVE, {
-    if (P) hipLaunchKernelGGL(k_reject, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b);
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(kScanBlock), 0, c->stream, pd, nd, b, prm);
+    if (P) {
+      hipLaunchKernelGGL(k_reject, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b);
+      hipLaunchKernelGGL(k_final_a, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, nd, b);
+      const dim3 fg(cdiv(P, 256));
+      switch (ts) {
+        case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<0>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<1>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<2>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
+        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<3>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
+        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<4>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<-1>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
+      }
+    }
   });
   if (run_filter && P) {
     const uint32_t ptiles = cdiv(P, 64);
-    uint32_t nsplit = std::max<uint32_t>(1, 4096 / ptiles);
-    nsplit = std::min<uint32_t>(nsplit, std::max<uint32_t>(W, 1));
-    const uint32_t bpw = std::max<uint32_t>(1, cdiv(std::max<uint32_t>(W, 1), nsplit));
+    uint32_t nsplit = std::max<uint32_t>(1, c->target_waves / ptiles);
+    nsplit = std::min<uint32_t>(nsplit, std::max<uint32_t>(cdiv(W, 2), 1));
+    const uint32_t bpw = std::max<uint32_t>(2, cdiv(cdiv(std::max<uint32_t>(W, 1), nsplit), 2) * 2);   // multiple of NB
     TIMED(c, BS_KERNEL_FILTER, {
-      hipLaunchKernelGGL(k_filter_params, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, gr, b, prm);
-      if (W) hipLaunchKernelGGL(k_filter, dim3(cdiv(ptiles, 4), cdiv(W, bpw)), blk, 0, c->stream, pd, nd, b, bpw, 1u);
+      if (W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(ptiles, 4), cdiv(W, bpw)), blk, 0, c->stream, pd, nd, b, bpw, 1u);
     });
   } else if (P) {
     HIPCHK(c, hipMemsetAsync(b.fl_code, BS_FL_NOT_RUN, P, c->stream));
-    HIPCHK(c, hipMemsetAsync(b.fl_feasible, 0, (size_t)P * 4, c->stream));
   }
   if (stages & BS_BATCH_COMMIT) {
     if (G) hipLaunchKernelGGL(k_commit, dim3(cdiv(G, 256)), blk, 0, c->stream, pd, b, prm, c->d_gflags.as<uint8_t>(), c->d_gcls.as<uint32_t>(),
@@ -864,7 +903,7 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
   prm.collect_stats = 0;
   prm.seg_len = pick_seg_len(c, 1, M);
   if (M) {
-    launch_scan(c, dim3(1, cdiv(M, prm.seg_len)), b, prm, M);
+    launch_scan(c, dim3(1, cdiv(M, prm.seg_len)), b, prm, M, 1);
     HIPCHK(c, hipGetLastError());
   }
   uint32_t row = BS_INF;
@@ -887,9 +926,9 @@ int bs_find_max_pg(bs_ctx* c, int32_t* leader, uint32_t* finished, uint8_t* pani
   prm.C = 0;
   prm.collect_stats = 0;
   const uint32_t one = 1;
-  hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(c->G, 8), 256)), dim3(256), 0, c->stream, gr, b, prm, 0u);
+  hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(c->G, 8), 256)), dim3(256), 0, c->stream, gr, b, prm, 0u, 1u);
   HIPCHK(c, hipMemcpyAsync(b.nepochs, &one, 4, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_leader, dim3(1), dim3(256), 0, c->stream, gr, b);
+  hipLaunchKernelGGL(k_leader, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b);
   HIPCHK(c, hipGetLastError());
   int32_t l = -1;
   uint8_t pn = 0;
@@ -954,7 +993,7 @@ int bs_filter_one(bs_ctx* c, int32_t pod_group, const int64_t* pod_req, uint32_t
   NodesDev nd = nodes_dev(c);
   hipLaunchKernelGGL(k_filter_params, dim3(1), dim3(256), 0, c->stream, pd, gr, b, prm);
   const uint32_t W = cdiv(N, 64);
-  if (W) hipLaunchKernelGGL(k_filter, dim3(1, 1), dim3(256), 0, c->stream, pd, nd, b, W, 1u);
+  if (W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(1, 1), dim3(256), 0, c->stream, pd, nd, b, W, 1u);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(k_filter_one, dim3(1), dim3(64), 0, c->stream, nd, b, node, base + 768 + 16);
   HIPCHK(c, hipGetLastError());

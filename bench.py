@@ -94,7 +94,7 @@ def main():
     stages = soa.STAGE_ALL if args.stages == "all" else (soa.STAGE_PREFILTER | soa.STAGE_TALLY)
     L = nodes.lanes
 
-    ctx = bsa.Context(scalar_lanes=L - 4, device=local_rank, enable_timing=1)
+    ctx = bsa.Context(scalar_lanes=L - 4, device=local_rank, enable_timing=int(os.environ.get("BS_TIMING", "1")))
     ctx.load_nodes(nodes, fit)
     ctx.load_groups(groups)
     ctx.load_pods(pods)
@@ -190,7 +190,7 @@ def main():
             "gang_admit_latency_ms_p50": float(np.percentile(lat, 50)) if lat else None,
             "gang_admit_latency_note": "host-observed: pods H2D + one batch + decision D2H; every group of the batch is decided by that call",
             "roofline": roofline,
-            "kernel_ms_per_step": {"scan": scan_ms / max(1, scan_launches), "filter": filt_ms / max(1, filt_launches)},
+            "kernel_ms_per_step": {k: v[0] / v[1] for k, v in timing.items() if v[1]},
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
