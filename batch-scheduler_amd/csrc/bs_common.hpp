@@ -10,7 +10,6 @@
 #include "../../include/bsched.h"
 
 #define BS_INF 0xFFFFFFFFu
-#define BS_PF_NOT_OWNED 0xFFu
 
 namespace bs {
 

@@ -916,39 +916,7 @@ __global__ void k_reject(PodsDev pods, BatchDev b) {
   }
 }
 
-// Final codes in queue order.  A pod behind the first rejected pod of its group meets the deny entry
-// at core.go:105-110 and never gets further.  Also records, per 256-pod block, the last pod that
-// really reached findMaxPG (for the stale-leader propagation of k_final_b).
-__global__ __launch_bounds__(256) void k_final_a(PodsDev pods, NodesDev nd, BatchDev b) {
-  __shared__ uint32_t lds[16];
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  int key = -1;
-  if (i < pods.p) {
-    uint8_t code = b.tcode[i], st = b.stage[i];
-    uint32_t fk = BS_K_NOT_SCANNED;
-    bool reach6 = st & ST_REACH6;
-    if (st & ST_OWNED) {
-      if ((st & ST_ELIG) && b.first_reject[pods.group[i]] < i) {
-        code = BS_PF_ERR_DENIED;
-        reach6 = false;
-      } else if (st & ST_QUERY) {
-        const uint32_t row = b.first_row[i];
-        fk = row == BS_INF ? BS_K_NONE : nd.kmap[row];
-      }
-    } else {
-      code = BS_PF_NOT_OWNED;
-    }
-    if (!reach6) st &= (uint8_t)~ST_REACH6;
-    b.stage[i] = st;
-    b.pf_code[i] = code;
-    b.pf_first_k[i] = fk;
-    if (reach6) key = (int)i;
-  }
-  const uint32_t m = block_max_u32((uint32_t)(key + 1), lds);      // 0 = none
-  if (threadIdx.x == 0) b.blk_scratch[blockIdx.x] = m;
-}
-
-// Filter per-pod parameters (see the Filter section below); defined here because k_final_b fuses it.
+// Filter per-pod parameters (see the Filter section below); defined here because k_final fuses it.
 template <int TS>
 __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm,
                                                   uint32_t i, uint8_t pf, int32_t leader) {
@@ -993,18 +961,57 @@ __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const Gro
   b.fl_code[i] = fl;
 }
 
+// Did pod j really reach findMaxPG (core.go:118-123)?  Tentatively yes (k_query) and not behind the
+// first rejected pod of its group (deny entry, core.go:105-110).  Non-owned pods: tentative value.
+__device__ __forceinline__ bool reached_find_max(const PodsDev& pods, const BatchDev& b, uint32_t j) {
+  const uint8_t st = b.stage[j];
+  if (!(st & ST_REACH6)) return false;
+  if ((st & ST_OWNED) && (st & ST_ELIG) && b.first_reject[pods.group[j]] < j) return false;
+  return true;
+}
+
+// Final codes in queue order.  A pod behind the first rejected pod of its group meets the deny entry
+// at core.go:105-110 and never gets further.
 // pf_leader = sop.maxFinishedPG after the pod's PreFilter returned: the value findMaxPG produced for
 // it, or — if the call returned before core.go:120 — what the latest earlier pod left there (carried in
-// from before the batch when there is none).  Prefix-max over "last pod that reached findMaxPG":
-// block summaries from k_final_a + in-block scan.  Fused: the Filter parameters of the pod.
+// from before the batch when there is none): a prefix "last pod that reached findMaxPG".  Inside the
+// block it is a wave/block scan; for the pods before the block it is a backward search that almost
+// always ends at the block's immediate predecessor.  Fused: the Filter parameters of the pod.
 template <int TS>
-__global__ __launch_bounds__(256) void k_final_b(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
+__global__ __launch_bounds__(256) void k_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm) {
   __shared__ uint32_t lds[16];
-  uint32_t part = 0;
-  for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256u) part = max(part, b.blk_scratch[j]);
-  const uint32_t prev = block_max_u32(part, lds);                  // key+1 of earlier blocks, 0 none
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  uint32_t v = (i < pods.p && (b.stage[i] & ST_REACH6)) ? i + 1u : 0u;
+  const uint32_t base = blockIdx.x * 256u;
+  // last pod before this block that reached findMaxPG (as index + 1, 0 = none)
+  uint32_t prev = 0;
+  for (uint32_t hi = base; hi > 0 && prev == 0;) {
+    const uint32_t lo = hi >= 256u ? hi - 256u : 0u;
+    const uint32_t j = lo + threadIdx.x;
+    uint32_t cand = 0;
+    if (j < hi && reached_find_max(pods, b, j)) cand = j + 1u;
+    prev = block_max_u32(cand, lds);
+    hi = lo;
+  }
+  const uint32_t i = base + threadIdx.x;
+  uint32_t v = 0;
+  uint8_t code = 0;
+  if (i < pods.p) {
+    code = b.tcode[i];
+    const uint8_t st = b.stage[i];
+    uint32_t fk = BS_K_NOT_SCANNED;
+    if (st & ST_OWNED) {
+      if ((st & ST_ELIG) && b.first_reject[pods.group[i]] < i) {
+        code = BS_PF_ERR_DENIED;
+      } else if (st & ST_QUERY) {
+        const uint32_t row = b.first_row[i];
+        fk = row == BS_INF ? BS_K_NONE : nd.kmap[row];
+      }
+    } else {
+      code = BS_PF_NOT_OWNED;
+    }
+    b.pf_code[i] = code;
+    b.pf_first_k[i] = fk;
+    if (reached_find_max(pods, b, i)) v = i + 1u;
+  }
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const uint32_t u = (uint32_t)__shfl_up((int)v, o);
@@ -1019,7 +1026,7 @@ __global__ __launch_bounds__(256) void k_final_b(PodsDev pods, GroupsDev gr, Bat
   if (i < pods.p) {
     const int32_t leader = jp1 ? b.leader_raw[jp1 - 1u] : prm.sop_leader0;
     b.pf_leader[i] = leader;
-    if (prm.run_filter) filter_params_for<TS>(pods, gr, b, prm, i, b.pf_code[i], leader);
+    if (prm.run_filter) filter_params_for<TS>(pods, gr, b, prm, i, code, leader);
   }
 }
 
@@ -1041,42 +1048,48 @@ __global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchPar
 // left has no scalar keys, so any non-zero scalar in a request fails compareResourceAndRequire
 // (core.go:688-691) for every node: that is one per-pod bit (scalar_block / leader_block).
 // ------------------------------------------------------------------------------------------------
-// One wave = 64 consecutive pods x a range of 64-node blocks, NB blocks at a time.
-// Lanes are NODES while comparing: lane n holds left[n] (4 int64) in VGPRs, the pod's request R is
-// wave-uniform (one s_load), and an EXEC-chained
+// One wave = 64 consecutive pods x a range of 64-node blocks, two blocks at a time.
+// Lanes are NODES while comparing: lane n holds left[n] (4 int64) of two node blocks in VGPRs, the
+// pod's request R is wave-uniform (one s_load_dwordx8), and the EXEC-chained
 //     s_mov_b64 exec, ok ; 4 x v_cmpx_le_i64 vcc, R[j], left[j]
 // leaves in EXEC the 64 node-feasibility bits of case 2 for that pod — the compare result IS the
-// bitmap word ("ballot").  OR-ing the pod-independent case-3 mask gives the word; v_writelane (lane
-// select in M0) drops it into lane pp, so that after 64 pods lane pp owns pod pp's word: lanes are
-// PODS for the outputs (coalesced 512-byte bitmap store, popcount -> feasible-node count).
-__device__ __forceinline__ void filter_cmp(uint32_t& wlo, uint32_t& whi, unsigned long long ok, const int64_t (&R)[4],
-                                           const int64_t (&l)[4], uint32_t nlf_lo, uint32_t nlf_hi) {
-  asm volatile("s_mov_b64 exec, %[ok]\n\t"
-               "v_cmpx_le_i64 vcc, %[R0], %[l0]\n\t"
-               "v_cmpx_le_i64 vcc, %[R1], %[l1]\n\t"
-               "v_cmpx_le_i64 vcc, %[R2], %[l2]\n\t"
-               "v_cmpx_le_i64 vcc, %[R3], %[l3]\n\t"
-               "s_or_b32 %[wlo], exec_lo, %[nlo]\n\t"
-               "s_or_b32 %[whi], exec_hi, %[nhi]\n\t"
+// bitmap word ("ballot") — which v_writelane (lane select in M0, data = exec_lo / exec_hi) drops
+// into lane pp.  After 64 pods lane pp owns pod pp's words: lanes are PODS for the outputs, where
+// the pod-independent case-3 mask is OR-ed in, non-evaluated pods get their constant word, the
+// popcount accumulates the feasible-node count and the store is one coalesced 512 bytes per block.
+// Per pod and node block: 3 SALU + 6 VALU, no branch.
+__device__ __forceinline__ void filter_pod2(uint32_t pp, const int64_t (&R)[4], unsigned long long ok0, unsigned long long ok1,
+                                            const int64_t (&l0)[4], const int64_t (&l1)[4], uint32_t& vlo0, uint32_t& vhi0,
+                                            uint32_t& vlo1, uint32_t& vhi1) {
+  asm volatile("s_mov_b32 m0, %[pp]\n\t"
+               "s_mov_b64 exec, %[ok0]\n\t"
+               "v_cmpx_le_i64 vcc, %[R0], %[a0]\n\t"
+               "v_cmpx_le_i64 vcc, %[R1], %[a1]\n\t"
+               "v_cmpx_le_i64 vcc, %[R2], %[a2]\n\t"
+               "v_cmpx_le_i64 vcc, %[R3], %[a3]\n\t"
+               "s_nop 3\n\t"
+               "v_writelane_b32 %[vlo0], exec_lo, m0\n\t"
+               "v_writelane_b32 %[vhi0], exec_hi, m0\n\t"
+               "s_mov_b64 exec, %[ok1]\n\t"
+               "v_cmpx_le_i64 vcc, %[R0], %[b0]\n\t"
+               "v_cmpx_le_i64 vcc, %[R1], %[b1]\n\t"
+               "v_cmpx_le_i64 vcc, %[R2], %[b2]\n\t"
+               "v_cmpx_le_i64 vcc, %[R3], %[b3]\n\t"
+               "s_nop 3\n\t"
+               "v_writelane_b32 %[vlo1], exec_lo, m0\n\t"
+               "v_writelane_b32 %[vhi1], exec_hi, m0\n\t"
                "s_mov_b64 exec, -1"
-               : [wlo] "=&s"(wlo), [whi] "=&s"(whi)
-               : [ok] "s"(ok), [R0] "s"(R[0]), [l0] "v"(l[0]), [R1] "s"(R[1]), [l1] "v"(l[1]), [R2] "s"(R[2]), [l2] "v"(l[2]),
-                 [R3] "s"(R[3]), [l3] "v"(l[3]), [nlo] "s"(nlf_lo), [nhi] "s"(nlf_hi)
-               : "vcc", "scc");
-}
-// v_writelane_b32 with the lane select in M0 (gfx9 allows one SGPR source besides M0)
-__device__ __forceinline__ void put_word(uint32_t& vlo, uint32_t& vhi, uint32_t wlo, uint32_t whi, uint32_t lane_sel) {
-  asm volatile("s_mov_b32 m0, %[sel]\n\t"
-               "s_nop 0\n\t"
-               "v_writelane_b32 %[vlo], %[wlo], m0\n\t"
-               "v_writelane_b32 %[vhi], %[whi], m0"
-               : [vlo] "+v"(vlo), [vhi] "+v"(vhi)
-               : [wlo] "s"(wlo), [whi] "s"(whi), [sel] "s"(lane_sel));
+               : [vlo0] "+v"(vlo0), [vhi0] "+v"(vhi0), [vlo1] "+v"(vlo1), [vhi1] "+v"(vhi1)
+               : [pp] "s"(pp), [ok0] "s"(ok0), [ok1] "s"(ok1), [R0] "s"(R[0]), [R1] "s"(R[1]), [R2] "s"(R[2]), [R3] "s"(R[3]),
+                 [a0] "v"(l0[0]), [a1] "v"(l0[1]), [a2] "v"(l0[2]), [a3] "v"(l0[3]), [b0] "v"(l1[0]), [b1] "v"(l1[1]), [b2] "v"(l1[2]),
+                 [b3] "v"(l1[3])
+               : "vcc");
 }
 
 template <int NB>
 __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, BatchDev b, uint32_t blocks_per_wave,
                                                 uint32_t want_bitmap) {
+  static_assert(NB == 2, "the inner statement handles two node blocks");
   typedef const __attribute__((address_space(4))) uint32_t* cflag_t;
   const int lane = lane_id();
   const uint32_t ptile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id());
@@ -1091,8 +1104,9 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
   // Is the leader's single-member request M the same for every evaluated pod of the tile?  (It is,
   // unless the tile straddles a first-pod capture.)  Then case 3 is one mask per node block.
   const bool mine = (uint32_t)lane < np;
-  const uint32_t myff = mine ? b.fflags[p0 + lane] : 0u;
-  const bool ev = (myff >> 8) == BS_FL_EVALUATED;
+  const uint32_t myff = mine ? b.fflags[p0 + lane] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  const uint32_t myfl = myff >> 8;
+  const bool ev = myfl == BS_FL_EVALUATED;
   int64_t M[4] = {0, 0, 0, 0};
   if (ev) {
     const int64_t* src = b.fparams + (size_t)(p0 + lane) * 8 + 4;
@@ -1121,8 +1135,8 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
   uint32_t cnt = 0;
   for (uint32_t w = w0; w < w1; w += NB) {
     int64_t l[NB][4];
-    unsigned long long okmask[NB], in_range[NB];
-    uint32_t nlf_lo[NB], nlf_hi[NB], vlo[NB], vhi[NB];
+    unsigned long long okmask[NB], in_range[NB], nlf[NB];
+    uint32_t vlo[NB], vhi[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const uint32_t n = (w + nb) * 64u + (uint32_t)lane;
@@ -1140,65 +1154,41 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
       // case 3 for the tile's common leader: nodes that cannot hold one leader member
       unsigned long long lf = 0;
       if (!lb0) lf = __ballot(l[nb][0] >= M0[0]) & __ballot(l[nb][1] >= M0[1]) & __ballot(l[nb][2] >= M0[2]) & __ballot(l[nb][3] >= M0[3]);
-      const unsigned long long nlf = okmask[nb] & ~lf;
-      nlf_lo[nb] = __builtin_amdgcn_readfirstlane((uint32_t)nlf);
-      nlf_hi[nb] = __builtin_amdgcn_readfirstlane((uint32_t)(nlf >> 32));
+      nlf[nb] = okmask[nb] & ~lf;
       vlo[nb] = 0;
       vhi[nb] = 0;
     }
     if (uniformM) {
       // software-pipelined over pods: the next pod's request is in flight while this one is compared
       int64_t RA[4], RB[4];
-      uint32_t fa, fb;
 #pragma unroll
       for (int j = 0; j < 4; ++j) RA[j] = FP[(size_t)p0 * 8 + j];
-      fa = FF[p0];
       BS_S_WAIT_LGKM0();
       for (uint32_t pp = 0; pp < np; pp += 2) {
         const uint32_t pn = p0 + min(pp + 1, np - 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) RB[j] = FP[(size_t)pn * 8 + j];
-        fb = FF[pn];
         __builtin_amdgcn_sched_barrier(0);
-        {
-          const uint32_t fl = fa >> 8;
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            uint32_t wlo, whi;
-            if (fl == BS_FL_EVALUATED) {
-              filter_cmp(wlo, whi, (fa & 1u) ? 0ull : okmask[nb], RA, l[nb], nlf_lo[nb], nlf_hi[nb]);
-            } else {
-              const unsigned long long word = fl < 16u ? in_range[nb] : 0ull;   // nil before any node lookup / error
-              wlo = (uint32_t)word;
-              whi = (uint32_t)(word >> 32);
-            }
-            put_word(vlo[nb], vhi[nb], wlo, whi, pp);
-          }
-        }
+        filter_pod2(pp, RA, okmask[0], okmask[1], l[0], l[1], vlo[0], vhi[0], vlo[1], vhi[1]);
         BS_S_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t pn2 = p0 + min(pp + 2, np - 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) RA[j] = FP[(size_t)pn2 * 8 + j];
-        fa = FF[pn2];
         __builtin_amdgcn_sched_barrier(0);
-        if (pp + 1 < np) {
-          const uint32_t fl = fb >> 8;
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            uint32_t wlo, whi;
-            if (fl == BS_FL_EVALUATED) {
-              filter_cmp(wlo, whi, (fb & 1u) ? 0ull : okmask[nb], RB, l[nb], nlf_lo[nb], nlf_hi[nb]);
-            } else {
-              const unsigned long long word = fl < 16u ? in_range[nb] : 0ull;
-              wlo = (uint32_t)word;
-              whi = (uint32_t)(word >> 32);
-            }
-            put_word(vlo[nb], vhi[nb], wlo, whi, pp + 1);
-          }
-        }
+        filter_pod2(min(pp + 1, np - 1), RB, okmask[0], okmask[1], l[0], l[1], vlo[0], vhi[0], vlo[1], vhi[1]);
         BS_S_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
+      }
+      // lanes are pods now: finish the word
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const unsigned long long c2 = ((unsigned long long)vhi[nb] << 32) | vlo[nb];
+        unsigned long long word;
+        if (ev) word = ((myff & 1u) ? 0ull : c2) | nlf[nb];
+        else word = myfl < 16u ? in_range[nb] : 0ull;           // nil before any node lookup / error
+        vlo[nb] = (uint32_t)word;
+        vhi[nb] = (uint32_t)(word >> 32);
       }
     } else {
       // generic path: per-pod leader request (tile straddles a capture); plain ballots
@@ -1219,7 +1209,8 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
           } else {
             word = fl < 16u ? in_range[nb] : 0ull;
           }
-          put_word(vlo[nb], vhi[nb], (uint32_t)word, (uint32_t)(word >> 32), pp);
+          vlo[nb] = writelane_u32((uint32_t)word, pp, vlo[nb]);
+          vhi[nb] = writelane_u32((uint32_t)(word >> 32), pp, vhi[nb]);
         }
       }
     }

@@ -674,7 +674,6 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   });
   {
     const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
-    // chunk totals are indexed [slot][nchunks_cap]: pass the capacity as gridDim.y only when it equals nchunks
     TIMED(c, BS_KERNEL_TABLES, {
       hipLaunchKernelGGL(k_tables_local, dim3(2 * C, nchunks), dim3(kTblChunk), 0, c->stream, nd, b, prm, 0u);
       if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, 0u);
@@ -687,15 +686,14 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   TIMED(c, BS_KERNEL_RESOLVE, {
     if (P) {
       hipLaunchKernelGGL(k_reject, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b);
-      hipLaunchKernelGGL(k_final_a, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, nd, b);
       const dim3 fg(cdiv(P, 256));
       switch (ts) {
-        case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<0>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
-        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<1>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
-        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<2>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
-        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<3>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
-        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<4>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final_b<-1>), fg, blk, 0, c->stream, pd, gr, b, prm); break;
+        case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<0>), fg, blk, 0, c->stream, pd, gr, nd, b, prm); break;
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<1>), fg, blk, 0, c->stream, pd, gr, nd, b, prm); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<2>), fg, blk, 0, c->stream, pd, gr, nd, b, prm); break;
+        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<3>), fg, blk, 0, c->stream, pd, gr, nd, b, prm); break;
+        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<4>), fg, blk, 0, c->stream, pd, gr, nd, b, prm); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<-1>), fg, blk, 0, c->stream, pd, gr, nd, b, prm); break;
       }
     }
   });

@@ -249,10 +249,12 @@ int bs_batch_sync(bs_ctx* ctx);
 int bs_batch_read(bs_ctx* ctx, const bs_batch_out* out);
 
 /* ---- pod-axis sharding (one process per GPU) -------------------------------------- */
-/* Only pods [lo,hi) of the loaded batch are evaluated by this context; deny replay stays
- * exact because each rank replays the PreFilter codes of ALL pods of a group it owns pods of
- * (groups never straddle ranks when the caller cuts at group boundaries; otherwise the
- * straddling group's earlier pods are re-evaluated locally). */
+/* Rank `rank` of `nranks` evaluates only the pods it owns: every pod of a group belongs to the rank
+ * whose block of the queue ([rank*P/nranks, (rank+1)*P/nranks)) holds the group's FIRST pod; ungrouped
+ * pods go by their own index.  Groups never straddle ranks, so the deny replay stays exact and the
+ * per-group admit counters of different ranks are disjoint (one all-reduce(sum) merges them).
+ * Pods of other ranks report pf_code 0xFF (BS_PF_NOT_OWNED).  The whole batch is loaded on every rank. */
+#define BS_PF_NOT_OWNED 0xFFu
 int bs_shard_set(bs_ctx* ctx, uint32_t rank, uint32_t nranks);
 /* Device address of the per-group admit counters (uint32[g]) so the caller's collective
  * (torch.distributed / RCCL all-reduce, sum) can run in place between the two halves. */
