@@ -88,7 +88,10 @@ struct BatchDev {
   int32_t* qtable;          // scan table id (class + C * (pct==0.7)), -1 none
   int64_t* qreq;            // [P][LP] effective request (absent scalar -> INT64_MIN)
   uint32_t* qflags;         // bits 0..11 request key present, bits 16..27 "zero/absent" (passes w/o left key)
-  uint32_t* first_row;      // [P] min table row satisfying the request (INF none)
+  uint32_t* first_row;      // [P] by SORTED query position: min table row satisfying the request (INF none)
+  int64_t* qreq_s;          // [P][LP] requests in tile order (k_scatter)
+  uint32_t* qflags_s;       // [P]
+  uint32_t* qpos;           // [P] pod -> sorted position (valid iff ST_QUERY)
   // tables / tiles
   uint32_t* tbl_count;      // [2C]
   uint32_t* tbl_off;        // [2C+1]
@@ -594,12 +597,21 @@ __global__ __launch_bounds__(kScanBlock) void k_plan(BatchDev b, BatchParams prm
   }
 }
 
-__global__ void k_scatter(PodsDev pods, BatchDev b) {
+__global__ void k_scatter(PodsDev pods, BatchDev b, BatchParams prm) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < pods.p;
   const int32_t table = valid ? b.qtable[i] : -1;
   const uint32_t slot = wave_aggregated_inc(b.tbl_cursor, (uint32_t)(table < 0 ? 0 : table), table >= 0);
-  if (table >= 0) b.qlist[b.tbl_off[table] + slot] = i;
+  if (table >= 0) {
+    // tile order: the scan wave reads its 64*Q requests as contiguous rows, no indirection
+    const uint32_t pos = b.tbl_off[table] + slot;
+    b.qlist[pos] = i;
+    b.qpos[i] = pos;
+    b.qflags_s[pos] = b.qflags[i];
+    const int64_t* src = b.qreq + (size_t)i * prm.LP;
+    int64_t* dst = b.qreq_s + (size_t)pos * prm.LP;
+    for (uint32_t j = 0; j < prm.LP; ++j) dst[j] = src[j];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -705,27 +717,27 @@ __device__ __forceinline__ crow_t as_const_rows(const int64_t* p) { return (crow
 
 #define BS_CX(j) "v_cmpx_ge_i64 vcc, %[a" #j "], %[r" #j "]\n\t"
 #define BS_ROW_HEAD "s_mov_b64 exec, %[nf]\n\t"
-#define BS_ROW_TAIL "v_mov_b32 %[myk], %[k]\n\ts_andn2_b64 %[nf], %[nf], exec\n\ts_mov_b64 exec, -1"
+#define BS_ROW_TAIL "v_min_u32 %[myk], %[k], %[myk]\n\ts_mov_b64 exec, -1"
 #define BS_OPS4 [a0] "s"(a[0]), [r0] "v"(r[0]), [a1] "s"(a[1]), [r1] "v"(r[1]), [a2] "s"(a[2]), [r2] "v"(r[2]), [a3] "s"(a[3]), [r3] "v"(r[3])
 
 template <int L>
-__device__ __forceinline__ void row_step(unsigned long long& nf, uint32_t& myk, uint32_t k, const int64_t (&a)[L], const int64_t (&r)[L]) {
+__device__ __forceinline__ void row_step(unsigned long long nf, uint32_t& myk, uint32_t k, const int64_t (&a)[L], const int64_t (&r)[L]) {
   if constexpr (L == 4) {
     asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_ROW_TAIL
-                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4 : "vcc");
+                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4 : "vcc");
   } else if constexpr (L == 5) {
     asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_ROW_TAIL
-                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]) : "vcc");
+                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]) : "vcc");
   } else if constexpr (L == 6) {
     asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_ROW_TAIL
-                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]) : "vcc");
+                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]) : "vcc");
   } else if constexpr (L == 7) {
     asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_CX(6) BS_ROW_TAIL
-                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]),
+                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]),
                    [a6] "s"(a[6]), [r6] "v"(r[6]) : "vcc");
   } else if constexpr (L == 8) {
     asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_CX(6) BS_CX(7) BS_ROW_TAIL
-                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]),
+                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]),
                    [a6] "s"(a[6]), [r6] "v"(r[6]), [a7] "s"(a[7]), [r7] "v"(r[7]) : "vcc");
   } else {
     // wide rows (S > 4): two chained statements; the surviving-lane mask travels in an SGPR pair
@@ -750,9 +762,43 @@ __device__ __forceinline__ void row_step(unsigned long long& nf, uint32_t& myk, 
       asm volatile("s_mov_b64 exec, %[m]\n\tv_cmpx_ge_i64 vcc, %[a], %[r]\n\ts_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
                    : [m] "+s"(m) : [a] "s"(a[j]), [r] "v"(r[j]) : "vcc");
     }
-    asm volatile("s_mov_b64 exec, %[m]\n\tv_mov_b32 %[myk], %[k]\n\ts_andn2_b64 %[nf], %[nf], exec\n\ts_mov_b64 exec, -1"
-                 : [nf] "+s"(nf), [myk] "+v"(myk) : [k] "s"(k), [m] "s"(m));
+    asm volatile("s_mov_b64 exec, %[m]\n\tv_min_u32 %[myk], %[k], %[myk]\n\ts_mov_b64 exec, -1"
+                 : [myk] "+v"(myk) : [k] "s"(k), [m] "s"(m));
   }
+}
+
+// Two query blocks against one row in ONE statement: EXEC is restored once.
+#define BS_CXQ(q, j) "v_cmpx_ge_i64 vcc, %[a" #j "], %[r" #q #j "]\n\t"
+#define BS_QHEAD(q) "s_mov_b64 exec, %[nf" #q "]\n\t"
+#define BS_QTAIL(q) "v_min_u32 %[myk" #q "], %[k], %[myk" #q "]\n\t"
+#define BS_QOUT [myk0] "+v"(myk0), [myk1] "+v"(myk1)
+#define BS_AOPS4 [a0] "s"(a[0]), [a1] "s"(a[1]), [a2] "s"(a[2]), [a3] "s"(a[3])
+#define BS_ROPS4(q, arr) [r##q##0] "v"(arr[0]), [r##q##1] "v"(arr[1]), [r##q##2] "v"(arr[2]), [r##q##3] "v"(arr[3])
+template <int L>
+__device__ __forceinline__ void row_step2(unsigned long long nf0, uint32_t& myk0, unsigned long long nf1, uint32_t& myk1, uint32_t k,
+                                          const int64_t (&a)[L], const int64_t (&r0)[L], const int64_t (&r1)[L]) {
+  if constexpr (L == 4) {
+    asm volatile(BS_QHEAD(0) BS_CXQ(0, 0) BS_CXQ(0, 1) BS_CXQ(0, 2) BS_CXQ(0, 3) BS_QTAIL(0)
+                 BS_QHEAD(1) BS_CXQ(1, 0) BS_CXQ(1, 1) BS_CXQ(1, 2) BS_CXQ(1, 3) BS_QTAIL(1) "s_mov_b64 exec, -1"
+                 : BS_QOUT : [nf0] "s"(nf0), [nf1] "s"(nf1), [k] "s"(k), BS_AOPS4, BS_ROPS4(0, r0), BS_ROPS4(1, r1) : "vcc");
+  } else if constexpr (L == 5) {
+    asm volatile(BS_QHEAD(0) BS_CXQ(0, 0) BS_CXQ(0, 1) BS_CXQ(0, 2) BS_CXQ(0, 3) BS_CXQ(0, 4) BS_QTAIL(0)
+                 BS_QHEAD(1) BS_CXQ(1, 0) BS_CXQ(1, 1) BS_CXQ(1, 2) BS_CXQ(1, 3) BS_CXQ(1, 4) BS_QTAIL(1) "s_mov_b64 exec, -1"
+                 : BS_QOUT : [nf0] "s"(nf0), [nf1] "s"(nf1), [k] "s"(k), BS_AOPS4, [a4] "s"(a[4]), BS_ROPS4(0, r0), [r04] "v"(r0[4]), BS_ROPS4(1, r1), [r14] "v"(r1[4]) : "vcc");
+  } else if constexpr (L == 6) {
+    asm volatile(BS_QHEAD(0) BS_CXQ(0, 0) BS_CXQ(0, 1) BS_CXQ(0, 2) BS_CXQ(0, 3) BS_CXQ(0, 4) BS_CXQ(0, 5) BS_QTAIL(0)
+                 BS_QHEAD(1) BS_CXQ(1, 0) BS_CXQ(1, 1) BS_CXQ(1, 2) BS_CXQ(1, 3) BS_CXQ(1, 4) BS_CXQ(1, 5) BS_QTAIL(1) "s_mov_b64 exec, -1"
+                 : BS_QOUT : [nf0] "s"(nf0), [nf1] "s"(nf1), [k] "s"(k), BS_AOPS4, [a4] "s"(a[4]), [a5] "s"(a[5]), BS_ROPS4(0, r0), [r04] "v"(r0[4]), [r05] "v"(r0[5]),
+                   BS_ROPS4(1, r1), [r14] "v"(r1[4]), [r15] "v"(r1[5]) : "vcc");
+  } else {
+    row_step<L>(nf0, myk0, k, a, r0);
+    row_step<L>(nf1, myk1, k, a, r1);
+  }
+}
+template <int L, int Q>
+__device__ __forceinline__ void row_all(const unsigned long long (&nf)[Q], uint32_t (&myk)[Q], uint32_t k, const int64_t (&a)[L], const int64_t (&r)[Q][L]) {
+  if constexpr (Q == 2) row_step2<L>(nf[0], myk[0], nf[1], myk[1], k, a, r[0], r[1]);
+  else row_step<L>(nf[0], myk[0], k, a, r[0]);
 }
 
 template <int S, int Q>
@@ -772,22 +818,22 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
   const uint32_t cnt = __builtin_amdgcn_readfirstlane(tl.count);
 
   int64_t r[Q][L];
-  uint32_t pod[Q], myk[Q], qf[Q];
+  uint32_t pos[Q], myk[Q], qf[Q];
   unsigned long long nf[Q];                      // lanes still looking for their first row
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const uint32_t qi = (uint32_t)q * 64u + (uint32_t)lane;
     const bool valid = qi < cnt;
-    pod[q] = valid ? b.qlist[q0 + qi] : 0u;
+    pos[q] = q0 + qi;                            // sorted position: requests are contiguous per tile
     myk[q] = BS_INF;
     qf[q] = 0;
     uint32_t seen = 0;
     if (valid) {
-      const int64_t* src = b.qreq + (size_t)pod[q] * LP;
+      const int64_t* src = b.qreq_s + (size_t)pos[q] * LP;
 #pragma unroll
       for (int j = 0; j < L; ++j) r[q][j] = src[j];
-      qf[q] = b.qflags[pod[q]];
-      seen = __hip_atomic_load(&b.first_row[pod[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      qf[q] = b.qflags_s[pos[q]];
+      seen = __hip_atomic_load(&b.first_row[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
 #pragma unroll
       for (int j = 0; j < L; ++j) r[q][j] = INT64_MAX;
@@ -832,54 +878,51 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
     const uint32_t pairs = (e - a) / (2u * U);
     if (pairs) {
       int64_t A[U][L], B[U][L];
+      crow_t pr = T + (size_t)k * LP;             // running row pointer: constant offsets below fold into s_load
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int j = 0; j < L; ++j) A[u][j] = T[(size_t)(k + u) * LP + j];
+        for (int j = 0; j < L; ++j) A[u][j] = pr[u * LP + j];
       BS_S_WAIT_LGKM0();
       for (uint32_t it = 0; it < pairs; ++it) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-          for (int j = 0; j < L; ++j) B[u][j] = T[(size_t)(k + U + u) * LP + j];
+          for (int j = 0; j < L; ++j) B[u][j] = pr[(U + u) * LP + j];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int q = 0; q < Q; ++q) row_step<L>(act[q], myk[q], k + u, A[u], r[q]);
+        for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + u, A[u], r);
         BS_S_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
         // rows k+2U.. may lie past the piece (prefetch only; the table has slack rows)
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-          for (int j = 0; j < L; ++j) A[u][j] = T[(size_t)(k + 2 * U + u) * LP + j];
+          for (int j = 0; j < L; ++j) A[u][j] = pr[(2 * U + u) * LP + j];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int q = 0; q < Q; ++q) row_step<L>(act[q], myk[q], k + U + u, B[u], r[q]);
+        for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + U + u, B[u], r);
         BS_S_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
         k += 2 * U;
-        unsigned long long left = 0;
+        pr += 2 * U * LP;
+        unsigned long long left = 0;              // lanes of this piece still without a row
 #pragma unroll
-        for (int q = 0; q < Q; ++q) left |= act[q];
+        for (int q = 0; q < Q; ++q) left |= act[q] & __ballot(myk[q] == BS_INF);
         if (left == 0) break;
       }
     }
     {
       unsigned long long left = 0;
 #pragma unroll
-      for (int q = 0; q < Q; ++q) left |= act[q];
+      for (int q = 0; q < Q; ++q) left |= act[q] & __ballot(myk[q] == BS_INF);
       if (left) {
         for (; k < e; ++k) {                     // < 2U leftover rows of the piece
           int64_t R1[L];
 #pragma unroll
           for (int j = 0; j < L; ++j) R1[j] = T[(size_t)k * LP + j];
           BS_S_WAIT_LGKM0();
-#pragma unroll
-          for (int q = 0; q < Q; ++q) row_step<L>(act[q], myk[q], k, R1, r[q]);
+          row_all<L, Q>(act, myk, k, R1, r);
         }
       }
     }
@@ -887,7 +930,7 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
     unsigned long long left = 0;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      nf[q] |= act[q];
+      nf[q] = (nf[q] | act[q]) & __ballot(myk[q] == BS_INF);
       left |= nf[q];
     }
     if (left == 0) break;
@@ -895,7 +938,7 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
   }
 #pragma unroll
   for (int q = 0; q < Q; ++q)
-    if (myk[q] != BS_INF) atomicMin(&b.first_row[pod[q]], myk[q]);
+    if (myk[q] != BS_INF) atomicMin(&b.first_row[pos[q]], myk[q]);
   if (prm.collect_stats && lane == 0) {
     atomicAdd((unsigned long long*)&b.stats[0], (unsigned long long)rows_done);
     atomicAdd((unsigned long long*)&b.stats[1], (unsigned long long)rows_done * cnt);
@@ -909,7 +952,7 @@ __global__ void k_reject(PodsDev pods, BatchDev b) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pods.p) return;
   if (!(b.stage[i] & ST_QUERY)) return;
-  if (b.first_row[i] == BS_INF) {
+  if (b.first_row[b.qpos[i]] == BS_INF) {
     // compareClusterResourceAndRequire returned false: AddToDenyCache (core.go:142,163)
     b.tcode[i] = (b.tcode[i] == BS_PF_PASS_FIRST_FITS) ? BS_PF_REJECT_FIRST : BS_PF_REJECT_RESERVE;
     atomicMin(&b.first_reject[pods.group[i]], i);
@@ -1002,7 +1045,7 @@ __global__ __launch_bounds__(256) void k_final(PodsDev pods, GroupsDev gr, Nodes
       if ((st & ST_ELIG) && b.first_reject[pods.group[i]] < i) {
         code = BS_PF_ERR_DENIED;
       } else if (st & ST_QUERY) {
-        const uint32_t row = b.first_row[i];
+        const uint32_t row = b.first_row[b.qpos[i]];
         fk = row == BS_INF ? BS_K_NONE : nd.kmap[row];
       }
     } else {

@@ -66,7 +66,7 @@ struct bs_ctx {
   // ---- batch scratch / outputs
   DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
   DevBuf d_epoch, d_nepochs, d_leader_epoch, d_panic_epoch;
-  DevBuf d_tcode, d_stage, d_leader_raw, d_qtable, d_qreq, d_qflags, d_first_row;
+  DevBuf d_tcode, d_stage, d_leader_raw, d_qtable, d_qreq, d_qflags, d_first_row, d_qreq_s, d_qflags_s, d_qpos;
   DevBuf d_tbl_count, d_tbl_off, d_tbl_cursor, d_tbl_slot, d_desc, d_ntables, d_tiles, d_ntiles, d_qlist;
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch;
   DevBuf d_pf_code, d_pf_first_k, d_pf_leader, d_fl_code, d_fl_feasible, d_fl_bitmap, d_admit, d_ready;
@@ -214,6 +214,9 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.qreq = c->d_qreq.as<int64_t>();
   b.qflags = c->d_qflags.as<uint32_t>();
   b.first_row = c->d_first_row.as<uint32_t>();
+  b.qreq_s = c->d_qreq_s.as<int64_t>();
+  b.qflags_s = c->d_qflags_s.as<uint32_t>();
+  b.qpos = c->d_qpos.as<uint32_t>();
   b.tbl_count = c->d_tbl_count.as<uint32_t>();
   b.tbl_off = c->d_tbl_off.as<uint32_t>();
   b.tbl_cursor = c->d_tbl_cursor.as<uint32_t>();
@@ -565,6 +568,9 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, c->d_qreq.reserve(n * c->LP * 8));
   HIPCHK(c, c->d_qflags.reserve(n * 4));
   HIPCHK(c, c->d_first_row.reserve(n * 4));
+  HIPCHK(c, c->d_qreq_s.reserve(n * c->LP * 8));
+  HIPCHK(c, c->d_qflags_s.reserve(n * 4));
+  HIPCHK(c, c->d_qpos.reserve(n * 4));
   HIPCHK(c, c->d_qlist.reserve(n * 4));
   HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
   HIPCHK(c, c->d_fflags.reserve(n * 4));
@@ -670,7 +676,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       }
     }
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(kScanBlock), 0, c->stream, b, prm);
-    if (P) hipLaunchKernelGGL(k_scatter, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b);
+    if (P) hipLaunchKernelGGL(k_scatter, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b, prm);
   });
   {
     const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
@@ -894,9 +900,9 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
   b.ntiles = reinterpret_cast<uint32_t*>(sq + 64);
   b.tiles = reinterpret_cast<Tile*>(sq + 128);
   b.qlist = reinterpret_cast<uint32_t*>(sq + 192);
-  b.qflags = reinterpret_cast<uint32_t*>(sq + 256);
+  b.qflags_s = reinterpret_cast<uint32_t*>(sq + 256);
   b.first_row = reinterpret_cast<uint32_t*>(sq + 320);
-  b.qreq = reinterpret_cast<int64_t*>(sq + 512);
+  b.qreq_s = reinterpret_cast<int64_t*>(sq + 512);
   BatchParams prm = batch_params(c);
   prm.collect_stats = 0;
   prm.seg_len = pick_seg_len(c, 1, M);
