@@ -93,10 +93,9 @@ struct BatchDev {
   uint32_t* qflags_s;       // [P]
   uint32_t* qpos;           // [P] pod -> sorted position (valid iff ST_QUERY)
   // tables / tiles
-  uint32_t* tbl_count;      // [2C]
-  uint32_t* tbl_off;        // [2C+1]
-  uint32_t* tbl_cursor;     // [2C]
-  int32_t* tbl_slot;        // [2C] slot in `tables`, -1 not needed
+  uint32_t* needed;         // [2C+1] table (class + C*(pct==0.7)) is used by some query of the batch
+  uint32_t* qcount;         // [1] scan queries emitted
+  uint32_t* ticket;         // [4] last-block tickets
   TableDesc* desc;          // [slots]
   uint32_t* ntables;        // [1]
   Tile* tiles;
@@ -162,9 +161,10 @@ __global__ __launch_bounds__(kScanBlock) void k_nodes_derive(NodesDev nd, uint32
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_init: reset per-batch scratch
+// k_init: full scratch reset (after a load, or when the previous batch left the per-group minima
+// dirty).  In steady state it is not launched: k_tally's last block re-arms them for the next batch.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_init(GroupsDev gr, BatchDev b, BatchParams prm, uint32_t P, uint32_t no_capture) {
+__global__ void k_init(GroupsDev gr, BatchDev b) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < gr.g) {
     b.first_elig[t] = BS_INF;
@@ -172,27 +172,40 @@ __global__ void k_init(GroupsDev gr, BatchDev b, BatchParams prm, uint32_t P, ui
     b.first_reject[t] = BS_INF;
     b.first_pod[t] = BS_INF;
     b.cap_epoch[t] = (gr.flags[t] & BS_GROUP_HAS_POD) ? 0u : BS_INF;
-    b.admit[t] = 0;
   }
-  if (t < 2 * prm.C) {
-    b.tbl_count[t] = 0;
-    b.tbl_cursor[t] = 0;
-  }
-  if (t < P) {
-    b.first_row[t] = BS_INF;
-    b.fl_feasible[t] = 0;
-    if (no_capture) b.epoch[t] = 0;
-  }
-  if (t == 0 && no_capture) *b.nepochs = 1;      // every group already has its pod: one epoch
-  if (t < 8 && prm.collect_stats) b.stats[t] = 0;
+  if (t < 4) b.ticket[t] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_prepass: steps of PreFilter that do not need any other pod (core.go:89-110)
+// k_prepass: per-batch resets + the steps of PreFilter that do not need any other pod
+// (core.go:89-110).  When no first-pod capture can happen in the batch (every group already has its
+// pod) the LAST block runs findMaxPG for the single epoch instead (k_leader's body): one launch less.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_prepass(PodsDev pods, GroupsDev gr, BatchDev b) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void leader_block(const GroupsDev& gr, const BatchDev& b, uint32_t e);
+
+constexpr int kPrepassBlock = 512;
+
+__global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm, uint32_t no_capture,
+                                                           uint32_t fused_leader) {
+  if (fused_leader && blockIdx.x == gridDim.x - 1) {
+    leader_block(gr, b, 0);
+    return;
+  }
+  const uint32_t i = blockIdx.x * kPrepassBlock + threadIdx.x;
+  // resets whose consumers run in later launches
+  if (i < gr.g) b.admit[i] = 0;
+  if (i < (2 * prm.C + 1) * 16) b.kp[i] = BS_INF;
+  if (i < 2 * prm.C + 1) b.needed[i] = 0;
+  if (i == 0) {
+    *b.ntiles = 0;
+    *b.qcount = 0;
+    if (no_capture) *b.nepochs = 1;
+  }
+  if (i < 8 && prm.collect_stats) b.stats[i] = 0;
   if (i >= pods.p) return;
+  b.first_row[i] = BS_INF;
+  b.fl_feasible[i] = 0;
+  if (no_capture) b.epoch[i] = 0;
   const int32_t gi = pods.group[i];
   uint8_t st = 0;
   if (gi >= 0 && (uint32_t)gi < gr.g) {
@@ -285,11 +298,9 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v
 constexpr int kLeaderBlock = 512;
 constexpr int kLeaderPerThread = 16;     // groups cached in registers per thread (G <= 8192), else recomputed
 
-__global__ __launch_bounds__(kLeaderBlock) void k_leader(GroupsDev gr, BatchDev b) {
+__device__ __forceinline__ void leader_block(const GroupsDev& gr, const BatchDev& b, uint32_t e) {
   __shared__ unsigned long long lds64[16];
   __shared__ uint32_t lds[16];
-  const uint32_t e = blockIdx.x;
-  if (e >= *b.nepochs) return;
   // per thread: up to kLeaderPerThread groups cached in registers (candidate bit + finished)
   uint32_t fin[kLeaderPerThread];
   uint32_t cand = 0;
@@ -347,6 +358,11 @@ __global__ __launch_bounds__(kLeaderBlock) void k_leader(GroupsDev gr, BatchDev 
     cur = nxt;
   }
   if (threadIdx.x == 0) { b.leader_epoch[e] = (int32_t)cur; b.panic_epoch[e] = 0; }
+}
+
+__global__ __launch_bounds__(kLeaderBlock) void k_leader(GroupsDev gr, BatchDev b) {
+  if (blockIdx.x >= *b.nepochs) return;
+  leader_block(gr, b, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,118 +515,55 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
       }
     }
     if (!(st & ST_OWNED)) table = -1;
-    if (table >= 0) {
-      st |= ST_QUERY;
-      uint32_t absok = 0;
-#pragma unroll
-      for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
-        if (s < sh.S()) {
-          const bool pres = q.present & (1u << s);
-          if (!pres || q.v[4 + s] == 0) absok |= 1u << s;       // core.go:688-692
-          if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
-        }
-      }
-      int64_t* dst = b.qreq + (size_t)i * prm.LP;
-#pragma unroll
-      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-        if (j < prm.LP) dst[j] = j < sh.L() ? q.v[j] : INT64_MIN;
-      b.qflags[i] = q.present | (absok << 16);
-    }
+    if (table >= 0) st |= ST_QUERY;
     b.tcode[i] = code;
     b.stage[i] = st;
     b.leader_raw[i] = leader;
-    b.qtable[i] = table;
   }
-  // one atomic per distinct table per wave
-  wave_aggregated_inc(b.tbl_count, (uint32_t)(table < 0 ? 0 : table), valid && table >= 0);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_plan: offsets per table, table slots + descriptors, scan tiles.  Single block.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kScanBlock) void k_plan(BatchDev b, BatchParams prm) {
-  __shared__ uint32_t lds[16];
-  __shared__ uint32_t s_carry[3];
-  __shared__ uint32_t s_tile0[kScanBlock + 1], s_off[kScanBlock], s_cnt[kScanBlock], s_slot[kScanBlock];
-  const uint32_t T = 2 * prm.C;
-  const uint32_t tq = prm.tile_queries;
-  if (threadIdx.x == 0) { s_carry[0] = 0; s_carry[1] = 0; s_carry[2] = 0; }
-  __syncthreads();
-  for (uint32_t base = 0; base < T; base += kScanBlock) {
-    const uint32_t t = base + threadIdx.x;
-    const uint32_t cnt = t < T ? b.tbl_count[t] : 0u;
-    const uint32_t need = cnt ? 1u : 0u;
-    const uint32_t ntile = (cnt + tq - 1u) / tq;
-    uint32_t tot_c, tot_n, tot_t;
-    const uint32_t inc_c = block_incl_scan_add<uint32_t>(cnt, lds, tot_c);
-    const uint32_t inc_n = block_incl_scan_add<uint32_t>(need, lds, tot_n);
-    const uint32_t inc_t = block_incl_scan_add<uint32_t>(ntile, lds, tot_t);
-    const uint32_t c0 = s_carry[0], n0 = s_carry[1], t0 = s_carry[2];
-    const uint32_t off = c0 + inc_c - cnt;
-    const uint32_t slot = n0 + inc_n - 1;
-    s_tile0[threadIdx.x] = inc_t - ntile;              // exclusive, relative to t0
-    s_off[threadIdx.x] = off;
-    s_cnt[threadIdx.x] = cnt;
-    s_slot[threadIdx.x] = slot;
-    if (threadIdx.x == kScanBlock - 1) s_tile0[kScanBlock] = inc_t;
-    if (t < T) {
-      b.tbl_off[t] = off;
-      if (need) {
-        b.tbl_slot[t] = (int32_t)slot;
-        TableDesc d;
-        d.cls = t % prm.C;
-        d.pct = t < prm.C ? 1.0f : 0.7f;        // core.go:140 (percent 1) / :161 (percent 0.7)
-        b.desc[slot] = d;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) b.kp[slot * 16 + s] = BS_INF;
-      } else {
-        b.tbl_slot[t] = -1;
-      }
-    }
-    __syncthreads();
-    // all threads write this chunk's tiles: tile x belongs to the table whose exclusive offset is the
-    // last one <= x (binary search over the 1024 offsets in LDS)
-    for (uint32_t x = threadIdx.x; x < tot_t; x += kScanBlock) {
-      uint32_t lo = 0, hi = kScanBlock - 1;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (s_tile0[mid] <= x) lo = mid; else hi = mid - 1;
-      }
-      // skip empty tables that share the same offset: advance to the one that really owns x
-      while (lo + 1 < kScanBlock && s_tile0[lo + 1] <= x) ++lo;
-      const uint32_t k = x - s_tile0[lo];
+  // Tile emission.  The lanes of this wave that query the same table become one scan tile: one lane
+  // reserves `count` consecutive slots of the tile-ordered request arrays and appends the tile.  No
+  // sort, no second pass: a scan wave later reads its requests as contiguous rows.
+  const bool has_q = valid && table >= 0;
+  uint32_t pos = 0;
+  unsigned long long todo = __ballot(has_q);
+  while (todo) {
+    const int ldr = __ffsll((long long)todo) - 1;
+    const int32_t t0 = __shfl(table, ldr);
+    const unsigned long long same = __ballot(has_q && table == t0);
+    const uint32_t cnt = (uint32_t)__popcll(same);
+    uint32_t base = 0;
+    if (lane_id() == ldr) {
+      base = atomicAdd(b.qcount, cnt);
+      const uint32_t tid = atomicAdd(b.ntiles, 1u);
       Tile tl;
-      tl.slot = s_slot[lo];
-      tl.q0 = s_off[lo] + tq * k;
-      tl.count = min(tq, s_cnt[lo] - tq * k);
+      tl.slot = (uint32_t)t0;
+      tl.q0 = base;
+      tl.count = cnt;
       tl.pad = 0;
-      b.tiles[t0 + x] = tl;
+      b.tiles[tid] = tl;
+      b.needed[t0] = 1;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) { s_carry[0] = c0 + tot_c; s_carry[1] = n0 + tot_n; s_carry[2] = t0 + tot_t; }
-    __syncthreads();
+    base = (uint32_t)__shfl((int)base, ldr);
+    if (has_q && table == t0) pos = base + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull));
+    todo &= ~same;
   }
-  if (threadIdx.x == 0) {
-    b.tbl_off[T] = s_carry[0];
-    *b.ntables = s_carry[1];
-    *b.ntiles = s_carry[2];
-  }
-}
-
-__global__ void k_scatter(PodsDev pods, BatchDev b, BatchParams prm) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < pods.p;
-  const int32_t table = valid ? b.qtable[i] : -1;
-  const uint32_t slot = wave_aggregated_inc(b.tbl_cursor, (uint32_t)(table < 0 ? 0 : table), table >= 0);
-  if (table >= 0) {
-    // tile order: the scan wave reads its 64*Q requests as contiguous rows, no indirection
-    const uint32_t pos = b.tbl_off[table] + slot;
+  if (has_q) {
+    uint32_t absok = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+      if (s < sh.S()) {
+        const bool pres = q.present & (1u << s);
+        if (!pres || q.v[4 + s] == 0) absok |= 1u << s;       // core.go:688-692
+        if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
+      }
+    }
+    int64_t* dst = b.qreq_s + (size_t)pos * prm.LP;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < prm.LP) dst[j] = j < sh.L() ? q.v[j] : INT64_MIN;
+    b.qflags_s[pos] = q.present | (absok << 16);
     b.qlist[pos] = i;
     b.qpos[i] = pos;
-    b.qflags_s[pos] = b.qflags[i];
-    const int64_t* src = b.qreq + (size_t)i * prm.LP;
-    int64_t* dst = b.qreq_s + (size_t)pos * prm.LP;
-    for (uint32_t j = 0; j < prm.LP; ++j) dst[j] = src[j];
   }
 }
 
@@ -624,14 +577,24 @@ __global__ void k_scatter(PodsDev pods, BatchDev b, BatchParams prm) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kTblChunk = 256;
 
-__global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDev b, BatchParams prm, uint32_t nslots_host) {
+// table id t: fit class t % C, percent 1 for t < C (core.go:140), 0.7 otherwise (core.go:161);
+// `forced` != null: a single explicit descriptor (single-query entry points).
+__device__ __forceinline__ TableDesc table_desc(uint32_t t, uint32_t C, const TableDesc* forced) {
+  if (forced) return *forced;
+  TableDesc d;
+  d.cls = t % C;
+  d.pct = t < C ? 1.0f : 0.7f;
+  return d;
+}
+
+__global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDev b, BatchParams prm, const TableDesc* forced) {
   __shared__ unsigned long long lds64[16];
   const uint32_t slot = blockIdx.x;
-  if (nslots_host == 0 ? slot >= *b.ntables : slot >= nslots_host) return;
+  if (!forced && !b.needed[slot]) return;
   const uint32_t chunk = blockIdx.y, nchunks = gridDim.y;
   const uint32_t k = chunk * kTblChunk + threadIdx.x;
   if (chunk * kTblChunk >= nd.m) return;
-  const TableDesc d = b.desc[slot];
+  const TableDesc d = table_desc(slot, prm.C, forced);
   const uint32_t L = prm.L, S = prm.S, LP = prm.LP;
   int64_t* T = b.tables + (size_t)slot * prm.mcap * LP;
   const bool valid = k < nd.m;
@@ -661,10 +624,10 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDe
   }
 }
 
-__global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev b, BatchParams prm, uint32_t nslots_host) {
+__global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev b, BatchParams prm, const TableDesc* forced) {
   __shared__ unsigned long long off[BS_MAX_LANES];
   const uint32_t slot = blockIdx.x;
-  if (nslots_host == 0 ? slot >= *b.ntables : slot >= nslots_host) return;
+  if (!forced && !b.needed[slot]) return;
   const uint32_t chunk = blockIdx.y + 1, nchunks = gridDim.y + 1;      // chunk 0 needs no fix-up
   if (chunk * kTblChunk >= nd.m) return;
   const uint32_t L = prm.L, LP = prm.LP;
@@ -802,29 +765,20 @@ __device__ __forceinline__ void row_all(const unsigned long long (&nf)[Q], uint3
 }
 
 template <int S, int Q>
-__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m) {
+__device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t k0, uint32_t k1, uint32_t slot,
+                                          const uint32_t (&tq0)[Q], const uint32_t (&tcnt)[Q]) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
   constexpr int U = (L <= 5) ? 2 : 1;            // rows per buffer (SGPR budget: 2 buffers x U x L pairs)
   const int lane = lane_id();
-  const uint32_t tile_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id());
-  if (tile_id >= *b.ntiles) return;
-  const uint32_t k0 = blockIdx.y * prm.seg_len;
-  if (k0 >= m) return;
-  const uint32_t k1 = min(m, k0 + prm.seg_len);
-  const Tile tl = b.tiles[tile_id];
-  const uint32_t slot = __builtin_amdgcn_readfirstlane(tl.slot);
-  const uint32_t q0 = __builtin_amdgcn_readfirstlane(tl.q0);
-  const uint32_t cnt = __builtin_amdgcn_readfirstlane(tl.count);
 
   int64_t r[Q][L];
   uint32_t pos[Q], myk[Q], qf[Q];
   unsigned long long nf[Q];                      // lanes still looking for their first row
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    const uint32_t qi = (uint32_t)q * 64u + (uint32_t)lane;
-    const bool valid = qi < cnt;
-    pos[q] = q0 + qi;                            // sorted position: requests are contiguous per tile
+    const bool valid = (uint32_t)lane < tcnt[q];
+    pos[q] = tq0[q] + (uint32_t)lane;            // tile order: the tile's requests are contiguous rows
     myk[q] = BS_INF;
     qf[q] = 0;
     uint32_t seen = 0;
@@ -940,8 +894,45 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
   for (int q = 0; q < Q; ++q)
     if (myk[q] != BS_INF) atomicMin(&b.first_row[pos[q]], myk[q]);
   if (prm.collect_stats && lane == 0) {
+    uint32_t nq = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) nq += tcnt[q];
     atomicAdd((unsigned long long*)&b.stats[0], (unsigned long long)rows_done);
-    atomicAdd((unsigned long long*)&b.stats[1], (unsigned long long)rows_done * cnt);
+    atomicAdd((unsigned long long*)&b.stats[1], (unsigned long long)rows_done * nq);
+  }
+}
+
+// Work loop: item = (pair of tiles, segment of rows).  Tiles come in emission order; two tiles of the
+// same table share one pass over the rows (Q = 2: every row is loaded once for 128 requests), tiles of
+// different tables are scanned one after the other.  The grid is fixed; waves stride over the items.
+template <int S>
+__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t nseg) {
+  const uint32_t ntiles = *b.ntiles;
+  const uint32_t npairs = (ntiles + 1u) >> 1;
+  const uint32_t items = npairs * nseg;
+  const uint32_t stride = gridDim.x * 4u;
+  for (uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id()); w < items; w += stride) {
+    const uint32_t seg = w / npairs, pair = w - seg * npairs;      // consecutive waves: same rows, different tiles
+    const uint32_t k0 = seg * prm.seg_len;
+    if (k0 >= m) continue;
+    const uint32_t k1 = min(m, k0 + prm.seg_len);
+    const Tile ta = b.tiles[2u * pair];
+    const bool has_b = 2u * pair + 1u < ntiles;
+    const Tile tb = b.tiles[has_b ? 2u * pair + 1u : 2u * pair];
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(ta.slot), sb = __builtin_amdgcn_readfirstlane(tb.slot);
+    const uint32_t qa = __builtin_amdgcn_readfirstlane(ta.q0), qb = __builtin_amdgcn_readfirstlane(tb.q0);
+    const uint32_t ca = __builtin_amdgcn_readfirstlane(ta.count), cb = __builtin_amdgcn_readfirstlane(tb.count);
+    if (has_b && sa == sb) {
+      const uint32_t q0s[2] = {qa, qb}, cnts[2] = {ca, cb};
+      scan_core<S, 2>(b, prm, k0, k1, sa, q0s, cnts);
+    } else {
+      const uint32_t q0a[1] = {qa}, cna[1] = {ca};
+      scan_core<S, 1>(b, prm, k0, k1, sa, q0a, cna);
+      if (has_b) {
+        const uint32_t q0b[1] = {qb}, cnb[1] = {cb};
+        scan_core<S, 1>(b, prm, k0, k1, sb, q0b, cnb);
+      }
+    }
   }
 }
 
@@ -1272,8 +1263,15 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
 // ------------------------------------------------------------------------------------------------
 // k_tally / k_ready
 // ------------------------------------------------------------------------------------------------
-__global__ void k_tally(PodsDev pods, GroupsDev gr, BatchDev b, uint32_t run_filter) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// Per-group admit counts with one atomic per distinct group per wave; the LAST block to finish
+// (ticket) then evaluates the quorum predicate of Permit (core.go:303) for every group and re-arms
+// the per-group minima for the next batch — no separate launches for either.
+constexpr int kTallyBlock = 1024;
+
+__global__ __launch_bounds__(kTallyBlock) void k_tally(PodsDev pods, GroupsDev gr, BatchDev b, uint32_t run_filter, uint32_t do_ready,
+                                                        uint32_t rearm) {
+  __shared__ uint32_t s_last;
+  const uint32_t i = blockIdx.x * kTallyBlock + threadIdx.x;
   bool admit = false;
   uint32_t g = 0;
   if (i < pods.p) {
@@ -1286,9 +1284,39 @@ __global__ void k_tally(PodsDev pods, GroupsDev gr, BatchDev b, uint32_t run_fil
     }
   }
   wave_aggregated_inc(b.admit, g, admit);
+  // nobody reads the per-group minima any more in this batch: every block re-arms a slice of them
+  if (rearm) {
+    for (uint32_t gg = i; gg < gr.g; gg += gridDim.x * kTallyBlock) {
+      b.first_elig[gg] = BS_INF;
+      b.first_owner[gg] = BS_INF;
+      b.first_reject[gg] = BS_INF;
+      b.first_pod[gg] = BS_INF;
+    }
+  }
+  if (!do_ready) return;
+  // publish, take a ticket (every wave drains its own atomics before the block-level hand-off)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(&b.ticket[0], 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    b.ticket[0] = 0;
+  }
+  __syncthreads();
+  for (uint32_t gg = threadIdx.x; gg < gr.g; gg += kTallyBlock) {
+    const uint32_t have = gr.matched[gg] + __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b.ready[gg] = have >= (uint32_t)(gr.min_member[gg] - gr.status_scheduled[gg]) ? 1 : 0;
+  }
 }
 
-// quorum predicate of Permit, core.go:303, with every admitted pod counted as matched
+// quorum predicate of Permit, core.go:303, with every admitted pod counted as matched (used after
+// the cross-rank all-reduce of the admit counters)
 __global__ void k_ready(GroupsDev gr, BatchDev b) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= gr.g) return;

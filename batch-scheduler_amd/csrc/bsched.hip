@@ -67,7 +67,8 @@ struct bs_ctx {
   DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
   DevBuf d_epoch, d_nepochs, d_leader_epoch, d_panic_epoch;
   DevBuf d_tcode, d_stage, d_leader_raw, d_qtable, d_qreq, d_qflags, d_first_row, d_qreq_s, d_qflags_s, d_qpos;
-  DevBuf d_tbl_count, d_tbl_off, d_tbl_cursor, d_tbl_slot, d_desc, d_ntables, d_tiles, d_ntiles, d_qlist;
+  DevBuf d_needed, d_qcount, d_ticket, d_desc, d_tiles, d_ntiles, d_qlist;
+  bool scratch_armed = false;   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch;
   DevBuf d_pf_code, d_pf_first_k, d_pf_leader, d_fl_code, d_fl_feasible, d_fl_bitmap, d_admit, d_ready;
   // single-query scratch
@@ -217,12 +218,10 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.qreq_s = c->d_qreq_s.as<int64_t>();
   b.qflags_s = c->d_qflags_s.as<uint32_t>();
   b.qpos = c->d_qpos.as<uint32_t>();
-  b.tbl_count = c->d_tbl_count.as<uint32_t>();
-  b.tbl_off = c->d_tbl_off.as<uint32_t>();
-  b.tbl_cursor = c->d_tbl_cursor.as<uint32_t>();
-  b.tbl_slot = c->d_tbl_slot.as<int32_t>();
+  b.needed = c->d_needed.as<uint32_t>();
+  b.qcount = c->d_qcount.as<uint32_t>();
+  b.ticket = c->d_ticket.as<uint32_t>();
   b.desc = c->d_desc.as<TableDesc>();
-  b.ntables = c->d_ntables.as<uint32_t>();
   b.tiles = c->d_tiles.as<Tile>();
   b.ntiles = c->d_ntiles.as<uint32_t>();
   b.qlist = c->d_qlist.as<uint32_t>();
@@ -267,11 +266,12 @@ int ensure_tables(bs_ctx* c) {
   HIPCHK(c, c->d_kp.reserve((size_t)slots * 16 * sizeof(uint32_t)));
   HIPCHK(c, c->d_chunk_tot.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
   HIPCHK(c, c->d_desc.reserve((size_t)slots * sizeof(TableDesc)));
-  HIPCHK(c, c->d_tbl_count.reserve((size_t)(2 * c->C + 1) * 4));
-  HIPCHK(c, c->d_tbl_off.reserve((size_t)(2 * c->C + 2) * 4));
-  HIPCHK(c, c->d_tbl_cursor.reserve((size_t)(2 * c->C + 1) * 4));
-  HIPCHK(c, c->d_tbl_slot.reserve((size_t)(2 * c->C + 1) * 4));
-  HIPCHK(c, c->d_ntables.reserve(16));
+  HIPCHK(c, c->d_needed.reserve((size_t)(2 * c->C + 1) * 4));
+  HIPCHK(c, c->d_qcount.reserve(16));
+  if (!c->d_ticket.p) {
+    HIPCHK(c, c->d_ticket.reserve(16));
+    HIPCHK(c, hipMemset(c->d_ticket.p, 0, 16));
+  }
   HIPCHK(c, c->d_ntiles.reserve(16));
   HIPCHK(c, c->d_stats.reserve(8 * sizeof(uint64_t)));
   HIPCHK(c, c->d_sq.reserve(4096));
@@ -327,25 +327,24 @@ int upload_fit(bs_ctx* c) {
 }
 
 template <int S>
-void launch_scan_s(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, int q) {
-  if (q == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S, 2>), grid, dim3(256), 0, c->stream, b, p, m);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S, 1>), grid, dim3(256), 0, c->stream, b, p, m);
+void launch_scan_s(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S>), grid, dim3(256), 0, c->stream, b, p, m, nseg);
 }
-void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, int q) {
+void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg) {
   switch (c->S) {
-    case 0: launch_scan_s<0>(c, grid, b, p, m, q); break;
-    case 1: launch_scan_s<1>(c, grid, b, p, m, q); break;
-    case 2: launch_scan_s<2>(c, grid, b, p, m, q); break;
-    case 3: launch_scan_s<3>(c, grid, b, p, m, q); break;
-    case 4: launch_scan_s<4>(c, grid, b, p, m, q); break;
-    case 5: launch_scan_s<5>(c, grid, b, p, m, q); break;
-    case 6: launch_scan_s<6>(c, grid, b, p, m, q); break;
-    case 7: launch_scan_s<7>(c, grid, b, p, m, q); break;
-    case 8: launch_scan_s<8>(c, grid, b, p, m, q); break;
-    case 9: launch_scan_s<9>(c, grid, b, p, m, q); break;
-    case 10: launch_scan_s<10>(c, grid, b, p, m, q); break;
-    case 11: launch_scan_s<11>(c, grid, b, p, m, q); break;
-    default: launch_scan_s<12>(c, grid, b, p, m, q); break;
+    case 0: launch_scan_s<0>(c, grid, b, p, m, nseg); break;
+    case 1: launch_scan_s<1>(c, grid, b, p, m, nseg); break;
+    case 2: launch_scan_s<2>(c, grid, b, p, m, nseg); break;
+    case 3: launch_scan_s<3>(c, grid, b, p, m, nseg); break;
+    case 4: launch_scan_s<4>(c, grid, b, p, m, nseg); break;
+    case 5: launch_scan_s<5>(c, grid, b, p, m, nseg); break;
+    case 6: launch_scan_s<6>(c, grid, b, p, m, nseg); break;
+    case 7: launch_scan_s<7>(c, grid, b, p, m, nseg); break;
+    case 8: launch_scan_s<8>(c, grid, b, p, m, nseg); break;
+    case 9: launch_scan_s<9>(c, grid, b, p, m, nseg); break;
+    case 10: launch_scan_s<10>(c, grid, b, p, m, nseg); break;
+    case 11: launch_scan_s<11>(c, grid, b, p, m, nseg); break;
+    default: launch_scan_s<12>(c, grid, b, p, m, nseg); break;
   }
 }
 
@@ -377,8 +376,9 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
   b2.kp = b.kp + (size_t)slot * 16;
   b2.desc = b.desc + slot;
   b2.chunk_tot = b.chunk_tot + (size_t)slot * cdiv(c->Ncap, 256) * 16;
-  hipLaunchKernelGGL(k_tables_local, dim3(1, nchunks), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, 1u);
-  if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(1, nchunks - 1), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, 1u);
+  const TableDesc* forced = b.desc + slot;
+  hipLaunchKernelGGL(k_tables_local, dim3(1, nchunks), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, forced);
+  if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(1, nchunks - 1), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, forced);
   HIPCHK(c, hipGetLastError());
   *slot_out = slot;
   return BS_OK;
@@ -524,6 +524,7 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_groups = true;
+  c->scratch_armed = false;
   return BS_OK;
 }
 
@@ -636,9 +637,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const uint32_t W = cdiv(N, 64);
   const bool run_filter = stages & BS_STAGE_FILTER;
   if (run_filter) HIPCHK(c, c->d_fl_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
-  const int scan_q = (c->scan_q_override ? (int)c->scan_q_override : (P >= 4096 ? 2 : 1));
-  const uint32_t max_tiles = cdiv(P, 64 * scan_q) + 2 * C;
-  HIPCHK(c, c->d_tiles.reserve((size_t)(max_tiles + 1) * sizeof(Tile)));
+  HIPCHK(c, c->d_tiles.reserve((size_t)(P + 2) * sizeof(Tile)));     // worst case: one tile per query
 
   NodesDev nd = nodes_dev(c);
   GroupsDev gr = groups_dev(c);
@@ -646,23 +645,34 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   BatchDev b = batch_dev(c);
   BatchParams prm = batch_params(c);
   prm.run_filter = run_filter;
-  prm.tile_queries = 64u * (uint32_t)scan_q;
-  prm.seg_len = pick_seg_len(c, cdiv(std::max<uint32_t>(P, 1), prm.tile_queries), c->M);
+  const uint32_t tiles_est = cdiv(std::max<uint32_t>(P, 1), 64);
+  const uint32_t pairs_est = cdiv(tiles_est, 2);
+  prm.tile_queries = 64;
+  prm.seg_len = pick_seg_len(c, pairs_est, c->M);
+  const uint32_t nseg = cdiv(std::max<uint32_t>(c->M, 1), prm.seg_len);
 
-  const uint32_t init_n = std::max(std::max(G, 2 * C), std::max(P, 8u));
   const dim3 blk(256);
   const bool captures_possible = c->n_uncaptured > 0 && P > 0;
   const int ts = c->S <= 4 ? (int)c->S : -1;
+
+  // ---- per-batch resets + eligibility (+ findMaxPG when no first-pod capture can occur)
   TIMED(c, BS_KERNEL_PREPASS, {
-    hipLaunchKernelGGL(k_init, dim3(cdiv(init_n, 256)), blk, 0, c->stream, gr, b, prm, P, captures_possible ? 0u : 1u);
-    if (P) hipLaunchKernelGGL(k_prepass, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, gr, b);
+    if (!c->scratch_armed) hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(G, 4), 256)), blk, 0, c->stream, gr, b);
+    const uint32_t span = std::max(std::max(P, G), (2 * C + 1) * 16);
+    const uint32_t fused = captures_possible ? 0u : 1u;
+    hipLaunchKernelGGL(k_prepass, dim3(cdiv(span, kPrepassBlock) + fused), dim3(kPrepassBlock), 0, c->stream, pd, gr, b, prm,
+                       captures_possible ? 0u : 1u, fused);
     if (captures_possible) {
       hipLaunchKernelGGL(k_epochs_a, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
       hipLaunchKernelGGL(k_epochs_b, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
     }
   });
-  const uint32_t max_epochs = std::min(c->n_uncaptured, P) + 1;
-  TIMED(c, BS_KERNEL_LEADER, hipLaunchKernelGGL(k_leader, dim3(max_epochs), dim3(kLeaderBlock), 0, c->stream, gr, b));
+  c->scratch_armed = false;
+  if (captures_possible) {
+    const uint32_t max_epochs = std::min(c->n_uncaptured, P) + 1;
+    TIMED(c, BS_KERNEL_LEADER, hipLaunchKernelGGL(k_leader, dim3(max_epochs), dim3(kLeaderBlock), 0, c->stream, gr, b));
+  }
+  // ---- decisions that need no node scan, request vectors, scan tiles
   TIMED(c, BS_KERNEL_QUERY, {
     if (P) {
       const dim3 qg(cdiv(P, 256));
@@ -675,20 +685,19 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
         default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<-1>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
       }
     }
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(kScanBlock), 0, c->stream, b, prm);
-    if (P) hipLaunchKernelGGL(k_scatter, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b, prm);
   });
-  {
+  // ---- running-sum tables of the (class, percent) pairs some query uses
+  if (c->M && P) {
     const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
     TIMED(c, BS_KERNEL_TABLES, {
-      hipLaunchKernelGGL(k_tables_local, dim3(2 * C, nchunks), dim3(kTblChunk), 0, c->stream, nd, b, prm, 0u);
-      if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, 0u);
+      hipLaunchKernelGGL(k_tables_local, dim3(2 * C, nchunks), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
+      if (nchunks > 1)
+        hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
     });
+    const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * nseg), 4));
+    TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg));
   }
-  if (c->M && P) {
-    const dim3 grid(cdiv(max_tiles, 4), cdiv(c->M, prm.seg_len));
-    TIMED(c, BS_KERNEL_SCAN, launch_scan(c, grid, b, prm, c->M, scan_q));
-  }
+  // ---- REJECT codes, deny replay, stale-leader propagation, Filter parameters
   TIMED(c, BS_KERNEL_RESOLVE, {
     if (P) {
       hipLaunchKernelGGL(k_reject, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b);
@@ -732,9 +741,14 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   c->last_stages = stages;
   c->batch_pending_finish = false;
   if (stages & BS_STAGE_TALLY) {
+    const bool local_ready = c->nranks == 1;
+    // re-arming is only valid when the group minima were not also needed for capture epochs (cap_epoch is rewritten then)
+    const bool rearm = !captures_possible && !(stages & BS_BATCH_COMMIT);
     TIMED(c, BS_KERNEL_TALLY, {
-      if (P) hipLaunchKernelGGL(k_tally, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, gr, b, run_filter ? 1u : 0u);
+      hipLaunchKernelGGL(k_tally, dim3(std::max<uint32_t>(1, cdiv(P, kTallyBlock))), dim3(kTallyBlock), 0, c->stream, pd, gr, b,
+                         run_filter ? 1u : 0u, local_ready ? 1u : 0u, rearm ? 1u : 0u);
     });
+    c->scratch_armed = rearm;
     if (c->nranks > 1) {
       if (c->comm) {
         // native RCCL: one all-reduce(sum) of the per-group admit counters on the context stream
@@ -748,8 +762,6 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       } else {
         c->batch_pending_finish = true;   // caller reduces bs_group_admit_devptr, then bs_batch_finish
       }
-    } else if (G) {
-      hipLaunchKernelGGL(k_ready, dim3(cdiv(G, 256)), blk, 0, c->stream, gr, b);
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -907,7 +919,8 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
   prm.collect_stats = 0;
   prm.seg_len = pick_seg_len(c, 1, M);
   if (M) {
-    launch_scan(c, dim3(1, cdiv(M, prm.seg_len)), b, prm, M, 1);
+    const uint32_t nseg = cdiv(M, prm.seg_len);
+    launch_scan(c, dim3(cdiv(nseg, 4)), b, prm, M, nseg);
     HIPCHK(c, hipGetLastError());
   }
   uint32_t row = BS_INF;
@@ -930,7 +943,8 @@ int bs_find_max_pg(bs_ctx* c, int32_t* leader, uint32_t* finished, uint8_t* pani
   prm.C = 0;
   prm.collect_stats = 0;
   const uint32_t one = 1;
-  hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(c->G, 8), 256)), dim3(256), 0, c->stream, gr, b, prm, 0u, 1u);
+  hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(c->G, 8), 256)), dim3(256), 0, c->stream, gr, b);
+  c->scratch_armed = false;
   HIPCHK(c, hipMemcpyAsync(b.nepochs, &one, 4, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_leader, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b);
   HIPCHK(c, hipGetLastError());
@@ -1156,12 +1170,14 @@ int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   uint64_t raw[8] = {0};
-  uint32_t nt = 0, ntl = 0;
+  uint32_t nt = 0, nq = 0;
   if (c->d_stats.p) HIPCHK(c, hipMemcpy(raw, c->d_stats.p, sizeof(raw), hipMemcpyDeviceToHost));
-  if (c->d_ntables.p) HIPCHK(c, hipMemcpy(&nt, c->d_ntables.p, 4, hipMemcpyDeviceToHost));
-  if (c->d_ntiles.p) HIPCHK(c, hipMemcpy(&ntl, c->d_ntiles.p, 4, hipMemcpyDeviceToHost));
-  uint32_t nq = 0;
-  if (c->d_tbl_off.p && c->C) HIPCHK(c, hipMemcpy(&nq, c->d_tbl_off.as<uint32_t>() + 2 * c->C, 4, hipMemcpyDeviceToHost));
+  if (c->d_qcount.p) HIPCHK(c, hipMemcpy(&nq, c->d_qcount.p, 4, hipMemcpyDeviceToHost));
+  if (c->d_needed.p && c->C) {
+    std::vector<uint32_t> need(2 * c->C);
+    HIPCHK(c, hipMemcpy(need.data(), c->d_needed.p, need.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t x : need) nt += x ? 1u : 0u;
+  }
   out->scan_rows_executed = raw[0];
   out->scan_evals_executed = raw[1];
   out->scan_queries = nq;
@@ -1169,7 +1185,6 @@ int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {
   out->logical_evals = (uint64_t)c->P * c->N;
   out->filter_evals = (c->last_stages & BS_STAGE_FILTER) ? (uint64_t)c->P * c->N : 0;
   c->collect_stats = 0;
-  (void)ntl;
   return BS_OK;
 }
 
