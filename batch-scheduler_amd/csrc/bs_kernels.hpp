@@ -61,7 +61,10 @@ struct PodsDev {
 };
 
 struct TableDesc { uint32_t cls; float pct; };
-struct Tile { uint32_t slot, q0, count, pad; };
+struct Tile {
+  uint32_t slot, q0, count, pad;
+  int64_t rmin[4];          // per fixed lane: smallest request of the tile (segment pruning)
+};
 
 // per-pod stage bits (scratch)
 constexpr uint8_t ST_ELIG = 1;      // passed core.go:89-110 against the batch-start deny flags
@@ -106,6 +109,7 @@ struct BatchDev {
   uint64_t* stats;          // [8] counters (only touched when collect_stats)
   unsigned long long* chunk_tot;   // [slots][nchunks][16] chunk totals of the two-level table scan
   uint32_t* blk_scratch;    // per-block summaries of the two-level pod scans
+  int64_t* gmax;            // [slot][ceil(mcap/64)][4] per 64-row group: max running sum per fixed lane (pruning)
   // filter
   int64_t* fparams;         // [P][8]: R[4] = pod + maxSingle, M[4] = maxSingle  (fixed lanes)
   uint32_t* fflags;         // [P] bit0 scalar_block (case 2 impossible), bit1 leader_block, bits 8.. fl_code
@@ -186,7 +190,7 @@ __device__ __forceinline__ void leader_block(const GroupsDev& gr, const BatchDev
 constexpr int kPrepassBlock = 512;
 
 __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm, uint32_t no_capture,
-                                                           uint32_t fused_leader) {
+                                                           uint32_t fused_leader, uint32_t side_slot) {
   if (fused_leader && blockIdx.x == gridDim.x - 1) {
     leader_block(gr, b, 0);
     return;
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsD
   const uint32_t i = blockIdx.x * kPrepassBlock + threadIdx.x;
   // resets whose consumers run in later launches
   if (i < gr.g) b.admit[i] = 0;
-  if (i < (2 * prm.C + 1) * 16) b.kp[i] = BS_INF;
+  if (i < (2 * prm.C + 1) * 16 && (i >> 4) != side_slot) b.kp[i] = BS_INF;   // side_slot: being built on the side stream
   if (i < 2 * prm.C + 1) b.needed[i] = 0;
   if (i == 0) {
     *b.ntiles = 0;
@@ -293,6 +297,23 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v
   unsigned long long r = 0;
   for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r = lds[w] > r ? lds[w] : r;
   return r;
+}
+
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int64_t u = __shfl_xor(v, o);
+    v = u > v ? u : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int64_t wave_min_i64(int64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int64_t u = __shfl_xor(v, o);
+    v = u < v ? u : v;
+  }
+  return v;
 }
 
 constexpr int kLeaderBlock = 512;
@@ -531,6 +552,10 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
     const int32_t t0 = __shfl(table, ldr);
     const unsigned long long same = __ballot(has_q && table == t0);
     const uint32_t cnt = (uint32_t)__popcll(same);
+    const bool member = has_q && table == t0;
+    int64_t mn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mn[j] = wave_min_i64(member ? q.v[j] : INT64_MAX);
     uint32_t base = 0;
     if (lane_id() == ldr) {
       base = atomicAdd(b.qcount, cnt);
@@ -540,6 +565,8 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
       tl.q0 = base;
       tl.count = cnt;
       tl.pad = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tl.rmin[j] = mn[j];
       b.tiles[tid] = tl;
       b.needed[t0] = 1;
     }
@@ -618,6 +645,14 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDe
   }
   if (valid)
     for (uint32_t j = L; j < LP; ++j) T[(size_t)k * LP + j] = INT64_MAX;
+  if (chunk == 0) {                    // rows of the first chunk are already final: their group maxima
+    const uint32_t grp = k >> 6, ngroups = (prm.mcap + 63u) >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t mx = wave_max_i64(valid ? T[(size_t)k * LP + j] : INT64_MIN);
+      if (lane_id() == 0 && (chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m) b.gmax[((size_t)slot * ngroups + grp) * 4 + j] = mx;
+    }
+  }
   for (uint32_t s = 0; s < S; ++s) {
     const unsigned long long m = __ballot(valid && (pres & (1u << s)));
     if (m && lane_id() == 0) atomicMin(&b.kp[slot * 16 + s], chunk * kTblChunk + (uint32_t)(threadIdx.x & ~63u) + (uint32_t)(__ffsll((long long)m) - 1));
@@ -638,9 +673,25 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev 
   }
   __syncthreads();
   const uint32_t k = chunk * kTblChunk + threadIdx.x;
-  if (k >= nd.m) return;
+  const bool valid = k < nd.m;
   int64_t* row = b.tables + ((size_t)slot * prm.mcap + k) * LP;
-  for (uint32_t j = 0; j < L; ++j) row[j] = (int64_t)((unsigned long long)row[j] + off[j]);
+  int64_t fixed4[4] = {INT64_MIN, INT64_MIN, INT64_MIN, INT64_MIN};
+  if (valid) {
+    for (uint32_t j = 0; j < L; ++j) {
+      const int64_t v = (int64_t)((unsigned long long)row[j] + off[j]);
+      row[j] = v;
+      if (j < 4) fixed4[j] = v;
+    }
+  }
+  // per 64-row group: max of the running sum per fixed lane — lets k_scan skip groups no request can pass
+  const uint32_t grp = k >> 6, ngroups = (prm.mcap + 63u) >> 6;
+  if ((chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t mx = wave_max_i64(fixed4[j]);
+      if (lane_id() == 0) b.gmax[((size_t)slot * ngroups + grp) * 4 + j] = mx;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -766,7 +817,7 @@ __device__ __forceinline__ void row_all(const unsigned long long (&nf)[Q], uint3
 
 template <int S, int Q>
 __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t k0, uint32_t k1, uint32_t slot,
-                                          const uint32_t (&tq0)[Q], const uint32_t (&tcnt)[Q]) {
+                                          const uint32_t (&tq0)[Q], const uint32_t (&tcnt)[Q], unsigned long long pruned) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
   constexpr int U = (L <= 5) ? 2 : 1;            // rows per buffer (SGPR budget: 2 buffers x U x L pairs)
@@ -811,9 +862,13 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   crow_t T = as_const_rows(b.tables + (size_t)slot * prm.mcap * LP);
   uint32_t rows_done = 0;
   uint32_t a = k0;
+  const uint32_t g0 = k0 >> 6;
   while (a < k1) {
-    // piece [a, e): no kp[s] strictly inside
-    uint32_t e = k1;
+    // 64-row groups in which some fixed lane stays below every request of the tile cannot satisfy anybody
+    const uint32_t gend = min(k1, ((a >> 6) + 1u) << 6);
+    if ((pruned >> ((a >> 6) - g0)) & 1ull) { a = gend; continue; }
+    // piece [a, e): inside one group, no kp[s] strictly inside
+    uint32_t e = gend;
 #pragma unroll
     for (int s = 0; s < S; ++s)
       if (kp[s] > a && kp[s] < e) e = kp[s];
@@ -902,11 +957,29 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   }
 }
 
+// Which 64-row groups of [k0,k1) can be skipped for a tile: a group is dead when, on some fixed lane,
+// even its largest running sum is below the tile's smallest request (then `row >= r` fails for every
+// row of the group and every request of the tile — compareResourceAndRequire cannot return true).
+__device__ __forceinline__ unsigned long long prune_mask(const BatchDev& b, const BatchParams& prm, uint32_t slot, uint32_t k0, uint32_t k1,
+                                                         const int64_t (&rmin)[4], unsigned long long& all_mask) {
+  const uint32_t g0 = k0 >> 6, ng = ((k1 + 63u) >> 6) - g0;          // ng <= 64 (seg_len <= 4096)
+  const uint32_t ngroups = (prm.mcap + 63u) >> 6;
+  bool dead = false;
+  if ((uint32_t)lane_id() < ng) {
+    const int64_t* gm = b.gmax + ((size_t)slot * ngroups + g0 + (uint32_t)lane_id()) * 4;
+    dead = gm[0] < rmin[0] || gm[1] < rmin[1] || gm[2] < rmin[2] || gm[3] < rmin[3];
+  }
+  all_mask = ng >= 64 ? ~0ull : ((1ull << ng) - 1ull);
+  return __ballot(dead);
+}
+
 // Work loop: item = (pair of tiles, segment of rows).  Tiles come in emission order; two tiles of the
 // same table share one pass over the rows (Q = 2: every row is loaded once for 128 requests), tiles of
 // different tables are scanned one after the other.  The grid is fixed; waves stride over the items.
 template <int S>
 __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t nseg) {
+  typedef const __attribute__((address_space(4))) Tile* ctile_t;
+  ctile_t CT = (ctile_t)(uintptr_t)b.tiles;
   const uint32_t ntiles = *b.ntiles;
   const uint32_t npairs = (ntiles + 1u) >> 1;
   const uint32_t items = npairs * nseg;
@@ -916,21 +989,35 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
     const uint32_t k0 = seg * prm.seg_len;
     if (k0 >= m) continue;
     const uint32_t k1 = min(m, k0 + prm.seg_len);
-    const Tile ta = b.tiles[2u * pair];
     const bool has_b = 2u * pair + 1u < ntiles;
-    const Tile tb = b.tiles[has_b ? 2u * pair + 1u : 2u * pair];
-    const uint32_t sa = __builtin_amdgcn_readfirstlane(ta.slot), sb = __builtin_amdgcn_readfirstlane(tb.slot);
-    const uint32_t qa = __builtin_amdgcn_readfirstlane(ta.q0), qb = __builtin_amdgcn_readfirstlane(tb.q0);
-    const uint32_t ca = __builtin_amdgcn_readfirstlane(ta.count), cb = __builtin_amdgcn_readfirstlane(tb.count);
+    const uint32_t ia = 2u * pair, ib = has_b ? 2u * pair + 1u : 2u * pair;
+    const uint32_t sa = CT[ia].slot, sb = CT[ib].slot;
+    const uint32_t qa = CT[ia].q0, qb = CT[ib].q0;
+    const uint32_t ca = CT[ia].count, cb = CT[ib].count;
+    int64_t ra[4], rb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ra[j] = CT[ia].rmin[j]; rb[j] = CT[ib].rmin[j]; }
+    unsigned long long all;
     if (has_b && sa == sb) {
+      int64_t rm[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rm[j] = ra[j] < rb[j] ? ra[j] : rb[j];
+      const unsigned long long pruned = prune_mask(b, prm, sa, k0, k1, rm, all);
+      if ((pruned & all) == all) continue;
       const uint32_t q0s[2] = {qa, qb}, cnts[2] = {ca, cb};
-      scan_core<S, 2>(b, prm, k0, k1, sa, q0s, cnts);
+      scan_core<S, 2>(b, prm, k0, k1, sa, q0s, cnts, pruned);
     } else {
-      const uint32_t q0a[1] = {qa}, cna[1] = {ca};
-      scan_core<S, 1>(b, prm, k0, k1, sa, q0a, cna);
+      const unsigned long long pa = prune_mask(b, prm, sa, k0, k1, ra, all);
+      if ((pa & all) != all) {
+        const uint32_t q0a[1] = {qa}, cna[1] = {ca};
+        scan_core<S, 1>(b, prm, k0, k1, sa, q0a, cna, pa);
+      }
       if (has_b) {
-        const uint32_t q0b[1] = {qb}, cnb[1] = {cb};
-        scan_core<S, 1>(b, prm, k0, k1, sb, q0b, cnb);
+        const unsigned long long pb = prune_mask(b, prm, sb, k0, k1, rb, all);
+        if ((pb & all) != all) {
+          const uint32_t q0b[1] = {qb}, cnb[1] = {cb};
+          scan_core<S, 1>(b, prm, k0, k1, sb, q0b, cnb, pb);
+        }
       }
     }
   }

@@ -57,6 +57,11 @@ struct bs_ctx {
 
   // ---- groups
   uint32_t G = 0, n_uncaptured = 0;
+  std::vector<uint32_t> h_gmatched, h_gcls;
+  std::vector<uint8_t> h_gflags;
+  int32_t steady_table = -1;        // the one table every reservation query uses when no capture can occur, -1 unknown
+  hipStream_t stream2 = nullptr;    // side stream: that table is built while the pod pre-pass runs
+  hipEvent_t ev_scan_done = nullptr, ev_tables = nullptr;
   DevBuf d_gmm, d_gsc, d_gmatched, d_gflags, d_gcls, d_gminres, d_gmrpres, d_gocc;
 
   // ---- pods
@@ -69,7 +74,7 @@ struct bs_ctx {
   DevBuf d_tcode, d_stage, d_leader_raw, d_qtable, d_qreq, d_qflags, d_first_row, d_qreq_s, d_qflags_s, d_qpos;
   DevBuf d_needed, d_qcount, d_ticket, d_desc, d_tiles, d_ntiles, d_qlist;
   bool scratch_armed = false;   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
-  DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch;
+  DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax;
   DevBuf d_pf_code, d_pf_first_k, d_pf_leader, d_fl_code, d_fl_feasible, d_fl_bitmap, d_admit, d_ready;
   // single-query scratch
   DevBuf d_sq;
@@ -78,7 +83,7 @@ struct bs_ctx {
   uint32_t rank = 0, nranks = 1;
   uint32_t* ext_admit = nullptr;     // caller-owned device memory for the admit counters
   int32_t sop_leader0 = -1;
-  uint32_t last_stages = 0;
+  uint32_t last_stages = 0, batch_seq = 0;
   bool batch_pending_finish = false;
   uint32_t seg_len_override = 0, scan_q_override = 0, target_waves = 8192, collect_stats = 0;
   bs_batch_stats stats{};
@@ -111,7 +116,9 @@ inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 int timer_begin(bs_ctx* c, uint32_t id, size_t* slot) {
   *slot = (size_t)-1;
   if (!c->cfg.enable_timing) return BS_OK;
-  if (c->cfg.enable_timing == 1 && id != BS_KERNEL_SCAN && id != BS_KERNEL_FILTER) return BS_OK;
+  // mode 1: only the two dominant kernels, and only every 8th batch — an event pair costs a few
+  // microseconds of stream time, sampling keeps the timed region representative
+  if (c->cfg.enable_timing == 1 && ((id != BS_KERNEL_SCAN && id != BS_KERNEL_FILTER) || (c->batch_seq & 7u) != 0)) return BS_OK;
   if (c->events_used == c->events.size()) {
     EventPair ep{};
     HIPCHK(c, hipEventCreate(&ep.a));
@@ -230,6 +237,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.stats = c->d_stats.as<uint64_t>();
   b.chunk_tot = c->d_chunk_tot.as<unsigned long long>();
   b.blk_scratch = c->d_blk_scratch.as<uint32_t>();
+  b.gmax = c->d_gmax.as<int64_t>();
   b.fparams = c->d_fparams.as<int64_t>();
   b.fflags = c->d_fflags.as<uint32_t>();
   b.pf_code = c->d_pf_code.as<uint8_t>();
@@ -265,6 +273,7 @@ int ensure_tables(bs_ctx* c) {
   HIPCHK(c, c->d_tables.reserve(bytes));
   HIPCHK(c, c->d_kp.reserve((size_t)slots * 16 * sizeof(uint32_t)));
   HIPCHK(c, c->d_chunk_tot.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
+  HIPCHK(c, c->d_gmax.reserve((size_t)slots * cdiv(c->Ncap, 64) * 4 * 8));
   HIPCHK(c, c->d_desc.reserve((size_t)slots * sizeof(TableDesc)));
   HIPCHK(c, c->d_needed.reserve((size_t)(2 * c->C + 1) * 4));
   HIPCHK(c, c->d_qcount.reserve(16));
@@ -355,8 +364,8 @@ uint32_t pick_seg_len(const bs_ctx* c, uint32_t tiles, uint32_t m) {
   uint32_t nseg = std::max<uint32_t>(1, target_waves / std::max<uint32_t>(1, tiles));
   nseg = std::min<uint32_t>(nseg, cdiv(m, 64));
   uint32_t seg = cdiv(m, nseg);
-  seg = cdiv(seg, 32) * 32;
-  return std::max<uint32_t>(seg, 32);
+  seg = cdiv(seg, 64) * 64;                                    // whole 64-row pruning groups, at most 64 of them
+  return std::min<uint32_t>(std::max<uint32_t>(seg, 64), 4096);
 }
 
 // Build the running-sum table for (cls, pct) in the scratch slot (last one) — single queries.
@@ -376,11 +385,36 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
   b2.kp = b.kp + (size_t)slot * 16;
   b2.desc = b.desc + slot;
   b2.chunk_tot = b.chunk_tot + (size_t)slot * cdiv(c->Ncap, 256) * 16;
+  b2.gmax = b.gmax + (size_t)slot * cdiv(c->Ncap, 64) * 4;
   const TableDesc* forced = b.desc + slot;
   hipLaunchKernelGGL(k_tables_local, dim3(1, nchunks), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, forced);
   if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(1, nchunks - 1), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, forced);
   HIPCHK(c, hipGetLastError());
   *slot_out = slot;
+  return BS_OK;
+}
+
+// After the group state changed: re-arm the scratch and learn, for the no-capture case, which single
+// table the batch will query — findMaxPG (on the device) decides it: leader with matched > 0 means every
+// other group's pods reserve for it at percent 0.7 against the leader's fit class (core.go:157-161).
+int analyse_groups(bs_ctx* c) {
+  c->steady_table = -1;
+  if (!c->G) { c->scratch_armed = false; return BS_OK; }
+  GroupsDev gr = groups_dev(c);
+  BatchDev b = batch_dev(c);
+  const uint32_t one = 1;
+  hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(c->G, 8), 256)), dim3(256), 0, c->stream, gr, b);
+  HIPCHK(c, hipMemcpyAsync(b.nepochs, &one, 4, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_leader, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b);
+  HIPCHK(c, hipGetLastError());
+  int32_t l = -1;
+  uint8_t pn = 0;
+  HIPCHK(c, hipMemcpyAsync(&l, b.leader_epoch, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&pn, b.panic_epoch, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->scratch_armed = true;
+  if (c->n_uncaptured == 0 && !pn && l >= 0 && c->have_fit && c->h_gmatched[l] > 0 && c->h_gcls[l] < c->C)
+    c->steady_table = (int32_t)(c->C + c->h_gcls[l]);
   return BS_OK;
 }
 
@@ -427,6 +461,12 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     delete c;
     return BS_ERR_NO_DEVICE;
   }
+  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_scan_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return BS_ERR_NO_DEVICE;
+  }
   if (const char* e = std::getenv("BS_SEG_LEN")) c->seg_len_override = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("BS_SCAN_Q")) { int q = std::atoi(e); c->scan_q_override = (q == 1 || q == 2) ? (uint32_t)q : 0; }
   if (const char* e = std::getenv("BS_TARGET_WAVES")) c->target_waves = std::max(1, std::atoi(e));
@@ -444,6 +484,9 @@ int bs_destroy(bs_ctx* c) {
     destroy_t f = (destroy_t)dlsym(c->rccl_handle, "ncclCommDestroy");
     if (f) f(c->comm);
   }
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->ev_scan_done) (void)hipEventDestroy(c->ev_scan_done);
+  if (c->ev_tables) (void)hipEventDestroy(c->ev_tables);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return BS_OK;
@@ -481,7 +524,9 @@ int bs_fit_load(bs_ctx* c, uint32_t n_classes, const uint32_t* fit_bits) {
   c->C = n_classes;
   c->fit_words = cdiv(c->N, 32);
   c->h_fit.assign(fit_bits, fit_bits + (size_t)n_classes * c->fit_words);
-  return upload_fit(c);
+  rc = upload_fit(c);
+  if (rc == BS_OK && c->have_groups) rc = analyse_groups(c);
+  return rc;
 }
 
 int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
@@ -521,11 +566,13 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
     HIPCHK(c, hipMemcpyAsync(c->d_gocc.p, g->occupied_by, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
     for (uint32_t i = 0; i < G; ++i)
       if (!(g->flags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+    c->h_gmatched.assign(g->matched, g->matched + G);
+    c->h_gcls.assign(g->cls, g->cls + G);
+    c->h_gflags.assign(g->flags, g->flags + G);
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_groups = true;
-  c->scratch_armed = false;
-  return BS_OK;
+  return analyse_groups(c);
 }
 
 int bs_groups_read(bs_ctx* c, bs_groups_soa* g) {
@@ -654,6 +701,28 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const dim3 blk(256);
   const bool captures_possible = c->n_uncaptured > 0 && P > 0;
   const int ts = c->S <= 4 ? (int)c->S : -1;
+  bool commit_dirty = false;
+  // No capture possible and the leader has matched pods: every scan query of the batch uses ONE known
+  // table (analyse_groups).  Build it on the side stream while the pod pre-pass and k_query run.
+  const bool side_tables = !captures_possible && c->steady_table >= 0 && c->M && P && c->cfg.enable_timing < 2;
+  const uint32_t side_slot = side_tables ? (uint32_t)c->steady_table : 0xFFFFFFFFu;
+  const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
+  if (side_tables) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_scan_done, 0));      // the previous batch's scan is done with the tables
+    TableDesc d{side_slot % C, side_slot < C ? 1.0f : 0.7f};
+    HIPCHK(c, hipMemcpyAsync(b.desc + side_slot, &d, sizeof(d), hipMemcpyHostToDevice, c->stream2));
+    HIPCHK(c, hipMemsetAsync(b.kp + (size_t)side_slot * 16, 0xFF, 16 * sizeof(uint32_t), c->stream2));
+    BatchDev b2 = b;                                                     // blockIdx.x 0 == side_slot
+    b2.tables = b.tables + (size_t)side_slot * prm.mcap * prm.LP;
+    b2.kp = b.kp + (size_t)side_slot * 16;
+    b2.chunk_tot = b.chunk_tot + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
+    b2.gmax = b.gmax + (size_t)side_slot * cdiv(c->Ncap, 64) * 4;
+    const TableDesc* forced = b.desc + side_slot;
+    hipLaunchKernelGGL(k_tables_local, dim3(1, nchunks), dim3(kTblChunk), 0, c->stream2, nd, b2, prm, forced);
+    if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(1, nchunks - 1), dim3(kTblChunk), 0, c->stream2, nd, b2, prm, forced);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_tables, c->stream2));
+  }
 
   // ---- per-batch resets + eligibility (+ findMaxPG when no first-pod capture can occur)
   TIMED(c, BS_KERNEL_PREPASS, {
@@ -661,7 +730,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     const uint32_t span = std::max(std::max(P, G), (2 * C + 1) * 16);
     const uint32_t fused = captures_possible ? 0u : 1u;
     hipLaunchKernelGGL(k_prepass, dim3(cdiv(span, kPrepassBlock) + fused), dim3(kPrepassBlock), 0, c->stream, pd, gr, b, prm,
-                       captures_possible ? 0u : 1u, fused);
+                       captures_possible ? 0u : 1u, fused, side_slot);
     if (captures_possible) {
       hipLaunchKernelGGL(k_epochs_a, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
       hipLaunchKernelGGL(k_epochs_b, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
@@ -688,14 +757,18 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   });
   // ---- running-sum tables of the (class, percent) pairs some query uses
   if (c->M && P) {
-    const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
-    TIMED(c, BS_KERNEL_TABLES, {
-      hipLaunchKernelGGL(k_tables_local, dim3(2 * C, nchunks), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
-      if (nchunks > 1)
-        hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
-    });
+    if (side_tables) {
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_tables, 0));
+    } else {
+      TIMED(c, BS_KERNEL_TABLES, {
+        hipLaunchKernelGGL(k_tables_local, dim3(2 * C, nchunks), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
+        if (nchunks > 1)
+          hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
+      });
+    }
     const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * nseg), 4));
     TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg));
+    HIPCHK(c, hipEventRecord(c->ev_scan_done, c->stream));
   }
   // ---- REJECT codes, deny replay, stale-leader propagation, Filter parameters
   TIMED(c, BS_KERNEL_RESOLVE, {
@@ -733,12 +806,16 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       c->sop_leader0 = last;
     }
     // the committed capture may have given every group a pod
-    std::vector<uint8_t> fl(G);
-    if (G) HIPCHK(c, hipMemcpy(fl.data(), c->d_gflags.p, G, hipMemcpyDeviceToHost));
+    if (G) {
+      HIPCHK(c, hipMemcpy(c->h_gflags.data(), c->d_gflags.p, G, hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(c->h_gcls.data(), c->d_gcls.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+    }
     c->n_uncaptured = 0;
-    for (uint32_t i = 0; i < G; ++i) if (!(fl[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+    for (uint32_t i = 0; i < G; ++i) if (!(c->h_gflags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+    commit_dirty = true;
   }
   c->last_stages = stages;
+  c->batch_seq++;
   c->batch_pending_finish = false;
   if (stages & BS_STAGE_TALLY) {
     const bool local_ready = c->nranks == 1;
@@ -765,6 +842,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     }
   }
   HIPCHK(c, hipGetLastError());
+  if (commit_dirty) return analyse_groups(c);
   return BS_OK;
 }
 
@@ -889,7 +967,7 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
   // scratch layout (bytes): 0 ntables | 64 ntiles | 128 Tile | 192 qlist | 256 qflags | 320 first_row | 512 qreq[LP]
   uint8_t* sq = c->d_sq.as<uint8_t>();
   struct { uint32_t ntiles; } h_nt{1};
-  Tile tl{slot, 0, 1, 0};
+  Tile tl{slot, 0, 1, 0, {0, 0, 0, 0}};
   uint32_t zero = 0, inf = BS_INF, qflags = 0;
   int64_t q[BS_MAX_LANES];
   for (uint32_t j = 0; j < LP; ++j) q[j] = INT64_MIN;
@@ -902,6 +980,7 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
     q[4 + s] = pres ? req[4 + s] : INT64_MIN;
   }
   qflags = (req_present & 0xFFFu) | (absok << 16);
+  for (uint32_t j = 0; j < 4; ++j) tl.rmin[j] = q[j];
   HIPCHK(c, hipMemcpyAsync(sq + 64, &h_nt, 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(sq + 128, &tl, sizeof(tl), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(sq + 192, &zero, 4, hipMemcpyHostToDevice, c->stream));
@@ -1096,7 +1175,9 @@ int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
       if (fit[cl][n]) c->h_fit[(size_t)cl * c->fit_words + (n >> 5)] |= 1u << (n & 31);
   rc = upload_nodes(c);
   if (rc) return rc;
-  return upload_fit(c);
+  rc = upload_fit(c);
+  if (rc == BS_OK && c->have_groups) rc = analyse_groups(c);
+  return rc;
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -80,10 +80,11 @@ def main():
     bsa = importlib.import_module("batch-scheduler_amd")
     soa, synth = bsa.soa, bsa.synth
     dist = None
-    if world > 1:
+    if world > 1 or bool(int(os.environ.get("BS_FORCE_DIST", "0"))):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
@@ -99,23 +100,27 @@ def main():
     ctx.load_groups(groups)
     ctx.load_pods(pods)
     admit_t = None
-    if world > 1:
+    lib_stream = None
+    if dist is not None:
         ctx.set_shard(rank, world)
         admit_t = torch.zeros(groups.g, dtype=torch.int32, device=f"cuda:{local_rank}")
         ctx.bind_admit(admit_t.data_ptr())
+        # run the collective stream-ordered against the library's HIP stream: no host synchronisation per step
+        lib_stream = torch.cuda.ExternalStream(ctx.stream(), device=f"cuda:{local_rank}")
+
+    force_dist = bool(int(os.environ.get("BS_FORCE_DIST", "0")))   # exercise the collective path at world size 1
 
     def step():
         ctx.run(stages)
-        if world > 1:
-            ctx.sync()                         # counters complete on the library stream
-            dist.all_reduce(admit_t)           # ONE RCCL all-reduce (sum) of per-group admit counts
-            torch.cuda.current_stream().synchronize()
-            ctx.finish()                       # quorum bits from the reduced counters
+        if world > 1 or force_dist:
+            with torch.cuda.stream(lib_stream):
+                dist.all_reduce(admit_t)       # ONE RCCL all-reduce (sum) of per-group admit counts, ordered after k_tally
+            ctx.finish()                       # quorum bits from the reduced counters (same stream, after the collective)
 
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -127,7 +132,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -194,7 +199,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
