@@ -25,6 +25,27 @@ def hipcc() -> str:
     return exe
 
 
+HOST_LIB_PATH = os.path.join(HERE, "libbsched_host.so")
+HOST_SRC = os.path.join(HERE, "host", "bs_host.cpp")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """The C++ host-side mirror of the reference's ScheduleOperation; links against libbsched.so."""
+    build()
+    deps = [HOST_SRC, os.path.join(HERE, "..", "include", "bsched.h"), LIB_PATH]
+    if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
+        return HOST_LIB_PATH
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB_PATH, HOST_SRC, "-L" + HERE, "-lbsched",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + res.stdout + res.stderr)
+    return HOST_LIB_PATH
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -49,3 +70,4 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
 
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

@@ -1,0 +1,153 @@
+"""Python face of the C++ host-side mirror (libbsched_host.so) of the reference's ScheduleOperation.
+
+Same entry points and argument meaning as pkg/scheduler/core/core.go (PreFilter / Filter / Permit /
+PostBind / Compare) and the batch release of batchscheduler.go:254-344, one pod at a time, TTL caches
+on a virtual clock.  All node arithmetic goes through the HIP library (bs_find_max_pg,
+bs_cluster_fits, bs_filter_one): no GPU, no decisions.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from . import capi, soa
+
+SECOND = 1_000_000_000
+PERMIT_READY, PERMIT_WAITING, PERMIT_NOT_MATCHED, PERMIT_NOT_FOUND = 0, 1, 2, 3
+
+HOST_SYMBOLS = ["bsh_create", "bsh_destroy", "bsh_set_time", "bsh_time", "bsh_gpu_calls", "bsh_add_group", "bsh_prefilter", "bsh_filter",
+                "bsh_permit", "bsh_postbind", "bsh_less", "bsh_start_batch", "bsh_group_matched", "bsh_group_status_scheduled",
+                "bsh_group_flags", "bsh_group_denied", "bsh_ttl_new", "bsh_ttl_free", "bsh_ttl_set", "bsh_ttl_add", "bsh_ttl_get",
+                "bsh_ttl_delete", "bsh_ttl_count"]
+
+_hlib = None
+
+
+def load_host_library():
+    global _hlib
+    if _hlib is None:
+        path = _build.HOST_LIB_PATH
+        if not os.path.exists(path):
+            raise capi.BsError(-2, "load_host_library", f"{path} not built")
+        capi.load_library()          # libbsched.so first (RTLD_GLOBAL not needed: DT_NEEDED + rpath $ORIGIN)
+        L = C.CDLL(path)
+        vp, u64, i64, u32, i32, u8 = C.c_void_p, C.c_uint64, C.c_int64, C.c_uint32, C.c_int32, C.c_uint8
+        P = C.POINTER
+        L.bsh_create.restype = vp
+        L.bsh_create.argtypes = [vp, u32, i64]
+        L.bsh_destroy.argtypes = [vp]
+        L.bsh_set_time.argtypes = [vp, i64]
+        L.bsh_time.restype = i64
+        L.bsh_time.argtypes = [vp]
+        L.bsh_gpu_calls.restype = u64
+        L.bsh_gpu_calls.argtypes = [vp]
+        L.bsh_add_group.restype = i32
+        L.bsh_add_group.argtypes = [vp, u32, u32, i64, i64, u64, P(i64), u32]
+        L.bsh_prefilter.argtypes = [vp, u64, u64, i32, P(i64), u32, u32, u64, P(u32)]
+        L.bsh_filter.argtypes = [vp, u64, i32, P(i64), u32, u32, P(u8), P(u8)]
+        L.bsh_permit.argtypes = [vp, u64, u64, i32, u32, P(u8)]
+        L.bsh_postbind.argtypes = [vp, i32]
+        L.bsh_less.argtypes = [vp, i32, i32, i64, i32, i32, i64]
+        L.bsh_start_batch.restype = u32
+        L.bsh_start_batch.argtypes = [vp, i32, P(u64), P(u32), u32]
+        for n in ("bsh_group_matched", "bsh_group_status_scheduled", "bsh_group_flags"):
+            getattr(L, n).restype = u32
+            getattr(L, n).argtypes = [vp, i32]
+        L.bsh_group_denied.argtypes = [vp, i32]
+        L.bsh_ttl_new.restype = vp
+        L.bsh_ttl_free.argtypes = [vp]
+        L.bsh_ttl_set.argtypes = [vp, u64, u64, i64, i64]
+        L.bsh_ttl_add.argtypes = [vp, u64, u64, i64, i64]
+        L.bsh_ttl_get.argtypes = [vp, u64, i64, P(u64)]
+        L.bsh_ttl_delete.argtypes = [vp, u64]
+        L.bsh_ttl_count.restype = u32
+        L.bsh_ttl_count.argtypes = [vp, i64]
+        _hlib = L
+    return _hlib
+
+
+class ScheduleOperation:
+    """core.go ScheduleOperation over one capi.Context (which holds the node snapshot)."""
+
+    def __init__(self, ctx: capi.Context, max_schedule_time_s: float = 60.0):
+        self._lib = load_host_library()
+        self.ctx = ctx
+        self.L = ctx.L
+        self._h = C.c_void_p(self._lib.bsh_create(ctx._h, ctx.S, int(max_schedule_time_s * SECOND)))
+        if not self._h:
+            raise capi.BsError(-1, "bsh_create")
+
+    def close(self):
+        if self._h:
+            self._lib.bsh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _lanes(self, req):
+        a = np.zeros(soa.MAX_LANES, np.int64)
+        if req is not None:
+            a[: len(req)] = req
+        return a, a.ctypes.data_as(C.POINTER(C.c_int64))
+
+    def set_time(self, seconds: float):
+        self._lib.bsh_set_time(self._h, int(round(seconds * SECOND)))
+
+    @property
+    def gpu_calls(self) -> int:
+        return int(self._lib.bsh_gpu_calls(self._h))
+
+    def add_group(self, min_member: int, status_scheduled: int = 0, max_schedule_time_s: float | None = None, creation_ts: int = 0,
+                  name_rank: int = 0, min_resources=None, min_resources_present: int = 0) -> int:
+        keep, ptr = self._lanes(min_resources)
+        null = C.POINTER(C.c_int64)()
+        mst = -1 if max_schedule_time_s is None else int(max_schedule_time_s * SECOND)
+        return int(self._lib.bsh_add_group(self._h, min_member, status_scheduled, mst, creation_ts, name_rank,
+                                           ptr if min_resources is not None else null, min_resources_present))
+
+    def PreFilter(self, uid: int, name: int, group: int, req, present: int = 0, cls: int = 0, owner: int = 0):
+        keep, ptr = self._lanes(req)
+        fk = C.c_uint32(0)
+        code = self._lib.bsh_prefilter(self._h, uid, name, group, ptr, present, cls, owner, C.byref(fk))
+        if code < 0:
+            raise capi.BsError(code, "bsh_prefilter")
+        return int(code), int(fk.value)
+
+    def Filter(self, uid: int, group: int, req, present: int, node: int):
+        keep, ptr = self._lanes(req)
+        fl, fn = C.c_uint8(0), C.c_uint8(0)
+        rc = self._lib.bsh_filter(self._h, uid, group, ptr, present, node, C.byref(fl), C.byref(fn))
+        if rc != 0:
+            raise capi.BsError(rc, "bsh_filter")
+        return int(fl.value), int(fn.value)
+
+    def Permit(self, uid: int, name: int, group: int, node: int):
+        ready = C.c_uint8(0)
+        code = self._lib.bsh_permit(self._h, uid, name, group, node, C.byref(ready))
+        return bool(ready.value), int(code)
+
+    def PostBind(self, group: int):
+        self._lib.bsh_postbind(self._h, group)
+
+    def Less(self, a, b) -> bool:
+        """a, b = (group, priority, queue_timestamp) — batchscheduler.go:214 -> core.go:368"""
+        return bool(self._lib.bsh_less(self._h, a[0], a[1], a[2], b[0], b[1], b[2]))
+
+    def StartBatchSchedule(self, group: int, cap: int = 4096):
+        uids = (C.c_uint64 * cap)()
+        nodes = (C.c_uint32 * cap)()
+        n = int(self._lib.bsh_start_batch(self._h, group, uids, nodes, cap))
+        return [(int(uids[i]), int(nodes[i])) for i in range(min(n, cap))]
+
+    def group_state(self, g: int) -> dict:
+        f = int(self._lib.bsh_group_flags(self._h, g))
+        return dict(matched=int(self._lib.bsh_group_matched(self._h, g)), status_scheduled=int(self._lib.bsh_group_status_scheduled(self._h, g)),
+                    scheduled_latch=bool(f & 1), has_pod=bool(f & 2), has_minres=bool(f & 4), phase=f >> 8,
+                    denied=bool(self._lib.bsh_group_denied(self._h, g)))
