@@ -1,19 +1,21 @@
 // bs_kernels.hpp — gfx950 kernels of the batched PreFilter / Filter / Permit path.
 //
-// Pipeline of one batch (bs_batch_run), all on one HIP stream:
-//   k_init      reset per-batch scratch
-//   k_prepass   per pod: eligibility (core.go:89-110), first eligible pod / first owner per group
-//   k_epochs    queue-order prefix count of first-pod captures (core.go:486-488) -> epoch per pod
-//   k_leader    findMaxPG (core.go:701-739) once per epoch (candidate set grows with captures)
+// Pipeline of one batch (bs_batch_run); steady state = 8 launches on the main stream, the table build
+// overlapped on a side stream:
+//   k_prepass   per-batch resets; per pod: eligibility (core.go:89-110), first eligible pod / first owner
+//               per group; LAST block: findMaxPG (core.go:701-739) when no first-pod capture can occur
+//   [k_init, k_epochs_a/b, k_leader   only when groups without a pod exist: capture epochs, one
+//               findMaxPG per epoch]
 //   k_query     per pod: fillOccupiedObj check, branch A/B/C/D of core.go:127-166, request vector
-//               (getPreAllocatedResource core.go:774-793 [+ pod request :157-159]) and scan table id
-//   k_plan/k_scatter   bucket queries by (fit class, percent) table, build 64-query tiles
-//   k_tables    singleNodeResource (core.go:634-670) + running sums of core.go:602,621 per table
+//               (getPreAllocatedResource core.go:774-793 [+ pod request :157-159]); the lanes of a wave
+//               that query the same table become one scan tile (no sort pass)
+//   k_tables_local/fix   singleNodeResource (core.go:634-670) + running sums of core.go:602,621 per
+//               table, per-group maxima for pruning           [side stream in steady state]
 //   k_scan      THE hot kernel: exists k : prefix_k >= request (core.go:623), first such k
 //   k_reject/k_final   REJECT codes, deny-cache replay in queue order (core.go:105-110,142,163),
-//               stale sop.maxFinishedPG propagation, first_k -> node list index
-//   k_filter_params/k_filter   computeResourceSatisfied (core.go:514-564) pods x nodes bitmap
-//   k_tally/k_ready    per-group admit counts and the quorum predicate core.go:303
+//               stale sop.maxFinishedPG propagation, first_k -> node list index, Filter parameters
+//   k_filter    computeResourceSatisfied (core.go:514-564) pods x nodes bitmap + feasible counts
+//   k_tally     per-group admit counts; last block: quorum predicate core.go:303, re-arm for next batch
 //
 // No MFMA anywhere: this is int64 compare/add work (north_star).  Lanes of a wave are pods
 // (queries); node rows are wave-uniform and arrive through the scalar cache, so one 64-bit
@@ -89,11 +91,9 @@ struct BatchDev {
   uint8_t* stage;
   int32_t* leader_raw;      // leader findMaxPG returned for this pod (valid iff ST_REACH6)
   int32_t* qtable;          // scan table id (class + C * (pct==0.7)), -1 none
-  int64_t* qreq;            // [P][LP] effective request (absent scalar -> INT64_MIN)
-  uint32_t* qflags;         // bits 0..11 request key present, bits 16..27 "zero/absent" (passes w/o left key)
   uint32_t* first_row;      // [P] by SORTED query position: min table row satisfying the request (INF none)
-  int64_t* qreq_s;          // [P][LP] requests in tile order (k_scatter)
-  uint32_t* qflags_s;       // [P]
+  int64_t* qreq_s;          // [P][LP] effective requests in tile order (absent scalar -> INT64_MIN)
+  uint32_t* qflags_s;       // [P] bits 0..11 request key present, bits 16..27 "zero/absent" (passes w/o left key)
   uint32_t* qpos;           // [P] pod -> sorted position (valid iff ST_QUERY)
   // tables / tiles
   uint32_t* needed;         // [2C+1] table (class + C*(pct==0.7)) is used by some query of the batch
@@ -108,6 +108,7 @@ struct BatchDev {
   uint32_t* kp;             // [slots][16] first row at which scalar key s exists in the running sum
   uint64_t* stats;          // [8] counters (only touched when collect_stats)
   unsigned long long* chunk_tot;   // [slots][nchunks][16] chunk totals of the two-level table scan
+  uint32_t* chunk_kp;       // [slots][nchunks][16] per chunk: first row at which scalar key s is present
   uint32_t* blk_scratch;    // per-block summaries of the two-level pod scans
   int64_t* gmax;            // [slot][ceil(mcap/64)][4] per 64-row group: max running sum per fixed lane (pruning)
   // filter
@@ -190,7 +191,7 @@ __device__ __forceinline__ void leader_block(const GroupsDev& gr, const BatchDev
 constexpr int kPrepassBlock = 512;
 
 __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm, uint32_t no_capture,
-                                                           uint32_t fused_leader, uint32_t side_slot) {
+                                                           uint32_t fused_leader) {
   if (fused_leader && blockIdx.x == gridDim.x - 1) {
     leader_block(gr, b, 0);
     return;
@@ -198,7 +199,6 @@ __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsD
   const uint32_t i = blockIdx.x * kPrepassBlock + threadIdx.x;
   // resets whose consumers run in later launches
   if (i < gr.g) b.admit[i] = 0;
-  if (i < (2 * prm.C + 1) * 16 && (i >> 4) != side_slot) b.kp[i] = BS_INF;   // side_slot: being built on the side stream
   if (i < 2 * prm.C + 1) b.needed[i] = 0;
   if (i == 0) {
     *b.ntiles = 0;
@@ -614,48 +614,90 @@ __device__ __forceinline__ TableDesc table_desc(uint32_t t, uint32_t C, const Ta
   return d;
 }
 
+template <int TS>
 __global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDev b, BatchParams prm, const TableDesc* forced) {
-  __shared__ unsigned long long lds64[16];
+  __shared__ unsigned long long s_wtot[BS_MAX_LANES][4];     // per resource lane, per wave: wave total
+  __shared__ uint32_t s_kp[BS_MAX_SCALARS];
   const uint32_t slot = blockIdx.x;
-  if (!forced && !b.needed[slot]) return;
   const uint32_t chunk = blockIdx.y, nchunks = gridDim.y;
-  const uint32_t k = chunk * kTblChunk + threadIdx.x;
   if (chunk * kTblChunk >= nd.m) return;
-  const TableDesc d = table_desc(slot, prm.C, forced);
-  const uint32_t L = prm.L, S = prm.S, LP = prm.LP;
-  int64_t* T = b.tables + (size_t)slot * prm.mcap * LP;
+  const uint32_t k = chunk * kTblChunk + threadIdx.x;
   const bool valid = k < nd.m;
-  uint32_t n = 0, pres = 0;
-  bool fit = false;
-  if (valid) {
-    n = nd.kmap[k];
-    const uint32_t* fitrow = nd.fit + (size_t)d.cls * nd.fit_words;
-    fit = ((fitrow[n >> 5] >> (n & 31u)) & 1u) && !(nd.flags[n] & BS_NODE_TAINT_ERR);
-    if (fit) pres = nd.apres[n] & nd.rpres[n];
+  // level 0: everything that does not depend on another load
+  const uint32_t need = forced ? 1u : b.needed[slot];
+  const uint32_t n = valid ? nd.kmap[k] : 0u;
+  if (!need) return;
+  const TableDesc d = table_desc(slot, prm.C, forced);
+  const Shape<TS> sh(prm.S);
+  const uint32_t L = sh.L(), S = sh.S(), LP = prm.LP;
+  int64_t* T = b.tables + (size_t)slot * prm.mcap * LP;
+  // level 1: every field of the node, issued together
+  const uint32_t fw = nd.fit[(size_t)d.cls * nd.fit_words + (n >> 5)];
+  const uint8_t fl = nd.flags[n];
+  const uint32_t ap = nd.apres[n], rp = nd.rpres[n];
+  int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    if (j < L) {
+      al[j] = nd.alloc[(size_t)j * nd.stride + n];
+      rq[j] = nd.req[(size_t)j * nd.stride + n];
+    }
   }
-  for (uint32_t j = 0; j < L; ++j) {
-    unsigned long long left = 0;
-    const bool lane_live = fit && (j < 4 || (pres & (1u << (j - 4))));
-    if (lane_live && !(j == BS_LANE_EPH && !prm.eph_gate))
-      left = (unsigned long long)wsub(scale_f32(nd.alloc[(size_t)j * nd.stride + n], d.pct), nd.req[(size_t)j * nd.stride + n]);
-    unsigned long long total;
-    const unsigned long long incl = block_incl_scan_add<unsigned long long>(left, lds64, total);
-    if (valid) T[(size_t)k * LP + j] = (int64_t)incl;
-    if (threadIdx.x == 0) b.chunk_tot[((size_t)slot * nchunks + chunk) * 16 + j] = total;
+  const bool fit = valid && ((fw >> (n & 31u)) & 1u) && !(fl & BS_NODE_TAINT_ERR);
+  const uint32_t pres = fit ? (ap & rp) : 0u;
+  if (threadIdx.x < BS_MAX_SCALARS) s_kp[threadIdx.x] = BS_INF;
+  // wave-level inclusive scans of every lane, then ONE exchange of the wave totals
+  unsigned long long incl[BS_MAX_LANES];
+  const int w = wave_id();
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    if (j < L) {
+      const bool live = fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
+      const unsigned long long left = live ? (unsigned long long)wsub(scale_f32(al[j], d.pct), rq[j]) : 0ull;
+      incl[j] = wave_incl_scan_add<unsigned long long>(left);
+      if (lane_id() == 63) s_wtot[j][w] = incl[j];
+    }
   }
-  if (valid)
-    for (uint32_t j = L; j < LP; ++j) T[(size_t)k * LP + j] = INT64_MAX;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    if (j < L) {
+      unsigned long long off = 0, tot = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned long long x = s_wtot[j][i];
+        if (i < w) off += x;
+        tot += x;
+      }
+      incl[j] += off;
+      if (valid) T[(size_t)k * LP + j] = (int64_t)incl[j];
+      if (threadIdx.x == 0) b.chunk_tot[((size_t)slot * nchunks + chunk) * 16 + j] = tot;
+    } else if (j < LP && valid) {
+      T[(size_t)k * LP + j] = INT64_MAX;
+    }
+  }
   if (chunk == 0) {                    // rows of the first chunk are already final: their group maxima
     const uint32_t grp = k >> 6, ngroups = (prm.mcap + 63u) >> 6;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t mx = wave_max_i64(valid ? T[(size_t)k * LP + j] : INT64_MIN);
+      const int64_t mx = wave_max_i64(valid ? (int64_t)incl[j] : INT64_MIN);
       if (lane_id() == 0 && (chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m) b.gmax[((size_t)slot * ngroups + grp) * 4 + j] = mx;
     }
   }
-  for (uint32_t s = 0; s < S; ++s) {
-    const unsigned long long m = __ballot(valid && (pres & (1u << s)));
-    if (m && lane_id() == 0) atomicMin(&b.kp[slot * 16 + s], chunk * kTblChunk + (uint32_t)(threadIdx.x & ~63u) + (uint32_t)(__ffsll((long long)m) - 1));
+  // first row of this chunk at which key s joins the running sum; the fix-up pass (or, for a single
+  // chunk, this block) reduces the per-chunk values to kp[s] — no pre-initialised global needed
+#pragma unroll
+  for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+    if (s < S) {
+      const unsigned long long m = __ballot(valid && (pres & (1u << s)));
+      if (m && lane_id() == 0) atomicMin(&s_kp[s], chunk * kTblChunk + (uint32_t)(threadIdx.x & ~63u) + (uint32_t)(__ffsll((long long)m) - 1));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const uint32_t v = threadIdx.x < BS_MAX_SCALARS ? s_kp[threadIdx.x] : BS_INF;
+    b.chunk_kp[((size_t)slot * nchunks + chunk) * 16 + threadIdx.x] = v;
+    if (nchunks == 1) b.kp[slot * 16 + threadIdx.x] = v;
   }
 }
 
@@ -664,6 +706,12 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev 
   const uint32_t slot = blockIdx.x;
   if (!forced && !b.needed[slot]) return;
   const uint32_t chunk = blockIdx.y + 1, nchunks = gridDim.y + 1;      // chunk 0 needs no fix-up
+  if (blockIdx.y == 0 && threadIdx.x < 16) {                           // kp[s] = min over the chunks' first rows
+    uint32_t v = BS_INF;
+    for (uint32_t cc = 0; cc < nchunks; ++cc)
+      if (cc * kTblChunk < nd.m) v = min(v, b.chunk_kp[((size_t)slot * nchunks + cc) * 16 + threadIdx.x]);
+    b.kp[slot * 16 + threadIdx.x] = v;
+  }
   if (chunk * kTblChunk >= nd.m) return;
   const uint32_t L = prm.L, LP = prm.LP;
   if (threadIdx.x < L) {
@@ -1254,22 +1302,33 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
   crow_t FP = as_const_rows(b.fparams);
   cflag_t FF = (cflag_t)(uintptr_t)b.fflags;
   uint32_t cnt = 0;
-  for (uint32_t w = w0; w < w1; w += NB) {
-    int64_t l[NB][4];
-    unsigned long long okmask[NB], in_range[NB], nlf[NB];
-    uint32_t vlo[NB], vhi[NB];
+  // node blocks are double-buffered: the loads of step w+NB are in flight during the pod loop of step w
+  int64_t l[NB][4], ln[NB][4];
+  uint8_t nfl[NB], nfln[NB];
+  auto load_blocks = [&](uint32_t w, int64_t (&dst)[NB][4], uint8_t (&fl)[NB]) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const uint32_t n = (w + nb) * 64u + (uint32_t)lane;
       const bool nvalid = (w + nb) < w1 && n < nd.n;
-      bool node_ok = false;
+      fl[nb] = 0xFF;                                    // invalid
 #pragma unroll
-      for (int j = 0; j < 4; ++j) l[nb][j] = INT64_MIN;
+      for (int j = 0; j < 4; ++j) dst[nb][j] = INT64_MIN;
       if (nvalid) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) l[nb][j] = nd.left4[(size_t)j * nd.stride + n];
-        node_ok = !(nd.flags[n] & (BS_NODE_NIL | BS_NODE_NO_NODE));              // core.go:442-449
+        for (int j = 0; j < 4; ++j) dst[nb][j] = nd.left4[(size_t)j * nd.stride + n];
+        fl[nb] = nd.flags[n];
       }
+    }
+  };
+  load_blocks(w0, l, nfl);
+  for (uint32_t w = w0; w < w1; w += NB) {
+    if (w + NB < w1) load_blocks(w + NB, ln, nfln);
+    unsigned long long okmask[NB], in_range[NB], nlf[NB];
+    uint32_t vlo[NB], vhi[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const bool nvalid = nfl[nb] != 0xFF;
+      const bool node_ok = nvalid && !(nfl[nb] & (BS_NODE_NIL | BS_NODE_NO_NODE));     // core.go:442-449
       in_range[nb] = __ballot(nvalid);
       okmask[nb] = __ballot(node_ok);
       // case 3 for the tile's common leader: nodes that cannot hold one leader member
@@ -1343,6 +1402,12 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
         if (want_bitmap) b.fl_bitmap[(size_t)(w + nb) * pods.p + p0 + lane] = word;
       }
     }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      nfl[nb] = nfln[nb];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) l[nb][j] = ln[nb][j];
+    }
   }
   if (mine && cnt) atomicAdd(&b.fl_feasible[p0 + lane], cnt);
 }
@@ -1372,6 +1437,7 @@ __global__ __launch_bounds__(kTallyBlock) void k_tally(PodsDev pods, GroupsDev g
   }
   wave_aggregated_inc(b.admit, g, admit);
   // nobody reads the per-group minima any more in this batch: every block re-arms a slice of them
+  // (and the key-presence rows of the table the next batch builds on the side stream)
   if (rearm) {
     for (uint32_t gg = i; gg < gr.g; gg += gridDim.x * kTallyBlock) {
       b.first_elig[gg] = BS_INF;
@@ -1474,11 +1540,6 @@ __global__ void k_node_left(NodesDev nd, uint32_t cls, float pct, uint32_t L, in
     left[(size_t)j * nd.n + n] = v;
   }
   present[n] = pres;
-}
-
-__global__ void k_scale_probe(const int64_t* a, const float* pct, int64_t* out, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = scale_f32(a[i], pct[i]);
 }
 
 }  // namespace bs

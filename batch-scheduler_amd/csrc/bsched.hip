@@ -71,10 +71,11 @@ struct bs_ctx {
   // ---- batch scratch / outputs
   DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
   DevBuf d_epoch, d_nepochs, d_leader_epoch, d_panic_epoch;
-  DevBuf d_tcode, d_stage, d_leader_raw, d_qtable, d_qreq, d_qflags, d_first_row, d_qreq_s, d_qflags_s, d_qpos;
+  DevBuf d_tcode, d_stage, d_leader_raw, d_qtable, d_first_row, d_qreq_s, d_qflags_s, d_qpos;
   DevBuf d_needed, d_qcount, d_ticket, d_desc, d_tiles, d_ntiles, d_qlist;
-  bool scratch_armed = false;   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
-  DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax;
+  bool scratch_armed = false;
+  bool side_ready = false;      // desc[] / kp[] of the side-stream table are in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
+  DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
   DevBuf d_pf_code, d_pf_first_k, d_pf_leader, d_fl_code, d_fl_feasible, d_fl_bitmap, d_admit, d_ready;
   // single-query scratch
   DevBuf d_sq;
@@ -219,8 +220,6 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.stage = c->d_stage.as<uint8_t>();
   b.leader_raw = c->d_leader_raw.as<int32_t>();
   b.qtable = c->d_qtable.as<int32_t>();
-  b.qreq = c->d_qreq.as<int64_t>();
-  b.qflags = c->d_qflags.as<uint32_t>();
   b.first_row = c->d_first_row.as<uint32_t>();
   b.qreq_s = c->d_qreq_s.as<int64_t>();
   b.qflags_s = c->d_qflags_s.as<uint32_t>();
@@ -238,6 +237,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.chunk_tot = c->d_chunk_tot.as<unsigned long long>();
   b.blk_scratch = c->d_blk_scratch.as<uint32_t>();
   b.gmax = c->d_gmax.as<int64_t>();
+  b.chunk_kp = c->d_chunk_kp.as<uint32_t>();
   b.fparams = c->d_fparams.as<int64_t>();
   b.fflags = c->d_fflags.as<uint32_t>();
   b.pf_code = c->d_pf_code.as<uint8_t>();
@@ -274,6 +274,7 @@ int ensure_tables(bs_ctx* c) {
   HIPCHK(c, c->d_kp.reserve((size_t)slots * 16 * sizeof(uint32_t)));
   HIPCHK(c, c->d_chunk_tot.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
   HIPCHK(c, c->d_gmax.reserve((size_t)slots * cdiv(c->Ncap, 64) * 4 * 8));
+  HIPCHK(c, c->d_chunk_kp.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 4));
   HIPCHK(c, c->d_desc.reserve((size_t)slots * sizeof(TableDesc)));
   HIPCHK(c, c->d_needed.reserve((size_t)(2 * c->C + 1) * 4));
   HIPCHK(c, c->d_qcount.reserve(16));
@@ -357,6 +358,18 @@ void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, 
   }
 }
 
+void launch_tables_local(bs_ctx* c, hipStream_t st, dim3 grid, const NodesDev& nd, const BatchDev& b, const BatchParams& p, const TableDesc* forced) {
+  const dim3 tb(kTblChunk);
+  switch (c->S <= 4 ? (int)c->S : -1) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local<0>), grid, tb, 0, st, nd, b, p, forced); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local<1>), grid, tb, 0, st, nd, b, p, forced); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local<2>), grid, tb, 0, st, nd, b, p, forced); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local<3>), grid, tb, 0, st, nd, b, p, forced); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local<4>), grid, tb, 0, st, nd, b, p, forced); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local<-1>), grid, tb, 0, st, nd, b, p, forced); break;
+  }
+}
+
 uint32_t pick_seg_len(const bs_ctx* c, uint32_t tiles, uint32_t m) {
   if (c->seg_len_override) return c->seg_len_override;
   if (m == 0) return 64;
@@ -377,7 +390,6 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
   BatchParams p = batch_params(c);
   TableDesc d{cls, pct};
   HIPCHK(c, hipMemcpyAsync(b.desc + slot, &d, sizeof(d), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(b.kp + (size_t)slot * 16, 0xFF, 16 * sizeof(uint32_t), c->stream));
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
   // one slot: shift the table / kp / desc / chunk-total bases so that blockIdx.x 0 == slot
   BatchDev b2 = b;
@@ -386,8 +398,9 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
   b2.desc = b.desc + slot;
   b2.chunk_tot = b.chunk_tot + (size_t)slot * cdiv(c->Ncap, 256) * 16;
   b2.gmax = b.gmax + (size_t)slot * cdiv(c->Ncap, 64) * 4;
+  b2.chunk_kp = b.chunk_kp + (size_t)slot * cdiv(c->Ncap, 256) * 16;
   const TableDesc* forced = b.desc + slot;
-  hipLaunchKernelGGL(k_tables_local, dim3(1, nchunks), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, forced);
+  launch_tables_local(c, c->stream, dim3(1, nchunks), nodes_dev(c), b2, p, forced);
   if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(1, nchunks - 1), dim3(kTblChunk), 0, c->stream, nodes_dev(c), b2, p, forced);
   HIPCHK(c, hipGetLastError());
   *slot_out = slot;
@@ -399,6 +412,7 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
 // other group's pods reserve for it at percent 0.7 against the leader's fit class (core.go:157-161).
 int analyse_groups(bs_ctx* c) {
   c->steady_table = -1;
+  c->side_ready = false;
   if (!c->G) { c->scratch_armed = false; return BS_OK; }
   GroupsDev gr = groups_dev(c);
   BatchDev b = batch_dev(c);
@@ -413,8 +427,11 @@ int analyse_groups(bs_ctx* c) {
   HIPCHK(c, hipMemcpyAsync(&pn, b.panic_epoch, 1, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->scratch_armed = true;
-  if (c->n_uncaptured == 0 && !pn && l >= 0 && c->have_fit && c->h_gmatched[l] > 0 && c->h_gcls[l] < c->C)
+  if (c->n_uncaptured == 0 && !pn && l >= 0 && c->have_fit && c->h_gmatched[l] > 0 && c->h_gcls[l] < c->C) {
     c->steady_table = (int32_t)(c->C + c->h_gcls[l]);
+    TableDesc d{c->h_gcls[l], 0.7f};                       // descriptor of the side-stream table, written once
+    HIPCHK(c, hipMemcpy(b.desc + c->steady_table, &d, sizeof(d), hipMemcpyHostToDevice));
+  }
   return BS_OK;
 }
 
@@ -613,8 +630,6 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, c->d_stage.reserve(n));
   HIPCHK(c, c->d_leader_raw.reserve(n * 4));
   HIPCHK(c, c->d_qtable.reserve(n * 4));
-  HIPCHK(c, c->d_qreq.reserve(n * c->LP * 8));
-  HIPCHK(c, c->d_qflags.reserve(n * 4));
   HIPCHK(c, c->d_first_row.reserve(n * 4));
   HIPCHK(c, c->d_qreq_s.reserve(n * c->LP * 8));
   HIPCHK(c, c->d_qflags_s.reserve(n * 4));
@@ -705,20 +720,18 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   // No capture possible and the leader has matched pods: every scan query of the batch uses ONE known
   // table (analyse_groups).  Build it on the side stream while the pod pre-pass and k_query run.
   const bool side_tables = !captures_possible && c->steady_table >= 0 && c->M && P && c->cfg.enable_timing < 2;
-  const uint32_t side_slot = side_tables ? (uint32_t)c->steady_table : 0xFFFFFFFFu;
+  const uint32_t side_slot = side_tables ? (uint32_t)c->steady_table : 0u;
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
   if (side_tables) {
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_scan_done, 0));      // the previous batch's scan is done with the tables
-    TableDesc d{side_slot % C, side_slot < C ? 1.0f : 0.7f};
-    HIPCHK(c, hipMemcpyAsync(b.desc + side_slot, &d, sizeof(d), hipMemcpyHostToDevice, c->stream2));
-    HIPCHK(c, hipMemsetAsync(b.kp + (size_t)side_slot * 16, 0xFF, 16 * sizeof(uint32_t), c->stream2));
     BatchDev b2 = b;                                                     // blockIdx.x 0 == side_slot
     b2.tables = b.tables + (size_t)side_slot * prm.mcap * prm.LP;
     b2.kp = b.kp + (size_t)side_slot * 16;
     b2.chunk_tot = b.chunk_tot + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
     b2.gmax = b.gmax + (size_t)side_slot * cdiv(c->Ncap, 64) * 4;
+    b2.chunk_kp = b.chunk_kp + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
     const TableDesc* forced = b.desc + side_slot;
-    hipLaunchKernelGGL(k_tables_local, dim3(1, nchunks), dim3(kTblChunk), 0, c->stream2, nd, b2, prm, forced);
+    launch_tables_local(c, c->stream2, dim3(1, nchunks), nd, b2, prm, forced);
     if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(1, nchunks - 1), dim3(kTblChunk), 0, c->stream2, nd, b2, prm, forced);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_tables, c->stream2));
@@ -730,13 +743,14 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     const uint32_t span = std::max(std::max(P, G), (2 * C + 1) * 16);
     const uint32_t fused = captures_possible ? 0u : 1u;
     hipLaunchKernelGGL(k_prepass, dim3(cdiv(span, kPrepassBlock) + fused), dim3(kPrepassBlock), 0, c->stream, pd, gr, b, prm,
-                       captures_possible ? 0u : 1u, fused, side_slot);
+                       captures_possible ? 0u : 1u, fused);
     if (captures_possible) {
       hipLaunchKernelGGL(k_epochs_a, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
       hipLaunchKernelGGL(k_epochs_b, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
     }
   });
   c->scratch_armed = false;
+  c->side_ready = false;
   if (captures_possible) {
     const uint32_t max_epochs = std::min(c->n_uncaptured, P) + 1;
     TIMED(c, BS_KERNEL_LEADER, hipLaunchKernelGGL(k_leader, dim3(max_epochs), dim3(kLeaderBlock), 0, c->stream, gr, b));
@@ -761,14 +775,14 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_tables, 0));
     } else {
       TIMED(c, BS_KERNEL_TABLES, {
-        hipLaunchKernelGGL(k_tables_local, dim3(2 * C, nchunks), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
+        launch_tables_local(c, c->stream, dim3(2 * C, nchunks), nd, b, prm, (const TableDesc*)nullptr);
         if (nchunks > 1)
           hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
       });
     }
     const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * nseg), 4));
     TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg));
-    HIPCHK(c, hipEventRecord(c->ev_scan_done, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_scan_done, c->stream));   // the tables may be rebuilt (next batch) from here on
   }
   // ---- REJECT codes, deny replay, stale-leader propagation, Filter parameters
   TIMED(c, BS_KERNEL_RESOLVE, {
@@ -826,6 +840,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
                          run_filter ? 1u : 0u, local_ready ? 1u : 0u, rearm ? 1u : 0u);
     });
     c->scratch_armed = rearm;
+    c->side_ready = rearm && side_tables;
     if (c->nranks > 1) {
       if (c->comm) {
         // native RCCL: one all-reduce(sum) of the per-group admit counters on the context stream
