@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "bs_nodes_apply", "bs_nodes_count",
     "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
     "bs_batch_run", "bs_batch_sync", "bs_batch_read",
-    "bs_shard_set", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
+    "bs_shard_set", "bs_reduce_external", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
     "bs_timing_reset", "bs_timing_get", "bs_kernel_name", "bs_batch_stats_get",
 ]
 
@@ -102,6 +102,7 @@ def load_library(path: str | None = None):
     L.bs_batch_read.argtypes = [vp, P(soa.BatchOutStruct)]
     L.bs_shard_set.argtypes = [vp, u32, u32]
     L.bs_group_admit_devptr.argtypes = [vp, P(vp), P(u32)]
+    L.bs_reduce_external.argtypes = [vp, u32]
     L.bs_group_admit_bind.argtypes = [vp, vp]
     L.bs_stream.argtypes = [vp, P(vp)]
     L.bs_comm_unique_id.argtypes = [P(u8)]
@@ -272,6 +273,9 @@ class Context:
     # -- sharding / measurement
     def set_shard(self, rank: int, nranks: int):
         self._chk(self._lib.bs_shard_set(self._h, rank, nranks), "bs_shard_set")
+
+    def reduce_external(self, on: bool = True):
+        self._chk(self._lib.bs_reduce_external(self._h, 1 if on else 0), "bs_reduce_external")
 
     def admit_devptr(self):
         p, n = C.c_void_p(), C.c_uint32(0)

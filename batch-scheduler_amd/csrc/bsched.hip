@@ -82,6 +82,7 @@ struct bs_ctx {
   uint32_t table_slots = 0, table_mcap = 0;
 
   uint32_t rank = 0, nranks = 1;
+  bool reduce_external = false;      // partitioned mode: tally only, the caller reduces and calls bs_batch_finish
   uint32_t* ext_admit = nullptr;     // caller-owned device memory for the admit counters
   int32_t sop_leader0 = -1;
   uint32_t last_stages = 0, batch_seq = 0;
@@ -670,6 +671,12 @@ int bs_stream(bs_ctx* c, void** stream) {
   return BS_OK;
 }
 
+int bs_reduce_external(bs_ctx* c, uint32_t on) {
+  if (!c) return BS_ERR_INVALID;
+  c->reduce_external = on != 0;
+  return BS_OK;
+}
+
 int bs_group_admit_bind(bs_ctx* c, void* dptr) {
   if (!c) return BS_ERR_INVALID;
   c->ext_admit = reinterpret_cast<uint32_t*>(dptr);
@@ -832,7 +839,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   c->batch_seq++;
   c->batch_pending_finish = false;
   if (stages & BS_STAGE_TALLY) {
-    const bool local_ready = c->nranks == 1;
+    const bool local_ready = c->nranks == 1 && !c->reduce_external;
     // re-arming is only valid when the group minima were not also needed for capture epochs (cap_epoch is rewritten then)
     const bool rearm = !captures_possible && !(stages & BS_BATCH_COMMIT);
     TIMED(c, BS_KERNEL_TALLY, {
@@ -841,7 +848,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     });
     c->scratch_armed = rearm;
     c->side_ready = rearm && side_tables;
-    if (c->nranks > 1) {
+    if (c->nranks > 1 || c->reduce_external) {
       if (c->comm) {
         // native RCCL: one all-reduce(sum) of the per-group admit counters on the context stream
         typedef int (*allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);

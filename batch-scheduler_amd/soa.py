@@ -243,6 +243,11 @@ class Pods:
                           _ptr(self.req_present, C.c_uint32), _ptr(self.cls, C.c_uint32),
                           _ptr(self.owner, C.c_uint64), _ptr(self.flags, C.c_uint8))
 
+    def take(self, idx) -> "Pods":
+        """the sub-batch of pods `idx` (queue order preserved when idx is increasing)"""
+        idx = np.asarray(idx)
+        return Pods(self.group[idx], self.req[:, idx], self.req_present[idx], self.cls[idx], self.owner[idx], self.flags[idx])
+
     def copy(self) -> "Pods":
         return Pods(self.group.copy(), self.req.copy(), self.req_present.copy(), self.cls.copy(),
                     self.owner.copy(), self.flags.copy())

@@ -98,11 +98,24 @@ def main():
     ctx = bsa.Context(scalar_lanes=L - 4, device=local_rank, enable_timing=int(os.environ.get("BS_TIMING", "1")))
     ctx.load_nodes(nodes, fit)
     ctx.load_groups(groups)
+    all_pods = pods
+    partitioned = False
+    if dist is not None and bool((groups.flags & soa.GROUP_HAS_POD).all()):
+        # Steady state (every group has its pod): no pod's decision depends on a pod of another group, so each
+        # rank loads only the pods it owns (whole groups, same ownership rule as the device) and the group
+        # state is replicated.  Otherwise: whole batch on every rank + device-side ownership (bs_shard_set).
+        bdist = importlib.import_module("batch-scheduler_amd.dist")
+        own = bdist.owner_ranks(pods.group, groups.g, world)
+        pods = pods.take(np.nonzero(own == rank)[0])
+        partitioned = True
     ctx.load_pods(pods)
     admit_t = None
     lib_stream = None
     if dist is not None:
-        ctx.set_shard(rank, world)
+        if partitioned:
+            ctx.reduce_external(True)
+        else:
+            ctx.set_shard(rank, world)
         admit_t = torch.zeros(groups.g, dtype=torch.int32, device=f"cuda:{local_rank}")
         ctx.bind_admit(admit_t.data_ptr())
         # run the collective stream-ordered against the library's HIP stream: no host synchronisation per step
@@ -145,7 +158,7 @@ def main():
     stats = ctx.stats_read()
     out = ctx.read(bitmap=False)
 
-    logical = pods.p * nodes.n                        # whole job: every pending pod against every node
+    logical = all_pods.p * nodes.n                    # whole job: every pending pod (all ranks) against every node
     ms_per_step = elapsed / args.steps * 1e3
     value = logical * args.steps / elapsed
 
@@ -195,7 +208,8 @@ def main():
             "config": {"workload": f"{args.config}/{args.scenario}: {pods.p} pods / {groups.g} groups / {nodes.n} nodes, "
                                    f"{L} int64 lanes (cpu, mem, eph, pods{', gpu' if L > 4 else ''}), seed {args.seed}",
                        "stages": "prefilter+filter+tally+ready" if args.stages == "all" else "prefilter+tally+ready",
-                       "parallelism": f"pod-axis shard x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"pod-axis shard x{world}, " + ("pods partitioned by owning rank" if partitioned else "replicated batch, device-side ownership")
+                                       + ", 1 all-reduce of admit[G]") if dist is not None else "single GPU",
                        "logical_evals_per_step": logical,
                        "scan_evals_executed_per_step": stats["scan_evals_executed"],
                        "filter_evals_per_step": stats["filter_evals"],

@@ -260,6 +260,13 @@ int bs_shard_set(bs_ctx* ctx, uint32_t rank, uint32_t nranks);
 /* Device address of the per-group admit counters (uint32[g]) so the caller's collective
  * (torch.distributed / RCCL all-reduce, sum) can run in place between the two halves. */
 int bs_group_admit_devptr(bs_ctx* ctx, void** dptr, uint32_t* count);
+/* Partitioned mode: the caller loads on each rank ONLY the pods that rank owns (whole groups, group
+ * indices global, group state replicated) and reduces the admit counters itself.  With `on` the batch
+ * stops after the per-group tally (no quorum pass); the caller all-reduces bs_group_admit_devptr and
+ * calls bs_batch_finish.  Decisions equal the single-context batch whenever no first-pod capture can
+ * occur in the batch (every group already has its pod): then no pod's decision depends on a pod of
+ * another group.  Otherwise use bs_shard_set (whole batch on every rank). */
+int bs_reduce_external(bs_ctx* ctx, uint32_t on);
 /* Use caller-owned device memory (uint32[g], e.g. a torch tensor's data_ptr) for the admit counters,
  * so that a framework collective can reduce it in place.  NULL restores the internal buffer. */
 int bs_group_admit_bind(bs_ctx* ctx, void* dptr);
