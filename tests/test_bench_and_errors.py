@@ -1,0 +1,87 @@
+"""bench.py's JSON contract and the ABI's error behaviour (GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_json_contract():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--config", "cfg2",
+                          "--cpu-reps", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line"
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "int64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["logical_evals_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 10e6, "north_star target: >= 10M pod x node fit evaluations/s"
+
+
+def test_error_codes_not_crashes(bsa, soa):
+    capi = bsa.capi
+    nodes, fit, groups, pods, _ = bsa.synth.make("tiny", "warm")
+    with bsa.Context(scalar_lanes=1) as ctx:
+        with pytest.raises(capi.BsError) as e:
+            ctx.run(soa.STAGE_ALL)                       # nothing loaded
+        assert e.value.status == -4                      # BS_ERR_STATE
+        ctx.load_nodes(nodes)
+        with pytest.raises(capi.BsError):
+            ctx.cluster_fits(0, 1.0, [0] * 5)            # fit masks not loaded
+        ctx.load_fit(fit)
+        with pytest.raises(capi.BsError) as e:
+            ctx.cluster_fits(fit.n_classes, 1.0, [0] * 5)   # class out of range
+        assert e.value.status == -1
+        ctx.load_groups(groups)
+        ctx.load_pods(pods)
+        with pytest.raises(capi.BsError):
+            ctx.run(soa.STAGE_FILTER)                    # PREFILTER is mandatory
+        ctx.set_shard(0, 2)
+        with pytest.raises(capi.BsError):
+            ctx.run(soa.STAGE_ALL | soa.BATCH_COMMIT)    # COMMIT is single-rank only
+        with pytest.raises(capi.BsError):
+            ctx.set_shard(3, 2)
+        ctx.set_shard(0, 1)
+        out = ctx.batch(soa.STAGE_ALL)                   # still usable after the errors
+        assert out.pf_code.shape == (pods.p,)
+    with pytest.raises(capi.BsError):
+        bsa.Context(scalar_lanes=13)                     # > BS_MAX_SCALARS
+    with pytest.raises(capi.BsError):
+        bsa.Context(scalar_lanes=0, device=99)           # no such device
+
+
+def test_reference_panics_are_codes(bsa, soa, orc):
+    """MinMember == 0 with Scheduled > 0 divides by zero in findMaxPG (core.go:716-717); Filter without a leader
+    dereferences nil (core.go:525).  Both surface as codes."""
+    import naive_ref as nv
+    a, r = nv.Resource(), nv.Resource()
+    a.Add({"cpu": 8000, "pods": 110})
+    r.Add({"cpu": 0})
+    info = nv.NodeInfo(a, r, 0)
+    pg = nv.PodGroup("ns/z", 0, status_scheduled=2)
+    pgs = nv.PGS(pg)
+    pgs.pod = nv.Pod("rep", "ns/z", {"cpu": 100})
+    cache = {"ns/z": pgs, "ns/y": nv.PGS(nv.PodGroup("ns/y", 3))}
+    pods = [nv.Pod("u1", "ns/y", {"cpu": 100}), nv.Pod("u2", None, {"cpu": 100})]
+    n, f, g, p, _ = nv.to_soa([info], cache, pods, [], 1)
+    exp = orc.Sop(orc.Snapshot(n, f), g).batch(p, soa.STAGE_ALL)
+    with bsa.Context(scalar_lanes=0) as ctx:
+        ctx.load_nodes(n, f)
+        ctx.load_groups(g)
+        ctx.load_pods(p)
+        got = ctx.batch(soa.STAGE_ALL)
+    assert got.pf_code.tolist() == exp.pf_code.tolist() == [soa.PF_PANIC_DIV0, soa.PF_PASS_NOT_GROUPED]
+    assert got.fl_code.tolist() == exp.fl_code.tolist()
