@@ -143,11 +143,13 @@ struct BatchParams {
 
 // kmap: stable compaction of the nodes compareClusterResourceAndRequire does not skip
 // (core.go:606-617); left4: getLeftResource lanes (core.go:460-463).  Single block.
+// Incremental: nodes below `base0` (a multiple of the block size) are unchanged since the last call and
+// contribute `m_before` rows; only [base0, n) is recomputed (node churn: rescan from the first change).
 __global__ __launch_bounds__(kScanBlock) void k_nodes_derive(NodesDev nd, uint32_t* kmap, uint32_t* m_out,
-                                                             int64_t* left4) {
+                                                             int64_t* left4, uint32_t base0, uint32_t m_before) {
   __shared__ uint32_t lds[16];
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < nd.n; base += kScanBlock) {
+  uint32_t carry = m_before;
+  for (uint32_t base = base0; base < nd.n; base += kScanBlock) {
     const uint32_t i = base + threadIdx.x;
     uint32_t keep = 0;
     if (i < nd.n) {

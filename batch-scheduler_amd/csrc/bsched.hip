@@ -291,14 +291,18 @@ int ensure_tables(bs_ctx* c) {
   return BS_OK;
 }
 
-int upload_nodes(bs_ctx* c) {
+// Upload the node mirror from list index `lo` on (0 = everything) and re-derive kmap / left4 from there.
+int upload_nodes(bs_ctx* c, uint32_t lo = 0) {
   const uint32_t N = c->N, L = c->L;
   if (N > c->Ncap || c->Ncap == 0) {
     c->Ncap = std::max<uint32_t>(64, N + N / 4 + 64);
     c->d_tables.release();   // row capacity changed: tables are re-reserved in ensure_tables
+    lo = 0;
   }
   const size_t cap = c->Ncap;
+  const size_t old_cap_bytes = c->d_alloc.cap;
   HIPCHK(c, c->d_alloc.reserve(cap * L * 8));
+  if (c->d_alloc.cap != old_cap_bytes) lo = 0;     // (re)allocated: nothing resident yet
   HIPCHK(c, c->d_nreq.reserve(cap * L * 8));
   HIPCHK(c, c->d_left4.reserve(cap * 4 * 8));
   HIPCHK(c, c->d_apres.reserve(cap * 4));
@@ -306,24 +310,31 @@ int upload_nodes(bs_ctx* c) {
   HIPCHK(c, c->d_nflags.reserve(cap));
   HIPCHK(c, c->d_kmap.reserve(cap * 4));
   HIPCHK(c, c->d_m.reserve(16));
-  if (N) {
+  lo = std::min(lo, N);
+  const uint32_t base0 = (lo / kScanBlock) * kScanBlock;         // derive restarts at a block boundary
+  const uint32_t cnt = N - base0;
+  if (cnt) {
     for (uint32_t j = 0; j < L; ++j) {
-      HIPCHK(c, hipMemcpyAsync(c->d_alloc.as<int64_t>() + j * cap, c->h_alloc.data() + (size_t)j * N, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->d_nreq.as<int64_t>() + j * cap, c->h_nreq.data() + (size_t)j * N, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->d_alloc.as<int64_t>() + j * cap + base0, c->h_alloc.data() + (size_t)j * N + base0, (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->d_nreq.as<int64_t>() + j * cap + base0, c->h_nreq.data() + (size_t)j * N + base0, (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_apres.p, c->h_apres.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_rpres.p, c->h_rpres.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_nflags.p, c->h_nflags.data(), (size_t)N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_apres.as<uint32_t>() + base0, c->h_apres.data() + base0, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_rpres.as<uint32_t>() + base0, c->h_rpres.data() + base0, (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_nflags.as<uint8_t>() + base0, c->h_nflags.data() + base0, (size_t)cnt, hipMemcpyHostToDevice, c->stream));
   }
+  // rows contributed by the unchanged nodes [0, base0): kmap is increasing, so a lower bound finds them
+  uint32_t m_before = 0;
+  if (base0) m_before = (uint32_t)(std::lower_bound(c->h_kmap.begin(), c->h_kmap.end(), base0) - c->h_kmap.begin());
   NodesDev nd = nodes_dev(c);
-  hipLaunchKernelGGL(k_nodes_derive, dim3(1), dim3(kScanBlock), 0, c->stream, nd, c->d_kmap.as<uint32_t>(), c->d_m.as<uint32_t>(), c->d_left4.as<int64_t>());
+  hipLaunchKernelGGL(k_nodes_derive, dim3(1), dim3(kScanBlock), 0, c->stream, nd, c->d_kmap.as<uint32_t>(), c->d_m.as<uint32_t>(), c->d_left4.as<int64_t>(),
+                     base0, m_before);
   HIPCHK(c, hipGetLastError());
   uint32_t m = 0;
   HIPCHK(c, hipMemcpyAsync(&m, c->d_m.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->M = m;
   c->h_kmap.resize(m);
-  if (m) HIPCHK(c, hipMemcpy(c->h_kmap.data(), c->d_kmap.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+  if (m > m_before) HIPCHK(c, hipMemcpy(c->h_kmap.data() + m_before, c->d_kmap.as<uint32_t>() + m_before, (size_t)(m - m_before) * 4, hipMemcpyDeviceToHost));
   c->have_nodes = true;
   return ensure_tables(c);
 }
@@ -1151,8 +1162,10 @@ int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
     al[j].assign(c->h_alloc.begin() + (size_t)j * N, c->h_alloc.begin() + (size_t)(j + 1) * N);
     rq[j].assign(c->h_nreq.begin() + (size_t)j * N, c->h_nreq.begin() + (size_t)(j + 1) * N);
   }
+  uint32_t lo = N;                     // first list index whose content changes
   for (uint32_t d = 0; d < count; ++d) {
     const bs_node_delta& x = deltas[d];
+    lo = std::min(lo, x.kind == BS_DELTA_APPEND ? N : x.index);
     if (x.kind == BS_DELTA_REMOVE) {
       if (x.index >= N) return BS_ERR_INVALID;
       for (uint32_t j = 0; j < L; ++j) { al[j].erase(al[j].begin() + x.index); rq[j].erase(rq[j].begin() + x.index); }
@@ -1195,7 +1208,7 @@ int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
   for (uint32_t cl = 0; cl < C; ++cl)
     for (uint32_t n = 0; n < N; ++n)
       if (fit[cl][n]) c->h_fit[(size_t)cl * c->fit_words + (n >> 5)] |= 1u << (n & 31);
-  rc = upload_nodes(c);
+  rc = upload_nodes(c, lo);            // suffix upload + re-derive from the first changed index
   if (rc) return rc;
   rc = upload_fit(c);
   if (rc == BS_OK && c->have_groups) rc = analyse_groups(c);

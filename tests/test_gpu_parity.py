@@ -232,18 +232,20 @@ def test_max_scalar_lanes(bsa, soa, orc):
                 assert ctx.cluster_fits(cls, 0.7, reqv, pres) == (ok, fk)
 
 
-def test_churn_apply_equals_reload(bsa, soa, orc):
-    """BASELINE config 5 in miniature: a stream of update / append / stable-remove edits."""
+def _churn(bsa, soa, orc, config, scenario, rounds, events, stages, seed):
+    """A stream of node events (40 % requested-update, 30 % append, 30 % stable remove — BASELINE config 5);
+    after every `events` of them the batch is re-scored and compared with a full oracle recompute."""
     capi = bsa.capi
-    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "warm", seed=5)
-    rng = np.random.default_rng(11)
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario, seed=seed)
+    rng = np.random.default_rng(seed + 11)
+    L = nodes.lanes
     alloc, req = nodes.allocatable.copy(), nodes.requested.copy()
     ap, rp, fl = nodes.allocatable_present.copy(), nodes.requested_present.copy(), nodes.flags.copy()
     fitb = fit.to_bool()
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
-        for rnd in range(6):
+        for rnd in range(rounds):
             deltas = []
-            for _ in range(25):
+            for _ in range(events):
                 kind = int(rng.choice([capi.DELTA_UPDATE, capi.DELTA_APPEND, capi.DELTA_REMOVE], p=[0.4, 0.3, 0.3]))
                 n = alloc.shape[1]
                 d = capi.NodeDelta()
@@ -259,8 +261,10 @@ def test_churn_apply_equals_reload(bsa, soa, orc):
                     col_a, col_r = alloc[:, src].copy(), req[:, src].copy()
                     col_r[0] = int(col_a[0] * rng.random())
                     col_r[1] = int(col_a[1] * rng.random())
-                    for j in range(4):
+                    a_p, r_p = int(ap[src]), int(rp[src])
+                    for j in range(L):
                         d.allocatable[j], d.requested[j] = int(col_a[j]), int(col_r[j])
+                    d.allocatable_present, d.requested_present = a_p, r_p
                     d.fit_default, d.n_fit_exceptions = 1, 1
                     exc = int(rng.integers(0, fitb.shape[0]))
                     d.fit_exceptions[0] = exc
@@ -269,11 +273,12 @@ def test_churn_apply_equals_reload(bsa, soa, orc):
                     if kind == capi.DELTA_UPDATE:
                         idx = int(rng.integers(0, n))
                         d.index = idx
-                        alloc[:, idx], req[:, idx], ap[idx], rp[idx], fl[idx] = col_a, col_r, 0, 0, 0
+                        alloc[:, idx], req[:, idx], ap[idx], rp[idx], fl[idx] = col_a, col_r, a_p, r_p, 0
                         fitb[:, idx] = fcol
                     else:
                         alloc, req = np.concatenate([alloc, col_a[:, None]], 1), np.concatenate([req, col_r[:, None]], 1)
-                        ap, rp, fl = np.append(ap, 0).astype(np.uint32), np.append(rp, 0).astype(np.uint32), np.append(fl, 0).astype(np.uint8)
+                        ap, rp = np.append(ap, a_p).astype(np.uint32), np.append(rp, r_p).astype(np.uint32)
+                        fl = np.append(fl, 0).astype(np.uint8)
                         fitb = np.concatenate([fitb, fcol[:, None]], 1)
                 deltas.append(d)
             ctx.apply_node_deltas(deltas)
@@ -281,8 +286,21 @@ def test_churn_apply_equals_reload(bsa, soa, orc):
             cur_fit = soa.FitMasks.from_bool(fitb)
             assert ctx.n == cur_nodes.n
             sop = orc.Sop(orc.Snapshot(cur_nodes, cur_fit), groups)
-            exp = sop.batch(pods, soa.STAGE_ALL)
-            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"churn round {rnd}")
+            exp = sop.batch(pods, stages, bitmap=bool(stages & soa.STAGE_FILTER))
+            got = ctx.batch(stages, bitmap=bool(stages & soa.STAGE_FILTER))
+            assert_batch_equal(got, exp, f"churn round {rnd}", bitmap=bool(stages & soa.STAGE_FILTER))
+
+
+def test_churn_apply_equals_reload(bsa, soa, orc):
+    """BASELINE config 5 in miniature: update / append / stable-remove edits, full batch compared each round."""
+    _churn(bsa, soa, orc, "cfg2", "warm", rounds=8, events=25, stages=soa.STAGE_ALL, seed=5)
+    _churn(bsa, soa, orc, "cfg2", "tail", rounds=4, events=40, stages=soa.STAGE_ALL, seed=6)
+
+
+def test_churn_cfg3_incremental_rescore(bsa, soa, orc):
+    """BASELINE config 5 at size: 10k pods / 5k nodes, 100 events between re-scores (the suffix of the node
+    list from the first changed index is re-uploaded and re-derived), admit / reject identical each time."""
+    _churn(bsa, soa, orc, "cfg3", "tail", rounds=5, events=100, stages=soa.STAGE_PREFILTER | soa.STAGE_TALLY, seed=7)
 
 
 def test_sharded_union_equals_single(bsa, soa, orc):
