@@ -1251,7 +1251,7 @@ __device__ __forceinline__ void filter_pod2(uint32_t pp, const int64_t (&R)[4], 
                "v_writelane_b32 %[vhi1], exec_hi, m0\n\t"
                "s_mov_b64 exec, -1"
                : [vlo0] "+v"(vlo0), [vhi0] "+v"(vhi0), [vlo1] "+v"(vlo1), [vhi1] "+v"(vhi1)
-               : [pp] "s"(pp), [ok0] "s"(ok0), [ok1] "s"(ok1), [R0] "s"(R[0]), [R1] "s"(R[1]), [R2] "s"(R[2]), [R3] "s"(R[3]),
+               : [pp] "s"(pp), [ok0] "s"(ok0), [ok1] "s"(ok1), [R0] "v"(R[0]), [R1] "v"(R[1]), [R2] "v"(R[2]), [R3] "v"(R[3]),
                  [a0] "v"(l0[0]), [a1] "v"(l0[1]), [a2] "v"(l0[2]), [a3] "v"(l0[3]), [b0] "v"(l1[0]), [b1] "v"(l1[1]), [b2] "v"(l1[2]),
                  [b3] "v"(l1[3])
                : "vcc");
@@ -1283,6 +1283,18 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
     const int64_t* src = b.fparams + (size_t)(p0 + lane) * 8 + 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) M[j] = src[j];
+  }
+  __shared__ int64_t s_R[4][64][4];               // per wave: the tile's requests (pod + maxSingle, fixed lanes)
+  {
+    int64_t myR[4] = {0, 0, 0, 0};
+    if (mine) {
+      const int64_t* src = b.fparams + (size_t)(p0 + lane) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) myR[j] = src[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_R[wave_id()][lane][j] = myR[j];
+    __builtin_amdgcn_wave_barrier();               // same wave writes and reads: LDS is in order, keep the compiler honest
   }
   const unsigned long long evmask = __ballot(ev);
   bool uniformM = true;
@@ -1341,26 +1353,20 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
       vhi[nb] = 0;
     }
     if (uniformM) {
-      // software-pipelined over pods: the next pod's request is in flight while this one is compared
-      int64_t RA[4], RB[4];
+      // the tile's 64 requests sit in this wave's LDS slice; a uniform-address ds_read_b128 broadcasts one
+      // into VGPRs (in-order LDS counter: the compiler pipelines four pods per step) — no global/scalar
+      // memory latency inside the pod loop
+      for (uint32_t pp = 0; pp < np; pp += 4) {
+        int64_t R[4][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) RA[j] = FP[(size_t)p0 * 8 + j];
-      BS_S_WAIT_LGKM0();
-      for (uint32_t pp = 0; pp < np; pp += 2) {
-        const uint32_t pn = p0 + min(pp + 1, np - 1);
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t pu = min(pp + (uint32_t)u, np - 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) RB[j] = FP[(size_t)pn * 8 + j];
-        __builtin_amdgcn_sched_barrier(0);
-        filter_pod2(pp, RA, okmask[0], okmask[1], l[0], l[1], vlo[0], vhi[0], vlo[1], vhi[1]);
-        BS_S_WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        const uint32_t pn2 = p0 + min(pp + 2, np - 1);
+          for (int j = 0; j < 4; ++j) R[u][j] = s_R[wave_id()][pu][j];
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) RA[j] = FP[(size_t)pn2 * 8 + j];
-        __builtin_amdgcn_sched_barrier(0);
-        filter_pod2(min(pp + 1, np - 1), RB, okmask[0], okmask[1], l[0], l[1], vlo[0], vhi[0], vlo[1], vhi[1]);
-        BS_S_WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < 4; ++u)
+          filter_pod2(min(pp + (uint32_t)u, np - 1), R[u], okmask[0], okmask[1], l[0], l[1], vlo[0], vhi[0], vlo[1], vhi[1]);
       }
       // lanes are pods now: finish the word
 #pragma unroll

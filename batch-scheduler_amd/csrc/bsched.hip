@@ -87,7 +87,7 @@ struct bs_ctx {
   int32_t sop_leader0 = -1;
   uint32_t last_stages = 0, batch_seq = 0;
   bool batch_pending_finish = false;
-  uint32_t seg_len_override = 0, scan_q_override = 0, target_waves = 8192, collect_stats = 0;
+  uint32_t seg_len_override = 0, scan_q_override = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   bs_batch_stats stats{};
 
   // ---- timing
@@ -499,6 +499,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_SEG_LEN")) c->seg_len_override = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("BS_SCAN_Q")) { int q = std::atoi(e); c->scan_q_override = (q == 1 || q == 2) ? (uint32_t)q : 0; }
   if (const char* e = std::getenv("BS_TARGET_WAVES")) c->target_waves = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BS_FILTER_WAVES")) c->filter_waves = std::max(1, std::atoi(e));
   *out = c;
   return BS_OK;
 }
@@ -819,7 +820,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   });
   if (run_filter && P) {
     const uint32_t ptiles = cdiv(P, 64);
-    uint32_t nsplit = std::max<uint32_t>(1, c->target_waves / ptiles);
+    uint32_t nsplit = std::max<uint32_t>(1, c->filter_waves / ptiles);
     nsplit = std::min<uint32_t>(nsplit, std::max<uint32_t>(cdiv(W, 2), 1));
     const uint32_t bpw = std::max<uint32_t>(2, cdiv(cdiv(std::max<uint32_t>(W, 1), nsplit), 2) * 2);   // multiple of NB
     TIMED(c, BS_KERNEL_FILTER, {
