@@ -260,8 +260,10 @@ class Context:
     def finish(self):
         self._chk(self._lib.bs_batch_finish(self._h), "bs_batch_finish")
 
-    def read(self, bitmap: bool = True) -> soa.BatchOut:
-        out = soa.BatchOut.alloc(self.p, self.g, self.n, bitmap=bitmap)
+    def read(self, bitmap: bool = True, out: soa.BatchOut | None = None) -> soa.BatchOut:
+        """Copy the results of the last batch to the host (into `out` when given: no allocation)."""
+        if out is None:
+            out = soa.BatchOut.alloc(self.p, self.g, self.n, bitmap=bitmap)
         st = out.as_struct()
         self._chk(self._lib.bs_batch_read(self._h, C.byref(st)), "bs_batch_read")
         return out

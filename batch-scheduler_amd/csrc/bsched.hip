@@ -66,7 +66,12 @@ struct bs_ctx {
 
   // ---- pods
   uint32_t P = 0;
-  DevBuf d_pgroup, d_preq, d_ppres, d_pcls, d_powner, d_pflags;
+  // pods live in ONE device allocation (one H2D per batch from a pinned staging buffer); outputs likewise (one D2H)
+  DevBuf d_podpack, d_outpack;
+  void* h_stage = nullptr;           // pinned host staging
+  size_t h_stage_cap = 0;
+  size_t off_pgroup = 0, off_preq = 0, off_ppres = 0, off_pcls = 0, off_powner = 0, off_pflags = 0, podpack_bytes = 0;
+  size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, outpack_bytes = 0;
 
   // ---- batch scratch / outputs
   DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
@@ -76,7 +81,7 @@ struct bs_ctx {
   bool scratch_armed = false;
   bool side_ready = false;      // desc[] / kp[] of the side-stream table are in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
-  DevBuf d_pf_code, d_pf_first_k, d_pf_leader, d_fl_code, d_fl_feasible, d_fl_bitmap, d_admit, d_ready;
+  DevBuf d_fl_bitmap, d_admit, d_ready;
   // single-query scratch
   DevBuf d_sq;
   uint32_t table_slots = 0, table_mcap = 0;
@@ -198,12 +203,13 @@ GroupsDev groups_dev(const bs_ctx* c) {
 PodsDev pods_dev(const bs_ctx* c) {
   PodsDev p{};
   p.p = c->P;
-  p.group = c->d_pgroup.as<int32_t>();
-  p.req = c->d_preq.as<int64_t>();
-  p.pres = c->d_ppres.as<uint32_t>();
-  p.cls = c->d_pcls.as<uint32_t>();
-  p.owner = c->d_powner.as<uint64_t>();
-  p.flags = c->d_pflags.as<uint8_t>();
+  uint8_t* pk = c->d_podpack.as<uint8_t>();
+  p.group = reinterpret_cast<int32_t*>(pk + c->off_pgroup);
+  p.req = reinterpret_cast<int64_t*>(pk + c->off_preq);
+  p.pres = reinterpret_cast<uint32_t*>(pk + c->off_ppres);
+  p.cls = reinterpret_cast<uint32_t*>(pk + c->off_pcls);
+  p.owner = reinterpret_cast<uint64_t*>(pk + c->off_powner);
+  p.flags = pk + c->off_pflags;
   return p;
 }
 BatchDev batch_dev(const bs_ctx* c) {
@@ -241,11 +247,12 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.chunk_kp = c->d_chunk_kp.as<uint32_t>();
   b.fparams = c->d_fparams.as<int64_t>();
   b.fflags = c->d_fflags.as<uint32_t>();
-  b.pf_code = c->d_pf_code.as<uint8_t>();
-  b.pf_first_k = c->d_pf_first_k.as<uint32_t>();
-  b.pf_leader = c->d_pf_leader.as<int32_t>();
-  b.fl_code = c->d_fl_code.as<uint8_t>();
-  b.fl_feasible = c->d_fl_feasible.as<uint32_t>();
+  uint8_t* ok = c->d_outpack.as<uint8_t>();
+  b.pf_code = ok + c->off_pf_code;
+  b.pf_first_k = reinterpret_cast<uint32_t*>(ok + c->off_pf_first_k);
+  b.pf_leader = reinterpret_cast<int32_t*>(ok + c->off_pf_leader);
+  b.fl_code = ok + c->off_fl_code;
+  b.fl_feasible = reinterpret_cast<uint32_t*>(ok + c->off_fl_feasible);
   b.fl_bitmap = c->d_fl_bitmap.as<uint64_t>();
   b.admit = c->ext_admit ? c->ext_admit : c->d_admit.as<uint32_t>();
   b.ready = c->d_ready.as<uint8_t>();
@@ -514,6 +521,7 @@ int bs_destroy(bs_ctx* c) {
     destroy_t f = (destroy_t)dlsym(c->rccl_handle, "ncclCommDestroy");
     if (f) f(c->comm);
   }
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->ev_scan_done) (void)hipEventDestroy(c->ev_scan_done);
   if (c->ev_tables) (void)hipEventDestroy(c->ev_tables);
@@ -626,18 +634,43 @@ int bs_groups_read(bs_ctx* c, bs_groups_soa* g) {
   return BS_OK;
 }
 
+static int ensure_stage(bs_ctx* c, size_t bytes) {
+  if (bytes <= c->h_stage_cap) return BS_OK;
+  if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
+  HIPCHK(c, hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault));
+  c->h_stage_cap = bytes;
+  return BS_OK;
+}
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   if (!c || !pods) return BS_ERR_INVALID;
   int rc = use_device(c);
   if (rc) return rc;
   const uint32_t P = pods->p, L = c->L;
+  if (P && (!pods->group || !pods->req || !pods->req_present || !pods->cls || !pods->owner || !pods->flags)) return BS_ERR_INVALID;
   const size_t n = std::max<uint32_t>(P, 1);
-  HIPCHK(c, c->d_pgroup.reserve(n * 4));
-  HIPCHK(c, c->d_preq.reserve(n * L * 8));
-  HIPCHK(c, c->d_ppres.reserve(n * 4));
-  HIPCHK(c, c->d_pcls.reserve(n * 4));
-  HIPCHK(c, c->d_powner.reserve(n * 8));
-  HIPCHK(c, c->d_pflags.reserve(n));
+  // pod arrays: one allocation, one transfer
+  size_t o = 0;
+  c->off_pgroup = o; o = align256(o + n * 4);
+  c->off_preq = o; o = align256(o + n * L * 8);
+  c->off_ppres = o; o = align256(o + n * 4);
+  c->off_pcls = o; o = align256(o + n * 4);
+  c->off_powner = o; o = align256(o + n * 8);
+  c->off_pflags = o; o = align256(o + n);
+  c->podpack_bytes = o;
+  HIPCHK(c, c->d_podpack.reserve(o));
+  // per-pod outputs: one allocation, one transfer back
+  o = 0;
+  c->off_pf_code = o; o = align256(o + n);
+  c->off_pf_first_k = o; o = align256(o + n * 4);
+  c->off_pf_leader = o; o = align256(o + n * 4);
+  c->off_fl_code = o; o = align256(o + n);
+  c->off_fl_feasible = o; o = align256(o + n * 4);
+  c->outpack_bytes = o;
+  HIPCHK(c, c->d_outpack.reserve(o));
+  rc = ensure_stage(c, std::max(c->podpack_bytes, c->outpack_bytes));
+  if (rc) return rc;
   HIPCHK(c, c->d_epoch.reserve(n * 4));
   HIPCHK(c, c->d_tcode.reserve(n));
   HIPCHK(c, c->d_stage.reserve(n));
@@ -651,19 +684,16 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
   HIPCHK(c, c->d_fflags.reserve(n * 4));
   HIPCHK(c, c->d_blk_scratch.reserve((n / 256 + 2) * 4));
-  HIPCHK(c, c->d_pf_code.reserve(n));
-  HIPCHK(c, c->d_pf_first_k.reserve(n * 4));
-  HIPCHK(c, c->d_pf_leader.reserve(n * 4));
-  HIPCHK(c, c->d_fl_code.reserve(n));
-  HIPCHK(c, c->d_fl_feasible.reserve(n * 4));
   c->P = P;
   if (P) {
-    HIPCHK(c, hipMemcpyAsync(c->d_pgroup.p, pods->group, (size_t)P * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_preq.p, pods->req, (size_t)P * L * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_ppres.p, pods->req_present, (size_t)P * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_pcls.p, pods->cls, (size_t)P * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_powner.p, pods->owner, (size_t)P * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_pflags.p, pods->flags, (size_t)P, hipMemcpyHostToDevice, c->stream));
+    uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
+    std::memcpy(st + c->off_pgroup, pods->group, (size_t)P * 4);
+    std::memcpy(st + c->off_preq, pods->req, (size_t)P * L * 8);
+    std::memcpy(st + c->off_ppres, pods->req_present, (size_t)P * 4);
+    std::memcpy(st + c->off_pcls, pods->cls, (size_t)P * 4);
+    std::memcpy(st + c->off_powner, pods->owner, (size_t)P * 8);
+    std::memcpy(st + c->off_pflags, pods->flags, (size_t)P);
+    HIPCHK(c, hipMemcpyAsync(c->d_podpack.p, st, c->podpack_bytes, hipMemcpyHostToDevice, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_pods = true;
@@ -904,18 +934,21 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   if (!c->have_pods || !c->have_groups) return BS_ERR_STATE;
   int rc = use_device(c);
   if (rc) return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   const uint32_t P = c->P, G = c->G, W = cdiv(c->N, 64);
-  if (P) {
-    if (out->pf_code) HIPCHK(c, hipMemcpy(out->pf_code, c->d_pf_code.p, P, hipMemcpyDeviceToHost));
-    if (out->pf_first_k) HIPCHK(c, hipMemcpy(out->pf_first_k, c->d_pf_first_k.p, (size_t)P * 4, hipMemcpyDeviceToHost));
-    if (out->pf_leader) HIPCHK(c, hipMemcpy(out->pf_leader, c->d_pf_leader.p, (size_t)P * 4, hipMemcpyDeviceToHost));
-    if (out->fl_code) HIPCHK(c, hipMemcpy(out->fl_code, c->d_fl_code.p, P, hipMemcpyDeviceToHost));
-    if (out->fl_feasible) HIPCHK(c, hipMemcpy(out->fl_feasible, c->d_fl_feasible.p, (size_t)P * 4, hipMemcpyDeviceToHost));
-    if (out->fl_bitmap && W) {
-      if (c->last_stages & BS_STAGE_FILTER) HIPCHK(c, hipMemcpy(out->fl_bitmap, c->d_fl_bitmap.p, (size_t)W * P * 8, hipMemcpyDeviceToHost));
-      else std::memset(out->fl_bitmap, 0, (size_t)W * P * 8);
-    }
+  const bool want_pod = P && (out->pf_code || out->pf_first_k || out->pf_leader || out->fl_code || out->fl_feasible);
+  uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
+  if (want_pod) HIPCHK(c, hipMemcpyAsync(st, c->d_outpack.p, c->outpack_bytes, hipMemcpyDeviceToHost, c->stream));   // ONE transfer
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (want_pod) {
+    if (out->pf_code) std::memcpy(out->pf_code, st + c->off_pf_code, P);
+    if (out->pf_first_k) std::memcpy(out->pf_first_k, st + c->off_pf_first_k, (size_t)P * 4);
+    if (out->pf_leader) std::memcpy(out->pf_leader, st + c->off_pf_leader, (size_t)P * 4);
+    if (out->fl_code) std::memcpy(out->fl_code, st + c->off_fl_code, P);
+    if (out->fl_feasible) std::memcpy(out->fl_feasible, st + c->off_fl_feasible, (size_t)P * 4);
+  }
+  if (P && out->fl_bitmap && W) {
+    if (c->last_stages & BS_STAGE_FILTER) HIPCHK(c, hipMemcpy(out->fl_bitmap, c->d_fl_bitmap.p, (size_t)W * P * 8, hipMemcpyDeviceToHost));
+    else std::memset(out->fl_bitmap, 0, (size_t)W * P * 8);
   }
   if (G && (c->last_stages & BS_STAGE_TALLY)) {
     if (out->group_admit) HIPCHK(c, hipMemcpy(out->group_admit, c->ext_admit ? (void*)c->ext_admit : c->d_admit.p, (size_t)G * 4, hipMemcpyDeviceToHost));
