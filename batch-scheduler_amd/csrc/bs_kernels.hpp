@@ -38,6 +38,7 @@ struct NodesDev {
   const uint32_t* kmap;          // [m] row -> node list index (non-skipped nodes, list order)
   uint32_t m;                    // rows
   const int64_t* left4;          // [4][stride] getLeftResource lanes (core.go:460-463)
+  const int64_t* lglob;          // [8] min[4], max[4] of left4 over the nodes Filter can evaluate
 };
 
 struct GroupsDev {
@@ -145,18 +146,37 @@ struct BatchParams {
 // (core.go:606-617); left4: getLeftResource lanes (core.go:460-463).  Single block.
 // Incremental: nodes below `base0` (a multiple of the block size) are unchanged since the last call and
 // contribute `m_before` rows; only [base0, n) is recomputed (node churn: rescan from the first change).
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v);
+__device__ __forceinline__ int64_t wave_min_i64(int64_t v);
+
 __global__ __launch_bounds__(kScanBlock) void k_nodes_derive(NodesDev nd, uint32_t* kmap, uint32_t* m_out,
-                                                             int64_t* left4, uint32_t base0, uint32_t m_before) {
+                                                             int64_t* left4, int64_t* lglob, uint32_t base0, uint32_t m_before) {
   __shared__ uint32_t lds[16];
+  __shared__ int64_t s_mm[16][8];
+  int64_t gmin[4] = {INT64_MAX, INT64_MAX, INT64_MAX, INT64_MAX}, gmx[4] = {INT64_MIN, INT64_MIN, INT64_MIN, INT64_MIN};
+  // unchanged prefix: its left4 is already resident, fold it into the cluster-wide bounds
+  for (uint32_t i = threadIdx.x; i < base0; i += kScanBlock) {
+    if (nd.flags[i] & (BS_NODE_NIL | BS_NODE_NO_NODE)) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t v = left4[(size_t)j * nd.stride + i];
+      gmin[j] = v < gmin[j] ? v : gmin[j];
+      gmx[j] = v > gmx[j] ? v : gmx[j];
+    }
+  }
   uint32_t carry = m_before;
   for (uint32_t base = base0; base < nd.n; base += kScanBlock) {
     const uint32_t i = base + threadIdx.x;
     uint32_t keep = 0;
     if (i < nd.n) {
       keep = (nd.flags[i] & BS_NODE_SKIP_MASK) ? 0u : 1u;
+      const bool ok = !(nd.flags[i] & (BS_NODE_NIL | BS_NODE_NO_NODE));
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        left4[(size_t)j * nd.stride + i] = wsub(nd.alloc[(size_t)j * nd.stride + i], nd.req[(size_t)j * nd.stride + i]);
+      for (int j = 0; j < 4; ++j) {
+        const int64_t v = wsub(nd.alloc[(size_t)j * nd.stride + i], nd.req[(size_t)j * nd.stride + i]);
+        left4[(size_t)j * nd.stride + i] = v;
+        if (ok) { gmin[j] = v < gmin[j] ? v : gmin[j]; gmx[j] = v > gmx[j] ? v : gmx[j]; }
+      }
     }
     uint32_t total;
     const uint32_t incl = block_incl_scan_add<uint32_t>(keep, lds, total);
@@ -165,6 +185,21 @@ __global__ __launch_bounds__(kScanBlock) void k_nodes_derive(NodesDev nd, uint32
     __syncthreads();
   }
   if (threadIdx.x == 0) *m_out = carry;
+  // cluster-wide min / max of left per fixed lane (k_filter's lane-subset test)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t mn = wave_min_i64(gmin[j]), mx = wave_max_i64(gmx[j]);
+    if (lane_id() == 0) { s_mm[wave_id()][j] = mn; s_mm[wave_id()][4 + j] = mx; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    int64_t r = s_mm[0][threadIdx.x];
+    for (int w = 1; w < kScanBlock / 64; ++w) {
+      const int64_t x = s_mm[w][threadIdx.x];
+      r = threadIdx.x < 4 ? (x < r ? x : r) : (x > r ? x : r);
+    }
+    lglob[threadIdx.x] = r;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1229,32 +1264,73 @@ __global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchPar
 // the pod-independent case-3 mask is OR-ed in, non-evaluated pods get their constant word, the
 // popcount accumulates the feasible-node count and the store is one coalesced 512 bytes per block.
 // Per pod and node block: 3 SALU + 6 VALU, no branch.
+// Lane subsets: when, for a whole pod tile, even the cluster-wide smallest `left` of a resource lane
+// covers the tile's largest request, that lane's compare is true for every (pod, node) of the tile and is
+// left out.  MASK bit j = lane j is compared.  (Typically one or two lanes bind; the others are free.)
+#define BS_OPT_0(x) ""
+#define BS_OPT_1(x) x
+#define BS_OPT(flag, x) BS_OPT_##flag(x)
+template <int MASK>
 __device__ __forceinline__ void filter_pod2(uint32_t pp, const int64_t (&R)[4], unsigned long long ok0, unsigned long long ok1,
                                             const int64_t (&l0)[4], const int64_t (&l1)[4], uint32_t& vlo0, uint32_t& vhi0,
-                                            uint32_t& vlo1, uint32_t& vhi1) {
-  asm volatile("s_mov_b32 m0, %[pp]\n\t"
-               "s_mov_b64 exec, %[ok0]\n\t"
-               "v_cmpx_le_i64 vcc, %[R0], %[a0]\n\t"
-               "v_cmpx_le_i64 vcc, %[R1], %[a1]\n\t"
-               "v_cmpx_le_i64 vcc, %[R2], %[a2]\n\t"
-               "v_cmpx_le_i64 vcc, %[R3], %[a3]\n\t"
-               "s_nop 3\n\t"
-               "v_writelane_b32 %[vlo0], exec_lo, m0\n\t"
-               "v_writelane_b32 %[vhi0], exec_hi, m0\n\t"
-               "s_mov_b64 exec, %[ok1]\n\t"
-               "v_cmpx_le_i64 vcc, %[R0], %[b0]\n\t"
-               "v_cmpx_le_i64 vcc, %[R1], %[b1]\n\t"
-               "v_cmpx_le_i64 vcc, %[R2], %[b2]\n\t"
-               "v_cmpx_le_i64 vcc, %[R3], %[b3]\n\t"
-               "s_nop 3\n\t"
-               "v_writelane_b32 %[vlo1], exec_lo, m0\n\t"
-               "v_writelane_b32 %[vhi1], exec_hi, m0\n\t"
-               "s_mov_b64 exec, -1"
-               : [vlo0] "+v"(vlo0), [vhi0] "+v"(vhi0), [vlo1] "+v"(vlo1), [vhi1] "+v"(vhi1)
-               : [pp] "s"(pp), [ok0] "s"(ok0), [ok1] "s"(ok1), [R0] "v"(R[0]), [R1] "v"(R[1]), [R2] "v"(R[2]), [R3] "v"(R[3]),
-                 [a0] "v"(l0[0]), [a1] "v"(l0[1]), [a2] "v"(l0[2]), [a3] "v"(l0[3]), [b0] "v"(l1[0]), [b1] "v"(l1[1]), [b2] "v"(l1[2]),
-                 [b3] "v"(l1[3])
-               : "vcc");
+                                            uint32_t& vlo1, uint32_t& vhi1);
+#define BS_DEF_FILTER_POD2(MASK, f0, f1, f2, f3)                                                                          \
+  template <>                                                                                                             \
+  __device__ __forceinline__ void filter_pod2<MASK>(uint32_t pp, const int64_t (&R)[4], unsigned long long ok0,          \
+                                                    unsigned long long ok1, const int64_t (&l0)[4], const int64_t (&l1)[4], \
+                                                    uint32_t& vlo0, uint32_t& vhi0, uint32_t& vlo1, uint32_t& vhi1) {       \
+    asm volatile("s_mov_b32 m0, %[pp]\n\t"                                                                                \
+                 "s_mov_b64 exec, %[ok0]\n\t"                                                                             \
+                 BS_OPT(f0, "v_cmpx_le_i64 vcc, %[R0], %[a0]\n\t") BS_OPT(f1, "v_cmpx_le_i64 vcc, %[R1], %[a1]\n\t")       \
+                 BS_OPT(f2, "v_cmpx_le_i64 vcc, %[R2], %[a2]\n\t") BS_OPT(f3, "v_cmpx_le_i64 vcc, %[R3], %[a3]\n\t")       \
+                 "s_nop 3\n\t"                                                                                            \
+                 "v_writelane_b32 %[vlo0], exec_lo, m0\n\t"                                                               \
+                 "v_writelane_b32 %[vhi0], exec_hi, m0\n\t"                                                               \
+                 "s_mov_b64 exec, %[ok1]\n\t"                                                                             \
+                 BS_OPT(f0, "v_cmpx_le_i64 vcc, %[R0], %[b0]\n\t") BS_OPT(f1, "v_cmpx_le_i64 vcc, %[R1], %[b1]\n\t")       \
+                 BS_OPT(f2, "v_cmpx_le_i64 vcc, %[R2], %[b2]\n\t") BS_OPT(f3, "v_cmpx_le_i64 vcc, %[R3], %[b3]\n\t")       \
+                 "s_nop 3\n\t"                                                                                            \
+                 "v_writelane_b32 %[vlo1], exec_lo, m0\n\t"                                                               \
+                 "v_writelane_b32 %[vhi1], exec_hi, m0\n\t"                                                               \
+                 "s_mov_b64 exec, -1"                                                                                     \
+                 : [vlo0] "+v"(vlo0), [vhi0] "+v"(vhi0), [vlo1] "+v"(vlo1), [vhi1] "+v"(vhi1)                             \
+                 : [pp] "s"(pp), [ok0] "s"(ok0), [ok1] "s"(ok1), [R0] "v"(R[0]), [R1] "v"(R[1]), [R2] "v"(R[2]),          \
+                   [R3] "v"(R[3]), [a0] "v"(l0[0]), [a1] "v"(l0[1]), [a2] "v"(l0[2]), [a3] "v"(l0[3]), [b0] "v"(l1[0]),   \
+                   [b1] "v"(l1[1]), [b2] "v"(l1[2]), [b3] "v"(l1[3])                                                      \
+                 : "vcc");                                                                                                \
+  }
+BS_DEF_FILTER_POD2(1, 1, 0, 0, 0)
+BS_DEF_FILTER_POD2(2, 0, 1, 0, 0)
+BS_DEF_FILTER_POD2(3, 1, 1, 0, 0)
+BS_DEF_FILTER_POD2(4, 0, 0, 1, 0)
+BS_DEF_FILTER_POD2(5, 1, 0, 1, 0)
+BS_DEF_FILTER_POD2(6, 0, 1, 1, 0)
+BS_DEF_FILTER_POD2(7, 1, 1, 1, 0)
+BS_DEF_FILTER_POD2(8, 0, 0, 0, 1)
+BS_DEF_FILTER_POD2(9, 1, 0, 0, 1)
+BS_DEF_FILTER_POD2(10, 0, 1, 0, 1)
+BS_DEF_FILTER_POD2(11, 1, 1, 0, 1)
+BS_DEF_FILTER_POD2(12, 0, 0, 1, 1)
+BS_DEF_FILTER_POD2(13, 1, 0, 1, 1)
+BS_DEF_FILTER_POD2(14, 0, 1, 1, 1)
+BS_DEF_FILTER_POD2(15, 1, 1, 1, 1)
+
+// the 64-pod loop of one step for a given lane subset; requests come from this wave's LDS slice
+template <int MASK>
+__device__ __forceinline__ void filter_pod_loop(uint32_t np, const int64_t (*sR)[4], const unsigned long long (&okmask)[2],
+                                                const int64_t (&l)[2][4], uint32_t (&vlo)[2], uint32_t (&vhi)[2]) {
+  for (uint32_t pp = 0; pp < np; pp += 4) {
+    int64_t R[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t pu = min(pp + (uint32_t)u, np - 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) R[u][j] = ((MASK >> j) & 1) ? sR[pu][j] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      filter_pod2<MASK>(min(pp + (uint32_t)u, np - 1), R[u], okmask[0], okmask[1], l[0], l[1], vlo[0], vhi[0], vlo[1], vhi[1]);
+  }
 }
 
 template <int NB>
@@ -1285,6 +1361,10 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
     for (int j = 0; j < 4; ++j) M[j] = src[j];
   }
   __shared__ int64_t s_R[4][64][4];               // per wave: the tile's requests (pod + maxSingle, fixed lanes)
+  // which resource lanes can decide anything for this tile?  (nd.lglob: cluster-wide min[4] / max[4] of left
+  // over the nodes Filter can evaluate)
+  uint32_t lane_mask = 0;          // bit j: lane j must be compared
+  bool tile_allfail = false;       // some lane fails for every (pod, node): case 2 never holds
   {
     int64_t myR[4] = {0, 0, 0, 0};
     if (mine) {
@@ -1292,9 +1372,21 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
 #pragma unroll
       for (int j = 0; j < 4; ++j) myR[j] = src[j];
     }
+    int64_t gl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gl[j] = nd.lglob[j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s_R[wave_id()][lane][j] = myR[j];
     __builtin_amdgcn_wave_barrier();               // same wave writes and reads: LDS is in order, keep the compiler honest
+    const bool c2pod = ev && !(myff & 1u);
+    const unsigned long long c2mask = __ballot(c2pod);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // lane j is free when even the cluster's smallest left covers every request of the tile (ballots, no
+      // 64-bit reductions); it fails everywhere when the largest left is below every request
+      if (__ballot(c2pod && !(gl[j] >= myR[j]))) lane_mask |= 1u << j;
+      if (c2mask && !__ballot(c2pod && gl[4 + j] >= myR[j])) tile_allfail = true;
+    }
   }
   const unsigned long long evmask = __ballot(ev);
   bool uniformM = true;
@@ -1355,18 +1447,32 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
     if (uniformM) {
       // the tile's 64 requests sit in this wave's LDS slice; a uniform-address ds_read_b128 broadcasts one
       // into VGPRs (in-order LDS counter: the compiler pipelines four pods per step) — no global/scalar
-      // memory latency inside the pod loop
-      for (uint32_t pp = 0; pp < np; pp += 4) {
-        int64_t R[4][4];
+      // memory latency inside the pod loop.  Only the lanes that can bind for this tile are compared.
+      const int64_t (*sR)[4] = s_R[wave_id()];
+      if (tile_allfail) {
+        // case 2 impossible for every pod: words stay 0
+      } else {
+        switch (lane_mask) {
+          case 0:                                     // every lane is free: case 2 holds on every evaluable node
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t pu = min(pp + (uint32_t)u, np - 1);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) R[u][j] = s_R[wave_id()][pu][j];
+            for (int nb = 0; nb < NB; ++nb) { vlo[nb] = (uint32_t)okmask[nb]; vhi[nb] = (uint32_t)(okmask[nb] >> 32); }
+            break;
+          case 1: filter_pod_loop<1>(np, sR, okmask, l, vlo, vhi); break;
+          case 2: filter_pod_loop<2>(np, sR, okmask, l, vlo, vhi); break;
+          case 3: filter_pod_loop<3>(np, sR, okmask, l, vlo, vhi); break;
+          case 4: filter_pod_loop<4>(np, sR, okmask, l, vlo, vhi); break;
+          case 5: filter_pod_loop<5>(np, sR, okmask, l, vlo, vhi); break;
+          case 6: filter_pod_loop<6>(np, sR, okmask, l, vlo, vhi); break;
+          case 7: filter_pod_loop<7>(np, sR, okmask, l, vlo, vhi); break;
+          case 8: filter_pod_loop<8>(np, sR, okmask, l, vlo, vhi); break;
+          case 9: filter_pod_loop<9>(np, sR, okmask, l, vlo, vhi); break;
+          case 10: filter_pod_loop<10>(np, sR, okmask, l, vlo, vhi); break;
+          case 11: filter_pod_loop<11>(np, sR, okmask, l, vlo, vhi); break;
+          case 12: filter_pod_loop<12>(np, sR, okmask, l, vlo, vhi); break;
+          case 13: filter_pod_loop<13>(np, sR, okmask, l, vlo, vhi); break;
+          case 14: filter_pod_loop<14>(np, sR, okmask, l, vlo, vhi); break;
+          default: filter_pod_loop<15>(np, sR, okmask, l, vlo, vhi); break;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          filter_pod2(min(pp + (uint32_t)u, np - 1), R[u], okmask[0], okmask[1], l[0], l[1], vlo[0], vhi[0], vlo[1], vhi[1]);
       }
       // lanes are pods now: finish the word
 #pragma unroll

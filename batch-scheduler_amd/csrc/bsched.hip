@@ -49,7 +49,7 @@ struct bs_ctx {
   // ---- nodes
   bool have_nodes = false, have_fit = false, have_groups = false, have_pods = false;
   uint32_t N = 0, Ncap = 0, M = 0, C = 0, fit_words = 0;
-  DevBuf d_alloc, d_nreq, d_apres, d_rpres, d_nflags, d_fit, d_kmap, d_m, d_left4;
+  DevBuf d_alloc, d_nreq, d_apres, d_rpres, d_nflags, d_fit, d_kmap, d_m, d_left4, d_lglob;
   std::vector<int64_t> h_alloc, h_nreq;          // [L][N] mirrors (churn + read-back)
   std::vector<uint32_t> h_apres, h_rpres, h_kmap;
   std::vector<uint8_t> h_nflags;
@@ -185,6 +185,7 @@ NodesDev nodes_dev(const bs_ctx* c) {
   nd.kmap = c->d_kmap.as<uint32_t>();
   nd.m = c->M;
   nd.left4 = c->d_left4.as<int64_t>();
+  nd.lglob = c->d_lglob.as<int64_t>();
   return nd;
 }
 GroupsDev groups_dev(const bs_ctx* c) {
@@ -312,6 +313,7 @@ int upload_nodes(bs_ctx* c, uint32_t lo = 0) {
   if (c->d_alloc.cap != old_cap_bytes) lo = 0;     // (re)allocated: nothing resident yet
   HIPCHK(c, c->d_nreq.reserve(cap * L * 8));
   HIPCHK(c, c->d_left4.reserve(cap * 4 * 8));
+  HIPCHK(c, c->d_lglob.reserve(64));
   HIPCHK(c, c->d_apres.reserve(cap * 4));
   HIPCHK(c, c->d_rpres.reserve(cap * 4));
   HIPCHK(c, c->d_nflags.reserve(cap));
@@ -334,7 +336,7 @@ int upload_nodes(bs_ctx* c, uint32_t lo = 0) {
   if (base0) m_before = (uint32_t)(std::lower_bound(c->h_kmap.begin(), c->h_kmap.end(), base0) - c->h_kmap.begin());
   NodesDev nd = nodes_dev(c);
   hipLaunchKernelGGL(k_nodes_derive, dim3(1), dim3(kScanBlock), 0, c->stream, nd, c->d_kmap.as<uint32_t>(), c->d_m.as<uint32_t>(), c->d_left4.as<int64_t>(),
-                     base0, m_before);
+                     c->d_lglob.as<int64_t>(), base0, m_before);
   HIPCHK(c, hipGetLastError());
   uint32_t m = 0;
   HIPCHK(c, hipMemcpyAsync(&m, c->d_m.p, 4, hipMemcpyDeviceToHost, c->stream));
