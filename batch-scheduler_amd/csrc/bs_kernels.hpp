@@ -134,7 +134,7 @@ struct BatchParams {
   uint32_t run_filter;
   uint32_t collect_stats;
   uint32_t mcap;               // table row capacity
-  uint32_t seg_len;            // rows per scan segment
+  uint32_t seg_len;            // unused (k_scan deals 64-row groups)
   uint32_t tile_queries;       // queries per scan tile (64 x Q)
 };
 
@@ -900,136 +900,175 @@ __device__ __forceinline__ void row_all(const unsigned long long (&nf)[Q], uint3
   else row_step<L>(nf[0], myk[0], k, a, r[0]);
 }
 
+// One wave's share of one tile (pair): the 64-row groups of the tile's table that are LIVE for the tile
+// (some request could pass: on every fixed lane the group's largest running sum reaches the tile's
+// smallest request), dealt round-robin over the J waves of the tile — wave `share` takes the live
+// groups whose rank is = share (mod J).  Every wave recomputes the live set itself (one gather of the
+// group maxima per 64 groups), so the deal is balanced wherever the live groups are, and a wave that
+// gets nothing leaves before touching the requests.
 template <int S, int Q>
-__device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t k0, uint32_t k1, uint32_t slot,
-                                          const uint32_t (&tq0)[Q], const uint32_t (&tcnt)[Q], unsigned long long pruned) {
+__device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, const uint32_t (&tq0)[Q],
+                                          const uint32_t (&tcnt)[Q], const int64_t (&rmin)[4], uint32_t share, uint32_t J) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
   constexpr int U = (L <= 5) ? 2 : 1;            // rows per buffer (SGPR budget: 2 buffers x U x L pairs)
   const int lane = lane_id();
+  const uint32_t ngroups = (m + 63u) >> 6, gstride = (prm.mcap + 63u) >> 6;
 
   int64_t r[Q][L];
-  uint32_t pos[Q], myk[Q], qf[Q];
+  uint32_t pos[Q], myk[Q], qf[Q], seen[Q];
   unsigned long long nf[Q];                      // lanes still looking for their first row
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const bool valid = (uint32_t)lane < tcnt[q];
-    pos[q] = tq0[q] + (uint32_t)lane;            // tile order: the tile's requests are contiguous rows
-    myk[q] = BS_INF;
-    qf[q] = 0;
-    uint32_t seen = 0;
-    if (valid) {
-      const int64_t* src = b.qreq_s + (size_t)pos[q] * LP;
-#pragma unroll
-      for (int j = 0; j < L; ++j) r[q][j] = src[j];
-      qf[q] = b.qflags_s[pos[q]];
-      seen = __hip_atomic_load(&b.first_row[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-#pragma unroll
-      for (int j = 0; j < L; ++j) r[q][j] = INT64_MAX;
-    }
-    nf[q] = __ballot(valid && seen >= k0);       // an earlier segment may already own a smaller row
-  }
-  unsigned long long any = 0;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) any |= nf[q];
-  if (any == 0) return;
-
   uint32_t kp[S > 0 ? S : 1];
   unsigned long long absok[Q][S > 0 ? S : 1];
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    kp[s] = __builtin_amdgcn_readfirstlane(b.kp[slot * 16 + s]);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) absok[q][s] = __ballot((qf[q] >> (16 + s)) & 1u);
-  }
-
+  bool loaded = false;
   crow_t T = as_const_rows(b.tables + (size_t)slot * prm.mcap * LP);
   uint32_t rows_done = 0;
-  uint32_t a = k0;
-  const uint32_t g0 = k0 >> 6;
-  while (a < k1) {
-    // 64-row groups in which some fixed lane stays below every request of the tile cannot satisfy anybody
-    const uint32_t gend = min(k1, ((a >> 6) + 1u) << 6);
-    if ((pruned >> ((a >> 6) - g0)) & 1ull) { a = gend; continue; }
-    // piece [a, e): inside one group, no kp[s] strictly inside
-    uint32_t e = gend;
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-      if (kp[s] > a && kp[s] < e) e = kp[s];
-    // lanes that can pass while key s is absent from the running sum (core.go:688-692)
-    unsigned long long act[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      unsigned long long el = ~0ull;
-#pragma unroll
-      for (int s = 0; s < S; ++s)
-        if (kp[s] > a) el &= absok[q][s];
-      act[q] = nf[q] & el;
-      nf[q] &= ~el;                              // parked until a later piece
+  uint32_t turn = 0;                             // rank of the next live group modulo J
+
+  for (uint32_t c0 = 0; c0 < ngroups; c0 += 64u) {
+    // live mask of groups c0 .. c0+63 (lane l <-> group c0+l)
+    bool dead = true;
+    const uint32_t g = c0 + (uint32_t)lane;
+    if (g < ngroups) {
+      const int64_t* gm = b.gmax + ((size_t)slot * gstride + g) * 4;
+      dead = gm[0] < rmin[0] || gm[1] < rmin[1] || gm[2] < rmin[2] || gm[3] < rmin[3];
     }
-    uint32_t k = a;
-    const uint32_t pairs = (e - a) / (2u * U);
-    if (pairs) {
-      int64_t A[U][L], B[U][L];
-      crow_t pr = T + (size_t)k * LP;             // running row pointer: constant offsets below fold into s_load
+    unsigned long long live = __ballot(!dead);
+    while (live) {
+      const uint32_t bit = (uint32_t)__ffsll((long long)live) - 1u;
+      live &= live - 1ull;
+      const bool mine = turn == share;
+      turn = turn + 1u == J ? 0u : turn + 1u;
+      if (!mine) continue;
+      // ---- this group is ours: rows [a, gend)
+      if (!loaded) {                             // first live group: now the requests are worth loading
+        loaded = true;
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+        for (int q = 0; q < Q; ++q) {
+          const bool valid = (uint32_t)lane < tcnt[q];
+          pos[q] = tq0[q] + (uint32_t)lane;      // tile order: the tile's requests are contiguous rows
+          myk[q] = BS_INF;
+          qf[q] = 0;
+          seen[q] = 0;
+          if (valid) {
+            const int64_t* src = b.qreq_s + (size_t)pos[q] * LP;
 #pragma unroll
-        for (int j = 0; j < L; ++j) A[u][j] = pr[u * LP + j];
-      BS_S_WAIT_LGKM0();
-      for (uint32_t it = 0; it < pairs; ++it) {
+            for (int j = 0; j < L; ++j) r[q][j] = src[j];
+            qf[q] = b.qflags_s[pos[q]];
+            seen[q] = __hip_atomic_load(&b.first_row[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int j = 0; j < L; ++j) r[q][j] = INT64_MAX;
+          }
+          nf[q] = __ballot(valid);
+        }
 #pragma unroll
-          for (int j = 0; j < L; ++j) B[u][j] = pr[(U + u) * LP + j];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < S; ++s) {
+          kp[s] = __builtin_amdgcn_readfirstlane(b.kp[slot * 16 + s]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + u, A[u], r);
-        BS_S_WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        // rows k+2U.. may lie past the piece (prefetch only; the table has slack rows)
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int j = 0; j < L; ++j) A[u][j] = pr[(2 * U + u) * LP + j];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + U + u, B[u], r);
-        BS_S_WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        k += 2 * U;
-        pr += 2 * U * LP;
-        unsigned long long left = 0;              // lanes of this piece still without a row
-#pragma unroll
-        for (int q = 0; q < Q; ++q) left |= act[q] & __ballot(myk[q] == BS_INF);
-        if (left == 0) break;
-      }
-    }
-    {
-      unsigned long long left = 0;
-#pragma unroll
-      for (int q = 0; q < Q; ++q) left |= act[q] & __ballot(myk[q] == BS_INF);
-      if (left) {
-        for (; k < e; ++k) {                     // < 2U leftover rows of the piece
-          int64_t R1[L];
-#pragma unroll
-          for (int j = 0; j < L; ++j) R1[j] = T[(size_t)k * LP + j];
-          BS_S_WAIT_LGKM0();
-          row_all<L, Q>(act, myk, k, R1, r);
+          for (int q = 0; q < Q; ++q) absok[q][s] = __ballot((qf[q] >> (16 + s)) & 1u);
         }
       }
-    }
-    rows_done += k - a;
-    unsigned long long left = 0;
+      uint32_t a = (c0 + bit) << 6;
+      const uint32_t gend = min(m, a + 64u);
+      // lanes another wave already served with an earlier row need nothing from this group
+      unsigned long long want[Q];
+      unsigned long long any = 0;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      nf[q] = (nf[q] | act[q]) & __ballot(myk[q] == BS_INF);
-      left |= nf[q];
+      for (int q = 0; q < Q; ++q) {
+        want[q] = nf[q] & __ballot(seen[q] >= a);
+        any |= want[q];
+      }
+      if (any == 0) continue;
+      while (a < gend) {
+        // piece [a, e): no kp[s] strictly inside
+        uint32_t e = gend;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+          if (kp[s] > a && kp[s] < e) e = kp[s];
+        // lanes that can pass while key s is absent from the running sum (core.go:688-692)
+        unsigned long long act[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          unsigned long long el = ~0ull;
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+            if (kp[s] > a) el &= absok[q][s];
+          act[q] = want[q] & el;
+        }
+        uint32_t k = a;
+        const uint32_t pairs = (e - a) / (2u * U);
+        if (pairs) {
+          int64_t A[U][L], B[U][L];
+          crow_t pr = T + (size_t)k * LP;         // running row pointer: constant offsets below fold into s_load
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < L; ++j) A[u][j] = pr[u * LP + j];
+          BS_S_WAIT_LGKM0();
+          for (uint32_t it = 0; it < pairs; ++it) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int j = 0; j < L; ++j) B[u][j] = pr[(U + u) * LP + j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + u, A[u], r);
+            BS_S_WAIT_LGKM0();
+            __builtin_amdgcn_sched_barrier(0);
+            // rows k+2U.. may lie past the piece (prefetch only; the table has slack rows)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int j = 0; j < L; ++j) A[u][j] = pr[(2 * U + u) * LP + j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + U + u, B[u], r);
+            BS_S_WAIT_LGKM0();
+            __builtin_amdgcn_sched_barrier(0);
+            k += 2 * U;
+            pr += 2 * U * LP;
+            unsigned long long left = 0;          // lanes of this piece still without a row
+#pragma unroll
+            for (int q = 0; q < Q; ++q) left |= act[q] & __ballot(myk[q] == BS_INF);
+            if (left == 0) break;
+          }
+        }
+        {
+          unsigned long long left = 0;
+#pragma unroll
+          for (int q = 0; q < Q; ++q) left |= act[q] & __ballot(myk[q] == BS_INF);
+          if (left) {
+            for (; k < e; ++k) {                 // < 2U leftover rows of the piece
+              int64_t R1[L];
+#pragma unroll
+              for (int j = 0; j < L; ++j) R1[j] = T[(size_t)k * LP + j];
+              BS_S_WAIT_LGKM0();
+              row_all<L, Q>(act, myk, k, R1, r);
+            }
+          }
+        }
+        rows_done += k - a;
+        unsigned long long left = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          want[q] &= __ballot(myk[q] == BS_INF);
+          left |= want[q];
+        }
+        if (left == 0) break;
+        a = e;
+      }
+      // found lanes are done for good (this wave walks its groups in increasing row order)
+      unsigned long long left = 0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        nf[q] &= __ballot(myk[q] == BS_INF);
+        left |= nf[q];
+      }
+      if (left == 0) { c0 = ngroups; break; }
     }
-    if (left == 0) break;
-    a = e;
   }
+  if (!loaded) return;
 #pragma unroll
   for (int q = 0; q < Q; ++q)
     if (myk[q] != BS_INF) atomicMin(&b.first_row[pos[q]], myk[q]);
@@ -1042,38 +1081,20 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   }
 }
 
-// Which 64-row groups of [k0,k1) can be skipped for a tile: a group is dead when, on some fixed lane,
-// even its largest running sum is below the tile's smallest request (then `row >= r` fails for every
-// row of the group and every request of the tile — compareResourceAndRequire cannot return true).
-__device__ __forceinline__ unsigned long long prune_mask(const BatchDev& b, const BatchParams& prm, uint32_t slot, uint32_t k0, uint32_t k1,
-                                                         const int64_t (&rmin)[4], unsigned long long& all_mask) {
-  const uint32_t g0 = k0 >> 6, ng = ((k1 + 63u) >> 6) - g0;          // ng <= 64 (seg_len <= 4096)
-  const uint32_t ngroups = (prm.mcap + 63u) >> 6;
-  bool dead = false;
-  if ((uint32_t)lane_id() < ng) {
-    const int64_t* gm = b.gmax + ((size_t)slot * ngroups + g0 + (uint32_t)lane_id()) * 4;
-    dead = gm[0] < rmin[0] || gm[1] < rmin[1] || gm[2] < rmin[2] || gm[3] < rmin[3];
-  }
-  all_mask = ng >= 64 ? ~0ull : ((1ull << ng) - 1ull);
-  return __ballot(dead);
-}
-
-// Work loop: item = (pair of tiles, segment of rows).  Tiles come in emission order; two tiles of the
-// same table share one pass over the rows (Q = 2: every row is loaded once for 128 requests), tiles of
-// different tables are scanned one after the other.  The grid is fixed; waves stride over the items.
+// Work loop: item = (pair of tiles, share j of J).  Tiles come in emission order; two tiles of the same
+// table share one pass over the rows (Q = 2: every row is loaded once for 128 requests), tiles of
+// different tables are scanned one after the other.  Consecutive waves take different pairs with the
+// same share (the same rows, reused from the scalar cache).  The grid is fixed; waves stride over items.
 template <int S>
-__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t nseg) {
+__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t J) {
   typedef const __attribute__((address_space(4))) Tile* ctile_t;
   ctile_t CT = (ctile_t)(uintptr_t)b.tiles;
   const uint32_t ntiles = *b.ntiles;
   const uint32_t npairs = (ntiles + 1u) >> 1;
-  const uint32_t items = npairs * nseg;
+  const uint32_t items = npairs * J;
   const uint32_t stride = gridDim.x * 4u;
   for (uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id()); w < items; w += stride) {
-    const uint32_t seg = w / npairs, pair = w - seg * npairs;      // consecutive waves: same rows, different tiles
-    const uint32_t k0 = seg * prm.seg_len;
-    if (k0 >= m) continue;
-    const uint32_t k1 = min(m, k0 + prm.seg_len);
+    const uint32_t share = w / npairs, pair = w - share * npairs;
     const bool has_b = 2u * pair + 1u < ntiles;
     const uint32_t ia = 2u * pair, ib = has_b ? 2u * pair + 1u : 2u * pair;
     const uint32_t sa = CT[ia].slot, sb = CT[ib].slot;
@@ -1082,27 +1103,18 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
     int64_t ra[4], rb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ra[j] = CT[ia].rmin[j]; rb[j] = CT[ib].rmin[j]; }
-    unsigned long long all;
     if (has_b && sa == sb) {
       int64_t rm[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) rm[j] = ra[j] < rb[j] ? ra[j] : rb[j];
-      const unsigned long long pruned = prune_mask(b, prm, sa, k0, k1, rm, all);
-      if ((pruned & all) == all) continue;
       const uint32_t q0s[2] = {qa, qb}, cnts[2] = {ca, cb};
-      scan_core<S, 2>(b, prm, k0, k1, sa, q0s, cnts, pruned);
+      scan_core<S, 2>(b, prm, m, sa, q0s, cnts, rm, share, J);
     } else {
-      const unsigned long long pa = prune_mask(b, prm, sa, k0, k1, ra, all);
-      if ((pa & all) != all) {
-        const uint32_t q0a[1] = {qa}, cna[1] = {ca};
-        scan_core<S, 1>(b, prm, k0, k1, sa, q0a, cna, pa);
-      }
+      const uint32_t q0a[1] = {qa}, cna[1] = {ca};
+      scan_core<S, 1>(b, prm, m, sa, q0a, cna, ra, share, J);
       if (has_b) {
-        const unsigned long long pb = prune_mask(b, prm, sb, k0, k1, rb, all);
-        if ((pb & all) != all) {
-          const uint32_t q0b[1] = {qb}, cnb[1] = {cb};
-          scan_core<S, 1>(b, prm, k0, k1, sb, q0b, cnb, pb);
-        }
+        const uint32_t q0b[1] = {qb}, cnb[1] = {cb};
+        scan_core<S, 1>(b, prm, m, sb, q0b, cnb, rb, share, J);
       }
     }
   }

@@ -92,7 +92,7 @@ struct bs_ctx {
   int32_t sop_leader0 = -1;
   uint32_t last_stages = 0, batch_seq = 0;
   bool batch_pending_finish = false;
-  uint32_t seg_len_override = 0, scan_q_override = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
+  uint32_t scan_share_override = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   bs_batch_stats stats{};
 
   // ---- timing
@@ -391,15 +391,12 @@ void launch_tables_local(bs_ctx* c, hipStream_t st, dim3 grid, const NodesDev& n
   }
 }
 
-uint32_t pick_seg_len(const bs_ctx* c, uint32_t tiles, uint32_t m) {
-  if (c->seg_len_override) return c->seg_len_override;
-  if (m == 0) return 64;
-  const uint32_t target_waves = c->target_waves;              // waves in flight wanted (1024 SIMDs x 8)
-  uint32_t nseg = std::max<uint32_t>(1, target_waves / std::max<uint32_t>(1, tiles));
-  nseg = std::min<uint32_t>(nseg, cdiv(m, 64));
-  uint32_t seg = cdiv(m, nseg);
-  seg = cdiv(seg, 64) * 64;                                    // whole 64-row pruning groups, at most 64 of them
-  return std::min<uint32_t>(std::max<uint32_t>(seg, 64), 4096);
+// Waves that share the live 64-row groups of one tile pair (k_scan deals them round-robin).  More than
+// 32 only adds waves that recompute the live set and leave.
+uint32_t pick_scan_share(const bs_ctx* c, uint32_t pairs, uint32_t m) {
+  const uint32_t ngroups = std::max<uint32_t>(1, cdiv(m, 64));
+  uint32_t j = c->scan_share_override ? c->scan_share_override : std::min<uint32_t>(32, c->target_waves / std::max<uint32_t>(1, pairs));
+  return std::min<uint32_t>(ngroups, std::max<uint32_t>(1, j));
 }
 
 // Build the running-sum table for (cls, pct) in the scratch slot (last one) — single queries.
@@ -505,8 +502,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     delete c;
     return BS_ERR_NO_DEVICE;
   }
-  if (const char* e = std::getenv("BS_SEG_LEN")) c->seg_len_override = (uint32_t)std::atoi(e);
-  if (const char* e = std::getenv("BS_SCAN_Q")) { int q = std::atoi(e); c->scan_q_override = (q == 1 || q == 2) ? (uint32_t)q : 0; }
+  if (const char* e = std::getenv("BS_SCAN_SHARE")) c->scan_share_override = (uint32_t)std::max(0, std::atoi(e));
   if (const char* e = std::getenv("BS_TARGET_WAVES")) c->target_waves = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_FILTER_WAVES")) c->filter_waves = std::max(1, std::atoi(e));
   *out = c;
@@ -761,8 +757,9 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const uint32_t tiles_est = cdiv(std::max<uint32_t>(P, 1), 64);
   const uint32_t pairs_est = cdiv(tiles_est, 2);
   prm.tile_queries = 64;
-  prm.seg_len = pick_seg_len(c, pairs_est, c->M);
-  const uint32_t nseg = cdiv(std::max<uint32_t>(c->M, 1), prm.seg_len);
+  prm.seg_len = 64;
+  // J waves share the live 64-row groups of one tile pair (k_scan deals them round-robin)
+  const uint32_t nseg = pick_scan_share(c, pairs_est, c->M);
 
   const dim3 blk(256);
   const bool captures_possible = c->n_uncaptured > 0 && P > 0;
@@ -1065,9 +1062,9 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
   b.qreq_s = reinterpret_cast<int64_t*>(sq + 512);
   BatchParams prm = batch_params(c);
   prm.collect_stats = 0;
-  prm.seg_len = pick_seg_len(c, 1, M);
+  prm.seg_len = 64;
   if (M) {
-    const uint32_t nseg = cdiv(M, prm.seg_len);
+    const uint32_t nseg = std::min<uint32_t>(cdiv(M, 64), 64);      // waves sharing the live groups of the one query
     launch_scan(c, dim3(cdiv(nseg, 4)), b, prm, M, nseg);
     HIPCHK(c, hipGetLastError());
   }
