@@ -15,7 +15,7 @@ def __getattr__(name):
     if name in ("Context", "BsError", "load_library", "LIB_PATH"):
         from . import capi
         return getattr(capi, name)
-    if name in ("synth", "build", "capi", "plugin", "dist"):
+    if name in ("synth", "build", "capi", "plugin", "dist", "fitspec"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from . import soa
+from . import fitspec, soa
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbsched.so")
@@ -22,7 +22,7 @@ KERNEL_PREPASS, KERNEL_LEADER, KERNEL_QUERY, KERNEL_TABLES, KERNEL_SCAN, KERNEL_
 # every symbol include/bsched.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "bs_abi_version", "bs_strerror", "bs_last_error", "bs_create", "bs_destroy",
-    "bs_nodes_load", "bs_fit_load", "bs_groups_load", "bs_groups_read", "bs_pods_load",
+    "bs_nodes_load", "bs_fit_load", "bs_fit_build", "bs_fit_read", "bs_groups_load", "bs_groups_read", "bs_pods_load",
     "bs_nodes_apply", "bs_nodes_count",
     "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
     "bs_batch_run", "bs_batch_sync", "bs_batch_read",
@@ -86,6 +86,8 @@ def load_library(path: str | None = None):
     L.bs_destroy.argtypes = [vp]
     L.bs_nodes_load.argtypes = [vp, P(soa.NodesStruct)]
     L.bs_fit_load.argtypes = [vp, u32, P(u32)]
+    L.bs_fit_build.argtypes = [vp, P(fitspec.NodeLabelsStruct), P(fitspec.FitTemplatesStruct)]
+    L.bs_fit_read.argtypes = [vp, P(u32)]
     L.bs_groups_load.argtypes = [vp, P(soa.GroupsStruct)]
     L.bs_groups_read.argtypes = [vp, P(soa.GroupsStruct)]
     L.bs_pods_load.argtypes = [vp, P(soa.PodsStruct)]
@@ -181,6 +183,19 @@ class Context:
             bits = np.zeros((fit.n_classes, 1), np.uint32)
         self._chk(self._lib.bs_fit_load(self._h, fit.n_classes, _u32p(bits)), "bs_fit_load")
         self.n_classes = fit.n_classes
+
+    def build_fit(self, node_labels: "fitspec.NodeLabels", templates: "fitspec.FitTemplates"):
+        """checkFit (core.go:741-759) for every (class, node) on the device; replaces load_fit."""
+        assert node_labels.n == self.n
+        ns, ts = node_labels.as_struct(), templates.as_struct()
+        self._chk(self._lib.bs_fit_build(self._h, C.byref(ns), C.byref(ts)), "bs_fit_build")
+        self.n_classes = templates.c
+
+    def read_fit(self) -> soa.FitMasks:
+        words = (self.n + 31) // 32
+        bits = np.zeros(self.n_classes * words + 1, np.uint32)        # +1: never hand out a NULL pointer
+        self._chk(self._lib.bs_fit_read(self._h, _u32p(bits)), "bs_fit_read")
+        return soa.FitMasks(bits[:-1].reshape(self.n_classes, words).copy(), self.n)
 
     def load_groups(self, groups: soa.Groups):
         assert groups.min_resources.shape[0] == self.L

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "bs_kernels.hpp"
+#include "bs_fit.hpp"
 
 using namespace bs;
 
@@ -38,6 +39,19 @@ struct DevBuf {
 
 struct EventPair { hipEvent_t a, b; uint32_t id; };
 
+// Host-side packing of the fit-builder inputs: every array goes into one byte arena (16-byte aligned
+// pieces) that is uploaded with a single copy.
+struct FitArena {
+  std::vector<uint8_t> bytes;
+  size_t put(const void* src, size_t n) {
+    const size_t at = (bytes.size() + 15) & ~(size_t)15;
+    bytes.resize(at + n);
+    if (n) std::memcpy(bytes.data() + at, src, n);
+    return at;
+  }
+};
+template <typename T> const T* at_dev(const void* base, size_t off) { return reinterpret_cast<const T*>((const uint8_t*)base + off); }
+
 }  // namespace
 
 struct bs_ctx {
@@ -50,6 +64,7 @@ struct bs_ctx {
   bool have_nodes = false, have_fit = false, have_groups = false, have_pods = false;
   uint32_t N = 0, Ncap = 0, M = 0, C = 0, fit_words = 0;
   DevBuf d_alloc, d_nreq, d_apres, d_rpres, d_nflags, d_fit, d_kmap, d_m, d_left4, d_lglob;
+  DevBuf d_fitarena, d_fitcols;                  // bs_fit_build inputs / label columns
   std::vector<int64_t> h_alloc, h_nreq;          // [L][N] mirrors (churn + read-back)
   std::vector<uint32_t> h_apres, h_rpres, h_kmap;
   std::vector<uint8_t> h_nflags;
@@ -563,6 +578,129 @@ int bs_fit_load(bs_ctx* c, uint32_t n_classes, const uint32_t* fit_bits) {
   rc = upload_fit(c);
   if (rc == BS_OK && c->have_groups) rc = analyse_groups(c);
   return rc;
+}
+
+int bs_fit_build(bs_ctx* c, const bs_node_labels* nl, const bs_fit_templates* tp) {
+  if (!c || !nl || !tp || tp->c == 0) return BS_ERR_INVALID;
+  if (!c->have_nodes) { c->last_error = "bs_fit_build before bs_nodes_load"; return BS_ERR_STATE; }
+  if (nl->n != c->N) { c->last_error = "bs_fit_build: label table size differs from the snapshot"; return BS_ERR_INVALID; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t N = c->N, C = tp->c;
+  const uint32_t nlab = N ? nl->label_off[N] : 0, ntaint = N ? nl->taint_off[N] : 0;
+  const uint32_t nsel = tp->sel_off[C], nterm = tp->term_off[C], ntol = tp->tol_off[C];
+  const uint32_t nex = tp->exprs.count, nfl = tp->fields.count;
+  if ((nterm && (tp->term_expr_off[nterm] != nex || tp->term_field_off[nterm] != nfl)) || (!nterm && (nex || nfl))) {
+    c->last_error = "bs_fit_build: term offsets do not cover the requirement tables";
+    return BS_ERR_INVALID;
+  }
+  // the label keys any template mentions -> dense columns
+  std::vector<uint32_t> keys(tp->sel_key, tp->sel_key + nsel);
+  keys.insert(keys.end(), tp->exprs.key, tp->exprs.key + nex);
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  auto col_of = [&](uint32_t k) { return (uint32_t)(std::lower_bound(keys.begin(), keys.end(), k) - keys.begin()); };
+  std::vector<uint32_t> sel_col(nsel), ex_col(nex);
+  for (uint32_t i = 0; i < nsel; ++i) sel_col[i] = col_of(tp->sel_key[i]);
+  for (uint32_t i = 0; i < nex; ++i) ex_col[i] = col_of(tp->exprs.key[i]);
+  const uint32_t K = (uint32_t)keys.size(), Npad = (std::max<uint32_t>(N, 1) + 63u) & ~63u;
+
+  FitArena A;
+  const uint32_t zero_off[2] = {0, 0};
+  const size_t o_name = A.put(nl->name, (size_t)N * 4);
+  const size_t o_loff = A.put(N ? nl->label_off : zero_off, (size_t)(N + 1) * 4);
+  const size_t o_lkey = A.put(nl->label_key, (size_t)nlab * 4), o_lval = A.put(nl->label_val, (size_t)nlab * 4);
+  const size_t o_lint = A.put(nl->label_int, (size_t)nlab * 8), o_lok = A.put(nl->label_int_ok, nlab);
+  const size_t o_toff = A.put(N ? nl->taint_off : zero_off, (size_t)(N + 1) * 4);
+  const size_t o_tkey = A.put(nl->taint_key, (size_t)ntaint * 4), o_tval = A.put(nl->taint_val, (size_t)ntaint * 4);
+  const size_t o_teff = A.put(nl->taint_effect, ntaint);
+  const size_t o_keys = A.put(keys.data(), (size_t)K * 4);
+  const size_t o_flags = A.put(tp->flags, C);
+  const size_t o_soff = A.put(tp->sel_off, (size_t)(C + 1) * 4), o_scol = A.put(sel_col.data(), (size_t)nsel * 4);
+  const size_t o_sval = A.put(tp->sel_val, (size_t)nsel * 4);
+  const size_t o_moff = A.put(tp->term_off, (size_t)(C + 1) * 4);
+  const size_t o_meo = A.put(nterm ? tp->term_expr_off : zero_off, (size_t)(nterm + 1) * 4);
+  const size_t o_mfo = A.put(nterm ? tp->term_field_off : zero_off, (size_t)(nterm + 1) * 4);
+  auto put_req = [&](const bs_requirements& r, const uint32_t* key, size_t (&o)[6]) {
+    const uint32_t nv = r.count ? r.val_off[r.count] : 0;
+    o[0] = A.put(key, (size_t)r.count * 4);
+    o[1] = A.put(r.op, r.count);
+    o[2] = A.put(r.count ? r.val_off : zero_off, (size_t)(r.count + 1) * 4);
+    o[3] = A.put(r.val, (size_t)nv * 4);
+    o[4] = A.put(r.val_int, (size_t)nv * 8);
+    o[5] = A.put(r.val_int_ok, nv);
+  };
+  size_t o_ex[6], o_fl[6];
+  put_req(tp->exprs, ex_col.data(), o_ex);
+  put_req(tp->fields, tp->fields.key, o_fl);
+  const size_t o_ooff = A.put(tp->tol_off, (size_t)(C + 1) * 4);
+  const size_t o_okey = A.put(tp->tol_key, (size_t)ntol * 4), o_oval = A.put(tp->tol_val, (size_t)ntol * 4);
+  const size_t o_oop = A.put(tp->tol_op, ntol), o_oeff = A.put(tp->tol_effect, ntol);
+
+  HIPCHK(c, c->d_fitarena.reserve(A.bytes.size() + 16));
+  HIPCHK(c, hipMemcpyAsync(c->d_fitarena.p, A.bytes.data(), A.bytes.size(), hipMemcpyHostToDevice, c->stream));
+  const size_t colcells = (size_t)std::max<uint32_t>(K, 1) * Npad;
+  const size_t o_cval = 0, o_cival = (colcells * 4 + 15) & ~(size_t)15, o_cflag = o_cival + colcells * 8;
+  HIPCHK(c, c->d_fitcols.reserve(o_cflag + colcells));
+  HIPCHK(c, hipMemsetAsync(c->d_fitcols.p, 0, o_cflag + colcells, c->stream));
+
+  const void* B = c->d_fitarena.p;
+  FitNodesDev nd{};
+  nd.n = N;
+  nd.name = at_dev<uint32_t>(B, o_name);
+  nd.label_off = at_dev<uint32_t>(B, o_loff); nd.label_key = at_dev<uint32_t>(B, o_lkey); nd.label_val = at_dev<uint32_t>(B, o_lval);
+  nd.label_int = at_dev<int64_t>(B, o_lint); nd.label_int_ok = at_dev<uint8_t>(B, o_lok);
+  nd.taint_off = at_dev<uint32_t>(B, o_toff); nd.taint_key = at_dev<uint32_t>(B, o_tkey); nd.taint_val = at_dev<uint32_t>(B, o_tval);
+  nd.taint_effect = at_dev<uint8_t>(B, o_teff);
+  nd.nflags = c->d_nflags.as<uint8_t>();
+  FitCols cols{};
+  cols.K = K; cols.Npad = Npad;
+  cols.keys = at_dev<uint32_t>(B, o_keys);
+  cols.val = (uint32_t*)((uint8_t*)c->d_fitcols.p + o_cval);
+  cols.ival = (int64_t*)((uint8_t*)c->d_fitcols.p + o_cival);
+  cols.flag = (uint8_t*)c->d_fitcols.p + o_cflag;
+  FitTplDev td{};
+  td.c = C; td.field_name_key = tp->field_name_key;
+  td.flags = at_dev<uint8_t>(B, o_flags);
+  td.sel_off = at_dev<uint32_t>(B, o_soff); td.sel_col = at_dev<uint32_t>(B, o_scol); td.sel_val = at_dev<uint32_t>(B, o_sval);
+  td.term_off = at_dev<uint32_t>(B, o_moff); td.term_expr_off = at_dev<uint32_t>(B, o_meo); td.term_field_off = at_dev<uint32_t>(B, o_mfo);
+  auto req_dev = [&](const size_t (&o)[6]) {
+    FitReqDev r{};
+    r.key = at_dev<uint32_t>(B, o[0]); r.op = at_dev<uint8_t>(B, o[1]); r.val_off = at_dev<uint32_t>(B, o[2]);
+    r.val = at_dev<uint32_t>(B, o[3]); r.val_int = at_dev<int64_t>(B, o[4]); r.val_int_ok = at_dev<uint8_t>(B, o[5]);
+    return r;
+  };
+  td.ex = req_dev(o_ex); td.fl = req_dev(o_fl);
+  td.tol_off = at_dev<uint32_t>(B, o_ooff); td.tol_key = at_dev<uint32_t>(B, o_okey); td.tol_val = at_dev<uint32_t>(B, o_oval);
+  td.tol_op = at_dev<uint8_t>(B, o_oop); td.tol_effect = at_dev<uint8_t>(B, o_oeff);
+
+  c->C = C;
+  c->fit_words = cdiv(N, 32);
+  c->h_fit.assign((size_t)C * c->fit_words, 0);
+  HIPCHK(c, c->d_fit.reserve(std::max<size_t>(4, c->h_fit.size() * 4)));
+  if (N) {
+    const uint32_t nb = cdiv(N, 256);
+    hipLaunchKernelGGL(k_fit_cols, dim3(nb), dim3(256), 0, c->stream, nd, cols);
+    hipLaunchKernelGGL(k_fit_match, dim3(nb, std::min<uint32_t>(C, 1024)), dim3(256), 0, c->stream, nd, td, cols, c->d_fit.as<uint32_t>(), c->fit_words);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_fit.data(), c->d_fit.p, c->h_fit.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_fit = true;
+  rc = ensure_tables(c);
+  if (rc == BS_OK && c->have_groups) rc = analyse_groups(c);
+  return rc;
+}
+
+int bs_fit_read(bs_ctx* c, uint32_t* out) {
+  if (!c || !out) return BS_ERR_INVALID;
+  if (!c->have_fit) { c->last_error = "bs_fit_read before a fit load / build"; return BS_ERR_STATE; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t bytes = (size_t)c->C * c->fit_words * 4;
+  if (bytes) HIPCHK(c, hipMemcpyAsync(out, c->d_fit.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return BS_OK;
 }
 
 int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {

@@ -208,3 +208,110 @@ def make(config: str = "cfg3", scenario: str = "tail", seed: int = 20260921, **o
     groups, pods = make_groups_and_pods(seed, cfg["pods"], cfg["groups"], cfg["scalars"], cfg["classes"], scenario)
     meta = dict(config=config, scenario=scenario, seed=seed, **cfg)
     return nodes, fit, groups, pods, meta
+
+
+# ---------------------------------------------------------------------------------------------------
+# checkFit inputs (core.go:741-759): node labels / taints and pod templates in the object form of
+# fitspec.py.  `quirks` mixes in the corner cases of the upstream matchers (requirements that fail to
+# convert, empty terms, non-integer Gt/Lt operands, empty keys and values, unknown operators/effects).
+def make_fit_scene(seed: int, n: int, classes: int, quirks: bool = True):
+    import random
+    rnd = random.Random(seed * 1000003 + n * 131 + classes)
+    zones = ["az-a", "az-b", "az-c", "az-d"]
+    itypes = ["c32", "c64", "g96"]
+    teams = ["ml", "web", "batch"]
+    odd_values = ["12a", "+5", "-3", "", "007", "9223372036854775807", "9223372036854775808", "x_y.z-1"]
+    nodes = []
+    for i in range(n):
+        it = rnd.choices(itypes, [5, 3, 2])[0]
+        labels = {"kubernetes.io/hostname": f"node-{i}", "topology.kubernetes.io/zone": rnd.choice(zones),
+                  "node.kubernetes.io/instance-type": it, "pool": f"p{rnd.randrange(8)}", "rack": str(rnd.randrange(40))}
+        if it == "g96":
+            labels["gpu-count"] = "8"
+        if rnd.random() < 0.8:
+            labels["disk"] = rnd.choice(["ssd", "hdd"])
+        if quirks and rnd.random() < 0.3:
+            labels["weird"] = rnd.choice(odd_values)
+        taints = []
+        if rnd.random() < 0.15:
+            taints.append(("dedicated", rnd.choice(teams), "NoSchedule"))
+        if it == "g96" and rnd.random() < 0.5:
+            taints.append(("nvidia.com/gpu", "present", "NoSchedule"))
+        if rnd.random() < 0.03:
+            taints.append(("node.kubernetes.io/unreachable", "", "NoExecute"))
+        if rnd.random() < 0.10:
+            taints.append(("prefer", "x", "PreferNoSchedule"))
+        if quirks and rnd.random() < 0.01:
+            taints.append(("odd", "y", "SomethingElse"))
+        nodes.append({"name": f"node-{i}", "labels": labels, "taints": taints})
+
+    def rand_expr():
+        kind = rnd.randrange(12 if quirks else 7)
+        if kind == 0:
+            return ("topology.kubernetes.io/zone", "In", rnd.sample(zones, rnd.randrange(1, 4)))
+        if kind == 1:
+            return ("node.kubernetes.io/instance-type", "NotIn", [rnd.choice(itypes)])
+        if kind == 2:
+            return (rnd.choice(["gpu-count", "disk", "weird"]), "Exists", [])
+        if kind == 3:
+            return (rnd.choice(["gpu-count", "disk", "missing"]), "DoesNotExist", [])
+        if kind == 4:
+            return ("rack", "Gt", [str(rnd.randrange(-2, 40))])
+        if kind == 5:
+            return ("rack", "Lt", [str(rnd.randrange(0, 45))])
+        if kind == 6:
+            return ("pool", "In", [f"p{rnd.randrange(8)}", f"p{rnd.randrange(8)}"])
+        if kind == 7:
+            return ("weird", rnd.choice(["Gt", "Lt", "In", "NotIn"]), [rnd.choice(["4", "-3", "007", "12a"])])
+        if kind == 8:   # conversion errors: wrong value counts / non-integer operand
+            return rnd.choice([("pool", "In", []), ("disk", "Exists", ["ssd"]), ("rack", "Gt", ["abc"]), ("rack", "Lt", ["1", "2"]),
+                               ("rack", "Gt", [])])
+        if kind == 9:   # unknown operator, invalid key, invalid value
+            return rnd.choice([("pool", "Foo", ["p1"]), ("bad key!", "Exists", []), ("pool", "In", ["not valid!"]),
+                               ("a/b/c", "DoesNotExist", []), ("pool", "NotIn", ["x" * 64])])
+        if kind == 10:
+            return ("weird", "In", [""])                       # the empty string is a legal label value
+        return ("rack", rnd.choice(["Gt", "Lt"]), [rnd.choice(["+5", "-0", "9223372036854775807", "9223372036854775808"])])
+
+    def rand_field():
+        kind = rnd.randrange(6 if quirks else 2)
+        if kind == 0:
+            return ("metadata.name", "In", [f"node-{rnd.randrange(max(n, 1))}"])
+        if kind == 1:
+            return ("metadata.name", "NotIn", [f"node-{rnd.randrange(max(n, 1))}"])
+        if kind == 2:
+            return ("metadata.namespace", rnd.choice(["In", "NotIn"]), [rnd.choice(["", "default"])])
+        if kind == 3:
+            return ("metadata.name", "In", ["node-0", "node-1"])   # field selectors take exactly one value
+        if kind == 4:
+            return ("metadata.name", "Exists", [])
+        return ("metadata.name", "Bogus", ["node-0"])
+
+    tol_pool = [("dedicated", "Equal", "ml", "NoSchedule"), ("dedicated", "Equal", "web", ""), ("dedicated", "Exists", "", ""),
+                ("nvidia.com/gpu", "", "present", "NoSchedule"), ("nvidia.com/gpu", "Exists", "", "NoExecute"),
+                ("node.kubernetes.io/unreachable", "Exists", "", "NoExecute"), ("", "Exists", "", ""),
+                ("", "Exists", "", "NoSchedule"), ("dedicated", "Equal", "batch", "PreferNoSchedule")]
+    if quirks:
+        tol_pool += [("dedicated", "Weird", "ml", ""), ("", "Equal", "present", ""), ("", "", "", "NoExecute"),
+                     ("dedicated", "Equal", "ml", "SomethingElse")]
+    templates = []
+    for _ in range(classes):
+        tp = {"node_selector": {}, "required": None, "tolerations": []}
+        r = rnd.random()
+        if r < 0.35:
+            tp["node_selector"]["topology.kubernetes.io/zone"] = rnd.choice(zones)
+        if 0.25 < r < 0.45:
+            tp["node_selector"]["disk"] = rnd.choice(["ssd", "hdd"])
+        if quirks and rnd.random() < 0.06:
+            tp["node_selector"][rnd.choice(["bad key!", "pool"])] = rnd.choice(["p1", "not valid!", ""])
+        if rnd.random() < 0.5:
+            terms = []
+            for _t in range(rnd.choice([0, 1, 1, 1, 2, 3]) if quirks else rnd.choice([1, 1, 2])):
+                term = {"expressions": [rand_expr() for _e in range(rnd.choice([0, 1, 1, 2, 3]) if quirks else rnd.choice([1, 2]))],
+                        "fields": [rand_field() for _f in range(rnd.choice([0, 0, 0, 1, 2]) if quirks else 0)]}
+                terms.append(term)
+            tp["required"] = terms
+        for _o in range(rnd.choice([0, 0, 1, 1, 2, 3])):
+            tp["tolerations"].append(rnd.choice(tol_pool))
+        templates.append(tp)
+    return nodes, templates

@@ -158,6 +158,78 @@ typedef struct bs_pods_soa {
   const uint8_t*  flags;       /* [p] BS_POD_*                                                */
 } bs_pods_soa;
 
+/* ---- fit-mask builder: checkFit (core.go:741-759) for every (pod-template class, node) ----------
+ * checkFit = predicates.PodMatchNodeSelector && predicates.PodToleratesNodeTaints of
+ * k8s.io/kubernetes v1.17.5 (go.mod:102; not vendored).  Strings stay on the caller's side: every
+ * string crosses as an interned id (equal strings <=> equal ids, id 0 <=> the empty string), integers
+ * that upstream parses with strconv.ParseInt(s, 10, 64) cross as (value, ok). */
+#define BS_EFFECT_NONE               0u /* "" (tolerations only: matches every effect) */
+#define BS_EFFECT_NO_SCHEDULE        1u
+#define BS_EFFECT_PREFER_NO_SCHEDULE 2u /* ignored by PodToleratesNodeTaints' filter */
+#define BS_EFFECT_NO_EXECUTE         3u /* any other effect string: a distinct code >= 4 */
+
+#define BS_TOL_OP_DEFAULT 0u /* "" behaves as Equal */
+#define BS_TOL_OP_EQUAL   1u
+#define BS_TOL_OP_EXISTS  2u /* any other operator string: >= 3, tolerates nothing */
+
+#define BS_OP_IN             0u /* v1.NodeSelectorOperator */
+#define BS_OP_NOT_IN         1u
+#define BS_OP_EXISTS         2u
+#define BS_OP_DOES_NOT_EXIST 3u
+#define BS_OP_GT             4u
+#define BS_OP_LT             5u
+#define BS_OP_INVALID     0x80u /* OR-ed in by the caller: validateLabelKey / validateLabelValue fails
+                                   or the operator string is unknown (the selector conversion errors
+                                   and the whole term matches nothing); value-count errors are found
+                                   by the library from val_off */
+
+#define BS_TPL_HAS_REQUIRED     0x1u /* Affinity.NodeAffinity.RequiredDuringSchedulingIgnoredDuringExecution != nil */
+#define BS_TPL_SELECTOR_INVALID 0x2u /* a Spec.NodeSelector key/value fails label validation:
+                                        labels.SelectorFromSet returns the empty selector (matches all) */
+
+typedef struct bs_node_labels {
+  uint32_t n;                    /* must equal the loaded snapshot's n; list order                 */
+  const uint32_t* name;          /* [n] metadata.name (for matchFields)                            */
+  const uint32_t* label_off;     /* [n+1] CSR into label_*: node.Labels (keys unique per node)     */
+  const uint32_t* label_key;
+  const uint32_t* label_val;
+  const int64_t*  label_int;     /* ParseInt(value, 10, 64)                                        */
+  const uint8_t*  label_int_ok;  /* 1 iff it parsed                                                */
+  const uint32_t* taint_off;     /* [n+1] CSR into taint_*: node.Spec.Taints                       */
+  const uint32_t* taint_key;
+  const uint32_t* taint_val;
+  const uint8_t*  taint_effect;  /* BS_EFFECT_*                                                    */
+} bs_node_labels;
+
+typedef struct bs_requirements { /* a table of v1.NodeSelectorRequirement                          */
+  uint32_t count;
+  const uint32_t* key;           /* [count]                                                        */
+  const uint8_t*  op;            /* [count] BS_OP_* (| BS_OP_INVALID)                              */
+  const uint32_t* val_off;       /* [count+1] CSR into val*                                        */
+  const uint32_t* val;
+  const int64_t*  val_int;
+  const uint8_t*  val_int_ok;
+} bs_requirements;
+
+typedef struct bs_fit_templates { /* one entry per distinct pod template (fit class)               */
+  uint32_t c;
+  uint32_t field_name_key;       /* interned "metadata.name"                                       */
+  const uint8_t*  flags;         /* [c] BS_TPL_*                                                   */
+  const uint32_t* sel_off;       /* [c+1] CSR: Spec.NodeSelector pairs                             */
+  const uint32_t* sel_key;
+  const uint32_t* sel_val;
+  const uint32_t* term_off;      /* [c+1] CSR: Required.NodeSelectorTerms (ORed)                   */
+  const uint32_t* term_expr_off; /* [terms+1] CSR into exprs:  term.MatchExpressions (ANDed)       */
+  const uint32_t* term_field_off;/* [terms+1] CSR into fields: term.MatchFields (ANDed)            */
+  bs_requirements exprs;
+  bs_requirements fields;
+  const uint32_t* tol_off;       /* [c+1] CSR: Spec.Tolerations                                    */
+  const uint32_t* tol_key;
+  const uint32_t* tol_val;
+  const uint8_t*  tol_op;        /* BS_TOL_OP_*                                                    */
+  const uint8_t*  tol_effect;    /* BS_EFFECT_*                                                    */
+} bs_fit_templates;
+
 /* Outputs of one batch (any pointer may be NULL = not wanted). */
 typedef struct bs_batch_out {
   uint8_t*  pf_code;       /* [p] BS_PF_*                                                     */
@@ -194,6 +266,11 @@ int bs_destroy(bs_ctx* ctx);
 int bs_nodes_load(bs_ctx* ctx, const bs_nodes_soa* nodes);
 /* fit[c][n] = checkFit(rep pod of class c, node n), core.go:741-759; bit n&31 of word n>>5 */
 int bs_fit_load(bs_ctx* ctx, uint32_t n_classes, const uint32_t* fit_bits);
+/* Same result computed on the device from labels / taints / templates (replaces the checkFit call of
+ * core.go:646 for every (class, node) at once); nodes flagged NIL / NO_NODE / TAINT_ERR get 0.
+ * bs_fit_read copies the current masks out ([n_classes][ceil(n/32)] words, caller-sized). */
+int bs_fit_build(bs_ctx* ctx, const bs_node_labels* nodes, const bs_fit_templates* templates);
+int bs_fit_read(bs_ctx* ctx, uint32_t* fit_bits_out);
 int bs_groups_load(bs_ctx* ctx, const bs_groups_soa* groups);
 int bs_groups_read(bs_ctx* ctx, bs_groups_soa* groups_out); /* caller-sized arrays, g must match */
 int bs_pods_load(bs_ctx* ctx, const bs_pods_soa* pods);

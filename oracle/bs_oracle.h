@@ -109,6 +109,13 @@ int  orc_ttl_get(const orc_ttl* t, uint64_t key, int64_t now_ns, uint64_t* val);
 void orc_ttl_delete(orc_ttl* t, uint64_t key);
 uint32_t orc_ttl_count(const orc_ttl* t, int64_t now_ns); /* len(Items()) */
 
+/* checkFit (core.go:741-759) for one (class, node) pair and for all pairs; bs_oracle_fit.c lists the
+ * k8s.io/kubernetes v1.17.5 rules it follows (U6).  fit_bits: [c][ceil(n/32)]. */
+int  orc_check_fit(const bs_node_labels* nodes, const uint8_t* node_flags, const bs_fit_templates* tpl,
+                   uint32_t cls, uint32_t node);
+void orc_fit_build(const bs_node_labels* nodes, const uint8_t* node_flags, const bs_fit_templates* tpl,
+                   uint32_t* fit_bits);
+
 #ifdef __cplusplus
 }
 #endif

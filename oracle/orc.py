@@ -18,12 +18,13 @@ _ROOT = os.path.dirname(_HERE)
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 soa = importlib.import_module("batch-scheduler_amd.soa")
+fitspec = importlib.import_module("batch-scheduler_amd.fitspec")
 
 LIB_PATH = os.path.join(_HERE, "libbs_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("bs_oracle.c", "bs_oracle.h")] + [os.path.join(_ROOT, "include", "bsched.h")]
+    src = [os.path.join(_HERE, f) for f in ("bs_oracle.c", "bs_oracle_fit.c", "bs_oracle.h")] + [os.path.join(_ROOT, "include", "bsched.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libbs_oracle.so"], stdout=subprocess.DEVNULL)
@@ -103,8 +104,28 @@ def lib():
         L.orc_ttl_delete.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_ttl_count.restype = C.c_uint32
         L.orc_ttl_count.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_check_fit.restype = C.c_int
+        L.orc_check_fit.argtypes = [C.POINTER(fitspec.NodeLabelsStruct), C.POINTER(C.c_uint8), C.POINTER(fitspec.FitTemplatesStruct), C.c_uint32, C.c_uint32]
+        L.orc_fit_build.restype = None
+        L.orc_fit_build.argtypes = [C.POINTER(fitspec.NodeLabelsStruct), C.POINTER(C.c_uint8), C.POINTER(fitspec.FitTemplatesStruct), C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
+
+
+def fit_build(node_labels, node_flags, templates) -> np.ndarray:
+    """checkFit for every (class, node): [c, ceil(n/32)] uint32 masks (bs_oracle_fit.c)."""
+    flags = np.ascontiguousarray(node_flags, dtype=np.uint8)
+    assert flags.shape == (node_labels.n,)
+    out = np.zeros((templates.c, (node_labels.n + 31) // 32), np.uint32)
+    ns, ts = node_labels.as_struct(), templates.as_struct()
+    lib().orc_fit_build(C.byref(ns), flags.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(ts), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def check_fit(node_labels, node_flags, templates, cls: int, node: int) -> bool:
+    flags = np.ascontiguousarray(node_flags, dtype=np.uint8)
+    ns, ts = node_labels.as_struct(), templates.as_struct()
+    return bool(lib().orc_check_fit(C.byref(ns), flags.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(ts), cls, node))
 
 
 def scale(a: int, pct: float) -> int:

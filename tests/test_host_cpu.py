@@ -49,7 +49,7 @@ def test_product_never_imports_the_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "bs_oracle" not in text and "import orc" not in text and "naive_ref" not in text, f
+                assert "bs_oracle" not in text and "import orc" not in text and "naive_ref" not in text and "naive_fit" not in text, f
 
 
 def test_fit_masks_roundtrip(soa):
