@@ -84,7 +84,7 @@ struct BatchDev {
   uint32_t* cap_epoch;      // epoch at which pgs.Pod becomes non-nil (0 = already set, INF = never)
   // epochs
   uint32_t* epoch;          // [P] captures at indices <= i
-  uint32_t* nepochs;        // [1] E + 1
+  uint32_t* nepochs;        // [4] [0] E + 1; [1] first pod that reaches findMaxPG (early Filter)
   int32_t* leader_epoch;    // [E+1]
   uint8_t* panic_epoch;     // [E+1]
   // per pod
@@ -132,6 +132,7 @@ struct BatchParams {
   uint32_t rank, nranks;
   int32_t sop_leader0;         // sop.maxFinishedPG carried into the batch (-1 none)
   uint32_t run_filter;
+  uint32_t early_filter;       // Filter parameters come from k_fparams_early (Filter overlaps the node scan)
   uint32_t collect_stats;
   uint32_t mcap;               // table row capacity
   uint32_t seg_len;            // unused (k_scan deals 64-row groups)
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsD
     *b.ntiles = 0;
     *b.qcount = 0;
     if (no_capture) *b.nepochs = 1;
+    b.nepochs[1] = BS_INF;
   }
   if (i < 8 && prm.collect_stats) b.stats[i] = 0;
   if (i >= pods.p) return;
@@ -577,6 +579,11 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
     b.tcode[i] = code;
     b.stage[i] = st;
     b.leader_raw[i] = leader;
+  }
+  {
+    // first pod of the queue that reaches findMaxPG (lanes are in queue order)
+    const unsigned long long rb = __ballot(valid && (st & ST_REACH6));
+    if (rb && lane_id() == __ffsll((long long)rb) - 1) atomicMin(&b.nepochs[1], i);
   }
   // Tile emission.  The lanes of this wave that query the same table become one scan tile: one lane
   // reserves `count` consecutive slots of the tile-ordered request arrays and appends the tile.  No
@@ -1244,7 +1251,7 @@ __global__ __launch_bounds__(256) void k_final(PodsDev pods, GroupsDev gr, Nodes
   if (i < pods.p) {
     const int32_t leader = jp1 ? b.leader_raw[jp1 - 1u] : prm.sop_leader0;
     b.pf_leader[i] = leader;
-    if (prm.run_filter) filter_params_for<TS>(pods, gr, b, prm, i, code, leader);
+    if (prm.run_filter && !prm.early_filter) filter_params_for<TS>(pods, gr, b, prm, i, code, leader);
   }
 }
 
@@ -1253,6 +1260,25 @@ __global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchPar
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pods.p) return;
   filter_params_for<-1>(pods, gr, b, prm, i, b.pf_code[i], b.pf_leader[i]);
+}
+
+// Filter parameters BEFORE the node scan has run (no first-pod capture possible in this batch, so there
+// is one findMaxPG result Lc for the whole batch).  What the scan can still change for a pod is only
+// whether it passes PreFilter (REJECT_* / replayed ERR_DENIED), never its Filter inputs:
+//   * sop.maxFinishedPG seen by pod i (core.go:524) is Lc once some pod at or before i has reached
+//     findMaxPG, and the value carried into the batch before that.  Whether later pods reach findMaxPG
+//     depends on rejections, but every pod that does writes the same Lc — and the FIRST pod that
+//     tentatively reaches it really does (a replayed deny needs an earlier, reaching, rejected pod).
+//   * the pod's own request and the leader's MinResources are batch inputs.
+// So Filter runs for every tentatively passing pod concurrently with the scan; k_tally then voids the
+// rows of the pods PreFilter turned down.
+template <int TS>
+__global__ void k_fparams_early(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pods.p) return;
+  const uint8_t pf = (b.stage[i] & ST_OWNED) ? b.tcode[i] : (uint8_t)BS_PF_NOT_OWNED;
+  const int32_t leader = i >= b.nepochs[1] ? b.leader_epoch[0] : prm.sop_leader0;
+  filter_params_for<TS>(pods, gr, b, prm, i, pf, leader);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1536,6 +1562,23 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
     }
   }
   if (mine && cnt) atomicAdd(&b.fl_feasible[p0 + lane], cnt);
+}
+
+// Early Filter ran on the tentative PreFilter verdict.  The framework never calls Filter for a pod that
+// PreFilter turned down, so such a pod's row is void: code NOT_RUN, no feasible node, zero bitmap
+// words.  grid.y splits the bitmap words so the scattered stores come from many CUs.
+__global__ __launch_bounds__(256) void k_void_rows(PodsDev pods, BatchDev b, uint32_t words, uint32_t words_per_block) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= pods.p) return;
+  const uint8_t pf = b.pf_code[i];
+  if (pf != BS_PF_NOT_OWNED && BS_PF_IS_PASS(pf)) return;
+  if ((b.fflags[i] >> 8) == BS_FL_NOT_RUN) return;            // the early pass already left it out
+  if (blockIdx.y == 0) {
+    b.fl_code[i] = BS_FL_NOT_RUN;
+    b.fl_feasible[i] = 0;
+  }
+  const uint32_t w0 = blockIdx.y * words_per_block, w1 = min(words, w0 + words_per_block);
+  for (uint32_t w = w0; w < w1; ++w) b.fl_bitmap[(size_t)w * pods.p + i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -77,6 +77,9 @@ struct bs_ctx {
   int32_t steady_table = -1;        // the one table every reservation query uses when no capture can occur, -1 unknown
   hipStream_t stream2 = nullptr;    // side stream: that table is built while the pod pre-pass runs
   hipEvent_t ev_scan_done = nullptr, ev_tables = nullptr;
+  uint64_t early_filter_min = 200000000ull;   // pod x node pairs from which Filter overlaps the scan
+  hipStream_t stream3 = nullptr;    // early Filter: runs beside the node scan when no capture can occur
+  hipEvent_t ev_query = nullptr, ev_filter = nullptr;
   DevBuf d_gmm, d_gsc, d_gmatched, d_gflags, d_gcls, d_gminres, d_gmrpres, d_gocc;
 
   // ---- pods
@@ -135,7 +138,7 @@ const char* kKernelNames[BS_KERNEL_COUNT] = {"prepass", "leader", "query", "tabl
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-int timer_begin(bs_ctx* c, uint32_t id, size_t* slot) {
+int timer_begin(bs_ctx* c, uint32_t id, size_t* slot, hipStream_t st = nullptr) {
   *slot = (size_t)-1;
   if (!c->cfg.enable_timing) return BS_OK;
   // mode 1: only the two dominant kernels, and only every 8th batch — an event pair costs a few
@@ -149,12 +152,12 @@ int timer_begin(bs_ctx* c, uint32_t id, size_t* slot) {
   }
   *slot = c->events_used++;
   c->events[*slot].id = id;
-  HIPCHK(c, hipEventRecord(c->events[*slot].a, c->stream));
+  HIPCHK(c, hipEventRecord(c->events[*slot].a, st ? st : c->stream));
   return BS_OK;
 }
-int timer_end(bs_ctx* c, size_t slot) {
+int timer_end(bs_ctx* c, size_t slot, hipStream_t st = nullptr) {
   if (slot == (size_t)-1) return BS_OK;
-  HIPCHK(c, hipEventRecord(c->events[slot].b, c->stream));
+  HIPCHK(c, hipEventRecord(c->events[slot].b, st ? st : c->stream));
   return BS_OK;
 }
 int timer_collect(bs_ctx* c) {
@@ -169,16 +172,17 @@ int timer_collect(bs_ctx* c) {
   return BS_OK;
 }
 
-#define TIMED(ctx, id, ...)                                    \
+#define TIMED_ON(ctx, id, st, ...)                             \
   do {                                                         \
     size_t _slot;                                              \
-    int _rc = timer_begin(ctx, id, &_slot);                    \
+    int _rc = timer_begin(ctx, id, &_slot, st);                \
     if (_rc) return _rc;                                       \
     __VA_ARGS__;                                               \
     HIPCHK(ctx, hipGetLastError());                            \
-    _rc = timer_end(ctx, _slot);                               \
+    _rc = timer_end(ctx, _slot, st);                           \
     if (_rc) return _rc;                                       \
   } while (0)
+#define TIMED(ctx, id, ...) TIMED_ON(ctx, id, (hipStream_t) nullptr, __VA_ARGS__)
 
 int use_device(bs_ctx* c) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -406,6 +410,16 @@ void launch_tables_local(bs_ctx* c, hipStream_t st, dim3 grid, const NodesDev& n
   }
 }
 
+// k_filter geometry: a wave owns one 64-pod tile and a run of 64-node blocks
+void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const NodesDev& nd, const BatchDev& b) {
+  const uint32_t W = cdiv(c->N, 64), ptiles = cdiv(c->P, 64);
+  if (!W || !ptiles) return;
+  uint32_t nsplit = std::max<uint32_t>(1, c->filter_waves / ptiles);
+  nsplit = std::min<uint32_t>(nsplit, std::max<uint32_t>(cdiv(W, 2), 1));
+  const uint32_t bpw = std::max<uint32_t>(2, cdiv(cdiv(std::max<uint32_t>(W, 1), nsplit), 2) * 2);   // multiple of NB
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(ptiles, 4), cdiv(W, bpw)), dim3(256), 0, st, pd, nd, b, bpw, 1u);
+}
+
 // Waves that share the live 64-row groups of one tile pair (k_scan deals them round-robin).  More than
 // 32 only adds waves that recompute the live set and leave.
 uint32_t pick_scan_share(const bs_ctx* c, uint32_t pairs, uint32_t m) {
@@ -512,11 +526,15 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     return BS_ERR_NO_DEVICE;
   }
   if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_query, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_filter, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_scan_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return BS_ERR_NO_DEVICE;
   }
+  if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) c->early_filter_min = std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("BS_SCAN_SHARE")) c->scan_share_override = (uint32_t)std::max(0, std::atoi(e));
   if (const char* e = std::getenv("BS_TARGET_WAVES")) c->target_waves = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_FILTER_WAVES")) c->filter_waves = std::max(1, std::atoi(e));
@@ -536,6 +554,9 @@ int bs_destroy(bs_ctx* c) {
   }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+  if (c->ev_query) (void)hipEventDestroy(c->ev_query);
+  if (c->ev_filter) (void)hipEventDestroy(c->ev_filter);
   if (c->ev_scan_done) (void)hipEventDestroy(c->ev_scan_done);
   if (c->ev_tables) (void)hipEventDestroy(c->ev_tables);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -907,6 +928,12 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   // table (analyse_groups).  Build it on the side stream while the pod pre-pass and k_query run.
   const bool side_tables = !captures_possible && c->steady_table >= 0 && c->M && P && c->cfg.enable_timing < 2;
   const uint32_t side_slot = side_tables ? (uint32_t)c->steady_table : 0u;
+  // No capture possible: the Filter inputs do not depend on the node scan (k_fparams_early), so Filter
+  // runs on its own stream beside scan / reject / final and k_tally voids the rows PreFilter turned down.
+  // Joining a second stream costs ~10-20 us of cross-queue signalling, so only when Filter is long enough.
+  const bool early_filter = run_filter && !captures_possible && P && N && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing < 2 &&
+                            (uint64_t)P * N >= c->early_filter_min;
+  prm.early_filter = early_filter ? 1u : 0u;
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
   if (side_tables) {
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_scan_done, 0));      // the previous batch's scan is done with the tables
@@ -955,6 +982,21 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       }
     }
   });
+  if (early_filter) {
+    HIPCHK(c, hipEventRecord(c->ev_query, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_query, 0));
+    const dim3 fg(cdiv(P, 256));
+    switch (ts) {
+      case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<0>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
+      case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<1>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
+      case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<2>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
+      case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<3>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
+      case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<4>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
+      default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<-1>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
+    }
+    TIMED_ON(c, BS_KERNEL_FILTER, c->stream3, launch_filter(c, c->stream3, pd, nd, b));
+    HIPCHK(c, hipEventRecord(c->ev_filter, c->stream3));
+  }
   // ---- running-sum tables of the (class, percent) pairs some query uses
   if (c->M && P) {
     if (side_tables) {
@@ -985,14 +1027,12 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       }
     }
   });
-  if (run_filter && P) {
-    const uint32_t ptiles = cdiv(P, 64);
-    uint32_t nsplit = std::max<uint32_t>(1, c->filter_waves / ptiles);
-    nsplit = std::min<uint32_t>(nsplit, std::max<uint32_t>(cdiv(W, 2), 1));
-    const uint32_t bpw = std::max<uint32_t>(2, cdiv(cdiv(std::max<uint32_t>(W, 1), nsplit), 2) * 2);   // multiple of NB
-    TIMED(c, BS_KERNEL_FILTER, {
-      if (W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(ptiles, 4), cdiv(W, bpw)), blk, 0, c->stream, pd, nd, b, bpw, 1u);
-    });
+  if (run_filter && P && !early_filter) {
+    TIMED(c, BS_KERNEL_FILTER, launch_filter(c, c->stream, pd, nd, b));
+  } else if (early_filter) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_filter, 0));
+    const uint32_t wpb = 8;
+    hipLaunchKernelGGL(k_void_rows, dim3(cdiv(P, 256), cdiv(W, wpb)), blk, 0, c->stream, pd, b, W, wpb);
   } else if (P) {
     HIPCHK(c, hipMemsetAsync(b.fl_code, BS_FL_NOT_RUN, P, c->stream));
   }

@@ -426,3 +426,63 @@ def test_partitioned_ranks_equal_single(scenario, bsa, soa, orc):
             c.sync()
             assert np.array_equal(c.read(bitmap=False).group_ready, single.group_ready)
             c.close()
+
+
+# ---- early Filter (Filter on its own stream beside the node scan; rows of pods PreFilter turns down are
+# voided afterwards).  Production switches it on from 2e8 pod x node pairs; here it is forced on.
+@pytest.fixture
+def early(monkeypatch):
+    monkeypatch.setenv("BS_EARLY_FILTER_MIN", "0")
+
+
+@pytest.mark.parametrize("scenario", ["warm", "busy", "tail"])
+def test_early_filter_cfg2(scenario, early, bsa, soa, orc):
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", scenario)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        for _ in range(3):                       # back-to-back batches reuse the streams and events
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, scenario)
+        # without the tally stage the rows are voided all the same
+        got = ctx.batch(soa.STAGE_PREFILTER | soa.STAGE_FILTER)
+        for name in ("pf_code", "fl_code", "fl_feasible", "fl_bitmap"):
+            assert np.array_equal(getattr(got, name), getattr(exp, name)), name
+
+
+@pytest.mark.parametrize("seed", range(5000, 5060))
+def test_early_filter_random_after_commit(seed, early, bsa, soa, orc):
+    """First batch commits (every group gets its pod, denials persist); the second batch then has no
+    capture left and takes the early-Filter path.  Both must equal the sequential reference run twice."""
+    sc = random_objects(seed, n_nodes=90 + seed % 80, n_groups=10, n_pods=150, n_scalars=seed % 3, n_classes=3)
+    nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"],
+                                            denied=sc["denied"], permitted=sc["permitted"])
+    sop = orc.Sop(orc.Snapshot(nodes, fit), groups)
+    exp1 = sop.batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL | soa.BATCH_COMMIT), exp1, "committing batch")
+        # the deny entries of batch 1 would stop almost every pod: clear them on both sides (20 s later)
+        g2 = ctx.read_groups()
+        assert g2.state_equal(sop.groups)
+        g2.flags &= ~np.uint8(soa.GROUP_DENIED)
+        sop.groups.flags &= ~np.uint8(soa.GROUP_DENIED)
+        ctx.load_groups(g2)
+        exp2 = sop.batch(pods, soa.STAGE_ALL)
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp2, "early batch")
+
+
+def test_early_filter_cfg3_tail_and_shards(early, bsa, soa, orc):
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg3", "tail")
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "cfg3 tail early")
+        admit = np.zeros(groups.g, np.uint32)
+        for r in range(2):
+            ctx.set_shard(r, 2)
+            ctx.run(soa.STAGE_ALL)
+            part = ctx.read()
+            mine = part.pf_code != 0xFF
+            assert np.array_equal(part.fl_feasible[mine], exp.fl_feasible[mine])
+            assert np.array_equal(part.fl_code[mine], exp.fl_code[mine])
+            assert np.array_equal(part.fl_bitmap[:, mine], exp.fl_bitmap[:, mine])
+            admit += part.group_admit
+        assert np.array_equal(admit, exp.group_admit)
+        ctx.set_shard(0, 1)
