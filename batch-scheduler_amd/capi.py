@@ -58,7 +58,9 @@ class Timing(C.Structure):
 
 class BatchStats(C.Structure):
     _fields_ = [("scan_queries", C.c_uint64), ("scan_rows_executed", C.c_uint64), ("scan_evals_executed", C.c_uint64),
-                ("tables_built", C.c_uint64), ("logical_evals", C.c_uint64), ("filter_evals", C.c_uint64)]
+                ("tables_built", C.c_uint64), ("logical_evals", C.c_uint64), ("filter_evals", C.c_uint64),
+                ("filter_distinct", C.c_uint64), ("filter_evals_executed", C.c_uint64),
+                ("scan_queries_logical", C.c_uint64)]
 
 
 _lib = None
@@ -322,6 +324,13 @@ class Context:
     def stats_arm(self):
         s = BatchStats()
         self._chk(self._lib.bs_batch_stats_get(self._h, C.byref(s)), "bs_batch_stats_get")
+
+    def stats(self, stages: int = soa.STAGE_ALL) -> dict:
+        """Work counters of one instrumented batch (arm, run, read)."""
+        self.stats_arm()
+        self.run(stages)
+        self.sync()
+        return self.stats_read()
 
     def stats_read(self) -> dict:
         s = BatchStats()

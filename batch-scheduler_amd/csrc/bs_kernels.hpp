@@ -115,6 +115,20 @@ struct BatchDev {
   // filter
   int64_t* fparams;         // [P][8]: R[4] = pod + maxSingle, M[4] = maxSingle  (fixed lanes)
   uint32_t* fflags;         // [P] bit0 scalar_block (case 2 impossible), bit1 leader_block, bits 8.. fl_code
+  // scan-query de-duplication: pods with identical (table, request, flags) share one scanned query
+  unsigned long long* qu_slots;   // [fu_mask+1] hash slots (same geometry as fu_slots)
+  int64_t* qkey;            // [P][LP] normalised request of the pod's query (staging for key compares)
+  uint32_t* qkflags;        // [P] its qflags word
+  uint32_t* qrep;           // [P] pod whose query stands for this pod's (valid iff ST_QUERY)
+  // Filter de-duplication: pods with identical (R, M, flags) share one evaluated row
+  unsigned long long* fu_slots;   // [fu_mask+1] hash slots: bit63 valid | hash31 | representative pod
+  uint32_t fu_mask;
+  uint32_t* fu_rep;         // [P] representative pod of an EVALUATED pod
+  uint32_t* fu_id;          // [P] dense id of a representative
+  uint32_t* fu_list;        // [P] dense id -> representative pod
+  uint32_t* fu_count;       // [1] distinct requests
+  uint64_t* fu_bitmap;      // [W][P] rows of the distinct requests (column = dense id)
+  uint32_t* fu_feas;        // [P] feasible-node counts of the distinct requests
   // outputs
   uint8_t* pf_code;
   uint32_t* pf_first_k;
@@ -133,6 +147,7 @@ struct BatchParams {
   int32_t sop_leader0;         // sop.maxFinishedPG carried into the batch (-1 none)
   uint32_t run_filter;
   uint32_t early_filter;       // Filter parameters come from k_fparams_early (Filter overlaps the node scan)
+  uint32_t hash_keep;          // hash bits kept in a de-duplication slot (0x7FFFFFFF; fewer = forced collisions, tests)
   uint32_t collect_stats;
   uint32_t mcap;               // table row capacity
   uint32_t seg_len;            // unused (k_scan deals 64-row groups)
@@ -224,6 +239,48 @@ __global__ void k_init(GroupsDev gr, BatchDev b) {
 // (core.go:89-110).  When no first-pod capture can happen in the batch (every group already has its
 // pod) the LAST block runs findMaxPG for the single epoch instead (k_leader's body): one launch less.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Exact de-duplication of per-pod work.  Pods of one gang share a template, so the derived request
+// vectors repeat massively; a request is evaluated once and its row is copied to the duplicates.
+// Open-addressing table, one 64-bit slot = valid | 31 hash bits | representative pod.  The first pod to
+// claim a slot is the representative; a later pod that meets the same hash bits compares the full key
+// (the representative stored it before its CAS: release / acquire at agent scope) and otherwise probes on.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+  return x ^ (x >> 33);
+}
+template <class Same>
+__device__ __forceinline__ uint32_t dedupe_insert(unsigned long long* slots, uint32_t mask, uint32_t hash_keep, uint64_t h, uint32_t i,
+                                                  Same same_as, bool& winner) {
+  const uint32_t tag = (((uint32_t)(h >> 32)) & hash_keep) | 0x80000000u;
+  const unsigned long long mine = ((unsigned long long)tag << 32) | i;
+  uint32_t sl = (uint32_t)h & mask;
+  for (;;) {
+    unsigned long long cur = __hip_atomic_load(&slots[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0ull) {
+      unsigned long long expected = 0ull;
+      if (__hip_atomic_compare_exchange_strong(&slots[sl], &expected, mine, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+        winner = true;
+        return i;
+      }
+      cur = expected;
+    }
+    if ((uint32_t)(cur >> 32) == tag) {
+      const uint32_t rep = (uint32_t)cur;
+      if (same_as(rep)) { winner = false; return rep; }
+    }
+    sl = (sl + 1u) & mask;
+  }
+}
+
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ void leader_block(const GroupsDev& gr, const BatchDev& b, uint32_t e);
 
 constexpr int kPrepassBlock = 512;
@@ -245,9 +302,18 @@ __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsD
     b.nepochs[1] = BS_INF;
   }
   if (i < 8 && prm.collect_stats) b.stats[i] = 0;
+  {
+    const uint32_t nthreads = (gridDim.x - fused_leader) * kPrepassBlock;
+    for (uint32_t k = i; k <= b.fu_mask; k += nthreads) b.qu_slots[k] = 0ull;
+    if (prm.run_filter) {
+      if (i == 0) *b.fu_count = 0;
+      for (uint32_t k = i; k <= b.fu_mask; k += nthreads) b.fu_slots[k] = 0ull;
+    }
+  }
   if (i >= pods.p) return;
   b.first_row[i] = BS_INF;
   b.fl_feasible[i] = 0;
+  b.fu_feas[i] = 0;
   if (no_capture) b.epoch[i] = 0;
   const int32_t gi = pods.group[i];
   uint8_t st = 0;
@@ -585,18 +651,79 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
     const unsigned long long rb = __ballot(valid && (st & ST_REACH6));
     if (rb && lane_id() == __ffsll((long long)rb) - 1) atomicMin(&b.nepochs[1], i);
   }
-  // Tile emission.  The lanes of this wave that query the same table become one scan tile: one lane
-  // reserves `count` consecutive slots of the tile-ordered request arrays and appends the tile.  No
-  // sort, no second pass: a scan wave later reads its requests as contiguous rows.
+  // Normalise the request (what the scan compares), then de-duplicate: identical (table, request, flags)
+  // queries are scanned once.  Wave leaders of equal keys are elected in registers, only they go to the
+  // global table; the pod that claims a slot is the representative and emits the query.
   const bool has_q = valid && table >= 0;
+  uint32_t qfl = 0;
+  if (has_q) {
+    uint32_t absok = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+      if (s < sh.S()) {
+        const bool pres = q.present & (1u << s);
+        if (!pres || q.v[4 + s] == 0) absok |= 1u << s;       // core.go:688-692
+        if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
+      }
+    }
+    qfl = q.present | (absok << 16);
+  }
+  uint64_t h = mix64((uint64_t)(uint32_t)table * 0x9e3779b97f4a7c15ull + qfl);
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+    if (j < sh.L()) h = mix64(h ^ (uint64_t)q.v[j]);
+  int wl = lane_id();
+  {
+    unsigned long long todo = __ballot(has_q);
+    while (todo) {
+      const int ldr = __ffsll((long long)todo) - 1;
+      bool eq = has_q && h == bcast64(h, ldr);
+      if (__ballot(eq) != (1ull << ldr)) {
+        eq = eq && table == __builtin_amdgcn_readlane(table, ldr) && qfl == (uint32_t)__builtin_amdgcn_readlane((int)qfl, ldr);
+#pragma unroll
+        for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+          if (j < sh.L()) eq = eq && (uint64_t)q.v[j] == bcast64((uint64_t)q.v[j], ldr);
+      }
+      if (eq) wl = ldr;
+      todo &= ~__ballot(eq);
+    }
+  }
+  bool emit = false;
+  uint32_t rep = i;
+  if (has_q && wl == lane_id()) {
+    int64_t* kd = b.qkey + (size_t)i * prm.LP;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < sh.L()) kd[j] = q.v[j];
+    b.qkflags[i] = qfl;
+    b.qtable[i] = table;
+    rep = dedupe_insert(b.qu_slots, b.fu_mask, prm.hash_keep, h, i, [&](uint32_t r) {
+      if (r >= pods.p) return false;
+      bool eq = b.qtable[r] == table && b.qkflags[r] == qfl;
+      const int64_t* o = b.qkey + (size_t)r * prm.LP;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+        if (j < sh.L()) eq = eq && o[j] == q.v[j];
+      return eq;
+    }, emit);
+  }
+  rep = (uint32_t)__shfl((int)rep, wl);
+  if (has_q) b.qrep[i] = rep;
+  if (prm.collect_stats) {
+    const unsigned long long hq = __ballot(has_q);
+    if (lane_id() == 0 && hq) atomicAdd((unsigned long long*)&b.stats[2], (unsigned long long)__popcll(hq));
+  }
+  // Tile emission.  The representatives of this wave that query the same table become one scan tile: one
+  // lane reserves `count` consecutive slots of the tile-ordered request arrays and appends the tile.  No
+  // sort, no second pass: a scan wave later reads its requests as contiguous rows.
   uint32_t pos = 0;
-  unsigned long long todo = __ballot(has_q);
+  unsigned long long todo = __ballot(emit);
   while (todo) {
     const int ldr = __ffsll((long long)todo) - 1;
     const int32_t t0 = __shfl(table, ldr);
-    const unsigned long long same = __ballot(has_q && table == t0);
+    const bool member = emit && table == t0;
+    const unsigned long long same = __ballot(member);
     const uint32_t cnt = (uint32_t)__popcll(same);
-    const bool member = has_q && table == t0;
     int64_t mn[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) mn[j] = wave_min_i64(member ? q.v[j] : INT64_MAX);
@@ -615,24 +742,15 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
       b.needed[t0] = 1;
     }
     base = (uint32_t)__shfl((int)base, ldr);
-    if (has_q && table == t0) pos = base + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull));
+    if (member) pos = base + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull));
     todo &= ~same;
   }
-  if (has_q) {
-    uint32_t absok = 0;
-#pragma unroll
-    for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
-      if (s < sh.S()) {
-        const bool pres = q.present & (1u << s);
-        if (!pres || q.v[4 + s] == 0) absok |= 1u << s;       // core.go:688-692
-        if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
-      }
-    }
+  if (emit) {
     int64_t* dst = b.qreq_s + (size_t)pos * prm.LP;
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
       if (j < prm.LP) dst[j] = j < sh.L() ? q.v[j] : INT64_MIN;
-    b.qflags_s[pos] = q.present | (absok << 16);
+    b.qflags_s[pos] = qfl;
     b.qlist[pos] = i;
     b.qpos[i] = pos;
   }
@@ -824,7 +942,7 @@ __device__ __forceinline__ crow_t as_const_rows(const int64_t* p) { return (crow
 #define BS_CX(j) "v_cmpx_ge_i64 vcc, %[a" #j "], %[r" #j "]\n\t"
 #define BS_ROW_HEAD "s_mov_b64 exec, %[nf]\n\t"
 #define BS_ROW_TAIL "v_min_u32 %[myk], %[k], %[myk]\n\ts_mov_b64 exec, -1"
-#define BS_OPS4 [a0] "s"(a[0]), [r0] "v"(r[0]), [a1] "s"(a[1]), [r1] "v"(r[1]), [a2] "s"(a[2]), [r2] "v"(r[2]), [a3] "s"(a[3]), [r3] "v"(r[3])
+#define BS_OPS4 [a0] "v"(a[0]), [r0] "v"(r[0]), [a1] "v"(a[1]), [r1] "v"(r[1]), [a2] "v"(a[2]), [r2] "v"(r[2]), [a3] "v"(a[3]), [r3] "v"(r[3])
 
 template <int L>
 __device__ __forceinline__ void row_step(unsigned long long nf, uint32_t& myk, uint32_t k, const int64_t (&a)[L], const int64_t (&r)[L]) {
@@ -833,18 +951,18 @@ __device__ __forceinline__ void row_step(unsigned long long nf, uint32_t& myk, u
                  : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4 : "vcc");
   } else if constexpr (L == 5) {
     asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_ROW_TAIL
-                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]) : "vcc");
+                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "v"(a[4]), [r4] "v"(r[4]) : "vcc");
   } else if constexpr (L == 6) {
     asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_ROW_TAIL
-                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]) : "vcc");
+                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "v"(a[4]), [r4] "v"(r[4]), [a5] "v"(a[5]), [r5] "v"(r[5]) : "vcc");
   } else if constexpr (L == 7) {
     asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_CX(6) BS_ROW_TAIL
-                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]),
-                   [a6] "s"(a[6]), [r6] "v"(r[6]) : "vcc");
+                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "v"(a[4]), [r4] "v"(r[4]), [a5] "v"(a[5]), [r5] "v"(r[5]),
+                   [a6] "v"(a[6]), [r6] "v"(r[6]) : "vcc");
   } else if constexpr (L == 8) {
     asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_CX(6) BS_CX(7) BS_ROW_TAIL
-                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]),
-                   [a6] "s"(a[6]), [r6] "v"(r[6]), [a7] "s"(a[7]), [r7] "v"(r[7]) : "vcc");
+                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_OPS4, [a4] "v"(a[4]), [r4] "v"(r[4]), [a5] "v"(a[5]), [r5] "v"(r[5]),
+                   [a6] "v"(a[6]), [r6] "v"(r[6]), [a7] "v"(a[7]), [r7] "v"(r[7]) : "vcc");
   } else {
     // wide rows (S > 4): two chained statements; the surviving-lane mask travels in an SGPR pair
     static_assert(L > 8 && L <= 16, "row width");
@@ -858,15 +976,15 @@ __device__ __forceinline__ void row_step(unsigned long long nf, uint32_t& myk, u
                    "v_cmpx_ge_i64 vcc, %[a6], %[r6]\n\tv_cmpx_ge_i64 vcc, %[a7], %[r7]\n\t"
                    "s_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
                    : [m] "+s"(m)
-                   : [a0] "s"(a0[0]), [r0] "v"(r0[0]), [a1] "s"(a0[1]), [r1] "v"(r0[1]), [a2] "s"(a0[2]), [r2] "v"(r0[2]), [a3] "s"(a0[3]),
-                     [r3] "v"(r0[3]), [a4] "s"(a0[4]), [r4] "v"(r0[4]), [a5] "s"(a0[5]), [r5] "v"(r0[5]), [a6] "s"(a0[6]), [r6] "v"(r0[6]),
-                     [a7] "s"(a0[7]), [r7] "v"(r0[7])
+                   : [a0] "v"(a0[0]), [r0] "v"(r0[0]), [a1] "v"(a0[1]), [r1] "v"(r0[1]), [a2] "v"(a0[2]), [r2] "v"(r0[2]), [a3] "v"(a0[3]),
+                     [r3] "v"(r0[3]), [a4] "v"(a0[4]), [r4] "v"(r0[4]), [a5] "v"(a0[5]), [r5] "v"(r0[5]), [a6] "v"(a0[6]), [r6] "v"(r0[6]),
+                     [a7] "v"(a0[7]), [r7] "v"(r0[7])
                    : "vcc");
     }
 #pragma unroll
     for (int j = 8; j < L; ++j) {
       asm volatile("s_mov_b64 exec, %[m]\n\tv_cmpx_ge_i64 vcc, %[a], %[r]\n\ts_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
-                   : [m] "+s"(m) : [a] "s"(a[j]), [r] "v"(r[j]) : "vcc");
+                   : [m] "+s"(m) : [a] "v"(a[j]), [r] "v"(r[j]) : "vcc");
     }
     asm volatile("s_mov_b64 exec, %[m]\n\tv_min_u32 %[myk], %[k], %[myk]\n\ts_mov_b64 exec, -1"
                  : [myk] "+v"(myk) : [k] "s"(k), [m] "s"(m));
@@ -878,7 +996,7 @@ __device__ __forceinline__ void row_step(unsigned long long nf, uint32_t& myk, u
 #define BS_QHEAD(q) "s_mov_b64 exec, %[nf" #q "]\n\t"
 #define BS_QTAIL(q) "v_min_u32 %[myk" #q "], %[k], %[myk" #q "]\n\t"
 #define BS_QOUT [myk0] "+v"(myk0), [myk1] "+v"(myk1)
-#define BS_AOPS4 [a0] "s"(a[0]), [a1] "s"(a[1]), [a2] "s"(a[2]), [a3] "s"(a[3])
+#define BS_AOPS4 [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3])
 #define BS_ROPS4(q, arr) [r##q##0] "v"(arr[0]), [r##q##1] "v"(arr[1]), [r##q##2] "v"(arr[2]), [r##q##3] "v"(arr[3])
 template <int L>
 __device__ __forceinline__ void row_step2(unsigned long long nf0, uint32_t& myk0, unsigned long long nf1, uint32_t& myk1, uint32_t k,
@@ -890,11 +1008,11 @@ __device__ __forceinline__ void row_step2(unsigned long long nf0, uint32_t& myk0
   } else if constexpr (L == 5) {
     asm volatile(BS_QHEAD(0) BS_CXQ(0, 0) BS_CXQ(0, 1) BS_CXQ(0, 2) BS_CXQ(0, 3) BS_CXQ(0, 4) BS_QTAIL(0)
                  BS_QHEAD(1) BS_CXQ(1, 0) BS_CXQ(1, 1) BS_CXQ(1, 2) BS_CXQ(1, 3) BS_CXQ(1, 4) BS_QTAIL(1) "s_mov_b64 exec, -1"
-                 : BS_QOUT : [nf0] "s"(nf0), [nf1] "s"(nf1), [k] "s"(k), BS_AOPS4, [a4] "s"(a[4]), BS_ROPS4(0, r0), [r04] "v"(r0[4]), BS_ROPS4(1, r1), [r14] "v"(r1[4]) : "vcc");
+                 : BS_QOUT : [nf0] "s"(nf0), [nf1] "s"(nf1), [k] "s"(k), BS_AOPS4, [a4] "v"(a[4]), BS_ROPS4(0, r0), [r04] "v"(r0[4]), BS_ROPS4(1, r1), [r14] "v"(r1[4]) : "vcc");
   } else if constexpr (L == 6) {
     asm volatile(BS_QHEAD(0) BS_CXQ(0, 0) BS_CXQ(0, 1) BS_CXQ(0, 2) BS_CXQ(0, 3) BS_CXQ(0, 4) BS_CXQ(0, 5) BS_QTAIL(0)
                  BS_QHEAD(1) BS_CXQ(1, 0) BS_CXQ(1, 1) BS_CXQ(1, 2) BS_CXQ(1, 3) BS_CXQ(1, 4) BS_CXQ(1, 5) BS_QTAIL(1) "s_mov_b64 exec, -1"
-                 : BS_QOUT : [nf0] "s"(nf0), [nf1] "s"(nf1), [k] "s"(k), BS_AOPS4, [a4] "s"(a[4]), [a5] "s"(a[5]), BS_ROPS4(0, r0), [r04] "v"(r0[4]), [r05] "v"(r0[5]),
+                 : BS_QOUT : [nf0] "s"(nf0), [nf1] "s"(nf1), [k] "s"(k), BS_AOPS4, [a4] "v"(a[4]), [a5] "v"(a[5]), BS_ROPS4(0, r0), [r04] "v"(r0[4]), [r05] "v"(r0[5]),
                    BS_ROPS4(1, r1), [r14] "v"(r1[4]), [r15] "v"(r1[5]) : "vcc");
   } else {
     row_step<L>(nf0, myk0, k, a, r0);
@@ -915,10 +1033,14 @@ __device__ __forceinline__ void row_all(const unsigned long long (&nf)[Q], uint3
 // gets nothing leaves before touching the requests.
 template <int S, int Q>
 __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, const uint32_t (&tq0)[Q],
-                                          const uint32_t (&tcnt)[Q], const int64_t (&rmin)[4], uint32_t share, uint32_t J) {
+                                          const uint32_t (&tcnt)[Q], const int64_t (&rmin)[4], uint32_t share, uint32_t J,
+                                          int64_t (*rows)[4 + S]) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
-  constexpr int U = (L <= 5) ? 2 : 1;            // rows per buffer (SGPR budget: 2 buffers x U x L pairs)
+  constexpr int U = 4;                           // rows per step: their LDS reads are issued together
+  // A group's 64 rows are fetched with ONE vector load per lane (lane = row) and parked in this wave's
+  // LDS slice `rows`; the row loop then reads them back with uniform-address (broadcast) ds_reads, so no
+  // memory round trip sits inside the loop.
   const int lane = lane_id();
   const uint32_t ngroups = (m + 63u) >> 6, gstride = (prm.mcap + 63u) >> 6;
 
@@ -928,7 +1050,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   uint32_t kp[S > 0 ? S : 1];
   unsigned long long absok[Q][S > 0 ? S : 1];
   bool loaded = false;
-  crow_t T = as_const_rows(b.tables + (size_t)slot * prm.mcap * LP);
+  const int64_t* T = b.tables + (size_t)slot * prm.mcap * LP;
   uint32_t rows_done = 0;
   uint32_t turn = 0;                             // rank of the next live group modulo J
 
@@ -947,7 +1069,16 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
       const bool mine = turn == share;
       turn = turn + 1u == J ? 0u : turn + 1u;
       if (!mine) continue;
-      // ---- this group is ours: rows [a, gend)
+      // ---- this group is ours: rows [g0, gend)
+      const uint32_t g0 = (c0 + bit) << 6;
+      const uint32_t gend = min(m, g0 + 64u);
+      int64_t mine_row[L];
+      {
+        const uint32_t row = min(g0 + (uint32_t)lane, gend - 1u);
+        const int64_t* src = T + (size_t)row * LP;
+#pragma unroll
+        for (int j = 0; j < L; ++j) mine_row[j] = src[j];
+      }
       if (!loaded) {                             // first live group: now the requests are worth loading
         loaded = true;
 #pragma unroll
@@ -976,8 +1107,11 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
           for (int q = 0; q < Q; ++q) absok[q][s] = __ballot((qf[q] >> (16 + s)) & 1u);
         }
       }
-      uint32_t a = (c0 + bit) << 6;
-      const uint32_t gend = min(m, a + 64u);
+      __builtin_amdgcn_wave_barrier();           // the previous group's reads are behind us (LDS is in order)
+#pragma unroll
+      for (int j = 0; j < L; ++j) rows[lane][j] = mine_row[j];
+      __builtin_amdgcn_wave_barrier();
+      uint32_t a = g0;
       // lanes another wave already served with an earlier row need nothing from this group
       unsigned long long want[Q];
       unsigned long long any = 0;
@@ -1004,55 +1138,27 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
           act[q] = want[q] & el;
         }
         uint32_t k = a;
-        const uint32_t pairs = (e - a) / (2u * U);
-        if (pairs) {
-          int64_t A[U][L], B[U][L];
-          crow_t pr = T + (size_t)k * LP;         // running row pointer: constant offsets below fold into s_load
+        bool open = true;                        // some lane of this piece is still without a row
+        while (open && k + U <= e) {
+          int64_t A[U][L];
 #pragma unroll
           for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int j = 0; j < L; ++j) A[u][j] = pr[u * LP + j];
-          BS_S_WAIT_LGKM0();
-          for (uint32_t it = 0; it < pairs; ++it) {
+            for (int j = 0; j < L; ++j) A[u][j] = rows[k - g0 + u][j];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-              for (int j = 0; j < L; ++j) B[u][j] = pr[(U + u) * LP + j];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + u, A[u], r);
-            BS_S_WAIT_LGKM0();
-            __builtin_amdgcn_sched_barrier(0);
-            // rows k+2U.. may lie past the piece (prefetch only; the table has slack rows)
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-              for (int j = 0; j < L; ++j) A[u][j] = pr[(2 * U + u) * LP + j];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + U + u, B[u], r);
-            BS_S_WAIT_LGKM0();
-            __builtin_amdgcn_sched_barrier(0);
-            k += 2 * U;
-            pr += 2 * U * LP;
-            unsigned long long left = 0;          // lanes of this piece still without a row
-#pragma unroll
-            for (int q = 0; q < Q; ++q) left |= act[q] & __ballot(myk[q] == BS_INF);
-            if (left == 0) break;
-          }
-        }
-        {
+          for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + u, A[u], r);
+          k += U;
           unsigned long long left = 0;
 #pragma unroll
           for (int q = 0; q < Q; ++q) left |= act[q] & __ballot(myk[q] == BS_INF);
-          if (left) {
-            for (; k < e; ++k) {                 // < 2U leftover rows of the piece
-              int64_t R1[L];
+          open = left != 0;
+        }
+        if (open) {
+          for (; k < e; ++k) {                   // < U leftover rows of the piece
+            int64_t R1[L];
 #pragma unroll
-              for (int j = 0; j < L; ++j) R1[j] = T[(size_t)k * LP + j];
-              BS_S_WAIT_LGKM0();
-              row_all<L, Q>(act, myk, k, R1, r);
-            }
+            for (int j = 0; j < L; ++j) R1[j] = rows[k - g0][j];
+            row_all<L, Q>(act, myk, k, R1, r);
           }
         }
         rows_done += k - a;
@@ -1093,11 +1199,17 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 // different tables are scanned one after the other.  Consecutive waves take different pairs with the
 // same share (the same rows, reused from the scalar cache).  The grid is fixed; waves stride over items.
 template <int S>
-__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t J) {
+__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t jcap) {
   typedef const __attribute__((address_space(4))) Tile* ctile_t;
   ctile_t CT = (ctile_t)(uintptr_t)b.tiles;
   const uint32_t ntiles = *b.ntiles;
   const uint32_t npairs = (ntiles + 1u) >> 1;
+  if (!npairs) return;
+  // the number of tiles is only known here (queries are de-duplicated on the device): share every pair
+  // among as many waves as the grid has to spare, at most one per 64-row group
+  const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (gridDim.x * 4u) / npairs));
+  __shared__ int64_t s_rows[4][64][4 + S];
+  int64_t (*rows)[4 + S] = s_rows[wave_id()];
   const uint32_t items = npairs * J;
   const uint32_t stride = gridDim.x * 4u;
   for (uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id()); w < items; w += stride) {
@@ -1115,13 +1227,13 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
 #pragma unroll
       for (int j = 0; j < 4; ++j) rm[j] = ra[j] < rb[j] ? ra[j] : rb[j];
       const uint32_t q0s[2] = {qa, qb}, cnts[2] = {ca, cb};
-      scan_core<S, 2>(b, prm, m, sa, q0s, cnts, rm, share, J);
+      scan_core<S, 2>(b, prm, m, sa, q0s, cnts, rm, share, J, rows);
     } else {
       const uint32_t q0a[1] = {qa}, cna[1] = {ca};
-      scan_core<S, 1>(b, prm, m, sa, q0a, cna, ra, share, J);
+      scan_core<S, 1>(b, prm, m, sa, q0a, cna, ra, share, J, rows);
       if (has_b) {
         const uint32_t q0b[1] = {qb}, cnb[1] = {cb};
-        scan_core<S, 1>(b, prm, m, sb, q0b, cnb, rb, share, J);
+        scan_core<S, 1>(b, prm, m, sb, q0b, cnb, rb, share, J, rows);
       }
     }
   }
@@ -1134,7 +1246,7 @@ __global__ void k_reject(PodsDev pods, BatchDev b) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pods.p) return;
   if (!(b.stage[i] & ST_QUERY)) return;
-  if (b.first_row[b.qpos[i]] == BS_INF) {
+  if (b.first_row[b.qpos[b.qrep[i]]] == BS_INF) {
     // compareClusterResourceAndRequire returned false: AddToDenyCache (core.go:142,163)
     b.tcode[i] = (b.tcode[i] == BS_PF_PASS_FIRST_FITS) ? BS_PF_REJECT_FIRST : BS_PF_REJECT_RESERVE;
     atomicMin(&b.first_reject[pods.group[i]], i);
@@ -1142,9 +1254,11 @@ __global__ void k_reject(PodsDev pods, BatchDev b) {
 }
 
 // Filter per-pod parameters (see the Filter section below); defined here because k_final fuses it.
+struct FilterKey { int64_t R[4], M[4]; uint32_t ffw; };     // ffw = flag bits | fl_code << 8
+
 template <int TS>
 __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm,
-                                                  uint32_t i, uint8_t pf, int32_t leader) {
+                                                  uint32_t i, uint8_t pf, int32_t leader, FilterKey& key) {
   const Shape<TS> sh(prm.S);
   const uint32_t gate = prm.eph_gate;
   uint8_t fl = BS_FL_NOT_RUN;
@@ -1184,6 +1298,54 @@ __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const Gro
   for (int j = 0; j < 4; ++j) { dst[j] = R[j]; dst[4 + j] = M[j]; }
   b.fflags[i] = ff | ((uint32_t)fl << 8);
   b.fl_code[i] = fl;
+  key.ffw = ff | ((uint32_t)fl << 8);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { key.R[j] = R[j]; key.M[j] = M[j]; }
+}
+
+// De-duplicate the Filter requests of one wave's pods (all lanes must call; `active` = the pod is
+// EVALUATED).  Lanes with equal keys first elect a wave leader in registers (consecutive pods are
+// gang-mates, so a wave holds a handful of distinct keys); only the leaders go to the global table, all
+// at once, and hand the representative to their followers.
+__device__ __forceinline__ void filter_dedupe_wave(const PodsDev& pods, const BatchDev& b, const BatchParams& prm, uint32_t i, bool active,
+                                                   const FilterKey& key) {
+  uint64_t h = mix64((uint64_t)key.ffw + 0x9e3779b97f4a7c15ull);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { h = mix64(h ^ (uint64_t)key.R[j]); h = mix64(h ^ (uint64_t)key.M[j]); }
+  const int lane = lane_id();
+  int wl = lane;
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int ldr = __ffsll((long long)todo) - 1;
+    bool eq = active && h == bcast64(h, ldr);
+    if (__ballot(eq) != (1ull << ldr)) {            // same hash somewhere else: settle it on the full key
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        eq = eq && (uint64_t)key.R[j] == bcast64((uint64_t)key.R[j], ldr) && (uint64_t)key.M[j] == bcast64((uint64_t)key.M[j], ldr);
+      eq = eq && key.ffw == (uint32_t)__builtin_amdgcn_readlane((int)key.ffw, ldr);
+    }
+    if (eq) wl = ldr;
+    todo &= ~__ballot(eq);
+  }
+  uint32_t rep = i;
+  if (active && wl == lane) {
+    bool winner;
+    rep = dedupe_insert(b.fu_slots, b.fu_mask, prm.hash_keep, h, i, [&](uint32_t r) {
+      if (r >= pods.p) return false;
+      const int64_t* o = b.fparams + (size_t)r * 8;
+      bool eq = b.fflags[r] == key.ffw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) eq = eq && o[j] == key.R[j] && o[4 + j] == key.M[j];
+      return eq;
+    }, winner);
+    if (winner) {
+      const uint32_t id = atomicAdd(b.fu_count, 1u);
+      b.fu_id[i] = id;
+      b.fu_list[id] = i;
+    }
+  }
+  rep = (uint32_t)__shfl((int)rep, wl);
+  if (active) b.fu_rep[i] = rep;
 }
 
 // Did pod j really reach findMaxPG (core.go:118-123)?  Tentatively yes (k_query) and not behind the
@@ -1227,7 +1389,7 @@ __global__ __launch_bounds__(256) void k_final(PodsDev pods, GroupsDev gr, Nodes
       if ((st & ST_ELIG) && b.first_reject[pods.group[i]] < i) {
         code = BS_PF_ERR_DENIED;
       } else if (st & ST_QUERY) {
-        const uint32_t row = b.first_row[b.qpos[i]];
+        const uint32_t row = b.first_row[b.qpos[b.qrep[i]]];
         fk = row == BS_INF ? BS_K_NONE : nd.kmap[row];
       }
     } else {
@@ -1248,18 +1410,22 @@ __global__ __launch_bounds__(256) void k_final(PodsDev pods, GroupsDev gr, Nodes
   uint32_t off = prev;
   for (int w = 0; w < wave_id(); ++w) off = max(off, lds[w]);
   const uint32_t jp1 = max(v, off);
+  FilterKey key{};
+  const bool params = i < pods.p && prm.run_filter && !prm.early_filter;
   if (i < pods.p) {
     const int32_t leader = jp1 ? b.leader_raw[jp1 - 1u] : prm.sop_leader0;
     b.pf_leader[i] = leader;
-    if (prm.run_filter && !prm.early_filter) filter_params_for<TS>(pods, gr, b, prm, i, code, leader);
+    if (params) filter_params_for<TS>(pods, gr, b, prm, i, code, leader, key);
   }
+  if (prm.run_filter && !prm.early_filter) filter_dedupe_wave(pods, b, prm, i, params && (key.ffw >> 8) == BS_FL_EVALUATED, key);
 }
 
 // stand-alone Filter parameters (bs_filter_one): pf_code / pf_leader given
 __global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pods.p) return;
-  filter_params_for<-1>(pods, gr, b, prm, i, b.pf_code[i], b.pf_leader[i]);
+  FilterKey key;
+  filter_params_for<-1>(pods, gr, b, prm, i, b.pf_code[i], b.pf_leader[i], key);
 }
 
 // Filter parameters BEFORE the node scan has run (no first-pod capture possible in this batch, so there
@@ -1275,10 +1441,13 @@ __global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchPar
 template <int TS>
 __global__ void k_fparams_early(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= pods.p) return;
-  const uint8_t pf = (b.stage[i] & ST_OWNED) ? b.tcode[i] : (uint8_t)BS_PF_NOT_OWNED;
-  const int32_t leader = i >= b.nepochs[1] ? b.leader_epoch[0] : prm.sop_leader0;
-  filter_params_for<TS>(pods, gr, b, prm, i, pf, leader);
+  FilterKey key{};
+  if (i < pods.p) {
+    const uint8_t pf = (b.stage[i] & ST_OWNED) ? b.tcode[i] : (uint8_t)BS_PF_NOT_OWNED;
+    const int32_t leader = i >= b.nepochs[1] ? b.leader_epoch[0] : prm.sop_leader0;
+    filter_params_for<TS>(pods, gr, b, prm, i, pf, leader, key);
+  }
+  filter_dedupe_wave(pods, b, prm, i, i < pods.p && (key.ffw >> 8) == BS_FL_EVALUATED, key);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1372,33 +1541,29 @@ __device__ __forceinline__ void filter_pod_loop(uint32_t np, const int64_t (*sR)
 }
 
 template <int NB>
-__global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, BatchDev b, uint32_t blocks_per_wave,
-                                                uint32_t want_bitmap) {
+__device__ __forceinline__ void filter_item(const PodsDev& pods, const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ptile,
+                                            uint32_t w0, uint32_t w1) {
   static_assert(NB == 2, "the inner statement handles two node blocks");
   typedef const __attribute__((address_space(4))) uint32_t* cflag_t;
   const int lane = lane_id();
-  const uint32_t ptile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id());
   const uint32_t p0 = ptile * 64u;
-  if (p0 >= pods.p) return;
-  const uint32_t W = (nd.n + 63u) / 64u;
-  const uint32_t w0 = blockIdx.y * blocks_per_wave;
-  if (w0 >= W) return;
-  const uint32_t w1 = min(W, w0 + blocks_per_wave);
-  const uint32_t np = min(64u, pods.p - p0);
+  const uint32_t np = min(64u, U - p0);
 
   // Is the leader's single-member request M the same for every evaluated pod of the tile?  (It is,
   // unless the tile straddles a first-pod capture.)  Then case 3 is one mask per node block.
   const bool mine = (uint32_t)lane < np;
-  const uint32_t myff = mine ? b.fflags[p0 + lane] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  const uint32_t src = mine ? b.fu_list[p0 + lane] : 0u;          // the tile's requests: distinct ones only
+  const uint32_t myff = mine ? b.fflags[src] : ((uint32_t)BS_FL_NOT_RUN << 8);
   const uint32_t myfl = myff >> 8;
   const bool ev = myfl == BS_FL_EVALUATED;
   int64_t M[4] = {0, 0, 0, 0};
   if (ev) {
-    const int64_t* src = b.fparams + (size_t)(p0 + lane) * 8 + 4;
+    const int64_t* ms = b.fparams + (size_t)src * 8 + 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) M[j] = src[j];
+    for (int j = 0; j < 4; ++j) M[j] = ms[j];
   }
   __shared__ int64_t s_R[4][64][4];               // per wave: the tile's requests (pod + maxSingle, fixed lanes)
+  __builtin_amdgcn_wave_barrier();                // the previous item of this wave is done with its slice
   // which resource lanes can decide anything for this tile?  (nd.lglob: cluster-wide min[4] / max[4] of left
   // over the nodes Filter can evaluate)
   uint32_t lane_mask = 0;          // bit j: lane j must be compared
@@ -1406,9 +1571,9 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
   {
     int64_t myR[4] = {0, 0, 0, 0};
     if (mine) {
-      const int64_t* src = b.fparams + (size_t)(p0 + lane) * 8;
+      const int64_t* rs = b.fparams + (size_t)src * 8;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) myR[j] = src[j];
+      for (int j = 0; j < 4; ++j) myR[j] = rs[j];
     }
     int64_t gl[8];
 #pragma unroll
@@ -1445,6 +1610,7 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
 
   crow_t FP = as_const_rows(b.fparams);
   cflag_t FF = (cflag_t)(uintptr_t)b.fflags;
+  cflag_t UL = (cflag_t)(uintptr_t)b.fu_list;
   uint32_t cnt = 0;
   // node blocks are double-buffered: the loads of step w+NB are in flight during the pod loop of step w
   int64_t l[NB][4], ln[NB][4];
@@ -1525,7 +1691,7 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
     } else {
       // generic path: per-pod leader request (tile straddles a capture); plain ballots
       for (uint32_t pp = 0; pp < np; ++pp) {
-        const uint32_t p = p0 + pp;
+        const uint32_t p = UL[p0 + pp];
         const uint32_t ff = FF[p];
         const uint32_t fl = ff >> 8;
 #pragma unroll
@@ -1551,7 +1717,7 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
       if ((w + nb) < w1 && mine) {
         const unsigned long long word = ((unsigned long long)vhi[nb] << 32) | vlo[nb];
         cnt += (uint32_t)__popcll(word);
-        if (want_bitmap) b.fl_bitmap[(size_t)(w + nb) * pods.p + p0 + lane] = word;
+        b.fu_bitmap[(size_t)(w + nb) * pods.p + p0 + lane] = word;
       }
     }
 #pragma unroll
@@ -1561,7 +1727,27 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
       for (int j = 0; j < 4; ++j) l[nb][j] = ln[nb][j];
     }
   }
-  if (mine && cnt) atomicAdd(&b.fl_feasible[p0 + lane], cnt);
+  if (mine && cnt) atomicAdd(&b.fu_feas[p0 + lane], cnt);
+}
+
+// Work loop over (tile of 64 distinct requests, run of node blocks).  The number of distinct requests is
+// only known on the device, so the grid is fixed and every wave derives the split itself: as many node
+// runs as it takes to give the whole grid something to do.
+template <int NB>
+__global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, BatchDev b, uint32_t target_waves) {
+  const uint32_t U = __builtin_amdgcn_readfirstlane(*b.fu_count);
+  const uint32_t W = (nd.n + 63u) / 64u;
+  if (!U || !W) return;
+  const uint32_t tiles = (U + 63u) / 64u;
+  uint32_t nsplit = max(1u, target_waves / tiles);
+  nsplit = min(nsplit, max((W + 1u) / 2u, 1u));
+  const uint32_t bpw = max(2u, (((W + nsplit - 1u) / nsplit + 1u) / 2u) * 2u);     // multiple of NB
+  const uint32_t nchunk = (W + bpw - 1u) / bpw;
+  const uint32_t items = tiles * nchunk;
+  for (uint32_t it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id()); it < items; it += gridDim.x * 4u) {
+    const uint32_t chunk = it / tiles, tile = it - chunk * tiles;                   // neighbours share the node run
+    filter_item<NB>(pods, nd, b, U, tile, chunk * bpw, min(W, chunk * bpw + bpw));
+  }
 }
 
 // Early Filter ran on the tentative PreFilter verdict.  The framework never calls Filter for a pod that
@@ -1589,26 +1775,25 @@ __global__ __launch_bounds__(256) void k_void_rows(PodsDev pods, BatchDev b, uin
 // the per-group minima for the next batch — no separate launches for either.
 constexpr int kTallyBlock = 1024;
 
-__global__ __launch_bounds__(kTallyBlock) void k_tally(PodsDev pods, GroupsDev gr, BatchDev b, uint32_t run_filter, uint32_t do_ready,
-                                                        uint32_t rearm) {
-  __shared__ uint32_t s_last;
-  const uint32_t i = blockIdx.x * kTallyBlock + threadIdx.x;
+// Called by every thread of every participating block (`nblocks` of BLOCK threads, block index bx).
+// feasible = nodes on which Filter passes for pod i (any non-zero value when Filter did not run).
+template <int BLOCK>
+__device__ __forceinline__ void tally_block(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, uint32_t i, uint32_t feasible,
+                                            uint32_t do_ready, uint32_t rearm, uint32_t bx, uint32_t nblocks, uint32_t* s_last) {
   bool admit = false;
   uint32_t g = 0;
   if (i < pods.p) {
     const int32_t gi = pods.group[i];
     const uint8_t pf = b.pf_code[i];
-    if (gi >= 0 && (uint32_t)gi < gr.g && pf != BS_PF_NOT_OWNED && BS_PF_IS_PASS(pf) &&
-        (!run_filter || b.fl_feasible[i] > 0)) {
+    if (gi >= 0 && (uint32_t)gi < gr.g && pf != BS_PF_NOT_OWNED && BS_PF_IS_PASS(pf) && feasible > 0) {
       admit = true;
       g = (uint32_t)gi;
     }
   }
   wave_aggregated_inc(b.admit, g, admit);
   // nobody reads the per-group minima any more in this batch: every block re-arms a slice of them
-  // (and the key-presence rows of the table the next batch builds on the side stream)
   if (rearm) {
-    for (uint32_t gg = i; gg < gr.g; gg += gridDim.x * kTallyBlock) {
+    for (uint32_t gg = bx * BLOCK + threadIdx.x; gg < gr.g; gg += nblocks * BLOCK) {
       b.first_elig[gg] = BS_INF;
       b.first_owner[gg] = BS_INF;
       b.first_reject[gg] = BS_INF;
@@ -1622,19 +1807,54 @@ __global__ __launch_bounds__(kTallyBlock) void k_tally(PodsDev pods, GroupsDev g
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_last = atomicAdd(&b.ticket[0], 1u) == gridDim.x - 1 ? 1u : 0u;
+    *s_last = atomicAdd(&b.ticket[0], 1u) == nblocks - 1 ? 1u : 0u;
   }
   __syncthreads();
-  if (!s_last) return;
+  if (!*s_last) return;
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     b.ticket[0] = 0;
   }
   __syncthreads();
-  for (uint32_t gg = threadIdx.x; gg < gr.g; gg += kTallyBlock) {
+  for (uint32_t gg = threadIdx.x; gg < gr.g; gg += BLOCK) {
     const uint32_t have = gr.matched[gg] + __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     b.ready[gg] = have >= (uint32_t)(gr.min_member[gg] - gr.status_scheduled[gg]) ? 1 : 0;
   }
+}
+
+__global__ __launch_bounds__(kTallyBlock) void k_tally(PodsDev pods, GroupsDev gr, BatchDev b, uint32_t run_filter, uint32_t do_ready,
+                                                        uint32_t rearm) {
+  __shared__ uint32_t s_last;
+  const uint32_t i = blockIdx.x * kTallyBlock + threadIdx.x;
+  const uint32_t feasible = (run_filter && i < pods.p) ? b.fl_feasible[i] : 1u;
+  tally_block<kTallyBlock>(pods, gr, b, i, feasible, do_ready, rearm, blockIdx.x, gridDim.x, &s_last);
+}
+
+// Rows of all pods from the rows of the distinct requests.  Pods Filter passes without looking at a node
+// (not grouped, leader itself, no MinResources: core.go:171-174, :531-535, :542-544) pass on every list
+// entry; pods it errors for, or never sees, pass nowhere.  Pure streaming: P x ceil(N/64) words out.
+// tally != 0: the blocks of word-slice 0 also do k_tally's job (admit counts, quorum, re-arming).
+__global__ __launch_bounds__(256) void k_filter_expand(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, uint32_t words,
+                                                       uint32_t words_per_block, uint32_t tally, uint32_t do_ready, uint32_t rearm) {
+  __shared__ uint32_t s_last;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  uint32_t feasible = 0;
+  if (i < pods.p) {
+    const uint32_t fl = b.fflags[i] >> 8;
+    const uint32_t w0 = blockIdx.y * words_per_block, w1 = min(words, w0 + words_per_block);
+    if (fl == BS_FL_EVALUATED) {
+      const uint32_t u = b.fu_id[b.fu_rep[i]];
+      feasible = b.fu_feas[u];
+      for (uint32_t w = w0; w < w1; ++w) b.fl_bitmap[(size_t)w * pods.p + i] = b.fu_bitmap[(size_t)w * pods.p + u];
+    } else {
+      const bool all = fl < 16u;
+      feasible = all ? nd.n : 0u;
+      const unsigned long long last = (nd.n & 63u) ? ((1ull << (nd.n & 63u)) - 1ull) : ~0ull;
+      for (uint32_t w = w0; w < w1; ++w) b.fl_bitmap[(size_t)w * pods.p + i] = all ? (w + 1u == words ? last : ~0ull) : 0ull;
+    }
+    if (blockIdx.y == 0) b.fl_feasible[i] = feasible;
+  }
+  if (tally && blockIdx.y == 0) tally_block<256>(pods, gr, b, i, feasible, do_ready, rearm, blockIdx.x, gridDim.x, &s_last);
 }
 
 // quorum predicate of Permit, core.go:303, with every admitted pod counted as matched (used after

@@ -99,6 +99,9 @@ struct bs_ctx {
   bool scratch_armed = false;
   bool side_ready = false;      // desc[] / kp[] of the side-stream table are in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
+  DevBuf d_fu_slots, d_fu_rep, d_fu_id, d_fu_list, d_fu_bitmap, d_fu_feas;   // Filter de-duplication
+  DevBuf d_qu_slots, d_qkey, d_qkflags, d_qrep;                              // scan-query de-duplication
+  uint32_t fu_cap = 0, hash_keep = 0x7FFFFFFFu;
   DevBuf d_fl_bitmap, d_admit, d_ready;
   // single-query scratch
   DevBuf d_sq;
@@ -267,6 +270,18 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.chunk_kp = c->d_chunk_kp.as<uint32_t>();
   b.fparams = c->d_fparams.as<int64_t>();
   b.fflags = c->d_fflags.as<uint32_t>();
+  b.qu_slots = c->d_qu_slots.as<unsigned long long>();
+  b.qkey = c->d_qkey.as<int64_t>();
+  b.qkflags = c->d_qkflags.as<uint32_t>();
+  b.qrep = c->d_qrep.as<uint32_t>();
+  b.fu_slots = c->d_fu_slots.as<unsigned long long>();
+  b.fu_mask = c->fu_cap ? c->fu_cap - 1 : 0;
+  b.fu_rep = c->d_fu_rep.as<uint32_t>();
+  b.fu_id = c->d_fu_id.as<uint32_t>();
+  b.fu_list = c->d_fu_list.as<uint32_t>();
+  b.fu_count = c->d_nepochs.as<uint32_t>() + 2;
+  b.fu_bitmap = c->d_fu_bitmap.as<uint64_t>();
+  b.fu_feas = c->d_fu_feas.as<uint32_t>();
   uint8_t* ok = c->d_outpack.as<uint8_t>();
   b.pf_code = ok + c->off_pf_code;
   b.pf_first_k = reinterpret_cast<uint32_t*>(ok + c->off_pf_first_k);
@@ -285,6 +300,7 @@ BatchParams batch_params(const bs_ctx* c) {
   p.rank = c->rank; p.nranks = c->nranks;
   p.sop_leader0 = c->sop_leader0;
   p.run_filter = 0;
+  p.hash_keep = c->hash_keep;
   p.collect_stats = c->collect_stats;
   p.mcap = c->table_mcap;
   p.seg_len = 0;
@@ -410,23 +426,24 @@ void launch_tables_local(bs_ctx* c, hipStream_t st, dim3 grid, const NodesDev& n
   }
 }
 
-// k_filter geometry: a wave owns one 64-pod tile and a run of 64-node blocks
-void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const NodesDev& nd, const BatchDev& b) {
+// Filter: the distinct requests against every node (fixed grid, the kernel splits the work itself), then
+// every pod's row from its representative's.  tally: the expand kernel also does k_tally's job.
+void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, bool tally,
+                   bool do_ready, bool rearm) {
   const uint32_t W = cdiv(c->N, 64), ptiles = cdiv(c->P, 64);
-  if (!W || !ptiles) return;
-  uint32_t nsplit = std::max<uint32_t>(1, c->filter_waves / ptiles);
-  nsplit = std::min<uint32_t>(nsplit, std::max<uint32_t>(cdiv(W, 2), 1));
-  const uint32_t bpw = std::max<uint32_t>(2, cdiv(cdiv(std::max<uint32_t>(W, 1), nsplit), 2) * 2);   // multiple of NB
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(ptiles, 4), cdiv(W, bpw)), dim3(256), 0, st, pd, nd, b, bpw, 1u);
+  if (!ptiles) return;
+  if (W) {
+    const uint32_t waves = std::min<uint32_t>(c->filter_waves, ptiles * std::max<uint32_t>(1, cdiv(W, 2)));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(waves, 4)), dim3(256), 0, st, pd, nd, b, c->filter_waves);
+  }
+  const uint32_t wpb = 8;
+  hipLaunchKernelGGL(k_filter_expand, dim3(cdiv(c->P, 256), std::max<uint32_t>(1, cdiv(W, wpb))), dim3(256), 0, st, pd, gr, nd, b, W, wpb,
+                     tally ? 1u : 0u, do_ready ? 1u : 0u, rearm ? 1u : 0u);
 }
 
-// Waves that share the live 64-row groups of one tile pair (k_scan deals them round-robin).  More than
-// 32 only adds waves that recompute the live set and leave.
-uint32_t pick_scan_share(const bs_ctx* c, uint32_t pairs, uint32_t m) {
-  const uint32_t ngroups = std::max<uint32_t>(1, cdiv(m, 64));
-  uint32_t j = c->scan_share_override ? c->scan_share_override : std::min<uint32_t>(32, c->target_waves / std::max<uint32_t>(1, pairs));
-  return std::min<uint32_t>(ngroups, std::max<uint32_t>(1, j));
-}
+// Cap on the waves that share the live 64-row groups of one tile pair (k_scan picks the actual share
+// from the number of tiles it finds).
+uint32_t pick_scan_share(const bs_ctx* c) { return c->scan_share_override ? c->scan_share_override : 64u; }
 
 // Build the running-sum table for (cls, pct) in the scratch slot (last one) — single queries.
 int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) {
@@ -534,6 +551,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     delete c;
     return BS_ERR_NO_DEVICE;
   }
+  if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) c->early_filter_min = std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("BS_SCAN_SHARE")) c->scan_share_override = (uint32_t)std::max(0, std::atoi(e));
   if (const char* e = std::getenv("BS_TARGET_WAVES")) c->target_waves = std::max(1, std::atoi(e));
@@ -840,6 +858,20 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, c->d_qlist.reserve(n * 4));
   HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
   HIPCHK(c, c->d_fflags.reserve(n * 4));
+  HIPCHK(c, c->d_fu_rep.reserve(n * 4));
+  HIPCHK(c, c->d_qkey.reserve(n * c->LP * 8));
+  HIPCHK(c, c->d_qkflags.reserve(n * 4));
+  HIPCHK(c, c->d_qrep.reserve(n * 4));
+  HIPCHK(c, c->d_fu_id.reserve(n * 4));
+  HIPCHK(c, c->d_fu_list.reserve(n * 4));
+  HIPCHK(c, c->d_fu_feas.reserve(n * 4));
+  {
+    uint32_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    HIPCHK(c, c->d_fu_slots.reserve((size_t)cap * 8));
+    HIPCHK(c, c->d_qu_slots.reserve((size_t)cap * 8));
+    c->fu_cap = cap;
+  }
   HIPCHK(c, c->d_blk_scratch.reserve((n / 256 + 2) * 4));
   c->P = P;
   if (P) {
@@ -904,7 +936,10 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const uint32_t P = c->P, G = c->G, N = c->N, C = c->C;
   const uint32_t W = cdiv(N, 64);
   const bool run_filter = stages & BS_STAGE_FILTER;
-  if (run_filter) HIPCHK(c, c->d_fl_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
+  if (run_filter) {
+    HIPCHK(c, c->d_fl_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
+    HIPCHK(c, c->d_fu_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
+  }
   HIPCHK(c, c->d_tiles.reserve((size_t)(P + 2) * sizeof(Tile)));     // worst case: one tile per query
 
   NodesDev nd = nodes_dev(c);
@@ -918,7 +953,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   prm.tile_queries = 64;
   prm.seg_len = 64;
   // J waves share the live 64-row groups of one tile pair (k_scan deals them round-robin)
-  const uint32_t nseg = pick_scan_share(c, pairs_est, c->M);
+  const uint32_t nseg = pick_scan_share(c);
 
   const dim3 blk(256);
   const bool captures_possible = c->n_uncaptured > 0 && P > 0;
@@ -934,6 +969,12 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const bool early_filter = run_filter && !captures_possible && P && N && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing < 2 &&
                             (uint64_t)P * N >= c->early_filter_min;
   prm.early_filter = early_filter ? 1u : 0u;
+  // tally inputs (admit counts + quorum).  Without early Filter and without COMMIT the expand kernel of
+  // Filter does the tally on the way (one launch less).
+  const bool local_ready = c->nranks == 1 && !c->reduce_external;
+  // re-arming is only valid when the group minima were not also needed for capture epochs (cap_epoch is rewritten then)
+  const bool rearm = !captures_possible && !(stages & BS_BATCH_COMMIT);
+  const bool fuse_tally = run_filter && P && !early_filter && (stages & BS_STAGE_TALLY) && !(stages & BS_BATCH_COMMIT);
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
   if (side_tables) {
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_scan_done, 0));      // the previous batch's scan is done with the tables
@@ -994,7 +1035,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<4>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
       default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<-1>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
     }
-    TIMED_ON(c, BS_KERNEL_FILTER, c->stream3, launch_filter(c, c->stream3, pd, nd, b));
+    TIMED_ON(c, BS_KERNEL_FILTER, c->stream3, launch_filter(c, c->stream3, pd, gr, nd, b, false, false, false));
     HIPCHK(c, hipEventRecord(c->ev_filter, c->stream3));
   }
   // ---- running-sum tables of the (class, percent) pairs some query uses
@@ -1008,7 +1049,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
           hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
       });
     }
-    const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * nseg), 4));
+    const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
     TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg));
     HIPCHK(c, hipEventRecord(c->ev_scan_done, c->stream));   // the tables may be rebuilt (next batch) from here on
   }
@@ -1028,7 +1069,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     }
   });
   if (run_filter && P && !early_filter) {
-    TIMED(c, BS_KERNEL_FILTER, launch_filter(c, c->stream, pd, nd, b));
+    TIMED(c, BS_KERNEL_FILTER, launch_filter(c, c->stream, pd, gr, nd, b, fuse_tally, local_ready, rearm));
   } else if (early_filter) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_filter, 0));
     const uint32_t wpb = 8;
@@ -1058,10 +1099,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   c->batch_seq++;
   c->batch_pending_finish = false;
   if (stages & BS_STAGE_TALLY) {
-    const bool local_ready = c->nranks == 1 && !c->reduce_external;
-    // re-arming is only valid when the group minima were not also needed for capture epochs (cap_epoch is rewritten then)
-    const bool rearm = !captures_possible && !(stages & BS_BATCH_COMMIT);
-    TIMED(c, BS_KERNEL_TALLY, {
+    if (!fuse_tally) TIMED(c, BS_KERNEL_TALLY, {
       hipLaunchKernelGGL(k_tally, dim3(std::max<uint32_t>(1, cdiv(P, kTallyBlock))), dim3(kTallyBlock), 0, c->stream, pd, gr, b,
                          run_filter ? 1u : 0u, local_ready ? 1u : 0u, rearm ? 1u : 0u);
     });
@@ -1308,6 +1346,9 @@ int bs_filter_one(bs_ctx* c, int32_t pod_group, const int64_t* pod_req, uint32_t
   HIPCHK(c, hipMemcpyAsync(base + 512, &pf, 1, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(base + 576, &leader, 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(base + 640, 0, 256, c->stream));
+  const uint32_t one32 = 1;
+  HIPCHK(c, hipMemcpyAsync(base + 964, &one32, 4, hipMemcpyHostToDevice, c->stream));   // one distinct request: pod 0
+  HIPCHK(c, hipMemsetAsync(base + 960, 0, 4, c->stream));
   PodsDev pd{};
   pd.p = 1;
   pd.group = reinterpret_cast<int32_t*>(base + 0);
@@ -1324,6 +1365,10 @@ int bs_filter_one(bs_ctx* c, int32_t pod_group, const int64_t* pod_req, uint32_t
   b.fl_feasible = reinterpret_cast<uint32_t*>(base + 768);
   b.fparams = reinterpret_cast<int64_t*>(base + 832);
   b.fl_bitmap = reinterpret_cast<uint64_t*>(base + 4096);
+  b.fu_list = reinterpret_cast<uint32_t*>(base + 960);
+  b.fu_count = reinterpret_cast<uint32_t*>(base + 964);
+  b.fu_bitmap = b.fl_bitmap;                       // one pod: its row is the distinct request's row
+  b.fu_feas = b.fl_feasible;
   // first_elig must not redirect MinResources for a stand-alone query: use INF for every group
   DevBuf fe;
   HIPCHK(c, fe.reserve(std::max<size_t>(4, (size_t)c->G * 4)));
@@ -1334,7 +1379,7 @@ int bs_filter_one(bs_ctx* c, int32_t pod_group, const int64_t* pod_req, uint32_t
   NodesDev nd = nodes_dev(c);
   hipLaunchKernelGGL(k_filter_params, dim3(1), dim3(256), 0, c->stream, pd, gr, b, prm);
   const uint32_t W = cdiv(N, 64);
-  if (W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(1, 1), dim3(256), 0, c->stream, pd, nd, b, W, 1u);
+  if (W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(1), dim3(64), 0, c->stream, pd, nd, b, 1u);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(k_filter_one, dim3(1), dim3(64), 0, c->stream, nd, b, node, base + 768 + 16);
   HIPCHK(c, hipGetLastError());
@@ -1508,9 +1553,16 @@ int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {
   out->scan_rows_executed = raw[0];
   out->scan_evals_executed = raw[1];
   out->scan_queries = nq;
+  out->scan_queries_logical = raw[2];
   out->tables_built = nt;
   out->logical_evals = (uint64_t)c->P * c->N;
   out->filter_evals = (c->last_stages & BS_STAGE_FILTER) ? (uint64_t)c->P * c->N : 0;
+  if (c->last_stages & BS_STAGE_FILTER) {
+    uint32_t nu = 0;
+    HIPCHK(c, hipMemcpy(&nu, c->d_nepochs.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost));
+    out->filter_distinct = nu;
+    out->filter_evals_executed = (uint64_t)nu * c->N;
+  }
   c->collect_stats = 0;
   return BS_OK;
 }

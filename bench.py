@@ -213,7 +213,9 @@ def main():
                        "logical_evals_per_step": logical,
                        "scan_evals_executed_per_step": stats["scan_evals_executed"],
                        "filter_evals_per_step": stats["filter_evals"],
-                       "scan_queries": stats["scan_queries"], "tables_built": stats["tables_built"],
+                       "filter_distinct_requests": stats["filter_distinct"],
+                       "filter_evals_executed_per_step": stats["filter_evals_executed"],
+                       "scan_queries": stats["scan_queries_logical"], "scan_queries_distinct": stats["scan_queries"], "tables_built": stats["tables_built"],
                        "decisions": {soa.PF_NAMES.get(i, str(i)): int(c) for i, c in enumerate(codes) if c},
                        "groups_ready": int(out.group_ready.sum())},
             "gang_admit_latency_ms_p50": float(np.percentile(lat, 50)) if lat else None,

@@ -376,7 +376,10 @@ const char* bs_kernel_name(uint32_t kernel_id);
  * tiles), logical pods x nodes, scan queries, tables built. */
 typedef struct bs_batch_stats {
   uint64_t scan_queries, scan_rows_executed, scan_evals_executed, tables_built, logical_evals;
-  uint64_t filter_evals;
+  uint64_t filter_evals;            /* logical: pods x nodes                                  */
+  uint64_t filter_distinct;         /* distinct Filter requests actually evaluated            */
+  uint64_t filter_evals_executed;   /* filter_distinct x nodes                                */
+  uint64_t scan_queries_logical;    /* pods that needed a node scan (scan_queries = distinct ones scanned) */
 } bs_batch_stats;
 int bs_batch_stats_get(bs_ctx* ctx, bs_batch_stats* out);
 

@@ -486,3 +486,38 @@ def test_early_filter_cfg3_tail_and_shards(early, bsa, soa, orc):
             admit += part.group_admit
         assert np.array_equal(admit, exp.group_admit)
         ctx.set_shard(0, 1)
+
+
+# ---- request de-duplication (identical derived requests are evaluated once).  BS_HASH_BITS=0 drops every
+# hash bit from the slots, so every probe that meets an occupied slot has to compare full keys and walk on.
+@pytest.fixture
+def weak_hash(monkeypatch):
+    monkeypatch.setenv("BS_HASH_BITS", "0")
+
+
+@pytest.mark.parametrize("seed", range(6000, 6030))
+def test_dedupe_with_colliding_hashes_random(seed, weak_hash, bsa, soa, orc):
+    _batch_case(random_objects(seed, n_nodes=200, n_groups=16, n_pods=400, n_scalars=seed % 3, n_classes=4), bsa, soa, orc)
+
+
+@pytest.mark.parametrize("scenario", ["cold", "warm", "tail"])
+def test_dedupe_with_colliding_hashes_cfg2(scenario, weak_hash, early, bsa, soa, orc):
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", scenario)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, scenario)
+        st = ctx.stats(soa.STAGE_ALL)
+        assert 0 < st["filter_distinct"] <= pods.p
+        assert st["filter_evals_executed"] == st["filter_distinct"] * nodes.n
+
+
+def test_dedupe_all_requests_distinct(bsa, soa, orc):
+    """Worst case for the de-duplication: every pod asks for something else."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "warm")
+    pods.req[0, :] += np.arange(pods.p, dtype=np.int64)          # cpu-milli differs pod by pod
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp)
+        st = ctx.stats(soa.STAGE_ALL)
+        evaluated = int((exp.fl_code == soa.FL_EVALUATED).sum())
+        assert st["filter_distinct"] == evaluated
