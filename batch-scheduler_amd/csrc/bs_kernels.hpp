@@ -92,10 +92,10 @@ struct BatchDev {
   uint8_t* stage;
   int32_t* leader_raw;      // leader findMaxPG returned for this pod (valid iff ST_REACH6)
   int32_t* qtable;          // scan table id (class + C * (pct==0.7)), -1 none
-  uint32_t* first_row;      // [P] by SORTED query position: min table row satisfying the request (INF none)
-  int64_t* qreq_s;          // [P][LP] effective requests in tile order (absent scalar -> INT64_MIN)
-  uint32_t* qflags_s;       // [P] bits 0..11 request key present, bits 16..27 "zero/absent" (passes w/o left key)
-  uint32_t* qpos;           // [P] pod -> sorted position (valid iff ST_QUERY)
+  uint32_t* first_row;      // [scan slots] min table row satisfying the slot's request (INF none)
+  int64_t* qreq_s;          // [scan slots][LP] effective request (absent scalar -> INT64_MIN)
+  uint32_t* qflags_s;       // [scan slots] bits 0..11 request key present, bits 16..27 "zero/absent" (passes w/o left key)
+  uint32_t* qpos;           // [P] pod -> scan slot (valid iff ST_QUERY)
   // tables / tiles
   uint32_t* needed;         // [2C+1] table (class + C*(pct==0.7)) is used by some query of the batch
   uint32_t* qcount;         // [1] scan queries emitted
@@ -115,20 +115,22 @@ struct BatchDev {
   // filter
   int64_t* fparams;         // [P][8]: R[4] = pod + maxSingle, M[4] = maxSingle  (fixed lanes)
   uint32_t* fflags;         // [P] bit0 scalar_block (case 2 impossible), bit1 leader_block, bits 8.. fl_code
-  // scan-query de-duplication: pods with identical (table, request, flags) share one scanned query
-  unsigned long long* qu_slots;   // [fu_mask+1] hash slots (same geometry as fu_slots)
-  int64_t* qkey;            // [P][LP] normalised request of the pod's query (staging for key compares)
-  uint32_t* qkflags;        // [P] its qflags word
-  uint32_t* qrep;           // [P] pod whose query stands for this pod's (valid iff ST_QUERY)
-  // Filter de-duplication: pods with identical (R, M, flags) share one evaluated row
-  unsigned long long* fu_slots;   // [fu_mask+1] hash slots: bit63 valid | hash31 | representative pod
-  uint32_t fu_mask;
-  uint32_t* fu_rep;         // [P] representative pod of an EVALUATED pod
-  uint32_t* fu_id;          // [P] dense id of a representative
-  uint32_t* fu_list;        // [P] dense id -> representative pod
-  uint32_t* fu_count;       // [1] distinct requests
-  uint64_t* fu_bitmap;      // [W][P] rows of the distinct requests (column = dense id)
-  uint32_t* fu_feas;        // [P] feasible-node counts of the distinct requests
+  // Request slots.  Pods of one gang share a template, so derived requests repeat massively; work is done
+  // per SLOT and copied to the pods.  With request classes (pclass, built at bs_pods_load) a slot is
+  //   scan:    class c (reserve check, core.go:157-166)  or  K + group g (first check, core.go:136-147)
+  //   Filter:  class c + K * (pod precedes the first findMaxPG of the batch)
+  // and every pod of a slot writes the same values into it (plain stores, no atomics).  When a first-pod
+  // capture or a MinResources default can occur in the batch a slot is simply the pod itself.
+  const uint32_t* pclass;   // [P] request class of the pod: equal (request lanes, present bits) <=> equal class
+  const uint32_t* kclass;   // [1] K = number of classes
+  unsigned long long* cls_slots;  // [cls_mask+1] hash slots of the class builder: bit63 | hash31 | pod
+  uint32_t cls_mask;
+  int32_t* qtab_s;          // [scan slots] table id of the slot's query, -1 = slot unused in this batch
+  uint32_t* fu_slot;        // [P] Filter slot of the pod
+  int64_t* uparams;         // [filter slots][8] R[4] = pod + maxSingle, M[4] = maxSingle (fixed lanes)
+  uint32_t* uflags;         // [filter slots] as fflags; fl_code NOT_RUN = slot unused
+  uint64_t* fu_bitmap;      // [W][filter slots] rows of the slots
+  uint32_t* fu_feas;        // [filter slots] feasible-node counts of the slots
   // outputs
   uint8_t* pf_code;
   uint32_t* pf_first_k;
@@ -147,7 +149,9 @@ struct BatchParams {
   int32_t sop_leader0;         // sop.maxFinishedPG carried into the batch (-1 none)
   uint32_t run_filter;
   uint32_t early_filter;       // Filter parameters come from k_fparams_early (Filter overlaps the node scan)
-  uint32_t hash_keep;          // hash bits kept in a de-duplication slot (0x7FFFFFFF; fewer = forced collisions, tests)
+  uint32_t hash_keep;          // hash bits kept in a class-builder slot (0x7FFFFFFF; fewer = forced collisions, tests)
+  uint32_t use_classes;        // slots are request classes (no capture / MinResources default possible in this batch)
+  uint32_t scan_slots_cap, filter_slots_cap;   // entries to reset per batch
   uint32_t collect_stats;
   uint32_t mcap;               // table row capacity
   uint32_t seg_len;            // unused (k_scan deals 64-row groups)
@@ -281,6 +285,31 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v, int l) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Request classes of the loaded pods (bs_pods_load): equal (request lanes, present bits) <=> equal class.
+// k_pod_class_a: every pod looks its request up in the hash table; the first of a kind becomes the
+// representative and draws the class id.  k_pod_class_b: every pod takes its representative's id.
+__global__ void k_pod_class_a(PodsDev pods, unsigned long long* slots, uint32_t mask, uint32_t hash_keep, uint32_t L, uint32_t* rep,
+                              uint32_t* id, uint32_t* kcount) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pods.p) return;
+  const uint32_t pres = pods.pres[i];
+  uint64_t h = mix64((uint64_t)pres + 0x9e3779b97f4a7c15ull);
+  for (uint32_t j = 0; j < L; ++j) h = mix64(h ^ (uint64_t)pods.req[(size_t)j * pods.p + i]);
+  bool winner;
+  const uint32_t r = dedupe_insert(slots, mask, hash_keep, h, i, [&](uint32_t o) {
+    if (o >= pods.p || pods.pres[o] != pres) return false;
+    for (uint32_t j = 0; j < L; ++j)
+      if (pods.req[(size_t)j * pods.p + o] != pods.req[(size_t)j * pods.p + i]) return false;
+    return true;
+  }, winner);
+  rep[i] = r;
+  if (winner) id[i] = atomicAdd(kcount, 1u);
+}
+__global__ void k_pod_class_b(uint32_t p, const uint32_t* rep, const uint32_t* id, uint32_t* pclass) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p) pclass[i] = id[rep[i]];
+}
+
 __device__ __forceinline__ void leader_block(const GroupsDev& gr, const BatchDev& b, uint32_t e);
 
 constexpr int kPrepassBlock = 512;
@@ -303,17 +332,20 @@ __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsD
   }
   if (i < 8 && prm.collect_stats) b.stats[i] = 0;
   {
+    // request slots of this batch start out unused
     const uint32_t nthreads = (gridDim.x - fused_leader) * kPrepassBlock;
-    for (uint32_t k = i; k <= b.fu_mask; k += nthreads) b.qu_slots[k] = 0ull;
-    if (prm.run_filter) {
-      if (i == 0) *b.fu_count = 0;
-      for (uint32_t k = i; k <= b.fu_mask; k += nthreads) b.fu_slots[k] = 0ull;
+    for (uint32_t k = i; k < prm.scan_slots_cap; k += nthreads) {
+      b.qtab_s[k] = -1;
+      b.first_row[k] = BS_INF;
     }
+    if (prm.run_filter)
+      for (uint32_t k = i; k < prm.filter_slots_cap; k += nthreads) {
+        b.uflags[k] = (uint32_t)BS_FL_NOT_RUN << 8;
+        b.fu_feas[k] = 0;
+      }
   }
   if (i >= pods.p) return;
-  b.first_row[i] = BS_INF;
   b.fl_feasible[i] = 0;
-  b.fu_feas[i] = 0;
   if (no_capture) b.epoch[i] = 0;
   const int32_t gi = pods.group[i];
   uint8_t st = 0;
@@ -651,11 +683,9 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
     const unsigned long long rb = __ballot(valid && (st & ST_REACH6));
     if (rb && lane_id() == __ffsll((long long)rb) - 1) atomicMin(&b.nepochs[1], i);
   }
-  // Normalise the request (what the scan compares), then de-duplicate: identical (table, request, flags)
-  // queries are scanned once.  Wave leaders of equal keys are elected in registers, only they go to the
-  // global table; the pod that claims a slot is the representative and emits the query.
+  // The query goes into its request slot.  With request classes every pod of a slot derives the same
+  // (table, request, flags), so they all store the same values and the scan sees each distinct query once.
   const bool has_q = valid && table >= 0;
-  uint32_t qfl = 0;
   if (has_q) {
     uint32_t absok = 0;
 #pragma unroll
@@ -666,93 +696,20 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
         if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
       }
     }
-    qfl = q.present | (absok << 16);
-  }
-  uint64_t h = mix64((uint64_t)(uint32_t)table * 0x9e3779b97f4a7c15ull + qfl);
-#pragma unroll
-  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-    if (j < sh.L()) h = mix64(h ^ (uint64_t)q.v[j]);
-  int wl = lane_id();
-  {
-    unsigned long long todo = __ballot(has_q);
-    while (todo) {
-      const int ldr = __ffsll((long long)todo) - 1;
-      bool eq = has_q && h == bcast64(h, ldr);
-      if (__ballot(eq) != (1ull << ldr)) {
-        eq = eq && table == __builtin_amdgcn_readlane(table, ldr) && qfl == (uint32_t)__builtin_amdgcn_readlane((int)qfl, ldr);
-#pragma unroll
-        for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-          if (j < sh.L()) eq = eq && (uint64_t)q.v[j] == bcast64((uint64_t)q.v[j], ldr);
-      }
-      if (eq) wl = ldr;
-      todo &= ~__ballot(eq);
-    }
-  }
-  bool emit = false;
-  uint32_t rep = i;
-  if (has_q && wl == lane_id()) {
-    int64_t* kd = b.qkey + (size_t)i * prm.LP;
-#pragma unroll
-    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-      if (j < sh.L()) kd[j] = q.v[j];
-    b.qkflags[i] = qfl;
-    b.qtable[i] = table;
-    rep = dedupe_insert(b.qu_slots, b.fu_mask, prm.hash_keep, h, i, [&](uint32_t r) {
-      if (r >= pods.p) return false;
-      bool eq = b.qtable[r] == table && b.qkflags[r] == qfl;
-      const int64_t* o = b.qkey + (size_t)r * prm.LP;
-#pragma unroll
-      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-        if (j < sh.L()) eq = eq && o[j] == q.v[j];
-      return eq;
-    }, emit);
-  }
-  rep = (uint32_t)__shfl((int)rep, wl);
-  if (has_q) b.qrep[i] = rep;
-  if (prm.collect_stats) {
-    const unsigned long long hq = __ballot(has_q);
-    if (lane_id() == 0 && hq) atomicAdd((unsigned long long*)&b.stats[2], (unsigned long long)__popcll(hq));
-  }
-  // Tile emission.  The representatives of this wave that query the same table become one scan tile: one
-  // lane reserves `count` consecutive slots of the tile-ordered request arrays and appends the tile.  No
-  // sort, no second pass: a scan wave later reads its requests as contiguous rows.
-  uint32_t pos = 0;
-  unsigned long long todo = __ballot(emit);
-  while (todo) {
-    const int ldr = __ffsll((long long)todo) - 1;
-    const int32_t t0 = __shfl(table, ldr);
-    const bool member = emit && table == t0;
-    const unsigned long long same = __ballot(member);
-    const uint32_t cnt = (uint32_t)__popcll(same);
-    int64_t mn[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) mn[j] = wave_min_i64(member ? q.v[j] : INT64_MAX);
-    uint32_t base = 0;
-    if (lane_id() == ldr) {
-      base = atomicAdd(b.qcount, cnt);
-      const uint32_t tid = atomicAdd(b.ntiles, 1u);
-      Tile tl;
-      tl.slot = (uint32_t)t0;
-      tl.q0 = base;
-      tl.count = cnt;
-      tl.pad = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tl.rmin[j] = mn[j];
-      b.tiles[tid] = tl;
-      b.needed[t0] = 1;
-    }
-    base = (uint32_t)__shfl((int)base, ldr);
-    if (member) pos = base + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull));
-    todo &= ~same;
-  }
-  if (emit) {
-    int64_t* dst = b.qreq_s + (size_t)pos * prm.LP;
+    uint32_t slot = i;
+    if (prm.use_classes) slot = code == BS_PF_PASS_FIRST_FITS ? *b.kclass + (uint32_t)pods.group[i] : b.pclass[i];
+    int64_t* dst = b.qreq_s + (size_t)slot * prm.LP;
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
       if (j < prm.LP) dst[j] = j < sh.L() ? q.v[j] : INT64_MIN;
-    b.qflags_s[pos] = qfl;
-    b.qlist[pos] = i;
-    b.qpos[i] = pos;
+    b.qflags_s[slot] = q.present | (absok << 16);
+    b.qtab_s[slot] = table;
+    b.qpos[i] = slot;
+    b.needed[table] = 1;
+  }
+  if (prm.collect_stats) {
+    const unsigned long long hq = __ballot(has_q);
+    if (lane_id() == 0 && hq) atomicAdd((unsigned long long*)&b.stats[2], (unsigned long long)__popcll(hq));
   }
 }
 
@@ -1025,30 +982,31 @@ __device__ __forceinline__ void row_all(const unsigned long long (&nf)[Q], uint3
   else row_step<L>(nf[0], myk[0], k, a, r[0]);
 }
 
-// One wave's share of one tile (pair): the 64-row groups of the tile's table that are LIVE for the tile
-// (some request could pass: on every fixed lane the group's largest running sum reaches the tile's
-// smallest request), dealt round-robin over the J waves of the tile — wave `share` takes the live
-// groups whose rank is = share (mod J).  Every wave recomputes the live set itself (one gather of the
-// group maxima per 64 groups), so the deal is balanced wherever the live groups are, and a wave that
-// gets nothing leaves before touching the requests.
-template <int S, int Q>
-__device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, const uint32_t (&tq0)[Q],
-                                          const uint32_t (&tcnt)[Q], const int64_t (&rmin)[4], uint32_t share, uint32_t J,
-                                          int64_t (*rows)[4 + S]) {
+// One wave's share of one tile of 64 request slots, for the slots of the tile that use table `slot`
+// (`valid` lanes).  The 64-row groups of the table that are LIVE for them (on every fixed lane the group's
+// largest running sum reaches the smallest request) are dealt round-robin over the J waves of the tile:
+// wave `share` takes the live groups whose rank is = share (mod J).  Every wave recomputes the live set
+// itself (one gather of the group maxima per 64 groups), so the deal is balanced wherever the live groups
+// are.  A group's 64 rows are fetched with ONE vector load per lane (lane = row) and parked in this wave's
+// LDS slice `rows`; the row loop reads them back with uniform-address (broadcast) ds_reads, so no memory
+// round trip sits inside the loop.
+template <int S>
+__device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, uint32_t pos, bool valid,
+                                          const int64_t (&r)[1][4 + S], uint32_t qf, uint32_t share, uint32_t J, int64_t (*rows)[4 + S]) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
   constexpr int U = 4;                           // rows per step: their LDS reads are issued together
-  // A group's 64 rows are fetched with ONE vector load per lane (lane = row) and parked in this wave's
-  // LDS slice `rows`; the row loop then reads them back with uniform-address (broadcast) ds_reads, so no
-  // memory round trip sits inside the loop.
   const int lane = lane_id();
   const uint32_t ngroups = (m + 63u) >> 6, gstride = (prm.mcap + 63u) >> 6;
+  int64_t rmin[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rmin[j] = wave_min_i64(valid ? r[0][j] : INT64_MAX);
 
-  int64_t r[Q][L];
-  uint32_t pos[Q], myk[Q], qf[Q], seen[Q];
-  unsigned long long nf[Q];                      // lanes still looking for their first row
+  uint32_t myk[1] = {BS_INF};
+  uint32_t seen = 0;
+  unsigned long long nf = __ballot(valid);       // lanes still looking for their first row
   uint32_t kp[S > 0 ? S : 1];
-  unsigned long long absok[Q][S > 0 ? S : 1];
+  unsigned long long absok[S > 0 ? S : 1];
   bool loaded = false;
   const int64_t* T = b.tables + (size_t)slot * prm.mcap * LP;
   uint32_t rows_done = 0;
@@ -1079,32 +1037,13 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 #pragma unroll
         for (int j = 0; j < L; ++j) mine_row[j] = src[j];
       }
-      if (!loaded) {                             // first live group: now the requests are worth loading
+      if (!loaded) {                             // first live group of this wave
         loaded = true;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-          const bool valid = (uint32_t)lane < tcnt[q];
-          pos[q] = tq0[q] + (uint32_t)lane;      // tile order: the tile's requests are contiguous rows
-          myk[q] = BS_INF;
-          qf[q] = 0;
-          seen[q] = 0;
-          if (valid) {
-            const int64_t* src = b.qreq_s + (size_t)pos[q] * LP;
-#pragma unroll
-            for (int j = 0; j < L; ++j) r[q][j] = src[j];
-            qf[q] = b.qflags_s[pos[q]];
-            seen[q] = __hip_atomic_load(&b.first_row[pos[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else {
-#pragma unroll
-            for (int j = 0; j < L; ++j) r[q][j] = INT64_MAX;
-          }
-          nf[q] = __ballot(valid);
-        }
+        seen = valid ? __hip_atomic_load(&b.first_row[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           kp[s] = __builtin_amdgcn_readfirstlane(b.kp[slot * 16 + s]);
-#pragma unroll
-          for (int q = 0; q < Q; ++q) absok[q][s] = __ballot((qf[q] >> (16 + s)) & 1u);
+          absok[s] = __ballot((qf >> (16 + s)) & 1u);
         }
       }
       __builtin_amdgcn_wave_barrier();           // the previous group's reads are behind us (LDS is in order)
@@ -1113,14 +1052,8 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
       __builtin_amdgcn_wave_barrier();
       uint32_t a = g0;
       // lanes another wave already served with an earlier row need nothing from this group
-      unsigned long long want[Q];
-      unsigned long long any = 0;
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        want[q] = nf[q] & __ballot(seen[q] >= a);
-        any |= want[q];
-      }
-      if (any == 0) continue;
+      unsigned long long want = nf & __ballot(seen >= a);
+      if (want == 0) continue;
       while (a < gend) {
         // piece [a, e): no kp[s] strictly inside
         uint32_t e = gend;
@@ -1128,17 +1061,13 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
         for (int s = 0; s < S; ++s)
           if (kp[s] > a && kp[s] < e) e = kp[s];
         // lanes that can pass while key s is absent from the running sum (core.go:688-692)
-        unsigned long long act[Q];
+        unsigned long long el = ~0ull;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-          unsigned long long el = ~0ull;
-#pragma unroll
-          for (int s = 0; s < S; ++s)
-            if (kp[s] > a) el &= absok[q][s];
-          act[q] = want[q] & el;
-        }
+        for (int s = 0; s < S; ++s)
+          if (kp[s] > a) el &= absok[s];
+        const unsigned long long act[1] = {want & el};
         uint32_t k = a;
-        bool open = true;                        // some lane of this piece is still without a row
+        bool open = act[0] != 0;                 // some lane of this piece is still without a row
         while (open && k + U <= e) {
           int64_t A[U][L];
 #pragma unroll
@@ -1146,95 +1075,80 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 #pragma unroll
             for (int j = 0; j < L; ++j) A[u][j] = rows[k - g0 + u][j];
 #pragma unroll
-          for (int u = 0; u < U; ++u) row_all<L, Q>(act, myk, k + u, A[u], r);
+          for (int u = 0; u < U; ++u) row_all<L, 1>(act, myk, k + u, A[u], r);
           k += U;
-          unsigned long long left = 0;
-#pragma unroll
-          for (int q = 0; q < Q; ++q) left |= act[q] & __ballot(myk[q] == BS_INF);
-          open = left != 0;
+          open = (act[0] & __ballot(myk[0] == BS_INF)) != 0;
         }
         if (open) {
           for (; k < e; ++k) {                   // < U leftover rows of the piece
             int64_t R1[L];
 #pragma unroll
             for (int j = 0; j < L; ++j) R1[j] = rows[k - g0][j];
-            row_all<L, Q>(act, myk, k, R1, r);
+            row_all<L, 1>(act, myk, k, R1, r);
           }
         }
         rows_done += k - a;
-        unsigned long long left = 0;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-          want[q] &= __ballot(myk[q] == BS_INF);
-          left |= want[q];
-        }
-        if (left == 0) break;
+        want &= __ballot(myk[0] == BS_INF);
+        if (want == 0) break;
         a = e;
       }
       // found lanes are done for good (this wave walks its groups in increasing row order)
-      unsigned long long left = 0;
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        nf[q] &= __ballot(myk[q] == BS_INF);
-        left |= nf[q];
-      }
-      if (left == 0) { c0 = ngroups; break; }
+      nf &= __ballot(myk[0] == BS_INF);
+      if (nf == 0) { c0 = ngroups; break; }
     }
   }
   if (!loaded) return;
-#pragma unroll
-  for (int q = 0; q < Q; ++q)
-    if (myk[q] != BS_INF) atomicMin(&b.first_row[pos[q]], myk[q]);
+  if (myk[0] != BS_INF) atomicMin(&b.first_row[pos], myk[0]);
   if (prm.collect_stats && lane == 0) {
-    uint32_t nq = 0;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) nq += tcnt[q];
+    const uint32_t nq = (uint32_t)__popcll(__ballot(valid));
     atomicAdd((unsigned long long*)&b.stats[0], (unsigned long long)rows_done);
     atomicAdd((unsigned long long*)&b.stats[1], (unsigned long long)rows_done * nq);
   }
 }
 
-// Work loop: item = (pair of tiles, share j of J).  Tiles come in emission order; two tiles of the same
-// table share one pass over the rows (Q = 2: every row is loaded once for 128 requests), tiles of
-// different tables are scanned one after the other.  Consecutive waves take different pairs with the
-// same share (the same rows, reused from the scalar cache).  The grid is fixed; waves stride over items.
+// Work loop: item = (tile of 64 request slots, share j of J).  The slots of a tile that use the same
+// table are scanned together (steady state: one table for everything); consecutive waves take different
+// tiles with the same share.  The grid is fixed; the slot count is read on the device.
 template <int S>
-__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t jcap) {
-  typedef const __attribute__((address_space(4))) Tile* ctile_t;
-  ctile_t CT = (ctile_t)(uintptr_t)b.tiles;
-  const uint32_t ntiles = *b.ntiles;
-  const uint32_t npairs = (ntiles + 1u) >> 1;
-  if (!npairs) return;
-  // the number of tiles is only known here (queries are de-duplicated on the device): share every pair
-  // among as many waves as the grid has to spare, at most one per 64-row group
-  const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (gridDim.x * 4u) / npairs));
-  __shared__ int64_t s_rows[4][64][4 + S];
-  int64_t (*rows)[4 + S] = s_rows[wave_id()];
-  const uint32_t items = npairs * J;
-  const uint32_t stride = gridDim.x * 4u;
-  for (uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id()); w < items; w += stride) {
-    const uint32_t share = w / npairs, pair = w - share * npairs;
-    const bool has_b = 2u * pair + 1u < ntiles;
-    const uint32_t ia = 2u * pair, ib = has_b ? 2u * pair + 1u : 2u * pair;
-    const uint32_t sa = CT[ia].slot, sb = CT[ib].slot;
-    const uint32_t qa = CT[ia].q0, qb = CT[ib].q0;
-    const uint32_t ca = CT[ia].count, cb = CT[ib].count;
-    int64_t ra[4], rb[4];
+__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t nslots_fixed, uint32_t ngroups_g,
+                                              uint32_t tsplit) {
+  constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
+  constexpr int L = 4 + S;
+  __shared__ int64_t s_rows[4][64][L];
+  int64_t (*rows)[L] = s_rows[wave_id()];
+  const uint32_t nslots = prm.use_classes ? __builtin_amdgcn_readfirstlane(*b.kclass) + ngroups_g : nslots_fixed;
+  const uint32_t ntiles = (nslots + 63u) >> 6;
+  if (!ntiles || !m) return;
+  // tsplit > 1 (several tables in use): the distinct tables of a tile are dealt over tsplit waves as well
+  const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (gridDim.x * 4u) / (ntiles * tsplit)));
+  const uint32_t items = ntiles * tsplit * J;
+  const int lane = lane_id();
+  for (uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id()); w < items; w += gridDim.x * 4u) {
+    const uint32_t rest = w / ntiles, tile = w - rest * ntiles;
+    const uint32_t share = rest / tsplit, ts = rest - share * tsplit;
+    const uint32_t pos = tile * 64u + (uint32_t)lane;
+    const int32_t tab = pos < nslots ? b.qtab_s[pos] : -1;
+    unsigned long long todo = __ballot(tab >= 0);
+    if (!todo) continue;
+    int64_t r[1][L];
+    uint32_t qf = 0;
+    if (tab >= 0) {
+      const int64_t* src = b.qreq_s + (size_t)pos * LP;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { ra[j] = CT[ia].rmin[j]; rb[j] = CT[ib].rmin[j]; }
-    if (has_b && sa == sb) {
-      int64_t rm[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) rm[j] = ra[j] < rb[j] ? ra[j] : rb[j];
-      const uint32_t q0s[2] = {qa, qb}, cnts[2] = {ca, cb};
-      scan_core<S, 2>(b, prm, m, sa, q0s, cnts, rm, share, J, rows);
+      for (int j = 0; j < L; ++j) r[0][j] = src[j];
+      qf = b.qflags_s[pos];
     } else {
-      const uint32_t q0a[1] = {qa}, cna[1] = {ca};
-      scan_core<S, 1>(b, prm, m, sa, q0a, cna, ra, share, J, rows);
-      if (has_b) {
-        const uint32_t q0b[1] = {qb}, cnb[1] = {cb};
-        scan_core<S, 1>(b, prm, m, sb, q0b, cnb, rb, share, J, rows);
-      }
+#pragma unroll
+      for (int j = 0; j < L; ++j) r[0][j] = INT64_MAX;
+    }
+    if (prm.collect_stats && share == 0 && ts == 0 && lane == 0) atomicAdd((unsigned long long*)&b.stats[4], (unsigned long long)__popcll(todo));
+    uint32_t turn = 0;
+    while (todo) {
+      const int32_t t0 = __builtin_amdgcn_readlane(tab, __ffsll((long long)todo) - 1);
+      const bool member = tab == t0;
+      if (turn == ts) scan_core<S>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows);
+      turn = turn + 1u == tsplit ? 0u : turn + 1u;
+      todo &= ~__ballot(member);
     }
   }
 }
@@ -1246,7 +1160,7 @@ __global__ void k_reject(PodsDev pods, BatchDev b) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pods.p) return;
   if (!(b.stage[i] & ST_QUERY)) return;
-  if (b.first_row[b.qpos[b.qrep[i]]] == BS_INF) {
+  if (b.first_row[b.qpos[i]] == BS_INF) {
     // compareClusterResourceAndRequire returned false: AddToDenyCache (core.go:142,163)
     b.tcode[i] = (b.tcode[i] == BS_PF_PASS_FIRST_FITS) ? BS_PF_REJECT_FIRST : BS_PF_REJECT_RESERVE;
     atomicMin(&b.first_reject[pods.group[i]], i);
@@ -1254,11 +1168,9 @@ __global__ void k_reject(PodsDev pods, BatchDev b) {
 }
 
 // Filter per-pod parameters (see the Filter section below); defined here because k_final fuses it.
-struct FilterKey { int64_t R[4], M[4]; uint32_t ffw; };     // ffw = flag bits | fl_code << 8
-
 template <int TS>
 __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm,
-                                                  uint32_t i, uint8_t pf, int32_t leader, FilterKey& key) {
+                                                  uint32_t i, uint8_t pf, int32_t leader, uint32_t slot) {
   const Shape<TS> sh(prm.S);
   const uint32_t gate = prm.eph_gate;
   uint8_t fl = BS_FL_NOT_RUN;
@@ -1293,59 +1205,17 @@ __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const Gro
       }
     }
   }
-  int64_t* dst = b.fparams + (size_t)i * 8;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { dst[j] = R[j]; dst[4 + j] = M[j]; }
-  b.fflags[i] = ff | ((uint32_t)fl << 8);
+  const uint32_t ffw = ff | ((uint32_t)fl << 8);
+  b.fflags[i] = ffw;
   b.fl_code[i] = fl;
-  key.ffw = ff | ((uint32_t)fl << 8);
+  b.fu_slot[i] = slot;
+  if (fl == BS_FL_EVALUATED) {
+    // every pod of the slot stores the same values (see BatchDev)
+    int64_t* dst = b.uparams + (size_t)slot * 8;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { key.R[j] = R[j]; key.M[j] = M[j]; }
-}
-
-// De-duplicate the Filter requests of one wave's pods (all lanes must call; `active` = the pod is
-// EVALUATED).  Lanes with equal keys first elect a wave leader in registers (consecutive pods are
-// gang-mates, so a wave holds a handful of distinct keys); only the leaders go to the global table, all
-// at once, and hand the representative to their followers.
-__device__ __forceinline__ void filter_dedupe_wave(const PodsDev& pods, const BatchDev& b, const BatchParams& prm, uint32_t i, bool active,
-                                                   const FilterKey& key) {
-  uint64_t h = mix64((uint64_t)key.ffw + 0x9e3779b97f4a7c15ull);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { h = mix64(h ^ (uint64_t)key.R[j]); h = mix64(h ^ (uint64_t)key.M[j]); }
-  const int lane = lane_id();
-  int wl = lane;
-  unsigned long long todo = __ballot(active);
-  while (todo) {
-    const int ldr = __ffsll((long long)todo) - 1;
-    bool eq = active && h == bcast64(h, ldr);
-    if (__ballot(eq) != (1ull << ldr)) {            // same hash somewhere else: settle it on the full key
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        eq = eq && (uint64_t)key.R[j] == bcast64((uint64_t)key.R[j], ldr) && (uint64_t)key.M[j] == bcast64((uint64_t)key.M[j], ldr);
-      eq = eq && key.ffw == (uint32_t)__builtin_amdgcn_readlane((int)key.ffw, ldr);
-    }
-    if (eq) wl = ldr;
-    todo &= ~__ballot(eq);
+    for (int j = 0; j < 4; ++j) { dst[j] = R[j]; dst[4 + j] = M[j]; }
+    b.uflags[slot] = ffw;
   }
-  uint32_t rep = i;
-  if (active && wl == lane) {
-    bool winner;
-    rep = dedupe_insert(b.fu_slots, b.fu_mask, prm.hash_keep, h, i, [&](uint32_t r) {
-      if (r >= pods.p) return false;
-      const int64_t* o = b.fparams + (size_t)r * 8;
-      bool eq = b.fflags[r] == key.ffw;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) eq = eq && o[j] == key.R[j] && o[4 + j] == key.M[j];
-      return eq;
-    }, winner);
-    if (winner) {
-      const uint32_t id = atomicAdd(b.fu_count, 1u);
-      b.fu_id[i] = id;
-      b.fu_list[id] = i;
-    }
-  }
-  rep = (uint32_t)__shfl((int)rep, wl);
-  if (active) b.fu_rep[i] = rep;
 }
 
 // Did pod j really reach findMaxPG (core.go:118-123)?  Tentatively yes (k_query) and not behind the
@@ -1389,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_final(PodsDev pods, GroupsDev gr, Nodes
       if ((st & ST_ELIG) && b.first_reject[pods.group[i]] < i) {
         code = BS_PF_ERR_DENIED;
       } else if (st & ST_QUERY) {
-        const uint32_t row = b.first_row[b.qpos[b.qrep[i]]];
+        const uint32_t row = b.first_row[b.qpos[i]];
         fk = row == BS_INF ? BS_K_NONE : nd.kmap[row];
       }
     } else {
@@ -1410,22 +1280,22 @@ __global__ __launch_bounds__(256) void k_final(PodsDev pods, GroupsDev gr, Nodes
   uint32_t off = prev;
   for (int w = 0; w < wave_id(); ++w) off = max(off, lds[w]);
   const uint32_t jp1 = max(v, off);
-  FilterKey key{};
-  const bool params = i < pods.p && prm.run_filter && !prm.early_filter;
   if (i < pods.p) {
     const int32_t leader = jp1 ? b.leader_raw[jp1 - 1u] : prm.sop_leader0;
     b.pf_leader[i] = leader;
-    if (params) filter_params_for<TS>(pods, gr, b, prm, i, code, leader, key);
+    if (prm.run_filter && !prm.early_filter) {
+      // Filter slot: the pod's request class, apart for the pods that still see the leader carried into the batch
+      const uint32_t slot = prm.use_classes ? b.pclass[i] + (jp1 ? 0u : *b.kclass) : i;
+      filter_params_for<TS>(pods, gr, b, prm, i, code, leader, slot);
+    }
   }
-  if (prm.run_filter && !prm.early_filter) filter_dedupe_wave(pods, b, prm, i, params && (key.ffw >> 8) == BS_FL_EVALUATED, key);
 }
 
 // stand-alone Filter parameters (bs_filter_one): pf_code / pf_leader given
 __global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pods.p) return;
-  FilterKey key;
-  filter_params_for<-1>(pods, gr, b, prm, i, b.pf_code[i], b.pf_leader[i], key);
+  filter_params_for<-1>(pods, gr, b, prm, i, b.pf_code[i], b.pf_leader[i], i);
 }
 
 // Filter parameters BEFORE the node scan has run (no first-pod capture possible in this batch, so there
@@ -1441,13 +1311,12 @@ __global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchPar
 template <int TS>
 __global__ void k_fparams_early(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  FilterKey key{};
-  if (i < pods.p) {
-    const uint8_t pf = (b.stage[i] & ST_OWNED) ? b.tcode[i] : (uint8_t)BS_PF_NOT_OWNED;
-    const int32_t leader = i >= b.nepochs[1] ? b.leader_epoch[0] : prm.sop_leader0;
-    filter_params_for<TS>(pods, gr, b, prm, i, pf, leader, key);
-  }
-  filter_dedupe_wave(pods, b, prm, i, i < pods.p && (key.ffw >> 8) == BS_FL_EVALUATED, key);
+  if (i >= pods.p) return;
+  const uint8_t pf = (b.stage[i] & ST_OWNED) ? b.tcode[i] : (uint8_t)BS_PF_NOT_OWNED;
+  const bool after = i >= b.nepochs[1];
+  const int32_t leader = after ? b.leader_epoch[0] : prm.sop_leader0;
+  const uint32_t slot = prm.use_classes ? b.pclass[i] + (after ? 0u : *b.kclass) : i;
+  filter_params_for<TS>(pods, gr, b, prm, i, pf, leader, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1541,7 +1410,7 @@ __device__ __forceinline__ void filter_pod_loop(uint32_t np, const int64_t (*sR)
 }
 
 template <int NB>
-__device__ __forceinline__ void filter_item(const PodsDev& pods, const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ptile,
+__device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ustride, uint32_t ptile,
                                             uint32_t w0, uint32_t w1) {
   static_assert(NB == 2, "the inner statement handles two node blocks");
   typedef const __attribute__((address_space(4))) uint32_t* cflag_t;
@@ -1552,13 +1421,13 @@ __device__ __forceinline__ void filter_item(const PodsDev& pods, const NodesDev&
   // Is the leader's single-member request M the same for every evaluated pod of the tile?  (It is,
   // unless the tile straddles a first-pod capture.)  Then case 3 is one mask per node block.
   const bool mine = (uint32_t)lane < np;
-  const uint32_t src = mine ? b.fu_list[p0 + lane] : 0u;          // the tile's requests: distinct ones only
-  const uint32_t myff = mine ? b.fflags[src] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  const uint32_t src = p0 + (uint32_t)lane;                       // lanes are request slots
+  const uint32_t myff = mine ? b.uflags[src] : ((uint32_t)BS_FL_NOT_RUN << 8);
   const uint32_t myfl = myff >> 8;
   const bool ev = myfl == BS_FL_EVALUATED;
   int64_t M[4] = {0, 0, 0, 0};
   if (ev) {
-    const int64_t* ms = b.fparams + (size_t)src * 8 + 4;
+    const int64_t* ms = b.uparams + (size_t)src * 8 + 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) M[j] = ms[j];
   }
@@ -1571,7 +1440,7 @@ __device__ __forceinline__ void filter_item(const PodsDev& pods, const NodesDev&
   {
     int64_t myR[4] = {0, 0, 0, 0};
     if (mine) {
-      const int64_t* rs = b.fparams + (size_t)src * 8;
+      const int64_t* rs = b.uparams + (size_t)src * 8;
 #pragma unroll
       for (int j = 0; j < 4; ++j) myR[j] = rs[j];
     }
@@ -1592,6 +1461,7 @@ __device__ __forceinline__ void filter_item(const PodsDev& pods, const NodesDev&
     }
   }
   const unsigned long long evmask = __ballot(ev);
+  if (!evmask) return;                             // no slot of this tile is in use
   bool uniformM = true;
   int64_t M0[4] = {0, 0, 0, 0};
   uint32_t lb0 = 0;
@@ -1608,9 +1478,8 @@ __device__ __forceinline__ void filter_item(const PodsDev& pods, const NodesDev&
     uniformM = __ballot(ev && !same) == 0;
   }
 
-  crow_t FP = as_const_rows(b.fparams);
-  cflag_t FF = (cflag_t)(uintptr_t)b.fflags;
-  cflag_t UL = (cflag_t)(uintptr_t)b.fu_list;
+  crow_t FP = as_const_rows(b.uparams);
+  cflag_t FF = (cflag_t)(uintptr_t)b.uflags;
   uint32_t cnt = 0;
   // node blocks are double-buffered: the loads of step w+NB are in flight during the pod loop of step w
   int64_t l[NB][4], ln[NB][4];
@@ -1691,7 +1560,7 @@ __device__ __forceinline__ void filter_item(const PodsDev& pods, const NodesDev&
     } else {
       // generic path: per-pod leader request (tile straddles a capture); plain ballots
       for (uint32_t pp = 0; pp < np; ++pp) {
-        const uint32_t p = UL[p0 + pp];
+        const uint32_t p = p0 + pp;
         const uint32_t ff = FF[p];
         const uint32_t fl = ff >> 8;
 #pragma unroll
@@ -1717,7 +1586,7 @@ __device__ __forceinline__ void filter_item(const PodsDev& pods, const NodesDev&
       if ((w + nb) < w1 && mine) {
         const unsigned long long word = ((unsigned long long)vhi[nb] << 32) | vlo[nb];
         cnt += (uint32_t)__popcll(word);
-        b.fu_bitmap[(size_t)(w + nb) * pods.p + p0 + lane] = word;
+        b.fu_bitmap[(size_t)(w + nb) * ustride + p0 + lane] = word;
       }
     }
 #pragma unroll
@@ -1730,12 +1599,13 @@ __device__ __forceinline__ void filter_item(const PodsDev& pods, const NodesDev&
   if (mine && cnt) atomicAdd(&b.fu_feas[p0 + lane], cnt);
 }
 
-// Work loop over (tile of 64 distinct requests, run of node blocks).  The number of distinct requests is
-// only known on the device, so the grid is fixed and every wave derives the split itself: as many node
-// runs as it takes to give the whole grid something to do.
+// Work loop over (tile of 64 request slots, run of node blocks).  The slot count is only known on the
+// device, so the grid is fixed and every wave derives the split itself: as many node runs as it takes to
+// give the whole grid something to do.  ustride = row stride of fu_bitmap (slot capacity).
 template <int NB>
-__global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, BatchDev b, uint32_t target_waves) {
-  const uint32_t U = __builtin_amdgcn_readfirstlane(*b.fu_count);
+__global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, BatchDev b, uint32_t target_waves, uint32_t use_classes,
+                                                uint32_t ustride, uint32_t collect_stats) {
+  const uint32_t U = use_classes ? 2u * __builtin_amdgcn_readfirstlane(*b.kclass) : pods.p;
   const uint32_t W = (nd.n + 63u) / 64u;
   if (!U || !W) return;
   const uint32_t tiles = (U + 63u) / 64u;
@@ -1746,7 +1616,12 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
   const uint32_t items = tiles * nchunk;
   for (uint32_t it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id()); it < items; it += gridDim.x * 4u) {
     const uint32_t chunk = it / tiles, tile = it - chunk * tiles;                   // neighbours share the node run
-    filter_item<NB>(pods, nd, b, U, tile, chunk * bpw, min(W, chunk * bpw + bpw));
+    if (collect_stats && chunk == 0) {
+      const uint32_t sl = tile * 64u + (uint32_t)lane_id();
+      const unsigned long long evs = __ballot(sl < U && (b.uflags[sl] >> 8) == BS_FL_EVALUATED);
+      if (lane_id() == 0 && evs) atomicAdd((unsigned long long*)&b.stats[3], (unsigned long long)__popcll(evs));
+    }
+    filter_item<NB>(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw));
   }
 }
 
@@ -1834,24 +1709,32 @@ __global__ __launch_bounds__(kTallyBlock) void k_tally(PodsDev pods, GroupsDev g
 // (not grouped, leader itself, no MinResources: core.go:171-174, :531-535, :542-544) pass on every list
 // entry; pods it errors for, or never sees, pass nowhere.  Pure streaming: P x ceil(N/64) words out.
 // tally != 0: the blocks of word-slice 0 also do k_tally's job (admit counts, quorum, re-arming).
-__global__ __launch_bounds__(256) void k_filter_expand(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, uint32_t words,
-                                                       uint32_t words_per_block, uint32_t tally, uint32_t do_ready, uint32_t rearm) {
+constexpr int kExpandWords = 8;                    // bitmap words per thread (grid.y slices the row)
+__global__ __launch_bounds__(256) void k_filter_expand(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, uint32_t words, uint32_t ustride,
+                                                       uint32_t tally, uint32_t do_ready, uint32_t rearm) {
   __shared__ uint32_t s_last;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   uint32_t feasible = 0;
   if (i < pods.p) {
     const uint32_t fl = b.fflags[i] >> 8;
-    const uint32_t w0 = blockIdx.y * words_per_block, w1 = min(words, w0 + words_per_block);
+    const uint32_t w0 = blockIdx.y * kExpandWords;
+    unsigned long long v[kExpandWords];
     if (fl == BS_FL_EVALUATED) {
-      const uint32_t u = b.fu_id[b.fu_rep[i]];
+      const uint32_t u = b.fu_slot[i];
       feasible = b.fu_feas[u];
-      for (uint32_t w = w0; w < w1; ++w) b.fl_bitmap[(size_t)w * pods.p + i] = b.fu_bitmap[(size_t)w * pods.p + u];
+#pragma unroll
+      for (int k = 0; k < kExpandWords; ++k)       // all loads first: one memory round trip per thread
+        v[k] = w0 + k < words ? b.fu_bitmap[(size_t)(w0 + k) * ustride + u] : 0ull;
     } else {
       const bool all = fl < 16u;
       feasible = all ? nd.n : 0u;
       const unsigned long long last = (nd.n & 63u) ? ((1ull << (nd.n & 63u)) - 1ull) : ~0ull;
-      for (uint32_t w = w0; w < w1; ++w) b.fl_bitmap[(size_t)w * pods.p + i] = all ? (w + 1u == words ? last : ~0ull) : 0ull;
+#pragma unroll
+      for (int k = 0; k < kExpandWords; ++k) v[k] = all ? (w0 + k + 1u == words ? last : ~0ull) : 0ull;
     }
+#pragma unroll
+    for (int k = 0; k < kExpandWords; ++k)
+      if (w0 + k < words) b.fl_bitmap[(size_t)(w0 + k) * pods.p + i] = v[k];
     if (blockIdx.y == 0) b.fl_feasible[i] = feasible;
   }
   if (tally && blockIdx.y == 0) tally_block<256>(pods, gr, b, i, feasible, do_ready, rearm, blockIdx.x, gridDim.x, &s_last);

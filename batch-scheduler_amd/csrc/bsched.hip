@@ -71,7 +71,7 @@ struct bs_ctx {
   std::vector<uint32_t> h_fit;                   // [C][fit_words]
 
   // ---- groups
-  uint32_t G = 0, n_uncaptured = 0;
+  uint32_t G = 0, n_uncaptured = 0;   // groups without a pod (first-pod capture possible)
   std::vector<uint32_t> h_gmatched, h_gcls;
   std::vector<uint8_t> h_gflags;
   int32_t steady_table = -1;        // the one table every reservation query uses when no capture can occur, -1 unknown
@@ -99,9 +99,9 @@ struct bs_ctx {
   bool scratch_armed = false;
   bool side_ready = false;      // desc[] / kp[] of the side-stream table are in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
-  DevBuf d_fu_slots, d_fu_rep, d_fu_id, d_fu_list, d_fu_bitmap, d_fu_feas;   // Filter de-duplication
-  DevBuf d_qu_slots, d_qkey, d_qkflags, d_qrep;                              // scan-query de-duplication
-  uint32_t fu_cap = 0, hash_keep = 0x7FFFFFFFu;
+  // request slots (see BatchDev): classes of the loaded pods + per-batch slot arrays
+  DevBuf d_pclass, d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_fu_bitmap, d_fu_feas;
+  uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
   DevBuf d_fl_bitmap, d_admit, d_ready;
   // single-query scratch
   DevBuf d_sq;
@@ -270,16 +270,14 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.chunk_kp = c->d_chunk_kp.as<uint32_t>();
   b.fparams = c->d_fparams.as<int64_t>();
   b.fflags = c->d_fflags.as<uint32_t>();
-  b.qu_slots = c->d_qu_slots.as<unsigned long long>();
-  b.qkey = c->d_qkey.as<int64_t>();
-  b.qkflags = c->d_qkflags.as<uint32_t>();
-  b.qrep = c->d_qrep.as<uint32_t>();
-  b.fu_slots = c->d_fu_slots.as<unsigned long long>();
-  b.fu_mask = c->fu_cap ? c->fu_cap - 1 : 0;
-  b.fu_rep = c->d_fu_rep.as<uint32_t>();
-  b.fu_id = c->d_fu_id.as<uint32_t>();
-  b.fu_list = c->d_fu_list.as<uint32_t>();
-  b.fu_count = c->d_nepochs.as<uint32_t>() + 2;
+  b.pclass = c->d_pclass.as<uint32_t>();
+  b.kclass = c->d_nepochs.as<uint32_t>() + 2;
+  b.cls_slots = c->d_cls_slots.as<unsigned long long>();
+  b.cls_mask = c->cls_cap ? c->cls_cap - 1 : 0;
+  b.qtab_s = c->d_qtab_s.as<int32_t>();
+  b.fu_slot = c->d_fu_slot.as<uint32_t>();
+  b.uparams = c->d_uparams.as<int64_t>();
+  b.uflags = c->d_uflags.as<uint32_t>();
   b.fu_bitmap = c->d_fu_bitmap.as<uint64_t>();
   b.fu_feas = c->d_fu_feas.as<uint32_t>();
   uint8_t* ok = c->d_outpack.as<uint8_t>();
@@ -301,6 +299,9 @@ BatchParams batch_params(const bs_ctx* c) {
   p.sop_leader0 = c->sop_leader0;
   p.run_filter = 0;
   p.hash_keep = c->hash_keep;
+  p.use_classes = 0;
+  p.scan_slots_cap = 0;
+  p.filter_slots_cap = 0;
   p.collect_stats = c->collect_stats;
   p.mcap = c->table_mcap;
   p.seg_len = 0;
@@ -393,24 +394,24 @@ int upload_fit(bs_ctx* c) {
 }
 
 template <int S>
-void launch_scan_s(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S>), grid, dim3(256), 0, c->stream, b, p, m, nseg);
+void launch_scan_s(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg, uint32_t nslots, uint32_t ng, uint32_t ts) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S>), grid, dim3(256), 0, c->stream, b, p, m, nseg, nslots, ng, ts);
 }
-void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg) {
+void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg, uint32_t nslots, uint32_t ng, uint32_t ts) {
   switch (c->S) {
-    case 0: launch_scan_s<0>(c, grid, b, p, m, nseg); break;
-    case 1: launch_scan_s<1>(c, grid, b, p, m, nseg); break;
-    case 2: launch_scan_s<2>(c, grid, b, p, m, nseg); break;
-    case 3: launch_scan_s<3>(c, grid, b, p, m, nseg); break;
-    case 4: launch_scan_s<4>(c, grid, b, p, m, nseg); break;
-    case 5: launch_scan_s<5>(c, grid, b, p, m, nseg); break;
-    case 6: launch_scan_s<6>(c, grid, b, p, m, nseg); break;
-    case 7: launch_scan_s<7>(c, grid, b, p, m, nseg); break;
-    case 8: launch_scan_s<8>(c, grid, b, p, m, nseg); break;
-    case 9: launch_scan_s<9>(c, grid, b, p, m, nseg); break;
-    case 10: launch_scan_s<10>(c, grid, b, p, m, nseg); break;
-    case 11: launch_scan_s<11>(c, grid, b, p, m, nseg); break;
-    default: launch_scan_s<12>(c, grid, b, p, m, nseg); break;
+    case 0: launch_scan_s<0>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 1: launch_scan_s<1>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 2: launch_scan_s<2>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 3: launch_scan_s<3>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 4: launch_scan_s<4>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 5: launch_scan_s<5>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 6: launch_scan_s<6>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 7: launch_scan_s<7>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 8: launch_scan_s<8>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 9: launch_scan_s<9>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 10: launch_scan_s<10>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 11: launch_scan_s<11>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    default: launch_scan_s<12>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
   }
 }
 
@@ -428,17 +429,17 @@ void launch_tables_local(bs_ctx* c, hipStream_t st, dim3 grid, const NodesDev& n
 
 // Filter: the distinct requests against every node (fixed grid, the kernel splits the work itself), then
 // every pod's row from its representative's.  tally: the expand kernel also does k_tally's job.
-void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, bool tally,
-                   bool do_ready, bool rearm) {
+void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, bool use_classes,
+                   bool tally, bool do_ready, bool rearm) {
   const uint32_t W = cdiv(c->N, 64), ptiles = cdiv(c->P, 64);
   if (!ptiles) return;
   if (W) {
-    const uint32_t waves = std::min<uint32_t>(c->filter_waves, ptiles * std::max<uint32_t>(1, cdiv(W, 2)));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(waves, 4)), dim3(256), 0, st, pd, nd, b, c->filter_waves);
+    const uint32_t waves = std::min<uint32_t>(c->filter_waves, 2 * ptiles * std::max<uint32_t>(1, cdiv(W, 2)));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(waves, 4)), dim3(256), 0, st, pd, nd, b, c->filter_waves, use_classes ? 1u : 0u,
+                       c->filter_slots_cap, c->collect_stats);
   }
-  const uint32_t wpb = 8;
-  hipLaunchKernelGGL(k_filter_expand, dim3(cdiv(c->P, 256), std::max<uint32_t>(1, cdiv(W, wpb))), dim3(256), 0, st, pd, gr, nd, b, W, wpb,
-                     tally ? 1u : 0u, do_ready ? 1u : 0u, rearm ? 1u : 0u);
+  hipLaunchKernelGGL(k_filter_expand, dim3(cdiv(c->P, 256), std::max<uint32_t>(1, cdiv(W, kExpandWords))), dim3(256), 0, st, pd, gr, nd, b, W,
+                     c->filter_slots_cap, tally ? 1u : 0u, do_ready ? 1u : 0u, rearm ? 1u : 0u);
 }
 
 // Cap on the waves that share the live 64-row groups of one tile pair (k_scan picks the actual share
@@ -768,6 +769,7 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   HIPCHK(c, c->d_nepochs.reserve(16));
   c->G = G;
   c->n_uncaptured = 0;
+  c->n_nominres = 0;
   if (G) {
     HIPCHK(c, hipMemcpyAsync(c->d_gmm.p, g->min_member, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_gsc.p, g->status_scheduled, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
@@ -777,8 +779,10 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
     HIPCHK(c, hipMemcpyAsync(c->d_gminres.p, g->min_resources, (size_t)G * L * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_gmrpres.p, g->min_resources_present, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_gocc.p, g->occupied_by, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
-    for (uint32_t i = 0; i < G; ++i)
+    for (uint32_t i = 0; i < G; ++i) {
       if (!(g->flags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+      if (!(g->flags[i] & BS_GROUP_HAS_MINRES)) c->n_nominres++;
+    }
     c->h_gmatched.assign(g->matched, g->matched + G);
     c->h_gcls.assign(g->cls, g->cls + G);
     c->h_gflags.assign(g->flags, g->flags + G);
@@ -851,26 +855,19 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, c->d_stage.reserve(n));
   HIPCHK(c, c->d_leader_raw.reserve(n * 4));
   HIPCHK(c, c->d_qtable.reserve(n * 4));
-  HIPCHK(c, c->d_first_row.reserve(n * 4));
-  HIPCHK(c, c->d_qreq_s.reserve(n * c->LP * 8));
-  HIPCHK(c, c->d_qflags_s.reserve(n * 4));
   HIPCHK(c, c->d_qpos.reserve(n * 4));
   HIPCHK(c, c->d_qlist.reserve(n * 4));
   HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
   HIPCHK(c, c->d_fflags.reserve(n * 4));
-  HIPCHK(c, c->d_fu_rep.reserve(n * 4));
-  HIPCHK(c, c->d_qkey.reserve(n * c->LP * 8));
-  HIPCHK(c, c->d_qkflags.reserve(n * 4));
-  HIPCHK(c, c->d_qrep.reserve(n * 4));
-  HIPCHK(c, c->d_fu_id.reserve(n * 4));
-  HIPCHK(c, c->d_fu_list.reserve(n * 4));
-  HIPCHK(c, c->d_fu_feas.reserve(n * 4));
+  HIPCHK(c, c->d_fu_slot.reserve(n * 4));
+  HIPCHK(c, c->d_pclass.reserve(n * 4));
+  HIPCHK(c, c->d_cls_rep.reserve(n * 4));
+  HIPCHK(c, c->d_cls_id.reserve(n * 4));
   {
     uint32_t cap = 1024;
     while (cap < 2 * n) cap <<= 1;
-    HIPCHK(c, c->d_fu_slots.reserve((size_t)cap * 8));
-    HIPCHK(c, c->d_qu_slots.reserve((size_t)cap * 8));
-    c->fu_cap = cap;
+    HIPCHK(c, c->d_cls_slots.reserve((size_t)cap * 8));
+    c->cls_cap = cap;
   }
   HIPCHK(c, c->d_blk_scratch.reserve((n / 256 + 2) * 4));
   c->P = P;
@@ -883,6 +880,17 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
     std::memcpy(st + c->off_powner, pods->owner, (size_t)P * 8);
     std::memcpy(st + c->off_pflags, pods->flags, (size_t)P);
     HIPCHK(c, hipMemcpyAsync(c->d_podpack.p, st, c->podpack_bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  // request classes of the pods (slots of the per-batch de-duplication, see BatchDev)
+  HIPCHK(c, hipMemsetAsync(c->d_nepochs.as<uint32_t>() + 2, 0, 4, c->stream));
+  if (P) {
+    HIPCHK(c, hipMemsetAsync(c->d_cls_slots.p, 0, (size_t)c->cls_cap * 8, c->stream));
+    const PodsDev pd = pods_dev(c);
+    hipLaunchKernelGGL(k_pod_class_a, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, c->d_cls_slots.as<unsigned long long>(), c->cls_cap - 1,
+                       c->hash_keep, L, c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(), c->d_nepochs.as<uint32_t>() + 2);
+    hipLaunchKernelGGL(k_pod_class_b, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, P, c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(),
+                       c->d_pclass.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_pods = true;
@@ -936,11 +944,20 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const uint32_t P = c->P, G = c->G, N = c->N, C = c->C;
   const uint32_t W = cdiv(N, 64);
   const bool run_filter = stages & BS_STAGE_FILTER;
+  // request slots: scan = classes + groups (or one per pod), Filter = 2 x classes (or one per pod)
+  const uint32_t scan_cap = P + G + 64, filter_cap = 2 * P + 64;
+  HIPCHK(c, c->d_first_row.reserve((size_t)scan_cap * 4));
+  HIPCHK(c, c->d_qreq_s.reserve((size_t)scan_cap * c->LP * 8));
+  HIPCHK(c, c->d_qflags_s.reserve((size_t)scan_cap * 4));
+  HIPCHK(c, c->d_qtab_s.reserve((size_t)scan_cap * 4));
   if (run_filter) {
     HIPCHK(c, c->d_fl_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
-    HIPCHK(c, c->d_fu_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
+    HIPCHK(c, c->d_fu_bitmap.reserve(std::max<size_t>(8, (size_t)W * filter_cap * 8)));
+    HIPCHK(c, c->d_uparams.reserve((size_t)filter_cap * 64));
+    HIPCHK(c, c->d_uflags.reserve((size_t)filter_cap * 4));
+    HIPCHK(c, c->d_fu_feas.reserve((size_t)filter_cap * 4));
   }
-  HIPCHK(c, c->d_tiles.reserve((size_t)(P + 2) * sizeof(Tile)));     // worst case: one tile per query
+  c->filter_slots_cap = filter_cap;
 
   NodesDev nd = nodes_dev(c);
   GroupsDev gr = groups_dev(c);
@@ -957,6 +974,12 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
 
   const dim3 blk(256);
   const bool captures_possible = c->n_uncaptured > 0 && P > 0;
+  // request classes stand for the pods when nothing a pod derives can depend on its queue position:
+  // no first-pod capture and no MinResources default (core.go:486-493) left to happen
+  const bool use_classes = !captures_possible && c->n_nominres == 0;
+  prm.use_classes = use_classes ? 1u : 0u;
+  prm.scan_slots_cap = scan_cap;
+  prm.filter_slots_cap = filter_cap;
   const int ts = c->S <= 4 ? (int)c->S : -1;
   bool commit_dirty = false;
   // No capture possible and the leader has matched pods: every scan query of the batch uses ONE known
@@ -1035,7 +1058,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<4>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
       default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<-1>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
     }
-    TIMED_ON(c, BS_KERNEL_FILTER, c->stream3, launch_filter(c, c->stream3, pd, gr, nd, b, false, false, false));
+    TIMED_ON(c, BS_KERNEL_FILTER, c->stream3, launch_filter(c, c->stream3, pd, gr, nd, b, use_classes, false, false, false));
     HIPCHK(c, hipEventRecord(c->ev_filter, c->stream3));
   }
   // ---- running-sum tables of the (class, percent) pairs some query uses
@@ -1050,7 +1073,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       });
     }
     const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
-    TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg));
+    TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg, P, G, side_tables ? 1u : std::min<uint32_t>(16, 2 * C)));
     HIPCHK(c, hipEventRecord(c->ev_scan_done, c->stream));   // the tables may be rebuilt (next batch) from here on
   }
   // ---- REJECT codes, deny replay, stale-leader propagation, Filter parameters
@@ -1069,7 +1092,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     }
   });
   if (run_filter && P && !early_filter) {
-    TIMED(c, BS_KERNEL_FILTER, launch_filter(c, c->stream, pd, gr, nd, b, fuse_tally, local_ready, rearm));
+    TIMED(c, BS_KERNEL_FILTER, launch_filter(c, c->stream, pd, gr, nd, b, use_classes, fuse_tally, local_ready, rearm));
   } else if (early_filter) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_filter, 0));
     const uint32_t wpb = 8;
@@ -1092,7 +1115,11 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       HIPCHK(c, hipMemcpy(c->h_gcls.data(), c->d_gcls.p, (size_t)G * 4, hipMemcpyDeviceToHost));
     }
     c->n_uncaptured = 0;
-    for (uint32_t i = 0; i < G; ++i) if (!(c->h_gflags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+    c->n_nominres = 0;
+    for (uint32_t i = 0; i < G; ++i) {
+      if (!(c->h_gflags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+      if (!(c->h_gflags[i] & BS_GROUP_HAS_MINRES)) c->n_nominres++;
+    }
     commit_dirty = true;
   }
   c->last_stages = stages;
@@ -1246,11 +1273,10 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
   rc = build_scratch_table(c, cls, percent, &slot);
   if (rc) return rc;
   const uint32_t L = c->L, LP = c->LP, S = c->S, M = c->M;
-  // scratch layout (bytes): 0 ntables | 64 ntiles | 128 Tile | 192 qlist | 256 qflags | 320 first_row | 512 qreq[LP]
+  // scratch layout (bytes): 128 qtab | 256 qflags | 320 first_row | 512 qreq[LP]   (one request slot)
   uint8_t* sq = c->d_sq.as<uint8_t>();
-  struct { uint32_t ntiles; } h_nt{1};
-  Tile tl{slot, 0, 1, 0, {0, 0, 0, 0}};
-  uint32_t zero = 0, inf = BS_INF, qflags = 0;
+  const int32_t qtab = (int32_t)slot;
+  uint32_t inf = BS_INF, qflags = 0;
   int64_t q[BS_MAX_LANES];
   for (uint32_t j = 0; j < LP; ++j) q[j] = INT64_MIN;
   for (uint32_t j = 0; j < 4; ++j) q[j] = req[j];
@@ -1262,17 +1288,12 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
     q[4 + s] = pres ? req[4 + s] : INT64_MIN;
   }
   qflags = (req_present & 0xFFFu) | (absok << 16);
-  for (uint32_t j = 0; j < 4; ++j) tl.rmin[j] = q[j];
-  HIPCHK(c, hipMemcpyAsync(sq + 64, &h_nt, 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(sq + 128, &tl, sizeof(tl), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(sq + 192, &zero, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sq + 128, &qtab, 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(sq + 256, &qflags, 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(sq + 320, &inf, 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(sq + 512, q, (size_t)LP * 8, hipMemcpyHostToDevice, c->stream));
   BatchDev b = batch_dev(c);
-  b.ntiles = reinterpret_cast<uint32_t*>(sq + 64);
-  b.tiles = reinterpret_cast<Tile*>(sq + 128);
-  b.qlist = reinterpret_cast<uint32_t*>(sq + 192);
+  b.qtab_s = reinterpret_cast<int32_t*>(sq + 128);
   b.qflags_s = reinterpret_cast<uint32_t*>(sq + 256);
   b.first_row = reinterpret_cast<uint32_t*>(sq + 320);
   b.qreq_s = reinterpret_cast<int64_t*>(sq + 512);
@@ -1281,7 +1302,7 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
   prm.seg_len = 64;
   if (M) {
     const uint32_t nseg = std::min<uint32_t>(cdiv(M, 64), 64);      // waves sharing the live groups of the one query
-    launch_scan(c, dim3(cdiv(nseg, 4)), b, prm, M, nseg);
+    launch_scan(c, dim3(cdiv(nseg, 4)), b, prm, M, nseg, 1u, 0u, 1u);
     HIPCHK(c, hipGetLastError());
   }
   uint32_t row = BS_INF;
@@ -1346,9 +1367,6 @@ int bs_filter_one(bs_ctx* c, int32_t pod_group, const int64_t* pod_req, uint32_t
   HIPCHK(c, hipMemcpyAsync(base + 512, &pf, 1, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(base + 576, &leader, 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(base + 640, 0, 256, c->stream));
-  const uint32_t one32 = 1;
-  HIPCHK(c, hipMemcpyAsync(base + 964, &one32, 4, hipMemcpyHostToDevice, c->stream));   // one distinct request: pod 0
-  HIPCHK(c, hipMemsetAsync(base + 960, 0, 4, c->stream));
   PodsDev pd{};
   pd.p = 1;
   pd.group = reinterpret_cast<int32_t*>(base + 0);
@@ -1365,9 +1383,10 @@ int bs_filter_one(bs_ctx* c, int32_t pod_group, const int64_t* pod_req, uint32_t
   b.fl_feasible = reinterpret_cast<uint32_t*>(base + 768);
   b.fparams = reinterpret_cast<int64_t*>(base + 832);
   b.fl_bitmap = reinterpret_cast<uint64_t*>(base + 4096);
-  b.fu_list = reinterpret_cast<uint32_t*>(base + 960);
-  b.fu_count = reinterpret_cast<uint32_t*>(base + 964);
-  b.fu_bitmap = b.fl_bitmap;                       // one pod: its row is the distinct request's row
+  b.fu_slot = reinterpret_cast<uint32_t*>(base + 960);
+  b.uparams = b.fparams;                           // one pod, one slot: the slot arrays are the pod's
+  b.uflags = b.fflags;
+  b.fu_bitmap = b.fl_bitmap;
   b.fu_feas = b.fl_feasible;
   // first_elig must not redirect MinResources for a stand-alone query: use INF for every group
   DevBuf fe;
@@ -1379,7 +1398,7 @@ int bs_filter_one(bs_ctx* c, int32_t pod_group, const int64_t* pod_req, uint32_t
   NodesDev nd = nodes_dev(c);
   hipLaunchKernelGGL(k_filter_params, dim3(1), dim3(256), 0, c->stream, pd, gr, b, prm);
   const uint32_t W = cdiv(N, 64);
-  if (W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(1), dim3(64), 0, c->stream, pd, nd, b, 1u);
+  if (W) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(1), dim3(64), 0, c->stream, pd, nd, b, 1u, 0u, 1u, 0u);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(k_filter_one, dim3(1), dim3(64), 0, c->stream, nd, b, node, base + 768 + 16);
   HIPCHK(c, hipGetLastError());
@@ -1552,16 +1571,14 @@ int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {
   }
   out->scan_rows_executed = raw[0];
   out->scan_evals_executed = raw[1];
-  out->scan_queries = nq;
+  out->scan_queries = raw[4];
   out->scan_queries_logical = raw[2];
   out->tables_built = nt;
   out->logical_evals = (uint64_t)c->P * c->N;
   out->filter_evals = (c->last_stages & BS_STAGE_FILTER) ? (uint64_t)c->P * c->N : 0;
   if (c->last_stages & BS_STAGE_FILTER) {
-    uint32_t nu = 0;
-    HIPCHK(c, hipMemcpy(&nu, c->d_nepochs.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost));
-    out->filter_distinct = nu;
-    out->filter_evals_executed = (uint64_t)nu * c->N;
+    out->filter_distinct = raw[3];
+    out->filter_evals_executed = raw[3] * c->N;
   }
   c->collect_stats = 0;
   return BS_OK;
