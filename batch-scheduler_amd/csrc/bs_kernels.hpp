@@ -150,6 +150,7 @@ struct BatchParams {
   uint32_t run_filter;
   uint32_t early_filter;       // Filter parameters come from k_fparams_early (Filter overlaps the node scan)
   uint32_t hash_keep;          // hash bits kept in a class-builder slot (0x7FFFFFFF; fewer = forced collisions, tests)
+  uint32_t fuse_filter;        // class mode, no early Filter: k_query fills the Filter slots, k_scan_filter evaluates them
   uint32_t use_classes;        // slots are request classes (no capture / MinResources default possible in this batch)
   uint32_t scan_slots_cap, filter_slots_cap;   // entries to reset per batch
   uint32_t collect_stats;
@@ -608,6 +609,10 @@ __device__ __forceinline__ void pre_allocated(const GroupsDev& gr, uint32_t g, i
 }
 
 template <int TS>
+__device__ __forceinline__ void filter_params_for(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm,
+                                                  uint32_t i, uint8_t pf, int32_t leader, uint32_t slot, bool write_slot, bool write_pod);
+
+template <int TS>
 __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
   const Shape<TS> sh(prm.S);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -682,6 +687,15 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
     // first pod of the queue that reaches findMaxPG (lanes are in queue order)
     const unsigned long long rb = __ballot(valid && (st & ST_REACH6));
     if (rb && lane_id() == __ffsll((long long)rb) - 1) atomicMin(&b.nepochs[1], i);
+  }
+  // Filter slots (class mode): what Filter needs for a pod is its request class and the leader it sees —
+  // the batch's findMaxPG result or, for the pods before the first one that reaches findMaxPG, the leader
+  // carried into the batch.  Both are known here, so every pod that may pass fills both slots of its class
+  // (equal values from every writer) and Filter can be evaluated beside the node scan.
+  if (prm.fuse_filter && valid && (st & ST_OWNED) && BS_PF_IS_PASS(code)) {
+    const uint32_t c = b.pclass[i], K = *b.kclass;
+    filter_params_for<TS>(pods, gr, b, prm, i, code, b.leader_epoch[0], c, true, false);
+    filter_params_for<TS>(pods, gr, b, prm, i, code, prm.sop_leader0, c + K, true, false);
   }
   // The query goes into its request slot.  With request classes every pod of a slot derives the same
   // (table, request, flags), so they all store the same values and the scan sees each distinct query once.
@@ -1110,20 +1124,18 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 // table are scanned together (steady state: one table for everything); consecutive waves take different
 // tiles with the same share.  The grid is fixed; the slot count is read on the device.
 template <int S>
-__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t nslots_fixed, uint32_t ngroups_g,
-                                              uint32_t tsplit) {
+__device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t jcap, uint32_t nslots_fixed,
+                                          uint32_t ngroups_g, uint32_t tsplit, uint32_t bx, uint32_t nblocks, int64_t (*rows)[4 + S]) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
-  __shared__ int64_t s_rows[4][64][L];
-  int64_t (*rows)[L] = s_rows[wave_id()];
   const uint32_t nslots = prm.use_classes ? __builtin_amdgcn_readfirstlane(*b.kclass) + ngroups_g : nslots_fixed;
   const uint32_t ntiles = (nslots + 63u) >> 6;
   if (!ntiles || !m) return;
   // tsplit > 1 (several tables in use): the distinct tables of a tile are dealt over tsplit waves as well
-  const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (gridDim.x * 4u) / (ntiles * tsplit)));
+  const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (nblocks * 4u) / (ntiles * tsplit)));
   const uint32_t items = ntiles * tsplit * J;
   const int lane = lane_id();
-  for (uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id()); w < items; w += gridDim.x * 4u) {
+  for (uint32_t w = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()); w < items; w += nblocks * 4u) {
     const uint32_t rest = w / ntiles, tile = w - rest * ntiles;
     const uint32_t share = rest / tsplit, ts = rest - share * tsplit;
     const uint32_t pos = tile * 64u + (uint32_t)lane;
@@ -1152,6 +1164,12 @@ __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint3
     }
   }
 }
+template <int S>
+__global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t nslots_fixed, uint32_t ngroups_g,
+                                              uint32_t tsplit) {
+  __shared__ int64_t s_rows[4][64][4 + S];
+  scan_loop<S>(b, prm, m, jcap, nslots_fixed, ngroups_g, tsplit, blockIdx.x, gridDim.x, s_rows[wave_id()]);
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_reject / k_final_a / k_final_b
@@ -1170,7 +1188,7 @@ __global__ void k_reject(PodsDev pods, BatchDev b) {
 // Filter per-pod parameters (see the Filter section below); defined here because k_final fuses it.
 template <int TS>
 __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm,
-                                                  uint32_t i, uint8_t pf, int32_t leader, uint32_t slot) {
+                                                  uint32_t i, uint8_t pf, int32_t leader, uint32_t slot, bool write_slot, bool write_pod) {
   const Shape<TS> sh(prm.S);
   const uint32_t gate = prm.eph_gate;
   uint8_t fl = BS_FL_NOT_RUN;
@@ -1206,10 +1224,12 @@ __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const Gro
     }
   }
   const uint32_t ffw = ff | ((uint32_t)fl << 8);
-  b.fflags[i] = ffw;
-  b.fl_code[i] = fl;
-  b.fu_slot[i] = slot;
-  if (fl == BS_FL_EVALUATED) {
+  if (write_pod) {
+    b.fflags[i] = ffw;
+    b.fl_code[i] = fl;
+    b.fu_slot[i] = slot;
+  }
+  if (write_slot && fl == BS_FL_EVALUATED) {
     // every pod of the slot stores the same values (see BatchDev)
     int64_t* dst = b.uparams + (size_t)slot * 8;
 #pragma unroll
@@ -1286,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_final(PodsDev pods, GroupsDev gr, Nodes
     if (prm.run_filter && !prm.early_filter) {
       // Filter slot: the pod's request class, apart for the pods that still see the leader carried into the batch
       const uint32_t slot = prm.use_classes ? b.pclass[i] + (jp1 ? 0u : *b.kclass) : i;
-      filter_params_for<TS>(pods, gr, b, prm, i, code, leader, slot);
+      filter_params_for<TS>(pods, gr, b, prm, i, code, leader, slot, !prm.fuse_filter, true);
     }
   }
 }
@@ -1295,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_final(PodsDev pods, GroupsDev gr, Nodes
 __global__ void k_filter_params(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pods.p) return;
-  filter_params_for<-1>(pods, gr, b, prm, i, b.pf_code[i], b.pf_leader[i], i);
+  filter_params_for<-1>(pods, gr, b, prm, i, b.pf_code[i], b.pf_leader[i], i, true, true);
 }
 
 // Filter parameters BEFORE the node scan has run (no first-pod capture possible in this batch, so there
@@ -1316,7 +1336,7 @@ __global__ void k_fparams_early(PodsDev pods, GroupsDev gr, BatchDev b, BatchPar
   const bool after = i >= b.nepochs[1];
   const int32_t leader = after ? b.leader_epoch[0] : prm.sop_leader0;
   const uint32_t slot = prm.use_classes ? b.pclass[i] + (after ? 0u : *b.kclass) : i;
-  filter_params_for<TS>(pods, gr, b, prm, i, pf, leader, slot);
+  filter_params_for<TS>(pods, gr, b, prm, i, pf, leader, slot, true, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1603,8 +1623,8 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
 // device, so the grid is fixed and every wave derives the split itself: as many node runs as it takes to
 // give the whole grid something to do.  ustride = row stride of fu_bitmap (slot capacity).
 template <int NB>
-__global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, BatchDev b, uint32_t target_waves, uint32_t use_classes,
-                                                uint32_t ustride, uint32_t collect_stats) {
+__device__ __forceinline__ void filter_loop(const PodsDev& pods, const NodesDev& nd, const BatchDev& b, uint32_t target_waves, uint32_t use_classes,
+                                            uint32_t ustride, uint32_t collect_stats, uint32_t bx, uint32_t nblocks) {
   const uint32_t U = use_classes ? 2u * __builtin_amdgcn_readfirstlane(*b.kclass) : pods.p;
   const uint32_t W = (nd.n + 63u) / 64u;
   if (!U || !W) return;
@@ -1614,7 +1634,7 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
   const uint32_t bpw = max(2u, (((W + nsplit - 1u) / nsplit + 1u) / 2u) * 2u);     // multiple of NB
   const uint32_t nchunk = (W + bpw - 1u) / bpw;
   const uint32_t items = tiles * nchunk;
-  for (uint32_t it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (uint32_t)wave_id()); it < items; it += gridDim.x * 4u) {
+  for (uint32_t it = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()); it < items; it += nblocks * 4u) {
     const uint32_t chunk = it / tiles, tile = it - chunk * tiles;                   // neighbours share the node run
     if (collect_stats && chunk == 0) {
       const uint32_t sl = tile * 64u + (uint32_t)lane_id();
@@ -1623,6 +1643,25 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
     }
     filter_item<NB>(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw));
   }
+}
+template <int NB>
+__global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, BatchDev b, uint32_t target_waves, uint32_t use_classes,
+                                                uint32_t ustride, uint32_t collect_stats) {
+  filter_loop<NB>(pods, nd, b, target_waves, use_classes, ustride, collect_stats, blockIdx.x, gridDim.x);
+}
+
+// Node scan and Filter evaluation in ONE launch (class mode): both only need what k_query left behind and
+// are independent of each other, so the first `scan_blocks` blocks run the scan work loop and the rest the
+// Filter work loop — one launch boundary less on the critical path, and the two latency chains overlap.
+template <int S>
+__global__ __launch_bounds__(256) void k_scan_filter(PodsDev pods, NodesDev nd, BatchDev b, BatchParams prm, uint32_t m, uint32_t jcap,
+                                                     uint32_t nslots_fixed, uint32_t ngroups_g, uint32_t tsplit, uint32_t scan_blocks,
+                                                     uint32_t filter_waves, uint32_t ustride) {
+  __shared__ int64_t s_rows[4][64][4 + S];
+  if (blockIdx.x < scan_blocks)
+    scan_loop<S>(b, prm, m, jcap, nslots_fixed, ngroups_g, tsplit, blockIdx.x, scan_blocks, s_rows[wave_id()]);
+  else
+    filter_loop<2>(pods, nd, b, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - scan_blocks, gridDim.x - scan_blocks);
 }
 
 // Early Filter ran on the tentative PreFilter verdict.  The framework never calls Filter for a pod that

@@ -113,7 +113,7 @@ struct bs_ctx {
   int32_t sop_leader0 = -1;
   uint32_t last_stages = 0, batch_seq = 0;
   bool batch_pending_finish = false;
-  uint32_t scan_share_override = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
+  uint32_t scan_share_override = 0, no_fuse_filter = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   bs_batch_stats stats{};
 
   // ---- timing
@@ -427,13 +427,38 @@ void launch_tables_local(bs_ctx* c, hipStream_t st, dim3 grid, const NodesDev& n
   }
 }
 
+template <int S>
+void launch_scan_filter_s(bs_ctx* c, uint32_t scan_blocks, uint32_t filter_blocks, const PodsDev& pd, const NodesDev& nd, const BatchDev& b,
+                          const BatchParams& p, uint32_t m, uint32_t jcap, uint32_t nslots, uint32_t ng, uint32_t ts) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_filter<S>), dim3(scan_blocks + filter_blocks), dim3(256), 0, c->stream, pd, nd, b, p, m, jcap, nslots, ng,
+                     ts, scan_blocks, c->filter_waves, c->filter_slots_cap);
+}
+void launch_scan_filter(bs_ctx* c, uint32_t scan_blocks, uint32_t filter_blocks, const PodsDev& pd, const NodesDev& nd, const BatchDev& b,
+                        const BatchParams& p, uint32_t m, uint32_t jcap, uint32_t nslots, uint32_t ng, uint32_t ts) {
+  switch (c->S) {
+    case 0: launch_scan_filter_s<0>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 1: launch_scan_filter_s<1>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 2: launch_scan_filter_s<2>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 3: launch_scan_filter_s<3>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 4: launch_scan_filter_s<4>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 5: launch_scan_filter_s<5>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 6: launch_scan_filter_s<6>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 7: launch_scan_filter_s<7>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 8: launch_scan_filter_s<8>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 9: launch_scan_filter_s<9>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 10: launch_scan_filter_s<10>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 11: launch_scan_filter_s<11>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    default: launch_scan_filter_s<12>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+  }
+}
+
 // Filter: the distinct requests against every node (fixed grid, the kernel splits the work itself), then
 // every pod's row from its representative's.  tally: the expand kernel also does k_tally's job.
 void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, bool use_classes,
-                   bool tally, bool do_ready, bool rearm) {
+                   bool tally, bool do_ready, bool rearm, bool slots_done) {
   const uint32_t W = cdiv(c->N, 64), ptiles = cdiv(c->P, 64);
   if (!ptiles) return;
-  if (W) {
+  if (W && !slots_done) {
     const uint32_t waves = std::min<uint32_t>(c->filter_waves, 2 * ptiles * std::max<uint32_t>(1, cdiv(W, 2)));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(waves, 4)), dim3(256), 0, st, pd, nd, b, c->filter_waves, use_classes ? 1u : 0u,
                        c->filter_slots_cap, c->collect_stats);
@@ -552,6 +577,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     delete c;
     return BS_ERR_NO_DEVICE;
   }
+  if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) c->early_filter_min = std::strtoull(e, nullptr, 10);
   if (const char* e = std::getenv("BS_SCAN_SHARE")) c->scan_share_override = (uint32_t)std::max(0, std::atoi(e));
@@ -998,6 +1024,9 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   // re-arming is only valid when the group minima were not also needed for capture epochs (cap_epoch is rewritten then)
   const bool rearm = !captures_possible && !(stages & BS_BATCH_COMMIT);
   const bool fuse_tally = run_filter && P && !early_filter && (stages & BS_STAGE_TALLY) && !(stages & BS_BATCH_COMMIT);
+  // class mode without early Filter: k_query fills the Filter slots and ONE launch does node scan + Filter evaluation
+  const bool fuse_filter = run_filter && use_classes && !early_filter && P && N && !c->no_fuse_filter;
+  prm.fuse_filter = fuse_filter ? 1u : 0u;
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
   if (side_tables) {
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_scan_done, 0));      // the previous batch's scan is done with the tables
@@ -1058,7 +1087,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<4>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
       default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<-1>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
     }
-    TIMED_ON(c, BS_KERNEL_FILTER, c->stream3, launch_filter(c, c->stream3, pd, gr, nd, b, use_classes, false, false, false));
+    TIMED_ON(c, BS_KERNEL_FILTER, c->stream3, launch_filter(c, c->stream3, pd, gr, nd, b, use_classes, false, false, false, false));
     HIPCHK(c, hipEventRecord(c->ev_filter, c->stream3));
   }
   // ---- running-sum tables of the (class, percent) pairs some query uses
@@ -1073,8 +1102,18 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       });
     }
     const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
-    TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg, P, G, side_tables ? 1u : std::min<uint32_t>(16, 2 * C)));
+    const uint32_t tsplit = side_tables ? 1u : std::min<uint32_t>(16, 2 * C);
+    if (fuse_filter) {
+      const uint32_t fblocks = cdiv(std::min<uint32_t>(c->filter_waves, 2 * cdiv(P, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4);
+      TIMED(c, BS_KERNEL_SCAN, launch_scan_filter(c, scan_blocks, fblocks, pd, nd, b, prm, c->M, nseg, P, G, tsplit));
+    } else {
+      TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg, P, G, tsplit));
+    }
     HIPCHK(c, hipEventRecord(c->ev_scan_done, c->stream));   // the tables may be rebuilt (next batch) from here on
+  } else if (fuse_filter) {
+    // no schedulable node: nothing to scan, Filter still has its slots to evaluate
+    const uint32_t fblocks = cdiv(std::min<uint32_t>(c->filter_waves, 2 * cdiv(P, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4);
+    TIMED(c, BS_KERNEL_SCAN, launch_scan_filter(c, 1u, fblocks, pd, nd, b, prm, 0u, 1u, P, G, 1u));
   }
   // ---- REJECT codes, deny replay, stale-leader propagation, Filter parameters
   TIMED(c, BS_KERNEL_RESOLVE, {
@@ -1092,7 +1131,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     }
   });
   if (run_filter && P && !early_filter) {
-    TIMED(c, BS_KERNEL_FILTER, launch_filter(c, c->stream, pd, gr, nd, b, use_classes, fuse_tally, local_ready, rearm));
+    TIMED(c, BS_KERNEL_FILTER, launch_filter(c, c->stream, pd, gr, nd, b, use_classes, fuse_tally, local_ready, rearm, fuse_filter));
   } else if (early_filter) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_filter, 0));
     const uint32_t wpb = 8;

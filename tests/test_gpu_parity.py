@@ -521,3 +521,24 @@ def test_dedupe_all_requests_distinct(bsa, soa, orc):
         st = ctx.stats(soa.STAGE_ALL)
         evaluated = int((exp.fl_code == soa.FL_EVALUATED).sum())
         assert st["filter_distinct"] == evaluated
+
+
+@pytest.mark.parametrize("scenario", ["warm", "tail"])
+def test_class_mode_without_fused_scan_filter(scenario, monkeypatch, bsa, soa, orc):
+    """Class mode normally evaluates the Filter slots inside the scan launch (k_scan_filter); the separate
+    k_filter path (used with early Filter and when slot = pod) must agree."""
+    monkeypatch.setenv("BS_NO_FUSE_FILTER", "1")
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", scenario)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, scenario)
+
+
+def test_no_schedulable_node_still_filters(bsa, soa, orc):
+    """M = 0 (every node unschedulable): nothing to scan, every reserve check fails, Filter still runs for
+    the pods that pass without a scan."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "warm")
+    nodes.flags[:] = soa.NODE_UNSCHEDULABLE
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp)
