@@ -1,25 +1,31 @@
 // bs_kernels.hpp — gfx950 kernels of the batched PreFilter / Filter / Permit path.
 //
-// Pipeline of one batch (bs_batch_run); steady state = 8 launches on the main stream, the table build
+// Pipeline of one batch (bs_batch_run); steady state = 6 launches on the main stream, the table build
 // overlapped on a side stream:
 //   k_prepass   per-batch resets; per pod: eligibility (core.go:89-110), first eligible pod / first owner
 //               per group; LAST block: findMaxPG (core.go:701-739) when no first-pod capture can occur
 //   [k_init, k_epochs_a/b, k_leader   only when groups without a pod exist: capture epochs, one
 //               findMaxPG per epoch]
 //   k_query     per pod: fillOccupiedObj check, branch A/B/C/D of core.go:127-166, request vector
-//               (getPreAllocatedResource core.go:774-793 [+ pod request :157-159]); the lanes of a wave
-//               that query the same table become one scan tile (no sort pass)
+//               (getPreAllocatedResource core.go:774-793 [+ pod request :157-159]) into its request SLOT;
+//               class mode: also the Filter parameters of the pod's class into the Filter slots
 //   k_tables_local/fix   singleNodeResource (core.go:634-670) + running sums of core.go:602,621 per
 //               table, per-group maxima for pruning           [side stream in steady state]
-//   k_scan      THE hot kernel: exists k : prefix_k >= request (core.go:623), first such k
+//   k_scan_filter   node scan "exists k : prefix_k >= request" (core.go:623), first such k, per scan slot,
+//               and computeResourceSatisfied (core.go:514-564) per Filter slot x node, in one launch
+//               [k_scan, k_filter: the same two work loops as separate launches when slot = pod or
+//               with early Filter]
 //   k_reject/k_final   REJECT codes, deny-cache replay in queue order (core.go:105-110,142,163),
-//               stale sop.maxFinishedPG propagation, first_k -> node list index, Filter parameters
-//   k_filter    computeResourceSatisfied (core.go:514-564) pods x nodes bitmap + feasible counts
-//   k_tally     per-group admit counts; last block: quorum predicate core.go:303, re-arm for next batch
+//               stale sop.maxFinishedPG propagation, first_k -> node list index, Filter code + slot per pod
+//   k_filter_expand   every pod's bitmap row + feasible count from its slot's; per-group admit counts;
+//               last block: quorum predicate core.go:303, re-arm for the next batch   [k_tally when split]
 //
-// No MFMA anywhere: this is int64 compare/add work (north_star).  Lanes of a wave are pods
-// (queries); node rows are wave-uniform and arrive through the scalar cache, so one 64-bit
-// v_cmp per resource lane decides 64 pod x node pairs.
+// Request slots: pods of a gang share a template, so derived requests repeat; bs_pods_load builds request
+// classes (k_pod_class_a/b) and the batch evaluates each distinct request once (see BatchDev).
+//
+// No MFMA anywhere: this is int64 compare/add work (north_star).  Scan: lanes of a wave are request slots,
+// node rows are wave-uniform (LDS broadcast), so one 64-bit v_cmp per resource lane decides 64 slot x node
+// pairs.  Filter: lanes are nodes while comparing, slots' requests are broadcast from LDS.
 #pragma once
 
 #include "bs_common.hpp"
@@ -64,10 +70,6 @@ struct PodsDev {
 };
 
 struct TableDesc { uint32_t cls; float pct; };
-struct Tile {
-  uint32_t slot, q0, count, pad;
-  int64_t rmin[4];          // per fixed lane: smallest request of the tile (segment pruning)
-};
 
 // per-pod stage bits (scratch)
 constexpr uint8_t ST_ELIG = 1;      // passed core.go:89-110 against the batch-start deny flags
@@ -91,7 +93,6 @@ struct BatchDev {
   uint8_t* tcode;           // tentative PreFilter code
   uint8_t* stage;
   int32_t* leader_raw;      // leader findMaxPG returned for this pod (valid iff ST_REACH6)
-  int32_t* qtable;          // scan table id (class + C * (pct==0.7)), -1 none
   uint32_t* first_row;      // [scan slots] min table row satisfying the slot's request (INF none)
   int64_t* qreq_s;          // [scan slots][LP] effective request (absent scalar -> INT64_MIN)
   uint32_t* qflags_s;       // [scan slots] bits 0..11 request key present, bits 16..27 "zero/absent" (passes w/o left key)
@@ -102,9 +103,6 @@ struct BatchDev {
   uint32_t* ticket;         // [4] last-block tickets
   TableDesc* desc;          // [slots]
   uint32_t* ntables;        // [1]
-  Tile* tiles;
-  uint32_t* ntiles;         // [1]
-  uint32_t* qlist;          // [P] pod indices grouped by table
   int64_t* tables;          // [slots][mcap][LP] running sums, row-major (one s_load per row)
   uint32_t* kp;             // [slots][16] first row at which scalar key s exists in the running sum
   uint64_t* stats;          // [8] counters (only touched when collect_stats)
@@ -155,8 +153,6 @@ struct BatchParams {
   uint32_t scan_slots_cap, filter_slots_cap;   // entries to reset per batch
   uint32_t collect_stats;
   uint32_t mcap;               // table row capacity
-  uint32_t seg_len;            // unused (k_scan deals 64-row groups)
-  uint32_t tile_queries;       // queries per scan tile (64 x Q)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -326,7 +322,6 @@ __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsD
   if (i < gr.g) b.admit[i] = 0;
   if (i < 2 * prm.C + 1) b.needed[i] = 0;
   if (i == 0) {
-    *b.ntiles = 0;
     *b.qcount = 0;
     if (no_capture) *b.nepochs = 1;
     b.nepochs[1] = BS_INF;
@@ -879,9 +874,9 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev 
 // k_scan — the dominant kernel: "exists k : running_sum_k >= request" (core.go:602-631) for every
 // query, and the first such k (the reference's early exit, core.go:623-627).
 //
-// Geometry.  One wave = one tile of up to 64*Q queries (pods) that share a table x one segment of
-// table rows.  Lane l holds the request lanes of Q queries in VGPRs.  Rows are wave-uniform: a row
-// (LP int64) arrives through the scalar cache with one s_load and is shared by all 64*Q queries.
+// Geometry.  One wave = one tile of 64 request slots x its share of the live 64-row groups of the
+// table.  Lane l holds the request lanes of its slot in VGPRs.  Rows are wave-uniform: a group's 64 rows
+// are fetched with one vector load per lane into the wave's LDS slice and broadcast back row by row.
 //
 // Inner step (one row x 64 queries), hand-written because the compiler's form costs ~20 SALU
 // instructions per row (mask ANDs, selects, branches) around 5 compares:
@@ -889,10 +884,9 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev 
 //     v_cmpx_ge_i64 vcc, row[0], r0   ; EXEC narrows: each compare only keeps lanes that also
 //     ...                             ; satisfied the previous ones  (compareResourceAndRequire,
 //     v_cmpx_ge_i64 vcc, row[L-1], r  ;  core.go:672-699, is an AND over lanes)
-//     v_mov_b32   myk, k              ; surviving lanes record k — their FIRST satisfying row
-//     s_andn2_b64 nf, nf, exec        ; ... and stop looking
+//     v_min_u32   myk, k, myk         ; surviving lanes record k — rows ascend, so the first one sticks
 //     s_mov_b64   exec, -1
-// = 3 SALU + (L+1) VALU per 64 pod x node evaluations, no branch.  v_cmpx on a lane outside EXEC
+// = 2 SALU + (L+1) VALU per 64 slot x node evaluations, no branch.  v_cmpx on a lane outside EXEC
 // yields 0, so the chain is the AND; one v_cmp_*_i64 decides 64 pairs.
 //
 // Scalar keys (core.go:686-697).  Before row kp[s] the running sum has no key s: a lane passes iff
@@ -901,9 +895,7 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev 
 // same branch-free loop with the lanes that cannot pass masked out of EXEC (their padded request
 // INT64_MIN / 0 makes the absent-key compare trivially true for the others).
 //
-// Rows are double-buffered in SGPRs: the s_loads of the next U rows are in flight while the current U
-// rows are compared.  Table and request pointers are address-space-4 (constant) so that the loads
-// are scalar by construction.  Segments of one tile combine through atomicMin on first_row.
+// Shares of one tile combine through atomicMin on first_row.
 // ------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) int64_t* crow_t;
 __device__ __forceinline__ crow_t as_const_rows(const int64_t* p) { return (crow_t)(uintptr_t)p; }

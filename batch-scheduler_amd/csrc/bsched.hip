@@ -94,8 +94,8 @@ struct bs_ctx {
   // ---- batch scratch / outputs
   DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
   DevBuf d_epoch, d_nepochs, d_leader_epoch, d_panic_epoch;
-  DevBuf d_tcode, d_stage, d_leader_raw, d_qtable, d_first_row, d_qreq_s, d_qflags_s, d_qpos;
-  DevBuf d_needed, d_qcount, d_ticket, d_desc, d_tiles, d_ntiles, d_qlist;
+  DevBuf d_tcode, d_stage, d_leader_raw, d_first_row, d_qreq_s, d_qflags_s, d_qpos;
+  DevBuf d_needed, d_qcount, d_ticket, d_desc;
   bool scratch_armed = false;
   bool side_ready = false;      // desc[] / kp[] of the side-stream table are in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
@@ -249,7 +249,6 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.tcode = c->d_tcode.as<uint8_t>();
   b.stage = c->d_stage.as<uint8_t>();
   b.leader_raw = c->d_leader_raw.as<int32_t>();
-  b.qtable = c->d_qtable.as<int32_t>();
   b.first_row = c->d_first_row.as<uint32_t>();
   b.qreq_s = c->d_qreq_s.as<int64_t>();
   b.qflags_s = c->d_qflags_s.as<uint32_t>();
@@ -258,9 +257,6 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.qcount = c->d_qcount.as<uint32_t>();
   b.ticket = c->d_ticket.as<uint32_t>();
   b.desc = c->d_desc.as<TableDesc>();
-  b.tiles = c->d_tiles.as<Tile>();
-  b.ntiles = c->d_ntiles.as<uint32_t>();
-  b.qlist = c->d_qlist.as<uint32_t>();
   b.tables = c->d_tables.as<int64_t>();
   b.kp = c->d_kp.as<uint32_t>();
   b.stats = c->d_stats.as<uint64_t>();
@@ -304,8 +300,6 @@ BatchParams batch_params(const bs_ctx* c) {
   p.filter_slots_cap = 0;
   p.collect_stats = c->collect_stats;
   p.mcap = c->table_mcap;
-  p.seg_len = 0;
-  p.tile_queries = 64;
   return p;
 }
 
@@ -327,7 +321,6 @@ int ensure_tables(bs_ctx* c) {
     HIPCHK(c, c->d_ticket.reserve(16));
     HIPCHK(c, hipMemset(c->d_ticket.p, 0, 16));
   }
-  HIPCHK(c, c->d_ntiles.reserve(16));
   HIPCHK(c, c->d_stats.reserve(8 * sizeof(uint64_t)));
   HIPCHK(c, c->d_sq.reserve(4096));
   c->table_slots = slots;
@@ -880,9 +873,7 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, c->d_tcode.reserve(n));
   HIPCHK(c, c->d_stage.reserve(n));
   HIPCHK(c, c->d_leader_raw.reserve(n * 4));
-  HIPCHK(c, c->d_qtable.reserve(n * 4));
   HIPCHK(c, c->d_qpos.reserve(n * 4));
-  HIPCHK(c, c->d_qlist.reserve(n * 4));
   HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
   HIPCHK(c, c->d_fflags.reserve(n * 4));
   HIPCHK(c, c->d_fu_slot.reserve(n * 4));
@@ -993,8 +984,6 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   prm.run_filter = run_filter;
   const uint32_t tiles_est = cdiv(std::max<uint32_t>(P, 1), 64);
   const uint32_t pairs_est = cdiv(tiles_est, 2);
-  prm.tile_queries = 64;
-  prm.seg_len = 64;
   // J waves share the live 64-row groups of one tile pair (k_scan deals them round-robin)
   const uint32_t nseg = pick_scan_share(c);
 
@@ -1338,7 +1327,6 @@ int bs_cluster_fits(bs_ctx* c, uint32_t cls, float percent, const int64_t* req, 
   b.qreq_s = reinterpret_cast<int64_t*>(sq + 512);
   BatchParams prm = batch_params(c);
   prm.collect_stats = 0;
-  prm.seg_len = 64;
   if (M) {
     const uint32_t nseg = std::min<uint32_t>(cdiv(M, 64), 64);      // waves sharing the live groups of the one query
     launch_scan(c, dim3(cdiv(nseg, 4)), b, prm, M, nseg, 1u, 0u, 1u);
