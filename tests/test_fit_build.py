@@ -229,3 +229,17 @@ def test_gpu_fit_build_errors():
     assert ctx._lib.bs_fit_build(ctx._h, C.byref(st_n), C.byref(st_t)) == -1      # BS_ERR_INVALID
     fresh = capi.Context(scalar_lanes=1)
     assert fresh._lib.bs_fit_build(fresh._h, C.byref(st_n), C.byref(st_t)) == -4  # BS_ERR_STATE
+
+
+def test_oracle_fit_throughput_is_reported(capsys):
+    """Times the C oracle's checkFit loop (the CPU figure quoted beside bs_fit_build in BASELINE.md)."""
+    import time
+    nodes, templates = synth.make_fit_scene(20260921, 2000, 100)
+    nl, ft = fitspec.marshal(nodes, templates)
+    flags = np.zeros(2000, np.uint8)
+    t0 = time.perf_counter()
+    bits = orc.fit_build(nl, flags, ft)
+    dt = time.perf_counter() - t0
+    assert bits.shape == (100, 63)
+    with capsys.disabled():
+        print(f"\n[oracle checkFit] {2000 * 100 / dt:.3e} pairs/s on one core")

@@ -135,3 +135,13 @@ def test_two_rank_gloo_allreduce_of_admit_counters(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert res.stdout.count("ok") == 2
+
+
+def test_tools_and_product_do_not_touch_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    for d in ("tools", "batch-scheduler_amd"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".hip", ".hpp", ".cpp", ".h")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "import orc" not in text and "libbs_oracle" not in text and "naive_" not in text, os.path.join(dirpath, f)

@@ -1,5 +1,6 @@
-"""Times bs_fit_build (checkFit for every (class, node), core.go:741-759) against the C oracle on
-the same seeded scene.  Usage: python tools/fit_bench.py [nodes classes]...   (GPU box)"""
+"""Times bs_fit_build (checkFit for every (class, node), core.go:741-759) on a seeded scene.  Parity with
+the oracle is asserted in tests/test_fit_build.py (which also times the oracle); nothing under oracle/ is
+used here.  Usage: python tools/fit_bench.py [nodes classes]...   (GPU box)"""
 import importlib
 import json
 import os
@@ -7,12 +8,9 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
-import numpy as np
-
-import orc
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import numpy as np  # noqa: F401
 
 capi = importlib.import_module("batch-scheduler_amd.capi")
 synth = importlib.import_module("batch-scheduler_amd.synth")
@@ -33,14 +31,10 @@ def run(n, c, seed=20260921):
     for _ in range(reps):
         ctx.build_fit(nl, ft)
     t_gpu = (time.perf_counter() - t0) / reps
-    t0 = time.perf_counter()
-    exp = orc.fit_build(nl, nodes.flags, ft)
-    t_cpu = time.perf_counter() - t0
-    ok = bool(np.array_equal(ctx.read_fit().bits, exp))
+    fits = int(ctx.read_fit().to_bool().sum())
     return {"nodes": n, "classes": c, "pairs": n * c, "labels": int(nl.label_off[-1]), "exprs": int(len(ft.exprs.key)),
             "bs_fit_build_ms": round(t_gpu * 1e3, 3), "pairs_per_s": round(n * c / t_gpu),
-            "oracle_1core_ms": round(t_cpu * 1e3, 3), "oracle_pairs_per_s": round(n * c / t_cpu),
-            "marshal_python_ms": round(t_marshal * 1e3, 1), "bit_exact": ok,
+            "marshal_python_ms": round(t_marshal * 1e3, 1), "pairs_that_fit": fits,
             "note": "bs_fit_build time is host-observed: packing + one H2D + two kernels + mask D2H + table rebuild"}
 
 
