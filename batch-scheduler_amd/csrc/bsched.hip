@@ -113,7 +113,7 @@ struct bs_ctx {
   int32_t sop_leader0 = -1;
   uint32_t last_stages = 0, batch_seq = 0;
   bool batch_pending_finish = false;
-  uint32_t scan_share_override = 0, no_fuse_filter = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
+  uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   bs_batch_stats stats{};
 
   // ---- timing
@@ -572,7 +572,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   }
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
-  if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) c->early_filter_min = std::strtoull(e, nullptr, 10);
+  if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) { c->early_filter_min = std::strtoull(e, nullptr, 10); c->early_forced = 1; }
   if (const char* e = std::getenv("BS_SCAN_SHARE")) c->scan_share_override = (uint32_t)std::max(0, std::atoi(e));
   if (const char* e = std::getenv("BS_TARGET_WAVES")) c->target_waves = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_FILTER_WAVES")) c->filter_waves = std::max(1, std::atoi(e));
@@ -1001,11 +1001,12 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   // table (analyse_groups).  Build it on the side stream while the pod pre-pass and k_query run.
   const bool side_tables = !captures_possible && c->steady_table >= 0 && c->M && P && c->cfg.enable_timing < 2;
   const uint32_t side_slot = side_tables ? (uint32_t)c->steady_table : 0u;
+  // (With request classes Filter is cheap and rides in the scan launch; early Filter is for slot = pod batches.)
   // No capture possible: the Filter inputs do not depend on the node scan (k_fparams_early), so Filter
   // runs on its own stream beside scan / reject / final and k_tally voids the rows PreFilter turned down.
   // Joining a second stream costs ~10-20 us of cross-queue signalling, so only when Filter is long enough.
   const bool early_filter = run_filter && !captures_possible && P && N && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing < 2 &&
-                            (uint64_t)P * N >= c->early_filter_min;
+                            (uint64_t)P * N >= c->early_filter_min && (!use_classes || c->early_forced);
   prm.early_filter = early_filter ? 1u : 0u;
   // tally inputs (admit counts + quorum).  Without early Filter and without COMMIT the expand kernel of
   // Filter does the tally on the way (one launch less).

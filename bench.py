@@ -231,11 +231,18 @@ def main():
             "kernel_ms_per_step": {k: v[0] / v[1] for k, v in timing.items() if v[1]},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0:
+        # the JSON line goes out LAST: anything native libraries (RCCL) left in the C stdio buffer is flushed first
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)
     return result
 
 
