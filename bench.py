@@ -162,9 +162,10 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = logical * args.steps / elapsed
 
-    # roofline of the dominant kernel group: Filter = k_filter (request slots x nodes) + k_filter_expand (every
-    # pod's row from its slot's, + tally).  Algorithmic bytes per Filter evaluation: 16*4 + 1 in
-    # (alloc[4] + requested[4] int64 + flag byte; scalars are never read on this path) + 1/8 out (bitmap bit).
+    # roofline of the dominant kernel: k_filter_expand — it delivers the Filter result of every (pod, node) pair
+    # (each pod's bitmap row from its request slot's, evaluated by k_scan_filter) and does the tally.
+    # Algorithmic bytes per Filter evaluation: 16*4 + 1 in (alloc[4] + requested[4] int64 +
+    # flag byte; scalars are never read on this path) + 1/8 out (bitmap bit).
     filt_ms, filt_launches = timing["filter"]
     bytes_per_eval = 16 * 4 + 1 + 0.125
     roofline = None
@@ -176,22 +177,23 @@ def main():
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (same command, same workload only)
             if args.config == "cfg3" and args.scenario == "tail" and world == 1 and args.stages == "all":
                 t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                traffic = t["k_filter<2>"]["hbm_bytes_per_launch"] + t["k_filter_expand"]["hbm_bytes_per_launch"]
+                traffic = t["k_filter_expand"]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         out_bytes = pods.p * ((nodes.n + 63) // 64) * 8
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_filter<2> + k_filter_expand", "avg_launch_us": avg_s * 1e6, "launches": filt_launches,
+                    "traffic": traffic, "kernel": "k_filter_expand", "avg_launch_us": avg_s * 1e6, "launches": filt_launches,
                     "algorithmic_bytes_per_eval": bytes_per_eval, "evals_per_launch": evals,
                     "evals_executed_per_launch": stats["filter_evals_executed"],
                     "compulsory_output_bytes": out_bytes,
                     "physical_gbps": (traffic / avg_s / 1e9) if traffic else None,
-                    "note": "achieved = logical Filter evals (pods x nodes) x 65.125 B / mean time of the Filter kernel pair (hipEvents on the stream "
-                            "they run on, every 8th batch); it exceeds the HBM peak because the algorithmic figure assumes every evaluation re-reads its "
-                            "node, while here a node block is read once per 64 request slots and pods with equal requests share one evaluated row "
-                            "(evals_executed_per_launch). traffic = rocprofv3 FETCH(x2)+WRITE bytes per launch (profiles/r01_traffic.json): essentially "
-                            "the compulsory bitmap output (compulsory_output_bytes); physical_gbps = traffic / time. At this size the pair is bound "
-                            "by launch and memory latency, not by HBM bandwidth; see DESIGN.md"}
+                    "note": "achieved = logical Filter evals (pods x nodes) x 65.125 B / mean k_filter_expand time (hipEvents on the stream it runs "
+                            "on, every 8th batch; the events add ~1.5 us, rocprofv3 durations are in profiles/); it exceeds the HBM peak because the "
+                            "algorithmic figure assumes every evaluation re-reads its node, while here pods with equal requests share one evaluated row "
+                            "(evals_executed_per_launch, done inside k_scan_filter) and this kernel only streams the rows out. traffic = rocprofv3 "
+                            "FETCH(x2)+WRITE bytes per launch (profiles/r01_traffic.json) = the compulsory bitmap output (compulsory_output_bytes) + slot rows; "
+                            "physical_gbps = traffic / time: launch/latency bound at cfg3 (6 MB), HBM-write bound at cfg4 (125 MB at ~4.8 TB/s, "
+                            "profiles/r01_cfg4_tail.txt); see DESIGN.md"}
 
     result = None
     if rank == 0:
