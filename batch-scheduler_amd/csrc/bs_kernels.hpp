@@ -831,21 +831,40 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDe
 
 __global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev b, BatchParams prm, const TableDesc* forced) {
   __shared__ unsigned long long off[BS_MAX_LANES];
+  __shared__ unsigned long long part[kTblChunk];
+  static_assert(kTblChunk % 16 == 0, "a thread must always land on the same lane of the [chunk][16] arrays");
   const uint32_t slot = blockIdx.x;
   if (!forced && !b.needed[slot]) return;
   const uint32_t chunk = blockIdx.y + 1, nchunks = gridDim.y + 1;      // chunk 0 needs no fix-up
-  if (blockIdx.y == 0 && threadIdx.x < 16) {                           // kp[s] = min over the chunks' first rows
+  // Both reductions below run over [chunk][16] arrays with all threads: thread t only ever meets lane t % 16,
+  // keeps a private partial and 16 threads fold the 16 partials of their lane (no serial walk over the chunks).
+  if (blockIdx.y == 0) {                                               // kp[s] = min over the chunks' first rows
+    const uint32_t nvalid = min(nchunks, (nd.m + kTblChunk - 1u) / kTblChunk);
+    const uint32_t* src = b.chunk_kp + (size_t)slot * nchunks * 16;
     uint32_t v = BS_INF;
-    for (uint32_t cc = 0; cc < nchunks; ++cc)
-      if (cc * kTblChunk < nd.m) v = min(v, b.chunk_kp[((size_t)slot * nchunks + cc) * 16 + threadIdx.x]);
-    b.kp[slot * 16 + threadIdx.x] = v;
+    for (uint32_t e = threadIdx.x; e < nvalid * 16u; e += kTblChunk) v = min(v, src[e]);
+    part[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      uint32_t r = BS_INF;
+      for (int mm = 0; mm < kTblChunk / 16; ++mm) r = min(r, (uint32_t)part[threadIdx.x + 16 * mm]);
+      b.kp[slot * 16 + threadIdx.x] = r;
+    }
+    __syncthreads();
   }
   if (chunk * kTblChunk >= nd.m) return;
   const uint32_t L = prm.L, LP = prm.LP;
-  if (threadIdx.x < L) {
-    unsigned long long s = 0;
-    for (uint32_t c = 0; c < chunk; ++c) s += b.chunk_tot[((size_t)slot * nchunks + c) * 16 + threadIdx.x];
-    off[threadIdx.x] = s;
+  {
+    const unsigned long long* src = b.chunk_tot + (size_t)slot * nchunks * 16;
+    unsigned long long acc = 0;
+    for (uint32_t e = threadIdx.x; e < chunk * 16u; e += kTblChunk) acc += src[e];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      unsigned long long r = 0;
+      for (int mm = 0; mm < kTblChunk / 16; ++mm) r += part[threadIdx.x + 16 * mm];
+      off[threadIdx.x] = r;
+    }
   }
   __syncthreads();
   const uint32_t k = chunk * kTblChunk + threadIdx.x;
