@@ -87,6 +87,8 @@ struct bs_ctx {
   // pods live in ONE device allocation (one H2D per batch from a pinned staging buffer); outputs likewise (one D2H)
   DevBuf d_podpack, d_outpack;
   void* h_stage = nullptr;           // pinned host staging
+  hipEvent_t ev_stage = nullptr;     // the last H2D out of the staging buffer (bs_pods_load does not wait for it)
+  bool stage_busy = false;
   size_t h_stage_cap = 0;
   size_t off_pgroup = 0, off_preq = 0, off_ppres = 0, off_pcls = 0, off_powner = 0, off_pflags = 0, podpack_bytes = 0;
   size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, outpack_bytes = 0;
@@ -590,6 +592,7 @@ int bs_destroy(bs_ctx* c) {
     destroy_t f = (destroy_t)dlsym(c->rccl_handle, "ncclCommDestroy");
     if (f) f(c->comm);
   }
+  if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
@@ -833,6 +836,8 @@ int bs_groups_read(bs_ctx* c, bs_groups_soa* g) {
 }
 
 static int ensure_stage(bs_ctx* c, size_t bytes) {
+  // the previous upload may still be reading the staging buffer
+  if (c->stage_busy) { HIPCHK(c, hipEventSynchronize(c->ev_stage)); c->stage_busy = false; }
   if (bytes <= c->h_stage_cap) return BS_OK;
   if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
   HIPCHK(c, hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault));
@@ -909,7 +914,11 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
                        c->d_pclass.as<uint32_t>());
     HIPCHK(c, hipGetLastError());
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // no wait here: the batch that follows is ordered behind the upload on the same stream; only the staging
+  // buffer must not be touched again before the copy has left it (ensure_stage / bs_batch_read wait for that)
+  if (!c->ev_stage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_stage, c->stream));
+  c->stage_busy = true;
   c->have_pods = true;
   return BS_OK;
 }
@@ -1210,6 +1219,7 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
   if (want_pod) HIPCHK(c, hipMemcpyAsync(st, c->d_outpack.p, c->outpack_bytes, hipMemcpyDeviceToHost, c->stream));   // ONE transfer
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stage_busy = false;
   if (want_pod) {
     if (out->pf_code) std::memcpy(out->pf_code, st + c->off_pf_code, P);
     if (out->pf_first_k) std::memcpy(out->pf_first_k, st + c->off_pf_first_k, (size_t)P * 4);
