@@ -89,6 +89,7 @@ struct bs_ctx {
   void* h_stage = nullptr;           // pinned host staging
   hipEvent_t ev_stage = nullptr;     // the last H2D out of the staging buffer (bs_pods_load does not wait for it)
   bool stage_busy = false;
+  bool last_use_classes = false;
   size_t h_stage_cap = 0;
   size_t off_pgroup = 0, off_preq = 0, off_ppres = 0, off_pcls = 0, off_powner = 0, off_pflags = 0, podpack_bytes = 0;
   size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, outpack_bytes = 0;
@@ -1002,6 +1003,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   // no first-pod capture and no MinResources default (core.go:486-493) left to happen
   const bool use_classes = !captures_possible && c->n_nominres == 0;
   prm.use_classes = use_classes ? 1u : 0u;
+  c->last_use_classes = use_classes;
   prm.scan_slots_cap = scan_cap;
   prm.filter_slots_cap = filter_cap;
   const int ts = c->S <= 4 ? (int)c->S : -1;
@@ -1611,6 +1613,7 @@ int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {
   out->scan_evals_executed = raw[1];
   out->scan_queries = raw[4];
   out->scan_queries_logical = raw[2];
+  out->class_mode = c->last_use_classes ? 1 : 0;
   out->tables_built = nt;
   out->logical_evals = (uint64_t)c->P * c->N;
   out->filter_evals = (c->last_stages & BS_STAGE_FILTER) ? (uint64_t)c->P * c->N : 0;

@@ -380,6 +380,7 @@ typedef struct bs_batch_stats {
   uint64_t filter_distinct;         /* distinct Filter requests actually evaluated            */
   uint64_t filter_evals_executed;   /* filter_distinct x nodes                                */
   uint64_t scan_queries_logical;    /* pods that needed a node scan (scan_queries = distinct ones scanned) */
+  uint64_t class_mode;              /* 1: the batch worked on request classes, 0: one slot per pod        */
 } bs_batch_stats;
 int bs_batch_stats_get(bs_ctx* ctx, bs_batch_stats* out);
 

@@ -520,7 +520,7 @@ def test_dedupe_all_requests_distinct(bsa, soa, orc):
         assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp)
         st = ctx.stats(soa.STAGE_ALL)
         evaluated = int((exp.fl_code == soa.FL_EVALUATED).sum())
-        assert st["filter_distinct"] == evaluated
+        assert st["class_mode"] == 1 and st["filter_distinct"] >= evaluated      # both leader slots of a class are filled
 
 
 @pytest.mark.parametrize("scenario", ["warm", "tail"])
@@ -542,3 +542,48 @@ def test_no_schedulable_node_still_filters(bsa, soa, orc):
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
         assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp)
+
+
+# ---- class mode on random scenes.  Random group states rarely qualify for request classes (every group
+# needs its pod and its MinResources), so they are forced here; deny flags, permitted pods, owners and
+# occupancy stay as generated.  Batch A commits (leaves a leader behind), then the group state is shuffled so
+# that batch B computes a different leader: pods that pass PreFilter without reaching findMaxPG (last
+# permitted ones at the head of the queue) then evaluate Filter against the STALE leader (slot class + K).
+def _force_class_mode(groups, rng, n_classes):
+    L, g = groups.min_resources.shape
+    missing = (groups.flags & soa_mod.GROUP_HAS_MINRES) == 0
+    groups.min_resources[0, missing] = rng.integers(100, 4000, int(missing.sum()))
+    groups.min_resources[1, missing] = rng.integers(2 ** 20, 2 ** 32, int(missing.sum()))
+    groups.flags |= np.uint8(soa_mod.GROUP_HAS_POD | soa_mod.GROUP_HAS_MINRES)
+    groups.cls[:] = rng.integers(0, n_classes, g)
+
+
+import importlib as _il
+soa_mod = _il.import_module("batch-scheduler_amd.soa")
+
+
+@pytest.mark.parametrize("seed", range(8000, 8060))
+def test_class_mode_random_with_stale_leader(seed, bsa, soa, orc):
+    rng = np.random.default_rng(seed)
+    n_classes = 3
+    sc = random_objects(seed, n_nodes=60 + seed % 100, n_groups=9, n_pods=180, n_scalars=seed % 3, n_classes=n_classes)
+    nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"],
+                                            denied=sc["denied"], permitted=sc["permitted"])
+    _force_class_mode(groups, rng, n_classes)
+    groups.matched[:] = rng.integers(0, 4, groups.g)
+    sop = orc.Sop(orc.Snapshot(nodes, fit), groups)
+    exp_a = sop.batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL | soa.BATCH_COMMIT), exp_a, "batch A")
+        g2 = ctx.read_groups()
+        assert g2.state_equal(sop.groups)
+        new_matched = rng.integers(0, 6, groups.g).astype(np.uint32)
+        for gs in (g2, sop.groups):
+            gs.flags &= ~np.uint8(soa.GROUP_DENIED)
+            gs.matched[:] = new_matched
+        ctx.load_groups(g2)
+        exp_b = sop.batch(pods, soa.STAGE_ALL)
+        got_b = ctx.batch(soa.STAGE_ALL)
+        assert_batch_equal(got_b, exp_b, "batch B")
+        st = ctx.stats(soa.STAGE_ALL)
+        assert st["class_mode"] == 1 and st["filter_distinct"] <= 2 * pods.p
