@@ -273,7 +273,9 @@ int bs_fit_build(bs_ctx* ctx, const bs_node_labels* nodes, const bs_fit_template
 int bs_fit_read(bs_ctx* ctx, uint32_t* fit_bits_out);
 int bs_groups_load(bs_ctx* ctx, const bs_groups_soa* groups);
 int bs_groups_read(bs_ctx* ctx, bs_groups_soa* groups_out); /* caller-sized arrays, g must match */
-int bs_pods_load(bs_ctx* ctx, const bs_pods_soa* pods);
+int bs_pods_load(bs_ctx* ctx, const bs_pods_soa* pods);   /* also derives the pods' request classes on the device:
+                                                              equal (req lanes, req_present) <=> equal class; a batch then
+                                                              evaluates every distinct derived request once           */
 
 /* node churn (BASELINE config 5): stable delete / append / requested-update */
 #define BS_DELTA_UPDATE 0u   /* replace node `index` (all lanes, presence, flags, fit column) */
