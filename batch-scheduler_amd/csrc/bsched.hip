@@ -1218,8 +1218,18 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   if (rc) return rc;
   const uint32_t P = c->P, G = c->G, W = cdiv(c->N, 64);
   const bool want_pod = P && (out->pf_code || out->pf_first_k || out->pf_leader || out->fl_code || out->fl_feasible);
+  const bool want_grp = G && (c->last_stages & BS_STAGE_TALLY) && (out->group_admit || out->group_ready);
+  // everything small travels in ONE wait: the packed per-pod results and the two per-group arrays are copied
+  // asynchronously into the pinned staging buffer, then the stream is synchronised once
+  const size_t off_admit = (c->outpack_bytes + 255) & ~(size_t)255, off_ready = off_admit + (((size_t)G * 4 + 255) & ~(size_t)255);
+  rc = ensure_stage(c, std::max(c->podpack_bytes, off_ready + G + 256));
+  if (rc) return rc;
   uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
-  if (want_pod) HIPCHK(c, hipMemcpyAsync(st, c->d_outpack.p, c->outpack_bytes, hipMemcpyDeviceToHost, c->stream));   // ONE transfer
+  if (want_pod) HIPCHK(c, hipMemcpyAsync(st, c->d_outpack.p, c->outpack_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (want_grp) {
+    if (out->group_admit) HIPCHK(c, hipMemcpyAsync(st + off_admit, c->ext_admit ? (void*)c->ext_admit : c->d_admit.p, (size_t)G * 4, hipMemcpyDeviceToHost, c->stream));
+    if (out->group_ready) HIPCHK(c, hipMemcpyAsync(st + off_ready, c->d_ready.p, G, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stage_busy = false;
   if (want_pod) {
@@ -1229,13 +1239,13 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
     if (out->fl_code) std::memcpy(out->fl_code, st + c->off_fl_code, P);
     if (out->fl_feasible) std::memcpy(out->fl_feasible, st + c->off_fl_feasible, (size_t)P * 4);
   }
+  if (want_grp) {
+    if (out->group_admit) std::memcpy(out->group_admit, st + off_admit, (size_t)G * 4);
+    if (out->group_ready) std::memcpy(out->group_ready, st + off_ready, G);
+  }
   if (P && out->fl_bitmap && W) {
     if (c->last_stages & BS_STAGE_FILTER) HIPCHK(c, hipMemcpy(out->fl_bitmap, c->d_fl_bitmap.p, (size_t)W * P * 8, hipMemcpyDeviceToHost));
     else std::memset(out->fl_bitmap, 0, (size_t)W * P * 8);
-  }
-  if (G && (c->last_stages & BS_STAGE_TALLY)) {
-    if (out->group_admit) HIPCHK(c, hipMemcpy(out->group_admit, c->ext_admit ? (void*)c->ext_admit : c->d_admit.p, (size_t)G * 4, hipMemcpyDeviceToHost));
-    if (out->group_ready) HIPCHK(c, hipMemcpy(out->group_ready, c->d_ready.p, G, hipMemcpyDeviceToHost));
   }
   return BS_OK;
 }
