@@ -311,13 +311,9 @@ __device__ __forceinline__ void leader_block(const GroupsDev& gr, const BatchDev
 
 constexpr int kPrepassBlock = 512;
 
-__global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm, uint32_t no_capture,
-                                                           uint32_t fused_leader) {
-  if (fused_leader && blockIdx.x == gridDim.x - 1) {
-    leader_block(gr, b, 0);
-    return;
-  }
-  const uint32_t i = blockIdx.x * kPrepassBlock + threadIdx.x;
+// per-thread part of the pre-pass: thread i of nthreads (resets are strided over all of them)
+__device__ __forceinline__ void prepass_thread(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t no_capture,
+                                               uint32_t i, uint32_t nthreads) {
   // resets whose consumers run in later launches
   if (i < gr.g) b.admit[i] = 0;
   if (i < 2 * prm.C + 1) b.needed[i] = 0;
@@ -329,7 +325,6 @@ __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsD
   if (i < 8 && prm.collect_stats) b.stats[i] = 0;
   {
     // request slots of this batch start out unused
-    const uint32_t nthreads = (gridDim.x - fused_leader) * kPrepassBlock;
     for (uint32_t k = i; k < prm.scan_slots_cap; k += nthreads) {
       b.qtab_s[k] = -1;
       b.first_row[k] = BS_INF;
@@ -356,6 +351,15 @@ __global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsD
     }
   }
   b.stage[i] = st;
+}
+
+__global__ __launch_bounds__(kPrepassBlock) void k_prepass(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm, uint32_t no_capture,
+                                                           uint32_t fused_leader) {
+  if (fused_leader && blockIdx.x == gridDim.x - 1) {
+    leader_block(gr, b, 0);
+    return;
+  }
+  prepass_thread(pods, gr, b, prm, no_capture, blockIdx.x * kPrepassBlock + threadIdx.x, (gridDim.x - fused_leader) * kPrepassBlock);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -607,10 +611,10 @@ template <int TS>
 __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm,
                                                   uint32_t i, uint8_t pf, int32_t leader, uint32_t slot, bool write_slot, bool write_pod);
 
+// every lane of the wave calls this (wave-level ballots inside); i >= pods.p is a no-op lane
 template <int TS>
-__global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
+__device__ __forceinline__ void query_thread(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i) {
   const Shape<TS> sh(prm.S);
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < pods.p;
   const uint32_t gate = prm.eph_gate;
   uint8_t code = BS_PF_PASS_NOT_GROUPED, st = 0;
@@ -722,6 +726,11 @@ __global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm)
   }
 }
 
+template <int TS>
+__global__ void k_query(PodsDev pods, GroupsDev gr, BatchDev b, BatchParams prm) {
+  query_thread<TS>(pods, gr, b, prm, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_tables_local / k_tables_fix: running sums per table, two-level.
 // Row k (k-th non-skipped node in list order) holds leftResources after that node (core.go:602,621):
@@ -743,11 +752,10 @@ __device__ __forceinline__ TableDesc table_desc(uint32_t t, uint32_t C, const Ta
 }
 
 template <int TS>
-__global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDev b, BatchParams prm, const TableDesc* forced) {
+__device__ __forceinline__ void tables_local_block(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced,
+                                                   uint32_t slot, uint32_t chunk, uint32_t nchunks) {
   __shared__ unsigned long long s_wtot[BS_MAX_LANES][4];     // per resource lane, per wave: wave total
   __shared__ uint32_t s_kp[BS_MAX_SCALARS];
-  const uint32_t slot = blockIdx.x;
-  const uint32_t chunk = blockIdx.y, nchunks = gridDim.y;
   if (chunk * kTblChunk >= nd.m) return;
   const uint32_t k = chunk * kTblChunk + threadIdx.x;
   const bool valid = k < nd.m;
@@ -828,17 +836,22 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDe
     if (nchunks == 1) b.kp[slot * 16 + threadIdx.x] = v;
   }
 }
+template <int TS>
+__global__ __launch_bounds__(kTblChunk) void k_tables_local(NodesDev nd, BatchDev b, BatchParams prm, const TableDesc* forced) {
+  tables_local_block<TS>(nd, b, prm, forced, blockIdx.x, blockIdx.y, gridDim.y);
+}
 
-__global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev b, BatchParams prm, const TableDesc* forced) {
+// block (slot, fix_index): fixes chunk fix_index + 1 (chunk 0 needs no fix-up); fix_index 0 also reduces kp
+__device__ __forceinline__ void tables_fix_block(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced,
+                                                 uint32_t slot, uint32_t fix_index, uint32_t nchunks) {
   __shared__ unsigned long long off[BS_MAX_LANES];
   __shared__ unsigned long long part[kTblChunk];
   static_assert(kTblChunk % 16 == 0, "a thread must always land on the same lane of the [chunk][16] arrays");
-  const uint32_t slot = blockIdx.x;
   if (!forced && !b.needed[slot]) return;
-  const uint32_t chunk = blockIdx.y + 1, nchunks = gridDim.y + 1;      // chunk 0 needs no fix-up
+  const uint32_t chunk = fix_index + 1;
   // Both reductions below run over [chunk][16] arrays with all threads: thread t only ever meets lane t % 16,
   // keeps a private partial and 16 threads fold the 16 partials of their lane (no serial walk over the chunks).
-  if (blockIdx.y == 0) {                                               // kp[s] = min over the chunks' first rows
+  if (fix_index == 0) {                                                // kp[s] = min over the chunks' first rows
     const uint32_t nvalid = min(nchunks, (nd.m + kTblChunk - 1u) / kTblChunk);
     const uint32_t* src = b.chunk_kp + (size_t)slot * nchunks * 16;
     uint32_t v = BS_INF;
@@ -887,6 +900,36 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev 
       if (lane_id() == 0) b.gmax[((size_t)slot * ngroups + grp) * 4 + j] = mx;
     }
   }
+}
+__global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev b, BatchParams prm, const TableDesc* forced) {
+  tables_fix_block(nd, b, prm, forced, blockIdx.x, blockIdx.y, gridDim.y + 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Steady state (one known table per batch): the table build rides in the first two launches instead of on a
+// side stream.  Its two passes have the dependency shape of the launches they join — the local scans need only
+// the node arrays (k_prepass), the fix-up needs the local pass (k_query), the node scan needs the fix-up — so
+// no cross-queue event is left on the critical path and the host issues four calls less per batch.
+// `bt` = the batch view shifted to the table's slot (slot index 0), `forced` its descriptor.
+// ------------------------------------------------------------------------------------------------
+template <int TS>
+__global__ __launch_bounds__(kPrepassBlock) void k_prepass_tables(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm,
+                                                                  const TableDesc* forced, uint32_t nchunks, uint32_t pre_blocks) {
+  // block layout: [0, pre_blocks) pre-pass | pre_blocks: findMaxPG | pre_blocks + 1 + c: table chunk c
+  if (blockIdx.x < pre_blocks) {
+    prepass_thread(pods, gr, b, prm, 1u, blockIdx.x * kPrepassBlock + threadIdx.x, pre_blocks * kPrepassBlock);
+  } else if (blockIdx.x == pre_blocks) {
+    leader_block(gr, b, 0);
+  } else {
+    if (threadIdx.x >= kTblChunk) return;          // whole waves leave: the chunk code is written for kTblChunk threads
+    tables_local_block<TS>(nd, bt, prm, forced, 0u, blockIdx.x - pre_blocks - 1u, nchunks);
+  }
+}
+template <int TS>
+__global__ __launch_bounds__(kTblChunk) void k_query_tables(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm,
+                                                            const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks) {
+  if (blockIdx.x < query_blocks) query_thread<TS>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x);
+  else tables_fix_block(nd, bt, prm, forced, 0u, blockIdx.x - query_blocks, nchunks);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1029,19 +1029,16 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const bool fuse_filter = run_filter && use_classes && !early_filter && P && N && !c->no_fuse_filter;
   prm.fuse_filter = fuse_filter ? 1u : 0u;
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
+  // steady state: the one table is built inside the first two launches (k_prepass_tables / k_query_tables)
+  BatchDev bt = b;                                                       // the batch view shifted to the table's slot (slot index 0)
+  const TableDesc* forced = nullptr;
   if (side_tables) {
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_scan_done, 0));      // the previous batch's scan is done with the tables
-    BatchDev b2 = b;                                                     // blockIdx.x 0 == side_slot
-    b2.tables = b.tables + (size_t)side_slot * prm.mcap * prm.LP;
-    b2.kp = b.kp + (size_t)side_slot * 16;
-    b2.chunk_tot = b.chunk_tot + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
-    b2.gmax = b.gmax + (size_t)side_slot * cdiv(c->Ncap, 64) * 4;
-    b2.chunk_kp = b.chunk_kp + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
-    const TableDesc* forced = b.desc + side_slot;
-    launch_tables_local(c, c->stream2, dim3(1, nchunks), nd, b2, prm, forced);
-    if (nchunks > 1) hipLaunchKernelGGL(k_tables_fix, dim3(1, nchunks - 1), dim3(kTblChunk), 0, c->stream2, nd, b2, prm, forced);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev_tables, c->stream2));
+    bt.tables = b.tables + (size_t)side_slot * prm.mcap * prm.LP;
+    bt.kp = b.kp + (size_t)side_slot * 16;
+    bt.chunk_tot = b.chunk_tot + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
+    bt.gmax = b.gmax + (size_t)side_slot * cdiv(c->Ncap, 64) * 4;
+    bt.chunk_kp = b.chunk_kp + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
+    forced = b.desc + side_slot;
   }
 
   // ---- per-batch resets + eligibility (+ findMaxPG when no first-pod capture can occur)
@@ -1049,6 +1046,18 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     if (!c->scratch_armed) hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(G, 4), 256)), blk, 0, c->stream, gr, b);
     const uint32_t span = std::max(std::max(P, G), (2 * C + 1) * 16);
     const uint32_t fused = captures_possible ? 0u : 1u;
+    if (side_tables) {
+      const uint32_t pre = cdiv(span, kPrepassBlock);
+      const dim3 pg(pre + 1 + nchunks), pb(kPrepassBlock);
+      switch (ts) {
+        case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prepass_tables<0>), pg, pb, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, pre); break;
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prepass_tables<1>), pg, pb, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, pre); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prepass_tables<2>), pg, pb, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, pre); break;
+        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prepass_tables<3>), pg, pb, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, pre); break;
+        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prepass_tables<4>), pg, pb, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, pre); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prepass_tables<-1>), pg, pb, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, pre); break;
+      }
+    } else
     hipLaunchKernelGGL(k_prepass, dim3(cdiv(span, kPrepassBlock) + fused), dim3(kPrepassBlock), 0, c->stream, pd, gr, b, prm,
                        captures_possible ? 0u : 1u, fused);
     if (captures_possible) {
@@ -1064,7 +1073,18 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   }
   // ---- decisions that need no node scan, request vectors, scan tiles
   TIMED(c, BS_KERNEL_QUERY, {
-    if (P) {
+    if (P && side_tables) {
+      const uint32_t qb = cdiv(P, 256);
+      const dim3 qg(qb + (nchunks > 1 ? nchunks - 1 : 0));
+      switch (ts) {
+        case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_tables<0>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_tables<1>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_tables<2>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_tables<3>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_tables<4>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_tables<-1>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+      }
+    } else if (P) {
       const dim3 qg(cdiv(P, 256));
       switch (ts) {
         case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<0>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
@@ -1093,9 +1113,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   }
   // ---- running-sum tables of the (class, percent) pairs some query uses
   if (c->M && P) {
-    if (side_tables) {
-      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_tables, 0));
-    } else {
+    if (!side_tables) {
       TIMED(c, BS_KERNEL_TABLES, {
         launch_tables_local(c, c->stream, dim3(2 * C, nchunks), nd, b, prm, (const TableDesc*)nullptr);
         if (nchunks > 1)
@@ -1110,7 +1128,6 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     } else {
       TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg, P, G, tsplit));
     }
-    HIPCHK(c, hipEventRecord(c->ev_scan_done, c->stream));   // the tables may be rebuilt (next batch) from here on
   } else if (fuse_filter) {
     // no schedulable node: nothing to scan, Filter still has its slots to evaluate
     const uint32_t fblocks = cdiv(std::min<uint32_t>(c->filter_waves, 2 * cdiv(P, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4);
