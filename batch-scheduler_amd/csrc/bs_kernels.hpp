@@ -1,7 +1,7 @@
 // bs_kernels.hpp — gfx950 kernels of the batched PreFilter / Filter / Permit path.
 //
-// Pipeline of one batch (bs_batch_run); steady state = 6 launches on the main stream, the table build
-// overlapped on a side stream:
+// Pipeline of one batch (bs_batch_run); steady state = 6 launches on one stream (the table build rides in
+// the first two: k_prepass_tables, k_query_tables):
 //   k_prepass   per-batch resets; per pod: eligibility (core.go:89-110), first eligible pod / first owner
 //               per group; LAST block: findMaxPG (core.go:701-739) when no first-pod capture can occur
 //   [k_init, k_epochs_a/b, k_leader   only when groups without a pod exist: capture epochs, one
@@ -10,7 +10,7 @@
 //               (getPreAllocatedResource core.go:774-793 [+ pod request :157-159]) into its request SLOT;
 //               class mode: also the Filter parameters of the pod's class into the Filter slots
 //   k_tables_local/fix   singleNodeResource (core.go:634-670) + running sums of core.go:602,621 per
-//               table, per-group maxima for pruning           [side stream in steady state]
+//               table, per-group maxima for pruning           [extra blocks of the two launches above in steady state]
 //   k_scan_filter   node scan "exists k : prefix_k >= request" (core.go:623), first such k, per scan slot,
 //               and computeResourceSatisfied (core.go:514-564) per Filter slot x node, in one launch
 //               [k_scan, k_filter: the same two work loops as separate launches when slot = pod or

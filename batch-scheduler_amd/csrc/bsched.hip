@@ -75,8 +75,6 @@ struct bs_ctx {
   std::vector<uint32_t> h_gmatched, h_gcls;
   std::vector<uint8_t> h_gflags;
   int32_t steady_table = -1;        // the one table every reservation query uses when no capture can occur, -1 unknown
-  hipStream_t stream2 = nullptr;    // side stream: that table is built while the pod pre-pass runs
-  hipEvent_t ev_scan_done = nullptr, ev_tables = nullptr;
   uint64_t early_filter_min = 200000000ull;   // pod x node pairs from which Filter overlaps the scan
   hipStream_t stream3 = nullptr;    // early Filter: runs beside the node scan when no capture can occur
   hipEvent_t ev_query = nullptr, ev_filter = nullptr;
@@ -564,12 +562,9 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     delete c;
     return BS_ERR_NO_DEVICE;
   }
-  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_query, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_filter, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_scan_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->ev_filter, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return BS_ERR_NO_DEVICE;
   }
@@ -595,12 +590,9 @@ int bs_destroy(bs_ctx* c) {
   }
   if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
-  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   if (c->ev_query) (void)hipEventDestroy(c->ev_query);
   if (c->ev_filter) (void)hipEventDestroy(c->ev_filter);
-  if (c->ev_scan_done) (void)hipEventDestroy(c->ev_scan_done);
-  if (c->ev_tables) (void)hipEventDestroy(c->ev_tables);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return BS_OK;
@@ -1010,8 +1002,8 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   bool commit_dirty = false;
   // No capture possible and the leader has matched pods: every scan query of the batch uses ONE known
   // table (analyse_groups).  Build it on the side stream while the pod pre-pass and k_query run.
-  const bool side_tables = !captures_possible && c->steady_table >= 0 && c->M && P && c->cfg.enable_timing < 2;
-  const uint32_t side_slot = side_tables ? (uint32_t)c->steady_table : 0u;
+  const bool inline_tables = !captures_possible && c->steady_table >= 0 && c->M && P && c->cfg.enable_timing < 2;
+  const uint32_t side_slot = inline_tables ? (uint32_t)c->steady_table : 0u;
   // (With request classes Filter is cheap and rides in the scan launch; early Filter is for slot = pod batches.)
   // No capture possible: the Filter inputs do not depend on the node scan (k_fparams_early), so Filter
   // runs on its own stream beside scan / reject / final and k_tally voids the rows PreFilter turned down.
@@ -1032,7 +1024,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   // steady state: the one table is built inside the first two launches (k_prepass_tables / k_query_tables)
   BatchDev bt = b;                                                       // the batch view shifted to the table's slot (slot index 0)
   const TableDesc* forced = nullptr;
-  if (side_tables) {
+  if (inline_tables) {
     bt.tables = b.tables + (size_t)side_slot * prm.mcap * prm.LP;
     bt.kp = b.kp + (size_t)side_slot * 16;
     bt.chunk_tot = b.chunk_tot + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
@@ -1046,7 +1038,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     if (!c->scratch_armed) hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(G, 4), 256)), blk, 0, c->stream, gr, b);
     const uint32_t span = std::max(std::max(P, G), (2 * C + 1) * 16);
     const uint32_t fused = captures_possible ? 0u : 1u;
-    if (side_tables) {
+    if (inline_tables) {
       const uint32_t pre = cdiv(span, kPrepassBlock);
       const dim3 pg(pre + 1 + nchunks), pb(kPrepassBlock);
       switch (ts) {
@@ -1073,7 +1065,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   }
   // ---- decisions that need no node scan, request vectors, scan tiles
   TIMED(c, BS_KERNEL_QUERY, {
-    if (P && side_tables) {
+    if (P && inline_tables) {
       const uint32_t qb = cdiv(P, 256);
       const dim3 qg(qb + (nchunks > 1 ? nchunks - 1 : 0));
       switch (ts) {
@@ -1113,7 +1105,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   }
   // ---- running-sum tables of the (class, percent) pairs some query uses
   if (c->M && P) {
-    if (!side_tables) {
+    if (!inline_tables) {
       TIMED(c, BS_KERNEL_TABLES, {
         launch_tables_local(c, c->stream, dim3(2 * C, nchunks), nd, b, prm, (const TableDesc*)nullptr);
         if (nchunks > 1)
@@ -1121,7 +1113,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       });
     }
     const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
-    const uint32_t tsplit = side_tables ? 1u : std::min<uint32_t>(16, 2 * C);
+    const uint32_t tsplit = inline_tables ? 1u : std::min<uint32_t>(16, 2 * C);
     if (fuse_filter) {
       const uint32_t fblocks = cdiv(std::min<uint32_t>(c->filter_waves, 2 * cdiv(P, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4);
       TIMED(c, BS_KERNEL_SCAN, launch_scan_filter(c, scan_blocks, fblocks, pd, nd, b, prm, c->M, nseg, P, G, tsplit));
@@ -1188,7 +1180,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
                          run_filter ? 1u : 0u, local_ready ? 1u : 0u, rearm ? 1u : 0u);
     });
     c->scratch_armed = rearm;
-    c->side_ready = rearm && side_tables;
+    c->side_ready = rearm && inline_tables;
     if (c->nranks > 1 || c->reduce_external) {
       if (c->comm) {
         // native RCCL: one all-reduce(sum) of the per-group admit counters on the context stream
