@@ -204,7 +204,7 @@ def main():
                             "algorithmic figure assumes every evaluation re-reads its node, while here pods with equal requests share one evaluated row "
                             "(evals_executed_per_launch, done inside k_scan_filter) and this kernel only streams the rows out. traffic = rocprofv3 "
                             "FETCH(x2)+WRITE bytes per launch (profiles/r01_traffic.json) = the compulsory bitmap output (compulsory_output_bytes) + slot rows; "
-                            "physical_gbps = traffic / time: launch/latency bound at cfg3 (6 MB), HBM-write bound at cfg4 (130 MB in 31.8 us = 4.1 TB/s incl. the tally tail, "
+                            "physical_gbps = traffic / time: launch/latency bound at cfg3 (6 MB), HBM-write bound at cfg4 (130 MB in 31.3 us = 4.1 TB/s incl. the tally tail, "
                             "profiles/r01_cfg4_tail.txt); see DESIGN.md"}
 
     result = None
