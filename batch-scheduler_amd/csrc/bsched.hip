@@ -98,7 +98,7 @@ struct bs_ctx {
   DevBuf d_tcode, d_stage, d_leader_raw, d_first_row, d_qreq_s, d_qflags_s, d_qpos;
   DevBuf d_needed, d_qcount, d_ticket, d_desc;
   bool scratch_armed = false;
-  bool side_ready = false;      // desc[] / kp[] of the side-stream table are in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
+  bool side_ready = false;      // desc[] of the steady-state table is in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
   // request slots (see BatchDev): classes of the loaded pods + per-batch slot arrays
   DevBuf d_pclass, d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_fu_bitmap, d_fu_feas;
@@ -513,7 +513,7 @@ int analyse_groups(bs_ctx* c) {
   c->scratch_armed = true;
   if (c->n_uncaptured == 0 && !pn && l >= 0 && c->have_fit && c->h_gmatched[l] > 0 && c->h_gcls[l] < c->C) {
     c->steady_table = (int32_t)(c->C + c->h_gcls[l]);
-    TableDesc d{c->h_gcls[l], 0.7f};                       // descriptor of the side-stream table, written once
+    TableDesc d{c->h_gcls[l], 0.7f};                       // descriptor of the steady-state table, written once
     HIPCHK(c, hipMemcpy(b.desc + c->steady_table, &d, sizeof(d), hipMemcpyHostToDevice));
   }
   return BS_OK;
@@ -1001,7 +1001,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const int ts = c->S <= 4 ? (int)c->S : -1;
   bool commit_dirty = false;
   // No capture possible and the leader has matched pods: every scan query of the batch uses ONE known
-  // table (analyse_groups).  Build it on the side stream while the pod pre-pass and k_query run.
+  // table (analyse_groups).  It is built inside the pre-pass and query launches (extra blocks).
   const bool inline_tables = !captures_possible && c->steady_table >= 0 && c->M && P && c->cfg.enable_timing < 2;
   const uint32_t side_slot = inline_tables ? (uint32_t)c->steady_table : 0u;
   // (With request classes Filter is cheap and rides in the scan launch; early Filter is for slot = pod batches.)

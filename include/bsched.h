@@ -118,7 +118,8 @@ typedef struct bs_config {
   uint32_t eph_gate;      /* upstream feature gate LocalStorageCapacityIsolation (default 1):
                              Resource.Add counts ephemeral-storage only when on */
   uint32_t enable_timing; /* 0 off; 1 hipEvents around the scan and filter kernels of every 8th batch;
-                             2 around every kernel group of every batch (diagnostic, serialises the side stream) */
+                             2 around every kernel group of every batch (diagnostic: the table build and
+                             the scan / Filter evaluation then run as separate launches) */
   uint32_t reserved[3];
 } bs_config;
 
