@@ -243,3 +243,61 @@ def test_oracle_fit_throughput_is_reported(capsys):
     assert bits.shape == (100, 63)
     with capsys.disabled():
         print(f"\n[oracle checkFit] {2000 * 100 / dt:.3e} pairs/s on one core")
+
+
+# ---- property test: arbitrary (also malformed) strings through the marshaller and the C oracle must give what the
+# string-level restatement gives.  Strategies are biased towards the characters the upstream validators care about.
+from hypothesis import given, settings, strategies as st_
+
+_key_chars = "abzAZ09-_./ !"
+_keys = st_.one_of(st_.sampled_from(["zone", "rack", "disk", "a/b", "example.com/x", "bad key!", "", "x" * 64, "a/b/c", "-a", "k8s.io/role"]),
+                   st_.text(alphabet=_key_chars, min_size=0, max_size=6))
+_vals = st_.one_of(st_.sampled_from(["", "a", "b", "1", "12", "007", "+5", "-3", "12a", "9223372036854775807", "9223372036854775808", "no good", "x" * 64]),
+                   st_.text(alphabet="ab019+-_. ", min_size=0, max_size=5))
+_ops = st_.sampled_from(["In", "NotIn", "Exists", "DoesNotExist", "Gt", "Lt", "Foo", ""])
+_effects = st_.sampled_from(["NoSchedule", "NoExecute", "PreferNoSchedule", "", "Other"])
+_tol_ops = st_.sampled_from(["", "Equal", "Exists", "Weird"])
+_expr = st_.tuples(_keys, _ops, st_.lists(_vals, max_size=3))
+_field = st_.tuples(st_.sampled_from(["metadata.name", "metadata.namespace", ""]), st_.sampled_from(["In", "NotIn", "Exists", "Bogus"]),
+                    st_.lists(st_.sampled_from(["n0", "n1", "", "default"]), max_size=2))
+_term = st_.fixed_dictionaries({"expressions": st_.lists(_expr, max_size=3), "fields": st_.lists(_field, max_size=2)})
+_template = st_.fixed_dictionaries({
+    "node_selector": st_.dictionaries(_keys, _vals, max_size=2),
+    "required": st_.one_of(st_.none(), st_.lists(_term, max_size=3)),
+    "tolerations": st_.lists(st_.tuples(_keys, _tol_ops, _vals, _effects), max_size=3)})
+_node = st_.fixed_dictionaries({
+    "name": st_.sampled_from(["n0", "n1", "n2", ""]),
+    "labels": st_.dictionaries(_keys, _vals, max_size=4),
+    "taints": st_.lists(st_.tuples(_keys, _vals, _effects), max_size=3)})
+
+
+@settings(max_examples=300, deadline=None)
+@given(nodes=st_.lists(_node, min_size=1, max_size=4), templates=st_.lists(_template, min_size=1, max_size=3),
+       flags=st_.lists(st_.sampled_from([0, 0, 0, soa.NODE_UNSCHEDULABLE, soa.NODE_TAINT_ERR, soa.NODE_NO_NODE, soa.NODE_NIL]), min_size=4, max_size=4))
+def test_fit_property_oracle_matches_string_level(nodes, templates, flags):
+    fl = np.array(flags[: len(nodes)], np.uint8)
+    nl, ft = fitspec.marshal(nodes, templates)
+    got = soa.FitMasks(orc.fit_build(nl, fl, ft), len(nodes)).to_bool()
+    exp = np.array([[naive_fit.check_fit(t, nd, int(fl[i])) for i, nd in enumerate(nodes)] for t in templates], dtype=bool)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.gpu
+@settings(max_examples=150, deadline=None)
+@given(nodes=st_.lists(_node, min_size=1, max_size=4), templates=st_.lists(_template, min_size=1, max_size=3),
+       flags=st_.lists(st_.sampled_from([0, 0, 0, soa.NODE_UNSCHEDULABLE, soa.NODE_TAINT_ERR, soa.NODE_NO_NODE, soa.NODE_NIL]), min_size=4, max_size=4))
+def test_gpu_fit_property_matches_oracle(nodes, templates, flags):
+    capi = importlib.import_module("batch-scheduler_amd.capi")
+    n = len(nodes)
+    base = synth.make_nodes(1, n, 0, "warm")
+    base.flags[:] = np.array(flags[:n], np.uint8)
+    nl, ft = fitspec.marshal(nodes, templates)
+    ctx = _PROP_CTX.get("ctx")
+    if ctx is None:
+        ctx = _PROP_CTX["ctx"] = capi.Context(scalar_lanes=0)
+    ctx.load_nodes(base)
+    ctx.build_fit(nl, ft)
+    assert np.array_equal(ctx.read_fit().bits, orc.fit_build(nl, base.flags, ft))
+
+
+_PROP_CTX = {}
