@@ -22,10 +22,10 @@ KERNEL_PREPASS, KERNEL_LEADER, KERNEL_QUERY, KERNEL_TABLES, KERNEL_SCAN, KERNEL_
 # every symbol include/bsched.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "bs_abi_version", "bs_strerror", "bs_last_error", "bs_create", "bs_destroy",
-    "bs_nodes_load", "bs_fit_load", "bs_fit_build", "bs_fit_read", "bs_groups_load", "bs_groups_read", "bs_pods_load",
+    "bs_nodes_load", "bs_fit_load", "bs_fit_build", "bs_fit_read", "bs_groups_load", "bs_groups_read", "bs_groups_apply", "bs_pods_load",
     "bs_nodes_apply", "bs_nodes_count",
     "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
-    "bs_batch_run", "bs_batch_sync", "bs_batch_read",
+    "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_filter_rows_count",
     "bs_shard_set", "bs_reduce_external", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
     "bs_timing_reset", "bs_timing_get", "bs_kernel_name", "bs_batch_stats_get",
 ]
@@ -60,7 +60,7 @@ class BatchStats(C.Structure):
     _fields_ = [("scan_queries", C.c_uint64), ("scan_rows_executed", C.c_uint64), ("scan_evals_executed", C.c_uint64),
                 ("tables_built", C.c_uint64), ("logical_evals", C.c_uint64), ("filter_evals", C.c_uint64),
                 ("filter_distinct", C.c_uint64), ("filter_evals_executed", C.c_uint64),
-                ("scan_queries_logical", C.c_uint64), ("class_mode", C.c_uint64)]
+                ("scan_queries_logical", C.c_uint64), ("class_mode", C.c_uint64), ("fast_path", C.c_uint64), ("launches", C.c_uint64)]
 
 
 _lib = None
@@ -92,6 +92,8 @@ def load_library(path: str | None = None):
     L.bs_fit_read.argtypes = [vp, P(u32)]
     L.bs_groups_load.argtypes = [vp, P(soa.GroupsStruct)]
     L.bs_groups_read.argtypes = [vp, P(soa.GroupsStruct)]
+    L.bs_groups_apply.argtypes = [vp, P(soa.GroupDelta), u32]
+    L.bs_filter_rows_count.argtypes = [vp, P(u32)]
     L.bs_pods_load.argtypes = [vp, P(soa.PodsStruct)]
     L.bs_nodes_apply.argtypes = [vp, P(NodeDelta), u32]
     L.bs_nodes_count.argtypes = [vp, P(u32)]
@@ -211,6 +213,17 @@ class Context:
         self._chk(self._lib.bs_groups_read(self._h, C.byref(st)), "bs_groups_read")
         return out
 
+    def apply_group_deltas(self, deltas):
+        """deltas: iterable of (index, matched, status_scheduled, flags) — bs_groups_apply."""
+        deltas = list(deltas)
+        arr = (soa.GroupDelta * max(len(deltas), 1))(*[soa.GroupDelta(*map(int, d)) for d in deltas])
+        self._chk(self._lib.bs_groups_apply(self._h, arr, len(deltas)), "bs_groups_apply")
+
+    def filter_rows_count(self) -> int:
+        n = C.c_uint32(0)
+        self._chk(self._lib.bs_filter_rows_count(self._h, C.byref(n)), "bs_filter_rows_count")
+        return int(n.value)
+
     def load_pods(self, pods: soa.Pods):
         assert pods.req.shape[0] == self.L
         st = pods.as_struct()
@@ -277,17 +290,21 @@ class Context:
     def finish(self):
         self._chk(self._lib.bs_batch_finish(self._h), "bs_batch_finish")
 
-    def read(self, bitmap: bool = True, out: soa.BatchOut | None = None) -> soa.BatchOut:
-        """Copy the results of the last batch to the host (into `out` when given: no allocation)."""
+    def read(self, bitmap: bool = True, out: soa.BatchOut | None = None, rows: bool | None = None) -> soa.BatchOut:
+        """Copy the results of the last batch to the host (into `out` when given: no allocation).
+        rows: also the Filter slot rows (fl_rows / fl_slot; default: whenever the bitmap is asked for);
+        bitmap: the expanded pods x nodes bitmap (opt-in on the library side)."""
+        if rows is None:
+            rows = bitmap
         if out is None:
-            out = soa.BatchOut.alloc(self.p, self.g, self.n, bitmap=bitmap)
+            out = soa.BatchOut.alloc(self.p, self.g, self.n, bitmap=bitmap, rows_cap=max(self.filter_rows_count(), 1) if rows else 0)
         st = out.as_struct()
         self._chk(self._lib.bs_batch_read(self._h, C.byref(st)), "bs_batch_read")
         return out
 
-    def batch(self, stages: int = soa.STAGE_ALL, bitmap: bool = True) -> soa.BatchOut:
+    def batch(self, stages: int = soa.STAGE_ALL, bitmap: bool = True, rows: bool | None = None) -> soa.BatchOut:
         self.run(stages)
-        return self.read(bitmap=bitmap)
+        return self.read(bitmap=bitmap, rows=rows)
 
     # -- sharding / measurement
     def set_shard(self, rank: int, nranks: int):

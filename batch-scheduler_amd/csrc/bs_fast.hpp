@@ -1,0 +1,455 @@
+// bs_fast.hpp — the steady-state batch in THREE launches.
+//
+// Steady state = every group already has its pod and its MinResources (nothing a pod derives can depend on
+// its queue position: request classes stand for the pods) and the leader findMaxPG returns has matched pods
+// (every scan query of the batch is a reservation check against ONE table: core.go:157-166).  That is the
+// state a scheduler lives in once each gang has been seen; everything else takes the general chain of
+// bs_kernels.hpp.
+//
+// What makes three launches enough:
+//   * everything that depends on the pods alone is derived when the pods are loaded (bs_pods_load,
+//     k_pod_pairs): request classes, per-group first pod / first non-permitted pod / first owner, and the
+//     (group, request class) pairs of each group.  The per-batch pre-pass with its grid-wide minima is gone.
+//   * findMaxPG depends on the group state alone: it runs when the groups are loaded / patched
+//     (bs_groups_load, bs_groups_apply) and leaves leader, panic flag and the steady table's descriptor on
+//     the device.
+//   * nothing is reset per batch: slots carry the stamp of the batch that wrote them, the "first pod that
+//     ..." minima are 64-bit atomicMin keys with the inverted batch number in the high word (a later batch
+//     always wins).
+//   * the running-sum table stays CHUNK-LOCAL: the scan adds a chunk's offset while the rows travel to LDS
+//     (scan_core<S, true>), so the fix-up pass and its launch dependency disappear.  The last table block to
+//     finish turns the chunk totals into offsets (ticket, as the quorum tail does).
+//   * a rejection (core.go:161-165) is a property of the request class, so the deny replay (core.go:105-110)
+//     of a pod is "is there an earlier pod of my group whose class was rejected": a walk over the group's
+//     (group, class) pairs — no grid-wide first_reject minimum, k_reject is gone.
+//   * Filter's answer per (pod, node) is a bit of the pod's slot row; the pods x nodes bitmap is not
+//     materialised (k_filter_expand runs only when a caller asks for it).
+//
+//   launch A  k_fast_query_tables   per pod: decisions that need no scan, its scan query and Filter
+//                                   parameters into the class slots | chunk-local running sums of the table
+//   launch B  k_fast_scan_filter    node scan per scan slot | computeResourceSatisfied per Filter slot x node
+//   launch C  k_fast_final          REJECT / deny replay / stale leader, Filter code + slot + feasible count
+//                                   per pod, per-group admit counts, last block: quorum predicate core.go:303
+#pragma once
+
+#include "bs_kernels.hpp"
+
+namespace bs {
+
+// ------------------------------------------------------------------------------------------------
+// bs_pods_load: what the batch needs from the pods alone.
+//   gstat[0][g] first pod of group g (shard ownership)           gstat[1][g] first pod without LAST_PERMITTED
+//   gstat[2][g] first such pod with OwnerReferences              gstat[3][g] head of the group's pair chain
+// A pair = (group, request class); its id is the index of its representative pod.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* pclass, unsigned long long* slots, uint32_t mask, uint32_t hash_keep,
+                            uint32_t* gstat, uint32_t* ppair, uint32_t* pair_next) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pods.p) return;
+  const int32_t gi = pods.group[i];
+  if (gi < 0 || (uint32_t)gi >= G) { ppair[i] = BS_INF; return; }
+  atomicMin(&gstat[gi], i);
+  if (!(pods.flags[i] & BS_POD_LAST_PERMITTED)) {
+    atomicMin(&gstat[(size_t)G + gi], i);
+    if (pods.owner[i] != 0) atomicMin(&gstat[(size_t)2 * G + gi], i);
+  }
+  const uint32_t c = pclass[i];
+  const uint64_t h = mix64(((uint64_t)(uint32_t)gi << 32) | c);
+  bool winner;
+  const uint32_t rep = dedupe_insert(slots, mask, hash_keep, h, i, [&](uint32_t o) { return o < pods.p && pods.group[o] == gi && pclass[o] == c; }, winner);
+  ppair[i] = rep;
+  if (winner) pair_next[i] = atomicExch(&gstat[(size_t)3 * G + gi], i);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bs_groups_load / bs_groups_apply: findMaxPG for the loaded state + what the host wants to know about it
+// (read back asynchronously; bs_batch_run waits for it only if it has not arrived yet).
+//   info[0] leader (-1 none)  info[1] panic  info[2] steady table id (-1: none)  info[3] sequence tag
+// ------------------------------------------------------------------------------------------------
+struct GroupDelta { uint32_t index, matched, status_scheduled, flags; };
+
+__global__ void k_groups_apply(const GroupDelta* d, uint32_t n, uint32_t* matched, uint32_t* status_scheduled, uint8_t* flags) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const GroupDelta x = d[t];
+  matched[x.index] = x.matched;
+  status_scheduled[x.index] = x.status_scheduled;
+  flags[x.index] = (uint8_t)x.flags;
+}
+
+__global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, BatchDev b, uint32_t C, int32_t tag, int32_t* info) {
+  if (gr.g) leader_block(gr, b, 0);
+  if (threadIdx.x == 0) {
+    int32_t l = -1, pn = 0, steady = -1;
+    if (gr.g) { l = b.leader_epoch[0]; pn = b.panic_epoch[0]; }
+    else { b.leader_epoch[0] = -1; b.panic_epoch[0] = 0; }
+    if (!pn && l >= 0 && C && gr.matched[l] > 0 && (gr.flags[l] & BS_GROUP_HAS_POD) && gr.cls[l] < C) {
+      steady = (int32_t)(C + gr.cls[l]);
+      TableDesc d;
+      d.cls = gr.cls[l];
+      d.pct = 0.7f;                                   // core.go:161
+      b.desc[steady] = d;
+    }
+    info[0] = l; info[1] = pn; info[2] = steady; info[3] = tag;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch A, table part: chunk-local running sums (core.go:602,621 restarted at every 256-row chunk), chunk
+// totals, per 64-row group max / min of the local sums, per chunk first row of every scalar key; the last
+// block to finish turns totals into offsets and reduces kp.
+// ------------------------------------------------------------------------------------------------
+constexpr int kOffBatch = 128;                     // chunks per LDS batch of the tail
+
+template <int TS>
+__device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk,
+                                                  uint32_t nchunks) {
+  __shared__ unsigned long long s_wtot[BS_MAX_LANES][4];
+  __shared__ uint32_t s_kp[BS_MAX_SCALARS];
+  __shared__ uint32_t s_last;
+  __shared__ unsigned long long s_tot[kOffBatch][16];
+  __shared__ uint32_t s_kpv[kOffBatch][16];
+  const uint32_t k = chunk * kTblChunk + threadIdx.x;
+  const bool valid = k < nd.m;
+  const uint32_t n = valid ? nd.kmap[k] : 0u;
+  const TableDesc d = *forced;
+  const Shape<TS> sh(prm.S);
+  const uint32_t L = sh.L(), S = sh.S(), LP = prm.LP;
+  int64_t* T = b.tables;
+  const uint32_t fw = nd.fit[(size_t)d.cls * nd.fit_words + (n >> 5)];
+  const uint8_t fl = nd.flags[n];
+  const uint32_t ap = nd.apres[n], rp = nd.rpres[n];
+  int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    if (j < L) {
+      al[j] = nd.alloc[(size_t)j * nd.stride + n];
+      rq[j] = nd.req[(size_t)j * nd.stride + n];
+    }
+  }
+  const bool fit = valid && ((fw >> (n & 31u)) & 1u) && !(fl & BS_NODE_TAINT_ERR);
+  const uint32_t pres = fit ? (ap & rp) : 0u;
+  if (threadIdx.x < BS_MAX_SCALARS) s_kp[threadIdx.x] = BS_INF;
+  unsigned long long incl[BS_MAX_LANES];
+  const int w = wave_id();
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    if (j < L) {
+      const bool live = fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
+      const unsigned long long left = live ? (unsigned long long)wsub(scale_f32(al[j], d.pct), rq[j]) : 0ull;
+      incl[j] = wave_incl_scan_add<unsigned long long>(left);
+      if (lane_id() == 63) s_wtot[j][w] = incl[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    if (j < L) {
+      unsigned long long off = 0, tot = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned long long x = s_wtot[j][i];
+        if (i < w) off += x;
+        tot += x;
+      }
+      incl[j] += off;
+      if (valid) T[(size_t)k * LP + j] = (int64_t)incl[j];
+      if (threadIdx.x == 0) b.chunk_tot[(size_t)chunk * 16 + j] = tot;
+    } else {
+      if (j < LP && valid) T[(size_t)k * LP + j] = INT64_MAX;
+      if (threadIdx.x == 0) b.chunk_tot[(size_t)chunk * 16 + j] = 0ull;
+    }
+  }
+  // per 64-row group: max and min of the local sums per fixed lane (the scan prunes with max + chunk offset)
+  {
+    const uint32_t grp = k >> 6;
+    const bool grp_valid = (chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t mx = wave_max_i64(valid ? (int64_t)incl[j] : INT64_MIN);
+      const int64_t mn = wave_min_i64(valid ? (int64_t)incl[j] : INT64_MAX);
+      if (lane_id() == 0 && grp_valid) {
+        b.gmm8[(size_t)grp * 8 + j] = mx;
+        b.gmm8[(size_t)grp * 8 + 4 + j] = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+    if (s < S) {
+      const unsigned long long mk = __ballot(valid && (pres & (1u << s)));
+      if (mk && lane_id() == 0) atomicMin(&s_kp[s], chunk * kTblChunk + (uint32_t)(threadIdx.x & ~63u) + (uint32_t)(__ffsll((long long)mk) - 1));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) b.chunk_kp[(size_t)chunk * 16 + threadIdx.x] = threadIdx.x < BS_MAX_SCALARS ? s_kp[threadIdx.x] : BS_INF;
+  // ---- publish, take a ticket; the last chunk block finishes the table's side arrays
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(&b.ticket[1], 1u) == nchunks - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    b.ticket[1] = 0;
+  }
+  __syncthreads();
+  unsigned long long acc = 0;
+  uint32_t kpm = BS_INF;
+  for (uint32_t c0 = 0; c0 < nchunks; c0 += kOffBatch) {
+    const uint32_t nb = min((uint32_t)kOffBatch, nchunks - c0);
+    for (uint32_t e = threadIdx.x; e < nb * 16u; e += kTblChunk) {
+      s_tot[e >> 4][e & 15u] = __hip_atomic_load(&b.chunk_tot[(size_t)c0 * 16 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_kpv[e >> 4][e & 15u] = __hip_atomic_load(&b.chunk_kp[(size_t)c0 * 16 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      for (uint32_t c = 0; c < nb; ++c) {
+        b.chunk_off[(size_t)(c0 + c) * 16 + threadIdx.x] = acc;
+        acc += s_tot[c][threadIdx.x];
+        kpm = min(kpm, s_kpv[c][threadIdx.x]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 16) b.kp[threadIdx.x] = kpm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch A, pod part (core.go:88-167 up to the node scan).  Differences to query_thread: no capture epochs
+// (one findMaxPG result for the batch, from the group load), the per-group minima come from the pod load,
+// every scan query is a reservation check -> slot = request class, slots are stamped, not reset.
+// ------------------------------------------------------------------------------------------------
+template <int TS>
+__device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i,
+                                                  uint32_t nthreads) {
+  const Shape<TS> sh(prm.S);
+  for (uint32_t g = i; g < gr.g; g += nthreads) b.admit[g] = 0;        // consumed by launch C
+  if (i < 8 && prm.collect_stats) b.stats[i] = 0;
+  const bool valid = i < pods.p;
+  const uint32_t gate = prm.eph_gate;
+  uint8_t code = BS_PF_PASS_NOT_GROUPED, st = 0;
+  bool has_q = false;
+  Res q;
+  res_zero(q, sh);
+  const int32_t leader0 = b.leader_epoch[0];
+  if (valid) {
+    const int32_t gi = pods.group[i];
+    const bool grouped = gi >= 0 && (uint32_t)gi < gr.g;
+    // shard ownership: all pods of a group live on the rank of the group's first pod
+    const uint32_t anchor = grouped ? b.first_pod_s[gi] : i;
+    if ((uint32_t)(((uint64_t)anchor * prm.nranks) / pods.p) == prm.rank) st |= ST_OWNED;
+    if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                         // core.go:89-92
+    else if (pods.flags[i] & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;      // :95-98
+    else if (!grouped) code = BS_PF_ERR_PG_NOT_FOUND;                                      // :100-103
+    else if (gr.flags[gi] & BS_GROUP_DENIED) code = BS_PF_ERR_DENIED;                      // :105-110
+    else {
+      st |= ST_ELIG;
+      const uint32_t g = (uint32_t)gi;
+      bool occ_err = false;                                                                // :494-511 in queue order
+      const uint64_t own = pods.owner[i];
+      const uint64_t occ0 = gr.occupied[g];
+      if (occ0 != 0) occ_err = (own == 0) || (own != occ0);
+      else {
+        const uint32_t fo = b.first_owner_s[g];          // the group is not denied: every non-permitted pod of it is eligible
+        if (fo != BS_INF && i > fo) { const uint64_t occ = pods.owner[fo]; occ_err = (own == 0) || (own != occ); }
+      }
+      if (occ_err) code = BS_PF_ERR_OCCUPIED;                                              // :113-115
+      else if (b.panic_epoch[0]) code = BS_PF_PANIC_DIV0;                                  // :716-717
+      else {
+        st |= ST_REACH6;                                                                   // :118-123
+        if (leader0 < 0) code = BS_PF_PASS_NO_MAX;                                         // :127-130
+        else if (leader0 == gi) code = BS_PF_PASS_IS_MAX;                                  // :150-155 (leader.matched > 0 on this path)
+        else {                                                                             // :157-166
+          Res mr;
+          const bool have = group_minres_at(gr, pods, b, (uint32_t)leader0, i, sh, gate, mr);
+          pre_allocated(gr, (uint32_t)leader0, (int64_t)gr.matched[leader0], have, mr, sh, gate, q);
+          Res cur;
+          pod_require(pods, i, sh, gate, cur);
+          res_add(q, cur, sh, gate);
+          code = BS_PF_PASS_RESERVE_FITS;                                                  // tentative
+          has_q = (st & ST_OWNED) != 0;
+        }
+      }
+    }
+    if (has_q) st |= ST_QUERY;
+    b.tcode[i] = code;
+    b.stage[i] = st;
+  }
+  {
+    // first pod of the queue that reaches findMaxPG (lanes are in queue order); it really does: a replayed
+    // deny needs an earlier, reaching, rejected pod
+    const unsigned long long rb = __ballot(valid && (st & ST_REACH6));
+    if (rb && lane_id() == __ffsll((long long)rb) - 1) atomicMin(b.first_reach64, ((unsigned long long)prm.seq_inv << 32) | i);
+  }
+  // Filter slots: class c with the batch's leader, class c + K with the leader carried into the batch
+  if (prm.run_filter && valid && (st & ST_OWNED) && BS_PF_IS_PASS(code)) {
+    const uint32_t c = b.pclass[i], K = *b.kclass;
+    filter_params_for<TS>(pods, gr, b, prm, i, code, leader0, c, true, false);
+    filter_params_for<TS>(pods, gr, b, prm, i, code, prm.sop_leader0, c + K, true, false);
+  }
+  if (has_q) {
+    uint32_t absok = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+      if (s < sh.S()) {
+        const bool pres = q.present & (1u << s);
+        if (!pres || q.v[4 + s] == 0) absok |= 1u << s;       // core.go:688-692
+        if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
+      }
+    }
+    const uint32_t slot = b.pclass[i];
+    int64_t* dst = b.qreq_s + (size_t)slot * prm.LP;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < prm.LP) dst[j] = j < sh.L() ? q.v[j] : INT64_MIN;
+    b.qflags_s[slot] = q.present | (absok << 16);
+    b.qtab_s[slot] = 0;
+    b.first_row[slot] = BS_INF;                               // every writer stores the same; launch B takes minima
+    b.qstamp_s[slot] = prm.stamp;
+    b.qpos[i] = slot;
+    atomicMin(&b.pair_firstq[b.ppair[i]], ((unsigned long long)prm.seq_inv << 32) | i);
+  }
+  if (prm.collect_stats) {
+    const unsigned long long hq = __ballot(has_q);
+    if (lane_id() == 0 && hq) atomicAdd((unsigned long long*)&b.stats[2], (unsigned long long)__popcll(hq));
+  }
+}
+
+// block layout: [0, query_blocks) pods | query_blocks + c: table chunk c
+template <int TS>
+__global__ __launch_bounds__(kTblChunk) void k_fast_query_tables(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm,
+                                                                 const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks) {
+  if (blockIdx.x < query_blocks) fast_query_thread<TS>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
+  else tables_local_fast<TS>(nd, bt, prm, forced, blockIdx.x - query_blocks, nchunks);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch B: node scan over the class slots of this batch (chunk-local table + offsets) and Filter
+// evaluation over the Filter slots of this batch.  `bt` = the batch view with the table arrays shifted to
+// the steady table's slot.
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap,
+                                                          uint32_t scan_blocks, uint32_t filter_waves, uint32_t ustride) {
+  __shared__ int64_t s_rows[4][64][4 + S];
+  if (blockIdx.x < scan_blocks)
+    scan_loop<S, true>(bt, prm, m, jcap, 0u, 0u, 1u, blockIdx.x, scan_blocks, s_rows[wave_id()]);
+  else
+    filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - scan_blocks, gridDim.x - scan_blocks, prm.stamp);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch C: final codes in queue order, per pod independent.
+//   deny replay   pod i is behind a rejected pod of its group iff some (group, class) pair of the group has a
+//                 rejected class slot and its first querying pod precedes i (core.go:142,163 -> :105-110)
+//   stale leader  sop.maxFinishedPG after the pod's PreFilter = the batch's findMaxPG result from the first
+//                 pod that reaches findMaxPG on, the value carried into the batch before it (core.go:121)
+//   Filter        code, slot and feasible-node count of the pod from its class slot
+//   Permit        per-group admit counts; last block: quorum predicate core.go:303
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm) {
+  __shared__ uint32_t s_last;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  bool admit = false;
+  uint32_t ag = 0;
+  if (i < pods.p) {
+    uint8_t code = b.tcode[i];
+    const uint8_t st = b.stage[i];
+    const int32_t gi = pods.group[i];
+    const unsigned long long fr64 = *b.first_reach64;
+    const uint32_t first_reach = (uint32_t)(fr64 >> 32) == prm.seq_inv ? (uint32_t)fr64 : BS_INF;
+    uint32_t fk = BS_K_NOT_SCANNED;
+    if (st & ST_OWNED) {
+      bool denied = false;
+      if (st & ST_ELIG) {
+        uint32_t fr = BS_INF;
+        for (uint32_t r = b.pair_head[gi]; r != BS_INF; r = b.pair_next[r]) {
+          const unsigned long long pq = b.pair_firstq[r];
+          if ((uint32_t)(pq >> 32) != prm.seq_inv) continue;           // no pod of the pair had a query in this batch
+          const uint32_t fq = (uint32_t)pq;
+          if (fq < fr && b.first_row[b.pclass[r]] == BS_INF) fr = fq;  // the pair's class was rejected
+        }
+        denied = fr < i;
+        if (prm.commit && fr == i) b.fast_reject[gi] = fr;             // AddToDenyCache, kept for k_fast_commit
+      }
+      if (denied) code = BS_PF_ERR_DENIED;
+      else if (st & ST_QUERY) {
+        const uint32_t row = b.first_row[b.qpos[i]];
+        if (row == BS_INF) { code = BS_PF_REJECT_RESERVE; fk = BS_K_NONE; }                // core.go:161-165
+        else fk = nd.kmap[row];
+      }
+    } else {
+      code = BS_PF_NOT_OWNED;
+    }
+    b.pf_code[i] = code;
+    b.pf_first_k[i] = fk;
+    const bool reached = i >= first_reach;
+    const int32_t leader = reached ? b.leader_epoch[0] : prm.sop_leader0;
+    b.pf_leader[i] = leader;
+    const bool pass = code != BS_PF_NOT_OWNED && BS_PF_IS_PASS(code);
+    uint32_t feasible = 1u;
+    uint8_t fl = BS_FL_NOT_RUN;
+    if (prm.run_filter) {
+      uint32_t slot = 0;
+      if (pass) {
+        if (gi == BS_POD_NOT_GROUPED) fl = BS_FL_PASS_NOT_GROUPED;                         // core.go:171-174
+        else if (gi < 0 || (uint32_t)gi >= gr.g) fl = BS_FL_ERR_PG_NOT_FOUND;              // :177-180
+        else if (leader < 0) fl = BS_FL_PANIC_NIL_MAX;                                     // :525
+        else if (leader == gi) fl = BS_FL_PASS_IS_MAX;                                     // :531-535
+        else { fl = BS_FL_EVALUATED; slot = b.pclass[i] + (reached ? 0u : *b.kclass); }    // every group has MinResources here
+      }
+      feasible = fl == BS_FL_EVALUATED ? b.fu_feas[slot] : (fl < 16u ? nd.n : 0u);
+      b.fu_slot[i] = slot;
+      b.fl_feasible[i] = feasible;
+    } else {
+      b.fl_feasible[i] = 0;
+    }
+    b.fl_code[i] = fl;
+    b.fflags[i] = (uint32_t)fl << 8;
+    if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) { admit = true; ag = (uint32_t)gi; }
+  }
+  if (!prm.do_tally) return;
+  wave_aggregated_inc(b.admit, ag, admit);
+  if (!prm.do_ready) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(&b.ticket[0], 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    b.ticket[0] = 0;
+  }
+  __syncthreads();
+  for (uint32_t gg = threadIdx.x; gg < gr.g; gg += 256u) {
+    const uint32_t have = gr.matched[gg] + __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b.ready[gg] = have >= (uint32_t)(gr.min_member[gg] - gr.status_scheduled[gg]) ? 1 : 0;
+  }
+}
+
+// BS_BATCH_COMMIT on the fast path: every group has its pod and MinResources already, so what sequential
+// PreFilter calls would leave behind is OccupiedBy (core.go:494-500) and the deny entries (:142,:163).
+__global__ void k_fast_commit(PodsDev pods, BatchDev b, uint8_t* gflags, uint64_t* gocc, uint32_t G) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  uint8_t fl = gflags[g];
+  const uint32_t fe = (fl & BS_GROUP_DENIED) ? BS_INF : b.first_np_s[g];
+  const uint32_t fr = b.fast_reject[g];
+  if (fe != BS_INF && gocc[g] == 0) {
+    const uint32_t fo = b.first_owner_s[g];
+    if (fo != BS_INF && fo <= fr) gocc[g] = pods.owner[fo];
+  }
+  if (fr != BS_INF) fl |= BS_GROUP_DENIED;
+  gflags[g] = fl;
+}
+
+}  // namespace bs

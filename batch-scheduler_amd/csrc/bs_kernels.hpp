@@ -129,6 +129,19 @@ struct BatchDev {
   uint32_t* uflags;         // [filter slots] as fflags; fl_code NOT_RUN = slot unused
   uint64_t* fu_bitmap;      // [W][filter slots] rows of the slots
   uint32_t* fu_feas;        // [filter slots] feasible-node counts of the slots
+  // ---- steady-state fast path (bs_fast.hpp): nothing here is reset per batch
+  uint32_t* qstamp_s;       // [scan slots] batch stamp of the slot's last writer (slot live iff == prm.stamp)
+  const uint32_t* first_pod_s;    // [G] min pod index of the group                               } derived from the pods alone
+  const uint32_t* first_np_s;     // [G] min pod index without BS_POD_LAST_PERMITTED              } at bs_pods_load
+  const uint32_t* first_owner_s;  // [G] min such pod index that has OwnerReferences              } (k_pod_pairs)
+  const uint32_t* pair_head;      // [G] first (group, request class) pair of the group, BS_INF none: a chain through pair_next
+  const uint32_t* ppair;          // [P] pod -> its pair (= index of the pair's representative pod)
+  const uint32_t* pair_next;      // [P] valid at representatives
+  unsigned long long* pair_firstq;// [P] at representatives: (~batch_seq << 32) | first pod of the pair with a scan query
+  unsigned long long* first_reach64;  // [1] (~batch_seq << 32) | first pod that reaches findMaxPG
+  unsigned long long* chunk_off;  // [slots][nchunks][16] exclusive prefix of chunk_tot (tables stay chunk-local)
+  int64_t* gmm8;            // [slot][ceil(mcap/64)][8] per 64-row group of the chunk-local table: max[4], min[4]
+  uint32_t* fast_reject;    // [G] first rejected pod of the group (only maintained for BS_BATCH_COMMIT)
   // outputs
   uint8_t* pf_code;
   uint32_t* pf_first_k;
@@ -153,6 +166,10 @@ struct BatchParams {
   uint32_t scan_slots_cap, filter_slots_cap;   // entries to reset per batch
   uint32_t collect_stats;
   uint32_t mcap;               // table row capacity
+  uint32_t stamp;              // fast path: slot stamp of this batch (never 0)
+  uint32_t seq_inv;            // fast path: ~batch sequence number (64-bit atomicMin keys: a newer batch always wins)
+  uint32_t commit;             // fast path: keep fast_reject for k_fast_commit
+  uint32_t do_tally, do_ready; // fast path: stages of the final launch
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1058,7 +1075,11 @@ __device__ __forceinline__ void row_all(const unsigned long long (&nf)[Q], uint3
 // are.  A group's 64 rows are fetched with ONE vector load per lane (lane = row) and parked in this wave's
 // LDS slice `rows`; the row loop reads them back with uniform-address (broadcast) ds_reads, so no memory
 // round trip sits inside the loop.
-template <int S>
+// LOCAL: the table holds chunk-local running sums (fast path: no fix-up pass).  A row's final value is
+// local + chunk_off[chunk] in wrapping arithmetic; the offset is added while the group's rows travel to LDS,
+// and a group is pruned only when max + off and min + off both stay in range (then no row of it wraps and
+// max + off bounds them all) and the bound is below the tile's smallest request.
+template <int S, bool LOCAL = false>
 __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, uint32_t pos, bool valid,
                                           const int64_t (&r)[1][4 + S], uint32_t qf, uint32_t share, uint32_t J, int64_t (*rows)[4 + S]) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
@@ -1085,8 +1106,21 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
     bool dead = true;
     const uint32_t g = c0 + (uint32_t)lane;
     if (g < ngroups) {
-      const int64_t* gm = b.gmax + ((size_t)slot * gstride + g) * 4;
-      dead = gm[0] < rmin[0] || gm[1] < rmin[1] || gm[2] < rmin[2] || gm[3] < rmin[3];
+      if constexpr (LOCAL) {
+        const int64_t* gm = b.gmm8 + ((size_t)slot * gstride + g) * 8;
+        const unsigned long long* of = b.chunk_off + ((size_t)slot * ((prm.mcap + kTblChunk - 1u) / kTblChunk) + (g >> 2)) * 16;
+        dead = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          long long hi, lo;
+          const bool o1 = __builtin_saddll_overflow((long long)gm[j], (long long)of[j], &hi);
+          const bool o2 = __builtin_saddll_overflow((long long)gm[4 + j], (long long)of[j], &lo);
+          if (!o1 && !o2 && hi < rmin[j]) dead = true;
+        }
+      } else {
+        const int64_t* gm = b.gmax + ((size_t)slot * gstride + g) * 4;
+        dead = gm[0] < rmin[0] || gm[1] < rmin[1] || gm[2] < rmin[2] || gm[3] < rmin[3];
+      }
     }
     unsigned long long live = __ballot(!dead);
     while (live) {
@@ -1104,6 +1138,11 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
         const int64_t* src = T + (size_t)row * LP;
 #pragma unroll
         for (int j = 0; j < L; ++j) mine_row[j] = src[j];
+        if constexpr (LOCAL) {
+          const unsigned long long* of = b.chunk_off + ((size_t)slot * ((prm.mcap + kTblChunk - 1u) / kTblChunk) + (g0 / kTblChunk)) * 16;
+#pragma unroll
+          for (int j = 0; j < L; ++j) mine_row[j] = (int64_t)((unsigned long long)mine_row[j] + of[j]);
+        }
       }
       if (!loaded) {                             // first live group of this wave
         loaded = true;
@@ -1177,7 +1216,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 // Work loop: item = (tile of 64 request slots, share j of J).  The slots of a tile that use the same
 // table are scanned together (steady state: one table for everything); consecutive waves take different
 // tiles with the same share.  The grid is fixed; the slot count is read on the device.
-template <int S>
+template <int S, bool LOCAL = false>
 __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t jcap, uint32_t nslots_fixed,
                                           uint32_t ngroups_g, uint32_t tsplit, uint32_t bx, uint32_t nblocks, int64_t (*rows)[4 + S]) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
@@ -1193,7 +1232,10 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
     const uint32_t rest = w / ntiles, tile = w - rest * ntiles;
     const uint32_t share = rest / tsplit, ts = rest - share * tsplit;
     const uint32_t pos = tile * 64u + (uint32_t)lane;
-    const int32_t tab = pos < nslots ? b.qtab_s[pos] : -1;
+    int32_t tab = pos < nslots ? b.qtab_s[pos] : -1;
+    if constexpr (LOCAL) {                       // fast path: a slot is live iff a pod of THIS batch wrote it
+      if (pos < nslots && b.qstamp_s[pos] != prm.stamp) tab = -1;
+    }
     unsigned long long todo = __ballot(tab >= 0);
     if (!todo) continue;
     int64_t r[1][L];
@@ -1212,7 +1254,7 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
     while (todo) {
       const int32_t t0 = __builtin_amdgcn_readlane(tab, __ffsll((long long)todo) - 1);
       const bool member = tab == t0;
-      if (turn == ts) scan_core<S>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows);
+      if (turn == ts) scan_core<S, LOCAL>(b, prm, m, LOCAL ? 0u : (uint32_t)t0, pos, member, r, qf, share, J, rows);
       turn = turn + 1u == tsplit ? 0u : turn + 1u;
       todo &= ~__ballot(member);
     }
@@ -1288,7 +1330,8 @@ __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const Gro
     int64_t* dst = b.uparams + (size_t)slot * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { dst[j] = R[j]; dst[4 + j] = M[j]; }
-    b.uflags[slot] = ffw;
+    b.uflags[slot] = ffw | (prm.stamp << 16);      // fast path: stamped instead of reset per batch (prm.stamp == 0 otherwise)
+    if (prm.stamp) b.fu_feas[slot] = 0;
   }
 }
 
@@ -1483,9 +1526,10 @@ __device__ __forceinline__ void filter_pod_loop(uint32_t np, const int64_t (*sR)
   }
 }
 
+// stamp != 0 (fast path): a slot is in use iff the stamp in bits 16.. of its flags word is this batch's.
 template <int NB>
 __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ustride, uint32_t ptile,
-                                            uint32_t w0, uint32_t w1) {
+                                            uint32_t w0, uint32_t w1, uint32_t stamp = 0) {
   static_assert(NB == 2, "the inner statement handles two node blocks");
   typedef const __attribute__((address_space(4))) uint32_t* cflag_t;
   const int lane = lane_id();
@@ -1496,7 +1540,8 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
   // unless the tile straddles a first-pod capture.)  Then case 3 is one mask per node block.
   const bool mine = (uint32_t)lane < np;
   const uint32_t src = p0 + (uint32_t)lane;                       // lanes are request slots
-  const uint32_t myff = mine ? b.uflags[src] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  uint32_t myff = mine ? b.uflags[src] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  if (stamp) myff = (myff >> 16) == stamp ? (myff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
   const uint32_t myfl = myff >> 8;
   const bool ev = myfl == BS_FL_EVALUATED;
   int64_t M[4] = {0, 0, 0, 0};
@@ -1635,7 +1680,8 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
       // generic path: per-pod leader request (tile straddles a capture); plain ballots
       for (uint32_t pp = 0; pp < np; ++pp) {
         const uint32_t p = p0 + pp;
-        const uint32_t ff = FF[p];
+        uint32_t ff = FF[p];
+        if (stamp) ff = (ff >> 16) == stamp ? (ff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
         const uint32_t fl = ff >> 8;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -1678,7 +1724,7 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
 // give the whole grid something to do.  ustride = row stride of fu_bitmap (slot capacity).
 template <int NB>
 __device__ __forceinline__ void filter_loop(const PodsDev& pods, const NodesDev& nd, const BatchDev& b, uint32_t target_waves, uint32_t use_classes,
-                                            uint32_t ustride, uint32_t collect_stats, uint32_t bx, uint32_t nblocks) {
+                                            uint32_t ustride, uint32_t collect_stats, uint32_t bx, uint32_t nblocks, uint32_t stamp = 0) {
   const uint32_t U = use_classes ? 2u * __builtin_amdgcn_readfirstlane(*b.kclass) : pods.p;
   const uint32_t W = (nd.n + 63u) / 64u;
   if (!U || !W) return;
@@ -1692,10 +1738,11 @@ __device__ __forceinline__ void filter_loop(const PodsDev& pods, const NodesDev&
     const uint32_t chunk = it / tiles, tile = it - chunk * tiles;                   // neighbours share the node run
     if (collect_stats && chunk == 0) {
       const uint32_t sl = tile * 64u + (uint32_t)lane_id();
-      const unsigned long long evs = __ballot(sl < U && (b.uflags[sl] >> 8) == BS_FL_EVALUATED);
+      const uint32_t uf = sl < U ? b.uflags[sl] : 0u;
+      const unsigned long long evs = __ballot(sl < U && ((uf >> 8) & 0xFFu) == BS_FL_EVALUATED && (!stamp || (uf >> 16) == stamp));
       if (lane_id() == 0 && evs) atomicAdd((unsigned long long*)&b.stats[3], (unsigned long long)__popcll(evs));
     }
-    filter_item<NB>(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw));
+    filter_item<NB>(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), stamp);
   }
 }
 template <int NB>
@@ -1719,20 +1766,16 @@ __global__ __launch_bounds__(256) void k_scan_filter(PodsDev pods, NodesDev nd, 
 }
 
 // Early Filter ran on the tentative PreFilter verdict.  The framework never calls Filter for a pod that
-// PreFilter turned down, so such a pod's row is void: code NOT_RUN, no feasible node, zero bitmap
-// words.  grid.y splits the bitmap words so the scattered stores come from many CUs.
-__global__ __launch_bounds__(256) void k_void_rows(PodsDev pods, BatchDev b, uint32_t words, uint32_t words_per_block) {
+// PreFilter turned down, so such a pod's result is void: code NOT_RUN, no feasible node (its slot row, if it
+// has one of its own, is simply never referenced).
+__global__ __launch_bounds__(256) void k_void_rows(PodsDev pods, BatchDev b) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= pods.p) return;
   const uint8_t pf = b.pf_code[i];
   if (pf != BS_PF_NOT_OWNED && BS_PF_IS_PASS(pf)) return;
-  if ((b.fflags[i] >> 8) == BS_FL_NOT_RUN) return;            // the early pass already left it out
-  if (blockIdx.y == 0) {
-    b.fl_code[i] = BS_FL_NOT_RUN;
-    b.fl_feasible[i] = 0;
-  }
-  const uint32_t w0 = blockIdx.y * words_per_block, w1 = min(words, w0 + words_per_block);
-  for (uint32_t w = w0; w < w1; ++w) b.fl_bitmap[(size_t)w * pods.p + i] = 0;
+  if (((b.fflags[i] >> 8) & 0xFFu) == BS_FL_NOT_RUN) return;   // the early pass already left it out
+  b.fl_code[i] = BS_FL_NOT_RUN;
+  b.fflags[i] = (uint32_t)BS_FL_NOT_RUN << 8;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1790,47 +1833,53 @@ __device__ __forceinline__ void tally_block(const PodsDev& pods, const GroupsDev
   }
 }
 
-__global__ __launch_bounds__(kTallyBlock) void k_tally(PodsDev pods, GroupsDev gr, BatchDev b, uint32_t run_filter, uint32_t do_ready,
-                                                        uint32_t rearm) {
-  __shared__ uint32_t s_last;
-  const uint32_t i = blockIdx.x * kTallyBlock + threadIdx.x;
-  const uint32_t feasible = (run_filter && i < pods.p) ? b.fl_feasible[i] : 1u;
-  tally_block<kTallyBlock>(pods, gr, b, i, feasible, do_ready, rearm, blockIdx.x, gridDim.x, &s_last);
+// Nodes on which Filter passes for pod i, from its slot: pods Filter passes without looking at a node (not
+// grouped, leader itself, no MinResources: core.go:171-174, :531-535, :542-544) pass on every list entry;
+// pods it errors for, or never sees, pass nowhere.
+__device__ __forceinline__ uint32_t pod_feasible(const NodesDev& nd, const BatchDev& b, uint32_t i) {
+  const uint32_t fl = (b.fflags[i] >> 8) & 0xFFu;
+  if (fl == BS_FL_EVALUATED) return b.fu_feas[b.fu_slot[i]];
+  return fl < 16u ? nd.n : 0u;
 }
 
-// Rows of all pods from the rows of the distinct requests.  Pods Filter passes without looking at a node
-// (not grouped, leader itself, no MinResources: core.go:171-174, :531-535, :542-544) pass on every list
-// entry; pods it errors for, or never sees, pass nowhere.  Pure streaming: P x ceil(N/64) words out.
-// tally != 0: the blocks of word-slice 0 also do k_tally's job (admit counts, quorum, re-arming).
-constexpr int kExpandWords = 8;                    // bitmap words per thread (grid.y slices the row)
-__global__ __launch_bounds__(256) void k_filter_expand(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, uint32_t words, uint32_t ustride,
-                                                       uint32_t tally, uint32_t do_ready, uint32_t rearm) {
+// Per-pod feasible counts (from the Filter slots) and, with do_tally, the per-group admit counts / quorum.
+__global__ __launch_bounds__(kTallyBlock) void k_tally(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, uint32_t run_filter, uint32_t do_tally,
+                                                        uint32_t do_ready, uint32_t rearm) {
   __shared__ uint32_t s_last;
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  uint32_t feasible = 0;
-  if (i < pods.p) {
-    const uint32_t fl = b.fflags[i] >> 8;
-    const uint32_t w0 = blockIdx.y * kExpandWords;
-    unsigned long long v[kExpandWords];
-    if (fl == BS_FL_EVALUATED) {
-      const uint32_t u = b.fu_slot[i];
-      feasible = b.fu_feas[u];
-#pragma unroll
-      for (int k = 0; k < kExpandWords; ++k)       // all loads first: one memory round trip per thread
-        v[k] = w0 + k < words ? b.fu_bitmap[(size_t)(w0 + k) * ustride + u] : 0ull;
-    } else {
-      const bool all = fl < 16u;
-      feasible = all ? nd.n : 0u;
-      const unsigned long long last = (nd.n & 63u) ? ((1ull << (nd.n & 63u)) - 1ull) : ~0ull;
-#pragma unroll
-      for (int k = 0; k < kExpandWords; ++k) v[k] = all ? (w0 + k + 1u == words ? last : ~0ull) : 0ull;
-    }
-#pragma unroll
-    for (int k = 0; k < kExpandWords; ++k)
-      if (w0 + k < words) b.fl_bitmap[(size_t)(w0 + k) * pods.p + i] = v[k];
-    if (blockIdx.y == 0) b.fl_feasible[i] = feasible;
+  const uint32_t i = blockIdx.x * kTallyBlock + threadIdx.x;
+  uint32_t feasible = 1u;
+  if (run_filter && i < pods.p) {
+    feasible = pod_feasible(nd, b, i);
+    b.fl_feasible[i] = feasible;
   }
-  if (tally && blockIdx.y == 0) tally_block<256>(pods, gr, b, i, feasible, do_ready, rearm, blockIdx.x, gridDim.x, &s_last);
+  if (do_tally) tally_block<kTallyBlock>(pods, gr, b, i, feasible, do_ready, rearm, blockIdx.x, gridDim.x, &s_last);
+}
+
+// The pods x nodes bitmap, materialised ON REQUEST (bs_batch_read with fl_bitmap set): every pod's row from
+// its slot's.  The batch itself never needs it: Filter's answer for (pod, node) is bit `node` of row
+// fu_slot[pod] (exported by bs_batch_read as fl_rows / fl_slot), or "every node" / "no node" by fl_code.
+// Pure streaming: P x ceil(N/64) words out.
+constexpr int kExpandWords = 8;                    // bitmap words per thread (grid.y slices the row)
+__global__ __launch_bounds__(256) void k_filter_expand(PodsDev pods, NodesDev nd, BatchDev b, uint32_t words, uint32_t ustride) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= pods.p) return;
+  const uint32_t fl = (b.fflags[i] >> 8) & 0xFFu;
+  const uint32_t w0 = blockIdx.y * kExpandWords;
+  unsigned long long v[kExpandWords];
+  if (fl == BS_FL_EVALUATED) {
+    const uint32_t u = b.fu_slot[i];
+#pragma unroll
+    for (int k = 0; k < kExpandWords; ++k)       // all loads first: one memory round trip per thread
+      v[k] = w0 + k < words ? b.fu_bitmap[(size_t)(w0 + k) * ustride + u] : 0ull;
+  } else {
+    const bool all = fl < 16u;
+    const unsigned long long last = (nd.n & 63u) ? ((1ull << (nd.n & 63u)) - 1ull) : ~0ull;
+#pragma unroll
+    for (int k = 0; k < kExpandWords; ++k) v[k] = all ? (w0 + k + 1u == words ? last : ~0ull) : 0ull;
+  }
+#pragma unroll
+  for (int k = 0; k < kExpandWords; ++k)
+    if (w0 + k < words) b.fl_bitmap[(size_t)(w0 + k) * pods.p + i] = v[k];
 }
 
 // quorum predicate of Permit, core.go:303, with every admitted pod counted as matched (used after

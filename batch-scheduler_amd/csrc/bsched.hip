@@ -5,6 +5,7 @@
 // (the CPU restatement lives in oracle/ and is test infrastructure).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and enums only: librccl itself is dlopen'ed on demand (hosts without RCCL can still load the library)
 
 #include <algorithm>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include <vector>
 
 #include "bs_kernels.hpp"
+#include "bs_fast.hpp"
 #include "bs_fit.hpp"
 
 using namespace bs;
@@ -78,7 +80,20 @@ struct bs_ctx {
   uint64_t early_filter_min = 200000000ull;   // pod x node pairs from which Filter overlaps the scan
   hipStream_t stream3 = nullptr;    // early Filter: runs beside the node scan when no capture can occur
   hipEvent_t ev_query = nullptr, ev_filter = nullptr;
-  DevBuf d_gmm, d_gsc, d_gmatched, d_gflags, d_gcls, d_gminres, d_gmrpres, d_gocc;
+  // groups live in ONE device allocation (one pinned-staged H2D per load); d_info / h_info carry what findMaxPG
+  // found for the loaded state back to the host without a stream wait (see resolve_groups)
+  DevBuf d_gpack, d_info, d_gdelta;
+  size_t off_gmm = 0, off_gsc = 0, off_gmatched = 0, off_gflags = 0, off_gcls = 0, off_gminres = 0, off_gmrpres = 0, off_gocc = 0, gpack_bytes = 0;
+  void* h_gstage = nullptr;          // pinned: groups pack, then deltas
+  size_t h_gstage_cap = 0;
+  hipEvent_t ev_gstage = nullptr;
+  bool gstage_busy = false;
+  int32_t* h_info = nullptr;         // pinned [8]: leader, panic, steady table, tag | K of the loaded pods, tag
+  hipEvent_t ev_info = nullptr, ev_kinfo = nullptr;
+  int32_t info_tag = 0, kinfo_tag = 0;
+  bool info_pending = false, kinfo_pending = false;
+  uint32_t max_group_cls = 0, max_pod_cls = 0;   // largest fit class any HAS_POD group / grouped pod names (checked against C per batch)
+  uint32_t h_K = 0;                  // request classes of the loaded pods (valid after resolve_pods)
 
   // ---- pods
   uint32_t P = 0;
@@ -90,7 +105,7 @@ struct bs_ctx {
   bool last_use_classes = false;
   size_t h_stage_cap = 0;
   size_t off_pgroup = 0, off_preq = 0, off_ppres = 0, off_pcls = 0, off_powner = 0, off_pflags = 0, podpack_bytes = 0;
-  size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, outpack_bytes = 0;
+  size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, off_fl_slot = 0, outpack_bytes = 0;
 
   // ---- batch scratch / outputs
   DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
@@ -104,6 +119,13 @@ struct bs_ctx {
   DevBuf d_pclass, d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_fu_bitmap, d_fu_feas;
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
   DevBuf d_fl_bitmap, d_admit, d_ready;
+  // fast path (bs_fast.hpp)
+  DevBuf d_gstat, d_ppair, d_pair_next, d_pair_firstq, d_first_reach, d_qstamp_s, d_chunk_off, d_gmm8, d_fast_reject;
+  bool pairs_ready = false;          // d_gstat / pairs match the loaded pods and G
+  bool bitmap_valid = false;         // d_fl_bitmap holds the expanded rows of the last batch
+  bool last_fast = false;
+  bool batch_since_pods = false;     // a batch ran over the loaded pods (its slot mode is the one the rows have)
+  uint32_t no_fast = 0;
   // single-query scratch
   DevBuf d_sq;
   uint32_t table_slots = 0, table_mcap = 0;
@@ -122,9 +144,12 @@ struct bs_ctx {
   size_t events_used = 0;
   bs_timing timing{};
 
-  // ---- native RCCL (dlopen'ed on demand)
+  // ---- native RCCL (dlopen'ed on demand; entry points resolved once in bs_comm_init)
   void* rccl_handle = nullptr;
   void* comm = nullptr;
+  decltype(&ncclAllReduce) rccl_allreduce = nullptr;
+  decltype(&ncclCommDestroy) rccl_destroy = nullptr;
+  uint32_t launches = 0;             // kernel launches of the last batch
 };
 
 namespace {
@@ -147,7 +172,9 @@ int timer_begin(bs_ctx* c, uint32_t id, size_t* slot, hipStream_t st = nullptr) 
   if (!c->cfg.enable_timing) return BS_OK;
   // mode 1: only the two dominant kernels, and only every 8th batch — an event pair costs a few
   // microseconds of stream time, sampling keeps the timed region representative
-  if (c->cfg.enable_timing == 1 && ((id != BS_KERNEL_SCAN && id != BS_KERNEL_FILTER) || (c->batch_seq & 7u) != 0)) return BS_OK;
+  if (c->cfg.enable_timing == 1 &&
+      ((id != BS_KERNEL_QUERY && id != BS_KERNEL_SCAN && id != BS_KERNEL_RESOLVE && id != BS_KERNEL_FILTER) || (c->batch_seq & 7u) != 0))
+    return BS_OK;
   if (c->events_used == c->events.size()) {
     EventPair ep{};
     HIPCHK(c, hipEventCreate(&ep.a));
@@ -176,13 +203,22 @@ int timer_collect(bs_ctx* c) {
   return BS_OK;
 }
 
+// a failed launch is reported with the kernel group it belongs to (bs_kernel_name)
+#define LAUNCHCHK(ctx, id)                                                                         \
+  do {                                                                                             \
+    hipError_t _e = hipGetLastError();                                                             \
+    if (_e != hipSuccess) {                                                                        \
+      (ctx)->last_error = std::string("launch of kernel group '") + kKernelNames[id] + "': " + hipGetErrorString(_e); \
+      return BS_ERR_HIP;                                                                           \
+    }                                                                                              \
+  } while (0)
 #define TIMED_ON(ctx, id, st, ...)                             \
   do {                                                         \
     size_t _slot;                                              \
     int _rc = timer_begin(ctx, id, &_slot, st);                \
     if (_rc) return _rc;                                       \
     __VA_ARGS__;                                               \
-    HIPCHK(ctx, hipGetLastError());                            \
+    LAUNCHCHK(ctx, id);                                        \
     _rc = timer_end(ctx, _slot, st);                           \
     if (_rc) return _rc;                                       \
   } while (0)
@@ -214,14 +250,15 @@ NodesDev nodes_dev(const bs_ctx* c) {
 GroupsDev groups_dev(const bs_ctx* c) {
   GroupsDev g{};
   g.g = c->G;
-  g.min_member = c->d_gmm.as<uint32_t>();
-  g.status_scheduled = c->d_gsc.as<uint32_t>();
-  g.matched = c->d_gmatched.as<uint32_t>();
-  g.flags = c->d_gflags.as<uint8_t>();
-  g.cls = c->d_gcls.as<uint32_t>();
-  g.minres = c->d_gminres.as<int64_t>();
-  g.mrpres = c->d_gmrpres.as<uint32_t>();
-  g.occupied = c->d_gocc.as<uint64_t>();
+  uint8_t* pk = c->d_gpack.as<uint8_t>();
+  g.min_member = reinterpret_cast<uint32_t*>(pk + c->off_gmm);
+  g.status_scheduled = reinterpret_cast<uint32_t*>(pk + c->off_gsc);
+  g.matched = reinterpret_cast<uint32_t*>(pk + c->off_gmatched);
+  g.flags = pk + c->off_gflags;
+  g.cls = reinterpret_cast<uint32_t*>(pk + c->off_gcls);
+  g.minres = reinterpret_cast<int64_t*>(pk + c->off_gminres);
+  g.mrpres = reinterpret_cast<uint32_t*>(pk + c->off_gmrpres);
+  g.occupied = reinterpret_cast<uint64_t*>(pk + c->off_gocc);
   return g;
 }
 PodsDev pods_dev(const bs_ctx* c) {
@@ -272,17 +309,29 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.cls_slots = c->d_cls_slots.as<unsigned long long>();
   b.cls_mask = c->cls_cap ? c->cls_cap - 1 : 0;
   b.qtab_s = c->d_qtab_s.as<int32_t>();
-  b.fu_slot = c->d_fu_slot.as<uint32_t>();
   b.uparams = c->d_uparams.as<int64_t>();
   b.uflags = c->d_uflags.as<uint32_t>();
   b.fu_bitmap = c->d_fu_bitmap.as<uint64_t>();
   b.fu_feas = c->d_fu_feas.as<uint32_t>();
+  b.qstamp_s = c->d_qstamp_s.as<uint32_t>();
+  b.first_pod_s = c->d_gstat.as<uint32_t>();
+  b.first_np_s = c->d_gstat.as<uint32_t>() + (size_t)c->G;
+  b.first_owner_s = c->d_gstat.as<uint32_t>() + (size_t)2 * c->G;
+  b.pair_head = c->d_gstat.as<uint32_t>() + (size_t)3 * c->G;
+  b.ppair = c->d_ppair.as<uint32_t>();
+  b.pair_next = c->d_pair_next.as<uint32_t>();
+  b.pair_firstq = c->d_pair_firstq.as<unsigned long long>();
+  b.first_reach64 = c->d_first_reach.as<unsigned long long>();
+  b.chunk_off = c->d_chunk_off.as<unsigned long long>();
+  b.gmm8 = c->d_gmm8.as<int64_t>();
+  b.fast_reject = c->d_fast_reject.as<uint32_t>();
   uint8_t* ok = c->d_outpack.as<uint8_t>();
   b.pf_code = ok + c->off_pf_code;
   b.pf_first_k = reinterpret_cast<uint32_t*>(ok + c->off_pf_first_k);
   b.pf_leader = reinterpret_cast<int32_t*>(ok + c->off_pf_leader);
   b.fl_code = ok + c->off_fl_code;
   b.fl_feasible = reinterpret_cast<uint32_t*>(ok + c->off_fl_feasible);
+  b.fu_slot = reinterpret_cast<uint32_t*>(ok + c->off_fl_slot);     // per-pod Filter slot travels with the other per-pod results
   b.fl_bitmap = c->d_fl_bitmap.as<uint64_t>();
   b.admit = c->ext_admit ? c->ext_admit : c->d_admit.as<uint32_t>();
   b.ready = c->d_ready.as<uint8_t>();
@@ -315,13 +364,11 @@ int ensure_tables(bs_ctx* c) {
   HIPCHK(c, c->d_chunk_tot.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
   HIPCHK(c, c->d_gmax.reserve((size_t)slots * cdiv(c->Ncap, 64) * 4 * 8));
   HIPCHK(c, c->d_chunk_kp.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 4));
+  HIPCHK(c, c->d_chunk_off.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
+  HIPCHK(c, c->d_gmm8.reserve((size_t)slots * cdiv(c->Ncap, 64) * 8 * 8));
   HIPCHK(c, c->d_desc.reserve((size_t)slots * sizeof(TableDesc)));
   HIPCHK(c, c->d_needed.reserve((size_t)(2 * c->C + 1) * 4));
   HIPCHK(c, c->d_qcount.reserve(16));
-  if (!c->d_ticket.p) {
-    HIPCHK(c, c->d_ticket.reserve(16));
-    HIPCHK(c, hipMemset(c->d_ticket.p, 0, 16));
-  }
   HIPCHK(c, c->d_stats.reserve(8 * sizeof(uint64_t)));
   HIPCHK(c, c->d_sq.reserve(4096));
   c->table_slots = slots;
@@ -446,19 +493,38 @@ void launch_scan_filter(bs_ctx* c, uint32_t scan_blocks, uint32_t filter_blocks,
   }
 }
 
-// Filter: the distinct requests against every node (fixed grid, the kernel splits the work itself), then
-// every pod's row from its representative's.  tally: the expand kernel also does k_tally's job.
-void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, bool use_classes,
-                   bool tally, bool do_ready, bool rearm, bool slots_done) {
-  const uint32_t W = cdiv(c->N, 64), ptiles = cdiv(c->P, 64);
-  if (!ptiles) return;
-  if (W && !slots_done) {
-    const uint32_t waves = std::min<uint32_t>(c->filter_waves, 2 * ptiles * std::max<uint32_t>(1, cdiv(W, 2)));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(waves, 4)), dim3(256), 0, st, pd, nd, b, c->filter_waves, use_classes ? 1u : 0u,
-                       c->filter_slots_cap, c->collect_stats);
+template <int S>
+static void launch_fast_b_s(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg,
+                            uint32_t scan_blocks) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter<S>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->M, nseg, scan_blocks, c->filter_waves,
+                     c->filter_slots_cap);
+}
+static void launch_fast_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg,
+                          uint32_t scan_blocks) {
+  switch (c->S) {
+    case 0: launch_fast_b_s<0>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 1: launch_fast_b_s<1>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 2: launch_fast_b_s<2>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 3: launch_fast_b_s<3>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 4: launch_fast_b_s<4>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 5: launch_fast_b_s<5>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 6: launch_fast_b_s<6>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 7: launch_fast_b_s<7>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 8: launch_fast_b_s<8>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 9: launch_fast_b_s<9>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 10: launch_fast_b_s<10>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 11: launch_fast_b_s<11>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    default: launch_fast_b_s<12>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
   }
-  hipLaunchKernelGGL(k_filter_expand, dim3(cdiv(c->P, 256), std::max<uint32_t>(1, cdiv(W, kExpandWords))), dim3(256), 0, st, pd, gr, nd, b, W,
-                     c->filter_slots_cap, tally ? 1u : 0u, do_ready ? 1u : 0u, rearm ? 1u : 0u);
+}
+
+// Filter: the distinct requests (slots) against every node; fixed grid, the kernel splits the work itself.
+void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const NodesDev& nd, const BatchDev& b, bool use_classes) {
+  const uint32_t W = cdiv(c->N, 64), ptiles = cdiv(c->P, 64);
+  if (!ptiles || !W) return;
+  const uint32_t waves = std::min<uint32_t>(c->filter_waves, 2 * ptiles * std::max<uint32_t>(1, cdiv(W, 2)));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_filter<2>), dim3(cdiv(waves, 4)), dim3(256), 0, st, pd, nd, b, c->filter_waves, use_classes ? 1u : 0u,
+                     c->filter_slots_cap, c->collect_stats);
 }
 
 // Cap on the waves that share the live 64-row groups of one tile pair (k_scan picks the actual share
@@ -491,31 +557,81 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
   return BS_OK;
 }
 
-// After the group state changed: re-arm the scratch and learn, for the no-capture case, which single
-// table the batch will query — findMaxPG (on the device) decides it: leader with matched > 0 means every
-// other group's pods reserve for it at percent 0.7 against the leader's fit class (core.go:157-161).
-int analyse_groups(bs_ctx* c) {
+// After the group state (or the fit classes) changed: re-arm the general chain's scratch and run findMaxPG for
+// the loaded state (k_leader_info).  For the no-capture case it also decides, on the device, which single table
+// every reservation query of a batch will use — leader with matched > 0 means every other group's pods reserve
+// for it at percent 0.7 against the leader's fit class (core.go:157-161) — and writes that table's descriptor.
+// Leader, panic flag and table id come back through pinned memory; nothing waits here (resolve_groups does, at
+// the next bs_batch_run, and then only if the copy has not landed yet).
+int analyse_groups(bs_ctx* c, bool rearm_scratch = true) {
   c->steady_table = -1;
   c->side_ready = false;
+  c->info_pending = false;
   if (!c->G) { c->scratch_armed = false; return BS_OK; }
   GroupsDev gr = groups_dev(c);
   BatchDev b = batch_dev(c);
-  const uint32_t one = 1;
-  hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(c->G, 8), 256)), dim3(256), 0, c->stream, gr, b);
-  HIPCHK(c, hipMemcpyAsync(b.nepochs, &one, 4, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_leader, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b);
-  HIPCHK(c, hipGetLastError());
-  int32_t l = -1;
-  uint8_t pn = 0;
-  HIPCHK(c, hipMemcpyAsync(&l, b.leader_epoch, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&pn, b.panic_epoch, 1, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->scratch_armed = true;
-  if (c->n_uncaptured == 0 && !pn && l >= 0 && c->have_fit && c->h_gmatched[l] > 0 && c->h_gcls[l] < c->C) {
-    c->steady_table = (int32_t)(c->C + c->h_gcls[l]);
-    TableDesc d{c->h_gcls[l], 0.7f};                       // descriptor of the steady-state table, written once
-    HIPCHK(c, hipMemcpy(b.desc + c->steady_table, &d, sizeof(d), hipMemcpyHostToDevice));
+  if (rearm_scratch) {
+    hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(c->G, 8), 256)), dim3(256), 0, c->stream, gr, b);
+    c->scratch_armed = true;
   }
+  c->info_tag++;
+  hipLaunchKernelGGL(k_leader_info, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b, (c->have_fit && c->have_nodes) ? c->C : 0u, c->info_tag,
+                     c->d_info.as<int32_t>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_info, c->d_info.p, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_info, c->stream));
+  c->info_pending = true;
+  return BS_OK;
+}
+
+int resolve_groups(bs_ctx* c) {
+  if (!c->info_pending) return BS_OK;
+  HIPCHK(c, hipEventSynchronize(c->ev_info));
+  c->info_pending = false;
+  if (c->h_info[3] != c->info_tag) { c->last_error = "group analysis tag mismatch"; return BS_ERR_HIP; }
+  c->steady_table = (c->n_uncaptured == 0 && c->h_info[2] >= 0) ? c->h_info[2] : -1;
+  return BS_OK;
+}
+
+int resolve_pods(bs_ctx* c) {
+  if (!c->kinfo_pending) return BS_OK;
+  HIPCHK(c, hipEventSynchronize(c->ev_kinfo));
+  c->kinfo_pending = false;
+  c->h_K = (uint32_t)c->h_info[4];
+  return BS_OK;
+}
+
+// reserve and, when the buffer was (re)allocated, fill it: stamped arrays must never start out as garbage
+int reserve_filled(bs_ctx* c, DevBuf& d, size_t bytes, int byte_value) {
+  const void* before = d.p;
+  HIPCHK(c, d.reserve(bytes));
+  if (d.p != before) HIPCHK(c, hipMemsetAsync(d.p, byte_value, d.cap, c->stream));
+  return BS_OK;
+}
+
+int ensure_gstage(bs_ctx* c, size_t bytes) {
+  if (c->gstage_busy) { HIPCHK(c, hipEventSynchronize(c->ev_gstage)); c->gstage_busy = false; }
+  if (bytes <= c->h_gstage_cap) return BS_OK;
+  if (c->h_gstage) { (void)hipHostFree(c->h_gstage); c->h_gstage = nullptr; c->h_gstage_cap = 0; }
+  HIPCHK(c, hipHostMalloc(&c->h_gstage, bytes, hipHostMallocDefault));
+  c->h_gstage_cap = bytes;
+  return BS_OK;
+}
+
+// What the fast path needs from the pods alone (k_pod_pairs): needs the pods' request classes and G.
+int build_pairs(bs_ctx* c) {
+  const uint32_t G = c->G, P = c->P;
+  HIPCHK(c, c->d_gstat.reserve((size_t)4 * std::max<uint32_t>(G, 1) * 4));
+  HIPCHK(c, c->d_fast_reject.reserve((size_t)std::max<uint32_t>(G, 1) * 4));
+  if (G) HIPCHK(c, hipMemsetAsync(c->d_gstat.p, 0xFF, (size_t)4 * G * 4, c->stream));
+  if (P && G) {
+    unsigned long long* table = c->d_cls_slots.as<unsigned long long>() + c->cls_cap;       // second half: the pair table
+    HIPCHK(c, hipMemsetAsync(table, 0, (size_t)c->cls_cap * 8, c->stream));
+    hipLaunchKernelGGL(k_pod_pairs, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pods_dev(c), G, c->d_pclass.as<uint32_t>(), table, c->cls_cap - 1,
+                       c->hash_keep, c->d_gstat.as<uint32_t>(), c->d_ppair.as<uint32_t>(), c->d_pair_next.as<uint32_t>());
+    HIPCHK(c, hipGetLastError());
+  }
+  c->pairs_ready = true;
   return BS_OK;
 }
 
@@ -568,6 +684,24 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     delete c;
     return BS_ERR_NO_DEVICE;
   }
+  // small counters every load / batch path touches: owned by the context from the start, so no call order
+  // between bs_pods_load and bs_groups_load is implied
+  if (c->d_nepochs.reserve(64) != hipSuccess || hipMemset(c->d_nepochs.p, 0, 64) != hipSuccess || c->d_ticket.reserve(64) != hipSuccess ||
+      hipMemset(c->d_ticket.p, 0, 64) != hipSuccess) {
+    delete c;
+    return BS_ERR_NOMEM;
+  }
+  if (c->d_info.reserve(64) != hipSuccess || c->d_first_reach.reserve(64) != hipSuccess || hipMemset(c->d_first_reach.p, 0xFF, 64) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_info, 64, hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_info, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_kinfo, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_gstage, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return BS_ERR_NOMEM;
+  }
+  std::memset(c->h_info, 0, 64);
+  c->batch_seq = 1;                  // 64-bit atomicMin keys carry ~batch_seq: never all-ones
+  if (const char* e = std::getenv("BS_NO_FAST")) c->no_fast = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) { c->early_filter_min = std::strtoull(e, nullptr, 10); c->early_forced = 1; }
@@ -583,13 +717,14 @@ int bs_destroy(bs_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); }
   for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  if (c->comm && c->rccl_handle) {
-    typedef int (*destroy_t)(void*);
-    destroy_t f = (destroy_t)dlsym(c->rccl_handle, "ncclCommDestroy");
-    if (f) f(c->comm);
-  }
+  if (c->comm && c->rccl_destroy) (void)c->rccl_destroy((ncclComm_t)c->comm);
   if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->ev_info) (void)hipEventDestroy(c->ev_info);
+  if (c->ev_kinfo) (void)hipEventDestroy(c->ev_kinfo);
+  if (c->ev_gstage) (void)hipEventDestroy(c->ev_gstage);
+  if (c->h_info) (void)hipHostFree(c->h_info);
+  if (c->h_gstage) (void)hipHostFree(c->h_gstage);
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   if (c->ev_query) (void)hipEventDestroy(c->ev_query);
   if (c->ev_filter) (void)hipEventDestroy(c->ev_filter);
@@ -758,20 +893,29 @@ int bs_fit_read(bs_ctx* c, uint32_t* out) {
   return BS_OK;
 }
 
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   if (!c || !g) return BS_ERR_INVALID;
   int rc = use_device(c);
   if (rc) return rc;
   const uint32_t G = g->g, L = c->L;
+  if (G && (!g->min_member || !g->status_scheduled || !g->matched || !g->flags || !g->cls || !g->min_resources || !g->min_resources_present ||
+            !g->occupied_by))
+    return BS_ERR_INVALID;
   const size_t n = std::max<uint32_t>(G, 1);
-  HIPCHK(c, c->d_gmm.reserve(n * 4));
-  HIPCHK(c, c->d_gsc.reserve(n * 4));
-  HIPCHK(c, c->d_gmatched.reserve(n * 4));
-  HIPCHK(c, c->d_gflags.reserve(n));
-  HIPCHK(c, c->d_gcls.reserve(n * 4));
-  HIPCHK(c, c->d_gminres.reserve(n * L * 8));
-  HIPCHK(c, c->d_gmrpres.reserve(n * 4));
-  HIPCHK(c, c->d_gocc.reserve(n * 8));
+  // group arrays: one allocation, one pinned-staged transfer, no wait
+  size_t o = 0;
+  c->off_gmm = o; o = align256(o + n * 4);
+  c->off_gsc = o; o = align256(o + n * 4);
+  c->off_gmatched = o; o = align256(o + n * 4);
+  c->off_gflags = o; o = align256(o + n);
+  c->off_gcls = o; o = align256(o + n * 4);
+  c->off_gminres = o; o = align256(o + n * L * 8);
+  c->off_gmrpres = o; o = align256(o + n * 4);
+  c->off_gocc = o; o = align256(o + n * 8);
+  c->gpack_bytes = o;
+  HIPCHK(c, c->d_gpack.reserve(o));
   HIPCHK(c, c->d_first_elig.reserve(n * 4));
   HIPCHK(c, c->d_first_owner.reserve(n * 4));
   HIPCHK(c, c->d_first_reject.reserve(n * 4));
@@ -781,30 +925,70 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   HIPCHK(c, c->d_ready.reserve(n));
   HIPCHK(c, c->d_leader_epoch.reserve((n + 1) * 4));
   HIPCHK(c, c->d_panic_epoch.reserve(n + 1));
-  HIPCHK(c, c->d_nepochs.reserve(16));
+  if (G != c->G) c->pairs_ready = false;          // the per-group arrays of the pod load are sized by G
   c->G = G;
   c->n_uncaptured = 0;
   c->n_nominres = 0;
+  c->max_group_cls = 0;
   if (G) {
-    HIPCHK(c, hipMemcpyAsync(c->d_gmm.p, g->min_member, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_gsc.p, g->status_scheduled, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_gmatched.p, g->matched, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_gflags.p, g->flags, (size_t)G, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_gcls.p, g->cls, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_gminres.p, g->min_resources, (size_t)G * L * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_gmrpres.p, g->min_resources_present, (size_t)G * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_gocc.p, g->occupied_by, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
+    rc = ensure_gstage(c, c->gpack_bytes);
+    if (rc) return rc;
+    uint8_t* st = reinterpret_cast<uint8_t*>(c->h_gstage);
+    std::memcpy(st + c->off_gmm, g->min_member, (size_t)G * 4);
+    std::memcpy(st + c->off_gsc, g->status_scheduled, (size_t)G * 4);
+    std::memcpy(st + c->off_gmatched, g->matched, (size_t)G * 4);
+    std::memcpy(st + c->off_gflags, g->flags, (size_t)G);
+    std::memcpy(st + c->off_gcls, g->cls, (size_t)G * 4);
+    std::memcpy(st + c->off_gminres, g->min_resources, (size_t)G * L * 8);
+    std::memcpy(st + c->off_gmrpres, g->min_resources_present, (size_t)G * 4);
+    std::memcpy(st + c->off_gocc, g->occupied_by, (size_t)G * 8);
+    HIPCHK(c, hipMemcpyAsync(c->d_gpack.p, st, c->gpack_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_gstage, c->stream));
+    c->gstage_busy = true;
     for (uint32_t i = 0; i < G; ++i) {
       if (!(g->flags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+      else c->max_group_cls = std::max(c->max_group_cls, g->cls[i]);
       if (!(g->flags[i] & BS_GROUP_HAS_MINRES)) c->n_nominres++;
     }
-    c->h_gmatched.assign(g->matched, g->matched + G);
-    c->h_gcls.assign(g->cls, g->cls + G);
     c->h_gflags.assign(g->flags, g->flags + G);
+  } else {
+    c->h_gflags.clear();
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_groups = true;
   return analyse_groups(c);
+}
+
+int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
+  if (!c || (count && !deltas)) return BS_ERR_INVALID;
+  if (!c->have_groups) { c->last_error = "bs_groups_apply before bs_groups_load"; return BS_ERR_STATE; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!count) return BS_OK;
+  const uint8_t keep = BS_GROUP_HAS_POD | BS_GROUP_HAS_MINRES;
+  for (uint32_t d = 0; d < count; ++d) {            // validate everything before touching anything
+    const bs_group_delta& x = deltas[d];
+    if (x.index >= c->G || x.flags > 0xFFu) { c->last_error = "bs_groups_apply: index / flags out of range"; return BS_ERR_INVALID; }
+    if (((uint8_t)x.flags & keep) != (c->h_gflags[x.index] & keep)) {
+      c->last_error = "bs_groups_apply: HAS_POD / HAS_MINRES may not change (use bs_groups_load)";
+      return BS_ERR_INVALID;
+    }
+  }
+  static_assert(sizeof(bs_group_delta) == sizeof(GroupDelta), "delta layout");
+  const size_t bytes = (size_t)count * sizeof(bs_group_delta);
+  rc = ensure_gstage(c, std::max(bytes, c->gpack_bytes));
+  if (rc) return rc;
+  HIPCHK(c, c->d_gdelta.reserve(bytes));
+  std::memcpy(c->h_gstage, deltas, bytes);
+  HIPCHK(c, hipMemcpyAsync(c->d_gdelta.p, c->h_gstage, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_gstage, c->stream));
+  c->gstage_busy = true;
+  GroupsDev gr = groups_dev(c);
+  hipLaunchKernelGGL(k_groups_apply, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, c->d_gdelta.as<GroupDelta>(), count,
+                     const_cast<uint32_t*>(gr.matched), const_cast<uint32_t*>(gr.status_scheduled), const_cast<uint8_t*>(gr.flags));
+  HIPCHK(c, hipGetLastError());
+  for (uint32_t d = 0; d < count; ++d) c->h_gflags[deltas[d].index] = (uint8_t)deltas[d].flags;
+  // HAS_POD is unchanged, so the capture epochs the general chain's scratch holds stay valid: no re-arm
+  return analyse_groups(c, false);
 }
 
 int bs_groups_read(bs_ctx* c, bs_groups_soa* g) {
@@ -816,14 +1000,15 @@ int bs_groups_read(bs_ctx* c, bs_groups_soa* g) {
   const uint32_t G = c->G, L = c->L;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (G) {
-    HIPCHK(c, hipMemcpy(g->min_member, c->d_gmm.p, (size_t)G * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(g->status_scheduled, c->d_gsc.p, (size_t)G * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(g->matched, c->d_gmatched.p, (size_t)G * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(g->flags, c->d_gflags.p, (size_t)G, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(g->cls, c->d_gcls.p, (size_t)G * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(g->min_resources, c->d_gminres.p, (size_t)G * L * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(g->min_resources_present, c->d_gmrpres.p, (size_t)G * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(g->occupied_by, c->d_gocc.p, (size_t)G * 8, hipMemcpyDeviceToHost));
+    const uint8_t* pk = c->d_gpack.as<uint8_t>();
+    HIPCHK(c, hipMemcpy(g->min_member, pk + c->off_gmm, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->status_scheduled, pk + c->off_gsc, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->matched, pk + c->off_gmatched, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->flags, pk + c->off_gflags, (size_t)G, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->cls, pk + c->off_gcls, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->min_resources, pk + c->off_gminres, (size_t)G * L * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->min_resources_present, pk + c->off_gmrpres, (size_t)G * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(g->occupied_by, pk + c->off_gocc, (size_t)G * 8, hipMemcpyDeviceToHost));
   }
   return BS_OK;
 }
@@ -837,8 +1022,6 @@ static int ensure_stage(bs_ctx* c, size_t bytes) {
   c->h_stage_cap = bytes;
   return BS_OK;
 }
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
 int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   if (!c || !pods) return BS_ERR_INVALID;
   int rc = use_device(c);
@@ -863,6 +1046,7 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   c->off_pf_leader = o; o = align256(o + n * 4);
   c->off_fl_code = o; o = align256(o + n);
   c->off_fl_feasible = o; o = align256(o + n * 4);
+  c->off_fl_slot = o; o = align256(o + n * 4);
   c->outpack_bytes = o;
   HIPCHK(c, c->d_outpack.reserve(o));
   rc = ensure_stage(c, std::max(c->podpack_bytes, c->outpack_bytes));
@@ -874,18 +1058,26 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, c->d_qpos.reserve(n * 4));
   HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
   HIPCHK(c, c->d_fflags.reserve(n * 4));
-  HIPCHK(c, c->d_fu_slot.reserve(n * 4));
+  HIPCHK(c, c->d_ppair.reserve(n * 4));
+  HIPCHK(c, c->d_pair_next.reserve(n * 4));
+  rc = reserve_filled(c, c->d_pair_firstq, n * 8, 0xFF);     // 64-bit minima keyed by ~batch_seq: never reset, only born as "none"
+  if (rc) return rc;
   HIPCHK(c, c->d_pclass.reserve(n * 4));
   HIPCHK(c, c->d_cls_rep.reserve(n * 4));
   HIPCHK(c, c->d_cls_id.reserve(n * 4));
   {
     uint32_t cap = 1024;
     while (cap < 2 * n) cap <<= 1;
-    HIPCHK(c, c->d_cls_slots.reserve((size_t)cap * 8));
+    HIPCHK(c, c->d_cls_slots.reserve((size_t)cap * 8 * 2));  // request-class table | (group, class) pair table
     c->cls_cap = cap;
   }
   HIPCHK(c, c->d_blk_scratch.reserve((n / 256 + 2) * 4));
   c->P = P;
+  c->pairs_ready = false;
+  c->batch_since_pods = false;
+  c->max_pod_cls = 0;
+  for (uint32_t i = 0; i < P; ++i)
+    if (pods->group[i] >= 0) c->max_pod_cls = std::max(c->max_pod_cls, pods->cls[i]);
   if (P) {
     uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
     std::memcpy(st + c->off_pgroup, pods->group, (size_t)P * 4);
@@ -906,6 +1098,14 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
     hipLaunchKernelGGL(k_pod_class_b, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, P, c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(),
                        c->d_pclass.as<uint32_t>());
     HIPCHK(c, hipGetLastError());
+  }
+  // K travels back on its own (pinned memory + event): needed by the host only to size the Filter rows
+  HIPCHK(c, hipMemcpyAsync(c->h_info + 4, c->d_nepochs.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_kinfo, c->stream));
+  c->kinfo_pending = true;
+  if (c->have_groups) {
+    rc = build_pairs(c);
+    if (rc) return rc;
   }
   // no wait here: the batch that follows is ordered behind the upload on the same stream; only the staging
   // buffer must not be touched again before the copy has left it (ensure_stage / bs_batch_read wait for that)
@@ -950,6 +1150,125 @@ int bs_group_admit_devptr(bs_ctx* c, void** dptr, uint32_t* count) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// After the last kernel of a batch: the cross-rank reduction of the admit counters (native RCCL) or the hand-over
+// to the caller's collective.
+static int batch_collective(bs_ctx* c, uint32_t stages, const GroupsDev& gr, const BatchDev& b) {
+  c->batch_pending_finish = false;
+  if (!(stages & BS_STAGE_TALLY)) return BS_OK;
+  if (c->nranks > 1 || c->reduce_external) {
+    if (c->comm) {
+      // native RCCL: one all-reduce(sum) of the per-group admit counters on the context stream
+      if (!c->rccl_allreduce || c->rccl_allreduce(b.admit, b.admit, c->G, ncclUint32, ncclSum, (ncclComm_t)c->comm, c->stream) != ncclSuccess) {
+        c->last_error = "ncclAllReduce failed";
+        return BS_ERR_COMM;
+      }
+      if (c->G) hipLaunchKernelGGL(k_ready, dim3(cdiv(c->G, 256)), dim3(256), 0, c->stream, gr, b);
+      LAUNCHCHK(c, BS_KERNEL_TALLY);
+    } else {
+      c->batch_pending_finish = true;   // caller reduces bs_group_admit_devptr, then bs_batch_finish
+    }
+  }
+  return BS_OK;
+}
+
+// slot arrays shared by both chains (scan = classes + groups or one per pod, Filter = 2 x classes or one per pod)
+static int reserve_slots(bs_ctx* c, bool run_filter) {
+  const uint32_t P = c->P, G = c->G;
+  const uint32_t scan_cap = P + G + 64, filter_cap = 2 * P + 64;
+  int rc;
+  HIPCHK(c, c->d_first_row.reserve((size_t)scan_cap * 4));
+  HIPCHK(c, c->d_qreq_s.reserve((size_t)scan_cap * c->LP * 8));
+  HIPCHK(c, c->d_qflags_s.reserve((size_t)scan_cap * 4));
+  HIPCHK(c, c->d_qtab_s.reserve((size_t)scan_cap * 4));
+  if ((rc = reserve_filled(c, c->d_qstamp_s, (size_t)scan_cap * 4, 0))) return rc;
+  if (run_filter) {
+    HIPCHK(c, c->d_fu_bitmap.reserve(std::max<size_t>(8, (size_t)cdiv(c->N, 64) * filter_cap * 8)));
+    HIPCHK(c, c->d_uparams.reserve((size_t)filter_cap * 64));
+    if ((rc = reserve_filled(c, c->d_uflags, (size_t)filter_cap * 4, 0))) return rc;
+    HIPCHK(c, c->d_fu_feas.reserve((size_t)filter_cap * 4));
+  }
+  c->scan_slots_cap = scan_cap;
+  c->filter_slots_cap = filter_cap;
+  return BS_OK;
+}
+
+// The steady-state chain (bs_fast.hpp): three launches, nothing reset, no wait.
+static int run_fast(bs_ctx* c, uint32_t stages) {
+  int rc;
+  const uint32_t P = c->P, G = c->G, N = c->N;
+  const uint32_t W = cdiv(N, 64);
+  const bool run_filter = stages & BS_STAGE_FILTER;
+  const bool commit = stages & BS_BATCH_COMMIT;
+  NodesDev nd = nodes_dev(c);
+  GroupsDev gr = groups_dev(c);
+  PodsDev pd = pods_dev(c);
+  BatchDev b = batch_dev(c);
+  BatchParams prm = batch_params(c);
+  prm.run_filter = run_filter;
+  prm.use_classes = 1;
+  prm.fuse_filter = run_filter ? 1u : 0u;
+  prm.scan_slots_cap = c->scan_slots_cap;
+  prm.filter_slots_cap = c->filter_slots_cap;
+  prm.stamp = 1u + (c->batch_seq % 65535u);
+  prm.seq_inv = ~c->batch_seq;
+  prm.commit = commit ? 1u : 0u;
+  prm.do_tally = (stages & BS_STAGE_TALLY) ? 1u : 0u;
+  prm.do_ready = (prm.do_tally && c->nranks == 1 && !c->reduce_external) ? 1u : 0u;
+  const uint32_t side_slot = (uint32_t)c->steady_table;
+  const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
+  BatchDev bt = b;                                   // the batch view shifted to the steady table's slot (slot index 0)
+  bt.tables = b.tables + (size_t)side_slot * prm.mcap * prm.LP;
+  bt.kp = b.kp + (size_t)side_slot * 16;
+  bt.chunk_tot = b.chunk_tot + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
+  bt.chunk_kp = b.chunk_kp + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
+  bt.chunk_off = b.chunk_off + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
+  bt.gmm8 = b.gmm8 + (size_t)side_slot * cdiv(c->Ncap, 64) * 8;
+  const TableDesc* forced = b.desc + side_slot;
+  const int ts = c->S <= 4 ? (int)c->S : -1;
+  if (commit && G) HIPCHK(c, hipMemsetAsync(c->d_fast_reject.p, 0xFF, (size_t)G * 4, c->stream));
+
+  // ---- launch A: per-pod decisions, scan / Filter slots | chunk-local running sums of the table
+  TIMED(c, BS_KERNEL_QUERY, {
+    const uint32_t qb = cdiv(P, kTblChunk);
+    const dim3 qg(qb + nchunks), blk(kTblChunk);
+    switch (ts) {
+      case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<0>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+      case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<1>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+      case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<2>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+      case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<3>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+      case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<4>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+      default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<-1>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
+    }
+  });
+  // ---- launch B: node scan over the class slots | Filter evaluation over the Filter slots
+  // The work loops size themselves on the device (the class count lives there); the grid only has to be large
+  // enough.  K is known on the host once its copy from the pod load has landed — never waited for here.
+  if (c->kinfo_pending && hipEventQuery(c->ev_kinfo) == hipSuccess && (rc = resolve_pods(c))) return rc;
+  const uint32_t k_est = std::min<uint32_t>(P, c->kinfo_pending ? std::max<uint32_t>(2 * c->h_K, 1024) : std::max<uint32_t>(c->h_K, 1));
+  TIMED(c, BS_KERNEL_SCAN, {
+    const uint32_t nseg = pick_scan_share(c);
+    const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, cdiv(k_est, 64) * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
+    const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * k_est, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
+    const dim3 grid(scan_blocks + fblocks);
+    launch_fast_b(c, grid, pd, nd, bt, prm, nseg, scan_blocks);
+  });
+  // ---- launch C: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
+  TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm));
+  c->launches = 3;
+  if (commit) {
+    if (G) hipLaunchKernelGGL(k_fast_commit, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, pd, b, const_cast<uint8_t*>(gr.flags),
+                              const_cast<uint64_t*>(gr.occupied), G);
+    LAUNCHCHK(c, BS_KERNEL_RESOLVE);
+    int32_t last = -1;
+    HIPCHK(c, hipMemcpyAsync(&last, b.pf_leader + (P - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    if (G) HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), gr.flags, G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->sop_leader0 = last;            // findMaxPG ignores deny entries and OccupiedBy: the group analysis stays valid
+    c->launches++;
+  }
+  return batch_collective(c, stages, gr, b);
+}
+
 int bs_batch_run(bs_ctx* c, uint32_t stages) {
   if (!c) return BS_ERR_INVALID;
   if (!c->have_nodes || !c->have_fit || !c->have_groups || !c->have_pods) {
@@ -961,23 +1280,44 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   int rc = use_device(c);
   if (rc) return rc;
   const uint32_t P = c->P, G = c->G, N = c->N, C = c->C;
+  // fit-class indices address fit rows and running-sum tables on the device: out of range = refuse the batch
+  if ((G > c->n_uncaptured && c->max_group_cls >= C) || (P && c->max_pod_cls >= C)) {
+    c->last_error = "fit class index out of range (groups.cls / pods.cls vs the loaded fit classes)";
+    return BS_ERR_INVALID;
+  }
+  if ((rc = resolve_groups(c))) return rc;
+  if (!c->pairs_ready && (rc = build_pairs(c))) return rc;
   const uint32_t W = cdiv(N, 64);
   const bool run_filter = stages & BS_STAGE_FILTER;
-  // request slots: scan = classes + groups (or one per pod), Filter = 2 x classes (or one per pod)
-  const uint32_t scan_cap = P + G + 64, filter_cap = 2 * P + 64;
-  HIPCHK(c, c->d_first_row.reserve((size_t)scan_cap * 4));
-  HIPCHK(c, c->d_qreq_s.reserve((size_t)scan_cap * c->LP * 8));
-  HIPCHK(c, c->d_qflags_s.reserve((size_t)scan_cap * 4));
-  HIPCHK(c, c->d_qtab_s.reserve((size_t)scan_cap * 4));
-  if (run_filter) {
-    HIPCHK(c, c->d_fl_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
-    HIPCHK(c, c->d_fu_bitmap.reserve(std::max<size_t>(8, (size_t)W * filter_cap * 8)));
-    HIPCHK(c, c->d_uparams.reserve((size_t)filter_cap * 64));
-    HIPCHK(c, c->d_uflags.reserve((size_t)filter_cap * 4));
-    HIPCHK(c, c->d_fu_feas.reserve((size_t)filter_cap * 4));
-  }
-  c->filter_slots_cap = filter_cap;
+  if ((rc = reserve_slots(c, run_filter))) return rc;
+  const uint32_t scan_cap = c->scan_slots_cap, filter_cap = c->filter_slots_cap;
+  (void)W;
 
+  const bool captures_possible = c->n_uncaptured > 0 && P > 0;
+  // request classes stand for the pods when nothing a pod derives can depend on its queue position:
+  // no first-pod capture and no MinResources default (core.go:486-493) left to happen
+  const bool use_classes = !captures_possible && c->n_nominres == 0;
+  c->last_use_classes = use_classes;
+  c->last_stages = stages;
+  c->bitmap_valid = false;
+  c->batch_since_pods = true;
+  // No capture possible and the leader has matched pods: every scan query of the batch uses ONE known
+  // table (k_leader_info).
+  const bool inline_tables = !captures_possible && c->steady_table >= 0 && c->M && P && c->cfg.enable_timing < 2;
+  // No capture possible: the Filter inputs do not depend on the node scan (k_fparams_early), so Filter can
+  // run on its own stream beside scan / reject / final.  Joining a second stream costs ~10-20 us of
+  // cross-queue signalling, so only when Filter is long enough (slot = pod batches), or when forced.
+  const bool early_filter = run_filter && !captures_possible && P && N && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing < 2 &&
+                            (uint64_t)P * N >= c->early_filter_min && (!use_classes || c->early_forced);
+  // ---- steady state: the three-launch chain
+  c->last_fast = use_classes && inline_tables && !early_filter && N && !c->no_fast && !c->no_fuse_filter;
+  if (c->last_fast) {
+    rc = run_fast(c, stages);
+    c->batch_seq++;
+    return rc;
+  }
+
+  // ---- general chain (first-pod captures, MinResources defaults, leader without matched pods, early Filter)
   NodesDev nd = nodes_dev(c);
   GroupsDev gr = groups_dev(c);
   PodsDev pd = pods_dev(c);
@@ -988,40 +1328,23 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const uint32_t pairs_est = cdiv(tiles_est, 2);
   // J waves share the live 64-row groups of one tile pair (k_scan deals them round-robin)
   const uint32_t nseg = pick_scan_share(c);
-
   const dim3 blk(256);
-  const bool captures_possible = c->n_uncaptured > 0 && P > 0;
-  // request classes stand for the pods when nothing a pod derives can depend on its queue position:
-  // no first-pod capture and no MinResources default (core.go:486-493) left to happen
-  const bool use_classes = !captures_possible && c->n_nominres == 0;
   prm.use_classes = use_classes ? 1u : 0u;
-  c->last_use_classes = use_classes;
   prm.scan_slots_cap = scan_cap;
   prm.filter_slots_cap = filter_cap;
   const int ts = c->S <= 4 ? (int)c->S : -1;
   bool commit_dirty = false;
-  // No capture possible and the leader has matched pods: every scan query of the batch uses ONE known
-  // table (analyse_groups).  It is built inside the pre-pass and query launches (extra blocks).
-  const bool inline_tables = !captures_possible && c->steady_table >= 0 && c->M && P && c->cfg.enable_timing < 2;
   const uint32_t side_slot = inline_tables ? (uint32_t)c->steady_table : 0u;
-  // (With request classes Filter is cheap and rides in the scan launch; early Filter is for slot = pod batches.)
-  // No capture possible: the Filter inputs do not depend on the node scan (k_fparams_early), so Filter
-  // runs on its own stream beside scan / reject / final and k_tally voids the rows PreFilter turned down.
-  // Joining a second stream costs ~10-20 us of cross-queue signalling, so only when Filter is long enough.
-  const bool early_filter = run_filter && !captures_possible && P && N && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing < 2 &&
-                            (uint64_t)P * N >= c->early_filter_min && (!use_classes || c->early_forced);
   prm.early_filter = early_filter ? 1u : 0u;
-  // tally inputs (admit counts + quorum).  Without early Filter and without COMMIT the expand kernel of
-  // Filter does the tally on the way (one launch less).
   const bool local_ready = c->nranks == 1 && !c->reduce_external;
   // re-arming is only valid when the group minima were not also needed for capture epochs (cap_epoch is rewritten then)
   const bool rearm = !captures_possible && !(stages & BS_BATCH_COMMIT);
-  const bool fuse_tally = run_filter && P && !early_filter && (stages & BS_STAGE_TALLY) && !(stages & BS_BATCH_COMMIT);
   // class mode without early Filter: k_query fills the Filter slots and ONE launch does node scan + Filter evaluation
   const bool fuse_filter = run_filter && use_classes && !early_filter && P && N && !c->no_fuse_filter;
   prm.fuse_filter = fuse_filter ? 1u : 0u;
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
-  // steady state: the one table is built inside the first two launches (k_prepass_tables / k_query_tables)
+  uint32_t launches = 0;
+  // one known table: it is built inside the first two launches (k_prepass_tables / k_query_tables)
   BatchDev bt = b;                                                       // the batch view shifted to the table's slot (slot index 0)
   const TableDesc* forced = nullptr;
   if (inline_tables) {
@@ -1035,9 +1358,10 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
 
   // ---- per-batch resets + eligibility (+ findMaxPG when no first-pod capture can occur)
   TIMED(c, BS_KERNEL_PREPASS, {
-    if (!c->scratch_armed) hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(G, 4), 256)), blk, 0, c->stream, gr, b);
+    if (!c->scratch_armed) { hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(G, 4), 256)), blk, 0, c->stream, gr, b); launches++; }
     const uint32_t span = std::max(std::max(P, G), (2 * C + 1) * 16);
     const uint32_t fused = captures_possible ? 0u : 1u;
+    launches++;
     if (inline_tables) {
       const uint32_t pre = cdiv(span, kPrepassBlock);
       const dim3 pg(pre + 1 + nchunks), pb(kPrepassBlock);
@@ -1055,6 +1379,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     if (captures_possible) {
       hipLaunchKernelGGL(k_epochs_a, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
       hipLaunchKernelGGL(k_epochs_b, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
+      launches += 2;
     }
   });
   c->scratch_armed = false;
@@ -1062,6 +1387,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   if (captures_possible) {
     const uint32_t max_epochs = std::min(c->n_uncaptured, P) + 1;
     TIMED(c, BS_KERNEL_LEADER, hipLaunchKernelGGL(k_leader, dim3(max_epochs), dim3(kLeaderBlock), 0, c->stream, gr, b));
+    launches++;
   }
   // ---- decisions that need no node scan, request vectors, scan tiles
   TIMED(c, BS_KERNEL_QUERY, {
@@ -1076,6 +1402,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
         case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_tables<4>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
         default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query_tables<-1>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
       }
+      launches++;
     } else if (P) {
       const dim3 qg(cdiv(P, 256));
       switch (ts) {
@@ -1086,6 +1413,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
         case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<4>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
         default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_query<-1>), qg, blk, 0, c->stream, pd, gr, b, prm); break;
       }
+      launches++;
     }
   });
   if (early_filter) {
@@ -1100,8 +1428,9 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
       case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<4>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
       default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fparams_early<-1>), fg, blk, 0, c->stream3, pd, gr, b, prm); break;
     }
-    TIMED_ON(c, BS_KERNEL_FILTER, c->stream3, launch_filter(c, c->stream3, pd, gr, nd, b, use_classes, false, false, false, false));
+    TIMED_ON(c, BS_KERNEL_FILTER, c->stream3, launch_filter(c, c->stream3, pd, nd, b, use_classes));
     HIPCHK(c, hipEventRecord(c->ev_filter, c->stream3));
+    launches += 2;
   }
   // ---- running-sum tables of the (class, percent) pairs some query uses
   if (c->M && P) {
@@ -1111,6 +1440,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
         if (nchunks > 1)
           hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
       });
+      launches += nchunks > 1 ? 2 : 1;
     }
     const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
     const uint32_t tsplit = inline_tables ? 1u : std::min<uint32_t>(16, 2 * C);
@@ -1120,10 +1450,12 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     } else {
       TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg, P, G, tsplit));
     }
+    launches++;
   } else if (fuse_filter) {
     // no schedulable node: nothing to scan, Filter still has its slots to evaluate
     const uint32_t fblocks = cdiv(std::min<uint32_t>(c->filter_waves, 2 * cdiv(P, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4);
     TIMED(c, BS_KERNEL_SCAN, launch_scan_filter(c, 1u, fblocks, pd, nd, b, prm, 0u, 1u, P, G, 1u));
+    launches++;
   }
   // ---- REJECT codes, deny replay, stale-leader propagation, Filter parameters
   TIMED(c, BS_KERNEL_RESOLVE, {
@@ -1138,20 +1470,37 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
         case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<4>), fg, blk, 0, c->stream, pd, gr, nd, b, prm); break;
         default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<-1>), fg, blk, 0, c->stream, pd, gr, nd, b, prm); break;
       }
+      launches += 2;
     }
   });
   if (run_filter && P && !early_filter) {
-    TIMED(c, BS_KERNEL_FILTER, launch_filter(c, c->stream, pd, gr, nd, b, use_classes, fuse_tally, local_ready, rearm, fuse_filter));
+    if (!fuse_filter && W) {       // slot = pod (or class slots without the fused launch): Filter evaluation of the slots k_final filled
+      TIMED(c, BS_KERNEL_FILTER, launch_filter(c, c->stream, pd, nd, b, use_classes));
+      launches++;
+    }
   } else if (early_filter) {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_filter, 0));
-    const uint32_t wpb = 8;
-    hipLaunchKernelGGL(k_void_rows, dim3(cdiv(P, 256), cdiv(W, wpb)), blk, 0, c->stream, pd, b, W, wpb);
+    hipLaunchKernelGGL(k_void_rows, dim3(cdiv(P, 256)), blk, 0, c->stream, pd, b);
+    LAUNCHCHK(c, BS_KERNEL_FILTER);
+    launches++;
   } else if (P) {
     HIPCHK(c, hipMemsetAsync(b.fl_code, BS_FL_NOT_RUN, P, c->stream));
   }
+  // ---- per-pod feasible counts from the slots, per-group admit counts, quorum (last block), re-arm
+  const bool do_tally = stages & BS_STAGE_TALLY;
+  if (P ? (run_filter || do_tally) : do_tally) {
+    TIMED(c, BS_KERNEL_TALLY, {
+      hipLaunchKernelGGL(k_tally, dim3(std::max<uint32_t>(1, cdiv(P, kTallyBlock))), dim3(kTallyBlock), 0, c->stream, pd, gr, nd, b,
+                         run_filter ? 1u : 0u, do_tally ? 1u : 0u, (do_tally && local_ready) ? 1u : 0u, (do_tally && rearm) ? 1u : 0u);
+    });
+    launches++;
+  }
   if (stages & BS_BATCH_COMMIT) {
-    if (G) hipLaunchKernelGGL(k_commit, dim3(cdiv(G, 256)), blk, 0, c->stream, pd, b, prm, c->d_gflags.as<uint8_t>(), c->d_gcls.as<uint32_t>(),
-                              c->d_gminres.as<int64_t>(), c->d_gmrpres.as<uint32_t>(), c->d_gocc.as<uint64_t>(), G);
+    if (G) hipLaunchKernelGGL(k_commit, dim3(cdiv(G, 256)), blk, 0, c->stream, pd, b, prm, const_cast<uint8_t*>(gr.flags), const_cast<uint32_t*>(gr.cls),
+                              const_cast<int64_t*>(gr.minres), const_cast<uint32_t*>(gr.mrpres), const_cast<uint64_t*>(gr.occupied), G);
+    LAUNCHCHK(c, BS_KERNEL_RESOLVE);
+    launches++;
+    std::vector<uint32_t> cls(G);
     if (P) {
       int32_t last = -1;
       HIPCHK(c, hipMemcpyAsync(&last, b.pf_leader + (P - 1), 4, hipMemcpyDeviceToHost, c->stream));
@@ -1160,43 +1509,27 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     }
     // the committed capture may have given every group a pod
     if (G) {
-      HIPCHK(c, hipMemcpy(c->h_gflags.data(), c->d_gflags.p, G, hipMemcpyDeviceToHost));
-      HIPCHK(c, hipMemcpy(c->h_gcls.data(), c->d_gcls.p, (size_t)G * 4, hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(c->h_gflags.data(), gr.flags, G, hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(cls.data(), gr.cls, (size_t)G * 4, hipMemcpyDeviceToHost));
     }
     c->n_uncaptured = 0;
     c->n_nominres = 0;
+    c->max_group_cls = 0;
     for (uint32_t i = 0; i < G; ++i) {
       if (!(c->h_gflags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+      else c->max_group_cls = std::max(c->max_group_cls, cls[i]);
       if (!(c->h_gflags[i] & BS_GROUP_HAS_MINRES)) c->n_nominres++;
     }
     commit_dirty = true;
   }
-  c->last_stages = stages;
+  c->launches = launches;
   c->batch_seq++;
-  c->batch_pending_finish = false;
-  if (stages & BS_STAGE_TALLY) {
-    if (!fuse_tally) TIMED(c, BS_KERNEL_TALLY, {
-      hipLaunchKernelGGL(k_tally, dim3(std::max<uint32_t>(1, cdiv(P, kTallyBlock))), dim3(kTallyBlock), 0, c->stream, pd, gr, b,
-                         run_filter ? 1u : 0u, local_ready ? 1u : 0u, rearm ? 1u : 0u);
-    });
+  if (do_tally) {
     c->scratch_armed = rearm;
     c->side_ready = rearm && inline_tables;
-    if (c->nranks > 1 || c->reduce_external) {
-      if (c->comm) {
-        // native RCCL: one all-reduce(sum) of the per-group admit counters on the context stream
-        typedef int (*allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
-        allreduce_t ar = (allreduce_t)dlsym(c->rccl_handle, "ncclAllReduce");
-        if (!ar || ar(b.admit, b.admit, G, /*ncclUint32*/ 3, /*ncclSum*/ 0, c->comm, c->stream) != 0) {
-          c->last_error = "ncclAllReduce failed";
-          return BS_ERR_COMM;
-        }
-        if (G) hipLaunchKernelGGL(k_ready, dim3(cdiv(G, 256)), blk, 0, c->stream, gr, b);
-      } else {
-        c->batch_pending_finish = true;   // caller reduces bs_group_admit_devptr, then bs_batch_finish
-      }
-    }
   }
-  HIPCHK(c, hipGetLastError());
+  rc = batch_collective(c, stages, gr, b);
+  if (rc) return rc;
   if (commit_dirty) return analyse_groups(c);
   return BS_OK;
 }
@@ -1220,18 +1553,59 @@ int bs_batch_sync(bs_ctx* c) {
   return BS_OK;
 }
 
+// rows the last batch's Filter slots occupy: 2 x request classes (the batch's leader | the leader carried into
+// the batch) when classes stand for the pods, one per pod otherwise
+static int filter_rows_of(bs_ctx* c, uint32_t* rows) {
+  int rc = resolve_pods(c);
+  if (rc) return rc;
+  // the mode of the last batch over these pods if there was one, else of the batch the loaded state would run
+  const bool classes = c->batch_since_pods ? c->last_use_classes : (c->n_uncaptured == 0 && c->n_nominres == 0);
+  *rows = c->P ? (classes ? 2 * c->h_K : c->P) : 0;
+  return BS_OK;
+}
+
+int bs_filter_rows_count(bs_ctx* c, uint32_t* rows) {
+  if (!c || !rows) return BS_ERR_INVALID;
+  if (!c->have_pods || !c->have_groups) return BS_ERR_STATE;
+  int rc = use_device(c);
+  if (rc) return rc;
+  return filter_rows_of(c, rows);
+}
+
 int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   if (!c || !out) return BS_ERR_INVALID;
   if (!c->have_pods || !c->have_groups) return BS_ERR_STATE;
   int rc = use_device(c);
   if (rc) return rc;
   const uint32_t P = c->P, G = c->G, W = cdiv(c->N, 64);
-  const bool want_pod = P && (out->pf_code || out->pf_first_k || out->pf_leader || out->fl_code || out->fl_feasible);
+  const bool filtered = c->last_stages & BS_STAGE_FILTER;
+  const bool want_pod = P && (out->pf_code || out->pf_first_k || out->pf_leader || out->fl_code || out->fl_feasible || out->fl_slot);
   const bool want_grp = G && (c->last_stages & BS_STAGE_TALLY) && (out->group_admit || out->group_ready);
-  // everything small travels in ONE wait: the packed per-pod results and the two per-group arrays are copied
-  // asynchronously into the pinned staging buffer, then the stream is synchronised once
-  const size_t off_admit = (c->outpack_bytes + 255) & ~(size_t)255, off_ready = off_admit + (((size_t)G * 4 + 255) & ~(size_t)255);
-  rc = ensure_stage(c, std::max(c->podpack_bytes, off_ready + G + 256));
+  // Filter rows: the slots of the last batch, word-major, compacted to the rows in use
+  uint32_t nrows = 0;
+  if (out->fl_rows || out->fl_rows_feasible || out->fl_rows_n) {
+    if (filtered && (rc = filter_rows_of(c, &nrows))) return rc;
+    if (out->fl_rows_n) *out->fl_rows_n = nrows;
+    if ((out->fl_rows || out->fl_rows_feasible) && nrows > out->fl_rows_cap) {
+      c->last_error = "bs_batch_read: fl_rows_cap is smaller than the rows of the batch";
+      return BS_ERR_CAPACITY;
+    }
+  }
+  const bool want_rows = nrows && W && out->fl_rows, want_rfeas = nrows && out->fl_rows_feasible;
+  // the pods x nodes bitmap exists only when somebody asks for it
+  if (P && W && out->fl_bitmap && filtered && !c->bitmap_valid) {
+    HIPCHK(c, c->d_fl_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
+    hipLaunchKernelGGL(k_filter_expand, dim3(cdiv(P, 256), std::max<uint32_t>(1, cdiv(W, kExpandWords))), dim3(256), 0, c->stream, pods_dev(c),
+                       nodes_dev(c), batch_dev(c), W, c->filter_slots_cap);
+    LAUNCHCHK(c, BS_KERNEL_FILTER);
+    c->bitmap_valid = true;
+  }
+  // everything small travels under ONE wait: the packed per-pod results, the two per-group arrays and the Filter
+  // rows are copied asynchronously into the pinned staging buffer, then the stream is synchronised once
+  const size_t off_admit = align256(c->outpack_bytes), off_ready = off_admit + align256((size_t)G * 4);
+  const size_t off_rfeas = off_ready + align256(G), off_rows = off_rfeas + align256((size_t)nrows * 4);
+  const size_t rows_bytes = want_rows ? (size_t)W * nrows * 8 : 0;
+  rc = ensure_stage(c, std::max(c->podpack_bytes, off_rows + rows_bytes + 256));
   if (rc) return rc;
   uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
   if (want_pod) HIPCHK(c, hipMemcpyAsync(st, c->d_outpack.p, c->outpack_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1239,6 +1613,10 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
     if (out->group_admit) HIPCHK(c, hipMemcpyAsync(st + off_admit, c->ext_admit ? (void*)c->ext_admit : c->d_admit.p, (size_t)G * 4, hipMemcpyDeviceToHost, c->stream));
     if (out->group_ready) HIPCHK(c, hipMemcpyAsync(st + off_ready, c->d_ready.p, G, hipMemcpyDeviceToHost, c->stream));
   }
+  if (want_rfeas) HIPCHK(c, hipMemcpyAsync(st + off_rfeas, c->d_fu_feas.p, (size_t)nrows * 4, hipMemcpyDeviceToHost, c->stream));
+  if (want_rows)
+    HIPCHK(c, hipMemcpy2DAsync(st + off_rows, (size_t)nrows * 8, c->d_fu_bitmap.p, (size_t)c->filter_slots_cap * 8, (size_t)nrows * 8, W,
+                               hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stage_busy = false;
   if (want_pod) {
@@ -1247,13 +1625,17 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
     if (out->pf_leader) std::memcpy(out->pf_leader, st + c->off_pf_leader, (size_t)P * 4);
     if (out->fl_code) std::memcpy(out->fl_code, st + c->off_fl_code, P);
     if (out->fl_feasible) std::memcpy(out->fl_feasible, st + c->off_fl_feasible, (size_t)P * 4);
+    if (out->fl_slot) std::memcpy(out->fl_slot, st + c->off_fl_slot, (size_t)P * 4);
   }
   if (want_grp) {
     if (out->group_admit) std::memcpy(out->group_admit, st + off_admit, (size_t)G * 4);
     if (out->group_ready) std::memcpy(out->group_ready, st + off_ready, G);
   }
+  if (want_rfeas) std::memcpy(out->fl_rows_feasible, st + off_rfeas, (size_t)nrows * 4);
+  if (want_rows)
+    for (uint32_t w = 0; w < W; ++w) std::memcpy(out->fl_rows + (size_t)w * out->fl_rows_cap, st + off_rows + (size_t)w * nrows * 8, (size_t)nrows * 8);
   if (P && out->fl_bitmap && W) {
-    if (c->last_stages & BS_STAGE_FILTER) HIPCHK(c, hipMemcpy(out->fl_bitmap, c->d_fl_bitmap.p, (size_t)W * P * 8, hipMemcpyDeviceToHost));
+    if (filtered) HIPCHK(c, hipMemcpy(out->fl_bitmap, c->d_fl_bitmap.p, (size_t)W * P * 8, hipMemcpyDeviceToHost));
     else std::memset(out->fl_bitmap, 0, (size_t)W * P * 8);
   }
   return BS_OK;
@@ -1406,6 +1788,7 @@ int bs_filter_one(bs_ctx* c, int32_t pod_group, const int64_t* pod_req, uint32_t
   // expressible, so this entry point evaluates through k_filter_params/k_filter with a one-pod view.
   if (!c || !pod_req || !fl_code || !fn_code) return BS_ERR_INVALID;
   if (!c->have_nodes || !c->have_groups) return BS_ERR_STATE;
+  if (leader >= 0 && (uint32_t)leader >= c->G) { c->last_error = "bs_filter_one: leader out of range"; return BS_ERR_INVALID; }
   int rc = use_device(c);
   if (rc) return rc;
   const uint32_t L = c->L, N = c->N;
@@ -1496,6 +1879,9 @@ int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
     al[j].assign(c->h_alloc.begin() + (size_t)j * N, c->h_alloc.begin() + (size_t)(j + 1) * N);
     rq[j].assign(c->h_nreq.begin() + (size_t)j * N, c->h_nreq.begin() + (size_t)(j + 1) * N);
   }
+  // presence / flag mirrors are edited in copies too: an invalid delta anywhere in the list leaves the context untouched
+  std::vector<uint32_t> apres = c->h_apres, rpres = c->h_rpres;
+  std::vector<uint8_t> nflags = c->h_nflags;
   uint32_t lo = N;                     // first list index whose content changes
   for (uint32_t d = 0; d < count; ++d) {
     const bs_node_delta& x = deltas[d];
@@ -1503,9 +1889,9 @@ int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
     if (x.kind == BS_DELTA_REMOVE) {
       if (x.index >= N) return BS_ERR_INVALID;
       for (uint32_t j = 0; j < L; ++j) { al[j].erase(al[j].begin() + x.index); rq[j].erase(rq[j].begin() + x.index); }
-      c->h_apres.erase(c->h_apres.begin() + x.index);
-      c->h_rpres.erase(c->h_rpres.begin() + x.index);
-      c->h_nflags.erase(c->h_nflags.begin() + x.index);
+      apres.erase(apres.begin() + x.index);
+      rpres.erase(rpres.begin() + x.index);
+      nflags.erase(nflags.begin() + x.index);
       for (uint32_t cl = 0; cl < C; ++cl) fit[cl].erase(fit[cl].begin() + x.index);
       --N;
       continue;
@@ -1514,15 +1900,15 @@ int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
     if (x.kind == BS_DELTA_APPEND) {
       at = N++;
       for (uint32_t j = 0; j < L; ++j) { al[j].push_back(0); rq[j].push_back(0); }
-      c->h_apres.push_back(0); c->h_rpres.push_back(0); c->h_nflags.push_back(0);
+      apres.push_back(0); rpres.push_back(0); nflags.push_back(0);
       for (uint32_t cl = 0; cl < C; ++cl) fit[cl].push_back(0);
     } else if (x.kind != BS_DELTA_UPDATE || at >= N) {
       return BS_ERR_INVALID;
     }
     for (uint32_t j = 0; j < L; ++j) { al[j][at] = x.allocatable[j]; rq[j][at] = x.requested[j]; }
-    c->h_apres[at] = x.allocatable_present;
-    c->h_rpres[at] = x.requested_present;
-    c->h_nflags[at] = (uint8_t)x.flags;
+    apres[at] = x.allocatable_present;
+    rpres[at] = x.requested_present;
+    nflags[at] = (uint8_t)x.flags;
     if (x.n_fit_exceptions > 8) return BS_ERR_INVALID;
     for (uint32_t cl = 0; cl < C; ++cl) fit[cl][at] = x.fit_default ? 1 : 0;
     for (uint32_t e = 0; e < x.n_fit_exceptions; ++e) {
@@ -1531,6 +1917,9 @@ int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
     }
   }
   c->N = N;
+  c->h_apres.swap(apres);
+  c->h_rpres.swap(rpres);
+  c->h_nflags.swap(nflags);
   c->h_alloc.resize((size_t)L * N);
   c->h_nreq.resize((size_t)L * N);
   for (uint32_t j = 0; j < L; ++j) {
@@ -1561,11 +1950,13 @@ static void* open_rccl() {
 
 int bs_comm_unique_id(uint8_t id[128]) {
   if (!id) return BS_ERR_INVALID;
+  static_assert(sizeof(ncclUniqueId) == 128, "the ABI hands the RCCL unique id over as 128 bytes");
   void* h = open_rccl();
   if (!h) return BS_ERR_COMM;
-  typedef int (*getid_t)(void*);
-  getid_t f = (getid_t)dlsym(h, "ncclGetUniqueId");
-  if (!f || f(id) != 0) return BS_ERR_COMM;
+  auto f = (decltype(&ncclGetUniqueId))dlsym(h, "ncclGetUniqueId");
+  ncclUniqueId u;
+  if (!f || f(&u) != ncclSuccess) return BS_ERR_COMM;
+  std::memcpy(id, u.internal, 128);
   return BS_OK;
 }
 
@@ -1575,12 +1966,15 @@ int bs_comm_init(bs_ctx* c, const uint8_t id[128], uint32_t rank, uint32_t nrank
   if (rc) return rc;
   void* h = open_rccl();
   if (!h) { c->last_error = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "?"); return BS_ERR_COMM; }
-  struct uid { char internal[128]; } u;
+  ncclUniqueId u;
   std::memcpy(u.internal, id, 128);
-  typedef int (*init_t)(void**, int, uid, int);
-  init_t f = (init_t)dlsym(h, "ncclCommInitRank");
-  void* comm = nullptr;
-  if (!f || f(&comm, (int)nranks, u, (int)rank) != 0) { c->last_error = "ncclCommInitRank failed"; return BS_ERR_COMM; }
+  auto init = (decltype(&ncclCommInitRank))dlsym(h, "ncclCommInitRank");
+  c->rccl_allreduce = (decltype(&ncclAllReduce))dlsym(h, "ncclAllReduce");
+  c->rccl_destroy = (decltype(&ncclCommDestroy))dlsym(h, "ncclCommDestroy");
+  ncclComm_t comm = nullptr;
+  if (!init || !c->rccl_allreduce || !c->rccl_destroy) { c->last_error = "librccl lacks ncclCommInitRank / ncclAllReduce / ncclCommDestroy"; return BS_ERR_COMM; }
+  const ncclResult_t r = init(&comm, (int)nranks, u, (int)rank);
+  if (r != ncclSuccess) { c->last_error = std::string("ncclCommInitRank failed: code ") + std::to_string((int)r); return BS_ERR_COMM; }
   c->rccl_handle = h;
   c->comm = comm;
   c->rank = rank;
@@ -1633,7 +2027,9 @@ int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {
   out->scan_queries = raw[4];
   out->scan_queries_logical = raw[2];
   out->class_mode = c->last_use_classes ? 1 : 0;
-  out->tables_built = nt;
+  out->fast_path = c->last_fast ? 1 : 0;
+  out->launches = c->launches;
+  out->tables_built = c->last_fast ? 1 : nt;
   out->logical_evals = (uint64_t)c->P * c->N;
   out->filter_evals = (c->last_stages & BS_STAGE_FILTER) ? (uint64_t)c->P * c->N : 0;
   if (c->last_stages & BS_STAGE_FILTER) {

@@ -36,15 +36,15 @@ _EFFECTS = {"": EFFECT_NONE, "NoSchedule": EFFECT_NO_SCHEDULE, "PreferNoSchedule
 _TOL_OPS = {"": TOL_OP_DEFAULT, "Equal": TOL_OP_EQUAL, "Exists": TOL_OP_EXISTS}
 _OPS = {"In": OP_IN, "NotIn": OP_NOT_IN, "Exists": OP_EXISTS, "DoesNotExist": OP_DOES_NOT_EXIST, "Gt": OP_GT, "Lt": OP_LT}
 
-_INT_RE = re.compile(r"^[+-]?[0-9]+$")
-_NAME_RE = re.compile(r"^([A-Za-z0-9][-A-Za-z0-9_.]*)?[A-Za-z0-9]$")
+_INT_RE = re.compile(r"[+-]?[0-9]+")
+_NAME_RE = re.compile(r"([A-Za-z0-9][-A-Za-z0-9_.]*)?[A-Za-z0-9]")
 _DNS_LABEL = r"[a-z0-9]([-a-z0-9]*[a-z0-9])?"
-_SUBDOMAIN_RE = re.compile(r"^" + _DNS_LABEL + r"(\." + _DNS_LABEL + r")*$")
+_SUBDOMAIN_RE = re.compile(_DNS_LABEL + r"(\." + _DNS_LABEL + r")*")
 
 
 def parse_int(s: str):
     """strconv.ParseInt(s, 10, 64): optional sign, decimal digits only, must fit int64."""
-    if not _INT_RE.match(s):
+    if not _INT_RE.fullmatch(s):
         return 0, False
     v = int(s)
     if v < -(1 << 63) or v > (1 << 63) - 1:
@@ -60,16 +60,16 @@ def label_key_ok(key: str) -> bool:
         name = parts[0]
     elif len(parts) == 2:
         prefix, name = parts
-        if not prefix or len(prefix) > 253 or not _SUBDOMAIN_RE.match(prefix):
+        if not prefix or len(prefix) > 253 or not _SUBDOMAIN_RE.fullmatch(prefix):
             return False
     else:
         return False
-    return 0 < len(name) <= 63 and bool(_NAME_RE.match(name))
+    return 0 < len(name) <= 63 and bool(_NAME_RE.fullmatch(name))
 
 
 def label_value_ok(value: str) -> bool:
     """validation.IsValidLabelValue: empty, or at most 63 chars shaped like a qualified-name part."""
-    return value == "" or (len(value) <= 63 and bool(_NAME_RE.match(value)))
+    return value == "" or (len(value) <= 63 and bool(_NAME_RE.fullmatch(value)))
 
 
 class Interner:

@@ -28,6 +28,7 @@
 namespace {
 
 constexpr int64_t kSecond = 1000000000LL;
+constexpr uint32_t BSH_START_BATCH_TOO_SMALL = 0xFFFFFFFFu;   // bsh_start_batch: the gang does not fit the caller's buffers
 
 // patrickmn/go-cache v2.1.0 (go.mod:67): Set overwrites; Add fails while a live item exists; an item is
 // expired when now > expiration (strictly); Items() returns the unexpired ones.
@@ -339,19 +340,23 @@ int bsh_less(const bsh_sop* s, int32_t group1, int32_t prio1, int64_t ts1, int32
 // StartBatchSchedule, batchscheduler.go:254-344, in-memory part: when the quorum still holds, every
 // matched pod is allowed (returned to the caller, who binds it) and leaves MatchedPodNodes.
 // out_uids / out_nodes: capacity `cap`; returns the number released, 0 when the phase / quorum gate closes.
+// A gang larger than `cap` is NOT released in part (the surplus would leave the cache without ever being
+// bound): nothing is touched and BSH_START_BATCH_TOO_SMALL is returned; size the buffers from bsh_group_matched.
 uint32_t bsh_start_batch(bsh_sop* s, int32_t group, uint64_t* out_uids, uint32_t* out_nodes, uint32_t cap) {
   if (group < 0 || (size_t)group >= s->groups.size()) return 0;
   Group& pgs = s->groups[group];
   if (pgs.phase != PreScheduling && pgs.phase != Scheduling) return 0;            // :258-261
   const uint32_t have = pgs.matched.Count(s->now);
   if (have < (uint32_t)(pgs.min_member - pgs.status_scheduled)) return 0;          // :303-305
+  if (have > cap) return BSH_START_BATCH_TOO_SMALL;
   uint32_t n = 0;
   std::vector<uint64_t> keys = pgs.matched.Keys(s->now);
   std::sort(keys.begin(), keys.end());     // Go map order is random; any order releases the same set
   for (uint64_t uid : keys) {
     uint64_t node = 0;
     pgs.matched.Get(uid, s->now, &node);
-    if (n < cap) { out_uids[n] = uid; out_nodes[n] = (uint32_t)node; }
+    out_uids[n] = uid;
+    out_nodes[n] = (uint32_t)node;
     n++;
     pgs.matched.Delete(uid);               // :332 (pendingPodNameIDs.Delete(uid) at :333 uses the wrong key: a no-op)
   }

@@ -140,11 +140,17 @@ class ScheduleOperation:
         """a, b = (group, priority, queue_timestamp) — batchscheduler.go:214 -> core.go:368"""
         return bool(self._lib.bsh_less(self._h, a[0], a[1], a[2], b[0], b[1], b[2]))
 
-    def StartBatchSchedule(self, group: int, cap: int = 4096):
+    def StartBatchSchedule(self, group: int, cap: int | None = None):
+        """batchscheduler.go:254-344: releases the whole gang or nothing.  Buffers are sized from the group's
+        matched count; an explicit `cap` that is too small releases nothing and raises."""
+        if cap is None:
+            cap = max(1, int(self._lib.bsh_group_matched(self._h, group))) if 0 <= group else 1
         uids = (C.c_uint64 * cap)()
         nodes = (C.c_uint32 * cap)()
         n = int(self._lib.bsh_start_batch(self._h, group, uids, nodes, cap))
-        return [(int(uids[i]), int(nodes[i])) for i in range(min(n, cap))]
+        if n == 0xFFFFFFFF:
+            raise ValueError(f"StartBatchSchedule: gang of group {group} does not fit cap={cap}; nothing was released")
+        return [(int(uids[i]), int(nodes[i])) for i in range(n)]
 
     def group_state(self, g: int) -> dict:
         f = int(self._lib.bsh_group_flags(self._h, g))

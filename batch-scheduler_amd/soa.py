@@ -92,7 +92,17 @@ class BatchOutStruct(C.Structure):
                 ("fl_feasible", C.POINTER(C.c_uint32)),
                 ("fl_bitmap", C.POINTER(C.c_uint64)),
                 ("group_admit", C.POINTER(C.c_uint32)),
-                ("group_ready", C.POINTER(C.c_uint8))]
+                ("group_ready", C.POINTER(C.c_uint8)),
+                ("fl_slot", C.POINTER(C.c_uint32)),
+                ("fl_rows", C.POINTER(C.c_uint64)),
+                ("fl_rows_feasible", C.POINTER(C.c_uint32)),
+                ("fl_rows_cap", C.c_uint32),
+                ("fl_rows_n", C.POINTER(C.c_uint32))]
+
+
+class GroupDelta(C.Structure):
+    """bs_group_delta: replaces matched / status_scheduled / flags of group `index` (bs_groups_apply)."""
+    _fields_ = [("index", C.c_uint32), ("matched", C.c_uint32), ("status_scheduled", C.c_uint32), ("flags", C.c_uint32)]
 
 
 @dataclass
@@ -255,7 +265,10 @@ class Pods:
 
 @dataclass
 class BatchOut:
-    """Host-side result arrays of one batch."""
+    """Host-side result arrays of one batch.
+
+    Filter results come as rows of the DISTINCT requests (`fl_rows` [words, rows_cap], `fl_slot` [p]) — the
+    pods x nodes bitmap `fl_bitmap` is opt-in (the library materialises it only when asked)."""
     pf_code: np.ndarray
     pf_first_k: np.ndarray
     pf_leader: np.ndarray
@@ -264,22 +277,57 @@ class BatchOut:
     fl_bitmap: np.ndarray | None
     group_admit: np.ndarray
     group_ready: np.ndarray
+    fl_slot: np.ndarray | None = None
+    fl_rows: np.ndarray | None = None          # [ceil(n/64), rows_cap] uint64
+    fl_rows_feasible: np.ndarray | None = None
+    fl_rows_n: np.ndarray | None = None        # [1] uint32, filled by the library
+    n: int = 0
     _keep: list = field(default_factory=list, repr=False)
 
     @staticmethod
-    def alloc(p: int, g: int, n: int, bitmap: bool = True) -> "BatchOut":
+    def alloc(p: int, g: int, n: int, bitmap: bool = True, rows_cap: int = 0) -> "BatchOut":
         w = (n + 63) // 64
-        return BatchOut(np.zeros(p, np.uint8), np.zeros(p, np.uint32), np.zeros(p, np.int32), np.zeros(p, np.uint8),
-                        np.zeros(p, np.uint32), np.zeros((w, p), np.uint64) if bitmap else None,
-                        np.zeros(g, np.uint32), np.zeros(g, np.uint8))
+        out = BatchOut(np.zeros(p, np.uint8), np.zeros(p, np.uint32), np.zeros(p, np.int32), np.zeros(p, np.uint8),
+                       np.zeros(p, np.uint32), np.zeros((w, p), np.uint64) if bitmap else None,
+                       np.zeros(g, np.uint32), np.zeros(g, np.uint8), n=n)
+        if rows_cap:
+            out.fl_slot = np.zeros(p, np.uint32)
+            out.fl_rows = np.zeros((w, rows_cap), np.uint64)
+            out.fl_rows_feasible = np.zeros(rows_cap, np.uint32)
+            out.fl_rows_n = np.zeros(1, np.uint32)
+        return out
 
     def as_struct(self) -> BatchOutStruct:
-        null64 = C.POINTER(C.c_uint64)()
+        null64, null32 = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)()
+        rows = self.fl_rows is not None
         return BatchOutStruct(_ptr(self.pf_code, C.c_uint8), _ptr(self.pf_first_k, C.c_uint32),
                               _ptr(self.pf_leader, C.c_int32), _ptr(self.fl_code, C.c_uint8),
                               _ptr(self.fl_feasible, C.c_uint32),
                               _ptr(self.fl_bitmap, C.c_uint64) if self.fl_bitmap is not None else null64,
-                              _ptr(self.group_admit, C.c_uint32), _ptr(self.group_ready, C.c_uint8))
+                              _ptr(self.group_admit, C.c_uint32), _ptr(self.group_ready, C.c_uint8),
+                              _ptr(self.fl_slot, C.c_uint32) if rows else null32,
+                              _ptr(self.fl_rows, C.c_uint64) if rows else null64,
+                              _ptr(self.fl_rows_feasible, C.c_uint32) if rows else null32,
+                              self.fl_rows.shape[1] if rows else 0,
+                              _ptr(self.fl_rows_n, C.c_uint32) if rows else null32)
 
     def node_passes(self, pod: int, node: int) -> bool:
-        return bool((int(self.fl_bitmap[node >> 6, pod]) >> (node & 63)) & 1)
+        """Filter(pod, node) from the slot rows: the bit test the Go plugin's Filter does (no cgo crossing)."""
+        if self.fl_rows is None:
+            return bool((int(self.fl_bitmap[node >> 6, pod]) >> (node & 63)) & 1)
+        fl = int(self.fl_code[pod])
+        if fl != FL_EVALUATED:
+            return fl < 16 and node < self.n
+        return bool((int(self.fl_rows[node >> 6, int(self.fl_slot[pod])]) >> (node & 63)) & 1)
+
+    def bitmap_from_rows(self) -> np.ndarray:
+        """[ceil(n/64), p] bitmap rebuilt on the host from the slot rows (tests: must equal the expanded one)."""
+        w, p = self.fl_rows.shape[0], self.fl_code.shape[0]
+        out = np.zeros((w, p), np.uint64)
+        ev = self.fl_code == FL_EVALUATED
+        out[:, ev] = self.fl_rows[:, self.fl_slot[ev]]
+        full = np.full(w, np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+        if self.n & 63 and w:
+            full[-1] = np.uint64((1 << (self.n & 63)) - 1)
+        out[:, (~ev) & (self.fl_code < 16)] = full[:, None]
+        return out

@@ -2,23 +2,35 @@
 """bench.py — pod x node fit evaluations / s of the batched gang-feasibility path on MI355X.
 
 One "step" = one pass of the hot path over one batch that is already resident in HBM:
-PreFilter (core.go:88-167) for every pending pod against the node snapshot, Filter
-(core.go:514-564) for every (pod, node), per-group admit counts and the Permit quorum
-(core.go:303).  Workload at N=1: BASELINE.json's metric configuration "10k pods x 5k nodes"
-(configs[2]: 10k pods / 2k groups / 5k nodes, 4 resource dims), scenario "tail" (synth.py).
-For N>1 the pod axis is sharded over ranks (weak scaling: N x 10k pods, N x 2k groups, the same
-5k nodes replicated) with ONE all-reduce of the per-group admit counters per step.
+PreFilter (core.go:88-167) for every pending pod against the node snapshot (running-sum table rebuilt every
+step), Filter (core.go:514-564) for every (pod, node), per-group admit counts and the Permit quorum
+(core.go:303).  Workload at N=1: BASELINE.json's metric configuration "10k pods x 5k nodes" (configs[2]:
+10k pods / 2k groups / 5k nodes, 4 resource dims), scenario "tail" (synth.py).
+N>1: the pod axis is sharded over ranks with ONE all-reduce of the per-group admit counters per step;
+  --scaling weak   (default) N x 10k pods, N x 2k groups, the same 5k nodes replicated
+  --scaling strong the configuration is FIXED (use --config cfg4: 50k / 5k / 20k) and split over the ranks.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement).  Beside the contract's fields:
+  roofline        the longest launch of the step, priced on EXECUTED work (no figure can exceed 1); `roofline_launches`
+                  has every launch; `work_avoided` says how much of the logical pods x nodes space was never evaluated
+  host_cycle      SURVEY 8(d)'s host-observed scheduling cycle: group patch + pod H2D + batch + decision / Filter-row
+                  D2H, p50 / p95, and the evals/s that corresponds to it (PCIe inclusive — never `value`)
+  scenarios       cold / warm / busy / all-distinct requests / PreFilter-only, seeds 1..3
+  cpu_baseline    the oracle (C port of the Go path) on 1 core and on all host cores
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
+import glob
 import importlib
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,7 +39,9 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
+VOPC_EVALS_PER_S = 4.1e12   # 64-bit v_cmp issue rate x 64 lanes, measured by tools/ubench/cmp_rate.hip (profiles/r01*)
+LAUNCH_KERNELS = {"query": "k_fast_query_tables", "scan": "k_fast_scan_filter", "resolve": "k_fast_final"}
 
 
 def parse():
@@ -37,18 +51,41 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--scenario", default="tail")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--seed", type=int, default=20260921)
     ap.add_argument("--stages", default="all", choices=["all", "prefilter"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip scenarios / seeds / host-cycle measurements")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-run under rocprofv3 --pmc for HBM traffic")
+    ap.add_argument("--inner-pmc", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-reps", type=int, default=2)
     return ap.parse_args()
 
 
-def cpu_baseline(bsa, nodes, fit, groups, pods, stages, reps):
-    """The oracle (C port of the Go path, 1 core — upstream runs PreFilter on the single scheduling
-    goroutine) on the rank-0 share of the same workload.  Checker code, timed as the baseline only."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
+    return orc
+
+
+_MP = {}
+
+
+def _mp_worker(r):
+    orc, snap, groups, pods, stages, own = _MP["a"]
+    sub = pods.take(np.nonzero(own == r)[0])
+    sop = orc.Sop(snap, groups)
+    t0 = time.perf_counter()
+    sop.batch(sub, stages, bitmap=bool(stages & 2))
+    return time.perf_counter() - t0, sop.iters
+
+
+def cpu_baseline(bsa, nodes, fit, groups, pods, stages, reps):
+    """The oracle (C port of the Go path) on the same inputs and stages — checker code, timed as the baseline only.
+    1 core: upstream runs PreFilter on the single scheduling goroutine.  All cores: whole groups dealt over forked
+    workers (exact here: no pod's decision depends on a pod of another group in this scenario)."""
+    orc = _oracle()
     snap = orc.Snapshot(nodes, fit)
     best, iters = None, 0
     for _ in range(reps):
@@ -59,12 +96,128 @@ def cpu_baseline(bsa, nodes, fit, groups, pods, stages, reps):
         iters = sop.iters
         best = dt if best is None else min(best, dt)
     logical = pods.p * nodes.n
-    return {"value": logical / best, "unit": "pod x node fit evals/s", "cores": 1, "kind": "port",
+    ncores = os.cpu_count() or 1
+    allc = None
+    try:
+        import multiprocessing as mp
+        bdist = importlib.import_module("batch-scheduler_amd.dist")
+        own = bdist.owner_ranks(pods.group, groups.g, ncores)
+        _MP["a"] = (orc, snap, groups, pods, stages, own)
+        with mp.get_context("fork").Pool(ncores) as pool:
+            pool.map(abs, range(ncores))                     # workers are up
+            t0 = time.perf_counter()
+            pool.map(_mp_worker, range(ncores))
+            wall = time.perf_counter() - t0
+        allc = {"value": logical / wall, "cores": ncores, "seconds_per_batch": wall}
+    except Exception as e:                                    # pragma: no cover
+        allc = {"error": repr(e)}
+    return {"value": logical / best, "unit": "pod x node fit evals/s", "cores": 1, "kind": "port", "faithful_cost": False,
             "sample": f"{reps} x one full batch ({pods.p} pods x {nodes.n} nodes, same seeded inputs, same stages), best of {reps}; "
-                      f"reference node-loop iterations executed (core.go:604) = {iters} of {logical} logical",
-            "seconds_per_batch": best, "reference_loop_iterations": iters}
+                      f"reference node-loop iterations executed (core.go:604) = {iters} of {logical} logical; oracle's faithful_cost switch off "
+                      f"(the reference's unconditional computeClusterResource scan at core.go:152 is NOT charged to the baseline)",
+            "seconds_per_batch": best, "reference_loop_iterations": iters, "all_cores": allc}
 
 
+# ------------------------------------------------------------------------------------------------ HBM traffic (PMC)
+def pmc_traffic(args):
+    """HBM bytes per launch for the three launches of the step: this very command re-run (few steps, no extras) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domains), FETCH doubled per the gfx950
+    note of MI355X_MICROARCH.md.  Returns (dict kernel -> bytes, source)."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="bs_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--inner-pmc",
+                   "--config", args.config, "--scenario", args.scenario, "--seed", str(args.seed), "--stages", args.stages]
+            env = dict(os.environ, TMPDIR="/tmp")
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if res.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode})"
+            con = sqlite3.connect(dbs[0])
+            rows = con.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name",
+                               (counter,)).fetchall()
+            con.close()
+            for name, n, v in rows:
+                for key, kn in LAUNCH_KERNELS.items():
+                    if kn + "<" in name or kn + "(" in name:
+                        out.setdefault(key, {})[counter] = (int(n), float(v))
+    except Exception as e:                                    # pragma: no cover
+        return None, f"pmc pass failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for key, v in out.items():
+        f, w = v.get("FETCH_SIZE", (0, 0.0)), v.get("WRITE_SIZE", (0, 0.0))
+        res[key] = {"fetch_kb": f[1], "write_kb": w[1], "dispatches": f[0] or w[0], "hbm_bytes_per_launch": int(f[1] * 1024 * 2 + w[1] * 1024)}
+    return (res or None), "measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def resident_ms(bsa, nodes, fit, groups, pods, stages, steps, warmup=10):
+    """ms per step of a batch resident in HBM on a fresh single-GPU context + its work counters."""
+    with bsa.Context(scalar_lanes=nodes.lanes - 4) as ctx:
+        ctx.load_nodes(nodes, fit)
+        ctx.load_groups(groups)
+        ctx.load_pods(pods)
+        for _ in range(warmup):
+            ctx.run(stages)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.run(stages)
+        ctx.sync()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        st = ctx.stats(stages)
+    return ms, st
+
+
+def pct(xs, q):
+    return float(np.percentile(xs, q)) if len(xs) else None
+
+
+def host_cycle(bsa, ctx, groups, pods, nodes, stages, iters=60):
+    """One scheduling cycle as the Go shim would drive it, host-observed: patch the groups that changed (Permit /
+    PostBind counters), hand over the pending pods, run the batch, read decisions + Filter rows back."""
+    soa = bsa.soa
+    rows_cap = max(ctx.filter_rows_count(), 1)
+    out = soa.BatchOut.alloc(pods.p, groups.g, nodes.n, bitmap=False, rows_cap=rows_cap)
+    rng = np.random.default_rng(1)
+    idx = rng.choice(groups.g, min(32, groups.g), replace=False)
+    deltas = [(int(i), int(groups.matched[i]), int(groups.status_scheduled[i]), int(groups.flags[i])) for i in idx]   # same values: decisions stay put
+    parts = {"groups_apply": [], "pods_load": [], "run_sync": [], "read": [], "total": [], "total_full_groups_load": []}
+    for it in range(iters + 5):
+        t0 = time.perf_counter()
+        ctx.apply_group_deltas(deltas)
+        t1 = time.perf_counter()
+        ctx.load_pods(pods)
+        t2 = time.perf_counter()
+        ctx.run(stages)
+        t3 = time.perf_counter()
+        ctx.read(out=out)
+        t4 = time.perf_counter()
+        if it >= 5:
+            parts["groups_apply"].append((t1 - t0) * 1e3)
+            parts["pods_load"].append((t2 - t1) * 1e3)
+            parts["run_sync"].append((t3 - t2) * 1e3)
+            parts["read"].append((t4 - t3) * 1e3)
+            parts["total"].append((t4 - t0) * 1e3)
+    for it in range(iters // 2 + 5):
+        t0 = time.perf_counter()
+        ctx.load_groups(groups)
+        ctx.load_pods(pods)
+        ctx.run(stages)
+        ctx.read(out=out)
+        if it >= 5:
+            parts["total_full_groups_load"].append((time.perf_counter() - t0) * 1e3)
+    return {k: {"p50_ms": pct(v, 50), "p95_ms": pct(v, 95)} for k, v in parts.items()}, int(out.fl_rows_n[0]), out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,12 +243,13 @@ def main():
         torch.cuda.set_device(local_rank)
 
     base = synth.CONFIGS[args.config]
+    mult = world if args.scaling == "weak" else 1
     nodes, fit, groups, pods, meta = synth.make(args.config, args.scenario, seed=args.seed,
-                                                pods=base["pods"] * world, groups=base["groups"] * world)
+                                                pods=base["pods"] * mult, groups=base["groups"] * mult)
     stages = soa.STAGE_ALL if args.stages == "all" else (soa.STAGE_PREFILTER | soa.STAGE_TALLY)
     L = nodes.lanes
 
-    ctx = bsa.Context(scalar_lanes=L - 4, device=local_rank, enable_timing=int(os.environ.get("BS_TIMING", "1")))
+    ctx = bsa.Context(scalar_lanes=L - 4, device=local_rank, enable_timing=0 if args.inner_pmc else int(os.environ.get("BS_TIMING", "1")))
     ctx.load_nodes(nodes, fit)
     ctx.load_groups(groups)
     all_pods = pods
@@ -127,7 +281,7 @@ def main():
         ctx.run(stages)
         if world > 1 or force_dist:
             with torch.cuda.stream(lib_stream):
-                dist.all_reduce(admit_t)       # ONE RCCL all-reduce (sum) of per-group admit counts, ordered after k_tally
+                dist.all_reduce(admit_t)       # ONE RCCL all-reduce (sum) of per-group admit counts, ordered after the tally
             ctx.finish()                       # quorum bits from the reduced counters (same stream, after the collective)
 
     def fence():
@@ -135,6 +289,13 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+
+    if args.inner_pmc:                         # the PMC passes: a few plain steps, nothing else
+        for _ in range(12):
+            step()
+        fence()
+        ctx.close()
+        return None
 
     for _ in range(args.warmup):
         step()
@@ -156,92 +317,119 @@ def main():
     step()
     ctx.sync()
     stats = ctx.stats_read()
-    out = ctx.read(bitmap=False)
+    out = ctx.read(bitmap=False, rows=False)
 
     logical = all_pods.p * nodes.n                    # whole job: every pending pod (all ranks) against every node
     ms_per_step = elapsed / args.steps * 1e3
     value = logical * args.steps / elapsed
 
-    # roofline of the dominant kernel: k_filter_expand — it delivers the Filter result of every (pod, node) pair
-    # (each pod's bitmap row from its request slot's, evaluated by k_scan_filter) and does the tally.
-    # Algorithmic bytes per Filter evaluation: 16*4 + 1 in (alloc[4] + requested[4] int64 +
-    # flag byte; scalars are never read on this path) + 1/8 out (bitmap bit).
-    filt_ms, filt_launches = timing["filter"]
-    bytes_per_eval = 16 * 4 + 1 + 0.125
-    roofline = None
-    if filt_launches:
-        avg_s = filt_ms / filt_launches * 1e-3
-        evals = stats["filter_evals"]
-        achieved = evals * bytes_per_eval / avg_s / 1e9
-        traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (same command, same workload only)
-            if args.config == "cfg3" and args.scenario == "tail" and world == 1 and args.stages == "all":
-                t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                traffic = t["k_filter_expand"]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        rocprof_avg = None
-        try:   # mean duration of the same kernel in the committed rocprofv3 --kernel-trace --stats summary of this command
-            if args.config == "cfg3" and args.scenario == "tail" and world == 1 and args.stages == "all":
-                for line in open(os.path.join(ROOT, "profiles", "r01_final_cfg3_tail.txt")):
-                    if "k_filter_expand(" in line and not line.startswith(" "):
-                        rocprof_avg = float(line.split()[-2])
-                        break
-        except Exception:
-            rocprof_avg = None
-        out_bytes = pods.p * ((nodes.n + 63) // 64) * 8
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": "k_filter_expand", "avg_launch_us": avg_s * 1e6, "launches": filt_launches,
-                    "algorithmic_bytes_per_eval": bytes_per_eval, "evals_per_launch": evals,
-                    "evals_executed_per_launch": stats["filter_evals_executed"],
-                    "compulsory_output_bytes": out_bytes,
-                    "physical_gbps": (traffic / avg_s / 1e9) if traffic else None,
-                    "rocprof_avg_us": rocprof_avg,
-                    "note": "achieved = logical Filter evals (pods x nodes) x 65.125 B / mean k_filter_expand time (hipEvents on the stream it runs "
-                            "on, every 8th batch).  A hipEvent pair around ONE ~10 us kernel also spans the queue's barrier/dispatch gap before it and the "
-                            "completion signal after it (~5 us here), so avg_launch_us sits above rocprof_avg_us, the kernel-only mean of the committed "
-                            "rocprofv3 --stats run of this command (profiles/r01_final_cfg3_tail.txt); achieved/frac use the larger, event-based time.  achieved exceeds the HBM peak because the "
-                            "algorithmic figure assumes every evaluation re-reads its node, while here pods with equal requests share one evaluated row "
-                            "(evals_executed_per_launch, done inside k_scan_filter) and this kernel only streams the rows out. traffic = rocprofv3 "
-                            "FETCH(x2)+WRITE bytes per launch (profiles/r01_traffic.json) = the compulsory bitmap output (compulsory_output_bytes) + slot rows; "
-                            "physical_gbps = traffic / time: launch/latency bound at cfg3 (6 MB), HBM-write bound at cfg4 (130 MB in 31.3 us = 4.1 TB/s incl. the tally tail, "
-                            "profiles/r01_cfg4_tail.txt); see DESIGN.md"}
-
     result = None
     if rank == 0:
-        # admit latency of one cold call: pods H2D + batch + decisions D2H, host-observed
-        lat = []
-        lat_out = soa.BatchOut.alloc(pods.p, groups.g, nodes.n, bitmap=False)     # caller-owned result arrays, reused
-        for _ in range(25 if world == 1 else 0):
-            a = time.perf_counter()
-            ctx.load_pods(pods)
-            step()
-            ctx.read(bitmap=False, out=lat_out)
-            lat.append((time.perf_counter() - a) * 1e3)
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        single = world == 1 and not force_dist
+        # ---------------- roofline: every launch of the step priced on EXECUTED work
+        # algorithmic bytes: PreFilter-path eval 16 L + 2, Filter-path eval 16*4 + 1 in + 1/8 out;
+        # table build: N (16 L + 6) read + M 8 LP written; per-pod bookkeeping: inputs 8 L + 21 B, outputs 18 B
+        LP = 4 if L == 4 else (8 if L <= 8 else 16)
+        pf_eval_b, fl_eval_b = 16 * L + 2, 16 * 4 + 1 + 0.125
+        alg = {
+            "query": pods.p * (8 * L + 21) + nodes.n * (16 * L + 6) + nodes.n * 8 * LP,
+            "scan": stats["scan_evals_executed"] * pf_eval_b + stats["filter_evals_executed"] * fl_eval_b,
+            "resolve": pods.p * (18 + 14) + groups.g * 17,
+        }
+        traffic, traffic_src = (None, "not collected")
+        if single and not args.no_pmc and stats["fast_path"]:
+            traffic, traffic_src = pmc_traffic(args)
+        launches = []
+        for key in ("query", "scan", "resolve"):
+            ms, n = timing.get(key, (0.0, 0))
+            if not n:
+                continue
+            avg_s = ms / n * 1e-3
+            tb = traffic.get(key, {}).get("hbm_bytes_per_launch") if traffic else None
+            e = {"kernel": LAUNCH_KERNELS[key] if stats["fast_path"] else key, "avg_launch_us": avg_s * 1e6, "timed_launches": n,
+                 "algorithmic_bytes_per_launch": alg[key], "achieved": alg[key] / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": alg[key] / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": tb,
+                 "physical_gbps": (tb / avg_s / 1e9) if tb else None, "physical_frac": (tb / avg_s / 1e9 / HBM_PEAK_GBS) if tb else None}
+            if key == "scan":
+                ev = stats["scan_evals_executed"] + stats["filter_evals_executed"]
+                e["evals_executed_per_launch"] = ev
+                e["issue_rate_frac"] = ev / avg_s / VOPC_EVALS_PER_S
+            launches.append(e)
+        roofline = None
+        if launches:
+            dom = max(launches, key=lambda x: x["avg_launch_us"])
+            roofline = dict(dom)
+            roofline.update({"bound": "hbm", "traffic_source": traffic_src,
+                             "note": "the step's longest launch.  achieved = algorithmic bytes of the work this launch EXECUTES (SURVEY 8(d) per-unit bytes x executed "
+                                     "units, DESIGN.md section 7) / mean launch time from hipEvents on the library stream (every 8th batch of the timed region; an event pair "
+                                     "around one ~8 us kernel also spans the dispatch gap, so it reads ~2-3 us above rocprofv3's kernel-only mean in profiles/).  traffic = "
+                                     "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE); physical_frac = traffic / time / 8 TB/s.  The step is three "
+                                     "launch-latency-bound kernels over a working set that lives in L2 / Infinity Cache: no launch is near the HBM roofline, and the logical "
+                                     "pods x nodes space is mostly never evaluated (work_avoided)."})
+        work_avoided = {"logical_evals_per_step": logical,
+                        "prefilter_evals_executed": stats["scan_evals_executed"], "filter_evals_executed": stats["filter_evals_executed"],
+                        "scan_queries": stats["scan_queries_logical"], "scan_queries_distinct": stats["scan_queries"],
+                        "filter_distinct_requests": stats["filter_distinct"],
+                        "executed_fraction_of_logical": (stats["scan_evals_executed"] + stats["filter_evals_executed"]) / max(1, 2 * logical),
+                        "how": "pods with equal derived requests share one evaluated row (request classes), 64-row table groups whose largest running sum "
+                               "cannot reach the smallest request are skipped, the expanded pods x nodes bitmap is not materialised"}
+
+        cycle, extras, cpu = None, None, None
+        if single and not args.no_extras:
+            cyc, nrows, _ = host_cycle(bsa, ctx, groups, pods, nodes, stages)
+            p50 = cyc["total"]["p50_ms"]
+            cycle = {"definition": "host-observed: bs_groups_apply(32 groups) + bs_pods_load (H2D) + bs_batch_run + bs_batch_read (decisions, admit / ready, "
+                                   "Filter slot rows; one stream wait in the whole cycle)", "parts": cyc,
+                     "gang_admit_latency_ms_p50": p50, "gang_admit_latency_ms_p95": cyc["total"]["p95_ms"],
+                     "evals_per_s_at_p50": logical / (p50 * 1e-3), "filter_rows": nrows,
+                     "filter_result_bytes_d2h": nrows * ((nodes.n + 63) // 64) * 8 + pods.p * 4,
+                     "expanded_bitmap_bytes_avoided": pods.p * ((nodes.n + 63) // 64) * 8}
+            extras = {}
+            for sc in ("cold", "warm", "busy"):
+                n2, f2, g2, p2, _ = synth.make(args.config, sc, seed=args.seed)
+                ms, st = resident_ms(bsa, n2, f2, g2, p2, stages, 100)
+                extras[sc] = {"ms_per_step": ms, "evals_per_s": p2.p * n2.n / (ms * 1e-3), "fast_path": st["fast_path"], "launches": st["launches"],
+                              "class_mode": st["class_mode"]}
+            p3 = all_pods.copy()
+            p3.req[0, :] += np.arange(p3.p, dtype=np.int64)            # every pod asks for something else: no request is shared
+            ms, st = resident_ms(bsa, nodes, fit, groups, p3, stages, 60)
+            extras["all_distinct_requests"] = {"ms_per_step": ms, "evals_per_s": logical / (ms * 1e-3), "fast_path": st["fast_path"],
+                                               "filter_distinct_requests": st["filter_distinct"], "scan_queries_distinct": st["scan_queries"]}
+            ms, st = resident_ms(bsa, nodes, fit, groups, all_pods, soa.STAGE_PREFILTER | soa.STAGE_TALLY, 100)
+            extras["prefilter_only"] = {"ms_per_step": ms, "evals_per_s": logical / (ms * 1e-3)}
+            extras["filter_increment_ms"] = ms_per_step - ms if args.stages == "all" else None
+            seeds = {}
+            for sd in (1, 2, 3):
+                n2, f2, g2, p2, _ = synth.make(args.config, args.scenario, seed=sd)
+                ms, _st = resident_ms(bsa, n2, f2, g2, p2, stages, 60)
+                seeds[str(sd)] = ms
+            extras["ms_per_step_by_seed"] = seeds
+        if single and not args.no_cpu_baseline:
             cpu = cpu_baseline(bsa, nodes, fit, groups, pods, stages, args.cpu_reps)
         codes = np.bincount(out.pf_code, minlength=256)
         result = {
             "metric": "pod x node fit evals/sec", "value": value, "unit": "evals/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"{args.config}/{args.scenario}: {pods.p} pods / {groups.g} groups / {nodes.n} nodes, "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"{args.config}/{args.scenario}: {all_pods.p} pods / {groups.g} groups / {nodes.n} nodes, "
                                    f"{L} int64 lanes (cpu, mem, eph, pods{', gpu' if L > 4 else ''}), seed {args.seed}",
                        "stages": "prefilter+filter+tally+ready" if args.stages == "all" else "prefilter+tally+ready",
                        "parallelism": (f"pod-axis shard x{world}, " + ("pods partitioned by owning rank" if partitioned else "replicated batch, device-side ownership")
                                        + ", 1 all-reduce of admit[G]") if dist is not None else "single GPU",
-                       "logical_evals_per_step": logical,
-                       "scan_evals_executed_per_step": stats["scan_evals_executed"],
-                       "filter_evals_per_step": stats["filter_evals"],
-                       "filter_distinct_requests": stats["filter_distinct"],
-                       "filter_evals_executed_per_step": stats["filter_evals_executed"],
-                       "scan_queries": stats["scan_queries_logical"], "scan_queries_distinct": stats["scan_queries"], "tables_built": stats["tables_built"],
+                       "value_definition": "logical pods x nodes per step / step time; a step re-runs the whole path (table build, PreFilter, Filter, tally, quorum) over a "
+                                           "batch resident in HBM; request classes and per-group pod minima are derived at bs_pods_load, findMaxPG at bs_groups_load / "
+                                           "bs_groups_apply (both inside host_cycle, not inside value)",
+                       "logical_evals_per_step": logical, "fast_path": stats["fast_path"], "launches_per_step": stats["launches"],
+                       "tables_built": stats["tables_built"],
                        "decisions": {soa.PF_NAMES.get(i, str(i)): int(c) for i, c in enumerate(codes) if c},
                        "groups_ready": int(out.group_ready.sum())},
-            "gang_admit_latency_ms_p50": float(np.percentile(lat, 50)) if lat else None,
-            "gang_admit_latency_note": "host-observed: pods H2D + one batch + decision D2H; every group of the batch is decided by that call",
             "roofline": roofline,
+            "roofline_launches": launches,
+            "work_avoided": work_avoided,
+            "host_cycle": cycle,
+            "gang_admit_latency_ms_p50": cycle["gang_admit_latency_ms_p50"] if cycle else None,
+            "gang_admit_latency_ms_p95": cycle["gang_admit_latency_ms_p95"] if cycle else None,
+            "scenarios": extras,
             "kernel_ms_per_step": {k: v[0] / v[1] for k, v in timing.items() if v[1]},
             "cpu_baseline": cpu,
         }

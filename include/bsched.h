@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BS_ABI_VERSION 1u
+#define BS_ABI_VERSION 2u
 
 enum {
   BS_LANE_CPU = 0,       /* Resource.MilliCPU          */
@@ -241,10 +241,24 @@ typedef struct bs_batch_out {
                               core.go:120-122), -1 none                                       */
   uint8_t*  fl_code;       /* [p] BS_FL_*                                                     */
   uint32_t* fl_feasible;   /* [p] nodes on which Filter returns nil                           */
-  uint64_t* fl_bitmap;     /* [ceil(n/64)][p] word-major: bit (node&63) of word node>>6       */
+  uint64_t* fl_bitmap;     /* [ceil(n/64)][p] word-major: bit (node&63) of word node>>6.  OPT-IN: the
+                              pods x nodes bitmap is only materialised (one extra streaming kernel +
+                              a p*ceil(n/64)*8-byte copy) when this pointer is set; fl_rows below
+                              carries the same information ~p/rows times smaller                */
   uint32_t* group_admit;   /* [g] pods of the group that pass PreFilter and (if Filter ran)
                               have >=1 feasible node; summed over ranks when sharded          */
   uint8_t*  group_ready;   /* [g] quorum predicate core.go:303 with matched+admit             */
+  /* Filter results by distinct request ("slot rows").  Filter(pod, node) (core.go:170-191) ==
+   *   fl_code[pod] == BS_FL_EVALUATED ? bit (node&63) of fl_rows[(node>>6) * fl_rows_cap + fl_slot[pod]]
+   *                                   : fl_code[pod] < 16        (every node / no node)
+   * so the Go plugin's Filter is a bit test with no cgo crossing.  Pods with equal derived requests share
+   * a row; when a first-pod capture or MinResources default can still happen in the batch a row is the
+   * pod itself (fl_slot[pod] == pod). */
+  uint32_t* fl_slot;          /* [p] row of pod p; meaningful iff fl_code[p] == BS_FL_EVALUATED        */
+  uint64_t* fl_rows;          /* [ceil(n/64)][fl_rows_cap] word-major; rows >= *fl_rows_n untouched     */
+  uint32_t* fl_rows_feasible; /* [fl_rows_cap] feasible-node count per row (NULL ok)                    */
+  uint32_t  fl_rows_cap;      /* in: capacity in rows (bs_filter_rows_count tells how many are needed)  */
+  uint32_t* fl_rows_n;        /* out: rows of this batch (NULL ok); BS_ERR_CAPACITY if > fl_rows_cap    */
 } bs_batch_out;
 
 /* bs_batch_run stage bits */
@@ -274,9 +288,24 @@ int bs_fit_build(bs_ctx* ctx, const bs_node_labels* nodes, const bs_fit_template
 int bs_fit_read(bs_ctx* ctx, uint32_t* fit_bits_out);
 int bs_groups_load(bs_ctx* ctx, const bs_groups_soa* groups);
 int bs_groups_read(bs_ctx* ctx, bs_groups_soa* groups_out); /* caller-sized arrays, g must match */
-int bs_pods_load(bs_ctx* ctx, const bs_pods_soa* pods);   /* also derives the pods' request classes on the device:
-                                                              equal (req lanes, req_present) <=> equal class; a batch then
-                                                              evaluates every distinct derived request once           */
+/* Per-cycle group changes without a full reload: Permit adds to MatchedPodNodes (core.go:290), PostBind moves
+ * pods to Status.Scheduled (core.go:327), the quorum latch (core.go:305) and the deny TTL (core.go:105,424)
+ * flip flag bits.  Each delta REPLACES matched / status_scheduled / flags of group `index`;
+ * BS_GROUP_HAS_POD and BS_GROUP_HAS_MINRES must keep their loaded value (a first-pod capture changes cls and
+ * MinResources too: use bs_groups_load).  Validated as a whole before anything is applied.
+ * Like bs_groups_load it re-runs findMaxPG on the device and returns without waiting for the GPU. */
+typedef struct bs_group_delta {
+  uint32_t index, matched, status_scheduled, flags;
+} bs_group_delta;
+int bs_groups_apply(bs_ctx* ctx, const bs_group_delta* deltas, uint32_t count);
+int bs_pods_load(bs_ctx* ctx, const bs_pods_soa* pods);   /* also derives, on the device, what a batch needs from the pods
+                                                              alone: request classes (equal (req lanes, req_present) <=> equal
+                                                              class; a batch evaluates every distinct derived request once),
+                                                              per-group first pod / first owner, (group, class) pairs.
+                                                              Returns without waiting for the GPU.  No call order is implied
+                                                              between the loads; fit-class indices (pods.cls, groups.cls) are
+                                                              checked against the loaded fit classes by bs_batch_run
+                                                              (BS_ERR_INVALID).                                          */
 
 /* node churn (BASELINE config 5): stable delete / append / requested-update */
 #define BS_DELTA_UPDATE 0u   /* replace node `index` (all lanes, presence, flags, fit column) */
@@ -328,6 +357,8 @@ int bs_find_max_pg(bs_ctx* ctx, int32_t* leader, uint32_t* finished, uint8_t* pa
 int bs_batch_run(bs_ctx* ctx, uint32_t stages);
 int bs_batch_sync(bs_ctx* ctx);
 int bs_batch_read(bs_ctx* ctx, const bs_batch_out* out);
+/* Rows (distinct Filter requests) the last loaded pods can produce: sizes fl_rows / fl_rows_feasible. */
+int bs_filter_rows_count(bs_ctx* ctx, uint32_t* rows);
 
 /* ---- pod-axis sharding (one process per GPU) -------------------------------------- */
 /* Rank `rank` of `nranks` evaluates only the pods it owns: every pod of a group belongs to the rank
@@ -361,10 +392,10 @@ int bs_batch_finish(bs_ctx* ctx);
 /* ---- measurement ------------------------------------------------------------------ */
 #define BS_KERNEL_PREPASS   0u
 #define BS_KERNEL_LEADER    1u
-#define BS_KERNEL_QUERY     2u
+#define BS_KERNEL_QUERY     2u   /* steady state: launch A (per-pod decisions + chunk-local table build) */
 #define BS_KERNEL_TABLES    3u
-#define BS_KERNEL_SCAN      4u   /* the dominant kernel: pods x nodes prefix compare */
-#define BS_KERNEL_RESOLVE   5u
+#define BS_KERNEL_SCAN      4u   /* node scan (+ Filter evaluation in steady state: launch B) */
+#define BS_KERNEL_RESOLVE   5u   /* final codes (+ tally and quorum in steady state: launch C) */
 #define BS_KERNEL_FILTER    6u
 #define BS_KERNEL_TALLY     7u
 #define BS_KERNEL_COUNT     8u
@@ -384,6 +415,8 @@ typedef struct bs_batch_stats {
   uint64_t filter_evals_executed;   /* filter_distinct x nodes                                */
   uint64_t scan_queries_logical;    /* pods that needed a node scan (scan_queries = distinct ones scanned) */
   uint64_t class_mode;              /* 1: the batch worked on request classes, 0: one slot per pod        */
+  uint64_t fast_path;               /* 1: the three-launch steady-state chain ran                          */
+  uint64_t launches;                /* kernel launches of the batch                                        */
 } bs_batch_stats;
 int bs_batch_stats_get(bs_ctx* ctx, bs_batch_stats* out);
 

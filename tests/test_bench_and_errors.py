@@ -26,8 +26,17 @@ def test_bench_json_contract():
     assert abs(d["value"] - d["config"]["logical_evals_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "traffic" in r and "kernel" in r and r["avg_launch_us"] > 0
+    for e in d["roofline_launches"]:                      # priced on executed work: nothing can exceed the roofline
+        assert 0 < e["frac"] <= 1.0, e
+        assert e["physical_frac"] is None or e["physical_frac"] <= 1.0
+    assert d["config"]["fast_path"] == 1 and d["config"]["launches_per_step"] == 3
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and c["faithful_cost"] is False
+    assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0
+    hc = d["host_cycle"]
+    assert hc["gang_admit_latency_ms_p50"] <= hc["gang_admit_latency_ms_p95"] and hc["evals_per_s_at_p50"] > 10e6
+    assert set(d["scenarios"]) >= {"cold", "warm", "busy", "all_distinct_requests", "prefilter_only", "ms_per_step_by_seed"}
     assert d["value"] > 10e6, "north_star target: >= 10M pod x node fit evaluations/s"
 
 

@@ -110,15 +110,15 @@ def test_node_flags_force_no_fit():
 
 def test_go_parse_int_and_validation_agree():
     for s in ["0", "-0", "+5", "007", "12a", "", "+", "-", " 1", "1_000", "9223372036854775807", "9223372036854775808",
-              "-9223372036854775808", "-9223372036854775809", "0x10", "1e3"]:
+              "-9223372036854775808", "-9223372036854775809", "0x10", "1e3", "5\n", "\n5", "5\n\n"]:
         v, ok = fitspec.parse_int(s)
         assert (naive_fit.go_parse_int(s) is not None) == ok
         if ok:
             assert naive_fit.go_parse_int(s) == v
     for k in ["a", "a/b", "a/b/c", "", "/x", "x/", "Example.com/x", "example.com/x", "ex_ample.com/x", "a" * 63, "a" * 64,
-              "-a", "a-", "a.b_c-d", "bad key!", "x" * 253 + "/y", ("x" * 63 + ".") * 3 + "x" * 61 + "/y", ("x" * 63 + ".") * 4 + "/y"]:
+              "-a", "a-", "a.b_c-d", "bad key!", "a\n", "example.com\n/x", "example.com/x\n", "x" * 253 + "/y", ("x" * 63 + ".") * 3 + "x" * 61 + "/y", ("x" * 63 + ".") * 4 + "/y"]:
         assert fitspec.label_key_ok(k) == naive_fit.qualified_name_ok(k), k
-    for v in ["", "a", "a b", "a" * 63, "a" * 64, "_a", "a_", "A.b-C_d", "é"]:
+    for v in ["", "a", "a b", "a" * 63, "a" * 64, "_a", "a_", "A.b-C_d", "é", "a\n", "\n"]:
         assert fitspec.label_value_ok(v) == naive_fit.label_value_ok(v), v
 
 
@@ -249,11 +249,11 @@ def test_oracle_fit_throughput_is_reported(capsys):
 # string-level restatement gives.  Strategies are biased towards the characters the upstream validators care about.
 from hypothesis import given, settings, strategies as st_
 
-_key_chars = "abzAZ09-_./ !"
-_keys = st_.one_of(st_.sampled_from(["zone", "rack", "disk", "a/b", "example.com/x", "bad key!", "", "x" * 64, "a/b/c", "-a", "k8s.io/role"]),
+_key_chars = "abzAZ09-_./ !\n"
+_keys = st_.one_of(st_.sampled_from(["zone", "rack", "disk", "a/b", "example.com/x", "bad key!", "", "x" * 64, "a/b/c", "-a", "k8s.io/role", "zone\n", "example.com\n/x"]),
                    st_.text(alphabet=_key_chars, min_size=0, max_size=6))
-_vals = st_.one_of(st_.sampled_from(["", "a", "b", "1", "12", "007", "+5", "-3", "12a", "9223372036854775807", "9223372036854775808", "no good", "x" * 64]),
-                   st_.text(alphabet="ab019+-_. ", min_size=0, max_size=5))
+_vals = st_.one_of(st_.sampled_from(["", "a", "b", "1", "12", "007", "+5", "-3", "12a", "9223372036854775807", "9223372036854775808", "no good", "x" * 64, "5\n", "a\n"]),
+                   st_.text(alphabet="ab019+-_. \n", min_size=0, max_size=5))
 _ops = st_.sampled_from(["In", "NotIn", "Exists", "DoesNotExist", "Gt", "Lt", "Foo", ""])
 _effects = st_.sampled_from(["NoSchedule", "NoExecute", "PreferNoSchedule", "", "Other"])
 _tol_ops = st_.sampled_from(["", "Equal", "Exists", "Weird"])

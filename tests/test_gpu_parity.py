@@ -24,6 +24,13 @@ def assert_batch_equal(got, exp, what="", bitmap=True):
             raise AssertionError(f"{what}: {name} differs at {bad[:8].tolist()} ({len(bad)} total): got {a[bad[:8]].tolist()} exp {b[bad[:8]].tolist()}")
     if bitmap and exp.fl_bitmap is not None:
         assert np.array_equal(got.fl_bitmap, exp.fl_bitmap), f"{what}: fl_bitmap differs"
+        if got.fl_rows is not None:
+            # what the Go plugin's Filter does: a bit test on the row of the pod's slot — no expanded bitmap involved
+            assert np.array_equal(got.bitmap_from_rows(), exp.fl_bitmap), f"{what}: slot rows disagree with the reference bitmap"
+            ev = got.fl_code == 3
+            assert int(got.fl_rows_n[0]) <= got.fl_rows.shape[1]
+            assert np.all(got.fl_slot[ev] < got.fl_rows_n[0])
+            assert np.array_equal(got.fl_rows_feasible[got.fl_slot[ev]], exp.fl_feasible[ev]), f"{what}: per-row feasible counts"
 
 
 def load_ctx(bsa, nodes, fit, groups, pods, **kw):

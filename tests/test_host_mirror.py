@@ -107,6 +107,10 @@ def test_readme_race_scene_end_to_end(bsa, soa, orc):
             info.requested.MilliCPU += 1000
             info.pod_count += 1
             if ready:
+                # a buffer smaller than the gang releases nothing (no pod may leave the cache unreturned)
+                with pytest.raises(ValueError):
+                    sop.StartBatchSchedule(gidx[grp], cap=1)
+                assert sop.group_state(gidx[grp])["matched"] == 5
                 released = sop.StartBatchSchedule(gidx[grp])
                 assert released == ref.start_batch(grp)
                 for _ in released:
