@@ -42,10 +42,26 @@ namespace bs {
 //   gstat[2][g] first such pod with OwnerReferences              gstat[3][g] head of the group's pair chain
 // A pair = (group, request class); its id is the index of its representative pod.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* pclass, unsigned long long* slots, uint32_t mask, uint32_t hash_keep,
-                            uint32_t* gstat, uint32_t* ppair, uint32_t* pair_next) {
+__global__ void k_pods_prep(unsigned long long* tables, uint32_t ntab, uint32_t* gstat, uint32_t ngstat, uint32_t* kcount) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (uint32_t i = t; i < ntab; i += nt) tables[i] = 0ull;
+  for (uint32_t i = t; i < ngstat; i += nt) gstat[i] = BS_INF;
+  if (t == 0 && kcount) *kcount = 0;
+}
+
+// Second half of the class builder (every pod takes its representative's dense id) fused with the per-group
+// minima and the pair table.  `hinfo` = pinned host memory: K is handed to the host without a copy or an event
+// (value, then the tag with system-scope release; the host only looks when it needs the row count).
+__global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* rep, const uint32_t* id, uint32_t* pclass, unsigned long long* slots, uint32_t mask,
+                            uint32_t hash_keep, uint32_t* gstat, uint32_t* ppair, uint32_t* pair_next, const uint32_t* kcount, int32_t tag, int32_t* hinfo) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && hinfo) {
+    hinfo[4] = (int32_t)*kcount;
+    __hip_atomic_store(&hinfo[5], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (i >= pods.p) return;
+  const uint32_t c = id[rep[i]];
+  if (pclass) pclass[i] = c;
   const int32_t gi = pods.group[i];
   if (gi < 0 || (uint32_t)gi >= G) { ppair[i] = BS_INF; return; }
   atomicMin(&gstat[gi], i);
@@ -53,11 +69,10 @@ __global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* pclass, un
     atomicMin(&gstat[(size_t)G + gi], i);
     if (pods.owner[i] != 0) atomicMin(&gstat[(size_t)2 * G + gi], i);
   }
-  const uint32_t c = pclass[i];
   const uint64_t h = mix64(((uint64_t)(uint32_t)gi << 32) | c);
   bool winner;
-  const uint32_t rep = dedupe_insert(slots, mask, hash_keep, h, i, [&](uint32_t o) { return o < pods.p && pods.group[o] == gi && pclass[o] == c; }, winner);
-  ppair[i] = rep;
+  const uint32_t r = dedupe_insert(slots, mask, hash_keep, h, i, [&](uint32_t o) { return o < pods.p && pods.group[o] == gi && id[rep[o]] == c; }, winner);
+  ppair[i] = r;
   if (winner) pair_next[i] = atomicExch(&gstat[(size_t)3 * G + gi], i);
 }
 
@@ -77,7 +92,20 @@ __global__ void k_groups_apply(const GroupDelta* d, uint32_t n, uint32_t* matche
   flags[x.index] = (uint8_t)x.flags;
 }
 
-__global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, BatchDev b, uint32_t C, int32_t tag, int32_t* info) {
+constexpr int kInlineDeltas = 48;                  // group deltas that ride in the kernel arguments (no H2D, no staging)
+struct DeltaPack { uint32_t n; GroupDelta d[kInlineDeltas]; };
+
+// [apply up to kInlineDeltas group deltas] -> findMaxPG -> the steady table's descriptor -> info to the host.
+// `info` is pinned host memory the kernel writes directly; the tag goes last with system-scope release.
+__global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, BatchDev b, uint32_t C, int32_t tag, int32_t* info, DeltaPack dp,
+                                                              uint32_t* matched, uint32_t* status_scheduled, uint8_t* flags) {
+  if (threadIdx.x < dp.n) {
+    const GroupDelta x = dp.d[threadIdx.x];
+    matched[x.index] = x.matched;
+    status_scheduled[x.index] = x.status_scheduled;
+    flags[x.index] = (uint8_t)x.flags;
+  }
+  __syncthreads();
   if (gr.g) leader_block(gr, b, 0);
   if (threadIdx.x == 0) {
     int32_t l = -1, pn = 0, steady = -1;
@@ -90,7 +118,8 @@ __global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, Batc
       d.pct = 0.7f;                                   // core.go:161
       b.desc[steady] = d;
     }
-    info[0] = l; info[1] = pn; info[2] = steady; info[3] = tag;
+    info[0] = l; info[1] = pn; info[2] = steady;
+    __hip_atomic_store(&info[3], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

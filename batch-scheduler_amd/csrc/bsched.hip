@@ -89,7 +89,6 @@ struct bs_ctx {
   hipEvent_t ev_gstage = nullptr;
   bool gstage_busy = false;
   int32_t* h_info = nullptr;         // pinned [8]: leader, panic, steady table, tag | K of the loaded pods, tag
-  hipEvent_t ev_info = nullptr, ev_kinfo = nullptr;
   int32_t info_tag = 0, kinfo_tag = 0;
   bool info_pending = false, kinfo_pending = false;
   uint32_t max_group_cls = 0, max_pod_cls = 0;   // largest fit class any HAS_POD group / grouped pod names (checked against C per batch)
@@ -105,7 +104,7 @@ struct bs_ctx {
   bool last_use_classes = false;
   size_t h_stage_cap = 0;
   size_t off_pgroup = 0, off_preq = 0, off_ppres = 0, off_pcls = 0, off_powner = 0, off_pflags = 0, podpack_bytes = 0;
-  size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, off_fl_slot = 0, outpack_bytes = 0;
+  size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, off_fl_slot = 0, off_admit = 0, off_ready = 0, outpack_bytes = 0;
 
   // ---- batch scratch / outputs
   DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
@@ -312,7 +311,8 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.uparams = c->d_uparams.as<int64_t>();
   b.uflags = c->d_uflags.as<uint32_t>();
   b.fu_bitmap = c->d_fu_bitmap.as<uint64_t>();
-  b.fu_feas = c->d_fu_feas.as<uint32_t>();
+  // per-slot feasible counts sit right behind the last row of the slot bitmap: one 2-D copy returns rows + counts
+  b.fu_feas = reinterpret_cast<uint32_t*>(c->d_fu_bitmap.as<uint64_t>() + (size_t)cdiv(c->N, 64) * c->filter_slots_cap);
   b.qstamp_s = c->d_qstamp_s.as<uint32_t>();
   b.first_pod_s = c->d_gstat.as<uint32_t>();
   b.first_np_s = c->d_gstat.as<uint32_t>() + (size_t)c->G;
@@ -333,8 +333,8 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.fl_feasible = reinterpret_cast<uint32_t*>(ok + c->off_fl_feasible);
   b.fu_slot = reinterpret_cast<uint32_t*>(ok + c->off_fl_slot);     // per-pod Filter slot travels with the other per-pod results
   b.fl_bitmap = c->d_fl_bitmap.as<uint64_t>();
-  b.admit = c->ext_admit ? c->ext_admit : c->d_admit.as<uint32_t>();
-  b.ready = c->d_ready.as<uint8_t>();
+  b.admit = c->ext_admit ? c->ext_admit : reinterpret_cast<uint32_t*>(ok + c->off_admit);
+  b.ready = ok + c->off_ready;
   return b;
 }
 BatchParams batch_params(const bs_ctx* c) {
@@ -563,7 +563,7 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
 // for it at percent 0.7 against the leader's fit class (core.go:157-161) — and writes that table's descriptor.
 // Leader, panic flag and table id come back through pinned memory; nothing waits here (resolve_groups does, at
 // the next bs_batch_run, and then only if the copy has not landed yet).
-int analyse_groups(bs_ctx* c, bool rearm_scratch = true) {
+int analyse_groups(bs_ctx* c, bool rearm_scratch = true, const bs_group_delta* deltas = nullptr, uint32_t ndeltas = 0) {
   c->steady_table = -1;
   c->side_ready = false;
   c->info_pending = false;
@@ -574,28 +574,43 @@ int analyse_groups(bs_ctx* c, bool rearm_scratch = true) {
     hipLaunchKernelGGL(k_init, dim3(cdiv(std::max<uint32_t>(c->G, 8), 256)), dim3(256), 0, c->stream, gr, b);
     c->scratch_armed = true;
   }
+  DeltaPack dp;
+  dp.n = ndeltas;
+  static_assert(sizeof(bs_group_delta) == sizeof(GroupDelta), "delta layout");
+  if (ndeltas) std::memcpy(dp.d, deltas, (size_t)ndeltas * sizeof(GroupDelta));
   c->info_tag++;
-  hipLaunchKernelGGL(k_leader_info, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b, (c->have_fit && c->have_nodes) ? c->C : 0u, c->info_tag,
-                     c->d_info.as<int32_t>());
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_info, c->d_info.p, 16, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev_info, c->stream));
+  hipLaunchKernelGGL(k_leader_info, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b, (c->have_fit && c->have_nodes) ? c->C : 0u, c->info_tag, c->h_info,
+                     dp, const_cast<uint32_t*>(gr.matched), const_cast<uint32_t*>(gr.status_scheduled), const_cast<uint8_t*>(gr.flags));
+  LAUNCHCHK(c, BS_KERNEL_LEADER);
   c->info_pending = true;
+  return BS_OK;
+}
+
+// Wait until the kernel that wrote h_info[tag_at] = tag has done so (it writes pinned host memory directly).  By
+// the time anybody asks, the kernel has normally finished long ago and this is one load.
+int wait_host_tag(bs_ctx* c, int tag_at, int32_t tag) {
+  volatile int32_t* info = c->h_info;
+  for (uint32_t spin = 0; info[tag_at] != tag; ++spin) {
+    if (spin == 2000) (void)hipStreamQuery(c->stream);                    // make sure the launch has left the host
+    if (spin > 20000000u) { HIPCHK(c, hipStreamSynchronize(c->stream)); if (info[tag_at] != tag) { c->last_error = "host info tag never arrived"; return BS_ERR_HIP; } }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return BS_OK;
 }
 
 int resolve_groups(bs_ctx* c) {
   if (!c->info_pending) return BS_OK;
-  HIPCHK(c, hipEventSynchronize(c->ev_info));
+  int rc = wait_host_tag(c, 3, c->info_tag);
+  if (rc) return rc;
   c->info_pending = false;
-  if (c->h_info[3] != c->info_tag) { c->last_error = "group analysis tag mismatch"; return BS_ERR_HIP; }
   c->steady_table = (c->n_uncaptured == 0 && c->h_info[2] >= 0) ? c->h_info[2] : -1;
   return BS_OK;
 }
 
 int resolve_pods(bs_ctx* c) {
   if (!c->kinfo_pending) return BS_OK;
-  HIPCHK(c, hipEventSynchronize(c->ev_kinfo));
+  int rc = wait_host_tag(c, 5, c->kinfo_tag);
+  if (rc) return rc;
   c->kinfo_pending = false;
   c->h_K = (uint32_t)c->h_info[4];
   return BS_OK;
@@ -609,6 +624,8 @@ int reserve_filled(bs_ctx* c, DevBuf& d, size_t bytes, int byte_value) {
   return BS_OK;
 }
 
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 int ensure_gstage(bs_ctx* c, size_t bytes) {
   if (c->gstage_busy) { HIPCHK(c, hipEventSynchronize(c->ev_gstage)); c->gstage_busy = false; }
   if (bytes <= c->h_gstage_cap) return BS_OK;
@@ -618,20 +635,40 @@ int ensure_gstage(bs_ctx* c, size_t bytes) {
   return BS_OK;
 }
 
-// What the fast path needs from the pods alone (k_pod_pairs): needs the pods' request classes and G.
-int build_pairs(bs_ctx* c) {
+// Second half of the pod load (k_pod_pairs): dense class ids, per-group minima, (group, class) pairs; hands K to the
+// host.  Needs G, so it runs at bs_pods_load when the groups are already there and at the next batch otherwise.
+// fresh: the pair table and gstat were just reset by k_pods_prep.
+int build_pairs(bs_ctx* c, bool fresh) {
   const uint32_t G = c->G, P = c->P;
   HIPCHK(c, c->d_gstat.reserve((size_t)4 * std::max<uint32_t>(G, 1) * 4));
   HIPCHK(c, c->d_fast_reject.reserve((size_t)std::max<uint32_t>(G, 1) * 4));
-  if (G) HIPCHK(c, hipMemsetAsync(c->d_gstat.p, 0xFF, (size_t)4 * G * 4, c->stream));
-  if (P && G) {
-    unsigned long long* table = c->d_cls_slots.as<unsigned long long>() + c->cls_cap;       // second half: the pair table
-    HIPCHK(c, hipMemsetAsync(table, 0, (size_t)c->cls_cap * 8, c->stream));
-    hipLaunchKernelGGL(k_pod_pairs, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pods_dev(c), G, c->d_pclass.as<uint32_t>(), table, c->cls_cap - 1,
-                       c->hash_keep, c->d_gstat.as<uint32_t>(), c->d_ppair.as<uint32_t>(), c->d_pair_next.as<uint32_t>());
-    HIPCHK(c, hipGetLastError());
-  }
-  c->pairs_ready = true;
+  unsigned long long* table = c->d_cls_slots.as<unsigned long long>() + c->cls_cap;         // second half: the pair table
+  if (!fresh && P)
+    hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, table, c->cls_cap, c->d_gstat.as<uint32_t>(), 4 * G, (uint32_t*)nullptr);
+  c->kinfo_tag++;
+  hipLaunchKernelGGL(k_pod_pairs, dim3(std::max<uint32_t>(1, cdiv(P, 256))), dim3(256), 0, c->stream, pods_dev(c), G, c->d_cls_rep.as<uint32_t>(),
+                     c->d_cls_id.as<uint32_t>(), c->d_pclass.as<uint32_t>(), table, c->cls_cap - 1, c->hash_keep, c->d_gstat.as<uint32_t>(),
+                     c->d_ppair.as<uint32_t>(), c->d_pair_next.as<uint32_t>(), c->d_nepochs.as<uint32_t>() + 2, c->kinfo_tag, c->h_info);
+  LAUNCHCHK(c, BS_KERNEL_PREPASS);
+  c->kinfo_pending = true;
+  c->pairs_ready = c->have_groups;
+  return BS_OK;
+}
+
+// Device layout of everything bs_batch_read returns in its first copy: per-pod arrays | admit[G] | ready[G].
+int layout_out(bs_ctx* c) {
+  const size_t n = std::max<uint32_t>(c->P, 1), g = std::max<uint32_t>(c->G, 1);
+  size_t o = 0;
+  c->off_pf_code = o; o = align256(o + n);
+  c->off_pf_first_k = o; o = align256(o + n * 4);
+  c->off_pf_leader = o; o = align256(o + n * 4);
+  c->off_fl_code = o; o = align256(o + n);
+  c->off_fl_feasible = o; o = align256(o + n * 4);
+  c->off_fl_slot = o; o = align256(o + n * 4);
+  c->off_admit = o; o = align256(o + g * 4);
+  c->off_ready = o; o = align256(o + g);
+  c->outpack_bytes = o;
+  HIPCHK(c, c->d_outpack.reserve(o));
   return BS_OK;
 }
 
@@ -692,9 +729,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     return BS_ERR_NOMEM;
   }
   if (c->d_info.reserve(64) != hipSuccess || c->d_first_reach.reserve(64) != hipSuccess || hipMemset(c->d_first_reach.p, 0xFF, 64) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_info, 64, hipHostMallocDefault) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_info, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_kinfo, hipEventDisableTiming) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_info, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||   // kernels write it directly
       hipEventCreateWithFlags(&c->ev_gstage, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return BS_ERR_NOMEM;
@@ -720,8 +755,6 @@ int bs_destroy(bs_ctx* c) {
   if (c->comm && c->rccl_destroy) (void)c->rccl_destroy((ncclComm_t)c->comm);
   if (c->ev_stage) (void)hipEventDestroy(c->ev_stage);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
-  if (c->ev_info) (void)hipEventDestroy(c->ev_info);
-  if (c->ev_kinfo) (void)hipEventDestroy(c->ev_kinfo);
   if (c->ev_gstage) (void)hipEventDestroy(c->ev_gstage);
   if (c->h_info) (void)hipHostFree(c->h_info);
   if (c->h_gstage) (void)hipHostFree(c->h_gstage);
@@ -893,8 +926,6 @@ int bs_fit_read(bs_ctx* c, uint32_t* out) {
   return BS_OK;
 }
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
 int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   if (!c || !g) return BS_ERR_INVALID;
   int rc = use_device(c);
@@ -921,12 +952,11 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   HIPCHK(c, c->d_first_reject.reserve(n * 4));
   HIPCHK(c, c->d_first_pod.reserve(n * 4));
   HIPCHK(c, c->d_cap_epoch.reserve(n * 4));
-  HIPCHK(c, c->d_admit.reserve(n * 4));
-  HIPCHK(c, c->d_ready.reserve(n));
   HIPCHK(c, c->d_leader_epoch.reserve((n + 1) * 4));
   HIPCHK(c, c->d_panic_epoch.reserve(n + 1));
   if (G != c->G) c->pairs_ready = false;          // the per-group arrays of the pod load are sized by G
   c->G = G;
+  if ((rc = layout_out(c))) return rc;
   c->n_uncaptured = 0;
   c->n_nominres = 0;
   c->max_group_cls = 0;
@@ -973,7 +1003,10 @@ int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
       return BS_ERR_INVALID;
     }
   }
-  static_assert(sizeof(bs_group_delta) == sizeof(GroupDelta), "delta layout");
+  for (uint32_t d = 0; d < count; ++d) c->h_gflags[deltas[d].index] = (uint8_t)deltas[d].flags;
+  // HAS_POD is unchanged, so the capture epochs the general chain's scratch holds stay valid: no re-arm.
+  // Few deltas (the per-cycle case) ride in the arguments of the findMaxPG launch: ONE launch, no copy, no wait.
+  if (count <= (uint32_t)kInlineDeltas) return analyse_groups(c, false, deltas, count);
   const size_t bytes = (size_t)count * sizeof(bs_group_delta);
   rc = ensure_gstage(c, std::max(bytes, c->gpack_bytes));
   if (rc) return rc;
@@ -985,9 +1018,7 @@ int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
   GroupsDev gr = groups_dev(c);
   hipLaunchKernelGGL(k_groups_apply, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, c->d_gdelta.as<GroupDelta>(), count,
                      const_cast<uint32_t*>(gr.matched), const_cast<uint32_t*>(gr.status_scheduled), const_cast<uint8_t*>(gr.flags));
-  HIPCHK(c, hipGetLastError());
-  for (uint32_t d = 0; d < count; ++d) c->h_gflags[deltas[d].index] = (uint8_t)deltas[d].flags;
-  // HAS_POD is unchanged, so the capture epochs the general chain's scratch holds stay valid: no re-arm
+  LAUNCHCHK(c, BS_KERNEL_LEADER);
   return analyse_groups(c, false);
 }
 
@@ -1039,16 +1070,9 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   c->off_pflags = o; o = align256(o + n);
   c->podpack_bytes = o;
   HIPCHK(c, c->d_podpack.reserve(o));
-  // per-pod outputs: one allocation, one transfer back
-  o = 0;
-  c->off_pf_code = o; o = align256(o + n);
-  c->off_pf_first_k = o; o = align256(o + n * 4);
-  c->off_pf_leader = o; o = align256(o + n * 4);
-  c->off_fl_code = o; o = align256(o + n);
-  c->off_fl_feasible = o; o = align256(o + n * 4);
-  c->off_fl_slot = o; o = align256(o + n * 4);
-  c->outpack_bytes = o;
-  HIPCHK(c, c->d_outpack.reserve(o));
+  // per-pod outputs (+ the per-group ones): one allocation, one transfer back
+  c->P = P;
+  if ((rc = layout_out(c))) return rc;
   rc = ensure_stage(c, std::max(c->podpack_bytes, c->outpack_bytes));
   if (rc) return rc;
   HIPCHK(c, c->d_epoch.reserve(n * 4));
@@ -1072,7 +1096,6 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
     c->cls_cap = cap;
   }
   HIPCHK(c, c->d_blk_scratch.reserve((n / 256 + 2) * 4));
-  c->P = P;
   c->pairs_ready = false;
   c->batch_since_pods = false;
   c->max_pod_cls = 0;
@@ -1088,25 +1111,21 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
     std::memcpy(st + c->off_pflags, pods->flags, (size_t)P);
     HIPCHK(c, hipMemcpyAsync(c->d_podpack.p, st, c->podpack_bytes, hipMemcpyHostToDevice, c->stream));
   }
-  // request classes of the pods (slots of the per-batch de-duplication, see BatchDev)
-  HIPCHK(c, hipMemsetAsync(c->d_nepochs.as<uint32_t>() + 2, 0, 4, c->stream));
+  // request classes, per-group minima and (group, class) pairs of the pods: three launches behind the upload
+  // (reset | first half of the class builder | second half + pairs); K reaches the host through pinned memory
   if (P) {
-    HIPCHK(c, hipMemsetAsync(c->d_cls_slots.p, 0, (size_t)c->cls_cap * 8, c->stream));
     const PodsDev pd = pods_dev(c);
+    HIPCHK(c, c->d_gstat.reserve((size_t)4 * std::max<uint32_t>(c->G, 1) * 4));
+    hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, c->d_cls_slots.as<unsigned long long>(), 2 * c->cls_cap,
+                       c->d_gstat.as<uint32_t>(), c->have_groups ? 4 * c->G : 0u, c->d_nepochs.as<uint32_t>() + 2);
     hipLaunchKernelGGL(k_pod_class_a, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, c->d_cls_slots.as<unsigned long long>(), c->cls_cap - 1,
                        c->hash_keep, L, c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(), c->d_nepochs.as<uint32_t>() + 2);
-    hipLaunchKernelGGL(k_pod_class_b, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, P, c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(),
-                       c->d_pclass.as<uint32_t>());
-    HIPCHK(c, hipGetLastError());
+    LAUNCHCHK(c, BS_KERNEL_PREPASS);
+  } else {
+    HIPCHK(c, hipMemsetAsync(c->d_nepochs.as<uint32_t>() + 2, 0, 4, c->stream));
   }
-  // K travels back on its own (pinned memory + event): needed by the host only to size the Filter rows
-  HIPCHK(c, hipMemcpyAsync(c->h_info + 4, c->d_nepochs.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev_kinfo, c->stream));
-  c->kinfo_pending = true;
-  if (c->have_groups) {
-    rc = build_pairs(c);
-    if (rc) return rc;
-  }
+  rc = build_pairs(c, true);
+  if (rc) return rc;
   // no wait here: the batch that follows is ordered behind the upload on the same stream; only the staging
   // buffer must not be touched again before the copy has left it (ensure_stage / bs_batch_read wait for that)
   if (!c->ev_stage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
@@ -1144,7 +1163,7 @@ int bs_group_admit_bind(bs_ctx* c, void* dptr) {
 int bs_group_admit_devptr(bs_ctx* c, void** dptr, uint32_t* count) {
   if (!c || !dptr || !count) return BS_ERR_INVALID;
   if (!c->have_groups) return BS_ERR_STATE;
-  *dptr = c->ext_admit ? (void*)c->ext_admit : c->d_admit.p;
+  *dptr = (void*)batch_dev(c).admit;      // inside the result pack: re-query after a load that grows it
   *count = c->G;
   return BS_OK;
 }
@@ -1182,10 +1201,9 @@ static int reserve_slots(bs_ctx* c, bool run_filter) {
   HIPCHK(c, c->d_qtab_s.reserve((size_t)scan_cap * 4));
   if ((rc = reserve_filled(c, c->d_qstamp_s, (size_t)scan_cap * 4, 0))) return rc;
   if (run_filter) {
-    HIPCHK(c, c->d_fu_bitmap.reserve(std::max<size_t>(8, (size_t)cdiv(c->N, 64) * filter_cap * 8)));
+    HIPCHK(c, c->d_fu_bitmap.reserve((size_t)(cdiv(c->N, 64) + 1) * filter_cap * 8));      // slot rows, then the per-slot feasible counts
     HIPCHK(c, c->d_uparams.reserve((size_t)filter_cap * 64));
     if ((rc = reserve_filled(c, c->d_uflags, (size_t)filter_cap * 4, 0))) return rc;
-    HIPCHK(c, c->d_fu_feas.reserve((size_t)filter_cap * 4));
   }
   c->scan_slots_cap = scan_cap;
   c->filter_slots_cap = filter_cap;
@@ -1243,7 +1261,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   // ---- launch B: node scan over the class slots | Filter evaluation over the Filter slots
   // The work loops size themselves on the device (the class count lives there); the grid only has to be large
   // enough.  K is known on the host once its copy from the pod load has landed — never waited for here.
-  if (c->kinfo_pending && hipEventQuery(c->ev_kinfo) == hipSuccess && (rc = resolve_pods(c))) return rc;
+  if (c->kinfo_pending && ((volatile int32_t*)c->h_info)[5] == c->kinfo_tag && (rc = resolve_pods(c))) return rc;
   const uint32_t k_est = std::min<uint32_t>(P, c->kinfo_pending ? std::max<uint32_t>(2 * c->h_K, 1024) : std::max<uint32_t>(c->h_K, 1));
   TIMED(c, BS_KERNEL_SCAN, {
     const uint32_t nseg = pick_scan_share(c);
@@ -1286,7 +1304,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     return BS_ERR_INVALID;
   }
   if ((rc = resolve_groups(c))) return rc;
-  if (!c->pairs_ready && (rc = build_pairs(c))) return rc;
+  if (!c->pairs_ready && (rc = build_pairs(c, false))) return rc;
   const uint32_t W = cdiv(N, 64);
   const bool run_filter = stages & BS_STAGE_FILTER;
   if ((rc = reserve_slots(c, run_filter))) return rc;
@@ -1592,6 +1610,7 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
     }
   }
   const bool want_rows = nrows && W && out->fl_rows, want_rfeas = nrows && out->fl_rows_feasible;
+  if (nrows > c->filter_slots_cap) { c->last_error = "bs_batch_read: row count exceeds the slot capacity of the batch"; return BS_ERR_STATE; }
   // the pods x nodes bitmap exists only when somebody asks for it
   if (P && W && out->fl_bitmap && filtered && !c->bitmap_valid) {
     HIPCHK(c, c->d_fl_bitmap.reserve(std::max<size_t>(8, (size_t)W * P * 8)));
@@ -1600,22 +1619,21 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
     LAUNCHCHK(c, BS_KERNEL_FILTER);
     c->bitmap_valid = true;
   }
-  // everything small travels under ONE wait: the packed per-pod results, the two per-group arrays and the Filter
-  // rows are copied asynchronously into the pinned staging buffer, then the stream is synchronised once
-  const size_t off_admit = align256(c->outpack_bytes), off_ready = off_admit + align256((size_t)G * 4);
-  const size_t off_rfeas = off_ready + align256(G), off_rows = off_rfeas + align256((size_t)nrows * 4);
-  const size_t rows_bytes = want_rows ? (size_t)W * nrows * 8 : 0;
+  // ONE wait and at most two copies: the result pack (per-pod arrays | admit | ready, contiguous on the device) and the
+  // Filter rows with their feasible counts (a strided window of the slot bitmap; the counts sit behind its last row)
+  const bool ext = c->ext_admit != nullptr;
+  const size_t pack_bytes = want_grp ? c->outpack_bytes : c->off_admit;
+  const size_t off_xadmit = align256(c->outpack_bytes);
+  const size_t off_rows = off_xadmit + align256((size_t)G * 4);
+  const bool any_rows = want_rows || want_rfeas;
+  const size_t rows_h = any_rows ? (size_t)W + 1 : 0, rows_bytes = rows_h * nrows * 8;
   rc = ensure_stage(c, std::max(c->podpack_bytes, off_rows + rows_bytes + 256));
   if (rc) return rc;
   uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
-  if (want_pod) HIPCHK(c, hipMemcpyAsync(st, c->d_outpack.p, c->outpack_bytes, hipMemcpyDeviceToHost, c->stream));
-  if (want_grp) {
-    if (out->group_admit) HIPCHK(c, hipMemcpyAsync(st + off_admit, c->ext_admit ? (void*)c->ext_admit : c->d_admit.p, (size_t)G * 4, hipMemcpyDeviceToHost, c->stream));
-    if (out->group_ready) HIPCHK(c, hipMemcpyAsync(st + off_ready, c->d_ready.p, G, hipMemcpyDeviceToHost, c->stream));
-  }
-  if (want_rfeas) HIPCHK(c, hipMemcpyAsync(st + off_rfeas, c->d_fu_feas.p, (size_t)nrows * 4, hipMemcpyDeviceToHost, c->stream));
-  if (want_rows)
-    HIPCHK(c, hipMemcpy2DAsync(st + off_rows, (size_t)nrows * 8, c->d_fu_bitmap.p, (size_t)c->filter_slots_cap * 8, (size_t)nrows * 8, W,
+  if (want_pod || want_grp) HIPCHK(c, hipMemcpyAsync(st, c->d_outpack.p, pack_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (want_grp && ext && out->group_admit) HIPCHK(c, hipMemcpyAsync(st + off_xadmit, c->ext_admit, (size_t)G * 4, hipMemcpyDeviceToHost, c->stream));
+  if (any_rows)
+    HIPCHK(c, hipMemcpy2DAsync(st + off_rows, (size_t)nrows * 8, c->d_fu_bitmap.p, (size_t)c->filter_slots_cap * 8, (size_t)nrows * 8, rows_h,
                                hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stage_busy = false;
@@ -1628,10 +1646,10 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
     if (out->fl_slot) std::memcpy(out->fl_slot, st + c->off_fl_slot, (size_t)P * 4);
   }
   if (want_grp) {
-    if (out->group_admit) std::memcpy(out->group_admit, st + off_admit, (size_t)G * 4);
-    if (out->group_ready) std::memcpy(out->group_ready, st + off_ready, G);
+    if (out->group_admit) std::memcpy(out->group_admit, st + (ext ? off_xadmit : c->off_admit), (size_t)G * 4);
+    if (out->group_ready) std::memcpy(out->group_ready, st + c->off_ready, G);
   }
-  if (want_rfeas) std::memcpy(out->fl_rows_feasible, st + off_rfeas, (size_t)nrows * 4);
+  if (want_rfeas) std::memcpy(out->fl_rows_feasible, st + off_rows + (size_t)W * nrows * 8, (size_t)nrows * 4);
   if (want_rows)
     for (uint32_t w = 0; w < W; ++w) std::memcpy(out->fl_rows + (size_t)w * out->fl_rows_cap, st + off_rows + (size_t)w * nrows * 8, (size_t)nrows * 8);
   if (P && out->fl_bitmap && W) {

@@ -364,6 +364,10 @@ uint32_t bsh_start_batch(bsh_sop* s, int32_t group, uint64_t* out_uids, uint32_t
   return n;
 }
 
+// Push the PodGroup cache to the device now (bs_groups_load): what a shim does before handing a queue to
+// bs_batch_run, so that the batch starts from exactly the state the per-pod entry points have built up.
+int bsh_sync(bsh_sop* s) { return s->sync_groups(); }
+
 // observers for tests
 uint32_t bsh_group_matched(const bsh_sop* s, int32_t g) { return s->groups[g].matched.Count(s->now); }
 uint32_t bsh_group_status_scheduled(const bsh_sop* s, int32_t g) { return s->groups[g].status_scheduled; }

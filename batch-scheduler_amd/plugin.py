@@ -19,7 +19,7 @@ SECOND = 1_000_000_000
 PERMIT_READY, PERMIT_WAITING, PERMIT_NOT_MATCHED, PERMIT_NOT_FOUND = 0, 1, 2, 3
 
 HOST_SYMBOLS = ["bsh_create", "bsh_destroy", "bsh_set_time", "bsh_time", "bsh_gpu_calls", "bsh_add_group", "bsh_prefilter", "bsh_filter",
-                "bsh_permit", "bsh_postbind", "bsh_less", "bsh_start_batch", "bsh_group_matched", "bsh_group_status_scheduled",
+                "bsh_permit", "bsh_postbind", "bsh_less", "bsh_start_batch", "bsh_sync", "bsh_group_matched", "bsh_group_status_scheduled",
                 "bsh_group_flags", "bsh_group_denied", "bsh_ttl_new", "bsh_ttl_free", "bsh_ttl_set", "bsh_ttl_add", "bsh_ttl_get",
                 "bsh_ttl_delete", "bsh_ttl_count"]
 
@@ -50,6 +50,7 @@ def load_host_library():
         L.bsh_filter.argtypes = [vp, u64, i32, P(i64), u32, u32, P(u8), P(u8)]
         L.bsh_permit.argtypes = [vp, u64, u64, i32, u32, P(u8)]
         L.bsh_postbind.argtypes = [vp, i32]
+        L.bsh_sync.argtypes = [vp]
         L.bsh_less.argtypes = [vp, i32, i32, i64, i32, i32, i64]
         L.bsh_start_batch.restype = u32
         L.bsh_start_batch.argtypes = [vp, i32, P(u64), P(u32), u32]
@@ -132,6 +133,12 @@ class ScheduleOperation:
         ready = C.c_uint8(0)
         code = self._lib.bsh_permit(self._h, uid, name, group, node, C.byref(ready))
         return bool(ready.value), int(code)
+
+    def sync(self):
+        """push the PodGroup cache to the device (bs_groups_load) — the state a following bs_batch_run starts from"""
+        rc = self._lib.bsh_sync(self._h)
+        if rc != 0:
+            raise capi.BsError(rc, "bsh_sync")
 
     def PostBind(self, group: int):
         self._lib.bsh_postbind(self._h, group)

@@ -335,8 +335,9 @@ def test_sharded_union_equals_single(bsa, soa, orc):
         ctx.set_shard(0, 1)
 
 
-def test_native_rccl_single_rank(bsa, soa, orc):
+def test_native_rccl_single_rank(bsa, soa, orc, monkeypatch):
     """bs_comm_init + in-library ncclAllReduce at world size 1 (the only size one GPU allows)."""
+    monkeypatch.setenv("NCCL_SOCKET_IFNAME", "lo")          # the bootstrap must not go looking for a routable interface
     nodes, fit, groups, pods, _ = bsa.synth.make("tiny", "warm")
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:

@@ -1,5 +1,6 @@
-"""Host-observed breakdown of one admit cycle (what gang_admit_latency_ms_p50 in bench.py adds up):
-bs_pods_load (pack + H2D + request classes, asynchronous), bs_batch_run + sync, bs_batch_read.
+"""Host-observed breakdown of one scheduling cycle (what host_cycle in bench.py adds up): bs_groups_apply,
+bs_pods_load (pack + H2D + class / pair kernels, asynchronous), bs_batch_run, bs_batch_read — once as the cycle
+runs (no wait between the calls) and once with a stream wait after every call to see what each one costs the GPU.
 Usage (GPU box): python tools/latency_breakdown.py [config=cfg3] [scenario=tail]"""
 import importlib
 import json
@@ -23,28 +24,38 @@ def main():
     ctx = bsa.Context(scalar_lanes=nodes.lanes - 4)
     ctx.load_nodes(nodes, fit)
     ctx.load_groups(groups)
-    out = soa.BatchOut.alloc(pods.p, groups.g, nodes.n, bitmap=False)
-    rows = []
-    for it in range(40):
-        t0 = time.perf_counter()
-        ctx.load_pods(pods)
-        t1 = time.perf_counter()
-        ctx.sync()
-        t2 = time.perf_counter()
-        ctx.run(soa.STAGE_ALL)
-        t3 = time.perf_counter()
-        ctx.sync()
-        t4 = time.perf_counter()
-        ctx.read(bitmap=False, out=out)
-        t5 = time.perf_counter()
-        if it >= 10:
-            rows.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0))
-    med = np.median(np.array(rows), axis=0) * 1e6
-    print(json.dumps({"workload": f"{config}/{scenario}", "us_p50": {
-        "pods_load_call (pack + enqueue)": round(float(med[0]), 1), "upload + class kernels drain": round(float(med[1]), 1),
-        "batch_run call (enqueue)": round(float(med[2]), 1), "batch drain": round(float(med[3]), 1),
-        "batch_read (D2H + unpack)": round(float(med[4]), 1), "total with the two extra syncs": round(float(med[5]), 1)},
-        "note": "the extra ctx.sync() calls exist only to split the phases; bench.py's latency loop has none between load, run and read"}))
+    ctx.load_pods(pods)
+    ctx.run(soa.STAGE_ALL)
+    out = soa.BatchOut.alloc(pods.p, groups.g, nodes.n, bitmap=False, rows_cap=max(ctx.filter_rows_count(), 1))
+    small = soa.BatchOut.alloc(pods.p, groups.g, nodes.n, bitmap=False)
+    idx = np.random.default_rng(1).choice(groups.g, min(32, groups.g), replace=False)
+    deltas = [(int(i), int(groups.matched[i]), int(groups.status_scheduled[i]), int(groups.flags[i])) for i in idx]
+    names = ["groups_apply", "pods_load", "batch_run", "batch_read"]
+    res = {}
+    for mode in ("as_run", "drained_after_each_call", "read_without_rows"):
+        rows = []
+        for it in range(50):
+            ts = [time.perf_counter()]
+            ctx.apply_group_deltas(deltas)
+            if mode == "drained_after_each_call":
+                ctx.sync()
+            ts.append(time.perf_counter())
+            ctx.load_pods(pods)
+            if mode == "drained_after_each_call":
+                ctx.sync()
+            ts.append(time.perf_counter())
+            ctx.run(soa.STAGE_ALL)
+            if mode == "drained_after_each_call":
+                ctx.sync()
+            ts.append(time.perf_counter())
+            ctx.read(out=small if mode == "read_without_rows" else out)
+            ts.append(time.perf_counter())
+            if it >= 10:
+                rows.append([ts[k + 1] - ts[k] for k in range(4)] + [ts[4] - ts[0]])
+        med = np.median(np.array(rows), axis=0) * 1e6
+        res[mode] = {n: round(float(m), 1) for n, m in zip(names + ["total"], med)}
+    print(json.dumps({"workload": f"{config}/{scenario}", "us_p50": res,
+                      "note": "drained_after_each_call: a stream wait after every call (only to split the phases; the cycle itself has one wait, inside bs_batch_read)"}))
 
 
 if __name__ == "__main__":
