@@ -1,0 +1,212 @@
+// Package core — the batched mode of the cgo shim: one scheduling cycle = patch the groups that changed, hand over
+// the drained queue, run, read; the plugin hooks then answer from tables with no cgo crossing.
+//
+// SOURCE ONLY (see bsched_cgo.go).
+package core
+
+/*
+#include "bsched.h"
+*/
+import "C"
+
+import (
+	corev1 "k8s.io/api/core/v1"
+	"k8s.io/apimachinery/pkg/types"
+	"k8s.io/kubernetes/pkg/scheduler/nodeinfo"
+
+	"github.com/tenstack/batch-scheduler/pkg/scheduler/cache"
+	"github.com/tenstack/batch-scheduler/pkg/util"
+)
+
+// loadGroups flattens the PodGroup cache (cache.go:45-67) in a FIXED iteration order (findMaxPG ranges over a Go map,
+// core.go:703; parity is defined for the order handed over here, e.g. sorted by full name).  Full load: after a
+// first-pod capture or when groups come and go; per-cycle counter changes go through patchGroups.
+func (g *gpuCore) loadGroups(order []string, pgCache map[string]*cache.PodGroupMatchStatus, denied func(string) bool) error {
+	G, L := len(order), 4+len(g.scalars)
+	mm, sc, matched := make([]C.uint32_t, G+1), make([]C.uint32_t, G+1), make([]C.uint32_t, G+1)
+	flags, cls := make([]C.uint8_t, G+1), make([]C.uint32_t, G+1)
+	minres, mrp, occ := make([]C.int64_t, L*G+1), make([]C.uint32_t, G+1), make([]C.uint64_t, G+1)
+	for i, name := range order {
+		pgs := pgCache[name]
+		mm[i] = C.uint32_t(pgs.PodGroup.Spec.MinMember)
+		sc[i] = C.uint32_t(pgs.PodGroup.Status.Scheduled)
+		matched[i] = C.uint32_t(len(pgs.MatchedPodNodes.Items())) // core.go:716
+		flags[i] = C.uint8_t(g.groupFlags(name, pgs, denied))
+		if pgs.Pod != nil {
+			cls[i] = C.uint32_t(g.classOf(pgs.Pod))
+		}
+		if mr := pgs.PodGroup.Spec.MinResources; mr != nil { // core.go:489-493
+			var r nodeinfo.Resource
+			r.Add(*mr)
+			mrp[i] = g.lanes(&r, minres, G, i)
+		}
+		occ[i] = C.uint64_t(g.intern64(pgs.PodGroup.Status.OccupiedBy)) // 0 == ""
+	}
+	soa := C.bs_groups_soa{g: C.uint32_t(G), min_member: &mm[0], status_scheduled: &sc[0], matched: &matched[0], flags: &flags[0],
+		cls: &cls[0], min_resources: &minres[0], min_resources_present: &mrp[0], occupied_by: &occ[0]}
+	g.mu.Lock()
+	defer g.mu.Unlock()
+	return g.check("bs_groups_load", C.bs_groups_load(g.ctx, &soa))
+}
+
+func (g *gpuCore) groupFlags(name string, pgs *cache.PodGroupMatchStatus, denied func(string) bool) uint32 {
+	var f uint32
+	if pgs.Scheduled { // core.go:305
+		f |= C.BS_GROUP_SCHEDULED_LATCH
+	}
+	if pgs.Pod != nil {
+		f |= C.BS_GROUP_HAS_POD
+	}
+	if pgs.PodGroup.Spec.MinResources != nil {
+		f |= C.BS_GROUP_HAS_MINRES
+	}
+	if denied(name) { // live lastDeniedPG entry, core.go:105
+		f |= C.BS_GROUP_DENIED
+	}
+	return f
+}
+
+// patchGroups: what one scheduling cycle changes — Permit adds to MatchedPodNodes (core.go:290), PostBind moves pods to
+// Status.Scheduled (core.go:327), the quorum latch (core.go:305), deny entries appear and expire.  One kernel launch on
+// the library side, nothing waited for.
+func (g *gpuCore) patchGroups(index map[string]uint32, changed []string, pgCache map[string]*cache.PodGroupMatchStatus, denied func(string) bool) error {
+	if len(changed) == 0 {
+		return nil
+	}
+	d := make([]C.bs_group_delta, len(changed))
+	for i, name := range changed {
+		pgs := pgCache[name]
+		d[i] = C.bs_group_delta{index: C.uint32_t(index[name]), matched: C.uint32_t(len(pgs.MatchedPodNodes.Items())),
+			status_scheduled: C.uint32_t(pgs.PodGroup.Status.Scheduled), flags: C.uint32_t(g.groupFlags(name, pgs, denied))}
+	}
+	g.mu.Lock()
+	defer g.mu.Unlock()
+	return g.check("bs_groups_apply", C.bs_groups_apply(g.ctx, &d[0], C.uint32_t(len(d))))
+}
+
+// batchResult: Go-owned result arrays of one batch.  Filter is answered from the slot rows (distinct requests), never
+// from a pods x nodes bitmap.
+type batchResult struct {
+	index     map[types.UID]int // pod -> queue position
+	nodeIndex map[string]int    // node name -> list index of the snapshot
+	n         int
+	pfCode    []C.uint8_t
+	pfFirstK  []C.uint32_t
+	flCode    []C.uint8_t
+	flSlot    []C.uint32_t
+	rows      []C.uint64_t // [ceil(n/64)][rowsCap]
+	rowsCap   int
+	admit     []C.uint32_t
+	ready     []C.uint8_t
+}
+
+// filterPasses: Filter(pod i, node k) of core.go:170-191 as a bit test.
+func (r *batchResult) filterPasses(i, k int) bool {
+	switch code := r.flCode[i]; {
+	case code == C.BS_FL_EVALUATED:
+		return r.rows[(k>>6)*r.rowsCap+int(r.flSlot[i])]>>(uint(k)&63)&1 == 1
+	default:
+		return code < 16 // pass on every node (not grouped / leader itself / no MinResources) or on none (error codes)
+	}
+}
+
+// runBatch scores the drained scheduling queue (already ordered by Less) in one call.
+func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, permitted func(*corev1.Pod) bool) (*batchResult, error) {
+	P, L := len(queue), 4+len(g.scalars)
+	grp, req := make([]C.int32_t, P+1), make([]C.int64_t, L*P+1)
+	pres, cls, owner, flags := make([]C.uint32_t, P+1), make([]C.uint32_t, P+1), make([]C.uint64_t, P+1), make([]C.uint8_t, P+1)
+	res := &batchResult{index: make(map[types.UID]int, P), n: g.nodes}
+	for i, p := range queue {
+		res.index[p.UID] = i
+		name, ok := util.VerifyPodLabelSatisfied(p) // util/k8s.go:62-70
+		switch gi, found := groupIndex[p.Namespace+"/"+name]; {
+		case !ok:
+			grp[i] = C.BS_POD_NOT_GROUPED // core.go:89-92
+		case !found:
+			grp[i] = C.BS_POD_GROUP_MISSING // core.go:100-103
+		default:
+			grp[i] = C.int32_t(gi)
+		}
+		pres[i] = g.lanes(getPodResourceRequire(p), req, P, i) // core.go:761-772
+		cls[i] = C.uint32_t(g.classOf(p))
+		owner[i] = C.uint64_t(g.intern64(joinedOwnerUIDs(p))) // core.go:498-499, 0 = none
+		if permitted(p) {                                    // live lastPermittedPod entry, core.go:95
+			flags[i] |= C.BS_POD_LAST_PERMITTED
+		}
+	}
+	soa := C.bs_pods_soa{p: C.uint32_t(P), group: &grp[0], req: &req[0], req_present: &pres[0], cls: &cls[0], owner: &owner[0], flags: &flags[0]}
+	g.mu.Lock()
+	defer g.mu.Unlock()
+	if err := g.check("bs_pods_load", C.bs_pods_load(g.ctx, &soa)); err != nil {
+		return nil, err
+	}
+	if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, C.BS_STAGE_ALL)); err != nil {
+		return nil, err
+	}
+	var rowsNeeded C.uint32_t
+	if err := g.check("bs_filter_rows_count", C.bs_filter_rows_count(g.ctx, &rowsNeeded)); err != nil {
+		return nil, err
+	}
+	G, W := len(groupIndex), (g.nodes+63)/64
+	res.rowsCap = int(rowsNeeded) + 1
+	res.pfCode, res.pfFirstK = make([]C.uint8_t, P+1), make([]C.uint32_t, P+1)
+	res.flCode, res.flSlot = make([]C.uint8_t, P+1), make([]C.uint32_t, P+1)
+	res.rows = make([]C.uint64_t, W*res.rowsCap+1)
+	res.admit, res.ready = make([]C.uint32_t, G+1), make([]C.uint8_t, G+1)
+	var rowsN C.uint32_t
+	out := C.bs_batch_out{pf_code: &res.pfCode[0], pf_first_k: &res.pfFirstK[0], fl_code: &res.flCode[0], fl_slot: &res.flSlot[0],
+		fl_rows: &res.rows[0], fl_rows_cap: C.uint32_t(res.rowsCap), fl_rows_n: &rowsN, group_admit: &res.admit[0], group_ready: &res.ready[0]}
+	return res, g.check("bs_batch_read", C.bs_batch_read(g.ctx, &out)) // the one stream wait of the cycle
+}
+
+// All slices live only for the duration of the calls (cgo pointer rules: the library copies and keeps no Go pointer).
+//
+// Plugin hooks over a batchResult (batchscheduler.go:102,151,165) — table look-ups, no cgo crossing:
+//
+//	func (bs *batchSchedulingPlugin) PreFilter(ctx context.Context, st *framework.CycleState, p *corev1.Pod) *framework.Status {
+//		code := bs.batch.pfCode[bs.batch.index[p.UID]]
+//		if code >= 16 { // !BS_PF_IS_PASS
+//			if code == C.BS_PF_REJECT_FIRST || code == C.BS_PF_REJECT_RESERVE {
+//				bs.operation.AddToDenyCache(fullName(p)) // the 20 s TTL clock stays in Go, core.go:423
+//			}
+//			return framework.NewStatus(framework.Unschedulable, pfMessage[code]) // same strings as core.go:102,107,143,164
+//		}
+//		return framework.NewStatus(framework.Success, "")
+//	}
+//
+//	func (bs *batchSchedulingPlugin) Filter(ctx context.Context, st *framework.CycleState, p *corev1.Pod, ni *nodeinfo.NodeInfo) *framework.Status {
+//		if !bs.batch.filterPasses(bs.batch.index[p.UID], bs.batch.nodeIndex[ni.Node().Name]) {
+//			return framework.NewStatus(framework.Unschedulable, util.ErrorResourceNotEnough.Error())
+//		}
+//		return framework.NewStatus(framework.Success, "")
+//	}
+//
+// Permit keeps its TTL-map bookkeeping (core.go:284-300).  bs_batch_out.group_ready is the quorum predicate (:303) for
+// "every pod of the queue that passes is permitted" against the FROZEN snapshot: a pre-screen, not a reservation — the
+// batch does not charge the capacity one gang takes to the next (tests/test_batch_vs_sequential.py states the relation);
+// after admitting a gang the shim patches the node requests (bs_nodes_apply) and group counters (patchGroups) and re-runs
+// the batch for the rest of the queue (tens of microseconds).
+
+func joinedOwnerUIDs(p *corev1.Pod) string { // core.go:494-499: sorted, comma-joined OwnerReferences UIDs
+	if len(p.OwnerReferences) == 0 {
+		return ""
+	}
+	ids := make([]string, 0, len(p.OwnerReferences))
+	for _, o := range p.OwnerReferences {
+		ids = append(ids, string(o.UID))
+	}
+	sortStrings(ids)
+	out := ids[0]
+	for _, s := range ids[1:] {
+		out += "," + s
+	}
+	return out
+}
+
+func sortStrings(a []string) {
+	for i := 1; i < len(a); i++ {
+		for j := i; j > 0 && a[j] < a[j-1]; j-- {
+			a[j], a[j-1] = a[j-1], a[j]
+		}
+	}
+}

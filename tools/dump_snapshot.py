@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dump a seeded synthetic snapshot + the request vectors of its reservation queries as JSON, for the
-un-run Go benchmark bench_go/prefilter_bench_test.go.  usage: dump_snapshot.py <config> <scenario> [seed]"""
+un-run Go benchmark go/pkg/scheduler/core/prefilter_bench_test.go.  usage: dump_snapshot.py <config> <scenario> [seed]"""
 import importlib
 import json
 import os
