@@ -341,7 +341,9 @@ BatchParams batch_params(const bs_ctx* c) {
   BatchParams p{};
   p.L = c->L; p.S = c->S; p.LP = c->LP; p.C = c->C;
   p.eph_gate = c->cfg.eph_gate;
-  p.rank = c->rank; p.nranks = c->nranks;
+  // partitioned mode (bs_reduce_external): the caller dealt whole groups to the ranks, every loaded pod is this rank's
+  p.rank = c->reduce_external ? 0u : c->rank;
+  p.nranks = c->reduce_external ? 1u : c->nranks;
   p.sop_leader0 = c->sop_leader0;
   p.run_filter = 0;
   p.hash_keep = c->hash_keep;

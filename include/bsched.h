@@ -378,6 +378,18 @@ int bs_group_admit_devptr(bs_ctx* ctx, void** dptr, uint32_t* count);
  * occur in the batch (every group already has its pod): then no pod's decision depends on a pod of
  * another group.  Otherwise use bs_shard_set (whole batch on every rank). */
 int bs_reduce_external(bs_ctx* ctx, uint32_t on);
+/* The three multi-rank modes (one process per GPU; node / group / fit state replicated on every rank):
+ *   replicated   bs_shard_set(rank, nranks) [or bs_comm_init]: the whole queue on every rank, ownership decided on the device.
+ *   partitioned  bs_reduce_external(1): each rank holds only the pods of the groups it owns; with bs_comm_init the library
+ *                still performs the all-reduce itself, otherwise the caller reduces bs_group_admit_devptr and calls
+ *                bs_batch_finish.
+ * In both the per-group admit counters of different ranks are disjoint, so all-reduce(sum) == all-reduce(max).
+ * Exactness under sharding: decisions (pf_code, pf_first_k, Filter results, admit, ready) of owned pods equal the
+ * single-context batch.  pf_leader — the stale shared field sop.maxFinishedPG a pod leaves behind when it returns before
+ * core.go:120 — and with it the Filter result of BS_POD_LAST_PERMITTED pods is exact in replicated mode whenever no
+ * first-pod capture can occur in the batch; in partitioned mode (and in replicated mode with captures) such a pod sees the
+ * leader left by the latest reaching pod OF ITS OWN RANK'S view.  Nothing else is affected (tests/test_gpu_multirank.py
+ * asserts that set). */
 /* Use caller-owned device memory (uint32[g], e.g. a torch tensor's data_ptr) for the admit counters,
  * so that a framework collective can reduce it in place.  NULL restores the internal buffer. */
 int bs_group_admit_bind(bs_ctx* ctx, void* dptr);

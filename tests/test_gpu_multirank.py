@@ -1,0 +1,86 @@
+"""N > 1 ranks of DEVICE code meeting in a real collective (GPU).  gpurun boxes have one GPU, so the ranks are separate
+processes sharing it: each has its own bs_ctx and HIP stream; the admit counters meet either in the library's own
+ncclAllReduce (bs_comm_init, RCCL) or in a gloo all-reduce of the device buffers followed by bs_batch_finish."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REACHED = (2, 3, 4, 5, 19, 20)          # codes of pods that got as far as findMaxPG (core.go:118-123)
+
+
+def _run(mode, world, config, scenario, seed, timeout=240):
+    work = tempfile.mkdtemp(prefix="bs_mr_")
+    env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), mode, str(r), str(world), work, config, scenario, str(seed)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            out = "timeout"
+        logs.append(out)
+    res = []
+    for r in range(world):
+        path = os.path.join(work, f"rank{r}.npz")
+        assert os.path.exists(path), f"rank {r} left no result:\n{logs[r][-2000:]}"
+        res.append(dict(np.load(path, allow_pickle=False)))
+    return res
+
+
+def _check(res, mode, bsa, soa, orc, config, scenario, seed, pods, groups, exp):
+    admit = None
+    seen = np.zeros(pods.p, np.int32)
+    for r, d in enumerate(res):
+        idx = d["idx"]
+        owned = d["pf_code"] != 0xFF
+        seen[idx[owned]] += 1
+        e = lambda a: getattr(exp, a)[idx][owned]
+        g = lambda a: d[a][owned]
+        for a in ("pf_code", "pf_first_k"):
+            assert np.array_equal(g(a), e(a)), (mode, r, a)
+        assert np.array_equal(d["fl_bitmap"][:, owned], exp.fl_bitmap[:, idx][:, owned]), (mode, r, "fl_bitmap")
+        # the stale shared field (and the Filter result that hangs on it) may only differ for pods that never reached findMaxPG
+        diff = (g("pf_leader") != e("pf_leader")) | (g("fl_code") != e("fl_code")) | (g("fl_feasible") != e("fl_feasible"))
+        assert not np.any(diff & np.isin(g("pf_code"), REACHED)), (mode, r)
+        flags, grp = pods.flags[idx][owned], pods.group[idx][owned]
+        assert np.all((flags[diff] & soa.POD_LAST_PERMITTED) | (grp[diff] < 0)), (mode, r, "only LAST_PERMITTED / ungrouped pods can see another rank's view")
+        if mode == "native-replicated" and scenario != "cold":
+            assert not diff.any(), "replicated mode without captures is exact, stale leader included"
+        # after the collective every rank holds the whole job's counters and the quorum bits computed from them
+        assert np.array_equal(d["group_admit"], exp.group_admit), (mode, r, "admit after the all-reduce")
+        assert np.array_equal(d["group_ready"], exp.group_ready), (mode, r, "quorum bits")
+        assert bool(d["repeatable"])
+    assert np.all(seen == 1), "every pod is decided by exactly one rank"
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("mode,world", [("gloo-partitioned", 2), ("gloo-partitioned", 3), ("native-replicated", 2), ("native-partitioned", 2)])
+def test_ranks_meet_in_a_collective(mode, world, bsa, soa, orc):
+    if mode.startswith("native") and _gpus() < world:
+        # measured on the 1-GPU box: RCCL 2.27 either refuses a second rank of one communicator on the same device or never
+        # finishes the bootstrap; the library's ncclAllReduce path runs at world size 1 (test_native_rccl_single_rank) and,
+        # with one GPU per rank, here
+        pytest.skip(f"native RCCL needs one GPU per rank ({_gpus()} visible)")
+    config, scenario, seed = "cfg2", "busy", 3
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario, seed=seed)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    res = _run(mode, world, config, scenario, seed)
+    status = [str(d["status"]) for d in res]
+    if mode.startswith("native") and any(s != "ok" for s in status):
+        # RCCL may refuse several ranks of one communicator on a single device; the gloo variants above cover N > 1 then
+        pytest.skip(f"RCCL with {world} ranks on one GPU: {status}")
+    assert all(s == "ok" for s in status), status
+    _check(res, mode, bsa, soa, orc, config, scenario, seed, pods, groups, exp)

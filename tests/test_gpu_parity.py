@@ -329,6 +329,8 @@ def test_sharded_union_equals_single(bsa, soa, orc):
                 assert np.array_equal(part.pf_first_k[mine], single.pf_first_k[mine])
                 assert np.array_equal(part.fl_feasible[mine], single.fl_feasible[mine])
                 assert np.array_equal(part.fl_bitmap[:, mine], single.fl_bitmap[:, mine])
+                # no first-pod capture can occur here: the replicated mode is exact down to the stale shared leader field
+                assert np.array_equal(part.pf_leader[mine], single.pf_leader[mine]) and np.array_equal(part.fl_code[mine], single.fl_code[mine])
                 admit += part.group_admit
             assert np.all(owned == 1), "every pod is evaluated by exactly one rank"
             assert np.array_equal(admit, single.group_admit)
