@@ -132,7 +132,7 @@ constexpr int kOffBatch = 128;                     // chunks per LDS batch of th
 
 template <int TS>
 __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk,
-                                                  uint32_t nchunks) {
+                                                  uint32_t nchunks, uint32_t* ticket) {
   __shared__ unsigned long long s_wtot[BS_MAX_LANES][4];
   __shared__ uint32_t s_kp[BS_MAX_SCALARS];
   __shared__ uint32_t s_last;
@@ -183,23 +183,25 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
       }
       incl[j] += off;
       if (valid) T[(size_t)k * LP + j] = (int64_t)incl[j];
-      if (threadIdx.x == 0) b.chunk_tot[(size_t)chunk * 16 + j] = tot;
+      if (threadIdx.x == 0) __hip_atomic_store(&b.chunk_tot[(size_t)chunk * 16 + j], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if (j < LP && valid) T[(size_t)k * LP + j] = INT64_MAX;
-      if (threadIdx.x == 0) b.chunk_tot[(size_t)chunk * 16 + j] = 0ull;
+      if (threadIdx.x == 0) __hip_atomic_store(&b.chunk_tot[(size_t)chunk * 16 + j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  // per 64-row group: max and min of the local sums per fixed lane (the scan prunes with max + chunk offset)
+  // per 64-row group: max and min of the local sums per resource lane (the tail turns them into bounds of the final sums)
   {
     const uint32_t grp = k >> 6;
     const bool grp_valid = (chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t mx = wave_max_i64(valid ? (int64_t)incl[j] : INT64_MIN);
-      const int64_t mn = wave_min_i64(valid ? (int64_t)incl[j] : INT64_MAX);
-      if (lane_id() == 0 && grp_valid) {
-        b.gmm8[(size_t)grp * 8 + j] = mx;
-        b.gmm8[(size_t)grp * 8 + 4 + j] = mn;
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+      if (j < L) {
+        const int64_t mx = wave_max_i64(valid ? (int64_t)incl[j] : INT64_MIN);
+        const int64_t mn = wave_min_i64(valid ? (int64_t)incl[j] : INT64_MAX);
+        if (lane_id() == 0 && grp_valid) {     // read back by the tail of this launch: write-through at agent scope
+          __hip_atomic_store(&b.gmm8[(size_t)grp * 2 * LP + j], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&b.gmm8[(size_t)grp * 2 * LP + LP + j], mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }
@@ -211,22 +213,19 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
     }
   }
   __syncthreads();
-  if (threadIdx.x < 16) b.chunk_kp[(size_t)chunk * 16 + threadIdx.x] = threadIdx.x < BS_MAX_SCALARS ? s_kp[threadIdx.x] : BS_INF;
-  // ---- publish, take a ticket; the last chunk block finishes the table's side arrays
+  if (threadIdx.x < 16)
+    __hip_atomic_store(&b.chunk_kp[(size_t)chunk * 16 + threadIdx.x], threadIdx.x < BS_MAX_SCALARS ? s_kp[threadIdx.x] : BS_INF, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // ---- publish, take a ticket; the last chunk block finishes the table's side arrays.  What the tail reads (chunk
+  // totals, per-chunk key rows) was stored write-through at agent scope and is drained (vmcnt) before the ticket; the tail
+  // reads it back with agent-scope loads.  No release / acquire fence: on this 8-XCD part a fence is an L2 write-back or
+  // invalidate per block, and the table rows themselves only have to be visible to the NEXT launch.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_last = atomicAdd(&b.ticket[1], 1u) == nchunks - 1 ? 1u : 0u;
-  }
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunks - 1 ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    b.ticket[1] = 0;
-  }
-  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned long long acc = 0;
   uint32_t kpm = BS_INF;
   for (uint32_t c0 = 0; c0 < nchunks; c0 += kOffBatch) {
@@ -246,6 +245,20 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
     __syncthreads();
   }
   if (threadIdx.x < 16) b.kp[threadIdx.x] = kpm;
+  // per 64-row group: upper bound of the FINAL running sums per fixed lane = local max + chunk offset — exact when neither
+  // max + off nor min + off leaves the int64 range (then no row of the group wraps); otherwise "cannot prune" (INT64_MAX)
+  __syncthreads();                                 // chunk_off of this table is complete (written by threads < 16 above)
+  const uint32_t ngroups = (nd.m + 63u) >> 6;
+  for (uint32_t e = threadIdx.x; e < ngroups * LP; e += kTblChunk) {
+    const uint32_t g = e / LP, j = e - g * LP;
+    if (j >= L) continue;
+    const long long mx = (long long)__hip_atomic_load(&b.gmm8[(size_t)g * 2 * LP + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long mn = (long long)__hip_atomic_load(&b.gmm8[(size_t)g * 2 * LP + LP + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long of = (long long)b.chunk_off[(size_t)(g >> 2) * 16 + j];
+    long long hi, lo;
+    const bool o1 = __builtin_saddll_overflow(mx, of, &hi), o2 = __builtin_saddll_overflow(mn, of, &lo);
+    b.gmax[(size_t)g * LP + j] = (o1 || o2) ? INT64_MAX : (int64_t)hi;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -354,7 +367,7 @@ template <int TS>
 __global__ __launch_bounds__(kTblChunk) void k_fast_query_tables(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm,
                                                                  const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks) {
   if (blockIdx.x < query_blocks) fast_query_thread<TS>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
-  else tables_local_fast<TS>(nd, bt, prm, forced, blockIdx.x - query_blocks, nchunks);
+  else tables_local_fast<TS>(nd, bt, prm, forced, blockIdx.x - query_blocks, nchunks, &b.ticket[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,23 +458,123 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
   if (!prm.do_tally) return;
   wave_aggregated_inc(b.admit, ag, admit);
   if (!prm.do_ready) return;
+  // the admit counters are agent-scope atomics (performed at the coherence point, returned before vmcnt drains): a drained
+  // ticket orders them, the last block reads them back with agent-scope loads — no L2 write-back / invalidate per block
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_last = atomicAdd(&b.ticket[0], 1u) == gridDim.x - 1 ? 1u : 0u;
-  }
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    b.ticket[0] = 0;
-  }
-  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (uint32_t gg = threadIdx.x; gg < gr.g; gg += 256u) {
     const uint32_t have = gr.matched[gg] + __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     b.ready[gg] = have >= (uint32_t)(gr.min_member[gg] - gr.status_scheduled[gg]) ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// General chain, tables without the fix-up pass: block (table, chunk) of every table some query of the batch uses builds
+// its chunk-local running sums; the last block of each table turns its chunk totals into offsets (per-table ticket).
+// k_scan<S, true> adds the offsets while the rows travel to LDS.
+// ------------------------------------------------------------------------------------------------
+template <int TS>
+__global__ __launch_bounds__(kTblChunk) void k_tables_local_nofix(NodesDev nd, BatchDev b, BatchParams prm, uint32_t nchunks, uint32_t cstride,
+                                                                  uint32_t gstride) {
+  const uint32_t slot = blockIdx.x;
+  if (!b.needed[slot]) return;
+  BatchDev bt = b;
+  bt.tables = b.tables + (size_t)slot * prm.mcap * prm.LP;
+  bt.kp = b.kp + (size_t)slot * 16;
+  bt.chunk_tot = b.chunk_tot + (size_t)slot * cstride * 16;
+  bt.chunk_kp = b.chunk_kp + (size_t)slot * cstride * 16;
+  bt.chunk_off = b.chunk_off + (size_t)slot * cstride * 16;
+  bt.gmm8 = b.gmm8 + (size_t)slot * gstride * 2 * prm.LP;
+  bt.gmax = b.gmax + (size_t)slot * gstride * prm.LP;
+  const TableDesc d = table_desc(slot, prm.C, nullptr);
+  tables_local_fast<TS>(nd, bt, prm, &d, blockIdx.y, nchunks, &b.tticket[slot]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// findMaxPG for every capture epoch in ONE block (replaces one block per epoch).
+// The candidate set only grows with the epoch (epoch e adds the group captured there), and the fold of
+// core.go:701-739 over a candidate set is: F = largest progress, holder = FIRST candidate (group order) at F — unless
+// that one is fully scheduled (Status.Scheduled >= MinMember), where the tie rule :729-731 may hand over to a later
+// candidate.  (F, first index) is a prefix maximum over the epochs; the rare handed-over epochs are folded exactly
+// (leader_block) afterwards.  A uint32 divide by zero (:716-717) at some epoch panics every later epoch too.
+// key = (F + 1) << 31 | (0x7FFFFFFF - group): larger F wins, then the smaller group index; 0 = no candidate.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLeaderBlock) void k_leader_scan(GroupsDev gr, BatchDev b) {
+  __shared__ unsigned long long s_w[kLeaderBlock / 64];
+  __shared__ uint32_t s_p[kLeaderBlock / 64];
+  __shared__ unsigned long long s_carry;
+  __shared__ uint32_t s_pcarry, s_nexact, s_exact[64];
+  const uint32_t E1 = *b.nepochs;                 // epochs 0 .. E1-1
+  auto key_of = [&](uint32_t g, bool& panic) -> unsigned long long {
+    if (gr.flags[g] & BS_GROUP_SCHEDULED_LATCH) return 0ull;
+    const uint32_t f = leader_finished(gr, g, panic);
+    return (((unsigned long long)f + 1ull) << 31) | (unsigned long long)(0x7FFFFFFFu - g);
+  };
+  // epoch 0: the groups that already have their pod
+  unsigned long long k0 = 0;
+  bool p0 = false;
+  for (uint32_t g = threadIdx.x; g < gr.g; g += kLeaderBlock)
+    if (b.cap_epoch[g] == 0u) { const unsigned long long k = key_of(g, p0); k0 = k > k0 ? k : k0; }
+  {
+    const unsigned long long m = block_max_u64(k0, s_w);
+    const unsigned long long anyp = __ballot(p0);
+    if (lane_id() == 0) s_p[wave_id()] = anyp ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t pp = 0;
+      for (int w = 0; w < kLeaderBlock / 64; ++w) pp |= s_p[w];
+      s_carry = m;
+      s_pcarry = pp;
+      s_nexact = 0;
+    }
+    __syncthreads();
+  }
+  for (uint32_t base = 0; base < E1; base += kLeaderBlock) {
+    const uint32_t e = base + threadIdx.x;
+    unsigned long long k = 0;
+    bool pn = false;
+    if (e >= 1 && e < E1) k = key_of(b.epoch_group[e], pn);
+    uint32_t pv = pn ? 1u : 0u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {             // inclusive prefix max / or inside the wave
+      const unsigned long long u = __shfl_up(k, o);
+      const uint32_t q = (uint32_t)__shfl_up((int)pv, o);
+      if (lane_id() >= o) { k = u > k ? u : k; pv |= q; }
+    }
+    __syncthreads();
+    if (lane_id() == 63) { s_w[wave_id()] = k; s_p[wave_id()] = pv; }
+    __syncthreads();
+    unsigned long long off = s_carry;
+    uint32_t poff = s_pcarry;
+    for (int w = 0; w < wave_id(); ++w) { off = s_w[w] > off ? s_w[w] : off; poff |= s_p[w]; }
+    k = off > k ? off : k;
+    pv |= poff;
+    if (e < E1) {
+      int32_t leader = -1;
+      if (!pv && k) {
+        const uint32_t g = 0x7FFFFFFFu - (uint32_t)(k & 0x7FFFFFFFull);
+        leader = (int32_t)g;
+        if (gr.status_scheduled[g] >= gr.min_member[g]) {          // the tie rule may hand over: fold this epoch exactly
+          const uint32_t at = atomicAdd(&s_nexact, 1u);
+          if (at < 64) s_exact[at] = e;
+        }
+      }
+      b.leader_epoch[e] = leader;
+      b.panic_epoch[e] = pv ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == kLeaderBlock - 1) { s_carry = k; s_pcarry = pv; }
+    __syncthreads();
+  }
+  const uint32_t nex = s_nexact;
+  if (nex > 64) {                                   // pathological: every epoch exactly
+    for (uint32_t e = 0; e < E1; ++e) { __syncthreads(); if (!b.panic_epoch[e]) leader_block(gr, b, e); }
+  } else {
+    for (uint32_t x = 0; x < nex; ++x) { __syncthreads(); leader_block(gr, b, s_exact[x]); }
   }
 }
 

@@ -109,7 +109,7 @@ struct BatchDev {
   unsigned long long* chunk_tot;   // [slots][nchunks][16] chunk totals of the two-level table scan
   uint32_t* chunk_kp;       // [slots][nchunks][16] per chunk: first row at which scalar key s is present
   uint32_t* blk_scratch;    // per-block summaries of the two-level pod scans
-  int64_t* gmax;            // [slot][ceil(mcap/64)][4] per 64-row group: max running sum per fixed lane (pruning)
+  int64_t* gmax;            // [slot][ceil(mcap/64)][LP] per 64-row group: max running sum per resource lane (pruning)
   // filter
   int64_t* fparams;         // [P][8]: R[4] = pod + maxSingle, M[4] = maxSingle  (fixed lanes)
   uint32_t* fflags;         // [P] bit0 scalar_block (case 2 impossible), bit1 leader_block, bits 8.. fl_code
@@ -140,8 +140,10 @@ struct BatchDev {
   unsigned long long* pair_firstq;// [P] at representatives: (~batch_seq << 32) | first pod of the pair with a scan query
   unsigned long long* first_reach64;  // [1] (~batch_seq << 32) | first pod that reaches findMaxPG
   unsigned long long* chunk_off;  // [slots][nchunks][16] exclusive prefix of chunk_tot (tables stay chunk-local)
-  int64_t* gmm8;            // [slot][ceil(mcap/64)][8] per 64-row group of the chunk-local table: max[4], min[4]
+  int64_t* gmm8;            // [slot][ceil(mcap/64)][2 LP] per 64-row group of the chunk-local table: max[LP], min[LP]
   uint32_t* fast_reject;    // [G] first rejected pod of the group (only maintained for BS_BATCH_COMMIT)
+  uint32_t* tticket;        // [slots] per-table tickets of the chunk-local table build (self-resetting)
+  uint32_t* epoch_group;    // [E+1] group captured at epoch e (e >= 1)
   // outputs
   uint8_t* pf_code;
   uint32_t* pf_first_k;
@@ -335,7 +337,8 @@ __device__ __forceinline__ void prepass_thread(const PodsDev& pods, const Groups
   if (i < gr.g) b.admit[i] = 0;
   if (i < 2 * prm.C + 1) b.needed[i] = 0;
   if (i == 0) {
-    *b.qcount = 0;
+    b.qcount[0] = 0;
+    b.qcount[1] = 0;
     if (no_capture) *b.nepochs = 1;
     b.nepochs[1] = BS_INF;
   }
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(kScanBlock) void k_epochs_b(PodsDev pods, GroupsDev
   uint32_t total;
   const uint32_t incl = block_incl_scan_add<uint32_t>(cap, lds, total);
   if (i < pods.p) b.epoch[i] = prev + incl;
-  if (cap) b.cap_epoch[gi] = prev + incl;
+  if (cap) { b.cap_epoch[gi] = prev + incl; b.epoch_group[prev + incl] = (uint32_t)gi; }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *b.nepochs = prev + total + 1;
 }
 
@@ -726,8 +729,12 @@ __device__ __forceinline__ void query_thread(const PodsDev& pods, const GroupsDe
         if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
       }
     }
+    // A first check (core.go:136-147) asks for the GROUP's pre-allocation against the group's class: every pod of the
+    // group that gets here derives the same query (the capture and the MinResources default precede findMaxPG), so the
+    // slot is the group in every mode: behind the class slots, or behind the per-pod slots.
     uint32_t slot = i;
-    if (prm.use_classes) slot = code == BS_PF_PASS_FIRST_FITS ? *b.kclass + (uint32_t)pods.group[i] : b.pclass[i];
+    if (code == BS_PF_PASS_FIRST_FITS) slot = (prm.use_classes ? *b.kclass : pods.p) + (uint32_t)pods.group[i];
+    else if (prm.use_classes) slot = b.pclass[i];
     int64_t* dst = b.qreq_s + (size_t)slot * prm.LP;
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
@@ -736,6 +743,14 @@ __device__ __forceinline__ void query_thread(const PodsDev& pods, const GroupsDe
     b.qtab_s[slot] = table;
     b.qpos[i] = slot;
     b.needed[table] = 1;
+  }
+  if (!prm.use_classes) {
+    // how many queries sit in per-pod slots and how many in group slots: the scan sizes its shares on the tiles that can be live
+    const unsigned long long hp = __ballot(has_q && code != BS_PF_PASS_FIRST_FITS), hg = __ballot(has_q && code == BS_PF_PASS_FIRST_FITS);
+    if (lane_id() == 0) {
+      if (hp) atomicAdd(&b.qcount[0], (uint32_t)__popcll(hp));
+      if (hg) atomicAdd(&b.qcount[1], (uint32_t)__popcll(hg));
+    }
   }
   if (prm.collect_stats) {
     const unsigned long long hq = __ballot(has_q);
@@ -832,9 +847,11 @@ __device__ __forceinline__ void tables_local_block(const NodesDev& nd, const Bat
   if (chunk == 0) {                    // rows of the first chunk are already final: their group maxima
     const uint32_t grp = k >> 6, ngroups = (prm.mcap + 63u) >> 6;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t mx = wave_max_i64(valid ? (int64_t)incl[j] : INT64_MIN);
-      if (lane_id() == 0 && (chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m) b.gmax[((size_t)slot * ngroups + grp) * 4 + j] = mx;
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+      if (j < L) {
+        const int64_t mx = wave_max_i64(valid ? (int64_t)incl[j] : INT64_MIN);
+        if (lane_id() == 0 && (chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m) b.gmax[((size_t)slot * ngroups + grp) * LP + j] = mx;
+      }
     }
   }
   // first row of this chunk at which key s joins the running sum; the fix-up pass (or, for a single
@@ -900,22 +917,18 @@ __device__ __forceinline__ void tables_fix_block(const NodesDev& nd, const Batch
   const uint32_t k = chunk * kTblChunk + threadIdx.x;
   const bool valid = k < nd.m;
   int64_t* row = b.tables + ((size_t)slot * prm.mcap + k) * LP;
-  int64_t fixed4[4] = {INT64_MIN, INT64_MIN, INT64_MIN, INT64_MIN};
-  if (valid) {
-    for (uint32_t j = 0; j < L; ++j) {
-      const int64_t v = (int64_t)((unsigned long long)row[j] + off[j]);
-      row[j] = v;
-      if (j < 4) fixed4[j] = v;
-    }
-  }
-  // per 64-row group: max of the running sum per fixed lane — lets k_scan skip groups no request can pass
+  // fix the rows and record, per 64-row group, the max of the running sum per resource lane — lets k_scan skip groups no
+  // request can pass
   const uint32_t grp = k >> 6, ngroups = (prm.mcap + 63u) >> 6;
-  if ((chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t mx = wave_max_i64(fixed4[j]);
-      if (lane_id() == 0) b.gmax[((size_t)slot * ngroups + grp) * 4 + j] = mx;
+  const bool grp_valid = (chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m;
+  for (uint32_t j = 0; j < L; ++j) {
+    int64_t v = INT64_MIN;
+    if (valid) {
+      v = (int64_t)((unsigned long long)row[j] + off[j]);
+      row[j] = v;
     }
+    const int64_t mx = wave_max_i64(v);
+    if (grp_valid && lane_id() == 0) b.gmax[((size_t)slot * ngroups + grp) * LP + j] = mx;
   }
 }
 __global__ __launch_bounds__(kTblChunk) void k_tables_fix(NodesDev nd, BatchDev b, BatchParams prm, const TableDesc* forced) {
@@ -1087,9 +1100,9 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   constexpr int U = 4;                           // rows per step: their LDS reads are issued together
   const int lane = lane_id();
   const uint32_t ngroups = (m + 63u) >> 6, gstride = (prm.mcap + 63u) >> 6;
-  int64_t rmin[4];
+  int64_t rmin[L];                               // smallest request of the tile per resource lane (INT64_MIN where some slot does not ask)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) rmin[j] = wave_min_i64(valid ? r[0][j] : INT64_MAX);
+  for (int j = 0; j < L; ++j) rmin[j] = wave_min_i64(valid ? r[0][j] : INT64_MAX);
 
   uint32_t myk[1] = {BS_INF};
   uint32_t seen = 0;
@@ -1106,21 +1119,11 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
     bool dead = true;
     const uint32_t g = c0 + (uint32_t)lane;
     if (g < ngroups) {
-      if constexpr (LOCAL) {
-        const int64_t* gm = b.gmm8 + ((size_t)slot * gstride + g) * 8;
-        const unsigned long long* of = b.chunk_off + ((size_t)slot * ((prm.mcap + kTblChunk - 1u) / kTblChunk) + (g >> 2)) * 16;
-        dead = false;
+      // (chunk-local tables: gmax already holds max + chunk offset, or INT64_MAX where that bound could wrap)
+      const int64_t* gm = b.gmax + ((size_t)slot * gstride + g) * LP;
+      dead = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          long long hi, lo;
-          const bool o1 = __builtin_saddll_overflow((long long)gm[j], (long long)of[j], &hi);
-          const bool o2 = __builtin_saddll_overflow((long long)gm[4 + j], (long long)of[j], &lo);
-          if (!o1 && !o2 && hi < rmin[j]) dead = true;
-        }
-      } else {
-        const int64_t* gm = b.gmax + ((size_t)slot * gstride + g) * 4;
-        dead = gm[0] < rmin[0] || gm[1] < rmin[1] || gm[2] < rmin[2] || gm[3] < rmin[3];
-      }
+      for (int j = 0; j < L; ++j) dead = dead || gm[j] < rmin[j];
     }
     unsigned long long live = __ballot(!dead);
     while (live) {
@@ -1221,19 +1224,30 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
                                           uint32_t ngroups_g, uint32_t tsplit, uint32_t bx, uint32_t nblocks, int64_t (*rows)[4 + S]) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
-  const uint32_t nslots = prm.use_classes ? __builtin_amdgcn_readfirstlane(*b.kclass) + ngroups_g : nslots_fixed;
+  // slots: [request classes | groups] or [pods | groups] (the group slots carry the first checks, core.go:136-147)
+  const uint32_t nslots = (prm.use_classes ? __builtin_amdgcn_readfirstlane(*b.kclass) : nslots_fixed) + ngroups_g;
   const uint32_t ntiles = (nslots + 63u) >> 6;
   if (!ntiles || !m) return;
+  // tiles that can hold a query: all of them with request classes; otherwise the per-pod slots only if some pod has a query
+  // of its own, the group slots only if some first check (core.go:136-147) was asked
+  uint32_t t_lo = 0, t_hi = ntiles;
+  if (!prm.use_classes && ngroups_g) {
+    const uint32_t np = __builtin_amdgcn_readfirstlane(b.qcount[0]), ng = __builtin_amdgcn_readfirstlane(b.qcount[1]);
+    if (np == 0) t_lo = nslots_fixed >> 6;
+    if (ng == 0) t_hi = (nslots_fixed + 63u) >> 6;
+    if (t_hi <= t_lo) return;
+  }
+  const uint32_t ntl = t_hi - t_lo;
   // tsplit > 1 (several tables in use): the distinct tables of a tile are dealt over tsplit waves as well
-  const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (nblocks * 4u) / (ntiles * tsplit)));
-  const uint32_t items = ntiles * tsplit * J;
+  const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (nblocks * 4u) / (ntl * tsplit)));
+  const uint32_t items = ntl * tsplit * J;
   const int lane = lane_id();
   for (uint32_t w = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()); w < items; w += nblocks * 4u) {
-    const uint32_t rest = w / ntiles, tile = w - rest * ntiles;
+    const uint32_t rest = w / ntl, tile = t_lo + (w - rest * ntl);
     const uint32_t share = rest / tsplit, ts = rest - share * tsplit;
     const uint32_t pos = tile * 64u + (uint32_t)lane;
     int32_t tab = pos < nslots ? b.qtab_s[pos] : -1;
-    if constexpr (LOCAL) {                       // fast path: a slot is live iff a pod of THIS batch wrote it
+    if (prm.stamp) {                             // fast path: a slot is live iff a pod of THIS batch wrote it
       if (pos < nslots && b.qstamp_s[pos] != prm.stamp) tab = -1;
     }
     unsigned long long todo = __ballot(tab >= 0);
@@ -1254,17 +1268,17 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
     while (todo) {
       const int32_t t0 = __builtin_amdgcn_readlane(tab, __ffsll((long long)todo) - 1);
       const bool member = tab == t0;
-      if (turn == ts) scan_core<S, LOCAL>(b, prm, m, LOCAL ? 0u : (uint32_t)t0, pos, member, r, qf, share, J, rows);
+      if (turn == ts) scan_core<S, LOCAL>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows);
       turn = turn + 1u == tsplit ? 0u : turn + 1u;
       todo &= ~__ballot(member);
     }
   }
 }
-template <int S>
+template <int S, bool LOCAL = false>
 __global__ __launch_bounds__(256) void k_scan(BatchDev b, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t nslots_fixed, uint32_t ngroups_g,
                                               uint32_t tsplit) {
   __shared__ int64_t s_rows[4][64][4 + S];
-  scan_loop<S>(b, prm, m, jcap, nslots_fixed, ngroups_g, tsplit, blockIdx.x, gridDim.x, s_rows[wave_id()]);
+  scan_loop<S, LOCAL>(b, prm, m, jcap, nslots_fixed, ngroups_g, tsplit, blockIdx.x, gridDim.x, s_rows[wave_id()]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1754,13 +1768,13 @@ __global__ __launch_bounds__(256) void k_filter(PodsDev pods, NodesDev nd, Batch
 // Node scan and Filter evaluation in ONE launch (class mode): both only need what k_query left behind and
 // are independent of each other, so the first `scan_blocks` blocks run the scan work loop and the rest the
 // Filter work loop — one launch boundary less on the critical path, and the two latency chains overlap.
-template <int S>
+template <int S, bool LOCAL = false>
 __global__ __launch_bounds__(256) void k_scan_filter(PodsDev pods, NodesDev nd, BatchDev b, BatchParams prm, uint32_t m, uint32_t jcap,
                                                      uint32_t nslots_fixed, uint32_t ngroups_g, uint32_t tsplit, uint32_t scan_blocks,
                                                      uint32_t filter_waves, uint32_t ustride) {
   __shared__ int64_t s_rows[4][64][4 + S];
   if (blockIdx.x < scan_blocks)
-    scan_loop<S>(b, prm, m, jcap, nslots_fixed, ngroups_g, tsplit, blockIdx.x, scan_blocks, s_rows[wave_id()]);
+    scan_loop<S, LOCAL>(b, prm, m, jcap, nslots_fixed, ngroups_g, tsplit, blockIdx.x, scan_blocks, s_rows[wave_id()]);
   else
     filter_loop<2>(pods, nd, b, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - scan_blocks, gridDim.x - scan_blocks);
 }
@@ -1809,24 +1823,19 @@ __device__ __forceinline__ void tally_block(const PodsDev& pods, const GroupsDev
       b.first_owner[gg] = BS_INF;
       b.first_reject[gg] = BS_INF;
       b.first_pod[gg] = BS_INF;
+      b.cap_epoch[gg] = (gr.flags[gg] & BS_GROUP_HAS_POD) ? 0u : BS_INF;     // what k_init would write (the batch was a what-if: flags unchanged)
     }
   }
   if (!do_ready) return;
   // publish, take a ticket (every wave drains its own atomics before the block-level hand-off)
+  // the counters are agent-scope atomics and drained (vmcnt) before the ticket; the last block reads them with agent-scope
+  // loads: no release / acquire fence (= an L2 write-back / invalidate per block on the 8-XCD part)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    *s_last = atomicAdd(&b.ticket[0], 1u) == nblocks - 1 ? 1u : 0u;
-  }
+  if (threadIdx.x == 0) *s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1 ? 1u : 0u;
   __syncthreads();
   if (!*s_last) return;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    b.ticket[0] = 0;
-  }
-  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (uint32_t gg = threadIdx.x; gg < gr.g; gg += BLOCK) {
     const uint32_t have = gr.matched[gg] + __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     b.ready[gg] = have >= (uint32_t)(gr.min_member[gg] - gr.status_scheduled[gg]) ? 1 : 0;

@@ -119,7 +119,7 @@ struct bs_ctx {
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
   DevBuf d_fl_bitmap, d_admit, d_ready;
   // fast path (bs_fast.hpp)
-  DevBuf d_gstat, d_ppair, d_pair_next, d_pair_firstq, d_first_reach, d_qstamp_s, d_chunk_off, d_gmm8, d_fast_reject;
+  DevBuf d_gstat, d_ppair, d_pair_next, d_pair_firstq, d_first_reach, d_qstamp_s, d_chunk_off, d_gmm8, d_fast_reject, d_tticket, d_epoch_group;
   bool pairs_ready = false;          // d_gstat / pairs match the loaded pods and G
   bool bitmap_valid = false;         // d_fl_bitmap holds the expanded rows of the last batch
   bool last_fast = false;
@@ -136,6 +136,7 @@ struct bs_ctx {
   uint32_t last_stages = 0, batch_seq = 0;
   bool batch_pending_finish = false;
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
+  uint32_t general_waves = 4096;     // scan grid cap of the general chain (tools/cold_sweep.py)
   bs_batch_stats stats{};
 
   // ---- timing
@@ -325,6 +326,8 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.chunk_off = c->d_chunk_off.as<unsigned long long>();
   b.gmm8 = c->d_gmm8.as<int64_t>();
   b.fast_reject = c->d_fast_reject.as<uint32_t>();
+  b.tticket = c->d_tticket.as<uint32_t>();
+  b.epoch_group = c->d_epoch_group.as<uint32_t>();
   uint8_t* ok = c->d_outpack.as<uint8_t>();
   b.pf_code = ok + c->off_pf_code;
   b.pf_first_k = reinterpret_cast<uint32_t*>(ok + c->off_pf_first_k);
@@ -355,6 +358,14 @@ BatchParams batch_params(const bs_ctx* c) {
   return p;
 }
 
+// reserve and, when the buffer was (re)allocated, fill it: stamped arrays must never start out as garbage
+int reserve_filled(bs_ctx* c, DevBuf& d, size_t bytes, int byte_value) {
+  const void* before = d.p;
+  HIPCHK(c, d.reserve(bytes));
+  if (d.p != before) HIPCHK(c, hipMemsetAsync(d.p, byte_value, d.cap, c->stream));
+  return BS_OK;
+}
+
 // (re)allocate table storage once classes and node capacity are known
 int ensure_tables(bs_ctx* c) {
   if (!c->have_nodes || !c->have_fit) return BS_OK;
@@ -364,10 +375,14 @@ int ensure_tables(bs_ctx* c) {
   HIPCHK(c, c->d_tables.reserve(bytes));
   HIPCHK(c, c->d_kp.reserve((size_t)slots * 16 * sizeof(uint32_t)));
   HIPCHK(c, c->d_chunk_tot.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
-  HIPCHK(c, c->d_gmax.reserve((size_t)slots * cdiv(c->Ncap, 64) * 4 * 8));
+  HIPCHK(c, c->d_gmax.reserve((size_t)slots * cdiv(c->Ncap, 64) * c->LP * 8));
   HIPCHK(c, c->d_chunk_kp.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 4));
   HIPCHK(c, c->d_chunk_off.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
-  HIPCHK(c, c->d_gmm8.reserve((size_t)slots * cdiv(c->Ncap, 64) * 8 * 8));
+  HIPCHK(c, c->d_gmm8.reserve((size_t)slots * cdiv(c->Ncap, 64) * 2 * c->LP * 8));
+  {
+    int rc = reserve_filled(c, c->d_tticket, (size_t)slots * 4, 0);
+    if (rc) return rc;
+  }
   HIPCHK(c, c->d_desc.reserve((size_t)slots * sizeof(TableDesc)));
   HIPCHK(c, c->d_needed.reserve((size_t)(2 * c->C + 1) * 4));
   HIPCHK(c, c->d_qcount.reserve(16));
@@ -437,24 +452,28 @@ int upload_fit(bs_ctx* c) {
 }
 
 template <int S>
-void launch_scan_s(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg, uint32_t nslots, uint32_t ng, uint32_t ts) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S>), grid, dim3(256), 0, c->stream, b, p, m, nseg, nslots, ng, ts);
+void launch_scan_s(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg, uint32_t nslots, uint32_t ng, uint32_t ts,
+                   bool local) {
+  if (local) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S, true>), grid, dim3(256), 0, c->stream, b, p, m, nseg, nslots, ng, ts);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan<S, false>), grid, dim3(256), 0, c->stream, b, p, m, nseg, nslots, ng, ts);
 }
-void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg, uint32_t nslots, uint32_t ng, uint32_t ts) {
+// local: the tables are chunk-local (k_tables_local_nofix); otherwise final (k_tables_fix ran)
+void launch_scan(bs_ctx* c, dim3 grid, const BatchDev& b, const BatchParams& p, uint32_t m, uint32_t nseg, uint32_t nslots, uint32_t ng, uint32_t ts,
+                 bool local = false) {
   switch (c->S) {
-    case 0: launch_scan_s<0>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 1: launch_scan_s<1>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 2: launch_scan_s<2>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 3: launch_scan_s<3>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 4: launch_scan_s<4>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 5: launch_scan_s<5>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 6: launch_scan_s<6>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 7: launch_scan_s<7>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 8: launch_scan_s<8>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 9: launch_scan_s<9>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 10: launch_scan_s<10>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    case 11: launch_scan_s<11>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
-    default: launch_scan_s<12>(c, grid, b, p, m, nseg, nslots, ng, ts); break;
+    case 0: launch_scan_s<0>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 1: launch_scan_s<1>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 2: launch_scan_s<2>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 3: launch_scan_s<3>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 4: launch_scan_s<4>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 5: launch_scan_s<5>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 6: launch_scan_s<6>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 7: launch_scan_s<7>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 8: launch_scan_s<8>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 9: launch_scan_s<9>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 10: launch_scan_s<10>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    case 11: launch_scan_s<11>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
+    default: launch_scan_s<12>(c, grid, b, p, m, nseg, nslots, ng, ts, local); break;
   }
 }
 
@@ -472,26 +491,43 @@ void launch_tables_local(bs_ctx* c, hipStream_t st, dim3 grid, const NodesDev& n
 
 template <int S>
 void launch_scan_filter_s(bs_ctx* c, uint32_t scan_blocks, uint32_t filter_blocks, const PodsDev& pd, const NodesDev& nd, const BatchDev& b,
-                          const BatchParams& p, uint32_t m, uint32_t jcap, uint32_t nslots, uint32_t ng, uint32_t ts) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_filter<S>), dim3(scan_blocks + filter_blocks), dim3(256), 0, c->stream, pd, nd, b, p, m, jcap, nslots, ng,
-                     ts, scan_blocks, c->filter_waves, c->filter_slots_cap);
+                          const BatchParams& p, uint32_t m, uint32_t jcap, uint32_t nslots, uint32_t ng, uint32_t ts, bool local) {
+  if (local)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_filter<S, true>), dim3(scan_blocks + filter_blocks), dim3(256), 0, c->stream, pd, nd, b, p, m, jcap, nslots,
+                       ng, ts, scan_blocks, c->filter_waves, c->filter_slots_cap);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_filter<S, false>), dim3(scan_blocks + filter_blocks), dim3(256), 0, c->stream, pd, nd, b, p, m, jcap, nslots,
+                       ng, ts, scan_blocks, c->filter_waves, c->filter_slots_cap);
 }
 void launch_scan_filter(bs_ctx* c, uint32_t scan_blocks, uint32_t filter_blocks, const PodsDev& pd, const NodesDev& nd, const BatchDev& b,
-                        const BatchParams& p, uint32_t m, uint32_t jcap, uint32_t nslots, uint32_t ng, uint32_t ts) {
+                        const BatchParams& p, uint32_t m, uint32_t jcap, uint32_t nslots, uint32_t ng, uint32_t ts, bool local) {
   switch (c->S) {
-    case 0: launch_scan_filter_s<0>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 1: launch_scan_filter_s<1>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 2: launch_scan_filter_s<2>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 3: launch_scan_filter_s<3>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 4: launch_scan_filter_s<4>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 5: launch_scan_filter_s<5>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 6: launch_scan_filter_s<6>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 7: launch_scan_filter_s<7>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 8: launch_scan_filter_s<8>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 9: launch_scan_filter_s<9>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 10: launch_scan_filter_s<10>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    case 11: launch_scan_filter_s<11>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
-    default: launch_scan_filter_s<12>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts); break;
+    case 0: launch_scan_filter_s<0>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 1: launch_scan_filter_s<1>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 2: launch_scan_filter_s<2>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 3: launch_scan_filter_s<3>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 4: launch_scan_filter_s<4>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 5: launch_scan_filter_s<5>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 6: launch_scan_filter_s<6>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 7: launch_scan_filter_s<7>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 8: launch_scan_filter_s<8>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 9: launch_scan_filter_s<9>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 10: launch_scan_filter_s<10>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    case 11: launch_scan_filter_s<11>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+    default: launch_scan_filter_s<12>(c, scan_blocks, filter_blocks, pd, nd, b, p, m, jcap, nslots, ng, ts, local); break;
+  }
+}
+
+void launch_tables_nofix(bs_ctx* c, dim3 grid, const NodesDev& nd, const BatchDev& b, const BatchParams& p, uint32_t nchunks) {
+  const dim3 tb(kTblChunk);
+  const uint32_t cs = cdiv(c->Ncap, 256), gs = cdiv(c->Ncap, 64);
+  switch (c->S <= 4 ? (int)c->S : -1) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local_nofix<0>), grid, tb, 0, c->stream, nd, b, p, nchunks, cs, gs); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local_nofix<1>), grid, tb, 0, c->stream, nd, b, p, nchunks, cs, gs); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local_nofix<2>), grid, tb, 0, c->stream, nd, b, p, nchunks, cs, gs); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local_nofix<3>), grid, tb, 0, c->stream, nd, b, p, nchunks, cs, gs); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local_nofix<4>), grid, tb, 0, c->stream, nd, b, p, nchunks, cs, gs); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables_local_nofix<-1>), grid, tb, 0, c->stream, nd, b, p, nchunks, cs, gs); break;
   }
 }
 
@@ -549,7 +585,7 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
   b2.kp = b.kp + (size_t)slot * 16;
   b2.desc = b.desc + slot;
   b2.chunk_tot = b.chunk_tot + (size_t)slot * cdiv(c->Ncap, 256) * 16;
-  b2.gmax = b.gmax + (size_t)slot * cdiv(c->Ncap, 64) * 4;
+  b2.gmax = b.gmax + (size_t)slot * cdiv(c->Ncap, 64) * p.LP;
   b2.chunk_kp = b.chunk_kp + (size_t)slot * cdiv(c->Ncap, 256) * 16;
   const TableDesc* forced = b.desc + slot;
   launch_tables_local(c, c->stream, dim3(1, nchunks), nodes_dev(c), b2, p, forced);
@@ -615,14 +651,6 @@ int resolve_pods(bs_ctx* c) {
   if (rc) return rc;
   c->kinfo_pending = false;
   c->h_K = (uint32_t)c->h_info[4];
-  return BS_OK;
-}
-
-// reserve and, when the buffer was (re)allocated, fill it: stamped arrays must never start out as garbage
-int reserve_filled(bs_ctx* c, DevBuf& d, size_t bytes, int byte_value) {
-  const void* before = d.p;
-  HIPCHK(c, d.reserve(bytes));
-  if (d.p != before) HIPCHK(c, hipMemsetAsync(d.p, byte_value, d.cap, c->stream));
   return BS_OK;
 }
 
@@ -743,7 +771,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) { c->early_filter_min = std::strtoull(e, nullptr, 10); c->early_forced = 1; }
   if (const char* e = std::getenv("BS_SCAN_SHARE")) c->scan_share_override = (uint32_t)std::max(0, std::atoi(e));
-  if (const char* e = std::getenv("BS_TARGET_WAVES")) c->target_waves = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BS_TARGET_WAVES")) { c->target_waves = std::max(1, std::atoi(e)); c->general_waves = c->target_waves; }
   if (const char* e = std::getenv("BS_FILTER_WAVES")) c->filter_waves = std::max(1, std::atoi(e));
   *out = c;
   return BS_OK;
@@ -1078,6 +1106,7 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   rc = ensure_stage(c, std::max(c->podpack_bytes, c->outpack_bytes));
   if (rc) return rc;
   HIPCHK(c, c->d_epoch.reserve(n * 4));
+  HIPCHK(c, c->d_epoch_group.reserve((n + 2) * 4));
   HIPCHK(c, c->d_tcode.reserve(n));
   HIPCHK(c, c->d_stage.reserve(n));
   HIPCHK(c, c->d_leader_raw.reserve(n * 4));
@@ -1242,7 +1271,8 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   bt.chunk_tot = b.chunk_tot + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
   bt.chunk_kp = b.chunk_kp + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
   bt.chunk_off = b.chunk_off + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
-  bt.gmm8 = b.gmm8 + (size_t)side_slot * cdiv(c->Ncap, 64) * 8;
+  bt.gmm8 = b.gmm8 + (size_t)side_slot * cdiv(c->Ncap, 64) * 2 * prm.LP;
+  bt.gmax = b.gmax + (size_t)side_slot * cdiv(c->Ncap, 64) * prm.LP;
   const TableDesc* forced = b.desc + side_slot;
   const int ts = c->S <= 4 ? (int)c->S : -1;
   if (commit && G) HIPCHK(c, hipMemsetAsync(c->d_fast_reject.p, 0xFF, (size_t)G * 4, c->stream));
@@ -1345,9 +1375,11 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   BatchParams prm = batch_params(c);
   prm.run_filter = run_filter;
   const uint32_t tiles_est = cdiv(std::max<uint32_t>(P, 1), 64);
-  const uint32_t pairs_est = cdiv(tiles_est, 2);
-  // J waves share the live 64-row groups of one tile pair (k_scan deals them round-robin)
-  const uint32_t nseg = pick_scan_share(c);
+  // J waves share the live 64-row groups of one tile (k_scan deals them round-robin).  Measured on the cold batches
+  // (tools/cold_sweep.py): almost every query ends inside the first one or two live groups, and every extra share is a
+  // whole extra wave that scans a group for nothing — 13 us at J = 1 against 40 us at J = 8 (cfg3 cold), 28 us against
+  // 319 us (cfg4 cold).  So: at most two shares, and a grid that just covers tiles x tables.
+  const uint32_t nseg = c->scan_share_override ? c->scan_share_override : 2u;
   const dim3 blk(256);
   prm.use_classes = use_classes ? 1u : 0u;
   prm.scan_slots_cap = scan_cap;
@@ -1357,8 +1389,8 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   const uint32_t side_slot = inline_tables ? (uint32_t)c->steady_table : 0u;
   prm.early_filter = early_filter ? 1u : 0u;
   const bool local_ready = c->nranks == 1 && !c->reduce_external;
-  // re-arming is only valid when the group minima were not also needed for capture epochs (cap_epoch is rewritten then)
-  const bool rearm = !captures_possible && !(stages & BS_BATCH_COMMIT);
+  // the tally's last pass re-arms the per-group minima and capture epochs for the next batch (saves k_init)
+  const bool rearm = !(stages & BS_BATCH_COMMIT);      // (a committing batch changes the group flags: k_init re-derives the capture epochs)
   // class mode without early Filter: k_query fills the Filter slots and ONE launch does node scan + Filter evaluation
   const bool fuse_filter = run_filter && use_classes && !early_filter && P && N && !c->no_fuse_filter;
   prm.fuse_filter = fuse_filter ? 1u : 0u;
@@ -1371,7 +1403,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     bt.tables = b.tables + (size_t)side_slot * prm.mcap * prm.LP;
     bt.kp = b.kp + (size_t)side_slot * 16;
     bt.chunk_tot = b.chunk_tot + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
-    bt.gmax = b.gmax + (size_t)side_slot * cdiv(c->Ncap, 64) * 4;
+    bt.gmax = b.gmax + (size_t)side_slot * cdiv(c->Ncap, 64) * prm.LP;
     bt.chunk_kp = b.chunk_kp + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
     forced = b.desc + side_slot;
   }
@@ -1405,8 +1437,8 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   c->scratch_armed = false;
   c->side_ready = false;
   if (captures_possible) {
-    const uint32_t max_epochs = std::min(c->n_uncaptured, P) + 1;
-    TIMED(c, BS_KERNEL_LEADER, hipLaunchKernelGGL(k_leader, dim3(max_epochs), dim3(kLeaderBlock), 0, c->stream, gr, b));
+    // findMaxPG for every capture epoch: one block, prefix maximum over the epochs (k_leader_scan)
+    TIMED(c, BS_KERNEL_LEADER, hipLaunchKernelGGL(k_leader_scan, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b));
     launches++;
   }
   // ---- decisions that need no node scan, request vectors, scan tiles
@@ -1455,26 +1487,28 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   // ---- running-sum tables of the (class, percent) pairs some query uses
   if (c->M && P) {
     if (!inline_tables) {
-      TIMED(c, BS_KERNEL_TABLES, {
-        launch_tables_local(c, c->stream, dim3(2 * C, nchunks), nd, b, prm, (const TableDesc*)nullptr);
-        if (nchunks > 1)
-          hipLaunchKernelGGL(k_tables_fix, dim3(2 * C, nchunks - 1), dim3(kTblChunk), 0, c->stream, nd, b, prm, (const TableDesc*)nullptr);
-      });
-      launches += nchunks > 1 ? 2 : 1;
+      // chunk-local running sums of every table in use; the scan adds the chunk offsets (no fix-up pass)
+      TIMED(c, BS_KERNEL_TABLES, launch_tables_nofix(c, dim3(2 * C, nchunks), nd, b, prm, nchunks));
+      launches++;
     }
-    const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, (pairs_est + 2 * C) * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
-    const uint32_t tsplit = inline_tables ? 1u : std::min<uint32_t>(16, 2 * C);
+    const bool local = !inline_tables;
+    const uint32_t tsplit = inline_tables ? 1u : std::min<uint32_t>(32, 2 * C);
+    // the kernel finds out which tiles can be live (per-pod slots, group slots) and deals shares accordingly; the grid
+    // only has to offer about one wave per (tile that can be live, table split): the smaller of the two slot ranges is a
+    // good guess for cold batches (only first checks) and warm ones (only reservation checks) alike
+    const uint32_t tiles_guess = std::max(cdiv(G, 64), std::min(tiles_est, cdiv(G, 64) * 4)) + 1;
+    const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->general_waves, tiles_guess * tsplit * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
     if (fuse_filter) {
       const uint32_t fblocks = cdiv(std::min<uint32_t>(c->filter_waves, 2 * cdiv(P, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4);
-      TIMED(c, BS_KERNEL_SCAN, launch_scan_filter(c, scan_blocks, fblocks, pd, nd, b, prm, c->M, nseg, P, G, tsplit));
+      TIMED(c, BS_KERNEL_SCAN, launch_scan_filter(c, scan_blocks, fblocks, pd, nd, b, prm, c->M, nseg, P, G, tsplit, local));
     } else {
-      TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg, P, G, tsplit));
+      TIMED(c, BS_KERNEL_SCAN, launch_scan(c, dim3(scan_blocks), b, prm, c->M, nseg, P, G, tsplit, local));
     }
     launches++;
   } else if (fuse_filter) {
     // no schedulable node: nothing to scan, Filter still has its slots to evaluate
     const uint32_t fblocks = cdiv(std::min<uint32_t>(c->filter_waves, 2 * cdiv(P, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4);
-    TIMED(c, BS_KERNEL_SCAN, launch_scan_filter(c, 1u, fblocks, pd, nd, b, prm, 0u, 1u, P, G, 1u));
+    TIMED(c, BS_KERNEL_SCAN, launch_scan_filter(c, 1u, fblocks, pd, nd, b, prm, 0u, 1u, P, G, 1u, false));
     launches++;
   }
   // ---- REJECT codes, deny replay, stale-leader propagation, Filter parameters

@@ -63,8 +63,11 @@ def _check(res, mode, bsa, soa, orc, config, scenario, seed, pods, groups, exp):
 
 
 def _gpus():
-    import torch
-    return torch.cuda.device_count()
+    # NOT through torch: importing it here would put a second HIP runtime next to the one libbsched.so / librccl.so use in this process
+    import ctypes
+    n = ctypes.c_int(0)
+    hip = ctypes.CDLL("libamdhip64.so")
+    return int(n.value) if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
 
 
 @pytest.mark.parametrize("mode,world", [("gloo-partitioned", 2), ("gloo-partitioned", 3), ("native-replicated", 2), ("native-partitioned", 2)])
