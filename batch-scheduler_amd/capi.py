@@ -22,7 +22,7 @@ KERNEL_PREPASS, KERNEL_LEADER, KERNEL_QUERY, KERNEL_TABLES, KERNEL_SCAN, KERNEL_
 # every symbol include/bsched.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "bs_abi_version", "bs_strerror", "bs_last_error", "bs_create", "bs_destroy",
-    "bs_nodes_load", "bs_fit_load", "bs_fit_build", "bs_fit_read", "bs_groups_load", "bs_groups_read", "bs_groups_apply", "bs_pods_load",
+    "bs_nodes_load", "bs_fit_load", "bs_fit_build", "bs_fit_read", "bs_groups_load", "bs_groups_read", "bs_groups_apply", "bs_pods_map", "bs_pods_load",
     "bs_nodes_apply", "bs_nodes_count",
     "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
     "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_filter_rows_count",
@@ -95,6 +95,7 @@ def load_library(path: str | None = None):
     L.bs_groups_apply.argtypes = [vp, P(soa.GroupDelta), u32]
     L.bs_filter_rows_count.argtypes = [vp, P(u32)]
     L.bs_pods_load.argtypes = [vp, P(soa.PodsStruct)]
+    L.bs_pods_map.argtypes = [vp, u32, P(soa.PodsStruct)]
     L.bs_nodes_apply.argtypes = [vp, P(NodeDelta), u32]
     L.bs_nodes_count.argtypes = [vp, P(u32)]
     L.bs_cluster_fits.argtypes = [vp, u32, C.c_float, P(C.c_int64), u32, P(u8), P(u32)]
@@ -223,6 +224,28 @@ class Context:
         n = C.c_uint32(0)
         self._chk(self._lib.bs_filter_rows_count(self._h, C.byref(n)), "bs_filter_rows_count")
         return int(n.value)
+
+    def map_pods(self, p: int) -> soa.Pods:
+        """Zero-copy hand-over (bs_pods_map): a Pods whose arrays ARE the library's pinned upload buffer.  Fill them in
+        place and pass the object to load_pods — no packing copy.  Valid until the next map_pods / load_pods."""
+        st = soa.PodsStruct()
+        self._chk(self._lib.bs_pods_map(self._h, p, C.byref(st)), "bs_pods_map")
+
+        def view(ptr, ctype, dtype, shape):
+            n = int(np.prod(shape))
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype * n)).contents).view(dtype).reshape(shape)
+        pods = soa.Pods.__new__(soa.Pods)
+        pods.group = view(st.group, C.c_int32, np.int32, (p,))
+        pods.req = view(st.req, C.c_int64, np.int64, (self.L, p))
+        pods.req_present = view(st.req_present, C.c_uint32, np.uint32, (p,))
+        pods.cls = view(st.cls, C.c_uint32, np.uint32, (p,))
+        pods.owner = view(st.owner, C.c_uint64, np.uint64, (p,))
+        pods.flags = view(st.flags, C.c_uint8, np.uint8, (p,))
+        return pods
+
+    def apply_group_deltas_raw(self, arr, n: int):
+        """bs_groups_apply with a prebuilt (GroupDelta * n) array (no per-call marshalling)"""
+        self._chk(self._lib.bs_groups_apply(self._h, arr, n), "bs_groups_apply")
 
     def load_pods(self, pods: soa.Pods):
         assert pods.req.shape[0] == self.L

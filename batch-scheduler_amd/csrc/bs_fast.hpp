@@ -433,11 +433,11 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     const bool reached = i >= first_reach;
     const int32_t leader = reached ? b.leader_epoch[0] : prm.sop_leader0;
     b.pf_leader[i] = leader;
+    if (prm.host_tag) { b.h_pf_code[i] = code; b.h_pf_first_k[i] = fk; b.h_pf_leader[i] = leader; }
     const bool pass = code != BS_PF_NOT_OWNED && BS_PF_IS_PASS(code);
-    uint32_t feasible = 1u;
+    uint32_t feasible = 1u, slot = 0;
     uint8_t fl = BS_FL_NOT_RUN;
     if (prm.run_filter) {
-      uint32_t slot = 0;
       if (pass) {
         if (gi == BS_POD_NOT_GROUPED) fl = BS_FL_PASS_NOT_GROUPED;                         // core.go:171-174
         else if (gi < 0 || (uint32_t)gi >= gr.g) fl = BS_FL_ERR_PG_NOT_FOUND;              // :177-180
@@ -453,11 +453,15 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     }
     b.fl_code[i] = fl;
     b.fflags[i] = (uint32_t)fl << 8;
+    if (prm.host_tag) { b.h_fl_code[i] = fl; b.h_fl_feasible[i] = prm.run_filter ? feasible : 0u; b.h_fl_slot[i] = slot; }
     if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) { admit = true; ag = (uint32_t)gi; }
   }
-  if (!prm.do_tally) return;
-  wave_aggregated_inc(b.admit, ag, admit);
-  if (!prm.do_ready) return;
+  if (prm.host_tag && prm.run_filter) {             // per-row feasible counts of the slots in use
+    const uint32_t U = min(2u * *b.kclass, b.hstride);
+    for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
+  }
+  if (prm.do_tally) wave_aggregated_inc(b.admit, ag, admit);
+  if (!prm.do_ready && !prm.host_tag) return;
   // the admit counters are agent-scope atomics (performed at the coherence point, returned before vmcnt drains): a drained
   // ticket orders them, the last block reads them back with agent-scope loads — no L2 write-back / invalidate per block
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -467,8 +471,17 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
   if (!s_last) return;
   if (threadIdx.x == 0) __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (uint32_t gg = threadIdx.x; gg < gr.g; gg += 256u) {
-    const uint32_t have = gr.matched[gg] + __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    b.ready[gg] = have >= (uint32_t)(gr.min_member[gg] - gr.status_scheduled[gg]) ? 1 : 0;
+    const uint32_t ad = __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint8_t rd = (gr.matched[gg] + ad) >= (uint32_t)(gr.min_member[gg] - gr.status_scheduled[gg]) ? 1 : 0;
+    if (prm.do_ready) b.ready[gg] = rd;
+    if (prm.host_tag) { b.h_admit[gg] = ad; b.h_ready[gg] = rd; }
+  }
+  if (prm.host_tag) {
+    // every block drained its host writes before taking its ticket; this block's are drained here; then the completion
+    // word goes out with system-scope release — the host polls it (bs_batch_read) instead of waiting on the stream
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(b.h_tag, prm.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

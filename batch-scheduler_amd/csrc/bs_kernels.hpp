@@ -142,6 +142,9 @@ struct BatchDev {
   unsigned long long* chunk_off;  // [slots][nchunks][16] exclusive prefix of chunk_tot (tables stay chunk-local)
   int64_t* gmm8;            // [slot][ceil(mcap/64)][2 LP] per 64-row group of the chunk-local table: max[LP], min[LP]
   uint32_t* fast_reject;    // [G] first rejected pod of the group (only maintained for BS_BATCH_COMMIT)
+  // BS_BATCH_HOST_RESULTS: mirrors of the results in pinned host memory, written by the last launch (null = off)
+  uint8_t* h_pf_code; uint32_t* h_pf_first_k; int32_t* h_pf_leader; uint8_t* h_fl_code; uint32_t* h_fl_feasible; uint32_t* h_fl_slot;
+  uint32_t* h_admit; uint8_t* h_ready; uint32_t* h_feas; uint64_t* h_rows; int32_t* h_tag; uint32_t hstride;
   uint32_t* tticket;        // [slots] per-table tickets of the chunk-local table build (self-resetting)
   uint32_t* epoch_group;    // [E+1] group captured at epoch e (e >= 1)
   // outputs
@@ -172,6 +175,7 @@ struct BatchParams {
   uint32_t seq_inv;            // fast path: ~batch sequence number (64-bit atomicMin keys: a newer batch always wins)
   uint32_t commit;             // fast path: keep fast_reject for k_fast_commit
   uint32_t do_tally, do_ready; // fast path: stages of the final launch
+  int32_t host_tag;            // BS_BATCH_HOST_RESULTS: completion word the final launch publishes (0 = off)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1721,6 +1725,7 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
         const unsigned long long word = ((unsigned long long)vhi[nb] << 32) | vlo[nb];
         cnt += (uint32_t)__popcll(word);
         b.fu_bitmap[(size_t)(w + nb) * ustride + p0 + lane] = word;
+        if (b.h_rows && p0 + (uint32_t)lane < b.hstride) b.h_rows[(size_t)(w + nb) * b.hstride + p0 + lane] = word;   // latency mode: the row goes home as well
       }
     }
 #pragma unroll

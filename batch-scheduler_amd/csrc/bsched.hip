@@ -103,6 +103,7 @@ struct bs_ctx {
   bool stage_busy = false;
   bool last_use_classes = false;
   size_t h_stage_cap = 0;
+  uint32_t map_p = 0;                // pods the staging buffer is currently mapped for (bs_pods_map), 0 = not mapped
   size_t off_pgroup = 0, off_preq = 0, off_ppres = 0, off_pcls = 0, off_powner = 0, off_pflags = 0, podpack_bytes = 0;
   size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, off_fl_slot = 0, off_admit = 0, off_ready = 0, outpack_bytes = 0;
 
@@ -124,6 +125,15 @@ struct bs_ctx {
   bool bitmap_valid = false;         // d_fl_bitmap holds the expanded rows of the last batch
   bool last_fast = false;
   bool batch_since_pods = false;     // a batch ran over the loaded pods (its slot mode is the one the rows have)
+  // result staging (bs_batch_read) and, in latency mode, the pinned result pack the last launch writes itself
+  void* h_rstage = nullptr;
+  size_t h_rstage_cap = 0;
+  uint8_t* h_hout = nullptr;         // [outpack layout | feas[hstride] | tag]
+  uint64_t* h_hrows = nullptr;       // [W + 1][hstride]
+  size_t h_hout_cap = 0, h_hrows_cap = 0, off_hfeas = 0, off_htag = 0;
+  uint32_t hstride = 0;
+  int32_t host_tag = 0;
+  bool last_host_out = false;
   uint32_t no_fast = 0;
   // single-query scratch
   DevBuf d_sq;
@@ -626,8 +636,8 @@ int analyse_groups(bs_ctx* c, bool rearm_scratch = true, const bs_group_delta* d
 
 // Wait until the kernel that wrote h_info[tag_at] = tag has done so (it writes pinned host memory directly).  By
 // the time anybody asks, the kernel has normally finished long ago and this is one load.
-int wait_host_tag(bs_ctx* c, int tag_at, int32_t tag) {
-  volatile int32_t* info = c->h_info;
+int wait_host_tag(bs_ctx* c, int tag_at, int32_t tag, const int32_t* base = nullptr) {
+  volatile const int32_t* info = base ? base : c->h_info;
   for (uint32_t spin = 0; info[tag_at] != tag; ++spin) {
     if (spin == 2000) (void)hipStreamQuery(c->stream);                    // make sure the launch has left the host
     if (spin > 20000000u) { HIPCHK(c, hipStreamSynchronize(c->stream)); if (info[tag_at] != tag) { c->last_error = "host info tag never arrived"; return BS_ERR_HIP; } }
@@ -787,6 +797,9 @@ int bs_destroy(bs_ctx* c) {
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->ev_gstage) (void)hipEventDestroy(c->ev_gstage);
   if (c->h_info) (void)hipHostFree(c->h_info);
+  if (c->h_rstage) (void)hipHostFree(c->h_rstage);
+  if (c->h_hout) (void)hipHostFree(c->h_hout);
+  if (c->h_hrows) (void)hipHostFree(c->h_hrows);
   if (c->h_gstage) (void)hipHostFree(c->h_gstage);
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   if (c->ev_query) (void)hipEventDestroy(c->ev_query);
@@ -1083,14 +1096,8 @@ static int ensure_stage(bs_ctx* c, size_t bytes) {
   c->h_stage_cap = bytes;
   return BS_OK;
 }
-int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
-  if (!c || !pods) return BS_ERR_INVALID;
-  int rc = use_device(c);
-  if (rc) return rc;
-  const uint32_t P = pods->p, L = c->L;
-  if (P && (!pods->group || !pods->req || !pods->req_present || !pods->cls || !pods->owner || !pods->flags)) return BS_ERR_INVALID;
-  const size_t n = std::max<uint32_t>(P, 1);
-  // pod arrays: one allocation, one transfer
+static void pods_layout(bs_ctx* c, uint32_t P) {
+  const size_t n = std::max<uint32_t>(P, 1), L = c->L;
   size_t o = 0;
   c->off_pgroup = o; o = align256(o + n * 4);
   c->off_preq = o; o = align256(o + n * L * 8);
@@ -1099,12 +1106,47 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   c->off_powner = o; o = align256(o + n * 8);
   c->off_pflags = o; o = align256(o + n);
   c->podpack_bytes = o;
-  HIPCHK(c, c->d_podpack.reserve(o));
+}
+
+int bs_pods_map(bs_ctx* c, uint32_t p, bs_pods_soa* view) {
+  if (!c || !view || !p) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  pods_layout(c, p);
+  rc = ensure_stage(c, c->podpack_bytes);            // waits until the previous upload has left the buffer
+  if (rc) return rc;
+  uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
+  view->p = p;
+  view->group = reinterpret_cast<const int32_t*>(st + c->off_pgroup);
+  view->req = reinterpret_cast<const int64_t*>(st + c->off_preq);
+  view->req_present = reinterpret_cast<const uint32_t*>(st + c->off_ppres);
+  view->cls = reinterpret_cast<const uint32_t*>(st + c->off_pcls);
+  view->owner = reinterpret_cast<const uint64_t*>(st + c->off_powner);
+  view->flags = st + c->off_pflags;
+  c->map_p = p;
+  return BS_OK;
+}
+
+int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
+  if (!c || !pods) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t P = pods->p, L = c->L;
+  if (P && (!pods->group || !pods->req || !pods->req_present || !pods->cls || !pods->owner || !pods->flags)) return BS_ERR_INVALID;
+  const size_t n = std::max<uint32_t>(P, 1);
+  // pod arrays: one allocation, one transfer
+  pods_layout(c, P);
+  HIPCHK(c, c->d_podpack.reserve(c->podpack_bytes));
   // per-pod outputs (+ the per-group ones): one allocation, one transfer back
   c->P = P;
   if ((rc = layout_out(c))) return rc;
-  rc = ensure_stage(c, std::max(c->podpack_bytes, c->outpack_bytes));
-  if (rc) return rc;
+  const bool mapped = P && c->h_stage && c->map_p == P && (const void*)pods->group == (const void*)((uint8_t*)c->h_stage + c->off_pgroup) &&
+                      (const void*)pods->req == (const void*)((uint8_t*)c->h_stage + c->off_preq);
+  if (!mapped) {
+    rc = ensure_stage(c, c->podpack_bytes);
+    if (rc) return rc;
+  }
+  c->map_p = 0;
   HIPCHK(c, c->d_epoch.reserve(n * 4));
   HIPCHK(c, c->d_epoch_group.reserve((n + 2) * 4));
   HIPCHK(c, c->d_tcode.reserve(n));
@@ -1134,12 +1176,14 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
     if (pods->group[i] >= 0) c->max_pod_cls = std::max(c->max_pod_cls, pods->cls[i]);
   if (P) {
     uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
-    std::memcpy(st + c->off_pgroup, pods->group, (size_t)P * 4);
-    std::memcpy(st + c->off_preq, pods->req, (size_t)P * L * 8);
-    std::memcpy(st + c->off_ppres, pods->req_present, (size_t)P * 4);
-    std::memcpy(st + c->off_pcls, pods->cls, (size_t)P * 4);
-    std::memcpy(st + c->off_powner, pods->owner, (size_t)P * 8);
-    std::memcpy(st + c->off_pflags, pods->flags, (size_t)P);
+    if (!mapped) {                                   // (bs_pods_map: the caller marshalled the queue in place)
+      std::memcpy(st + c->off_pgroup, pods->group, (size_t)P * 4);
+      std::memcpy(st + c->off_preq, pods->req, (size_t)P * L * 8);
+      std::memcpy(st + c->off_ppres, pods->req_present, (size_t)P * 4);
+      std::memcpy(st + c->off_pcls, pods->cls, (size_t)P * 4);
+      std::memcpy(st + c->off_powner, pods->owner, (size_t)P * 8);
+      std::memcpy(st + c->off_pflags, pods->flags, (size_t)P);
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_podpack.p, st, c->podpack_bytes, hipMemcpyHostToDevice, c->stream));
   }
   // request classes, per-group minima and (group, class) pairs of the pods: three launches behind the upload
@@ -1241,6 +1285,31 @@ static int reserve_slots(bs_ctx* c, bool run_filter) {
   return BS_OK;
 }
 
+// Latency mode (BS_BATCH_HOST_RESULTS): pinned, GPU-visible result pack the last launch writes itself.
+// Layout = the device result pack (layout_out) | feas[hstride] | completion word; rows [W + 1][hstride] beside it.
+static int ensure_hout(bs_ctx* c) {
+  const uint32_t hs = std::min<uint32_t>(c->filter_slots_cap, 1024u);
+  const size_t off_feas = align256(c->outpack_bytes), off_tag = off_feas + align256((size_t)hs * 4), need = off_tag + 256;
+  const size_t need_rows = (size_t)(cdiv(c->N, 64) + 1) * hs * 8;
+  if (need > c->h_hout_cap) {
+    if (c->h_hout) (void)hipHostFree(c->h_hout);
+    c->h_hout = nullptr; c->h_hout_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_hout, need, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_hout, 0, need);
+    c->h_hout_cap = need;
+  }
+  if (need_rows > c->h_hrows_cap) {
+    if (c->h_hrows) (void)hipHostFree(c->h_hrows);
+    c->h_hrows = nullptr; c->h_hrows_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_hrows, need_rows, hipHostMallocMapped | hipHostMallocCoherent));
+    c->h_hrows_cap = need_rows;
+  }
+  c->hstride = hs;
+  c->off_hfeas = off_feas;
+  c->off_htag = off_tag;
+  return BS_OK;
+}
+
 // The steady-state chain (bs_fast.hpp): three launches, nothing reset, no wait.
 static int run_fast(bs_ctx* c, uint32_t stages) {
   int rc;
@@ -1263,6 +1332,27 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   prm.commit = commit ? 1u : 0u;
   prm.do_tally = (stages & BS_STAGE_TALLY) ? 1u : 0u;
   prm.do_ready = (prm.do_tally && c->nranks == 1 && !c->reduce_external) ? 1u : 0u;
+  // latency mode: the final launch mirrors every result into pinned host memory and publishes a completion word
+  const bool host_out = (stages & BS_BATCH_HOST_RESULTS) && c->nranks == 1 && !c->reduce_external && !c->ext_admit && !commit;
+  c->last_host_out = host_out;
+  if (host_out) {
+    if ((rc = ensure_hout(c))) return rc;
+    c->host_tag = c->host_tag == 0x7FFFFFFF ? 1 : c->host_tag + 1;
+    prm.host_tag = c->host_tag;
+    uint8_t* h = c->h_hout;
+    b.h_pf_code = h + c->off_pf_code;
+    b.h_pf_first_k = reinterpret_cast<uint32_t*>(h + c->off_pf_first_k);
+    b.h_pf_leader = reinterpret_cast<int32_t*>(h + c->off_pf_leader);
+    b.h_fl_code = h + c->off_fl_code;
+    b.h_fl_feasible = reinterpret_cast<uint32_t*>(h + c->off_fl_feasible);
+    b.h_fl_slot = reinterpret_cast<uint32_t*>(h + c->off_fl_slot);
+    b.h_admit = reinterpret_cast<uint32_t*>(h + c->off_admit);
+    b.h_ready = h + c->off_ready;
+    b.h_feas = reinterpret_cast<uint32_t*>(h + c->off_hfeas);
+    b.h_tag = reinterpret_cast<int32_t*>(h + c->off_htag);
+    b.h_rows = run_filter ? c->h_hrows : nullptr;
+    b.hstride = c->hstride;
+  }
   const uint32_t side_slot = (uint32_t)c->steady_table;
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
   BatchDev bt = b;                                   // the batch view shifted to the steady table's slot (slot index 0)
@@ -1368,6 +1458,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   }
 
   // ---- general chain (first-pod captures, MinResources defaults, leader without matched pods, early Filter)
+  c->last_host_out = false;
   NodesDev nd = nodes_dev(c);
   GroupsDev gr = groups_dev(c);
   PodsDev pd = pods_dev(c);
@@ -1655,6 +1746,32 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
     LAUNCHCHK(c, BS_KERNEL_FILTER);
     c->bitmap_valid = true;
   }
+  // latency mode: the batch wrote its results into pinned host memory itself — poll the completion word, copy out
+  if (c->last_host_out && c->batch_since_pods && !(P && out->fl_bitmap && W && filtered)) {
+    rc = wait_host_tag(c, 0, c->host_tag, reinterpret_cast<const int32_t*>(c->h_hout + c->off_htag));
+    if (rc) return rc;
+    const uint8_t* st = c->h_hout;
+    if (want_pod) {
+      if (out->pf_code) std::memcpy(out->pf_code, st + c->off_pf_code, P);
+      if (out->pf_first_k) std::memcpy(out->pf_first_k, st + c->off_pf_first_k, (size_t)P * 4);
+      if (out->pf_leader) std::memcpy(out->pf_leader, st + c->off_pf_leader, (size_t)P * 4);
+      if (out->fl_code) std::memcpy(out->fl_code, st + c->off_fl_code, P);
+      if (out->fl_feasible) std::memcpy(out->fl_feasible, st + c->off_fl_feasible, (size_t)P * 4);
+      if (out->fl_slot) std::memcpy(out->fl_slot, st + c->off_fl_slot, (size_t)P * 4);
+    }
+    if (want_grp) {
+      if (out->group_admit) std::memcpy(out->group_admit, st + c->off_admit, (size_t)G * 4);
+      if (out->group_ready) std::memcpy(out->group_ready, st + c->off_ready, G);
+    }
+    if ((want_rows || want_rfeas) && nrows <= c->hstride) {
+      if (want_rfeas) std::memcpy(out->fl_rows_feasible, st + c->off_hfeas, (size_t)nrows * 4);
+      if (want_rows)
+        for (uint32_t w = 0; w < W; ++w) std::memcpy(out->fl_rows + (size_t)w * out->fl_rows_cap, c->h_hrows + (size_t)w * c->hstride, (size_t)nrows * 8);
+      return BS_OK;
+    }
+    if (!(want_rows || want_rfeas)) return BS_OK;
+    // more rows than the pinned window holds: the rows (only) take the copy path below
+  }
   // ONE wait and at most two copies: the result pack (per-pod arrays | admit | ready, contiguous on the device) and the
   // Filter rows with their feasible counts (a strided window of the slot bitmap; the counts sit behind its last row)
   const bool ext = c->ext_admit != nullptr;
@@ -1663,16 +1780,20 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   const size_t off_rows = off_xadmit + align256((size_t)G * 4);
   const bool any_rows = want_rows || want_rfeas;
   const size_t rows_h = any_rows ? (size_t)W + 1 : 0, rows_bytes = rows_h * nrows * 8;
-  rc = ensure_stage(c, std::max(c->podpack_bytes, off_rows + rows_bytes + 256));
-  if (rc) return rc;
-  uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
+  if (off_rows + rows_bytes + 256 > c->h_rstage_cap) {
+    if (c->h_rstage) (void)hipHostFree(c->h_rstage);
+    c->h_rstage = nullptr; c->h_rstage_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->h_rstage, off_rows + rows_bytes + 256, hipHostMallocDefault));
+    c->h_rstage_cap = off_rows + rows_bytes + 256;
+  }
+  uint8_t* st = reinterpret_cast<uint8_t*>(c->h_rstage);
   if (want_pod || want_grp) HIPCHK(c, hipMemcpyAsync(st, c->d_outpack.p, pack_bytes, hipMemcpyDeviceToHost, c->stream));
   if (want_grp && ext && out->group_admit) HIPCHK(c, hipMemcpyAsync(st + off_xadmit, c->ext_admit, (size_t)G * 4, hipMemcpyDeviceToHost, c->stream));
   if (any_rows)
     HIPCHK(c, hipMemcpy2DAsync(st + off_rows, (size_t)nrows * 8, c->d_fu_bitmap.p, (size_t)c->filter_slots_cap * 8, (size_t)nrows * 8, rows_h,
                                hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->stage_busy = false;
+  c->stage_busy = false;                             // (the stream is idle: the pod upload has left its buffer too)
   if (want_pod) {
     if (out->pf_code) std::memcpy(out->pf_code, st + c->off_pf_code, P);
     if (out->pf_first_k) std::memcpy(out->pf_first_k, st + c->off_pf_first_k, (size_t)P * 4);

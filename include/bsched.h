@@ -268,6 +268,12 @@ typedef struct bs_batch_out {
 #define BS_STAGE_ALL       0x7u
 #define BS_BATCH_COMMIT    0x100u /* persist first-pod capture / occupancy / deny into the ctx
                                      group state (bs_groups_read), as sequential PreFilter would */
+#define BS_BATCH_HOST_RESULTS 0x200u /* latency mode: the last launch of the batch also writes every result bs_batch_read
+                                     returns (per-pod arrays, admit, ready, Filter rows) straight into pinned host memory;
+                                     bs_batch_read then needs no device-to-host copy and no stream wait — it polls a
+                                     completion word.  Honoured on the steady-state chain of a single-rank context; a
+                                     no-op (results are copied as usual) elsewhere.  Costs the batch a few microseconds
+                                     of PCIe writes, so throughput runs leave it off. */
 
 /* ---- lifecycle ------------------------------------------------------------------- */
 uint32_t    bs_abi_version(void);
@@ -298,6 +304,10 @@ typedef struct bs_group_delta {
   uint32_t index, matched, status_scheduled, flags;
 } bs_group_delta;
 int bs_groups_apply(bs_ctx* ctx, const bs_group_delta* deltas, uint32_t count);
+/* Zero-copy hand-over: points `view` at the library's pinned upload buffer, sized for `p` pods, so that the caller can
+ * marshal the queue in place (cast the const away) and pass the SAME struct to bs_pods_load, which then skips its packing
+ * copy.  The pointers stay valid until the next bs_pods_map / bs_pods_load on the context. */
+int bs_pods_map(bs_ctx* ctx, uint32_t p, bs_pods_soa* view);
 int bs_pods_load(bs_ctx* ctx, const bs_pods_soa* pods);   /* also derives, on the device, what a batch needs from the pods
                                                               alone: request classes (equal (req lanes, req_present) <=> equal
                                                               class; a batch evaluates every distinct derived request once),

@@ -173,3 +173,39 @@ def test_filter_rows_capacity_and_rows_only_read(bsa, soa, orc):
         with pytest.raises(bsa.BsError) as e:
             ctx.read(out=small)
         assert e.value.status == -5 and int(small.fl_rows_n[0]) == int(out.fl_rows_n[0])
+
+
+@pytest.mark.parametrize("config,scenario,distinct", [("cfg2", "tail", False), ("cfg2", "warm", False), ("tiny", "warm", False), ("cfg2", "busy", True)])
+def test_latency_mode_zero_copy_in_and_out(config, scenario, distinct, bsa, soa, orc):
+    """bs_pods_map (the queue is marshalled straight into the pinned upload buffer) + BS_BATCH_HOST_RESULTS (the last launch
+    writes the results into pinned host memory, bs_batch_read polls a completion word: no copy, no stream wait) give the
+    same bits as the ordinary calls; `distinct`: more Filter rows than the pinned window holds -> the rows take the copy path."""
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
+    if distinct:
+        pods.req[0, :] += np.arange(pods.p, dtype=np.int64)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with bsa.Context(scalar_lanes=nodes.lanes - 4) as ctx:
+        ctx.load_nodes(nodes, fit)
+        ctx.load_groups(groups)
+        for it in range(4):
+            view = ctx.map_pods(pods.p)
+            for name in ("group", "req", "req_present", "cls", "owner", "flags"):
+                getattr(view, name)[...] = getattr(pods, name)
+            ctx.load_pods(view)
+            ctx.run(soa.STAGE_ALL | (soa.BATCH_HOST_RESULTS if it != 2 else 0))      # one ordinary batch in between
+            out = soa.BatchOut.alloc(pods.p, groups.g, nodes.n, bitmap=False, rows_cap=max(ctx.filter_rows_count(), 1))
+            ctx.read(out=out)
+            assert_batch_equal(out, exp, f"latency mode, cycle {it}", bitmap=False)
+            assert np.array_equal(out.bitmap_from_rows(), exp.fl_bitmap)
+            assert np.array_equal(out.fl_rows_feasible[out.fl_slot[out.fl_code == 3]], exp.fl_feasible[out.fl_code == 3])
+        # the expanded bitmap can still be had after a latency-mode batch
+        ctx.run(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
+        assert_batch_equal(ctx.read(), exp, "bitmap after latency mode")
+        st = ctx.stats(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
+        assert st["fast_path"] == 1
+    # a batch that is not on the steady-state chain ignores the flag
+    n2, f2, g2, p2, _ = bsa.synth.make("tiny", "cold")
+    e2 = orc.Sop(orc.Snapshot(n2, f2), g2).batch(p2, soa.STAGE_ALL)
+    with load_ctx(bsa, n2, f2, g2, p2) as ctx:
+        ctx.run(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
+        assert_batch_equal(ctx.read(), e2, "cold batch with the latency flag")

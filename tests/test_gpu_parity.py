@@ -339,15 +339,15 @@ def test_sharded_union_equals_single(bsa, soa, orc):
 
 def test_native_rccl_single_rank():
     """bs_comm_init + in-library ncclAllReduce at world size 1 (the only size one GPU allows), in its own process with a
-    deadline: ncclCommInitRank has been seen to take from 2 s to 160 s on these single-GPU boxes."""
+    deadline: ncclCommInitRank takes 2 s on a good day and has been seen to take 160 s on these single-GPU boxes."""
     import subprocess
     import sys
     env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", RCCL_MSCCL_ENABLE="0", RCCL_MSCCLPP_ENABLE="0", NCCL_IB_DISABLE="1")
     try:
         res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_single_worker.py")], env=env,
-                             capture_output=True, text=True, timeout=75)
+                             capture_output=True, text=True, timeout=40)
     except subprocess.TimeoutExpired:
-        pytest.skip("RCCL bootstrap (ncclCommInitRank, 1 rank) did not finish within 75 s on this box")
+        pytest.skip("RCCL bootstrap (ncclCommInitRank, 1 rank) did not finish within 40 s on this box")
     assert res.returncode == 0 and "RCCL_SINGLE_OK" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
 
 
