@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "bs_nodes_load", "bs_fit_load", "bs_fit_build", "bs_fit_read", "bs_groups_load", "bs_groups_read", "bs_groups_apply", "bs_pods_map", "bs_pods_load",
     "bs_nodes_apply", "bs_nodes_count",
     "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
-    "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_filter_rows_count",
+    "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_filter_rows_count", "bs_queue_order_load", "bs_queue_sort",
     "bs_shard_set", "bs_reduce_external", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
     "bs_timing_reset", "bs_timing_get", "bs_kernel_name", "bs_batch_stats_get",
 ]
@@ -96,6 +96,8 @@ def load_library(path: str | None = None):
     L.bs_filter_rows_count.argtypes = [vp, P(u32)]
     L.bs_pods_load.argtypes = [vp, P(soa.PodsStruct)]
     L.bs_pods_map.argtypes = [vp, u32, P(soa.PodsStruct)]
+    L.bs_queue_order_load.argtypes = [vp, u32, P(u32)]
+    L.bs_queue_sort.argtypes = [vp, u32, P(i32), P(i32), P(C.c_int64), P(u32)]
     L.bs_nodes_apply.argtypes = [vp, P(NodeDelta), u32]
     L.bs_nodes_count.argtypes = [vp, P(u32)]
     L.bs_cluster_fits.argtypes = [vp, u32, C.c_float, P(C.c_int64), u32, P(u8), P(u32)]
@@ -224,6 +226,19 @@ class Context:
         n = C.c_uint32(0)
         self._chk(self._lib.bs_filter_rows_count(self._h, C.byref(n)), "bs_filter_rows_count")
         return int(n.value)
+
+    def load_queue_order(self, order_rank):
+        """per group: dense rank of (CreationTimestamp ascending, group name descending) — bs_queue_order_load"""
+        r = np.ascontiguousarray(order_rank, dtype=np.uint32)
+        self._chk(self._lib.bs_queue_order_load(self._h, len(r), _u32p(r if len(r) else np.zeros(1, np.uint32))), "bs_queue_order_load")
+
+    def queue_sort(self, priority, group, queue_ts) -> np.ndarray:
+        """the queue order ScheduleOperation.Compare (core.go:368-411) defines: perm[k] = pod at queue position k"""
+        pr, gr, ts = (np.ascontiguousarray(priority, np.int32), np.ascontiguousarray(group, np.int32), np.ascontiguousarray(queue_ts, np.int64))
+        perm = np.zeros(max(len(pr), 1), np.uint32)
+        self._chk(self._lib.bs_queue_sort(self._h, len(pr), pr.ctypes.data_as(C.POINTER(C.c_int32)), gr.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          _i64p(ts), _u32p(perm)), "bs_queue_sort")
+        return perm[: len(pr)]
 
     def map_pods(self, p: int) -> soa.Pods:
         """Zero-copy hand-over (bs_pods_map): a Pods whose arrays ARE the library's pinned upload buffer.  Fill them in

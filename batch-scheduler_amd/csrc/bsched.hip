@@ -17,6 +17,7 @@
 
 #include "bs_kernels.hpp"
 #include "bs_fast.hpp"
+#include "bs_sort.hpp"
 #include "bs_fit.hpp"
 
 using namespace bs;
@@ -120,6 +121,8 @@ struct bs_ctx {
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
   DevBuf d_fl_bitmap, d_admit, d_ready;
   // fast path (bs_fast.hpp)
+  DevBuf d_order_rank, d_sort;         // queue ordering: per-group order ranks; inputs | index ping-pong | permutation
+  uint32_t order_g = 0;
   DevBuf d_gstat, d_ppair, d_pair_next, d_pair_firstq, d_first_reach, d_qstamp_s, d_chunk_off, d_gmm8, d_fast_reject, d_tticket, d_epoch_group;
   bool pairs_ready = false;          // d_gstat / pairs match the loaded pods and G
   bool bitmap_valid = false;         // d_fl_bitmap holds the expanded rows of the last batch
@@ -1207,6 +1210,48 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, hipEventRecord(c->ev_stage, c->stream));
   c->stage_busy = true;
   c->have_pods = true;
+  return BS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// batched queue ordering (bs_sort.hpp)
+// -------------------------------------------------------------------------------------------------
+int bs_queue_order_load(bs_ctx* c, uint32_t g, const uint32_t* order_rank) {
+  if (!c || (g && !order_rank)) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(c, c->d_order_rank.reserve(std::max<size_t>(4, (size_t)g * 4)));
+  if (g) HIPCHK(c, hipMemcpyAsync(c->d_order_rank.p, order_rank, (size_t)g * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->order_g = g;
+  return BS_OK;
+}
+
+int bs_queue_sort(bs_ctx* c, uint32_t p, const int32_t* priority, const int32_t* group, const int64_t* queue_ts, uint32_t* perm_out) {
+  if (!c || (p && (!priority || !group || !queue_ts || !perm_out))) return BS_ERR_INVALID;
+  if (!p) return BS_OK;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t n = p;
+  const size_t o_prio = 0, o_grp = align256(n * 4), o_ts = o_grp + align256(n * 4), o_a = o_ts + align256(n * 8), o_b = o_a + align256(n * 4),
+               o_perm = o_b + align256(n * 4), total = o_perm + align256(n * 4);
+  HIPCHK(c, c->d_sort.reserve(total));
+  uint8_t* base = c->d_sort.as<uint8_t>();
+  HIPCHK(c, hipMemcpyAsync(base + o_prio, priority, n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + o_grp, group, n * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(base + o_ts, queue_ts, n * 8, hipMemcpyHostToDevice, c->stream));
+  SortIn in{};
+  in.p = p;
+  in.g = c->order_g;                                 // groups the order ranks cover; a label beyond it is a lister error
+  in.prio = reinterpret_cast<const int32_t*>(base + o_prio);
+  in.group = reinterpret_cast<const int32_t*>(base + o_grp);
+  in.ts = reinterpret_cast<const int64_t*>(base + o_ts);
+  in.order_rank = c->d_order_rank.as<uint32_t>();
+  hipLaunchKernelGGL(k_queue_sort, dim3(1), dim3(kSortBlock), 0, c->stream, in, reinterpret_cast<uint32_t*>(base + o_a),
+                     reinterpret_cast<uint32_t*>(base + o_b), reinterpret_cast<uint32_t*>(base + o_perm));
+  LAUNCHCHK(c, BS_KERNEL_PREPASS);
+  HIPCHK(c, hipMemcpyAsync(perm_out, base + o_perm, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return BS_OK;
 }
 

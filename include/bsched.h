@@ -370,6 +370,18 @@ int bs_batch_read(bs_ctx* ctx, const bs_batch_out* out);
 /* Rows (distinct Filter requests) the last loaded pods can produce: sizes fl_rows / fl_rows_feasible. */
 int bs_filter_rows_count(bs_ctx* ctx, uint32_t* rows);
 
+/* ---- batched queue ordering ---------------------------------------- */
+/* The permutation that sorts the pending pods the way the scheduling queue does through ScheduleOperation.Compare
+ * (core.go:368-411; Less, batchscheduler.go:214): perm_out[k] = index of the pod at queue position k.  Key, ascending:
+ * priority DESCENDING; pods without a PodGroup label, then labelled pods of known groups, then labelled pods whose
+ * group the lister does not know (for those Compare is false both ways: they go last within their priority); the
+ * group's order rank; the pod's queue timestamp; ties keep input order.  `group` uses bs_pods_soa.group's encoding.
+ * bs_queue_order_load hands over, per group of the loaded group state, the dense rank of (CreationTimestamp ascending,
+ * group name DESCENDING) — equal (timestamp, name) pairs share a rank (the reference compares names, not namespaces). */
+int bs_queue_order_load(bs_ctx* ctx, uint32_t g, const uint32_t* order_rank);
+int bs_queue_sort(bs_ctx* ctx, uint32_t p, const int32_t* priority, const int32_t* group, const int64_t* queue_ts,
+                  uint32_t* perm_out);
+
 /* ---- pod-axis sharding (one process per GPU) -------------------------------------- */
 /* Rank `rank` of `nranks` evaluates only the pods it owns: every pod of a group belongs to the rank
  * whose block of the queue ([rank*P/nranks, (rank+1)*P/nranks)) holds the group's FIRST pod; ungrouped

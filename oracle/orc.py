@@ -273,3 +273,44 @@ class TTL:
 
     def count(self, now) -> int:
         return int(lib().orc_ttl_count(self.h, now))
+
+
+# ---- batched queue ordering: ScheduleOperation.Compare, core.go:368-411, as the queue's Less ----------
+def queue_less(a, b) -> bool:
+    """Compare(podInfo1, podInfo2) of core.go:368-411.  a, b = (priority, group, queue_ts) with group = None (no PodGroup
+    label), a dict {"creation": int, "name": str} (the lister finds it) or "missing" (lister error)."""
+    (p1, g1, t1), (p2, g2, t2) = a, b
+    if p1 > p2:                                               # :379-381
+        return True
+    if p1 == p2:
+        if g1 is None and g2 is None:                         # :384-386
+            return t1 < t2
+        if g1 is None:                                        # :388-390
+            return True
+        if g2 is None:                                        # :391-393
+            return False
+    if not isinstance(g1, dict) or not isinstance(g2, dict):  # :395-399 (an empty name is a lister error too)
+        return False
+    if p1 == p2 and g1["creation"] < g2["creation"]:          # :400-402
+        return True
+    if p1 == p2 and g1["creation"] == g2["creation"] and g1["name"] > g2["name"]:   # :404-406
+        return True
+    return p1 == p2 and g1["creation"] == g2["creation"] and g1["name"] == g2["name"] and t1 < t2
+
+
+def queue_order_ranks(creation_ts, names) -> np.ndarray:
+    """dense rank of (CreationTimestamp ascending, group name DESCENDING) per group; equal pairs share a rank"""
+    keys = sorted({(int(c), n) for c, n in zip(creation_ts, names)}, key=lambda k: (k[0], [-ord(ch) for ch in k[1]] + [1]))
+    # (name descending: compare character codes negated; the trailing 1 makes a prefix sort AFTER its extensions)
+    rank = {k: i for i, k in enumerate(keys)}
+    return np.array([rank[(int(c), n)] for c, n in zip(creation_ts, names)], np.uint32)
+
+
+def queue_order(priority, group, queue_ts, order_rank) -> np.ndarray:
+    """the permutation bs_queue_sort returns, from a stable lexicographic sort of Compare's key (bs_sort.hpp header)"""
+    priority, group, queue_ts = np.asarray(priority, np.int64), np.asarray(group, np.int64), np.asarray(queue_ts, np.int64)
+    g = len(order_rank)
+    known = (group >= 0) & (group < g)
+    kind = np.where(group == soa.POD_NOT_GROUPED, 0, np.where(known, 1, 2))
+    rank = np.where(known, np.asarray(order_rank, np.int64)[np.clip(group, 0, max(g - 1, 0))] if g else 0, 0)
+    return np.lexsort((queue_ts, rank, kind, -priority)).astype(np.uint32)       # last key is the primary one; lexsort is stable
