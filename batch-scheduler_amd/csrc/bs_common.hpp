@@ -50,6 +50,26 @@ __device__ __forceinline__ T wave_incl_scan_add(T v) {
   return v;
 }
 
+// Wave64 inclusive scan (sum) of 64-bit values on the DPP path: row_shr 1/2/4/8 inside the 16-lane rows, then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 — VALU moves with a lane pattern, no LDS crossbar
+// (__shfl_up is ds_bpermute: ~100 cycles per dependent step, and the table build / the scan's chunk prefix do L of them).
+// Lanes without a source keep the old operand (0), so they add nothing.  Needs all 64 lanes active.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned long long dpp_shift_u64(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWMASK, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWMASK, 0xF, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_incl_scan_add_u64(unsigned long long v) {
+  v += dpp_shift_u64<0x111, 0xF>(v);     // row_shr:1
+  v += dpp_shift_u64<0x112, 0xF>(v);     // row_shr:2
+  v += dpp_shift_u64<0x114, 0xF>(v);     // row_shr:4
+  v += dpp_shift_u64<0x118, 0xF>(v);     // row_shr:8
+  v += dpp_shift_u64<0x142, 0xA>(v);     // row_bcast:15 -> rows 1, 3
+  v += dpp_shift_u64<0x143, 0xC>(v);     // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
@@ -127,6 +147,33 @@ __device__ __forceinline__ uint32_t wave_aggregated_inc(uint32_t* counters, uint
     todo &= ~same;
   }
   return slot;
+}
+
+// One lane per distinct key among the active lanes of the wave (the first one): for work every holder of a key would
+// repeat identically (filling a shared slot).
+__device__ __forceinline__ bool wave_elect_by_key(uint32_t key, bool active) {
+  bool elected = false;
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+    if (lane_id() == leader) elected = true;
+    todo &= ~__ballot(active && key == k0);
+  }
+  return elected;
+}
+
+// Same aggregation when nobody needs the old counter value: the adds are fire-and-forget, so the loop over the distinct
+// keys of a wave does not wait for an atomic round trip per key (it did: ~15 distinct groups per wave of pods).
+__device__ __forceinline__ void wave_aggregated_add(uint32_t* counters, uint32_t key, bool active) {
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+    const unsigned long long same = __ballot(active && key == k0) & todo;
+    if (lane_id() == leader) (void)__hip_atomic_fetch_add(&counters[k0], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    todo &= ~same;
+  }
 }
 
 }  // namespace bs

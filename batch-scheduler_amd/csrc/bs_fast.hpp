@@ -45,7 +45,7 @@ namespace bs {
 __global__ void k_pods_prep(unsigned long long* tables, uint32_t ntab, uint32_t* gstat, uint32_t ngstat, uint32_t* kcount) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
   for (uint32_t i = t; i < ntab; i += nt) tables[i] = 0ull;
-  for (uint32_t i = t; i < ngstat; i += nt) gstat[i] = BS_INF;
+  for (uint32_t i = t; i < ngstat; i += nt) gstat[i] = BS_INF;     // [3][G] minima + [G] 64-bit chain heads = 5 G words, all ones
   if (t == 0 && kcount) *kcount = 0;
 }
 
@@ -53,7 +53,8 @@ __global__ void k_pods_prep(unsigned long long* tables, uint32_t ntab, uint32_t*
 // minima and the pair table.  `hinfo` = pinned host memory: K is handed to the host without a copy or an event
 // (value, then the tag with system-scope release; the host only looks when it needs the row count).
 __global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* rep, const uint32_t* id, uint32_t* pclass, unsigned long long* slots, uint32_t mask,
-                            uint32_t hash_keep, uint32_t* gstat, uint32_t* ppair, uint32_t* pair_next, const uint32_t* kcount, int32_t tag, int32_t* hinfo) {
+                            uint32_t hash_keep, uint32_t* gstat, uint32_t* ppair, unsigned long long* pair_next, const uint32_t* kcount, int32_t tag,
+                            int32_t* hinfo) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && hinfo) {
     hinfo[4] = (int32_t)*kcount;
@@ -73,7 +74,12 @@ __global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* rep, const
   bool winner;
   const uint32_t r = dedupe_insert(slots, mask, hash_keep, h, i, [&](uint32_t o) { return o < pods.p && pods.group[o] == gi && id[rep[o]] == c; }, winner);
   ppair[i] = r;
-  if (winner) pair_next[i] = atomicExch(&gstat[(size_t)3 * G + gi], i);
+  // chain links carry the class of the pair they point to: (class << 32) | representative — the walker can ask for the
+  // class slot's scan result in the same round trip as the pair's own fields
+  if (winner) {
+    unsigned long long* head = reinterpret_cast<unsigned long long*>(gstat + (((size_t)3 * G + 1) & ~(size_t)1)) + gi;   // 8-byte aligned behind the minima
+    pair_next[i] = atomicExch(head, ((unsigned long long)c << 32) | i);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -128,16 +134,10 @@ __global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, Batc
 // totals, per 64-row group max / min of the local sums, per chunk first row of every scalar key; the last
 // block to finish turns totals into offsets and reduces kp.
 // ------------------------------------------------------------------------------------------------
-constexpr int kOffBatch = 128;                     // chunks per LDS batch of the tail
-
 template <int TS>
-__device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk,
-                                                  uint32_t nchunks, uint32_t* ticket) {
+__device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk) {
   __shared__ unsigned long long s_wtot[BS_MAX_LANES][4];
   __shared__ uint32_t s_kp[BS_MAX_SCALARS];
-  __shared__ uint32_t s_last;
-  __shared__ unsigned long long s_tot[kOffBatch][16];
-  __shared__ uint32_t s_kpv[kOffBatch][16];
   const uint32_t k = chunk * kTblChunk + threadIdx.x;
   const bool valid = k < nd.m;
   const uint32_t n = valid ? nd.kmap[k] : 0u;
@@ -166,7 +166,7 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
     if (j < L) {
       const bool live = fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
       const unsigned long long left = live ? (unsigned long long)wsub(scale_f32(al[j], d.pct), rq[j]) : 0ull;
-      incl[j] = wave_incl_scan_add<unsigned long long>(left);
+      incl[j] = wave_incl_scan_add_u64(left);
       if (lane_id() == 63) s_wtot[j][w] = incl[j];
     }
   }
@@ -183,25 +183,24 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
       }
       incl[j] += off;
       if (valid) T[(size_t)k * LP + j] = (int64_t)incl[j];
-      if (threadIdx.x == 0) __hip_atomic_store(&b.chunk_tot[(size_t)chunk * 16 + j], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      if (j < LP && valid) T[(size_t)k * LP + j] = INT64_MAX;
-      if (threadIdx.x == 0) __hip_atomic_store(&b.chunk_tot[(size_t)chunk * 16 + j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) b.chunk_tot[(size_t)chunk * 16 + j] = tot;
+    } else if (j < LP && valid) {
+      T[(size_t)k * LP + j] = INT64_MAX;
     }
   }
-  // per 64-row group: max and min of the local sums per resource lane (the tail turns them into bounds of the final sums)
+  // per 64-row group: max of the local sums per resource lane; the scan bounds the group's FINAL sums with max + chunk
+  // offset.  That bound is exact when nothing can wrap: a group whose local sums leave (-2^62, 2^62) is marked
+  // "cannot be pruned" (INT64_MAX) here, and the scan does not prune behind an offset outside that range either.
   {
     const uint32_t grp = k >> 6;
     const bool grp_valid = (chunk * kTblChunk + (threadIdx.x & ~63u)) < nd.m;
+    constexpr int64_t kSafe = (int64_t)1 << 62;
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
       if (j < L) {
         const int64_t mx = wave_max_i64(valid ? (int64_t)incl[j] : INT64_MIN);
         const int64_t mn = wave_min_i64(valid ? (int64_t)incl[j] : INT64_MAX);
-        if (lane_id() == 0 && grp_valid) {     // read back by the tail of this launch: write-through at agent scope
-          __hip_atomic_store(&b.gmm8[(size_t)grp * 2 * LP + j], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&b.gmm8[(size_t)grp * 2 * LP + LP + j], mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (lane_id() == 0 && grp_valid) b.gmax[(size_t)grp * LP + j] = (mx >= kSafe || mn <= -kSafe) ? INT64_MAX : mx;
       }
     }
   }
@@ -213,52 +212,9 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
     }
   }
   __syncthreads();
-  if (threadIdx.x < 16)
-    __hip_atomic_store(&b.chunk_kp[(size_t)chunk * 16 + threadIdx.x], threadIdx.x < BS_MAX_SCALARS ? s_kp[threadIdx.x] : BS_INF, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  // ---- publish, take a ticket; the last chunk block finishes the table's side arrays.  What the tail reads (chunk
-  // totals, per-chunk key rows) was stored write-through at agent scope and is drained (vmcnt) before the ticket; the tail
-  // reads it back with agent-scope loads.  No release / acquire fence: on this 8-XCD part a fence is an L2 write-back or
-  // invalidate per block, and the table rows themselves only have to be visible to the NEXT launch.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nchunks - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned long long acc = 0;
-  uint32_t kpm = BS_INF;
-  for (uint32_t c0 = 0; c0 < nchunks; c0 += kOffBatch) {
-    const uint32_t nb = min((uint32_t)kOffBatch, nchunks - c0);
-    for (uint32_t e = threadIdx.x; e < nb * 16u; e += kTblChunk) {
-      s_tot[e >> 4][e & 15u] = __hip_atomic_load(&b.chunk_tot[(size_t)c0 * 16 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_kpv[e >> 4][e & 15u] = __hip_atomic_load(&b.chunk_kp[(size_t)c0 * 16 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (threadIdx.x < 16) {
-      for (uint32_t c = 0; c < nb; ++c) {
-        b.chunk_off[(size_t)(c0 + c) * 16 + threadIdx.x] = acc;
-        acc += s_tot[c][threadIdx.x];
-        kpm = min(kpm, s_kpv[c][threadIdx.x]);
-      }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < 16) b.kp[threadIdx.x] = kpm;
-  // per 64-row group: upper bound of the FINAL running sums per fixed lane = local max + chunk offset — exact when neither
-  // max + off nor min + off leaves the int64 range (then no row of the group wraps); otherwise "cannot prune" (INT64_MAX)
-  __syncthreads();                                 // chunk_off of this table is complete (written by threads < 16 above)
-  const uint32_t ngroups = (nd.m + 63u) >> 6;
-  for (uint32_t e = threadIdx.x; e < ngroups * LP; e += kTblChunk) {
-    const uint32_t g = e / LP, j = e - g * LP;
-    if (j >= L) continue;
-    const long long mx = (long long)__hip_atomic_load(&b.gmm8[(size_t)g * 2 * LP + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long mn = (long long)__hip_atomic_load(&b.gmm8[(size_t)g * 2 * LP + LP + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long of = (long long)b.chunk_off[(size_t)(g >> 2) * 16 + j];
-    long long hi, lo;
-    const bool o1 = __builtin_saddll_overflow(mx, of, &hi), o2 = __builtin_saddll_overflow(mn, of, &lo);
-    b.gmax[(size_t)g * LP + j] = (o1 || o2) ? INT64_MAX : (int64_t)hi;
-  }
+  if (threadIdx.x < 16) b.chunk_kp[(size_t)chunk * 16 + threadIdx.x] = threadIdx.x < BS_MAX_SCALARS ? s_kp[threadIdx.x] : BS_INF;
+  // nothing else: offsets, key rows and pruning bounds are derived by the scan itself (scan_core<S, true>) from the chunk
+  // totals, the per-chunk key rows and the per-group max / min — no ticket, no tail, no grid-wide dependency in this launch
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -323,18 +279,36 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
     b.stage[i] = st;
   }
   {
-    // first pod of the queue that reaches findMaxPG (lanes are in queue order); it really does: a replayed
-    // deny needs an earlier, reaching, rejected pod
+    // First pod of the queue that reaches findMaxPG (it really does: a replayed deny needs an earlier, reaching, rejected
+    // pod).  Blocks are in queue order, so it is the first reaching pod of the first block that has one: every block
+    // leaves its own candidate in its own word (a single shared minimum was ~800 atomics on one address at 50k pods).
+    __shared__ uint32_t s_reach;
+    if (threadIdx.x == 0) s_reach = BS_INF;
+    __syncthreads();
     const unsigned long long rb = __ballot(valid && (st & ST_REACH6));
-    if (rb && lane_id() == __ffsll((long long)rb) - 1) atomicMin(b.first_reach64, ((unsigned long long)prm.seq_inv << 32) | i);
+    if (rb && lane_id() == __ffsll((long long)rb) - 1) atomicMin(&s_reach, i);
+    __syncthreads();
+    if (threadIdx.x == 0) b.first_reach64[blockIdx.x] = ((unsigned long long)prm.seq_inv << 32) | s_reach;
   }
-  // Filter slots: class c with the batch's leader, class c + K with the leader carried into the batch
-  if (prm.run_filter && valid && (st & ST_OWNED) && BS_PF_IS_PASS(code)) {
-    const uint32_t c = b.pclass[i], K = *b.kclass;
-    filter_params_for<TS>(pods, gr, b, prm, i, code, leader0, c, true, false);
-    filter_params_for<TS>(pods, gr, b, prm, i, code, prm.sop_leader0, c + K, true, false);
+  // Filter slots: class c with the batch's leader, class c + K with the leader carried into the batch.  Every pod of a
+  // class that may pass and is not in the leader's own group derives the same slot contents: one lane per (wave, class)
+  // is elected to fill it (tens of thousands of identical stores to a few hundred cache lines were a measurable part
+  // of this launch; electing ONE writer per batch with an atomic swap of the stamp was worse: a hot-spot of returning atomics).
+  if (prm.run_filter) {
+    const uint32_t c = valid ? b.pclass[i] : 0u;
+    const int32_t gi = valid ? pods.group[i] : BS_POD_NOT_GROUPED;
+    const bool may = valid && (st & ST_OWNED) && BS_PF_IS_PASS(code) && gi >= 0 && (uint32_t)gi < gr.g;
+    if (wave_elect_by_key(c, may && leader0 >= 0 && leader0 != gi)) filter_params_for<TS>(pods, gr, b, prm, i, code, leader0, c, true, false);
+    if (wave_elect_by_key(c, may && prm.sop_leader0 >= 0 && prm.sop_leader0 != gi))
+      filter_params_for<TS>(pods, gr, b, prm, i, code, prm.sop_leader0, c + *b.kclass, true, false);
   }
+  const uint32_t qslot = has_q ? b.pclass[i] : 0u;
+  const bool fill = wave_elect_by_key(qslot, has_q);   // one writer per (wave, class): ~10x fewer identical stores, no atomics
   if (has_q) {
+    b.qpos[i] = qslot;
+    atomicMin(&b.pair_firstq[b.ppair[i]], ((unsigned long long)prm.seq_inv << 32) | i);
+  }
+  if (fill) {
     uint32_t absok = 0;
 #pragma unroll
     for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
@@ -344,7 +318,7 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
         if (!pres) q.v[4 + s] = INT64_MIN;                    // key not requested: never constrains
       }
     }
-    const uint32_t slot = b.pclass[i];
+    const uint32_t slot = qslot;
     int64_t* dst = b.qreq_s + (size_t)slot * prm.LP;
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
@@ -353,8 +327,6 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
     b.qtab_s[slot] = 0;
     b.first_row[slot] = BS_INF;                               // every writer stores the same; launch B takes minima
     b.qstamp_s[slot] = prm.stamp;
-    b.qpos[i] = slot;
-    atomicMin(&b.pair_firstq[b.ppair[i]], ((unsigned long long)prm.seq_inv << 32) | i);
   }
   if (prm.collect_stats) {
     const unsigned long long hq = __ballot(has_q);
@@ -367,7 +339,7 @@ template <int TS>
 __global__ __launch_bounds__(kTblChunk) void k_fast_query_tables(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm,
                                                                  const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks) {
   if (blockIdx.x < query_blocks) fast_query_thread<TS>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
-  else tables_local_fast<TS>(nd, bt, prm, forced, blockIdx.x - query_blocks, nchunks, &b.ticket[1]);
+  else tables_local_fast<TS>(nd, bt, prm, forced, blockIdx.x - query_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,8 +366,24 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev
 //   Filter        code, slot and feasible-node count of the pod from its class slot
 //   Permit        per-group admit counts; last block: quorum predicate core.go:303
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm) {
-  __shared__ uint32_t s_last;
+__global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
+  __shared__ uint32_t s_last, s_first_reach;
+  // first pod that reaches findMaxPG = the candidate of the first block of launch A that has one (64 blocks per look)
+  if (threadIdx.x < 64) {
+    uint32_t found = BS_INF;
+    for (uint32_t b0 = 0; b0 < query_blocks && found == BS_INF; b0 += 64u) {
+      const uint32_t bk = b0 + threadIdx.x;
+      uint32_t v = BS_INF;
+      if (bk < query_blocks) {
+        const unsigned long long w = b.first_reach64[bk];
+        if ((uint32_t)(w >> 32) == prm.seq_inv) v = (uint32_t)w;
+      }
+      const unsigned long long any = __ballot(v != BS_INF);
+      if (any) found = (uint32_t)__shfl((int)v, __ffsll((long long)any) - 1);
+    }
+    if (threadIdx.x == 0) s_first_reach = found;
+  }
+  __syncthreads();
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   bool admit = false;
   uint32_t ag = 0;
@@ -403,18 +391,20 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     uint8_t code = b.tcode[i];
     const uint8_t st = b.stage[i];
     const int32_t gi = pods.group[i];
-    const unsigned long long fr64 = *b.first_reach64;
-    const uint32_t first_reach = (uint32_t)(fr64 >> 32) == prm.seq_inv ? (uint32_t)fr64 : BS_INF;
+    const uint32_t first_reach = s_first_reach;
     uint32_t fk = BS_K_NOT_SCANNED;
     if (st & ST_OWNED) {
       bool denied = false;
       if (st & ST_ELIG) {
         uint32_t fr = BS_INF;
-        for (uint32_t r = b.pair_head[gi]; r != BS_INF; r = b.pair_next[r]) {
-          const unsigned long long pq = b.pair_firstq[r];
+        for (unsigned long long link = b.pair_head[gi]; (uint32_t)link != BS_INF;) {
+          const uint32_t r = (uint32_t)link, cls = (uint32_t)(link >> 32);
+          const unsigned long long pq = b.pair_firstq[r];              // } one round trip: the pair's first querying pod,
+          const uint32_t row = b.first_row[cls];                       // } its class slot's scan result,
+          link = b.pair_next[r];                                       // } the next link
           if ((uint32_t)(pq >> 32) != prm.seq_inv) continue;           // no pod of the pair had a query in this batch
           const uint32_t fq = (uint32_t)pq;
-          if (fq < fr && b.first_row[b.pclass[r]] == BS_INF) fr = fq;  // the pair's class was rejected
+          if (fq < fr && row == BS_INF) fr = fq;                       // the pair's class was rejected
         }
         denied = fr < i;
         if (prm.commit && fr == i) b.fast_reject[gi] = fr;             // AddToDenyCache, kept for k_fast_commit
@@ -460,7 +450,7 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     const uint32_t U = min(2u * *b.kclass, b.hstride);
     for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
   }
-  if (prm.do_tally) wave_aggregated_inc(b.admit, ag, admit);
+  if (prm.do_tally) wave_aggregated_add(b.admit, ag, admit);
   if (!prm.do_ready && !prm.host_tag) return;
   // the admit counters are agent-scope atomics (performed at the coherence point, returned before vmcnt drains): a drained
   // ticket orders them, the last block reads them back with agent-scope loads — no L2 write-back / invalidate per block
@@ -470,11 +460,28 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
   __syncthreads();
   if (!s_last) return;
   if (threadIdx.x == 0) __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (uint32_t gg = threadIdx.x; gg < gr.g; gg += 256u) {
-    const uint32_t ad = __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint8_t rd = (gr.matched[gg] + ad) >= (uint32_t)(gr.min_member[gg] - gr.status_scheduled[gg]) ? 1 : 0;
-    if (prm.do_ready) b.ready[gg] = rd;
-    if (prm.host_tag) { b.h_admit[gg] = ad; b.h_ready[gg] = rd; }
+  // quorum pass: all loads of a batch of groups first, then the stores (one round trip per 8 x 256 groups, not one per 256)
+  constexpr int kQ = 8;
+  for (uint32_t g0 = 0; g0 < gr.g; g0 += kQ * 256u) {
+    uint32_t ad[kQ], ma[kQ], mm[kQ], sc[kQ];
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      const uint32_t gg = g0 + (uint32_t)u * 256u + threadIdx.x;
+      ad[u] = ma[u] = mm[u] = sc[u] = 0;
+      if (gg < gr.g) {
+        ad[u] = __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ma[u] = gr.matched[gg]; mm[u] = gr.min_member[gg]; sc[u] = gr.status_scheduled[gg];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      const uint32_t gg = g0 + (uint32_t)u * 256u + threadIdx.x;
+      if (gg < gr.g) {
+        const uint8_t rd = (ma[u] + ad[u]) >= (uint32_t)(mm[u] - sc[u]) ? 1 : 0;
+        if (prm.do_ready) b.ready[gg] = rd;
+        if (prm.host_tag) { b.h_admit[gg] = ad[u]; b.h_ready[gg] = rd; }
+      }
+    }
   }
   if (prm.host_tag) {
     // every block drained its host writes before taking its ticket; this block's are drained here; then the completion
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_local_nofix(NodesDev nd, B
   bt.gmm8 = b.gmm8 + (size_t)slot * gstride * 2 * prm.LP;
   bt.gmax = b.gmax + (size_t)slot * gstride * prm.LP;
   const TableDesc d = table_desc(slot, prm.C, nullptr);
-  tables_local_fast<TS>(nd, bt, prm, &d, blockIdx.y, nchunks, &b.tticket[slot]);
+  tables_local_fast<TS>(nd, bt, prm, &d, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------

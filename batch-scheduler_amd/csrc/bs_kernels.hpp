@@ -134,11 +134,11 @@ struct BatchDev {
   const uint32_t* first_pod_s;    // [G] min pod index of the group                               } derived from the pods alone
   const uint32_t* first_np_s;     // [G] min pod index without BS_POD_LAST_PERMITTED              } at bs_pods_load
   const uint32_t* first_owner_s;  // [G] min such pod index that has OwnerReferences              } (k_pod_pairs)
-  const uint32_t* pair_head;      // [G] first (group, request class) pair of the group, BS_INF none: a chain through pair_next
+  const unsigned long long* pair_head;  // [G] first (group, request class) pair of the group: (class << 32) | representative pod, low word BS_INF = none
   const uint32_t* ppair;          // [P] pod -> its pair (= index of the pair's representative pod)
-  const uint32_t* pair_next;      // [P] valid at representatives
+  const unsigned long long* pair_next;  // [P] at representatives: the next link of the group's chain, same encoding
   unsigned long long* pair_firstq;// [P] at representatives: (~batch_seq << 32) | first pod of the pair with a scan query
-  unsigned long long* first_reach64;  // [1] (~batch_seq << 32) | first pod that reaches findMaxPG
+  unsigned long long* first_reach64;  // [blocks of launch A] (~batch_seq << 32) | first pod of the block that reaches findMaxPG
   unsigned long long* chunk_off;  // [slots][nchunks][16] exclusive prefix of chunk_tot (tables stay chunk-local)
   int64_t* gmm8;            // [slot][ceil(mcap/64)][2 LP] per 64-row group of the chunk-local table: max[LP], min[LP]
   uint32_t* fast_reject;    // [G] first rejected pod of the group (only maintained for BS_BATCH_COMMIT)
@@ -826,7 +826,7 @@ __device__ __forceinline__ void tables_local_block(const NodesDev& nd, const Bat
     if (j < L) {
       const bool live = fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
       const unsigned long long left = live ? (unsigned long long)wsub(scale_f32(al[j], d.pct), rq[j]) : 0ull;
-      incl[j] = wave_incl_scan_add<unsigned long long>(left);
+      incl[j] = wave_incl_scan_add_u64(left);
       if (lane_id() == 63) s_wtot[j][w] = incl[j];
     }
   }
@@ -1092,13 +1092,54 @@ __device__ __forceinline__ void row_all(const unsigned long long (&nf)[Q], uint3
 // are.  A group's 64 rows are fetched with ONE vector load per lane (lane = row) and parked in this wave's
 // LDS slice `rows`; the row loop reads them back with uniform-address (broadcast) ds_reads, so no memory
 // round trip sits inside the loop.
-// LOCAL: the table holds chunk-local running sums (fast path: no fix-up pass).  A row's final value is
-// local + chunk_off[chunk] in wrapping arithmetic; the offset is added while the group's rows travel to LDS,
-// and a group is pruned only when max + off and min + off both stay in range (then no row of it wraps and
-// max + off bounds them all) and the bound is below the tile's smallest request.
+// LOCAL: the table holds chunk-local running sums (no fix-up pass, and nothing after the local scans in the building
+// launch).  A row's final value is local + (sum of the preceding chunks' totals) in wrapping arithmetic.  The scan keeps
+// the exclusive prefix of the chunk totals in registers — lane l of the wave owns chunk 64 w + l of the current window w
+// (one load + one wave scan per 16 384 rows) — and adds a group's offset while its rows travel to LDS.  A group is
+// pruned only when its local sums and the offset both lie inside (-2^62, 2^62) (then nothing wraps and local max + off
+// bounds every row of it) and that bound is below the tile's smallest request.  kp[s] = min of the chunks' first key rows.
+// What a wave derives from a chunk-local table before it scans it: the exclusive prefix of the chunk totals for window 0
+// (lane l <-> chunk l), the running total behind that window, and the first row of every scalar key.  When every item of
+// a launch uses the same table (steady state) a wave computes this ONCE, up front, while its first slot loads are in flight.
+template <int S>
+struct LocalPre {
+  unsigned long long offl[4 + S], carry[4 + S];
+  uint32_t kp[S > 0 ? S : 1];
+};
+template <int S>
+__device__ __forceinline__ void local_pre_load(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, LocalPre<S>& pre) {
+  constexpr int L = 4 + S;
+  const int lane = lane_id();
+  const uint32_t nchunks = (m + kTblChunk - 1u) / kTblChunk, cstride = (prm.mcap + kTblChunk - 1u) / kTblChunk;
+  const uint32_t ch = (uint32_t)lane;
+  const unsigned long long* ct = b.chunk_tot + ((size_t)slot * cstride + ch) * 16;
+  unsigned long long v[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) v[j] = ch < nchunks ? ct[j] : 0ull;
+  uint32_t kv[S > 0 ? S : 1];
+#pragma unroll
+  for (int s = 0; s < S; ++s) kv[s] = ch < nchunks ? b.chunk_kp[((size_t)slot * cstride + ch) * 16 + s] : BS_INF;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    const unsigned long long incl = wave_incl_scan_add_u64(v[j]);
+    pre.offl[j] = incl - v[j];
+    pre.carry[j] = __shfl(incl, 63);
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    uint32_t mn = wave_min_u32(kv[s]);
+    for (uint32_t w0 = 64u; w0 < nchunks; w0 += 64u) {          // tables beyond 16 384 rows: the remaining chunks' key rows
+      const uint32_t c2 = w0 + (uint32_t)lane;
+      mn = min(mn, wave_min_u32(c2 < nchunks ? b.chunk_kp[((size_t)slot * cstride + c2) * 16 + s] : BS_INF));
+    }
+    pre.kp[s] = __builtin_amdgcn_readfirstlane(mn);               // wave-uniform by construction: keep it scalar (it cuts row pieces)
+  }
+}
+
 template <int S, bool LOCAL = false>
 __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, uint32_t pos, bool valid,
-                                          const int64_t (&r)[1][4 + S], uint32_t qf, uint32_t share, uint32_t J, int64_t (*rows)[4 + S]) {
+                                          const int64_t (&r)[1][4 + S], uint32_t qf, uint32_t share, uint32_t J, int64_t (*rows)[4 + S],
+                                          const LocalPre<S>* pre_in = nullptr) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
   constexpr int U = 4;                           // rows per step: their LDS reads are issued together
@@ -1117,13 +1158,57 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   const int64_t* T = b.tables + (size_t)slot * prm.mcap * LP;
   uint32_t rows_done = 0;
   uint32_t turn = 0;                             // rank of the next live group modulo J
+  // chunk-local tables: exclusive prefix of the chunk totals, window by window (forward only)
+  const uint32_t nchunks = (m + kTblChunk - 1u) / kTblChunk, cstride = (prm.mcap + kTblChunk - 1u) / kTblChunk;
+  unsigned long long offl[L], carry[L];
+  uint32_t win = BS_INF;
+#pragma unroll
+  for (int j = 0; j < L; ++j) { offl[j] = 0; carry[j] = 0; }
+  if constexpr (LOCAL) {
+    LocalPre<S> mine_pre;
+    if (!pre_in) { local_pre_load<S>(b, prm, m, slot, mine_pre); pre_in = &mine_pre; }
+#pragma unroll
+    for (int j = 0; j < L; ++j) { offl[j] = pre_in->offl[j]; carry[j] = pre_in->carry[j]; }
+#pragma unroll
+    for (int s = 0; s < S; ++s) kp[s] = __builtin_amdgcn_readfirstlane(pre_in->kp[s]);
+    win = 0;
+  }
+  auto ensure_window = [&](uint32_t w) {
+    while (win != w) {
+      const uint32_t nxt = win + 1u;               // BS_INF + 1 == 0
+      const uint32_t ch = nxt * 64u + (uint32_t)lane;
+      const unsigned long long* ct = b.chunk_tot + ((size_t)slot * cstride + ch) * 16;
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        const unsigned long long v = ch < nchunks ? ct[j] : 0ull;
+        const unsigned long long incl = wave_incl_scan_add_u64(v);
+        offl[j] = carry[j] + incl - v;
+        carry[j] += __shfl(incl, 63);
+      }
+      win = nxt;
+    }
+  };
 
   for (uint32_t c0 = 0; c0 < ngroups; c0 += 64u) {
     // live mask of groups c0 .. c0+63 (lane l <-> group c0+l)
     bool dead = true;
     const uint32_t g = c0 + (uint32_t)lane;
-    if (g < ngroups) {
-      // (chunk-local tables: gmax already holds max + chunk offset, or INT64_MAX where that bound could wrap)
+    if constexpr (LOCAL) {
+      ensure_window(c0 >> 8);                      // groups c0 .. c0+63 = chunks (c0 >> 2) .. +15: inside one window
+      unsigned long long og[L];
+#pragma unroll
+      for (int j = 0; j < L; ++j) og[j] = __shfl(offl[j], (int)((g >> 2) & 63u));
+      if (g < ngroups) {
+        const int64_t* gm = b.gmax + ((size_t)slot * gstride + g) * LP;     // local max per lane, INT64_MAX = do not prune
+        constexpr long long kSafe = 1ll << 62;
+        dead = false;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+          const long long o = (long long)og[j];
+          if (gm[j] != INT64_MAX && o > -kSafe && o < kSafe && gm[j] + o < rmin[j]) dead = true;   // |max|, |off| < 2^62: no wrap, exact bound
+        }
+      }
+    } else if (g < ngroups) {
       const int64_t* gm = b.gmax + ((size_t)slot * gstride + g) * LP;
       dead = false;
 #pragma unroll
@@ -1145,10 +1230,9 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
         const int64_t* src = T + (size_t)row * LP;
 #pragma unroll
         for (int j = 0; j < L; ++j) mine_row[j] = src[j];
-        if constexpr (LOCAL) {
-          const unsigned long long* of = b.chunk_off + ((size_t)slot * ((prm.mcap + kTblChunk - 1u) / kTblChunk) + (g0 / kTblChunk)) * 16;
+        if constexpr (LOCAL) {                     // (the window of this group's chunk is the current one)
 #pragma unroll
-          for (int j = 0; j < L; ++j) mine_row[j] = (int64_t)((unsigned long long)mine_row[j] + of[j]);
+          for (int j = 0; j < L; ++j) mine_row[j] = (int64_t)((unsigned long long)mine_row[j] + __shfl(offl[j], (int)((g0 / kTblChunk) & 63u)));
         }
       }
       if (!loaded) {                             // first live group of this wave
@@ -1156,7 +1240,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
         seen = valid ? __hip_atomic_load(&b.first_row[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          kp[s] = __builtin_amdgcn_readfirstlane(b.kp[slot * 16 + s]);
+          if constexpr (!LOCAL) kp[s] = __builtin_amdgcn_readfirstlane(b.kp[slot * 16 + s]);
           absok[s] = __ballot((qf >> (16 + s)) & 1u);
         }
       }
@@ -1246,6 +1330,12 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
   const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (nblocks * 4u) / (ntl * tsplit)));
   const uint32_t items = ntl * tsplit * J;
   const int lane = lane_id();
+  // steady state (one table for every item, stamped slots): derive the table's offsets / key rows once per wave, now
+  LocalPre<S> pre;
+  const bool uni = LOCAL && prm.stamp != 0;
+  if constexpr (LOCAL) {
+    if (uni && __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()) < items) local_pre_load<S>(b, prm, m, 0u, pre);
+  }
   for (uint32_t w = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()); w < items; w += nblocks * 4u) {
     const uint32_t rest = w / ntl, tile = t_lo + (w - rest * ntl);
     const uint32_t share = rest / tsplit, ts = rest - share * tsplit;
@@ -1272,7 +1362,7 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
     while (todo) {
       const int32_t t0 = __builtin_amdgcn_readlane(tab, __ffsll((long long)todo) - 1);
       const bool member = tab == t0;
-      if (turn == ts) scan_core<S, LOCAL>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows);
+      if (turn == ts) scan_core<S, LOCAL>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows, uni ? &pre : (const LocalPre<S>*)nullptr);
       turn = turn + 1u == tsplit ? 0u : turn + 1u;
       todo &= ~__ballot(member);
     }
@@ -1345,11 +1435,11 @@ __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const Gro
   }
   if (write_slot && fl == BS_FL_EVALUATED) {
     // every pod of the slot stores the same values (see BatchDev)
-    int64_t* dst = b.uparams + (size_t)slot * 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { dst[j] = R[j]; dst[4 + j] = M[j]; }
     b.uflags[slot] = ffw | (prm.stamp << 16);      // fast path: stamped instead of reset per batch (prm.stamp == 0 otherwise)
     if (prm.stamp) b.fu_feas[slot] = 0;
+    int64_t* dst2 = b.uparams + (size_t)slot * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dst2[j] = R[j]; dst2[4 + j] = M[j]; }
   }
 }
 
@@ -1820,7 +1910,7 @@ __device__ __forceinline__ void tally_block(const PodsDev& pods, const GroupsDev
       g = (uint32_t)gi;
     }
   }
-  wave_aggregated_inc(b.admit, g, admit);
+  wave_aggregated_add(b.admit, g, admit);
   // nobody reads the per-group minima any more in this batch: every block re-arms a slice of them
   if (rearm) {
     for (uint32_t gg = bx * BLOCK + threadIdx.x; gg < gr.g; gg += nblocks * BLOCK) {

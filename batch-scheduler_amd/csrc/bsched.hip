@@ -331,9 +331,9 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.first_pod_s = c->d_gstat.as<uint32_t>();
   b.first_np_s = c->d_gstat.as<uint32_t>() + (size_t)c->G;
   b.first_owner_s = c->d_gstat.as<uint32_t>() + (size_t)2 * c->G;
-  b.pair_head = c->d_gstat.as<uint32_t>() + (size_t)3 * c->G;
+  b.pair_head = reinterpret_cast<const unsigned long long*>(c->d_gstat.as<uint32_t>() + (((size_t)3 * c->G + 1) & ~(size_t)1));
   b.ppair = c->d_ppair.as<uint32_t>();
-  b.pair_next = c->d_pair_next.as<uint32_t>();
+  b.pair_next = c->d_pair_next.as<unsigned long long>();
   b.pair_firstq = c->d_pair_firstq.as<unsigned long long>();
   b.first_reach64 = c->d_first_reach.as<unsigned long long>();
   b.chunk_off = c->d_chunk_off.as<unsigned long long>();
@@ -683,15 +683,15 @@ int ensure_gstage(bs_ctx* c, size_t bytes) {
 // fresh: the pair table and gstat were just reset by k_pods_prep.
 int build_pairs(bs_ctx* c, bool fresh) {
   const uint32_t G = c->G, P = c->P;
-  HIPCHK(c, c->d_gstat.reserve((size_t)4 * std::max<uint32_t>(G, 1) * 4));
+  HIPCHK(c, c->d_gstat.reserve((size_t)5 * std::max<uint32_t>(G, 1) * 4 + 16));
   HIPCHK(c, c->d_fast_reject.reserve((size_t)std::max<uint32_t>(G, 1) * 4));
   unsigned long long* table = c->d_cls_slots.as<unsigned long long>() + c->cls_cap;         // second half: the pair table
   if (!fresh && P)
-    hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, table, c->cls_cap, c->d_gstat.as<uint32_t>(), 4 * G, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, table, c->cls_cap, c->d_gstat.as<uint32_t>(), 5 * G + 1, (uint32_t*)nullptr);
   c->kinfo_tag++;
   hipLaunchKernelGGL(k_pod_pairs, dim3(std::max<uint32_t>(1, cdiv(P, 256))), dim3(256), 0, c->stream, pods_dev(c), G, c->d_cls_rep.as<uint32_t>(),
                      c->d_cls_id.as<uint32_t>(), c->d_pclass.as<uint32_t>(), table, c->cls_cap - 1, c->hash_keep, c->d_gstat.as<uint32_t>(),
-                     c->d_ppair.as<uint32_t>(), c->d_pair_next.as<uint32_t>(), c->d_nepochs.as<uint32_t>() + 2, c->kinfo_tag, c->h_info);
+                     c->d_ppair.as<uint32_t>(), c->d_pair_next.as<unsigned long long>(), c->d_nepochs.as<uint32_t>() + 2, c->kinfo_tag, c->h_info);
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
   c->kinfo_pending = true;
   c->pairs_ready = c->have_groups;
@@ -1150,6 +1150,8 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
     if (rc) return rc;
   }
   c->map_p = 0;
+  rc = reserve_filled(c, c->d_first_reach, (n / kTblChunk + 2) * 8, 0xFF);   // one candidate word per pod block of launch A
+  if (rc) return rc;
   HIPCHK(c, c->d_epoch.reserve(n * 4));
   HIPCHK(c, c->d_epoch_group.reserve((n + 2) * 4));
   HIPCHK(c, c->d_tcode.reserve(n));
@@ -1159,7 +1161,7 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
   HIPCHK(c, c->d_fflags.reserve(n * 4));
   HIPCHK(c, c->d_ppair.reserve(n * 4));
-  HIPCHK(c, c->d_pair_next.reserve(n * 4));
+  HIPCHK(c, c->d_pair_next.reserve(n * 8));
   rc = reserve_filled(c, c->d_pair_firstq, n * 8, 0xFF);     // 64-bit minima keyed by ~batch_seq: never reset, only born as "none"
   if (rc) return rc;
   HIPCHK(c, c->d_pclass.reserve(n * 4));
@@ -1193,9 +1195,9 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   // (reset | first half of the class builder | second half + pairs); K reaches the host through pinned memory
   if (P) {
     const PodsDev pd = pods_dev(c);
-    HIPCHK(c, c->d_gstat.reserve((size_t)4 * std::max<uint32_t>(c->G, 1) * 4));
+    HIPCHK(c, c->d_gstat.reserve((size_t)5 * std::max<uint32_t>(c->G, 1) * 4 + 16));
     hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, c->d_cls_slots.as<unsigned long long>(), 2 * c->cls_cap,
-                       c->d_gstat.as<uint32_t>(), c->have_groups ? 4 * c->G : 0u, c->d_nepochs.as<uint32_t>() + 2);
+                       c->d_gstat.as<uint32_t>(), c->have_groups ? 5 * c->G + 1 : 0u, c->d_nepochs.as<uint32_t>() + 2);
     hipLaunchKernelGGL(k_pod_class_a, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, c->d_cls_slots.as<unsigned long long>(), c->cls_cap - 1,
                        c->hash_keep, L, c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(), c->d_nepochs.as<uint32_t>() + 2);
     LAUNCHCHK(c, BS_KERNEL_PREPASS);
@@ -1438,7 +1440,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     launch_fast_b(c, grid, pd, nd, bt, prm, nseg, scan_blocks);
   });
   // ---- launch C: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
-  TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm));
+  TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
   c->launches = 3;
   if (commit) {
     if (G) hipLaunchKernelGGL(k_fast_commit, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, pd, b, const_cast<uint8_t*>(gr.flags),
