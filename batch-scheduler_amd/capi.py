@@ -60,7 +60,8 @@ class BatchStats(C.Structure):
     _fields_ = [("scan_queries", C.c_uint64), ("scan_rows_executed", C.c_uint64), ("scan_evals_executed", C.c_uint64),
                 ("tables_built", C.c_uint64), ("logical_evals", C.c_uint64), ("filter_evals", C.c_uint64),
                 ("filter_distinct", C.c_uint64), ("filter_evals_executed", C.c_uint64),
-                ("scan_queries_logical", C.c_uint64), ("class_mode", C.c_uint64), ("fast_path", C.c_uint64), ("launches", C.c_uint64)]
+                ("scan_queries_logical", C.c_uint64), ("class_mode", C.c_uint64), ("fast_path", C.c_uint64), ("launches", C.c_uint64),
+                ("chain", C.c_uint64)]
 
 
 _lib = None

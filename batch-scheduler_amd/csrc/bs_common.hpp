@@ -70,6 +70,27 @@ __device__ __forceinline__ unsigned long long wave_incl_scan_add_u64(unsigned lo
   return v;
 }
 
+// Wave64 maximum of signed 64-bit values on the same DPP path; the result is valid in LANE 63 only (the inclusive "scan"
+// of max ends there).  Lanes without a source see INT64_MIN.  A __shfl_xor butterfly is 12 ds_bpermute per value — the
+// table builders reduce L values per 64-row group in every block, and with every CU full of such blocks the LDS crossbar
+// was what the launch waited for.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ long long dpp_shift_i64_min(long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(unsigned long long)v, CTRL, ROWMASK, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)0x80000000u, (int)(uint32_t)((unsigned long long)v >> 32), CTRL, ROWMASK, 0xF, false);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long wave_max_i64_lane63(long long v) {
+  long long u;
+  u = dpp_shift_i64_min<0x111, 0xF>(v); v = u > v ? u : v;     // row_shr:1
+  u = dpp_shift_i64_min<0x112, 0xF>(v); v = u > v ? u : v;     // row_shr:2
+  u = dpp_shift_i64_min<0x114, 0xF>(v); v = u > v ? u : v;     // row_shr:4
+  u = dpp_shift_i64_min<0x118, 0xF>(v); v = u > v ? u : v;     // row_shr:8
+  u = dpp_shift_i64_min<0x142, 0xA>(v); v = u > v ? u : v;     // row_bcast:15 -> rows 1, 3
+  u = dpp_shift_i64_min<0x143, 0xC>(v); v = u > v ? u : v;     // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));

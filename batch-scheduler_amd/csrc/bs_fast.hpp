@@ -198,9 +198,10 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
       if (j < L) {
-        const int64_t mx = wave_max_i64(valid ? (int64_t)incl[j] : INT64_MIN);
-        const int64_t mn = wave_min_i64(valid ? (int64_t)incl[j] : INT64_MAX);
-        if (lane_id() == 0 && grp_valid) b.gmax[(size_t)grp * LP + j] = (mx >= kSafe || mn <= -kSafe) ? INT64_MAX : mx;
+        const int64_t x = (int64_t)incl[j];
+        const long long mx = wave_max_i64_lane63(valid ? x : INT64_MIN);
+        const bool risky = __ballot(valid && (x >= kSafe || x <= -kSafe)) != 0ull;      // some local sum could wrap with an offset on top
+        if (lane_id() == 63 && grp_valid) b.gmax[(size_t)grp * LP + j] = risky ? INT64_MAX : mx;
       }
     }
   }

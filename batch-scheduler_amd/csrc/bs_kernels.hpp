@@ -1833,8 +1833,9 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
 // give the whole grid something to do.  ustride = row stride of fu_bitmap (slot capacity).
 template <int NB>
 __device__ __forceinline__ void filter_loop(const PodsDev& pods, const NodesDev& nd, const BatchDev& b, uint32_t target_waves, uint32_t use_classes,
-                                            uint32_t ustride, uint32_t collect_stats, uint32_t bx, uint32_t nblocks, uint32_t stamp = 0) {
-  const uint32_t U = use_classes ? 2u * __builtin_amdgcn_readfirstlane(*b.kclass) : pods.p;
+                                            uint32_t ustride, uint32_t collect_stats, uint32_t bx, uint32_t nblocks, uint32_t stamp = 0,
+                                            uint32_t slots = 0) {
+  const uint32_t U = slots ? slots : (use_classes ? 2u * __builtin_amdgcn_readfirstlane(*b.kclass) : pods.p);     // slots != 0: (view, class) slots of bs_epoch.hpp
   const uint32_t W = (nd.n + 63u) / 64u;
   if (!U || !W) return;
   const uint32_t tiles = (U + 63u) / 64u;

@@ -17,6 +17,7 @@
 
 #include "bs_kernels.hpp"
 #include "bs_fast.hpp"
+#include "bs_epoch.hpp"
 #include "bs_sort.hpp"
 #include "bs_fit.hpp"
 
@@ -138,6 +139,13 @@ struct bs_ctx {
   int32_t host_tag = 0;
   bool last_host_out = false;
   uint32_t no_fast = 0;
+  // positional three-launch chain (bs_epoch.hpp): analysis of (groups, pods) kept across batches
+  DevBuf d_run_of_epoch, d_run_leader, d_gslot, d_gfirstq;
+  bool epochs_ready = false, einfo_pending = false;
+  int32_t einfo_tag = 0;
+  uint32_t h_R = 0, h_eflags = 0, no_epoch = 0;
+  uint32_t last_chain = 0;           // 0 general chain, 1 steady-state chain, 2 positional chain
+  uint32_t last_rows = 0;            // Filter slot rows of the last positional batch
   // single-query scratch
   DevBuf d_sq;
   uint32_t table_slots = 0, table_mcap = 0;
@@ -403,6 +411,7 @@ int ensure_tables(bs_ctx* c) {
   HIPCHK(c, c->d_sq.reserve(4096));
   c->table_slots = slots;
   c->table_mcap = c->Ncap;
+  c->epochs_ready = false;           // needed[] was written for another class count
   return BS_OK;
 }
 
@@ -634,6 +643,7 @@ int analyse_groups(bs_ctx* c, bool rearm_scratch = true, const bs_group_delta* d
                      dp, const_cast<uint32_t*>(gr.matched), const_cast<uint32_t*>(gr.status_scheduled), const_cast<uint8_t*>(gr.flags));
   LAUNCHCHK(c, BS_KERNEL_LEADER);
   c->info_pending = true;
+  c->epochs_ready = false;
   return BS_OK;
 }
 
@@ -695,6 +705,7 @@ int build_pairs(bs_ctx* c, bool fresh) {
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
   c->kinfo_pending = true;
   c->pairs_ready = c->have_groups;
+  c->epochs_ready = false;
   return BS_OK;
 }
 
@@ -712,6 +723,70 @@ int layout_out(bs_ctx* c) {
   c->off_ready = o; o = align256(o + g);
   c->outpack_bytes = o;
   HIPCHK(c, c->d_outpack.reserve(o));
+  return BS_OK;
+}
+
+// Positional analysis of the loaded (groups, pods) for the three-launch chain of bs_epoch.hpp: per-group minima gated by
+// the group flags, capture epochs, findMaxPG per epoch, leader runs, the tables the state can ask for, groups in class
+// order.  Five launches behind whatever was loaded last; runs / flags come back through pinned memory.
+int analyse_epochs(bs_ctx* c) {
+  const uint32_t G = c->G, P = c->P;
+  int rc;
+  HIPCHK(c, c->d_run_of_epoch.reserve((size_t)(G + 2) * 4));
+  HIPCHK(c, c->d_run_leader.reserve(64));
+  HIPCHK(c, c->d_gslot.reserve((size_t)std::max<uint32_t>(G, 1) * 4));
+  if ((rc = reserve_filled(c, c->d_gfirstq, (size_t)std::max<uint32_t>(G, 1) * 8, 0xFF))) return rc;
+  if ((rc = reserve_filled(c, c->d_pair_firstq, (size_t)std::max<uint32_t>(P, 1) * 8 * 2 * kMaxRuns, 0xFF))) return rc;
+  GroupsDev gr = groups_dev(c);
+  PodsDev pd = pods_dev(c);
+  BatchDev b = batch_dev(c);
+  EpochDev ep{};
+  ep.run_of_epoch = c->d_run_of_epoch.as<uint32_t>();
+  ep.run_leader = c->d_run_leader.as<int32_t>();
+  ep.gslot = c->d_gslot.as<uint32_t>();
+  ep.gfirstq = c->d_gfirstq.as<unsigned long long>();
+  hipLaunchKernelGGL(k_epoch_groups, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, gr, b);
+  hipLaunchKernelGGL(k_epochs2_a, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
+  hipLaunchKernelGGL(k_epochs2_b, dim3(cdiv(P, kScanBlock)), dim3(kScanBlock), 0, c->stream, pd, gr, b);
+  hipLaunchKernelGGL(k_leader_scan, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b);
+  c->einfo_tag++;
+  hipLaunchKernelGGL(k_epoch_views, dim3(1), dim3(kLeaderBlock), 0, c->stream, pd, gr, b, ep, c->C, c->einfo_tag, c->h_info + 8);
+  LAUNCHCHK(c, BS_KERNEL_LEADER);
+  c->einfo_pending = true;
+  c->epochs_ready = true;
+  c->scratch_armed = true;           // the per-group minima hold exactly what the general chain's pre-pass would derive again
+  return BS_OK;
+}
+
+// Both sides loaded and the state positional for sure (captures or MinResources defaults possible): analyse now, so the
+// first batch does not wait for it.  (A captured state whose leader has no matched pod is analysed by its first batch.)
+int maybe_analyse_epochs(bs_ctx* c) {
+  if (c->epochs_ready || c->no_fast || c->no_epoch || c->nranks != 1 || c->reduce_external) return BS_OK;
+  if (!c->have_groups || !c->have_pods || !c->have_fit || !c->have_nodes || !c->pairs_ready || !c->P || !c->G) return BS_OK;
+  if (c->n_uncaptured == 0 && c->n_nominres == 0) return BS_OK;
+  return analyse_epochs(c);
+}
+
+template <int TS>
+void launch_epoch_a(bs_ctx* c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchParams& prm,
+                           const EpochDev& ep, uint32_t nchunks, uint32_t qb, uint32_t ntab) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epoch_query_tables<TS>), grid, dim3(kTblChunk), 0, c->stream, pd, gr, nd, b, prm, ep, nchunks, cdiv(c->Ncap, 256),
+                     cdiv(c->Ncap, 64), qb, ntab);
+}
+template <int S>
+void launch_epoch_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const EpochDev& ep,
+                           uint32_t nseg, uint32_t scan_blocks, uint32_t filter_slots) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epoch_scan_filter<S>), grid, dim3(256), 0, c->stream, pd, nd, b, prm, ep, c->M, nseg, c->G, scan_blocks,
+                     c->filter_waves, c->filter_slots_cap, filter_slots);
+}
+
+int resolve_epochs(bs_ctx* c) {
+  if (!c->einfo_pending) return BS_OK;
+  int rc = wait_host_tag(c, 11, c->einfo_tag);
+  if (rc) return rc;
+  c->einfo_pending = false;
+  c->h_R = (uint32_t)c->h_info[8];
+  c->h_eflags = (uint32_t)c->h_info[9];
   return BS_OK;
 }
 
@@ -780,6 +855,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   std::memset(c->h_info, 0, 64);
   c->batch_seq = 1;                  // 64-bit atomicMin keys carry ~batch_seq: never all-ones
   if (const char* e = std::getenv("BS_NO_FAST")) c->no_fast = std::atoi(e) ? 1u : 0u;
+  if (const char* e = std::getenv("BS_NO_EPOCH")) c->no_epoch = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) { c->early_filter_min = std::strtoull(e, nullptr, 10); c->early_forced = 1; }
@@ -1031,7 +1107,8 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
     c->h_gflags.clear();
   }
   c->have_groups = true;
-  return analyse_groups(c);
+  if ((rc = analyse_groups(c))) return rc;
+  return maybe_analyse_epochs(c);
 }
 
 int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
@@ -1052,7 +1129,10 @@ int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
   for (uint32_t d = 0; d < count; ++d) c->h_gflags[deltas[d].index] = (uint8_t)deltas[d].flags;
   // HAS_POD is unchanged, so the capture epochs the general chain's scratch holds stay valid: no re-arm.
   // Few deltas (the per-cycle case) ride in the arguments of the findMaxPG launch: ONE launch, no copy, no wait.
-  if (count <= (uint32_t)kInlineDeltas) return analyse_groups(c, false, deltas, count);
+  if (count <= (uint32_t)kInlineDeltas) {
+    if ((rc = analyse_groups(c, false, deltas, count))) return rc;
+    return maybe_analyse_epochs(c);
+  }
   const size_t bytes = (size_t)count * sizeof(bs_group_delta);
   rc = ensure_gstage(c, std::max(bytes, c->gpack_bytes));
   if (rc) return rc;
@@ -1065,7 +1145,8 @@ int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
   hipLaunchKernelGGL(k_groups_apply, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, c->d_gdelta.as<GroupDelta>(), count,
                      const_cast<uint32_t*>(gr.matched), const_cast<uint32_t*>(gr.status_scheduled), const_cast<uint8_t*>(gr.flags));
   LAUNCHCHK(c, BS_KERNEL_LEADER);
-  return analyse_groups(c, false);
+  if ((rc = analyse_groups(c, false))) return rc;
+  return maybe_analyse_epochs(c);
 }
 
 int bs_groups_read(bs_ctx* c, bs_groups_soa* g) {
@@ -1175,6 +1256,7 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   }
   HIPCHK(c, c->d_blk_scratch.reserve((n / 256 + 2) * 4));
   c->pairs_ready = false;
+  c->epochs_ready = false;
   c->batch_since_pods = false;
   c->max_pod_cls = 0;
   for (uint32_t i = 0; i < P; ++i)
@@ -1212,7 +1294,7 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, hipEventRecord(c->ev_stage, c->stream));
   c->stage_busy = true;
   c->have_pods = true;
-  return BS_OK;
+  return maybe_analyse_epochs(c);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1456,6 +1538,96 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   return batch_collective(c, stages, gr, b);
 }
 
+// The positional chain (bs_epoch.hpp): three launches for batches in which captures, MinResources defaults or a leader
+// without matched pods make a pod's decision depend on its queue position.  `taken` = false: the analysis says this batch
+// is not for this chain (too many leader runs, slot capacity) and nothing was launched.
+static int run_epoch(bs_ctx* c, uint32_t stages, bool* taken) {
+  int rc;
+  *taken = false;
+  if (!c->epochs_ready && (rc = analyse_epochs(c))) return rc;
+  if ((rc = resolve_pods(c)) || (rc = resolve_epochs(c))) return rc;
+  const uint32_t P = c->P, G = c->G, N = c->N, C = c->C, K = c->h_K, R = c->h_R;
+  const uint32_t W = cdiv(N, 64);
+  const bool run_filter = stages & BS_STAGE_FILTER;
+  if ((c->h_eflags & 4u) || R == 0 || R > kMaxRuns || K == 0) return BS_OK;
+  const uint32_t GB = cdiv(2 * R * K, 64) * 64;                  // (view, class) slots, then the group slots from a tile boundary on
+  const uint32_t filter_slots = (R + 1) * K;
+  if ((uint64_t)GB + G > c->scan_slots_cap || filter_slots > c->filter_slots_cap || filter_slots > P) return BS_OK;
+  *taken = true;
+  NodesDev nd = nodes_dev(c);
+  GroupsDev gr = groups_dev(c);
+  PodsDev pd = pods_dev(c);
+  BatchDev b = batch_dev(c);
+  BatchParams prm = batch_params(c);
+  prm.run_filter = run_filter;
+  prm.use_classes = 0;
+  prm.fuse_filter = run_filter ? 1u : 0u;
+  prm.scan_slots_cap = c->scan_slots_cap;
+  prm.filter_slots_cap = c->filter_slots_cap;
+  prm.stamp = 1u + (c->batch_seq % 65535u);
+  prm.seq_inv = ~c->batch_seq;
+  prm.do_tally = (stages & BS_STAGE_TALLY) ? 1u : 0u;
+  prm.do_ready = prm.do_tally;
+  EpochDev ep{};
+  ep.run_of_epoch = c->d_run_of_epoch.as<uint32_t>();
+  ep.run_leader = c->d_run_leader.as<int32_t>();
+  ep.gslot = c->d_gslot.as<uint32_t>();
+  ep.gfirstq = c->d_gfirstq.as<unsigned long long>();
+  ep.R = R; ep.K = K; ep.GB = GB;
+  ep.has_first = c->h_eflags & 1u;
+  ep.has_reserve = (c->h_eflags >> 1) & 1u;
+  c->last_host_out = false;
+  c->last_rows = filter_slots;
+  const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
+  const int ts = c->S <= 4 ? (int)c->S : -1;
+  // ---- launch A: per-pod decisions, scan / Filter slots | chunk-local running sums of the tables the state can ask for
+  TIMED(c, BS_KERNEL_QUERY, {
+    const uint32_t qb = cdiv(P, kTblChunk);
+    const uint32_t ntab = ep.has_reserve ? 2 * C : (ep.has_first ? C : 0u);       // percent-0.7 tables only behind a leader with matched pods
+    const dim3 qg(qb + cdiv(ntab, kTableGroup) * nchunks);
+    switch (ts) {
+      case 0: launch_epoch_a<0>(c, qg, pd, gr, nd, b, prm, ep, nchunks, qb, ntab); break;
+      case 1: launch_epoch_a<1>(c, qg, pd, gr, nd, b, prm, ep, nchunks, qb, ntab); break;
+      case 2: launch_epoch_a<2>(c, qg, pd, gr, nd, b, prm, ep, nchunks, qb, ntab); break;
+      case 3: launch_epoch_a<3>(c, qg, pd, gr, nd, b, prm, ep, nchunks, qb, ntab); break;
+      case 4: launch_epoch_a<4>(c, qg, pd, gr, nd, b, prm, ep, nchunks, qb, ntab); break;
+      default: launch_epoch_a<-1>(c, qg, pd, gr, nd, b, prm, ep, nchunks, qb, ntab); break;
+    }
+  });
+  // ---- launch B: node scan over the live slots | Filter over the Filter slots
+  TIMED(c, BS_KERNEL_SCAN, {
+    // A tile here is 64 DIFFERENT queries against one table (groups in class order): it is done when the slowest of them
+    // is, so its live 64-row groups are dealt over many waves (there are only tens of tiles: waves are not scarce, the
+    // length of one wave's chain of groups is what the launch waits for).
+    const uint32_t tiles = (ep.has_reserve ? cdiv(2 * R * K, 64) : 0u) + (ep.has_first ? cdiv(G, 64) : 0u);
+    const uint32_t wave_cap = 4 * c->general_waves;
+    const uint32_t nseg = c->scan_share_override ? c->scan_share_override
+                                                 : std::max<uint32_t>(2, std::min<uint32_t>(64, wave_cap / (2 * std::max<uint32_t>(tiles, 1))));
+    const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(wave_cap, 2 * std::max<uint32_t>(tiles, 1) * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
+    const uint32_t fblocks = run_filter ? std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->filter_waves, cdiv(filter_slots, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4)) : 0u;
+    const dim3 grid(scan_blocks + fblocks);
+    switch (c->S) {
+      case 0: launch_epoch_b<0>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 1: launch_epoch_b<1>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 2: launch_epoch_b<2>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 3: launch_epoch_b<3>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 4: launch_epoch_b<4>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 5: launch_epoch_b<5>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 6: launch_epoch_b<6>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 7: launch_epoch_b<7>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 8: launch_epoch_b<8>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 9: launch_epoch_b<9>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 10: launch_epoch_b<10>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      case 11: launch_epoch_b<11>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+      default: launch_epoch_b<12>(c, grid, pd, nd, b, prm, ep, nseg, scan_blocks, filter_slots); break;
+    }
+  });
+  // ---- launch C: final codes, stale leader, Filter code / slot / feasible count per pod, admit counts, quorum
+  TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_epoch_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, ep));
+  c->launches = 3;
+  return batch_collective(c, stages, gr, b);
+}
+
 int bs_batch_run(bs_ctx* c, uint32_t stages) {
   if (!c) return BS_ERR_INVALID;
   if (!c->have_nodes || !c->have_fit || !c->have_groups || !c->have_pods) {
@@ -1498,11 +1670,25 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
                             (uint64_t)P * N >= c->early_filter_min && (!use_classes || c->early_forced);
   // ---- steady state: the three-launch chain
   c->last_fast = use_classes && inline_tables && !early_filter && N && !c->no_fast && !c->no_fuse_filter;
+  c->last_chain = c->last_fast ? 1u : 0u;
   if (c->last_fast) {
     rc = run_fast(c, stages);
     c->batch_seq++;
     return rc;
   }
+  // ---- positional state on one rank: the three-launch chain over (view, class) and group slots
+  if (!c->no_fast && !c->no_epoch && !c->no_fuse_filter && P && G && N && c->M && c->nranks == 1 && !c->reduce_external && !(stages & BS_BATCH_COMMIT) &&
+      !early_filter && c->cfg.enable_timing < 2) {
+    bool taken = false;
+    rc = run_epoch(c, stages, &taken);
+    if (rc) return rc;
+    if (taken) {
+      c->last_chain = 2;
+      c->batch_seq++;
+      return BS_OK;
+    }
+  }
+  c->epochs_ready = false;            // the general chain re-derives (and its tally re-arms) the per-group minima
 
   // ---- general chain (first-pod captures, MinResources defaults, leader without matched pods, early Filter)
   c->last_host_out = false;
@@ -1753,6 +1939,7 @@ static int filter_rows_of(bs_ctx* c, uint32_t* rows) {
   // the mode of the last batch over these pods if there was one, else of the batch the loaded state would run
   const bool classes = c->batch_since_pods ? c->last_use_classes : (c->n_uncaptured == 0 && c->n_nominres == 0);
   *rows = c->P ? (classes ? 2 * c->h_K : c->P) : 0;
+  if (c->batch_since_pods && c->last_chain == 2) *rows = c->last_rows;        // (leader run, class) rows of the positional chain: never more than P
   return BS_OK;
 }
 
@@ -2250,6 +2437,7 @@ int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {
   out->scan_queries_logical = raw[2];
   out->class_mode = c->last_use_classes ? 1 : 0;
   out->fast_path = c->last_fast ? 1 : 0;
+  out->chain = c->last_chain;
   out->launches = c->launches;
   out->tables_built = c->last_fast ? 1 : nt;
   out->logical_evals = (uint64_t)c->P * c->N;

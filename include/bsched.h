@@ -451,6 +451,7 @@ typedef struct bs_batch_stats {
   uint64_t class_mode;              /* 1: the batch worked on request classes, 0: one slot per pod        */
   uint64_t fast_path;               /* 1: the three-launch steady-state chain ran                          */
   uint64_t launches;                /* kernel launches of the batch                                        */
+  uint64_t chain;                   /* 0 general chain, 1 steady-state chain, 2 positional three-launch chain */
 } bs_batch_stats;
 int bs_batch_stats_get(bs_ctx* ctx, bs_batch_stats* out);
 
