@@ -91,6 +91,30 @@ __device__ __forceinline__ long long wave_max_i64_lane63(long long v) {
   return v;
 }
 
+// ... and the minimum, broadcast to every lane (two v_readlane of lane 63): the node scan needs the tile's smallest
+// request per resource lane before it can look at a single group bound.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ long long dpp_shift_i64_max(long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)(uint32_t)(unsigned long long)v, CTRL, ROWMASK, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)0x7FFFFFFFu, (int)(uint32_t)((unsigned long long)v >> 32), CTRL, ROWMASK, 0xF, false);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long readlane63_i64(long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(unsigned long long)v, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)v >> 32), 63);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long wave_min_i64_all(long long v) {
+  long long u;
+  u = dpp_shift_i64_max<0x111, 0xF>(v); v = u < v ? u : v;
+  u = dpp_shift_i64_max<0x112, 0xF>(v); v = u < v ? u : v;
+  u = dpp_shift_i64_max<0x114, 0xF>(v); v = u < v ? u : v;
+  u = dpp_shift_i64_max<0x118, 0xF>(v); v = u < v ? u : v;
+  u = dpp_shift_i64_max<0x142, 0xA>(v); v = u < v ? u : v;
+  u = dpp_shift_i64_max<0x143, 0xC>(v); v = u < v ? u : v;
+  return readlane63_i64(v);
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));

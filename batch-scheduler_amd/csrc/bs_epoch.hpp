@@ -457,18 +457,22 @@ __device__ __forceinline__ void epoch_scan_loop(const BatchDev& b, const BatchPa
     const uint32_t share = rest >> 1, ts = rest & 1u;
     const uint32_t tile = t < tiles_v ? t : (ep.GB >> 6) + (t - tiles_v);
     const uint32_t pos = tile * 64u + (uint32_t)lane;
-    int32_t tab = -1;
-    if (pos < nslots && b.qstamp_s[pos] == prm.stamp) tab = b.qtab_s[pos];          // live iff a pod of THIS batch wrote it
-    unsigned long long todo = __ballot(tab >= 0);
-    if (!todo) continue;
+    // everything a slot holds in ONE round trip (stamp, table, request, flags), then the liveness decision
+    const uint32_t ps = min(pos, nslots - 1u);
+    const uint32_t stp = b.qstamp_s[ps];
+    const int32_t tb = b.qtab_s[ps];
     int64_t r[1][L];
-    uint32_t qf = 0;
-    if (tab >= 0) {
-      const int64_t* src = b.qreq_s + (size_t)pos * LP;
+    {
+      const int64_t* src = b.qreq_s + (size_t)ps * LP;
 #pragma unroll
       for (int j = 0; j < L; ++j) r[0][j] = src[j];
-      qf = b.qflags_s[pos];
-    } else {
+    }
+    uint32_t qf = b.qflags_s[ps];
+    const int32_t tab = (pos < nslots && stp == prm.stamp) ? tb : -1;               // live iff a pod of THIS batch wrote it
+    unsigned long long todo = __ballot(tab >= 0);
+    if (!todo) continue;
+    if (tab < 0) {
+      qf = 0;
 #pragma unroll
       for (int j = 0; j < L; ++j) r[0][j] = INT64_MAX;
     }

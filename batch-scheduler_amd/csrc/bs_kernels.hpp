@@ -1123,7 +1123,7 @@ __device__ __forceinline__ void local_pre_load(const BatchDev& b, const BatchPar
   for (int j = 0; j < L; ++j) {
     const unsigned long long incl = wave_incl_scan_add_u64(v[j]);
     pre.offl[j] = incl - v[j];
-    pre.carry[j] = __shfl(incl, 63);
+    pre.carry[j] = (unsigned long long)readlane63_i64((long long)incl);
   }
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -1147,7 +1147,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   const uint32_t ngroups = (m + 63u) >> 6, gstride = (prm.mcap + 63u) >> 6;
   int64_t rmin[L];                               // smallest request of the tile per resource lane (INT64_MIN where some slot does not ask)
 #pragma unroll
-  for (int j = 0; j < L; ++j) rmin[j] = wave_min_i64(valid ? r[0][j] : INT64_MAX);
+  for (int j = 0; j < L; ++j) rmin[j] = wave_min_i64_all(valid ? r[0][j] : INT64_MAX);
 
   uint32_t myk[1] = {BS_INF};
   uint32_t seen = 0;
@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
         const unsigned long long v = ch < nchunks ? ct[j] : 0ull;
         const unsigned long long incl = wave_incl_scan_add_u64(v);
         offl[j] = carry[j] + incl - v;
-        carry[j] += __shfl(incl, 63);
+        carry[j] += (unsigned long long)readlane63_i64((long long)incl);
       }
       win = nxt;
     }
@@ -1232,12 +1232,14 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
         for (int j = 0; j < L; ++j) mine_row[j] = src[j];
         if constexpr (LOCAL) {                     // (the window of this group's chunk is the current one)
 #pragma unroll
-          for (int j = 0; j < L; ++j) mine_row[j] = (int64_t)((unsigned long long)mine_row[j] + __shfl(offl[j], (int)((g0 / kTblChunk) & 63u)));
+          for (int j = 0; j < L; ++j) mine_row[j] = (int64_t)((unsigned long long)mine_row[j] + bcast64(offl[j], (int)((g0 / kTblChunk) & 63u)));   // (uniform lane: v_readlane, not ds_bpermute)
         }
       }
-      if (!loaded) {                             // first live group of this wave
+      if (!loaded || (LOCAL && J > 2u)) {        // first live group of this wave; with many shares per tile, every group: what
+        seen = valid ? __hip_atomic_load(&b.first_row[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;   // another wave found since
+      }
+      if (!loaded) {
         loaded = true;
-        seen = valid ? __hip_atomic_load(&b.first_row[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           if constexpr (!LOCAL) kp[s] = __builtin_amdgcn_readfirstlane(b.kp[slot * 16 + s]);
@@ -1249,9 +1251,11 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
       for (int j = 0; j < L; ++j) rows[lane][j] = mine_row[j];
       __builtin_amdgcn_wave_barrier();
       uint32_t a = g0;
-      // lanes another wave already served with an earlier row need nothing from this group
-      unsigned long long want = nf & __ballot(seen >= a);
-      if (want == 0) continue;
+      // lanes another wave already served with an earlier row need nothing from this group — nor from any later one (this
+      // wave walks its groups in increasing row order)
+      nf &= __ballot(seen >= a);
+      if (nf == 0) { c0 = ngroups; break; }
+      unsigned long long want = nf;
       while (a < gend) {
         // piece [a, e): no kp[s] strictly inside
         uint32_t e = gend;
