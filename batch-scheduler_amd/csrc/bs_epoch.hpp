@@ -326,6 +326,7 @@ __device__ __forceinline__ void tables_local_multi(const NodesDev& nd, const Bat
                                                    uint32_t cstride, uint32_t gstride) {
   __shared__ unsigned long long s_wtot[2][BS_MAX_LANES][4];
   __shared__ uint32_t s_kp[2][BS_MAX_SCALARS];
+  __shared__ __attribute__((aligned(16))) int64_t s_rowbuf[kTblChunk * 16];      // the chunk's rows, row-major, as they will lie in the table
   if (chunk * kTblChunk >= nd.m) return;
   const uint32_t k = chunk * kTblChunk + threadIdx.x;
   const bool valid = k < nd.m;
@@ -387,11 +388,22 @@ __device__ __forceinline__ void tables_local_multi(const NodesDev& nd, const Bat
           tot += x;
         }
         incl[j] += off;
-        if (valid) T[(size_t)k * LP + j] = (int64_t)incl[j];
+        s_rowbuf[threadIdx.x * LP + j] = (int64_t)incl[j];
         if (threadIdx.x == 0) b.chunk_tot[((size_t)slot * cstride + chunk) * 16 + j] = tot;
-      } else if (j < LP && valid) {
-        T[(size_t)k * LP + j] = INT64_MAX;
+      } else if (j < LP) {
+        s_rowbuf[threadIdx.x * LP + j] = INT64_MAX;
       }
+    }
+    __syncthreads();
+    {
+      // A chunk's rows are one contiguous piece of the table: copy it out 16 bytes per lane, consecutive lanes consecutive
+      // addresses (a row per lane, 8 bytes at a time, is 8 store instructions that each touch 64 different cache lines:
+      // with 64 tables in flight the write path, not the arithmetic, was what this launch waited for).
+      const uint32_t rows = min((uint32_t)kTblChunk, nd.m - chunk * kTblChunk);
+      const uint32_t units = rows * LP / 2u;
+      const int4* src = reinterpret_cast<const int4*>(s_rowbuf);
+      int4* dst = reinterpret_cast<int4*>(T + (size_t)chunk * kTblChunk * LP);
+      for (uint32_t x = threadIdx.x; x < units; x += kTblChunk) dst[x] = src[x];
     }
     {
       const uint32_t grp = k >> 6;
