@@ -17,8 +17,9 @@
 //     ..." minima are 64-bit atomicMin keys with the inverted batch number in the high word (a later batch
 //     always wins).
 //   * the running-sum table stays CHUNK-LOCAL: the scan adds a chunk's offset while the rows travel to LDS
-//     (scan_core<S, true>), so the fix-up pass and its launch dependency disappear.  The last table block to
-//     finish turns the chunk totals into offsets (ticket, as the quorum tail does).
+//     (scan_core<S, true>), so the fix-up pass and its launch dependency disappear.  The scan derives the offsets
+//     (exclusive prefix of the chunk totals, in registers), the key rows and the pruning bounds itself: nothing
+//     follows the local scans in the building launch.
 //   * a rejection (core.go:161-165) is a property of the request class, so the deny replay (core.go:105-110)
 //     of a pod is "is there an earlier pod of my group whose class was rejected": a walk over the group's
 //     (group, class) pairs — no grid-wide first_reject minimum, k_reject is gone.
@@ -131,8 +132,7 @@ __global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, Batc
 
 // ------------------------------------------------------------------------------------------------
 // launch A, table part: chunk-local running sums (core.go:602,621 restarted at every 256-row chunk), chunk
-// totals, per 64-row group max / min of the local sums, per chunk first row of every scalar key; the last
-// block to finish turns totals into offsets and reduces kp.
+// totals, per 64-row group max of the local sums, per chunk first row of every scalar key.
 // ------------------------------------------------------------------------------------------------
 template <int TS>
 __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk) {
@@ -495,8 +495,7 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
 
 // ------------------------------------------------------------------------------------------------
 // General chain, tables without the fix-up pass: block (table, chunk) of every table some query of the batch uses builds
-// its chunk-local running sums; the last block of each table turns its chunk totals into offsets (per-table ticket).
-// k_scan<S, true> adds the offsets while the rows travel to LDS.
+// its chunk-local running sums; k_scan<S, true> derives the offsets and adds them while the rows travel to LDS.
 // ------------------------------------------------------------------------------------------------
 template <int TS>
 __global__ __launch_bounds__(kTblChunk) void k_tables_local_nofix(NodesDev nd, BatchDev b, BatchParams prm, uint32_t nchunks, uint32_t cstride,
@@ -508,8 +507,6 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_local_nofix(NodesDev nd, B
   bt.kp = b.kp + (size_t)slot * 16;
   bt.chunk_tot = b.chunk_tot + (size_t)slot * cstride * 16;
   bt.chunk_kp = b.chunk_kp + (size_t)slot * cstride * 16;
-  bt.chunk_off = b.chunk_off + (size_t)slot * cstride * 16;
-  bt.gmm8 = b.gmm8 + (size_t)slot * gstride * 2 * prm.LP;
   bt.gmax = b.gmax + (size_t)slot * gstride * prm.LP;
   const TableDesc d = table_desc(slot, prm.C, nullptr);
   tables_local_fast<TS>(nd, bt, prm, &d, blockIdx.y);

@@ -139,13 +139,10 @@ struct BatchDev {
   const unsigned long long* pair_next;  // [P] at representatives: the next link of the group's chain, same encoding
   unsigned long long* pair_firstq;// [P] at representatives: (~batch_seq << 32) | first pod of the pair with a scan query
   unsigned long long* first_reach64;  // [blocks of launch A] (~batch_seq << 32) | first pod of the block that reaches findMaxPG
-  unsigned long long* chunk_off;  // [slots][nchunks][16] exclusive prefix of chunk_tot (tables stay chunk-local)
-  int64_t* gmm8;            // [slot][ceil(mcap/64)][2 LP] per 64-row group of the chunk-local table: max[LP], min[LP]
   uint32_t* fast_reject;    // [G] first rejected pod of the group (only maintained for BS_BATCH_COMMIT)
   // BS_BATCH_HOST_RESULTS: mirrors of the results in pinned host memory, written by the last launch (null = off)
   uint8_t* h_pf_code; uint32_t* h_pf_first_k; int32_t* h_pf_leader; uint8_t* h_fl_code; uint32_t* h_fl_feasible; uint32_t* h_fl_slot;
   uint32_t* h_admit; uint8_t* h_ready; uint32_t* h_feas; uint64_t* h_rows; int32_t* h_tag; uint32_t hstride;
-  uint32_t* tticket;        // [slots] per-table tickets of the chunk-local table build (self-resetting)
   uint32_t* epoch_group;    // [E+1] group captured at epoch e (e >= 1)
   // outputs
   uint8_t* pf_code;

@@ -124,7 +124,7 @@ struct bs_ctx {
   // fast path (bs_fast.hpp)
   DevBuf d_order_rank, d_sort;         // queue ordering: per-group order ranks; inputs | index ping-pong | permutation
   uint32_t order_g = 0;
-  DevBuf d_gstat, d_ppair, d_pair_next, d_pair_firstq, d_first_reach, d_qstamp_s, d_chunk_off, d_gmm8, d_fast_reject, d_tticket, d_epoch_group;
+  DevBuf d_gstat, d_ppair, d_pair_next, d_pair_firstq, d_first_reach, d_qstamp_s, d_fast_reject, d_epoch_group;
   bool pairs_ready = false;          // d_gstat / pairs match the loaded pods and G
   bool bitmap_valid = false;         // d_fl_bitmap holds the expanded rows of the last batch
   bool last_fast = false;
@@ -344,10 +344,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.pair_next = c->d_pair_next.as<unsigned long long>();
   b.pair_firstq = c->d_pair_firstq.as<unsigned long long>();
   b.first_reach64 = c->d_first_reach.as<unsigned long long>();
-  b.chunk_off = c->d_chunk_off.as<unsigned long long>();
-  b.gmm8 = c->d_gmm8.as<int64_t>();
   b.fast_reject = c->d_fast_reject.as<uint32_t>();
-  b.tticket = c->d_tticket.as<uint32_t>();
   b.epoch_group = c->d_epoch_group.as<uint32_t>();
   uint8_t* ok = c->d_outpack.as<uint8_t>();
   b.pf_code = ok + c->off_pf_code;
@@ -398,12 +395,6 @@ int ensure_tables(bs_ctx* c) {
   HIPCHK(c, c->d_chunk_tot.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
   HIPCHK(c, c->d_gmax.reserve((size_t)slots * cdiv(c->Ncap, 64) * c->LP * 8));
   HIPCHK(c, c->d_chunk_kp.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 4));
-  HIPCHK(c, c->d_chunk_off.reserve((size_t)slots * cdiv(c->Ncap, 256) * 16 * 8));
-  HIPCHK(c, c->d_gmm8.reserve((size_t)slots * cdiv(c->Ncap, 64) * 2 * c->LP * 8));
-  {
-    int rc = reserve_filled(c, c->d_tticket, (size_t)slots * 4, 0);
-    if (rc) return rc;
-  }
   HIPCHK(c, c->d_desc.reserve((size_t)slots * sizeof(TableDesc)));
   HIPCHK(c, c->d_needed.reserve((size_t)(2 * c->C + 1) * 4));
   HIPCHK(c, c->d_qcount.reserve(16));
@@ -1489,8 +1480,6 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   bt.kp = b.kp + (size_t)side_slot * 16;
   bt.chunk_tot = b.chunk_tot + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
   bt.chunk_kp = b.chunk_kp + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
-  bt.chunk_off = b.chunk_off + (size_t)side_slot * cdiv(c->Ncap, 256) * 16;
-  bt.gmm8 = b.gmm8 + (size_t)side_slot * cdiv(c->Ncap, 64) * 2 * prm.LP;
   bt.gmax = b.gmax + (size_t)side_slot * cdiv(c->Ncap, 64) * prm.LP;
   const TableDesc* forced = b.desc + side_slot;
   const int ts = c->S <= 4 ? (int)c->S : -1;

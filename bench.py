@@ -405,8 +405,8 @@ def main():
             for sc in ("cold", "warm", "busy"):
                 n2, f2, g2, p2, _ = synth.make(args.config, sc, seed=args.seed)
                 ms, st = resident_ms(bsa, n2, f2, g2, p2, stages, 100)
-                extras[sc] = {"ms_per_step": ms, "evals_per_s": p2.p * n2.n / (ms * 1e-3), "fast_path": st["fast_path"], "launches": st["launches"],
-                              "class_mode": st["class_mode"]}
+                extras[sc] = {"ms_per_step": ms, "evals_per_s": p2.p * n2.n / (ms * 1e-3), "fast_path": st["fast_path"], "chain": st["chain"],
+                              "launches": st["launches"], "class_mode": st["class_mode"]}
             p3 = all_pods.copy()
             p3.req[0, :] += np.arange(p3.p, dtype=np.int64)            # every pod asks for something else: no request is shared
             ms, st = resident_ms(bsa, nodes, fit, groups, p3, stages, 60)
@@ -435,8 +435,9 @@ def main():
                                        + ", 1 all-reduce of admit[G]") if dist is not None else "single GPU",
                        "value_definition": "logical pods x nodes per step / step time; a step re-runs the whole path (table build, PreFilter, Filter, tally, quorum) over a "
                                            "batch resident in HBM; request classes and per-group pod minima are derived at bs_pods_load, findMaxPG at bs_groups_load / "
-                                           "bs_groups_apply (both inside host_cycle, not inside value)",
-                       "logical_evals_per_step": logical, "fast_path": stats["fast_path"], "launches_per_step": stats["launches"],
+                                           "bs_groups_apply, capture epochs / findMaxPG per epoch of a positional state when the later of groups and pods arrives (all inside "
+                                           "host_cycle, not inside value)",
+                       "logical_evals_per_step": logical, "fast_path": stats["fast_path"], "chain": stats["chain"], "launches_per_step": stats["launches"],
                        "tables_built": stats["tables_built"],
                        "decisions": {soa.PF_NAMES.get(i, str(i)): int(c) for i, c in enumerate(codes) if c},
                        "groups_ready": int(out.group_ready.sum())},

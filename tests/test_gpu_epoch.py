@@ -104,6 +104,9 @@ def test_positional_chain_is_the_common_case_on_mixed_scenes(bsa, soa, orc):
     assert taken >= 6
 
 
+_TAKEN = []
+
+
 @pytest.mark.parametrize("seed", range(9200, 9230))
 def test_random_object_scenes_positional_vs_general(seed, monkeypatch, bsa, soa, orc):
     """The object-level random scenes of the parity suite (captures, defaults, owners, denied groups, permitted pods):
@@ -111,10 +114,14 @@ def test_random_object_scenes_positional_vs_general(seed, monkeypatch, bsa, soa,
     sc = random_objects(seed, n_nodes=80 + seed % 150, n_groups=12, n_pods=260, n_scalars=seed % 3, n_classes=4)
     nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"],
                                             denied=sc["denied"], permitted=sc["permitted"])
+    if seed % 2:
+        pods = _share_templates(pods, np.random.default_rng(seed + 1))        # few request classes: the chain takes the batch
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
     rng = np.random.default_rng(seed)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
         assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"seed {seed}")
+        if seed % 2:
+            _TAKEN.append(ctx.stats(soa.STAGE_ALL)["chain"])
         cur = groups.copy()
         for rnd in range(3):                                      # per-cycle patches: matched / scheduled / deny flags
             idx = rng.choice(groups.g, 4, replace=False)
@@ -132,6 +139,10 @@ def test_random_object_scenes_positional_vs_general(seed, monkeypatch, bsa, soa,
         assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"seed {seed} general")
 
 
+def test_random_object_scenes_mostly_take_the_positional_chain():
+    assert len(_TAKEN) == 15 and sum(c == 2 for c in _TAKEN) >= 8, _TAKEN
+
+
 def test_pod_reload_between_batches(bsa, soa, orc):
     nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "cold")
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
@@ -141,3 +152,65 @@ def test_pod_reload_between_batches(bsa, soa, orc):
             exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(sub, soa.STAGE_ALL)
             assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"reload {k}")
             assert ctx.stats(soa.STAGE_ALL)["chain"] == 2
+
+
+def test_node_churn_between_positional_batches(bsa, soa, orc):
+    """BASELINE config 5's node events on a cold snapshot: the analysis of (groups, pods) stays, the tables are rebuilt from
+    the patched node list in every batch."""
+    from test_gpu_parity import _churn
+    _churn(bsa, soa, orc, "cfg2", "cold", rounds=6, events=30, stages=soa.STAGE_ALL, seed=15)
+
+
+def _share_templates(pods, rng):
+    """Pods of a gang share a template in real queues (that is what request classes live on); the object-level random
+    scenes draw every pod's request on its own.  Give every group two templates (two of its own pods' requests)."""
+    req, pres = pods.req.copy(), pods.req_present.copy()
+    for g in np.unique(pods.group[pods.group >= 0]):
+        idx = np.nonzero(pods.group == g)[0]
+        reps = rng.choice(idx, 2)
+        pick = reps[rng.integers(0, 2, idx.size)]
+        req[:, idx] = pods.req[:, pick]
+        pres[idx] = pods.req_present[pick]
+    pods.req[:, :] = req
+    pods.req_present[:] = pres
+    return pods
+
+
+def _widen(soa, nodes, groups, pods, S, rng):
+    """The same scene on 4 + S resource lanes: extra scalar keys with random presence and small random amounts (pods of a
+    gang keep sharing their template: the extra lanes are a function of the pod's group)."""
+    L0, L = nodes.lanes, 4 + S
+    if L <= L0:
+        return nodes, groups, pods
+    n, g, p = nodes.n, groups.g, pods.p
+    extra = ((1 << S) - 1) & ~((1 << (L0 - 4)) - 1)
+    def grow(a, cols, hi):
+        return np.concatenate([a, rng.integers(0, hi, size=(L - L0, cols)).astype(np.int64)], 0)
+    nodes2 = soa.Nodes(grow(nodes.allocatable, n, 64), grow(nodes.requested, n, 24),
+                       nodes.allocatable_present | (rng.integers(0, 1 << S, n).astype(np.uint32) & np.uint32(extra)),
+                       nodes.requested_present | (rng.integers(0, 1 << S, n).astype(np.uint32) & np.uint32(extra)), nodes.flags.copy())
+    gx = rng.integers(0, 3, size=(L - L0, g)).astype(np.int64)
+    gp = rng.integers(0, 1 << S, g).astype(np.uint32) & np.uint32(extra) & np.where(rng.random(g) < 0.5, 0xFFFFFFFF, 0).astype(np.uint32)
+    groups2 = soa.Groups(groups.min_member, groups.status_scheduled, groups.matched, groups.flags, groups.cls,
+                         np.concatenate([groups.min_resources, gx], 0), groups.min_resources_present | gp, groups.occupied_by)
+    gi = np.clip(pods.group, 0, g - 1)
+    pods2 = soa.Pods(pods.group, np.concatenate([pods.req, gx[:, gi]], 0), pods.req_present | gp[gi], pods.cls, pods.owner, pods.flags)
+    return nodes2, groups2.copy(), pods2.copy()
+
+
+@pytest.mark.parametrize("n_scalars", [0, 2, 5, 12])
+def test_positional_chain_with_scalar_lanes(n_scalars, bsa, soa, orc):
+    """Scalar resource lanes 0 / 2 (compile-time shapes), 5 and 12 (wider rows, LP = 16) through the positional chain."""
+    taken = 0
+    for seed in (9300, 9301, 9302):
+        sc = random_objects(seed, n_nodes=140, n_groups=10, n_pods=300, n_scalars=min(n_scalars, 2), n_classes=3)
+        nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"],
+                                                denied=sc["denied"], permitted=sc["permitted"])
+        pods = _share_templates(pods, np.random.default_rng(seed + 1))
+        nodes, groups, pods = _widen(soa, nodes, groups, pods, n_scalars, np.random.default_rng(seed))
+        assert nodes.lanes == 4 + n_scalars
+        exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+        with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"S={n_scalars} seed {seed}")
+            taken += ctx.stats(soa.STAGE_ALL)["chain"] == 2
+    assert taken >= 1
