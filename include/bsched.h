@@ -252,8 +252,10 @@ typedef struct bs_batch_out {
    *   fl_code[pod] == BS_FL_EVALUATED ? bit (node&63) of fl_rows[(node>>6) * fl_rows_cap + fl_slot[pod]]
    *                                   : fl_code[pod] < 16        (every node / no node)
    * so the Go plugin's Filter is a bit test with no cgo crossing.  Pods with equal derived requests share
-   * a row; when a first-pod capture or MinResources default can still happen in the batch a row is the
-   * pod itself (fl_slot[pod] == pod). */
+   * a row: (request class, leader seen) in steady state, (leader run, request class) while first-pod captures
+   * or MinResources defaults can still happen in the batch (single rank, what-if batch); on the general
+   * chain (BS_BATCH_COMMIT of such a state, several ranks) a row is the pod itself (fl_slot[pod] == pod).
+   * Rows no pod of the batch refers to are unspecified.  bs_filter_rows_count never exceeds p. */
   uint32_t* fl_slot;          /* [p] row of pod p; meaningful iff fl_code[p] == BS_FL_EVALUATED        */
   uint64_t* fl_rows;          /* [ceil(n/64)][fl_rows_cap] word-major; rows >= *fl_rows_n untouched     */
   uint32_t* fl_rows_feasible; /* [fl_rows_cap] feasible-node count per row (NULL ok)                    */
@@ -272,7 +274,7 @@ typedef struct bs_batch_out {
                                      returns (per-pod arrays, admit, ready, Filter rows) straight into pinned host memory;
                                      bs_batch_read then needs no device-to-host copy and no stream wait — it polls a
                                      completion word.  Honoured on the steady-state chain of a single-rank context; a
-                                     no-op (results are copied as usual) elsewhere.  Costs the batch a few microseconds
+                                     no-op (results are copied as usual) elsewhere (positional and general chain).  Costs the batch a few microseconds
                                      of PCIe writes, so throughput runs leave it off. */
 
 /* ---- lifecycle ------------------------------------------------------------------- */
