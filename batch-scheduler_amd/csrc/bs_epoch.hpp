@@ -30,6 +30,7 @@
 //   launch B  k_epoch_scan_filter    node scan per live scan slot | computeResourceSatisfied per Filter slot x node
 //   launch C  k_epoch_final          REJECT / deny replay / stale leader, Filter code + slot + feasible count per
 //                                    pod, per-group admit counts, last block: quorum predicate core.go:303
+//   (BS_BATCH_COMMIT: + k_epoch_reject_groups + k_commit, then the analysis is redone for the committed state)
 #pragma once
 
 #include "bs_fast.hpp"
@@ -538,6 +539,13 @@ __device__ __forceinline__ uint32_t epoch_first_reject(const BatchDev& b, const 
     }
   }
   return fr;
+}
+
+// BS_BATCH_COMMIT: what k_commit needs besides the analysis — the group's first rejected pod (its deny entry, core.go:142,163)
+__global__ void k_epoch_reject_groups(GroupsDev gr, BatchDev b, BatchParams prm, EpochDev ep, uint32_t P) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= gr.g) return;
+  b.first_reject[g] = b.first_elig[g] != BS_INF ? epoch_first_reject(b, prm, ep, P, g) : BS_INF;
 }
 
 __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, EpochDev ep) {

@@ -1530,6 +1530,32 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
 // The positional chain (bs_epoch.hpp): three launches for batches in which captures, MinResources defaults or a leader
 // without matched pods make a pod's decision depend on its queue position.  `taken` = false: the analysis says this batch
 // is not for this chain (too many leader runs, slot capacity) and nothing was launched.
+// After k_commit / k_fast_commit changed the group state on the device: the leader carried into the next batch and the
+// host's view of the flags (captures / MinResources defaults may be gone now).
+static int commit_readback(bs_ctx* c, const GroupsDev& gr, const BatchDev& b) {
+  const uint32_t P = c->P, G = c->G;
+  std::vector<uint32_t> cls(G);
+  if (P) {
+    int32_t last = -1;
+    HIPCHK(c, hipMemcpyAsync(&last, b.pf_leader + (P - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->sop_leader0 = last;
+  }
+  if (G) {
+    HIPCHK(c, hipMemcpy(c->h_gflags.data(), gr.flags, G, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cls.data(), gr.cls, (size_t)G * 4, hipMemcpyDeviceToHost));
+  }
+  c->n_uncaptured = 0;
+  c->n_nominres = 0;
+  c->max_group_cls = 0;
+  for (uint32_t i = 0; i < G; ++i) {
+    if (!(c->h_gflags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+    else c->max_group_cls = std::max(c->max_group_cls, cls[i]);
+    if (!(c->h_gflags[i] & BS_GROUP_HAS_MINRES)) c->n_nominres++;
+  }
+  return BS_OK;
+}
+
 static int run_epoch(bs_ctx* c, uint32_t stages, bool* taken) {
   int rc;
   *taken = false;
@@ -1614,6 +1640,17 @@ static int run_epoch(bs_ctx* c, uint32_t stages, bool* taken) {
   // ---- launch C: final codes, stale leader, Filter code / slot / feasible count per pod, admit counts, quorum
   TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_epoch_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, ep));
   c->launches = 3;
+  if (stages & BS_BATCH_COMMIT) {
+    // persist what the sequential PreFilter calls would have left behind (k_commit): captures and MinResources defaults from
+    // the analysis, OccupiedBy, and the deny entries = every group's first rejected pod
+    hipLaunchKernelGGL(k_epoch_reject_groups, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, gr, b, prm, ep, P);
+    hipLaunchKernelGGL(k_commit, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, pd, b, prm, const_cast<uint8_t*>(gr.flags), const_cast<uint32_t*>(gr.cls),
+                       const_cast<int64_t*>(gr.minres), const_cast<uint32_t*>(gr.mrpres), const_cast<uint64_t*>(gr.occupied), G);
+    LAUNCHCHK(c, BS_KERNEL_RESOLVE);
+    c->launches = 5;
+    if ((rc = commit_readback(c, gr, b))) return rc;
+    if ((rc = analyse_groups(c))) return rc;              // (findMaxPG for the committed state; the positional analysis is redone by whoever needs it)
+  }
   return batch_collective(c, stages, gr, b);
 }
 
@@ -1666,8 +1703,8 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     return rc;
   }
   // ---- positional state on one rank: the three-launch chain over (view, class) and group slots
-  if (!c->no_fast && !c->no_epoch && !c->no_fuse_filter && P && G && N && c->M && c->nranks == 1 && !c->reduce_external && !(stages & BS_BATCH_COMMIT) &&
-      !early_filter && c->cfg.enable_timing < 2) {
+  if (!c->no_fast && !c->no_epoch && !c->no_fuse_filter && P && G && N && c->M && c->nranks == 1 && !c->reduce_external && !early_filter &&
+      c->cfg.enable_timing < 2) {
     bool taken = false;
     rc = run_epoch(c, stages, &taken);
     if (rc) return rc;
@@ -1867,26 +1904,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
                               const_cast<int64_t*>(gr.minres), const_cast<uint32_t*>(gr.mrpres), const_cast<uint64_t*>(gr.occupied), G);
     LAUNCHCHK(c, BS_KERNEL_RESOLVE);
     launches++;
-    std::vector<uint32_t> cls(G);
-    if (P) {
-      int32_t last = -1;
-      HIPCHK(c, hipMemcpyAsync(&last, b.pf_leader + (P - 1), 4, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      c->sop_leader0 = last;
-    }
-    // the committed capture may have given every group a pod
-    if (G) {
-      HIPCHK(c, hipMemcpy(c->h_gflags.data(), gr.flags, G, hipMemcpyDeviceToHost));
-      HIPCHK(c, hipMemcpy(cls.data(), gr.cls, (size_t)G * 4, hipMemcpyDeviceToHost));
-    }
-    c->n_uncaptured = 0;
-    c->n_nominres = 0;
-    c->max_group_cls = 0;
-    for (uint32_t i = 0; i < G; ++i) {
-      if (!(c->h_gflags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
-      else c->max_group_cls = std::max(c->max_group_cls, cls[i]);
-      if (!(c->h_gflags[i] & BS_GROUP_HAS_MINRES)) c->n_nominres++;
-    }
+    if ((rc = commit_readback(c, gr, b))) return rc;      // the committed capture may have given every group a pod
     commit_dirty = true;
   }
   c->launches = launches;

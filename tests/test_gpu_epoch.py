@@ -82,7 +82,7 @@ def test_mixed_positional_scenes(seed, monkeypatch, bsa, soa, orc):
         if st["chain"] == 2:
             assert st["launches"] == 3
         _check_all_stage_sets(ctx, nodes, fit, groups, pods, soa, orc, f"seed {seed}")
-        # a committing batch takes the general chain and must leave the sequential reference's state behind
+        # a committing batch (same chain + k_commit) must leave the sequential reference's state behind
         sop = orc.Sop(orc.Snapshot(nodes, fit), groups)
         exp_c = sop.batch(pods, soa.STAGE_ALL)
         assert_batch_equal(ctx.batch(soa.STAGE_ALL | soa.BATCH_COMMIT), exp_c, f"seed {seed} commit")
