@@ -1,5 +1,7 @@
-"""Launch-geometry sweep of the general chain (GPU box): BS_TARGET_WAVES / BS_FILTER_WAVES vs the scan / Filter kernel times."""
+"""Launch-geometry sweep of the GENERAL chain (GPU box): BS_TARGET_WAVES / BS_FILTER_WAVES vs the scan / Filter kernel times.
+Cold batches take the positional chain (bs_epoch.hpp) by default; BS_NO_EPOCH=1 keeps them on the chain this tool tunes."""
 import importlib, time, sys, os
+os.environ["BS_NO_EPOCH"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 bsa = importlib.import_module("batch-scheduler_amd"); soa = bsa.soa
 for cfg, sc in (("cfg3", "cold"), ("cfg4", "cold")):
