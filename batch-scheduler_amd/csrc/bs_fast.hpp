@@ -369,6 +369,12 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
   __shared__ uint32_t s_last, s_first_reach;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  // the pod's own fields travel while the block finds the first reaching pod (one round trip for both)
+  uint8_t code0 = 0, st0 = 0;
+  int32_t gi0 = BS_POD_NOT_GROUPED;
+  uint32_t qpos0 = 0, pclass0 = 0;
+  if (i < pods.p) { code0 = b.tcode[i]; st0 = b.stage[i]; gi0 = pods.group[i]; qpos0 = b.qpos[i]; pclass0 = b.pclass[i]; }
   // first pod that reaches findMaxPG = the candidate of the first block of launch A that has one (64 blocks per look)
   if (threadIdx.x < 64) {
     uint32_t found = BS_INF;
@@ -385,13 +391,12 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     if (threadIdx.x == 0) s_first_reach = found;
   }
   __syncthreads();
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   bool admit = false;
   uint32_t ag = 0;
   if (i < pods.p) {
-    uint8_t code = b.tcode[i];
-    const uint8_t st = b.stage[i];
-    const int32_t gi = pods.group[i];
+    uint8_t code = code0;
+    const uint8_t st = st0;
+    const int32_t gi = gi0;
     const uint32_t first_reach = s_first_reach;
     uint32_t fk = BS_K_NOT_SCANNED;
     if (st & ST_OWNED) {
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
       }
       if (denied) code = BS_PF_ERR_DENIED;
       else if (st & ST_QUERY) {
-        const uint32_t row = b.first_row[b.qpos[i]];
+        const uint32_t row = b.first_row[qpos0];
         if (row == BS_INF) { code = BS_PF_REJECT_RESERVE; fk = BS_K_NONE; }                // core.go:161-165
         else fk = nd.kmap[row];
       }
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
         else if (gi < 0 || (uint32_t)gi >= gr.g) fl = BS_FL_ERR_PG_NOT_FOUND;              // :177-180
         else if (leader < 0) fl = BS_FL_PANIC_NIL_MAX;                                     // :525
         else if (leader == gi) fl = BS_FL_PASS_IS_MAX;                                     // :531-535
-        else { fl = BS_FL_EVALUATED; slot = b.pclass[i] + (reached ? 0u : *b.kclass); }    // every group has MinResources here
+        else { fl = BS_FL_EVALUATED; slot = pclass0 + (reached ? 0u : *b.kclass); }        // every group has MinResources here
       }
       feasible = fl == BS_FL_EVALUATED ? b.fu_feas[slot] : (fl < 16u ? nd.n : 0u);
       b.fu_slot[i] = slot;

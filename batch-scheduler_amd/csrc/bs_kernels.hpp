@@ -1341,20 +1341,22 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
     const uint32_t rest = w / ntl, tile = t_lo + (w - rest * ntl);
     const uint32_t share = rest / tsplit, ts = rest - share * tsplit;
     const uint32_t pos = tile * 64u + (uint32_t)lane;
-    int32_t tab = pos < nslots ? b.qtab_s[pos] : -1;
-    if (prm.stamp) {                             // fast path: a slot is live iff a pod of THIS batch wrote it
-      if (pos < nslots && b.qstamp_s[pos] != prm.stamp) tab = -1;
-    }
-    unsigned long long todo = __ballot(tab >= 0);
-    if (!todo) continue;
+    // table, stamp, request and flags of the slot in ONE round trip (a dead slot's request is loaded for nothing)
+    const uint32_t ps = min(pos, nslots - 1u);
+    int32_t tab = b.qtab_s[ps];
+    const uint32_t stp = prm.stamp ? b.qstamp_s[ps] : 0u;
     int64_t r[1][L];
-    uint32_t qf = 0;
-    if (tab >= 0) {
-      const int64_t* src = b.qreq_s + (size_t)pos * LP;
+    {
+      const int64_t* src = b.qreq_s + (size_t)ps * LP;
 #pragma unroll
       for (int j = 0; j < L; ++j) r[0][j] = src[j];
-      qf = b.qflags_s[pos];
-    } else {
+    }
+    uint32_t qf = b.qflags_s[ps];
+    if (pos >= nslots || stp != prm.stamp) tab = -1;   // fast path: a slot is live iff a pod of THIS batch wrote it (stamp 0: every slot the pre-pass left >= 0)
+    unsigned long long todo = __ballot(tab >= 0);
+    if (!todo) continue;
+    if (tab < 0) {
+      qf = 0;
 #pragma unroll
       for (int j = 0; j < L; ++j) r[0][j] = INT64_MAX;
     }
@@ -1649,15 +1651,44 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
   // unless the tile straddles a first-pod capture.)  Then case 3 is one mask per node block.
   const bool mine = (uint32_t)lane < np;
   const uint32_t src = p0 + (uint32_t)lane;                       // lanes are request slots
+  // Everything this item needs from memory before it can compare is issued in ONE round trip: the slot's flags word, its
+  // request R and leader request M, the cluster-wide bounds, and the first two node blocks (they do not depend on the
+  // slots; a tile without a live slot has loaded them for nothing, which costs less than a second trip costs the rest).
   uint32_t myff = mine ? b.uflags[src] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  int64_t M[4] = {0, 0, 0, 0}, myR[4] = {0, 0, 0, 0};
+  if (mine) {
+    const int64_t* rs = b.uparams + (size_t)src * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { myR[j] = rs[j]; M[j] = rs[4 + j]; }
+  }
+  int64_t gl[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gl[j] = nd.lglob[j];
+  // node blocks are double-buffered: the loads of step w+NB are in flight during the pod loop of step w
+  int64_t l[NB][4], ln[NB][4];
+  uint8_t nfl[NB], nfln[NB];
+  auto load_blocks = [&](uint32_t w, int64_t (&dst)[NB][4], uint8_t (&fl)[NB]) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const uint32_t n = (w + nb) * 64u + (uint32_t)lane;
+      const bool nvalid = (w + nb) < w1 && n < nd.n;
+      fl[nb] = 0xFF;                                    // invalid
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[nb][j] = INT64_MIN;
+      if (nvalid) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[nb][j] = nd.left4[(size_t)j * nd.stride + n];
+        fl[nb] = nd.flags[n];
+      }
+    }
+  };
+  load_blocks(w0, l, nfl);
   if (stamp) myff = (myff >> 16) == stamp ? (myff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
   const uint32_t myfl = myff >> 8;
   const bool ev = myfl == BS_FL_EVALUATED;
-  int64_t M[4] = {0, 0, 0, 0};
-  if (ev) {
-    const int64_t* ms = b.uparams + (size_t)src * 8 + 4;
+  if (!ev) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) M[j] = ms[j];
+    for (int j = 0; j < 4; ++j) M[j] = 0;
   }
   __shared__ int64_t s_R[4][64][4];               // per wave: the tile's requests (pod + maxSingle, fixed lanes)
   __builtin_amdgcn_wave_barrier();                // the previous item of this wave is done with its slice
@@ -1666,15 +1697,6 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
   uint32_t lane_mask = 0;          // bit j: lane j must be compared
   bool tile_allfail = false;       // some lane fails for every (pod, node): case 2 never holds
   {
-    int64_t myR[4] = {0, 0, 0, 0};
-    if (mine) {
-      const int64_t* rs = b.uparams + (size_t)src * 8;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) myR[j] = rs[j];
-    }
-    int64_t gl[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) gl[j] = nd.lglob[j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s_R[wave_id()][lane][j] = myR[j];
     __builtin_amdgcn_wave_barrier();               // same wave writes and reads: LDS is in order, keep the compiler honest
@@ -1709,25 +1731,6 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
   crow_t FP = as_const_rows(b.uparams);
   cflag_t FF = (cflag_t)(uintptr_t)b.uflags;
   uint32_t cnt = 0;
-  // node blocks are double-buffered: the loads of step w+NB are in flight during the pod loop of step w
-  int64_t l[NB][4], ln[NB][4];
-  uint8_t nfl[NB], nfln[NB];
-  auto load_blocks = [&](uint32_t w, int64_t (&dst)[NB][4], uint8_t (&fl)[NB]) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const uint32_t n = (w + nb) * 64u + (uint32_t)lane;
-      const bool nvalid = (w + nb) < w1 && n < nd.n;
-      fl[nb] = 0xFF;                                    // invalid
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dst[nb][j] = INT64_MIN;
-      if (nvalid) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[nb][j] = nd.left4[(size_t)j * nd.stride + n];
-        fl[nb] = nd.flags[n];
-      }
-    }
-  };
-  load_blocks(w0, l, nfl);
   for (uint32_t w = w0; w < w1; w += NB) {
     if (w + NB < w1) load_blocks(w + NB, ln, nfln);
     unsigned long long okmask[NB], in_range[NB], nlf[NB];
