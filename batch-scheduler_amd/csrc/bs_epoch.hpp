@@ -25,6 +25,9 @@
 //     findMaxPG result of the last pod at or before it that really got there: a block-local prefix maximum, and a
 //     backward search over earlier blocks only when the block's first pod did not get there itself.
 //
+// Several ranks: ownership as everywhere (all pods of a group on the rank of the group's first pod), decisions of owned pods
+// only, the quorum pass after the collective (k_ready) — a non-owned pod's "reached findMaxPG" stays the tentative one.
+//
 //   launch A  k_epoch_query_tables   per pod: decisions that need no scan, scan / Filter slots | chunk-local running
 //                                    sums of every table the loaded state can ask for (known at analysis time)
 //   launch B  k_epoch_scan_filter    node scan per live scan slot | computeResourceSatisfied per Filter slot x node
@@ -206,9 +209,11 @@ __device__ __forceinline__ void epoch_query_thread(const PodsDev& pods, const Gr
   Res q;
   res_zero(q, sh);
   if (valid) {
-    st = ST_OWNED;                                                     // single rank on this chain
     gi = pods.group[i];
     grouped = gi >= 0 && (uint32_t)gi < gr.g;
+    // shard ownership: all pods of a group live on the rank of the group's first pod
+    const uint32_t anchor = grouped ? b.first_pod[gi] : i;
+    if ((uint32_t)(((uint64_t)anchor * prm.nranks) / pods.p) == prm.rank) st |= ST_OWNED;
     if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                         // core.go:89-92
     else if (pods.flags[i] & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;      // :95-98
     else if (!grouped) code = BS_PF_ERR_PG_NOT_FOUND;                                      // :100-103
@@ -259,6 +264,7 @@ __device__ __forceinline__ void epoch_query_thread(const PodsDev& pods, const Gr
         }
       }
     }
+    if (!(st & ST_OWNED)) has_q = first_q = false;                    // another rank evaluates this pod
     if (has_q) st |= ST_QUERY;
     b.tcode[i] = code;
     b.stage[i] = st;
@@ -268,7 +274,7 @@ __device__ __forceinline__ void epoch_query_thread(const PodsDev& pods, const Gr
   // getting there (LAST_PERMITTED) sees what the latest earlier pod left: any run up to its own, or the carried-in one.
   if (prm.run_filter) {
     const uint32_t c = valid ? b.pclass[i] : 0u;
-    const bool may = valid && BS_PF_IS_PASS(code) && grouped;
+    const bool may = valid && (st & ST_OWNED) && BS_PF_IS_PASS(code) && grouped;
     const bool own = may && (st & ST_REACH6) && leader >= 0 && leader != gi && minres_visible(gr, b, (uint32_t)leader, i);
     const uint32_t fslot = run * ep.K + c;
     if (wave_elect_by_key(fslot, own)) filter_params_for<TS>(pods, gr, b, prm, i, code, leader, fslot, true, false);
@@ -562,11 +568,12 @@ __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr,
     gi = pods.group[i];
     uint32_t fk = BS_K_NOT_SCANNED;
     bool denied = false;
-    if (st & ST_ELIG) {
+    if ((st & ST_OWNED) && (st & ST_ELIG)) {
       const uint32_t fr = epoch_first_reject(b, prm, ep, pods.p, (uint32_t)gi);
       denied = fr < i;
     }
-    if (denied) code = BS_PF_ERR_DENIED;                                                   // core.go:105-110 replayed
+    if (!(st & ST_OWNED)) code = BS_PF_NOT_OWNED;                                          // (its reach status stays the tentative one)
+    else if (denied) code = BS_PF_ERR_DENIED;                                              // core.go:105-110 replayed
     else if (st & ST_QUERY) {
       const uint32_t row = b.first_row[b.qpos[i]];
       if (row == BS_INF) { code = code == BS_PF_PASS_FIRST_FITS ? BS_PF_REJECT_FIRST : BS_PF_REJECT_RESERVE; fk = BS_K_NONE; }   // :140-146, :161-165
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr,
         const uint8_t sj = b.stage[j];
         if (sj & ST_REACH6) {
           bool den = false;
-          if (sj & ST_ELIG) den = epoch_first_reject(b, prm, ep, pods.p, (uint32_t)pods.group[j]) < j;
+          if ((sj & ST_OWNED) && (sj & ST_ELIG)) den = epoch_first_reject(b, prm, ep, pods.p, (uint32_t)pods.group[j]) < j;
           if (!den) cand = j + 1u;
         }
       }
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr,
       rr = ep.run_of_epoch[e2];
     }
     b.pf_leader[i] = leader;
-    const bool pass = BS_PF_IS_PASS(code);
+    const bool pass = code != BS_PF_NOT_OWNED && BS_PF_IS_PASS(code);
     uint32_t feasible = 1u, slot = 0;
     uint8_t fl = BS_FL_NOT_RUN;
     if (prm.run_filter) {

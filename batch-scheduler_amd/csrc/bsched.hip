@@ -752,7 +752,7 @@ int analyse_epochs(bs_ctx* c) {
 // Both sides loaded and the state positional for sure (captures or MinResources defaults possible): analyse now, so the
 // first batch does not wait for it.  (A captured state whose leader has no matched pod is analysed by its first batch.)
 int maybe_analyse_epochs(bs_ctx* c) {
-  if (c->epochs_ready || c->no_fast || c->no_epoch || c->nranks != 1 || c->reduce_external) return BS_OK;
+  if (c->epochs_ready || c->no_fast || c->no_epoch) return BS_OK;
   if (!c->have_groups || !c->have_pods || !c->have_fit || !c->have_nodes || !c->pairs_ready || !c->P || !c->G) return BS_OK;
   if (c->n_uncaptured == 0 && c->n_nominres == 0) return BS_OK;
   return analyse_epochs(c);
@@ -1582,7 +1582,7 @@ static int run_epoch(bs_ctx* c, uint32_t stages, bool* taken) {
   prm.stamp = 1u + (c->batch_seq % 65535u);
   prm.seq_inv = ~c->batch_seq;
   prm.do_tally = (stages & BS_STAGE_TALLY) ? 1u : 0u;
-  prm.do_ready = prm.do_tally;
+  prm.do_ready = (prm.do_tally && c->nranks == 1 && !c->reduce_external) ? 1u : 0u;
   EpochDev ep{};
   ep.run_of_epoch = c->d_run_of_epoch.as<uint32_t>();
   ep.run_leader = c->d_run_leader.as<int32_t>();
@@ -1702,9 +1702,8 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     c->batch_seq++;
     return rc;
   }
-  // ---- positional state on one rank: the three-launch chain over (view, class) and group slots
-  if (!c->no_fast && !c->no_epoch && !c->no_fuse_filter && P && G && N && c->M && c->nranks == 1 && !c->reduce_external && !early_filter &&
-      c->cfg.enable_timing < 2) {
+  // ---- positional state: the three-launch chain over (view, class) and group slots
+  if (!c->no_fast && !c->no_epoch && !c->no_fuse_filter && P && G && N && c->M && !early_filter && c->cfg.enable_timing < 2) {
     bool taken = false;
     rc = run_epoch(c, stages, &taken);
     if (rc) return rc;

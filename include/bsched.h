@@ -253,8 +253,8 @@ typedef struct bs_batch_out {
    *                                   : fl_code[pod] < 16        (every node / no node)
    * so the Go plugin's Filter is a bit test with no cgo crossing.  Pods with equal derived requests share
    * a row: (request class, leader seen) in steady state, (leader run, request class) while first-pod captures
-   * or MinResources defaults can still happen in the batch (single rank); on the general chain (several
-   * ranks, more than four leader changes in one batch) a row is the pod itself (fl_slot[pod] == pod).
+   * or MinResources defaults can still happen in the batch; on the general chain (more than four leader
+   * changes in one batch) a row is the pod itself (fl_slot[pod] == pod).
    * Rows no pod of the batch refers to are unspecified.  bs_filter_rows_count never exceeds p. */
   uint32_t* fl_slot;          /* [p] row of pod p; meaningful iff fl_code[p] == BS_FL_EVALUATED        */
   uint64_t* fl_rows;          /* [ceil(n/64)][fl_rows_cap] word-major; rows >= *fl_rows_n untouched     */

@@ -214,3 +214,50 @@ def test_positional_chain_with_scalar_lanes(n_scalars, bsa, soa, orc):
             assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"S={n_scalars} seed {seed}")
             taken += ctx.stats(soa.STAGE_ALL)["chain"] == 2
     assert taken >= 1
+
+
+@pytest.mark.parametrize("scene", ["cold", "mixed"])
+def test_sharded_positional_batches(scene, monkeypatch, bsa, soa, orc):
+    """Replicated mode (bs_shard_set) on a positional state: every rank runs the positional chain over the whole queue and
+    reports its own groups' pods.  Decisions of owned pods equal the single-context batch, the admit counters of the ranks add up
+    to the single-context ones, and rank by rank EVERYTHING equals what the general chain reports for the same shard."""
+    if scene == "cold":
+        nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "cold")
+    else:
+        nodes, fit, groups, pods = _mixed_scene(bsa, soa, 9107, "cfg2")
+    parts = {}
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        single = ctx.batch(soa.STAGE_ALL)
+        reach_codes = [soa.PF_PASS_NO_MAX, soa.PF_PASS_FIRST_FITS, soa.PF_PASS_IS_MAX, soa.PF_PASS_RESERVE_FITS, soa.PF_REJECT_FIRST, soa.PF_REJECT_RESERVE]
+        for nranks in (2, 3):
+            admit = np.zeros(groups.g, np.uint32)
+            owned = np.zeros(pods.p, np.int32)
+            for r in range(nranks):
+                ctx.set_shard(r, nranks)
+                part = ctx.batch(soa.STAGE_ALL)
+                assert ctx.stats(soa.STAGE_ALL)["chain"] == 2
+                parts[(nranks, r)] = part
+                mine = part.pf_code != 0xFF
+                owned += mine
+                assert np.array_equal(part.pf_code[mine], single.pf_code[mine])
+                assert np.array_equal(part.pf_first_k[mine], single.pf_first_k[mine])
+                # the stale shared leader (and the Filter result that hangs on it) is a per-rank view while captures can occur
+                fresh = mine & np.isin(part.pf_code, reach_codes)
+                assert np.array_equal(part.pf_leader[fresh], single.pf_leader[fresh])
+                assert np.array_equal(part.fl_code[fresh], single.fl_code[fresh])
+                assert np.array_equal(part.fl_feasible[fresh], single.fl_feasible[fresh])
+                assert np.array_equal(part.fl_bitmap[:, fresh], single.fl_bitmap[:, fresh])
+                admit += part.group_admit
+            assert np.all(owned == 1), "every pod is evaluated by exactly one rank"
+            stale_free = not np.any((single.pf_code == soa.PF_PASS_LAST_PERMITTED))
+            if stale_free:
+                assert np.array_equal(admit, single.group_admit)
+        ctx.set_shard(0, 1)
+    monkeypatch.setenv("BS_NO_EPOCH", "1")
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        for (nranks, r), part in parts.items():
+            ctx.set_shard(r, nranks)
+            gen = ctx.batch(soa.STAGE_ALL)
+            assert ctx.stats(soa.STAGE_ALL)["chain"] == 0
+            for name in ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible", "fl_bitmap", "group_admit"):
+                assert np.array_equal(getattr(part, name), getattr(gen, name)), (nranks, r, name)
