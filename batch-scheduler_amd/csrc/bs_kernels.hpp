@@ -1,24 +1,29 @@
-// bs_kernels.hpp — gfx950 kernels of the batched PreFilter / Filter / Permit path.
+// bs_kernels.hpp — gfx950 kernels of the batched PreFilter / Filter / Permit path: the shared work loops (node scan,
+// Filter evaluation, table build for the single-query entry points) and the GENERAL chain.
 //
-// Pipeline of one batch (bs_batch_run); steady state = 6 launches on one stream (the table build rides in
-// the first two: k_prepass_tables, k_query_tables):
+// A batch (bs_batch_run) takes one of three chains:
+//   steady state   bs_fast.hpp    three launches; every gang has its pod and MinResources, the leader has matched pods
+//   positional     bs_epoch.hpp   three launches; first-pod captures / MinResources defaults / leader without matched pods
+//   general        this file      what is left: more than four leader runs in one batch, early Filter, BS_NO_FAST / BS_NO_EPOCH
+// The three-launch chains use scan_core / scan_loop / filter_item / filter_loop / filter_params_for / tables_local_* from here.
+//
+// General chain, one stream:
 //   k_prepass   per-batch resets; per pod: eligibility (core.go:89-110), first eligible pod / first owner
 //               per group; LAST block: findMaxPG (core.go:701-739) when no first-pod capture can occur
-//   [k_init, k_epochs_a/b, k_leader   only when groups without a pod exist: capture epochs, one
-//               findMaxPG per epoch]
+//   [k_init, k_epochs_a/b, k_leader_scan   only when groups without a pod exist: capture epochs, findMaxPG per epoch]
 //   k_query     per pod: fillOccupiedObj check, branch A/B/C/D of core.go:127-166, request vector
 //               (getPreAllocatedResource core.go:774-793 [+ pod request :157-159]) into its request SLOT;
 //               class mode: also the Filter parameters of the pod's class into the Filter slots
-//   k_tables_local/fix   singleNodeResource (core.go:634-670) + running sums of core.go:602,621 per
-//               table, per-group maxima for pruning           [extra blocks of the two launches above in steady state]
+//   k_tables_local_nofix   singleNodeResource (core.go:634-670) + chunk-local running sums of core.go:602,621 per table in
+//               use, per-group maxima for pruning   [k_prepass_tables / k_query_tables: the one known table inside those launches]
 //   k_scan_filter   node scan "exists k : prefix_k >= request" (core.go:623), first such k, per scan slot,
 //               and computeResourceSatisfied (core.go:514-564) per Filter slot x node, in one launch
-//               [k_scan, k_filter: the same two work loops as separate launches when slot = pod or
-//               with early Filter]
+//               [k_scan, k_filter: the same two work loops as separate launches when slot = pod or with early Filter]
 //   k_reject/k_final   REJECT codes, deny-cache replay in queue order (core.go:105-110,142,163),
 //               stale sop.maxFinishedPG propagation, first_k -> node list index, Filter code + slot per pod
-//   k_filter_expand   every pod's bitmap row + feasible count from its slot's; per-group admit counts;
-//               last block: quorum predicate core.go:303, re-arm for the next batch   [k_tally when split]
+//   k_tally     per-pod feasible counts from the slots, per-group admit counts; last block: quorum predicate core.go:303,
+//               re-arm for the next batch
+//   k_filter_expand   only when a caller asks bs_batch_read for the pods x nodes bitmap: every pod's row from its slot's
 //
 // Request slots: pods of a gang share a template, so derived requests repeat; bs_pods_load builds request
 // classes (k_pod_class_a/b) and the batch evaluates each distinct request once (see BatchDev).
