@@ -261,3 +261,57 @@ def test_sharded_positional_batches(scene, monkeypatch, bsa, soa, orc):
             assert ctx.stats(soa.STAGE_ALL)["chain"] == 0
             for name in ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible", "fl_bitmap", "group_admit"):
                 assert np.array_equal(getattr(part, name), getattr(gen, name)), (nranks, r, name)
+
+
+def _ladder_scene(bsa, soa, steps, seed=4):
+    """A cold snapshot in which the leader changes `steps - 1` times inside the queue: the gangs arrive in group order and
+    each later one of the first `steps` has more progress than everything before it (core.go:721-724 strict '>')."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "cold", seed=seed)
+    order = np.argsort(np.where(pods.group < 0, 0, pods.group), kind="stable")        # queue in group order
+    pods = pods.take(order)
+    # eight request templates for the whole queue (few request classes: the slot count, not the run count, decides otherwise)
+    first = {int(g): int(np.nonzero(pods.group == g)[0][0]) for g in range(8)}
+    for i in np.nonzero(pods.group >= 0)[0]:
+        src = first[int(pods.group[i]) % 8]
+        pods.req[:, i] = pods.req[:, src]
+        pods.req_present[i] = pods.req_present[src]
+    groups.min_member[:steps] = 50
+    groups.matched[:steps] = np.arange(steps, dtype=np.uint32) * 3                    # progress 0, 60, 120, ... per mille
+    return nodes, fit, groups, pods
+
+
+# (the stretch before the first capture, with no leader at all, is a run of its own: `steps` leaders = steps + 1 runs)
+@pytest.mark.parametrize("steps,chain", [(2, 2), (3, 2), (4, 0), (9, 0)])
+def test_leader_ladder_and_the_run_limit(steps, chain, bsa, soa, orc):
+    nodes, fit, groups, pods = _ladder_scene(bsa, soa, steps)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    assert len(set(exp.pf_leader[exp.pf_leader >= 0].tolist())) >= steps - 1
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"ladder {steps}")
+        assert ctx.stats(soa.STAGE_ALL)["chain"] == chain           # more than four leader runs: the general chain takes the batch
+
+
+def test_every_pod_back_from_permit_and_a_panic_epoch(bsa, soa, orc):
+    """(a) every pod carries a live lastPermittedPod entry: nobody reaches findMaxPG, Filter runs against the leader carried
+    into the batch; (b) a gang with MinMember == 0 is captured in mid-queue: findMaxPG panics from that epoch on."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "cold", seed=8)
+    p2 = pods.copy()
+    p2.flags[:] |= soa.POD_LAST_PERMITTED
+    g2 = groups.copy()
+    g2.flags[3] |= soa.GROUP_HAS_POD | soa.GROUP_HAS_MINRES                 # somebody the carried-in leader can be
+    g2.min_resources[0, 3], g2.min_resources[1, 3] = 500, 1 << 30
+    sop = orc.Sop(orc.Snapshot(nodes, fit), g2)
+    warm = sop.batch(pods.take(np.arange(64)), soa.STAGE_ALL)               # leaves sop.maxFinishedPG behind
+    with load_ctx(bsa, nodes, fit, g2, pods.take(np.arange(64))) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL | soa.BATCH_COMMIT), warm, "first batch")
+        ctx.load_pods(p2)
+        exp = sop.batch(p2, soa.STAGE_ALL)
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "all permitted")
+    g3 = groups.copy()
+    g3.min_member[groups.g // 2] = 0
+    g3.status_scheduled[groups.g // 2] = 1                                   # uint32(MinMember - Scheduled) != 0 and MinMember == 0: divide by zero
+    exp = orc.Sop(orc.Snapshot(nodes, fit), g3).batch(pods, soa.STAGE_ALL)
+    assert (exp.pf_code == soa.PF_PANIC_DIV0).any() and (exp.pf_code == soa.PF_PASS_FIRST_FITS).any()
+    with load_ctx(bsa, nodes, fit, g3, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "panic epoch")
+        assert ctx.stats(soa.STAGE_ALL)["chain"] == 2
