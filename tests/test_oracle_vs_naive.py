@@ -96,3 +96,57 @@ def test_find_max_pg_and_prealloc(seed, orc, soa):
 def test_scale_hypothesis(a, pct_bits, orc):
     pct = float(np.uint32(pct_bits).view(np.float32))
     assert orc.scale(a, pct) == nv.scale(a, pct)
+
+
+# ---- structured positional scenes (the states the GPU's positional chain exists for): the C oracle and the independent
+# object-level restatement have to agree on them before the GPU is compared with the oracle (tests/test_gpu_epoch.py)
+def _check_scene(sc, orc, soa, what):
+    nodes, fit, groups, pods, _ = _flatten(sc)
+    out = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    ref = naive_batch(sc)
+    for name in ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible", "group_admit", "group_ready"):
+        assert getattr(out, name).tolist() == ref[name], (what, name)
+    return out
+
+
+def _cold(sc, rng, ladder):
+    """nothing seen yet: no group has its pod or MinResources; with `ladder`, later groups have more progress, so the leader
+    changes at their captures (core.go:721-724) and reservation checks follow the first checks"""
+    names = list(sc["cache"].keys())
+    for k, nm in enumerate(names):
+        pgs = sc["cache"][nm]
+        pgs.pod, pgs.scheduled = None, False
+        pgs.pod_group.min_resources = None
+        pgs.pod_group.status_scheduled = 0
+        pgs.pod_group.min_member = max(pgs.pod_group.min_member, 2) + 6
+        pgs.matched = (k if ladder else 0)
+    sc["denied"] = set()
+
+
+@pytest.mark.parametrize("seed", range(7000, 7040))
+def test_cold_start_and_leader_ladder_oracle_equals_naive(seed, orc, soa):
+    rng = np.random.default_rng(seed)
+    sc = random_objects(seed, n_nodes=30, n_groups=7, n_pods=70, n_scalars=seed % 3, n_classes=3)
+    _cold(sc, rng, ladder=bool(seed % 2))
+    if seed % 4 >= 2:                                            # queue in group order: one capture after the other
+        sc["pods"].sort(key=lambda p: (p.group is None, str(p.group)))
+    out = _check_scene(sc, orc, soa, f"cold {seed}")
+    reached = [c for c in out.pf_code.tolist() if c in (soa.PF_PASS_FIRST_FITS, soa.PF_REJECT_FIRST, soa.PF_PASS_RESERVE_FITS,
+                                                         soa.PF_REJECT_RESERVE, soa.PF_PASS_IS_MAX)]
+    assert reached, "the scene has to exercise findMaxPG"
+    if seed % 2 and seed % 4 >= 2:
+        assert len(set(out.pf_leader[out.pf_leader >= 0].tolist())) >= 2, "a ladder has to change the leader"
+
+
+@pytest.mark.parametrize("seed", range(7100, 7120))
+def test_permitted_queue_and_panic_epoch_oracle_equals_naive(seed, orc, soa):
+    sc = random_objects(seed, n_nodes=30, n_groups=6, n_pods=60, n_scalars=seed % 3, n_classes=3)
+    if seed % 2:
+        sc["permitted"] = {p.uid for p in sc["pods"]}            # nobody reaches findMaxPG: Filter sees the carried-in (nil) leader
+    else:
+        _cold(sc, np.random.default_rng(seed), ladder=False)
+        victim = list(sc["cache"].values())[3]
+        victim.pod_group.min_member, victim.pod_group.status_scheduled = 0, 1     # uint32(0 - 1) != 0, then / 0: core.go:716-717
+    out = _check_scene(sc, orc, soa, f"scene {seed}")
+    if seed % 2 == 0 and any(p.group == "ns/g3" for p in sc["pods"]):
+        assert (out.pf_code == soa.PF_PANIC_DIV0).any()
