@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libbsched.so")
 SOURCES = ["bsched.hip"]
-HEADERS = ["bs_common.hpp", "bs_kernels.hpp", "bs_fast.hpp", "bs_sort.hpp", "bs_fit.hpp", os.path.join("..", "..", "include", "bsched.h")]
+HEADERS = ["bs_common.hpp", "bs_kernels.hpp", "bs_fast.hpp", "bs_epoch.hpp", "bs_queue.hpp", "bs_sort.hpp", "bs_fit.hpp", os.path.join("..", "..", "include", "bsched.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

@@ -23,6 +23,7 @@ KERNEL_PREPASS, KERNEL_LEADER, KERNEL_QUERY, KERNEL_TABLES, KERNEL_SCAN, KERNEL_
 ABI_SYMBOLS = [
     "bs_abi_version", "bs_strerror", "bs_last_error", "bs_create", "bs_destroy",
     "bs_nodes_load", "bs_fit_load", "bs_fit_build", "bs_fit_read", "bs_groups_load", "bs_groups_read", "bs_groups_apply", "bs_pods_map", "bs_pods_load",
+    "bs_pods_apply", "bs_pods_count", "bs_pods_read", "bs_pods_apply_stats",
     "bs_nodes_apply", "bs_nodes_count",
     "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
     "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_filter_rows_count", "bs_queue_order_load", "bs_queue_sort",
@@ -97,6 +98,10 @@ def load_library(path: str | None = None):
     L.bs_filter_rows_count.argtypes = [vp, P(u32)]
     L.bs_pods_load.argtypes = [vp, P(soa.PodsStruct)]
     L.bs_pods_map.argtypes = [vp, u32, P(soa.PodsStruct)]
+    L.bs_pods_apply.argtypes = [vp, P(soa.PodsDeltaStruct)]
+    L.bs_pods_count.argtypes = [vp, P(u32)]
+    L.bs_pods_apply_stats.argtypes = [vp, P(C.c_uint64), P(C.c_uint64)]
+    L.bs_pods_read.argtypes = [vp, P(soa.PodsOutStruct)]
     L.bs_queue_order_load.argtypes = [vp, u32, P(u32)]
     L.bs_queue_sort.argtypes = [vp, u32, P(i32), P(i32), P(C.c_int64), P(u32)]
     L.bs_nodes_apply.argtypes = [vp, P(NodeDelta), u32]
@@ -268,6 +273,55 @@ class Context:
         st = pods.as_struct()
         self._chk(self._lib.bs_pods_load(self._h, C.byref(st)), "bs_pods_load")
         self.p = pods.p
+
+    def apply_pods(self, remove=(), flag_index=(), flag_value=(), insert: soa.Pods | None = None, insert_at=None):
+        """bs_pods_apply: patch the resident queue on the device (stable removals, flag updates, insertions)."""
+        rem = np.ascontiguousarray(remove, np.uint32)
+        fi = np.ascontiguousarray(flag_index, np.uint32)
+        fv = np.ascontiguousarray(flag_value, np.uint8)
+        assert fi.shape == fv.shape
+        d = soa.PodsDeltaStruct()
+        d.n_remove, d.remove = len(rem), _u32p(rem if len(rem) else np.zeros(1, np.uint32))
+        d.n_flags, d.flag_index = len(fi), _u32p(fi if len(fi) else np.zeros(1, np.uint32))
+        d.flag_value = (fv if len(fv) else np.zeros(1, np.uint8)).ctypes.data_as(C.POINTER(C.c_uint8))
+        keep = [rem, fi, fv]
+        if insert is not None and insert.p:
+            assert insert.req.shape[0] == self.L
+            d.insert = insert.as_struct()
+            if insert_at is not None:
+                at = np.ascontiguousarray(insert_at, np.uint32)
+                assert len(at) == insert.p
+                keep.append(at)
+                d.insert_at = _u32p(at)
+        self._chk(self._lib.bs_pods_apply(self._h, C.byref(d)), "bs_pods_apply")
+        self.p = self.pods_count()
+
+    def apply_pods_raw(self, delta: "soa.PodsDeltaStruct"):
+        """bs_pods_apply with a prebuilt struct (no per-call marshalling); the caller tracks p"""
+        self._chk(self._lib.bs_pods_apply(self._h, C.byref(delta)), "bs_pods_apply")
+
+    def apply_stats(self) -> tuple[int, int]:
+        a, r = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._lib.bs_pods_apply_stats(self._h, C.byref(a), C.byref(r)), "bs_pods_apply_stats")
+        return int(a.value), int(r.value)
+
+    def pods_count(self) -> int:
+        n = C.c_uint32(0)
+        self._chk(self._lib.bs_pods_count(self._h, C.byref(n)), "bs_pods_count")
+        return int(n.value)
+
+    def read_pods(self) -> soa.Pods:
+        """the resident queue (bs_pods_read)"""
+        p = self.pods_count()
+        out = soa.Pods.empty(max(p, 1), self.L)
+        st = soa.PodsOutStruct(p, *[getattr(out.as_struct(), k) for k in ("group", "req", "req_present", "cls", "owner", "flags")])
+        if p:
+            # the [L][p] lane stride must be p: read into exactly-sized arrays
+            out = soa.Pods.empty(p, self.L)
+            s2 = out.as_struct()
+            st = soa.PodsOutStruct(p, s2.group, s2.req, s2.req_present, s2.cls, s2.owner, s2.flags)
+        self._chk(self._lib.bs_pods_read(self._h, C.byref(st)), "bs_pods_read")
+        return out if p else soa.Pods.empty(0, self.L)
 
     def apply_node_deltas(self, deltas: list):
         arr = (NodeDelta * len(deltas))(*deltas)

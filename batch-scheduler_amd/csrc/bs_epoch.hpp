@@ -293,7 +293,7 @@ __device__ __forceinline__ void epoch_query_thread(const PodsDev& pods, const Gr
     b.qpos[i] = slot;
     const unsigned long long key = ((unsigned long long)prm.seq_inv << 32) | i;
     if (first_q) atomicMin(&ep.gfirstq[gi], key);
-    else atomicMin(&b.pair_firstq[(size_t)view * pods.p + b.ppair[i]], key);
+    else atomicMin(&b.pair_firstq[(size_t)view * b.pair_stride + b.ppair[i]], key);
   }
   if (fill) {
     uint32_t absok = 0;
@@ -537,7 +537,7 @@ __device__ __forceinline__ uint32_t epoch_first_reject(const BatchDev& b, const 
       const uint32_t r = (uint32_t)link, cls = (uint32_t)(link >> 32);
       link = b.pair_next[r];
       for (uint32_t v = 0; v < nv; ++v) {
-        const unsigned long long pq = b.pair_firstq[(size_t)v * P + r];
+        const unsigned long long pq = b.pair_firstq[(size_t)v * b.pair_stride + r];
         const uint32_t row = b.first_row[v * ep.K + cls];
         if ((uint32_t)(pq >> 32) != prm.seq_inv) continue;               // no pod of the pair asked with this view in this batch
         if (row == BS_INF) fr = min(fr, (uint32_t)pq);
@@ -556,7 +556,7 @@ __global__ void k_epoch_reject_groups(GroupsDev gr, BatchDev b, BatchParams prm,
 
 __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, EpochDev ep) {
   __shared__ uint32_t lds[16];
-  __shared__ uint32_t s_last, s_need_prev;
+  __shared__ uint32_t s_need_prev;
   const uint32_t base = blockIdx.x * 256u;
   const uint32_t i = base + threadIdx.x;
   uint8_t code = 0;
@@ -582,6 +582,7 @@ __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr,
     reached = (st & ST_REACH6) && !denied;
     b.pf_code[i] = code;
     b.pf_first_k[i] = fk;
+    if (prm.host_tag) { b.h_pf_code[i] = code; b.h_pf_first_k[i] = fk; }
   }
   // last pod at or before i that really reached findMaxPG (as index + 1, 0 = none)
   uint32_t v = reached ? i + 1u : 0u;
@@ -646,21 +647,15 @@ __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr,
     }
     b.fl_code[i] = fl;
     b.fflags[i] = (uint32_t)fl << 8;
+    if (prm.host_tag) { b.h_pf_leader[i] = leader; b.h_fl_code[i] = fl; b.h_fl_feasible[i] = prm.run_filter ? feasible : 0u; b.h_fl_slot[i] = slot; }
     if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) { admit = true; ag = (uint32_t)gi; }
   }
-  if (prm.do_tally) wave_aggregated_add(b.admit, ag, admit);
-  if (!prm.do_ready) return;
-  // drained ticket, agent-scope reads of the counters in the last block (see k_fast_final)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (uint32_t gg = threadIdx.x; gg < gr.g; gg += 256u) {
-    const uint32_t have = gr.matched[gg] + __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    b.ready[gg] = have >= (uint32_t)(gr.min_member[gg] - gr.status_scheduled[gg]) ? 1 : 0;
+  if (prm.host_tag && prm.run_filter) {             // per-row feasible counts of the (run, class) slots in use
+    const uint32_t U = min((ep.R + 1u) * ep.K, b.hstride);
+    for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
   }
+  if (prm.do_tally) wave_aggregated_add(b.admit, ag, admit);
+  final_tail(gr, b, prm);
 }
 
 }  // namespace bs

@@ -359,6 +359,54 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev
 }
 
 // ------------------------------------------------------------------------------------------------
+// The common end of a three-launch batch (k_fast_final, k_epoch_final; 256 threads per block): the LAST block to get here
+// evaluates the Permit quorum (core.go:303) from the admit counters and, in latency mode (BS_BATCH_HOST_RESULTS), mirrors
+// admit / ready into pinned host memory and publishes the completion word the host polls.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void final_tail(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm) {
+  __shared__ uint32_t s_last;
+  if (!prm.do_ready && !prm.host_tag) return;
+  // the admit counters are agent-scope atomics (performed at the coherence point, returned before vmcnt drains): a drained
+  // ticket orders them, the last block reads them back with agent-scope loads — no L2 write-back / invalidate per block
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // quorum pass: all loads of a batch of groups first, then the stores (one round trip per 8 x 256 groups, not one per 256)
+  constexpr int kQ = 8;
+  for (uint32_t g0 = 0; g0 < gr.g; g0 += kQ * 256u) {
+    uint32_t ad[kQ], ma[kQ], mm[kQ], sc[kQ];
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      const uint32_t gg = g0 + (uint32_t)u * 256u + threadIdx.x;
+      ad[u] = ma[u] = mm[u] = sc[u] = 0;
+      if (gg < gr.g) {
+        ad[u] = __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ma[u] = gr.matched[gg]; mm[u] = gr.min_member[gg]; sc[u] = gr.status_scheduled[gg];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kQ; ++u) {
+      const uint32_t gg = g0 + (uint32_t)u * 256u + threadIdx.x;
+      if (gg < gr.g) {
+        const uint8_t rd = (ma[u] + ad[u]) >= (uint32_t)(mm[u] - sc[u]) ? 1 : 0;
+        if (prm.do_ready) b.ready[gg] = rd;
+        if (prm.host_tag) { b.h_admit[gg] = ad[u]; b.h_ready[gg] = rd; }
+      }
+    }
+  }
+  if (prm.host_tag) {
+    // every block drained its host writes before taking its ticket; this block's are drained here; then the completion
+    // word goes out with system-scope release — the host polls it (bs_batch_read) instead of waiting on the stream
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(b.h_tag, prm.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch C: final codes in queue order, per pod independent.
 //   deny replay   pod i is behind a rejected pod of its group iff some (group, class) pair of the group has a
 //                 rejected class slot and its first querying pod precedes i (core.go:142,163 -> :105-110)
@@ -368,7 +416,7 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev
 //   Permit        per-group admit counts; last block: quorum predicate core.go:303
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
-  __shared__ uint32_t s_last, s_first_reach;
+  __shared__ uint32_t s_first_reach;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   // the pod's own fields travel while the block finds the first reaching pod (one round trip for both)
   uint8_t code0 = 0, st0 = 0;
@@ -457,45 +505,7 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
   }
   if (prm.do_tally) wave_aggregated_add(b.admit, ag, admit);
-  if (!prm.do_ready && !prm.host_tag) return;
-  // the admit counters are agent-scope atomics (performed at the coherence point, returned before vmcnt drains): a drained
-  // ticket orders them, the last block reads them back with agent-scope loads — no L2 write-back / invalidate per block
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // quorum pass: all loads of a batch of groups first, then the stores (one round trip per 8 x 256 groups, not one per 256)
-  constexpr int kQ = 8;
-  for (uint32_t g0 = 0; g0 < gr.g; g0 += kQ * 256u) {
-    uint32_t ad[kQ], ma[kQ], mm[kQ], sc[kQ];
-#pragma unroll
-    for (int u = 0; u < kQ; ++u) {
-      const uint32_t gg = g0 + (uint32_t)u * 256u + threadIdx.x;
-      ad[u] = ma[u] = mm[u] = sc[u] = 0;
-      if (gg < gr.g) {
-        ad[u] = __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ma[u] = gr.matched[gg]; mm[u] = gr.min_member[gg]; sc[u] = gr.status_scheduled[gg];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kQ; ++u) {
-      const uint32_t gg = g0 + (uint32_t)u * 256u + threadIdx.x;
-      if (gg < gr.g) {
-        const uint8_t rd = (ma[u] + ad[u]) >= (uint32_t)(mm[u] - sc[u]) ? 1 : 0;
-        if (prm.do_ready) b.ready[gg] = rd;
-        if (prm.host_tag) { b.h_admit[gg] = ad[u]; b.h_ready[gg] = rd; }
-      }
-    }
-  }
-  if (prm.host_tag) {
-    // every block drained its host writes before taking its ticket; this block's are drained here; then the completion
-    // word goes out with system-scope release — the host polls it (bs_batch_read) instead of waiting on the stream
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(b.h_tag, prm.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  final_tail(gr, b, prm);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -142,7 +142,8 @@ struct BatchDev {
   const unsigned long long* pair_head;  // [G] first (group, request class) pair of the group: (class << 32) | representative pod, low word BS_INF = none
   const uint32_t* ppair;          // [P] pod -> its pair (= index of the pair's representative pod)
   const unsigned long long* pair_next;  // [P] at representatives: the next link of the group's chain, same encoding
-  unsigned long long* pair_firstq;// [P] at representatives: (~batch_seq << 32) | first pod of the pair with a scan query
+  unsigned long long* pair_firstq;// [views][pair_stride] by pair id: (~batch_seq << 32) | first pod of the pair with a scan query
+  uint32_t pair_stride;           // id space of the pairs (a pair's id is its representative pod at bs_pods_load, a drawn number after bs_pods_apply)
   unsigned long long* first_reach64;  // [blocks of launch A] (~batch_seq << 32) | first pod of the block that reaches findMaxPG
   uint32_t* fast_reject;    // [G] first rejected pod of the group (only maintained for BS_BATCH_COMMIT)
   // BS_BATCH_HOST_RESULTS: mirrors of the results in pinned host memory, written by the last launch (null = off)

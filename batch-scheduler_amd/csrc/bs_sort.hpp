@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t sort_digit(const SortIn& in, uint32_t e, int
 }
 
 __global__ __launch_bounds__(kSortBlock) void k_queue_sort(SortIn in, uint32_t* idx_a, uint32_t* idx_b, uint32_t* perm_out) {
-  __shared__ uint32_t s_hist[256], s_base[256], s_uniform;
+  __shared__ uint32_t s_hist[256], s_base[256], s_wtot[4], s_uniform;
   __shared__ uint32_t s_wcnt[kSortBlock / 64][256];
   const uint32_t P = in.p, t = threadIdx.x;
   const int lane = lane_id(), wave = wave_id();
@@ -62,17 +62,19 @@ __global__ __launch_bounds__(kSortBlock) void k_queue_sort(SortIn in, uint32_t* 
     __syncthreads();
     if (t < 256 && s_hist[t] == P) s_uniform = 1;
     __syncthreads();
-    if (s_uniform) continue;                       // every pod has the same byte here: the order does not change
+    const bool uniform = s_uniform != 0;           // read by every wave before anyone can reset it for the next digit
+    __syncthreads();
+    if (uniform) continue;                         // every pod has the same byte here: the order does not change
     if (t < 256) {                                 // exclusive scan of the 256 counts (4 waves)
       const uint32_t v = s_hist[t];
       uint32_t incl = wave_incl_scan_add<uint32_t>(v);
       s_base[t] = incl - v;
-      if (lane == 63) s_hist[wave] = incl;         // wave totals (the counts themselves are no longer needed)
+      if (lane == 63) s_wtot[wave] = incl;         // wave totals, in their own words: other waves may still be reading their counts
     }
     __syncthreads();
     if (t < 256) {
       uint32_t off = 0;
-      for (int w = 0; w < wave; ++w) off += s_hist[w];
+      for (int w = 0; w < wave; ++w) off += s_wtot[w];
       s_base[t] += off;
     }
     __syncthreads();

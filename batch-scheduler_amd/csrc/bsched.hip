@@ -20,6 +20,7 @@
 #include "bs_epoch.hpp"
 #include "bs_sort.hpp"
 #include "bs_fit.hpp"
+#include "bs_queue.hpp"
 
 using namespace bs;
 
@@ -55,6 +56,34 @@ struct FitArena {
   }
 };
 template <typename T> const T* at_dev(const void* base, size_t off) { return reinterpret_cast<const T*>((const uint8_t*)base + off); }
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// One pod pack = the arrays of bs_pods_soa for exactly `p` pods (the part a load uploads in ONE copy, `in_bytes`) followed by
+// the per-pod ids the library derives (request class, (group, class) pair): what travels with a pod when the queue is patched.
+// The pinned staging buffer uses the same layout (input part only) — and its OWN copy of it (bs_pods_map must not disturb the
+// resident queue).
+struct PodLayout {
+  size_t group = 0, req = 0, pres = 0, cls = 0, owner = 0, flags = 0, in_bytes = 0, pclass = 0, ppair = 0, bytes = 0;
+  uint32_t p = 0;
+};
+PodLayout pod_layout(uint32_t P, uint32_t L) {
+  const size_t n = std::max<uint32_t>(P, 1);
+  PodLayout l;
+  size_t o = 0;
+  l.group = o; o = align256(o + n * 4);
+  l.req = o; o = align256(o + n * L * 8);
+  l.pres = o; o = align256(o + n * 4);
+  l.cls = o; o = align256(o + n * 4);
+  l.owner = o; o = align256(o + n * 8);
+  l.flags = o; o = align256(o + n);
+  l.in_bytes = o;
+  l.pclass = o; o = align256(o + n * 4);
+  l.ppair = o; o = align256(o + n * 4);
+  l.bytes = o;
+  l.p = P;
+  return l;
+}
 
 }  // namespace
 
@@ -99,14 +128,29 @@ struct bs_ctx {
   // ---- pods
   uint32_t P = 0;
   // pods live in ONE device allocation (one H2D per batch from a pinned staging buffer); outputs likewise (one D2H)
-  DevBuf d_podpack, d_outpack;
+  DevBuf d_pack[2], d_outpack;       // two pod packs: bs_pods_apply compacts from the current one into the other
+  PodLayout lay[2], stage_lay;       // their layouts, and the staging buffer's own
+  uint32_t cur_pack = 0;
   void* h_stage = nullptr;           // pinned host staging
   hipEvent_t ev_stage = nullptr;     // the last H2D out of the staging buffer (bs_pods_load does not wait for it)
   bool stage_busy = false;
   bool last_use_classes = false;
   size_t h_stage_cap = 0;
   uint32_t map_p = 0;                // pods the staging buffer is currently mapped for (bs_pods_map), 0 = not mapped
-  size_t off_pgroup = 0, off_preq = 0, off_ppres = 0, off_pcls = 0, off_powner = 0, off_pflags = 0, podpack_bytes = 0;
+  // queue-resident cycle (bs_pods_apply, bs_queue.hpp)
+  DevBuf d_gstat2, d_cdir, d_pdir, d_ckeys, d_cpres, d_pkeys;
+  uint32_t gstat_cur = 0;            // which of d_gstat / d_gstat2 holds the per-group minima of the resident queue
+  uint32_t pair_cap = 0, dir_slots = 0;   // id space of classes / pairs between two derivations; hash slots of each directory
+  uint32_t ids_used = 0;             // upper bound of the class / pair ids drawn since the last derivation
+  bool rep_valid = false;            // d_cls_rep / d_cls_id / pair ids still name pods of the resident queue (no compaction since)
+  bool dirs_ready = false;           // the directories match the resident queue's classes and pairs
+  uint32_t id_room = 0;              // BS_ID_ROOM: ids beyond the queue length (0 = the default: as many again + 1024)
+  uint32_t serial_insert_max = 2048; // more inserted pods than this: re-derive in parallel instead of the insert wave
+  void* h_dstage = nullptr;          // pinned: the delta the apply kernel reads in place
+  size_t h_dstage_cap = 0;
+  hipEvent_t ev_dstage = nullptr;
+  bool dstage_busy = false;
+  uint64_t n_applies = 0, n_rederives = 0;
   size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, off_fl_slot = 0, off_admit = 0, off_ready = 0, outpack_bytes = 0;
 
   // ---- batch scratch / outputs
@@ -118,13 +162,13 @@ struct bs_ctx {
   bool side_ready = false;      // desc[] of the steady-state table is in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
   // request slots (see BatchDev): classes of the loaded pods + per-batch slot arrays
-  DevBuf d_pclass, d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_fu_bitmap, d_fu_feas;
+  DevBuf d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_fu_bitmap, d_fu_feas;
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
   DevBuf d_fl_bitmap, d_admit, d_ready;
   // fast path (bs_fast.hpp)
   DevBuf d_order_rank, d_sort;         // queue ordering: per-group order ranks; inputs | index ping-pong | permutation
   uint32_t order_g = 0;
-  DevBuf d_gstat, d_ppair, d_pair_next, d_pair_firstq, d_first_reach, d_qstamp_s, d_fast_reject, d_epoch_group;
+  DevBuf d_gstat, d_pair_next, d_pair_firstq, d_first_reach, d_qstamp_s, d_fast_reject, d_epoch_group;
   bool pairs_ready = false;          // d_gstat / pairs match the loaded pods and G
   bool bitmap_valid = false;         // d_fl_bitmap holds the expanded rows of the last batch
   bool last_fast = false;
@@ -285,15 +329,19 @@ GroupsDev groups_dev(const bs_ctx* c) {
 PodsDev pods_dev(const bs_ctx* c) {
   PodsDev p{};
   p.p = c->P;
-  uint8_t* pk = c->d_podpack.as<uint8_t>();
-  p.group = reinterpret_cast<int32_t*>(pk + c->off_pgroup);
-  p.req = reinterpret_cast<int64_t*>(pk + c->off_preq);
-  p.pres = reinterpret_cast<uint32_t*>(pk + c->off_ppres);
-  p.cls = reinterpret_cast<uint32_t*>(pk + c->off_pcls);
-  p.owner = reinterpret_cast<uint64_t*>(pk + c->off_powner);
-  p.flags = pk + c->off_pflags;
+  uint8_t* pk = c->d_pack[c->cur_pack].as<uint8_t>();
+  const PodLayout& l = c->lay[c->cur_pack];
+  p.group = reinterpret_cast<int32_t*>(pk + l.group);
+  p.req = reinterpret_cast<int64_t*>(pk + l.req);
+  p.pres = reinterpret_cast<uint32_t*>(pk + l.pres);
+  p.cls = reinterpret_cast<uint32_t*>(pk + l.cls);
+  p.owner = reinterpret_cast<uint64_t*>(pk + l.owner);
+  p.flags = pk + l.flags;
   return p;
 }
+uint32_t* pclass_dev(const bs_ctx* c) { return reinterpret_cast<uint32_t*>(c->d_pack[c->cur_pack].as<uint8_t>() + c->lay[c->cur_pack].pclass); }
+uint32_t* ppair_dev(const bs_ctx* c) { return reinterpret_cast<uint32_t*>(c->d_pack[c->cur_pack].as<uint8_t>() + c->lay[c->cur_pack].ppair); }
+uint32_t* gstat_dev(const bs_ctx* c) { return (c->gstat_cur ? c->d_gstat2 : c->d_gstat).as<uint32_t>(); }
 BatchDev batch_dev(const bs_ctx* c) {
   BatchDev b{};
   b.first_elig = c->d_first_elig.as<uint32_t>();
@@ -325,7 +373,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.chunk_kp = c->d_chunk_kp.as<uint32_t>();
   b.fparams = c->d_fparams.as<int64_t>();
   b.fflags = c->d_fflags.as<uint32_t>();
-  b.pclass = c->d_pclass.as<uint32_t>();
+  b.pclass = pclass_dev(c);
   b.kclass = c->d_nepochs.as<uint32_t>() + 2;
   b.cls_slots = c->d_cls_slots.as<unsigned long long>();
   b.cls_mask = c->cls_cap ? c->cls_cap - 1 : 0;
@@ -336,11 +384,12 @@ BatchDev batch_dev(const bs_ctx* c) {
   // per-slot feasible counts sit right behind the last row of the slot bitmap: one 2-D copy returns rows + counts
   b.fu_feas = reinterpret_cast<uint32_t*>(c->d_fu_bitmap.as<uint64_t>() + (size_t)cdiv(c->N, 64) * c->filter_slots_cap);
   b.qstamp_s = c->d_qstamp_s.as<uint32_t>();
-  b.first_pod_s = c->d_gstat.as<uint32_t>();
-  b.first_np_s = c->d_gstat.as<uint32_t>() + (size_t)c->G;
-  b.first_owner_s = c->d_gstat.as<uint32_t>() + (size_t)2 * c->G;
+  b.first_pod_s = gstat_dev(c);
+  b.first_np_s = gstat_dev(c) + (size_t)c->G;
+  b.first_owner_s = gstat_dev(c) + (size_t)2 * c->G;
   b.pair_head = reinterpret_cast<const unsigned long long*>(c->d_gstat.as<uint32_t>() + (((size_t)3 * c->G + 1) & ~(size_t)1));
-  b.ppair = c->d_ppair.as<uint32_t>();
+  b.ppair = ppair_dev(c);
+  b.pair_stride = c->pair_cap;
   b.pair_next = c->d_pair_next.as<unsigned long long>();
   b.pair_firstq = c->d_pair_firstq.as<unsigned long long>();
   b.first_reach64 = c->d_first_reach.as<unsigned long long>();
@@ -668,8 +717,6 @@ int resolve_pods(bs_ctx* c) {
   return BS_OK;
 }
 
-size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
 int ensure_gstage(bs_ctx* c, size_t bytes) {
   if (c->gstage_busy) { HIPCHK(c, hipEventSynchronize(c->ev_gstage)); c->gstage_busy = false; }
   if (bytes <= c->h_gstage_cap) return BS_OK;
@@ -679,24 +726,88 @@ int ensure_gstage(bs_ctx* c, size_t bytes) {
   return BS_OK;
 }
 
-// Second half of the pod load (k_pod_pairs): dense class ids, per-group minima, (group, class) pairs; hands K to the
-// host.  Needs G, so it runs at bs_pods_load when the groups are already there and at the next batch otherwise.
-// fresh: the pair table and gstat were just reset by k_pods_prep.
-int build_pairs(bs_ctx* c, bool fresh) {
-  const uint32_t G = c->G, P = c->P;
+// What a batch needs from the pods alone, derived on the device from the RESIDENT queue: request classes (k_pod_class_a),
+// then dense class ids, per-group minima and (group, class) pairs (k_pod_pairs); K reaches the host through pinned memory.
+// Runs behind the upload of bs_pods_load, and again whenever ids cannot be patched any more (bs_pods_apply: id space used up,
+// too many inserts for the insert wave, group count changed after a compaction).
+// pairs_only: classes (d_cls_rep / d_cls_id) are still those of the resident queue, only G changed.
+int derive_pods(bs_ctx* c, bool pairs_only) {
+  const uint32_t G = c->G, P = c->P, L = c->L;
   HIPCHK(c, c->d_gstat.reserve((size_t)5 * std::max<uint32_t>(G, 1) * 4 + 16));
   HIPCHK(c, c->d_fast_reject.reserve((size_t)std::max<uint32_t>(G, 1) * 4));
-  unsigned long long* table = c->d_cls_slots.as<unsigned long long>() + c->cls_cap;         // second half: the pair table
-  if (!fresh && P)
-    hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, table, c->cls_cap, c->d_gstat.as<uint32_t>(), 5 * G + 1, (uint32_t*)nullptr);
+  c->gstat_cur = 0;
+  unsigned long long* ctab = c->d_cls_slots.as<unsigned long long>();
+  unsigned long long* ptab = ctab + c->cls_cap;                                            // second half: the pair table
+  uint32_t* kcount = c->d_nepochs.as<uint32_t>() + 2;
+  const uint32_t ngstat = c->have_groups ? 5 * G + 1 : 0u;
+  if (P) {
+    if (pairs_only) {
+      hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, ptab, c->cls_cap, c->d_gstat.as<uint32_t>(), ngstat, (uint32_t*)nullptr);
+    } else {
+      hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, ctab, 2 * c->cls_cap, c->d_gstat.as<uint32_t>(), ngstat, kcount);
+      hipLaunchKernelGGL(k_pod_class_a, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pods_dev(c), ctab, c->cls_cap - 1, c->hash_keep, L,
+                         c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(), kcount);
+    }
+    LAUNCHCHK(c, BS_KERNEL_PREPASS);
+  } else if (!pairs_only) {
+    HIPCHK(c, hipMemsetAsync(kcount, 0, 4, c->stream));
+  }
   c->kinfo_tag++;
   hipLaunchKernelGGL(k_pod_pairs, dim3(std::max<uint32_t>(1, cdiv(P, 256))), dim3(256), 0, c->stream, pods_dev(c), G, c->d_cls_rep.as<uint32_t>(),
-                     c->d_cls_id.as<uint32_t>(), c->d_pclass.as<uint32_t>(), table, c->cls_cap - 1, c->hash_keep, c->d_gstat.as<uint32_t>(),
-                     c->d_ppair.as<uint32_t>(), c->d_pair_next.as<unsigned long long>(), c->d_nepochs.as<uint32_t>() + 2, c->kinfo_tag, c->h_info);
+                     c->d_cls_id.as<uint32_t>(), pclass_dev(c), ptab, c->cls_cap - 1, c->hash_keep, c->d_gstat.as<uint32_t>(),
+                     ppair_dev(c), c->d_pair_next.as<unsigned long long>(), kcount, c->kinfo_tag, c->h_info);
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
   c->kinfo_pending = true;
   c->pairs_ready = c->have_groups;
   c->epochs_ready = false;
+  c->rep_valid = true;
+  c->dirs_ready = false;
+  c->ids_used = P;
+  return BS_OK;
+}
+
+// the pairs are missing or were built for another group count: bring them up to date before a batch / an apply
+int build_pairs(bs_ctx* c) {
+  if (!c->rep_valid) c->n_rederives++;
+  return derive_pods(c, c->rep_valid);
+}
+
+// Scratch and per-pod arrays sized by the queue length; `n` pods must fit.  Grows with headroom: a queue that gains a few
+// pods per cycle must not reallocate per cycle.
+int reserve_pod_scratch(bs_ctx* c, uint32_t P) {
+  int rc;
+  const size_t n = std::max<uint32_t>(P, 1);
+  const size_t room = n + n / 4 + 256;
+  auto grow = [&](DevBuf& d, size_t per) -> hipError_t { return d.cap >= n * per ? hipSuccess : d.reserve(room * per); };
+  if (c->d_first_reach.cap < (n / kTblChunk + 2) * 8 && (rc = reserve_filled(c, c->d_first_reach, (room / kTblChunk + 2) * 8, 0xFF))) return rc;   // one candidate word per pod block of launch A
+  HIPCHK(c, grow(c->d_epoch, 4));
+  if (c->d_epoch_group.cap < (n + 2) * 4) HIPCHK(c, c->d_epoch_group.reserve((room + 2) * 4));
+  HIPCHK(c, grow(c->d_tcode, 1));
+  HIPCHK(c, grow(c->d_stage, 1));
+  HIPCHK(c, grow(c->d_leader_raw, 4));
+  HIPCHK(c, grow(c->d_qpos, 4));
+  HIPCHK(c, grow(c->d_fparams, 64));
+  HIPCHK(c, grow(c->d_fflags, 4));
+  HIPCHK(c, grow(c->d_cls_rep, 4));
+  HIPCHK(c, grow(c->d_cls_id, 4));
+  if (c->d_blk_scratch.cap < (n / 256 + 2) * 4) HIPCHK(c, c->d_blk_scratch.reserve((room / 256 + 2) * 4));
+  // id space of pairs / classes: a pair's id is its representative pod at derivation time, drawn numbers follow behind
+  if (c->pair_cap < (c->id_room ? n + c->id_room : 2 * n + 1024)) {
+    const uint32_t cap = (uint32_t)std::min<size_t>(c->id_room ? n + c->id_room : 2 * room + 1024, 0x7FFFFFF0u);
+    HIPCHK(c, c->d_pair_next.reserve((size_t)cap * 8));
+    c->pair_cap = cap;
+    c->dirs_ready = false;
+    c->epochs_ready = false;
+  }
+  if ((rc = reserve_filled(c, c->d_pair_firstq, (size_t)c->pair_cap * 8, 0xFF))) return rc;   // 64-bit minima keyed by ~batch_seq: never reset, only born as "none"
+  {
+    uint32_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    if (cap > c->cls_cap || !c->d_cls_slots.p) {
+      HIPCHK(c, c->d_cls_slots.reserve((size_t)cap * 8 * 2));  // request-class table | (group, class) pair table
+      c->cls_cap = cap;
+    }
+  }
   return BS_OK;
 }
 
@@ -727,7 +838,7 @@ int analyse_epochs(bs_ctx* c) {
   HIPCHK(c, c->d_run_leader.reserve(64));
   HIPCHK(c, c->d_gslot.reserve((size_t)std::max<uint32_t>(G, 1) * 4));
   if ((rc = reserve_filled(c, c->d_gfirstq, (size_t)std::max<uint32_t>(G, 1) * 8, 0xFF))) return rc;
-  if ((rc = reserve_filled(c, c->d_pair_firstq, (size_t)std::max<uint32_t>(P, 1) * 8 * 2 * kMaxRuns, 0xFF))) return rc;
+  if ((rc = reserve_filled(c, c->d_pair_firstq, (size_t)std::max<uint32_t>(c->pair_cap, 1) * 8 * 2 * kMaxRuns, 0xFF))) return rc;
   GroupsDev gr = groups_dev(c);
   PodsDev pd = pods_dev(c);
   BatchDev b = batch_dev(c);
@@ -853,6 +964,8 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_SCAN_SHARE")) c->scan_share_override = (uint32_t)std::max(0, std::atoi(e));
   if (const char* e = std::getenv("BS_TARGET_WAVES")) { c->target_waves = std::max(1, std::atoi(e)); c->general_waves = c->target_waves; }
   if (const char* e = std::getenv("BS_FILTER_WAVES")) c->filter_waves = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BS_SERIAL_INSERT_MAX")) c->serial_insert_max = (uint32_t)std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("BS_ID_ROOM")) c->id_room = (uint32_t)std::max(1, std::atoi(e));   // tests: a tiny id space forces re-derivations
   *out = c;
   return BS_OK;
 }
@@ -871,6 +984,8 @@ int bs_destroy(bs_ctx* c) {
   if (c->h_hout) (void)hipHostFree(c->h_hout);
   if (c->h_hrows) (void)hipHostFree(c->h_hrows);
   if (c->h_gstage) (void)hipHostFree(c->h_gstage);
+  if (c->h_dstage) (void)hipHostFree(c->h_dstage);
+  if (c->ev_dstage) (void)hipEventDestroy(c->ev_dstage);
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   if (c->ev_query) (void)hipEventDestroy(c->ev_query);
   if (c->ev_filter) (void)hipEventDestroy(c->ev_filter);
@@ -1067,7 +1182,7 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   HIPCHK(c, c->d_cap_epoch.reserve(n * 4));
   HIPCHK(c, c->d_leader_epoch.reserve((n + 1) * 4));
   HIPCHK(c, c->d_panic_epoch.reserve(n + 1));
-  if (G != c->G) c->pairs_ready = false;          // the per-group arrays of the pod load are sized by G
+  if (G != c->G) { c->pairs_ready = false; c->dirs_ready = false; }   // the per-group arrays of the pod load are sized by G
   c->G = G;
   if ((rc = layout_out(c))) return rc;
   c->n_uncaptured = 0;
@@ -1116,6 +1231,13 @@ int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
       c->last_error = "bs_groups_apply: HAS_POD / HAS_MINRES may not change (use bs_groups_load)";
       return BS_ERR_INVALID;
     }
+  }
+  {
+    // every delta is applied by its own thread: two deltas for one group would leave whichever thread wrote last
+    std::vector<uint32_t> seen(count);
+    for (uint32_t d = 0; d < count; ++d) seen[d] = deltas[d].index;
+    std::sort(seen.begin(), seen.end());
+    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) { c->last_error = "bs_groups_apply: a group index appears twice"; return BS_ERR_INVALID; }
   }
   for (uint32_t d = 0; d < count; ++d) c->h_gflags[deltas[d].index] = (uint8_t)deltas[d].flags;
   // HAS_POD is unchanged, so the capture epochs the general chain's scratch holds stay valid: no re-arm.
@@ -1171,35 +1293,32 @@ static int ensure_stage(bs_ctx* c, size_t bytes) {
   c->h_stage_cap = bytes;
   return BS_OK;
 }
-static void pods_layout(bs_ctx* c, uint32_t P) {
-  const size_t n = std::max<uint32_t>(P, 1), L = c->L;
-  size_t o = 0;
-  c->off_pgroup = o; o = align256(o + n * 4);
-  c->off_preq = o; o = align256(o + n * L * 8);
-  c->off_ppres = o; o = align256(o + n * 4);
-  c->off_pcls = o; o = align256(o + n * 4);
-  c->off_powner = o; o = align256(o + n * 8);
-  c->off_pflags = o; o = align256(o + n);
-  c->podpack_bytes = o;
-}
-
 int bs_pods_map(bs_ctx* c, uint32_t p, bs_pods_soa* view) {
   if (!c || !view || !p) return BS_ERR_INVALID;
   int rc = use_device(c);
   if (rc) return rc;
-  pods_layout(c, p);
-  rc = ensure_stage(c, c->podpack_bytes);            // waits until the previous upload has left the buffer
+  const PodLayout l = pod_layout(p, c->L);           // the staging buffer's own layout: the resident queue is not touched
+  rc = ensure_stage(c, l.in_bytes);                  // waits until the previous upload has left the buffer
   if (rc) return rc;
+  c->stage_lay = l;
   uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
   view->p = p;
-  view->group = reinterpret_cast<const int32_t*>(st + c->off_pgroup);
-  view->req = reinterpret_cast<const int64_t*>(st + c->off_preq);
-  view->req_present = reinterpret_cast<const uint32_t*>(st + c->off_ppres);
-  view->cls = reinterpret_cast<const uint32_t*>(st + c->off_pcls);
-  view->owner = reinterpret_cast<const uint64_t*>(st + c->off_powner);
-  view->flags = st + c->off_pflags;
+  view->group = reinterpret_cast<const int32_t*>(st + l.group);
+  view->req = reinterpret_cast<const int64_t*>(st + l.req);
+  view->req_present = reinterpret_cast<const uint32_t*>(st + l.pres);
+  view->cls = reinterpret_cast<const uint32_t*>(st + l.cls);
+  view->owner = reinterpret_cast<const uint64_t*>(st + l.owner);
+  view->flags = st + l.flags;
   c->map_p = p;
   return BS_OK;
+}
+
+// after the resident queue changed length: result pack layout, scratch
+static int resize_queue(bs_ctx* c, uint32_t P) {
+  int rc;
+  c->P = P;
+  if ((rc = layout_out(c))) return rc;
+  return reserve_pod_scratch(c, P);
 }
 
 int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
@@ -1208,44 +1327,26 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   if (rc) return rc;
   const uint32_t P = pods->p, L = c->L;
   if (P && (!pods->group || !pods->req || !pods->req_present || !pods->cls || !pods->owner || !pods->flags)) return BS_ERR_INVALID;
-  const size_t n = std::max<uint32_t>(P, 1);
-  // pod arrays: one allocation, one transfer
-  pods_layout(c, P);
-  HIPCHK(c, c->d_podpack.reserve(c->podpack_bytes));
-  // per-pod outputs (+ the per-group ones): one allocation, one transfer back
-  c->P = P;
-  if ((rc = layout_out(c))) return rc;
-  const bool mapped = P && c->h_stage && c->map_p == P && (const void*)pods->group == (const void*)((uint8_t*)c->h_stage + c->off_pgroup) &&
-                      (const void*)pods->req == (const void*)((uint8_t*)c->h_stage + c->off_preq);
+  const PodLayout l = pod_layout(P, L);
+  // the caller's arrays ARE the mapped staging buffer (bs_pods_map): nothing to pack.  Pointers into the staging buffer that
+  // do not match the mapping (another p, a stale view) would make the packing copy overlap itself: refused.
+  const uint8_t* sb = reinterpret_cast<const uint8_t*>(c->h_stage);
+  const bool inside = P && sb && (const uint8_t*)pods->group >= sb && (const uint8_t*)pods->group < sb + c->h_stage_cap;
+  const bool mapped = inside && c->map_p == P && (const uint8_t*)pods->group == sb + c->stage_lay.group && (const uint8_t*)pods->req == sb + c->stage_lay.req &&
+                      (const uint8_t*)pods->req_present == sb + c->stage_lay.pres && (const uint8_t*)pods->cls == sb + c->stage_lay.cls &&
+                      (const uint8_t*)pods->owner == sb + c->stage_lay.owner && pods->flags == sb + c->stage_lay.flags;
+  if (inside && !mapped) { c->last_error = "bs_pods_load: pointers into the mapped staging buffer, but not the view bs_pods_map handed out for this p"; return BS_ERR_INVALID; }
   if (!mapped) {
-    rc = ensure_stage(c, c->podpack_bytes);
+    rc = ensure_stage(c, l.in_bytes);
     if (rc) return rc;
   }
   c->map_p = 0;
-  rc = reserve_filled(c, c->d_first_reach, (n / kTblChunk + 2) * 8, 0xFF);   // one candidate word per pod block of launch A
-  if (rc) return rc;
-  HIPCHK(c, c->d_epoch.reserve(n * 4));
-  HIPCHK(c, c->d_epoch_group.reserve((n + 2) * 4));
-  HIPCHK(c, c->d_tcode.reserve(n));
-  HIPCHK(c, c->d_stage.reserve(n));
-  HIPCHK(c, c->d_leader_raw.reserve(n * 4));
-  HIPCHK(c, c->d_qpos.reserve(n * 4));
-  HIPCHK(c, c->d_fparams.reserve(n * 8 * 8));
-  HIPCHK(c, c->d_fflags.reserve(n * 4));
-  HIPCHK(c, c->d_ppair.reserve(n * 4));
-  HIPCHK(c, c->d_pair_next.reserve(n * 8));
-  rc = reserve_filled(c, c->d_pair_firstq, n * 8, 0xFF);     // 64-bit minima keyed by ~batch_seq: never reset, only born as "none"
-  if (rc) return rc;
-  HIPCHK(c, c->d_pclass.reserve(n * 4));
-  HIPCHK(c, c->d_cls_rep.reserve(n * 4));
-  HIPCHK(c, c->d_cls_id.reserve(n * 4));
-  {
-    uint32_t cap = 1024;
-    while (cap < 2 * n) cap <<= 1;
-    HIPCHK(c, c->d_cls_slots.reserve((size_t)cap * 8 * 2));  // request-class table | (group, class) pair table
-    c->cls_cap = cap;
-  }
-  HIPCHK(c, c->d_blk_scratch.reserve((n / 256 + 2) * 4));
+  // pod arrays: one allocation, one transfer (the load always lands in pack 0)
+  c->cur_pack = 0;
+  if (c->d_pack[0].cap < l.bytes) HIPCHK(c, c->d_pack[0].reserve(l.bytes + l.bytes / 4));
+  c->lay[0] = l;
+  // per-pod outputs (+ the per-group ones): one allocation, one transfer back
+  if ((rc = resize_queue(c, P))) return rc;
   c->pairs_ready = false;
   c->epochs_ready = false;
   c->batch_since_pods = false;
@@ -1255,29 +1356,18 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   if (P) {
     uint8_t* st = reinterpret_cast<uint8_t*>(c->h_stage);
     if (!mapped) {                                   // (bs_pods_map: the caller marshalled the queue in place)
-      std::memcpy(st + c->off_pgroup, pods->group, (size_t)P * 4);
-      std::memcpy(st + c->off_preq, pods->req, (size_t)P * L * 8);
-      std::memcpy(st + c->off_ppres, pods->req_present, (size_t)P * 4);
-      std::memcpy(st + c->off_pcls, pods->cls, (size_t)P * 4);
-      std::memcpy(st + c->off_powner, pods->owner, (size_t)P * 8);
-      std::memcpy(st + c->off_pflags, pods->flags, (size_t)P);
+      std::memcpy(st + l.group, pods->group, (size_t)P * 4);
+      std::memcpy(st + l.req, pods->req, (size_t)P * L * 8);
+      std::memcpy(st + l.pres, pods->req_present, (size_t)P * 4);
+      std::memcpy(st + l.cls, pods->cls, (size_t)P * 4);
+      std::memcpy(st + l.owner, pods->owner, (size_t)P * 8);
+      std::memcpy(st + l.flags, pods->flags, (size_t)P);
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_podpack.p, st, c->podpack_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pack[0].p, st, l.in_bytes, hipMemcpyHostToDevice, c->stream));
   }
   // request classes, per-group minima and (group, class) pairs of the pods: three launches behind the upload
   // (reset | first half of the class builder | second half + pairs); K reaches the host through pinned memory
-  if (P) {
-    const PodsDev pd = pods_dev(c);
-    HIPCHK(c, c->d_gstat.reserve((size_t)5 * std::max<uint32_t>(c->G, 1) * 4 + 16));
-    hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, c->d_cls_slots.as<unsigned long long>(), 2 * c->cls_cap,
-                       c->d_gstat.as<uint32_t>(), c->have_groups ? 5 * c->G + 1 : 0u, c->d_nepochs.as<uint32_t>() + 2);
-    hipLaunchKernelGGL(k_pod_class_a, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, c->d_cls_slots.as<unsigned long long>(), c->cls_cap - 1,
-                       c->hash_keep, L, c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(), c->d_nepochs.as<uint32_t>() + 2);
-    LAUNCHCHK(c, BS_KERNEL_PREPASS);
-  } else {
-    HIPCHK(c, hipMemsetAsync(c->d_nepochs.as<uint32_t>() + 2, 0, 4, c->stream));
-  }
-  rc = build_pairs(c, true);
+  rc = derive_pods(c, false);
   if (rc) return rc;
   // no wait here: the batch that follows is ordered behind the upload on the same stream; only the staging
   // buffer must not be touched again before the copy has left it (ensure_stage / bs_batch_read wait for that)
@@ -1285,6 +1375,212 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   HIPCHK(c, hipEventRecord(c->ev_stage, c->stream));
   c->stage_busy = true;
   c->have_pods = true;
+  return maybe_analyse_epochs(c);
+}
+
+// ---- bs_pods_apply: the resident queue patched on the device (bs_queue.hpp) ----------------------------------------------
+static int ensure_dstage(bs_ctx* c, size_t bytes) {
+  if (c->dstage_busy) { HIPCHK(c, hipEventSynchronize(c->ev_dstage)); c->dstage_busy = false; }     // the previous apply may still be reading it
+  if (bytes <= c->h_dstage_cap) return BS_OK;
+  if (c->h_dstage) { (void)hipHostFree(c->h_dstage); c->h_dstage = nullptr; c->h_dstage_cap = 0; }
+  const size_t want = std::max<size_t>(bytes + bytes / 2, 64 << 10);
+  HIPCHK(c, hipHostMalloc(&c->h_dstage, want, hipHostMallocDefault));
+  c->h_dstage_cap = want;
+  return BS_OK;
+}
+
+static QueueDirs queue_dirs(const bs_ctx* c) {
+  QueueDirs q{};
+  q.cdir = c->d_cdir.as<unsigned long long>();
+  q.pdir = c->d_pdir.as<unsigned long long>();
+  q.cmask = q.pmask = c->dir_slots ? c->dir_slots - 1 : 0;
+  q.ckeys = c->d_ckeys.as<int64_t>();
+  q.cpres = c->d_cpres.as<uint32_t>();
+  q.kcap = c->pair_cap;
+  q.pkeys = c->d_pkeys.as<unsigned long long>();
+  q.kcount = c->d_nepochs.as<uint32_t>() + 2;
+  q.paircount = c->d_nepochs.as<uint32_t>() + 4;
+  q.pair_head = reinterpret_cast<unsigned long long*>(c->d_gstat.as<uint32_t>() + (((size_t)3 * c->G + 1) & ~(size_t)1));
+  q.pair_next = c->d_pair_next.as<unsigned long long>();
+  return q;
+}
+
+// Directories (hash -> class id, hash -> pair id) of a queue whose ids still name its own pods: the first apply after a
+// derivation files every class / pair representative; later applies only add to them.
+static int build_dirs(bs_ctx* c) {
+  const uint32_t P = c->P, G = c->G;
+  uint32_t slots = 2048;
+  while (slots < 2 * c->pair_cap) slots <<= 1;
+  HIPCHK(c, c->d_cdir.reserve((size_t)slots * 8));
+  HIPCHK(c, c->d_pdir.reserve((size_t)slots * 8));
+  HIPCHK(c, c->d_ckeys.reserve((size_t)c->pair_cap * c->L * 8));
+  HIPCHK(c, c->d_cpres.reserve((size_t)c->pair_cap * 4));
+  HIPCHK(c, c->d_pkeys.reserve((size_t)c->pair_cap * 8));
+  HIPCHK(c, c->d_gstat2.reserve((size_t)3 * std::max<uint32_t>(G, 1) * 4 + 16));
+  c->dir_slots = slots;
+  HIPCHK(c, hipMemsetAsync(c->d_cdir.p, 0, (size_t)slots * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_pdir.p, 0, (size_t)slots * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync((c->gstat_cur ? c->d_gstat : c->d_gstat2).p, 0xFF, (size_t)3 * std::max<uint32_t>(G, 1) * 4, c->stream));   // the spare minima
+  const uint32_t pc = P;                                                                    // pair ids below P belong to the derivation
+  HIPCHK(c, hipMemcpyAsync(c->d_nepochs.as<uint32_t>() + 4, &pc, 4, hipMemcpyHostToDevice, c->stream));
+  if (P) {
+    hipLaunchKernelGGL(k_dirs_build, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pods_dev(c), G, c->L, c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(),
+                       ppair_dev(c), queue_dirs(c), c->hash_keep);
+    LAUNCHCHK(c, BS_KERNEL_PREPASS);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // (`pc` is a stack word; once per derivation)
+  c->dirs_ready = true;
+  return BS_OK;
+}
+
+int bs_pods_apply_stats(const bs_ctx* c, uint64_t* applies, uint64_t* rederives) {
+  if (!c) return BS_ERR_INVALID;
+  if (applies) *applies = c->n_applies;
+  if (rederives) *rederives = c->n_rederives;
+  return BS_OK;
+}
+
+int bs_pods_count(const bs_ctx* c, uint32_t* p_out) {
+  if (!c || !p_out) return BS_ERR_INVALID;
+  if (!c->have_pods) return BS_ERR_STATE;
+  *p_out = c->P;
+  return BS_OK;
+}
+
+int bs_pods_read(bs_ctx* c, const bs_pods_out* out) {
+  if (!c || !out) return BS_ERR_INVALID;
+  if (!c->have_pods) return BS_ERR_STATE;
+  if (out->p != c->P) { c->last_error = "bs_pods_read: out->p does not match the resident queue"; return BS_ERR_INVALID; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t P = c->P, L = c->L;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!P) return BS_OK;
+  const PodsDev pd = pods_dev(c);
+  if (out->group) HIPCHK(c, hipMemcpy(out->group, pd.group, (size_t)P * 4, hipMemcpyDeviceToHost));
+  if (out->req) HIPCHK(c, hipMemcpy(out->req, pd.req, (size_t)P * L * 8, hipMemcpyDeviceToHost));
+  if (out->req_present) HIPCHK(c, hipMemcpy(out->req_present, pd.pres, (size_t)P * 4, hipMemcpyDeviceToHost));
+  if (out->cls) HIPCHK(c, hipMemcpy(out->cls, pd.cls, (size_t)P * 4, hipMemcpyDeviceToHost));
+  if (out->owner) HIPCHK(c, hipMemcpy(out->owner, pd.owner, (size_t)P * 8, hipMemcpyDeviceToHost));
+  if (out->flags) HIPCHK(c, hipMemcpy(out->flags, pd.flags, (size_t)P, hipMemcpyDeviceToHost));
+  return BS_OK;
+}
+
+int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
+  if (!c || !d) return BS_ERR_INVALID;
+  if (!c->have_pods) { c->last_error = "bs_pods_apply before bs_pods_load"; return BS_ERR_STATE; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t P = c->P, L = c->L, R = d->n_remove, F = d->n_flags, I = d->insert.p;
+  // ---- validate everything before touching anything
+  if ((R && !d->remove) || (F && (!d->flag_index || !d->flag_value))) return BS_ERR_INVALID;
+  const bs_pods_soa& in = d->insert;
+  if (I && (!in.group || !in.req || !in.req_present || !in.cls || !in.owner || !in.flags)) return BS_ERR_INVALID;
+  if (R > P) { c->last_error = "bs_pods_apply: more removals than pods"; return BS_ERR_INVALID; }
+  for (uint32_t i = 0; i < R; ++i)
+    if (d->remove[i] >= P || (i && d->remove[i] <= d->remove[i - 1])) { c->last_error = "bs_pods_apply: remove[] must be strictly ascending indices of the current queue"; return BS_ERR_INVALID; }
+  for (uint32_t i = 0; i < F; ++i)
+    if (d->flag_index[i] >= P || (i && d->flag_index[i] <= d->flag_index[i - 1])) { c->last_error = "bs_pods_apply: flag_index[] must be strictly ascending indices of the current queue"; return BS_ERR_INVALID; }
+  if ((uint64_t)P - R + I > 0x7FFFFFF0ull) { c->last_error = "bs_pods_apply: queue too long"; return BS_ERR_CAPACITY; }
+  const uint32_t Pn = P - R + I;
+  if (d->insert_at)
+    for (uint32_t i = 0; i < I; ++i)
+      if (d->insert_at[i] >= Pn || (i && d->insert_at[i] <= d->insert_at[i - 1])) { c->last_error = "bs_pods_apply: insert_at[] must be strictly ascending positions of the new queue"; return BS_ERR_INVALID; }
+  if (!R && !F && !I) return BS_OK;
+  if (c->batch_pending_finish) { c->last_error = "bs_pods_apply between a sharded batch and bs_batch_finish"; return BS_ERR_STATE; }
+  c->n_applies++;
+
+  // ---- the delta goes into pinned memory the kernel reads in place: index lists first, then the inserted pods (SoA)
+  size_t o = 0;
+  const size_t o_rem = o; o = align256(o + (size_t)R * 4);
+  const size_t o_at = o; o = align256(o + (size_t)I * 4);
+  const size_t o_fi = o; o = align256(o + (size_t)F * 4);
+  const size_t o_fv = o; o = align256(o + (size_t)F);
+  const PodLayout il = pod_layout(I, L);
+  const size_t o_ins = o; o += il.in_bytes;
+  if ((rc = ensure_dstage(c, o))) return rc;
+  uint8_t* st = reinterpret_cast<uint8_t*>(c->h_dstage);
+  if (R) std::memcpy(st + o_rem, d->remove, (size_t)R * 4);
+  if (I) {
+    uint32_t* at = reinterpret_cast<uint32_t*>(st + o_at);
+    if (d->insert_at) std::memcpy(at, d->insert_at, (size_t)I * 4);
+    else for (uint32_t i = 0; i < I; ++i) at[i] = P - R + i;
+    uint8_t* ib = st + o_ins;
+    std::memcpy(ib + il.group, in.group, (size_t)I * 4);
+    std::memcpy(ib + il.req, in.req, (size_t)I * L * 8);
+    std::memcpy(ib + il.pres, in.req_present, (size_t)I * 4);
+    std::memcpy(ib + il.cls, in.cls, (size_t)I * 4);
+    std::memcpy(ib + il.owner, in.owner, (size_t)I * 8);
+    std::memcpy(ib + il.flags, in.flags, (size_t)I);
+    for (uint32_t i = 0; i < I; ++i)
+      if (in.group[i] >= 0) c->max_pod_cls = std::max(c->max_pod_cls, in.cls[i]);
+  }
+  if (F) { std::memcpy(st + o_fi, d->flag_index, (size_t)F * 4); std::memcpy(st + o_fv, d->flag_value, (size_t)F); }
+
+  // ---- ids can be patched when the pairs are current, the directories can be had, the id space has room and the insert
+  // wave is not asked to do a parallel job; otherwise: copy only, then derive everything from the new resident queue
+  if (!c->pairs_ready && c->have_groups && c->rep_valid && (rc = build_pairs(c))) return rc;       // (G changed since the pods were derived)
+  bool derive = c->pairs_ready && c->have_groups && I <= c->serial_insert_max && (c->dirs_ready || c->rep_valid);
+  const uint32_t old_pair_cap = c->pair_cap;
+  const PodsDev old = pods_dev(c);
+  const uint32_t* old_pclass = pclass_dev(c);
+  const uint32_t* old_ppair = ppair_dev(c);
+  if (derive && (uint64_t)c->ids_used + I > c->pair_cap) derive = false;
+  if (derive && !c->dirs_ready && (rc = build_dirs(c))) return rc;
+  // ---- the other pack takes the new queue
+  const uint32_t np = c->cur_pack ^ 1u;
+  const PodLayout nl = pod_layout(Pn, L);
+  if (c->d_pack[np].cap < nl.bytes) HIPCHK(c, c->d_pack[np].reserve(nl.bytes + nl.bytes / 4));
+  c->lay[np] = nl;
+  if ((rc = resize_queue(c, Pn))) return rc;
+  if (c->pair_cap != old_pair_cap) derive = false;                   // the id space was re-sized: directories are gone
+  PodsMut nw{};
+  uint8_t* nb = c->d_pack[np].as<uint8_t>();
+  nw.group = reinterpret_cast<int32_t*>(nb + nl.group);
+  nw.req = reinterpret_cast<int64_t*>(nb + nl.req);
+  nw.pres = reinterpret_cast<uint32_t*>(nb + nl.pres);
+  nw.cls = reinterpret_cast<uint32_t*>(nb + nl.cls);
+  nw.owner = reinterpret_cast<uint64_t*>(nb + nl.owner);
+  nw.flags = nb + nl.flags;
+  nw.pclass = reinterpret_cast<uint32_t*>(nb + nl.pclass);
+  nw.ppair = reinterpret_cast<uint32_t*>(nb + nl.ppair);
+  nw.p = Pn;
+  PodDeltaDev dd{};
+  dd.n_remove = R; dd.n_insert = I; dd.n_flags = F;
+  dd.remove = reinterpret_cast<const uint32_t*>(st + o_rem);
+  dd.insert_at = reinterpret_cast<const uint32_t*>(st + o_at);
+  dd.flag_index = reinterpret_cast<const uint32_t*>(st + o_fi);
+  dd.flag_value = st + o_fv;
+  dd.ins.p = I;
+  dd.ins.group = reinterpret_cast<const int32_t*>(st + o_ins + il.group);
+  dd.ins.req = reinterpret_cast<const int64_t*>(st + o_ins + il.req);
+  dd.ins.pres = reinterpret_cast<const uint32_t*>(st + o_ins + il.pres);
+  dd.ins.cls = reinterpret_cast<const uint32_t*>(st + o_ins + il.cls);
+  dd.ins.owner = reinterpret_cast<const uint64_t*>(st + o_ins + il.owner);
+  dd.ins.flags = st + o_ins + il.flags;
+  const uint32_t gb = cdiv(std::max<uint32_t>(Pn, 1), kApplyBlock);
+  uint32_t* g_new = (c->gstat_cur ? c->d_gstat : c->d_gstat2).as<uint32_t>();
+  uint32_t* g_next = (c->gstat_cur ? c->d_gstat2 : c->d_gstat).as<uint32_t>();
+  if (derive) c->kinfo_tag++;
+  hipLaunchKernelGGL(k_pods_apply, dim3(gb + 1), dim3(kApplyBlock), 0, c->stream, old, old_pclass, old_ppair, nw, dd, c->G, L, g_new, g_next,
+                     derive ? queue_dirs(c) : QueueDirs{}, c->hash_keep, derive ? 1u : 0u, gb, c->kinfo_tag, c->h_info);
+  LAUNCHCHK(c, BS_KERNEL_PREPASS);
+  if (!c->ev_dstage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_dstage, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_dstage, c->stream));
+  c->dstage_busy = true;
+  c->cur_pack = np;
+  c->rep_valid = false;                                              // the queue was compacted: pod indices of the derivation are history
+  c->epochs_ready = false;
+  c->batch_since_pods = false;
+  c->bitmap_valid = false;
+  if (derive) {
+    c->gstat_cur ^= 1u;
+    c->ids_used += I;
+    c->kinfo_pending = true;
+  } else {
+    c->n_rederives++;
+    if ((rc = derive_pods(c, false))) return rc;
+  }
   return maybe_analyse_epochs(c);
 }
 
@@ -1430,6 +1726,32 @@ static int ensure_hout(bs_ctx* c) {
   return BS_OK;
 }
 
+// Latency mode (BS_BATCH_HOST_RESULTS) of the two three-launch chains: the final launch mirrors every result into pinned host
+// memory and publishes a completion word; this points the batch view at that memory.
+static int setup_host_out(bs_ctx* c, uint32_t stages, bool run_filter, BatchDev& b, BatchParams& prm) {
+  const bool host_out = (stages & BS_BATCH_HOST_RESULTS) && c->nranks == 1 && !c->reduce_external && !c->ext_admit && !(stages & BS_BATCH_COMMIT);
+  c->last_host_out = host_out;
+  if (!host_out) return BS_OK;
+  int rc = ensure_hout(c);
+  if (rc) return rc;
+  c->host_tag = c->host_tag == 0x7FFFFFFF ? 1 : c->host_tag + 1;
+  prm.host_tag = c->host_tag;
+  uint8_t* h = c->h_hout;
+  b.h_pf_code = h + c->off_pf_code;
+  b.h_pf_first_k = reinterpret_cast<uint32_t*>(h + c->off_pf_first_k);
+  b.h_pf_leader = reinterpret_cast<int32_t*>(h + c->off_pf_leader);
+  b.h_fl_code = h + c->off_fl_code;
+  b.h_fl_feasible = reinterpret_cast<uint32_t*>(h + c->off_fl_feasible);
+  b.h_fl_slot = reinterpret_cast<uint32_t*>(h + c->off_fl_slot);
+  b.h_admit = reinterpret_cast<uint32_t*>(h + c->off_admit);
+  b.h_ready = h + c->off_ready;
+  b.h_feas = reinterpret_cast<uint32_t*>(h + c->off_hfeas);
+  b.h_tag = reinterpret_cast<int32_t*>(h + c->off_htag);
+  b.h_rows = run_filter ? c->h_hrows : nullptr;
+  b.hstride = c->hstride;
+  return BS_OK;
+}
+
 // The steady-state chain (bs_fast.hpp): three launches, nothing reset, no wait.
 static int run_fast(bs_ctx* c, uint32_t stages) {
   int rc;
@@ -1452,27 +1774,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   prm.commit = commit ? 1u : 0u;
   prm.do_tally = (stages & BS_STAGE_TALLY) ? 1u : 0u;
   prm.do_ready = (prm.do_tally && c->nranks == 1 && !c->reduce_external) ? 1u : 0u;
-  // latency mode: the final launch mirrors every result into pinned host memory and publishes a completion word
-  const bool host_out = (stages & BS_BATCH_HOST_RESULTS) && c->nranks == 1 && !c->reduce_external && !c->ext_admit && !commit;
-  c->last_host_out = host_out;
-  if (host_out) {
-    if ((rc = ensure_hout(c))) return rc;
-    c->host_tag = c->host_tag == 0x7FFFFFFF ? 1 : c->host_tag + 1;
-    prm.host_tag = c->host_tag;
-    uint8_t* h = c->h_hout;
-    b.h_pf_code = h + c->off_pf_code;
-    b.h_pf_first_k = reinterpret_cast<uint32_t*>(h + c->off_pf_first_k);
-    b.h_pf_leader = reinterpret_cast<int32_t*>(h + c->off_pf_leader);
-    b.h_fl_code = h + c->off_fl_code;
-    b.h_fl_feasible = reinterpret_cast<uint32_t*>(h + c->off_fl_feasible);
-    b.h_fl_slot = reinterpret_cast<uint32_t*>(h + c->off_fl_slot);
-    b.h_admit = reinterpret_cast<uint32_t*>(h + c->off_admit);
-    b.h_ready = h + c->off_ready;
-    b.h_feas = reinterpret_cast<uint32_t*>(h + c->off_hfeas);
-    b.h_tag = reinterpret_cast<int32_t*>(h + c->off_htag);
-    b.h_rows = run_filter ? c->h_hrows : nullptr;
-    b.hstride = c->hstride;
-  }
+  if ((rc = setup_host_out(c, stages, run_filter, b, prm))) return rc;
   const uint32_t side_slot = (uint32_t)c->steady_table;
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
   BatchDev bt = b;                                   // the batch view shifted to the steady table's slot (slot index 0)
@@ -1591,7 +1893,7 @@ static int run_epoch(bs_ctx* c, uint32_t stages, bool* taken) {
   ep.R = R; ep.K = K; ep.GB = GB;
   ep.has_first = c->h_eflags & 1u;
   ep.has_reserve = (c->h_eflags >> 1) & 1u;
-  c->last_host_out = false;
+  if ((rc = setup_host_out(c, stages, run_filter, b, prm))) return rc;
   c->last_rows = filter_slots;
   const uint32_t nchunks = std::max<uint32_t>(1, cdiv(c->M, 256));
   const int ts = c->S <= 4 ? (int)c->S : -1;
@@ -1671,7 +1973,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     return BS_ERR_INVALID;
   }
   if ((rc = resolve_groups(c))) return rc;
-  if (!c->pairs_ready && (rc = build_pairs(c, false))) return rc;
+  if (!c->pairs_ready && (rc = build_pairs(c))) return rc;
   const uint32_t W = cdiv(N, 64);
   const bool run_filter = stages & BS_STAGE_FILTER;
   if ((rc = reserve_slots(c, run_filter))) return rc;

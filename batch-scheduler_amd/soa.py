@@ -100,6 +100,23 @@ class BatchOutStruct(C.Structure):
                 ("fl_rows_n", C.POINTER(C.c_uint32))]
 
 
+class PodsDeltaStruct(C.Structure):
+    """bs_pods_delta: stable removals, flag updates and insertions against the resident queue (bs_pods_apply)."""
+    _fields_ = [("n_remove", C.c_uint32), ("remove", C.POINTER(C.c_uint32)),
+                ("n_flags", C.c_uint32), ("flag_index", C.POINTER(C.c_uint32)), ("flag_value", C.POINTER(C.c_uint8)),
+                ("insert", PodsStruct), ("insert_at", C.POINTER(C.c_uint32))]
+
+
+class PodsOutStruct(C.Structure):
+    _fields_ = [("p", C.c_uint32),
+                ("group", C.POINTER(C.c_int32)),
+                ("req", C.POINTER(C.c_int64)),
+                ("req_present", C.POINTER(C.c_uint32)),
+                ("cls", C.POINTER(C.c_uint32)),
+                ("owner", C.POINTER(C.c_uint64)),
+                ("flags", C.POINTER(C.c_uint8))]
+
+
 class GroupDelta(C.Structure):
     """bs_group_delta: replaces matched / status_scheduled / flags of group `index` (bs_groups_apply)."""
     _fields_ = [("index", C.c_uint32), ("matched", C.c_uint32), ("status_scheduled", C.c_uint32), ("flags", C.c_uint32)]
@@ -261,6 +278,39 @@ class Pods:
     def copy(self) -> "Pods":
         return Pods(self.group.copy(), self.req.copy(), self.req_present.copy(), self.cls.copy(),
                     self.owner.copy(), self.flags.copy())
+
+    @staticmethod
+    def empty(p: int, lanes: int) -> "Pods":
+        return Pods(np.zeros(p, np.int32), np.zeros((lanes, p), np.int64), np.zeros(p, np.uint32), np.zeros(p, np.uint32),
+                    np.zeros(p, np.uint64), np.zeros(p, np.uint8))
+
+    def equal(self, other: "Pods") -> bool:
+        return all(np.array_equal(getattr(self, k), getattr(other, k)) for k in ("group", "req", "req_present", "cls", "owner", "flags"))
+
+    def patched(self, remove=(), flag_index=(), flag_value=(), insert: "Pods | None" = None, insert_at=None) -> "Pods":
+        """The queue bs_pods_apply leaves behind, computed on the host (the specification of the delta): flag updates and
+        stable removals against THIS queue, then the inserted pods at their positions in the NEW queue (None = appended)."""
+        fl = self.flags.copy()
+        if len(flag_index):
+            fl[np.asarray(flag_index, np.int64)] = np.asarray(flag_value, np.uint8)
+        keep = np.ones(self.p, bool)
+        if len(remove):
+            keep[np.asarray(remove, np.int64)] = False
+        kept = Pods(self.group[keep], self.req[:, keep], self.req_present[keep], self.cls[keep], self.owner[keep], fl[keep])
+        ni = insert.p if insert is not None else 0
+        if not ni:
+            return kept
+        pn = kept.p + ni
+        at = np.arange(kept.p, pn) if insert_at is None else np.asarray(insert_at, np.int64)
+        is_ins = np.zeros(pn, bool)
+        is_ins[at] = True
+        out = Pods.empty(pn, self.req.shape[0])
+        for k in ("group", "req_present", "cls", "owner", "flags"):
+            getattr(out, k)[is_ins] = getattr(insert, k)
+            getattr(out, k)[~is_ins] = getattr(kept, k)
+        out.req[:, is_ins] = insert.req
+        out.req[:, ~is_ins] = kept.req
+        return out
 
 
 @dataclass

@@ -1,4 +1,4 @@
-// Package core — cgo binding of libbsched.so (include/bsched.h, ABI v2) for tenstack/batch-scheduler.
+// Package core — cgo binding of libbsched.so (include/bsched.h, ABI v3) for tenstack/batch-scheduler.
 //
 // SOURCE ONLY.  The image this library is developed in has no Go toolchain and k8s.io/kubernetes v1.17.5 is
 // not vendored, so this file has been through neither `go build` nor `go vet`; it is kept as a real file

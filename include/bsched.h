@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BS_ABI_VERSION 2u
+#define BS_ABI_VERSION 3u
 
 enum {
   BS_LANE_CPU = 0,       /* Resource.MilliCPU          */
@@ -300,7 +300,8 @@ int bs_groups_read(bs_ctx* ctx, bs_groups_soa* groups_out); /* caller-sized arra
  * pods to Status.Scheduled (core.go:327), the quorum latch (core.go:305) and the deny TTL (core.go:105,424)
  * flip flag bits.  Each delta REPLACES matched / status_scheduled / flags of group `index`;
  * BS_GROUP_HAS_POD and BS_GROUP_HAS_MINRES must keep their loaded value (a first-pod capture changes cls and
- * MinResources too: use bs_groups_load).  Validated as a whole before anything is applied.
+ * MinResources too: use bs_groups_load).  A group index may appear only once per call.  Validated as a whole before
+ * anything is applied.
  * Like bs_groups_load it re-runs findMaxPG on the device and returns without waiting for the GPU. */
 typedef struct bs_group_delta {
   uint32_t index, matched, status_scheduled, flags;
@@ -308,7 +309,9 @@ typedef struct bs_group_delta {
 int bs_groups_apply(bs_ctx* ctx, const bs_group_delta* deltas, uint32_t count);
 /* Zero-copy hand-over: points `view` at the library's pinned upload buffer, sized for `p` pods, so that the caller can
  * marshal the queue in place (cast the const away) and pass the SAME struct to bs_pods_load, which then skips its packing
- * copy.  The pointers stay valid until the next bs_pods_map / bs_pods_load on the context. */
+ * copy.  The pointers stay valid until the next bs_pods_map / bs_pods_load on the context; the resident queue and every
+ * other entry point are unaffected by a mapping (the staging buffer has its own layout).  bs_pods_load with pointers
+ * into the mapped buffer but another `p` than it was mapped for is refused (BS_ERR_INVALID). */
 int bs_pods_map(bs_ctx* ctx, uint32_t p, bs_pods_soa* view);
 int bs_pods_load(bs_ctx* ctx, const bs_pods_soa* pods);   /* also derives, on the device, what a batch needs from the pods
                                                               alone: request classes (equal (req lanes, req_present) <=> equal
@@ -318,6 +321,45 @@ int bs_pods_load(bs_ctx* ctx, const bs_pods_soa* pods);   /* also derives, on th
                                                               between the loads; fit-class indices (pods.cls, groups.cls) are
                                                               checked against the loaded fit classes by bs_batch_run
                                                               (BS_ERR_INVALID).                                          */
+
+/* ---- the pending queue stays resident: per-cycle pod deltas ---------------------------------------
+ * The reference calls PreFilter (core.go:88) for every pending pod in every scheduling cycle, on a queue that
+ * changes by a few pods between cycles (a released gang leaves: batchscheduler.go:254-344; new pods arrive; the
+ * lastPermittedPod TTL, core.go:95,188, flips a flag).  bs_pods_apply patches the queue loaded by bs_pods_load ON
+ * THE DEVICE instead of re-uploading and re-hashing it: pods, their request classes, the (group, request class)
+ * pairs and the per-group pod minima stay resident.  One call = one delta against the CURRENT queue (p pods):
+ *   remove      [n_remove] indices into the current queue, strictly ascending: stable removal
+ *   flag_index  [n_flags]  indices into the current queue, strictly ascending, with flag_value[i] = the pod's new
+ *               bs_pods_soa.flags byte (an update of a pod that is also removed is ignored)
+ *   insert      insert.p new pods (same arrays as bs_pods_load); insert_at[k] = position of inserted pod k in the
+ *               NEW queue (p - n_remove + insert.p pods), strictly ascending; NULL = append at the tail.  Retained
+ *               pods keep their relative order and fill the positions in between.
+ * Validated as a whole before anything is applied (BS_ERR_INVALID leaves the queue untouched).  Results of the next
+ * bs_batch_run equal those after bs_pods_load of the new queue, bit for bit; only fl_slot row NUMBERS may differ
+ * (rows are named after request classes, and a class whose last pod left keeps its number until the library
+ * re-derives the classes — it does so by itself when the id space fills up).  Returns without waiting for the GPU.
+ * bs_pods_count / bs_pods_read report the resident queue (bs_pods_read: caller-sized arrays, out->p must match). */
+typedef struct bs_pods_delta {
+  uint32_t n_remove;
+  const uint32_t* remove;
+  uint32_t n_flags;
+  const uint32_t* flag_index;
+  const uint8_t*  flag_value;
+  bs_pods_soa     insert;
+  const uint32_t* insert_at;
+} bs_pods_delta;
+int bs_pods_apply(bs_ctx* ctx, const bs_pods_delta* delta);
+int bs_pods_count(const bs_ctx* ctx, uint32_t* p_out);
+typedef struct bs_pods_out {
+  uint32_t p;
+  int32_t*  group;
+  int64_t*  req;          /* [L][p] */
+  uint32_t* req_present;
+  uint32_t* cls;
+  uint64_t* owner;
+  uint8_t*  flags;
+} bs_pods_out;
+int bs_pods_read(bs_ctx* ctx, const bs_pods_out* out);
 
 /* node churn (BASELINE config 5): stable delete / append / requested-update */
 #define BS_DELTA_UPDATE 0u   /* replace node `index` (all lanes, presence, flags, fit column) */
@@ -456,6 +498,9 @@ typedef struct bs_batch_stats {
   uint64_t chain;                   /* 0 general chain, 1 steady-state chain, 2 positional three-launch chain */
 } bs_batch_stats;
 int bs_batch_stats_get(bs_ctx* ctx, bs_batch_stats* out);
+/* bs_pods_apply calls so far, and how many of them (plus later batches) had to re-derive classes and pairs from the
+ * resident queue instead of patching them (id space used up, very large deltas, group count changed). */
+int bs_pods_apply_stats(const bs_ctx* ctx, uint64_t* applies, uint64_t* rederives);
 
 #ifdef __cplusplus
 }

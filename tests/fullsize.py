@@ -19,6 +19,11 @@ BATCH_CASES = [("cfg3", "cold", 1), ("cfg3", "warm", 2), ("cfg3", "busy", 3), ("
 CHURN = dict(config="cfg3", scenario="tail", seed=7, rounds=100, events=100)
 
 
+# the pending-queue counterpart: 10 000 pod events (40 % stable remove, 30 % append, 10 % insert in mid-queue, 20 % flag flip),
+# a re-score every 100 through bs_pods_apply — the queue itself is never re-uploaded
+POD_CHURN = dict(config="cfg3", scenario="tail", seed=9, rounds=100, events=100)
+
+
 def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:32]
 
@@ -92,3 +97,40 @@ class ChurnStream:
 
     def current(self):
         return self.soa.Nodes(self.alloc, self.req, self.ap, self.rp, self.fl), self.soa.FitMasks.from_bool(self.fitb)
+
+
+class PodChurnStream:
+    """The pod event stream of POD_CHURN, seeded.  Every call draws one delta of `events` events against the current queue
+    (removals, flag flips, appended pods, pods inserted in mid-queue; one in ten new pods asks for something no pod asked
+    before: a new request class) and keeps the host mirror of the queue — what a full reload would upload."""
+
+    def __init__(self, pods, seed: int):
+        self.soa = importlib.import_module("batch-scheduler_amd.soa")
+        self.rng = np.random.default_rng(seed + 23)
+        self.pods = pods.copy()
+        self.novel = 0
+
+    def next_delta(self, events: int) -> dict:
+        rng, soa, cur = self.rng, self.soa, self.pods
+        kinds = rng.choice(4, events, p=[0.4, 0.3, 0.1, 0.2])
+        n_rem = min(int((kinds == 0).sum()), cur.p)
+        n_app, n_mid, n_flag = int((kinds == 1).sum()), int((kinds == 2).sum()), int((kinds == 3).sum())
+        remove = np.sort(rng.choice(cur.p, n_rem, replace=False)).astype(np.uint32)
+        stay = np.setdiff1d(np.arange(cur.p, dtype=np.uint32), remove)
+        flag_index = np.sort(rng.choice(stay, min(n_flag, len(stay)), replace=False)).astype(np.uint32)
+        flag_value = (cur.flags[flag_index] ^ np.uint8(soa.POD_LAST_PERMITTED)).astype(np.uint8)
+        ni = n_app + n_mid
+        src = rng.integers(0, cur.p, ni)
+        ins = cur.take(src)                                                # new pods of existing templates, in existing gangs
+        ins.flags[:] = 0
+        for k in np.nonzero(rng.random(ni) < 0.1)[0]:
+            self.novel += 1
+            ins.req[0, k] = 100 + 7 * self.novel                         # nobody asked for this before: a new request class
+        pn = cur.p - n_rem + ni
+        kept = cur.p - n_rem
+        mid = np.sort(rng.choice(max(kept + n_mid, 1), n_mid, replace=False)) if n_mid else np.zeros(0, np.int64)   # positions among kept + mid pods
+        insert_at = np.concatenate([mid, np.arange(pn - n_app, pn)]).astype(np.uint32)
+        delta = dict(remove=remove, flag_index=flag_index, flag_value=flag_value, insert=ins, insert_at=insert_at)
+        self.pods = cur.patched(**delta)
+        assert self.pods.p == pn
+        return delta

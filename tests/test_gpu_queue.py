@@ -1,0 +1,191 @@
+"""GPU tests of the queue-resident cycle: bs_pods_apply patches pods, request classes, (group, class) pairs and per-group
+minima on the device; every batch after a patch must equal the batch after a full reload of the same queue — and the
+oracle's sequential PreFilter calls (core.go:88-167) on it.  Everything goes through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fullsize
+import naive_ref as nv
+from scenarios import random_objects
+from test_gpu_parity import assert_batch_equal, load_ctx, _force_class_mode
+
+pytestmark = pytest.mark.gpu
+DIGESTS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_digests.json")))
+
+
+def random_delta(rng, cur, soa, max_events=12, novel_base=0):
+    """one random delta against `cur`: stable removals, flag flips, insertions anywhere (or None = append)"""
+    n_rem = int(rng.integers(0, min(max_events, cur.p) + 1))
+    remove = np.sort(rng.choice(cur.p, n_rem, replace=False)).astype(np.uint32)
+    stay = np.setdiff1d(np.arange(cur.p, dtype=np.uint32), remove)
+    n_flag = int(rng.integers(0, min(max_events, len(stay)) + 1))
+    flag_index = np.sort(rng.choice(stay, n_flag, replace=False)).astype(np.uint32) if n_flag else np.zeros(0, np.uint32)
+    flag_value = (cur.flags[flag_index] ^ np.uint8(soa.POD_LAST_PERMITTED)).astype(np.uint8)
+    ni = int(rng.integers(0, max_events + 1)) if cur.p else 0
+    ins, at = None, None
+    if ni:
+        ins = cur.take(rng.integers(0, cur.p, ni))
+        ins.flags[:] = rng.integers(0, 2, ni).astype(np.uint8) * np.uint8(soa.POD_LAST_PERMITTED) * (rng.random(ni) < 0.2)
+        for k in np.nonzero(rng.random(ni) < 0.3)[0]:                  # requests nobody made before, sometimes shared by two new pods
+            ins.req[0, k] = 77 + 13 * (novel_base + int(k) // 2)
+        pn = cur.p - n_rem + ni
+        if rng.random() < 0.7:
+            at = np.sort(rng.choice(pn, ni, replace=False)).astype(np.uint32)
+    return dict(remove=remove, flag_index=flag_index, flag_value=flag_value, insert=ins, insert_at=at)
+
+
+def scene(seed, bsa, soa, steady):
+    rng = np.random.default_rng(seed)
+    n_classes = 3
+    sc = random_objects(seed, n_nodes=40 + seed % 90, n_groups=9, n_pods=160, n_scalars=seed % 3, n_classes=n_classes)
+    nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"],
+                                            denied=sc["denied"], permitted=sc["permitted"])
+    if steady:
+        _force_class_mode(groups, rng, n_classes)
+        groups.matched[:] = rng.integers(1, 4, groups.g)
+    return rng, nodes, fit, groups, pods
+
+
+@pytest.mark.parametrize("steady", [True, False], ids=["steady", "positional"])
+@pytest.mark.parametrize("seed", range(9100, 9124))
+def test_pods_apply_equals_reload_and_oracle(seed, steady, bsa, soa, orc):
+    """Rounds of random deltas on random scenes: the resident queue == the host-patched queue (bs_pods_read), the batch ==
+    the oracle on that queue == a context that reloads it.  steady: every batch takes the three-launch class chain;
+    positional: first-pod captures and MinResources defaults are still possible (positional / general chain)."""
+    rng, nodes, fit, groups, pods = scene(seed, bsa, soa, steady)
+    snap = orc.Snapshot(nodes, fit)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx, load_ctx(bsa, nodes, fit, groups, pods) as ref:
+        cur = pods
+        for rnd in range(7):
+            if rnd != 3:                                                 # round 3: patch without a batch in between (two deltas back to back)
+                exp = orc.Sop(snap, groups).batch(cur, soa.STAGE_ALL)
+                got = ctx.batch(soa.STAGE_ALL)
+                assert_batch_equal(got, exp, f"seed {seed} round {rnd} (apply)")
+                if rnd in (0, 4):
+                    ref.load_pods(cur)
+                    assert_batch_equal(ref.batch(soa.STAGE_ALL), exp, f"seed {seed} round {rnd} (reload)")
+                if steady:
+                    assert ctx.stats(soa.STAGE_ALL)["fast_path"] == 1
+            d = random_delta(rng, cur, soa, novel_base=100 * rnd)
+            ctx.apply_pods(**d)
+            cur = cur.patched(**d)
+            assert ctx.p == cur.p
+            assert ctx.read_pods().equal(cur), f"seed {seed} round {rnd}: resident queue differs from the patched queue"
+        applies, rederives = ctx.apply_stats()
+        assert applies >= 6 and rederives == 0, "small deltas must be patched, not re-derived"
+
+
+@pytest.mark.parametrize("knob", ["BS_ID_ROOM=3", "BS_SERIAL_INSERT_MAX=0", "BS_HASH_BITS=2"])
+def test_pods_apply_rederive_paths(knob, monkeypatch, bsa, soa, orc):
+    """A used-up id space and a delta too large for the insert wave take the re-derivation path; a 2-bit hash makes every
+    directory probe collide.  Results stay those of a reload."""
+    k, v = knob.split("=")
+    monkeypatch.setenv(k, v)
+    rng, nodes, fit, groups, pods = scene(9300, bsa, soa, True)
+    snap = orc.Snapshot(nodes, fit)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        cur = pods
+        for rnd in range(6):
+            d = random_delta(rng, cur, soa, novel_base=50 * rnd)
+            ctx.apply_pods(**d)
+            cur = cur.patched(**d)
+            assert ctx.read_pods().equal(cur)
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), orc.Sop(snap, groups).batch(cur, soa.STAGE_ALL), f"{knob} round {rnd}")
+        applies, rederives = ctx.apply_stats()
+        assert (rederives > 0) == (k != "BS_HASH_BITS")
+
+
+def test_pods_apply_validates_and_is_atomic(bsa, soa, orc):
+    rng, nodes, fit, groups, pods = scene(9400, bsa, soa, True)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        one = pods.take([0])
+        two = pods.take([0, 1])
+        bad = [dict(remove=[pods.p]), dict(remove=[3, 3]), dict(remove=[4, 2]), dict(flag_index=[pods.p], flag_value=[0]),
+               dict(flag_index=[2, 1], flag_value=[0, 0]), dict(insert=one, insert_at=[pods.p + 1]), dict(insert=two, insert_at=[5, 5]),
+               dict(remove=[0], insert=one, insert_at=[pods.p])]
+        for b in bad:
+            with pytest.raises(bsa.BsError) as e:
+                ctx.apply_pods(**b)
+            assert e.value.status == -1, b
+        assert ctx.read_pods().equal(pods), "a refused delta must leave the queue untouched"
+        ctx.apply_pods()                                                   # the empty delta is fine
+        assert ctx.apply_stats()[0] == 0
+        # drain the queue completely, then fill it again
+        ctx.apply_pods(remove=np.arange(pods.p))
+        assert ctx.p == 0 and ctx.read_pods().p == 0
+        out = ctx.batch(soa.STAGE_ALL, bitmap=False)
+        assert out.group_admit.sum() == 0
+        ctx.apply_pods(insert=pods)
+        assert ctx.read_pods().equal(pods)
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL), "refilled queue")
+
+
+def test_pods_apply_with_group_and_node_changes_in_between(bsa, soa, orc):
+    """One scheduling cycle after another the way a shim drives them: group counters, node requests and the queue all move."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "tail", seed=5)
+    stream = fullsize.PodChurnStream(pods, 5)
+    rng = np.random.default_rng(5)
+    cur_groups = groups.copy()
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        for rnd in range(8):
+            idx = rng.choice(groups.g, 10, replace=False)
+            deltas = []
+            for i in idx:
+                cur_groups.matched[i] = rng.integers(0, cur_groups.min_member[i] + 1)
+                cur_groups.flags[i] = (cur_groups.flags[i] & 0x6) | (8 * int(rng.integers(0, 2)))
+                deltas.append((i, cur_groups.matched[i], cur_groups.status_scheduled[i], cur_groups.flags[i]))
+            ctx.apply_group_deltas(deltas)
+            ctx.apply_pods(**stream.next_delta(40))
+            if rnd == 4:                                                 # G changes: pairs and per-group minima are re-derived from the resident queue
+                cur_groups = soa.Groups(*[np.concatenate([getattr(cur_groups, k), getattr(cur_groups, k)[..., :1]], axis=-1) for k in
+                                          ("min_member", "status_scheduled", "matched", "flags", "cls", "min_resources", "min_resources_present", "occupied_by")])
+                ctx.load_groups(cur_groups)
+            exp = orc.Sop(orc.Snapshot(nodes, fit), cur_groups).batch(stream.pods, soa.STAGE_ALL)
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"cycle {rnd}")
+
+
+def test_pod_churn_stream_10000_events(bsa, soa, orc):
+    """cfg3 + 10 000 pod events, a re-score after every 100 through bs_pods_apply: 100 incremental re-scores, each equal to
+    a full oracle recompute on the patched queue (digest of every output array; every 10th round re-computed live)."""
+    c = DIGESTS["pod_churn"]["params"]
+    assert c == fullsize.POD_CHURN
+    nodes, fit, groups, pods, _ = bsa.synth.make(c["config"], c["scenario"], seed=c["seed"])
+    stream = fullsize.PodChurnStream(pods, c["seed"])
+    st = soa.STAGE_PREFILTER | soa.STAGE_TALLY
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        for rnd, want in enumerate(DIGESTS["pod_churn"]["rounds"]):
+            ctx.apply_pods(**stream.next_delta(c["events"]))
+            assert ctx.p == want["p"]
+            got = ctx.batch(st, bitmap=False)
+            have = fullsize.sha(np.concatenate([getattr(got, a).view(np.uint8).ravel() for a in fullsize.ARRAYS]))
+            if have != want["all"] or rnd % 10 == 9:
+                exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(stream.pods, st, bitmap=False)
+                assert_batch_equal(got, exp, f"pod churn round {rnd}", bitmap=False)
+            assert have == want["all"], f"pod churn round {rnd}: digest differs although the live oracle agrees -> stale golden file"
+        assert ctx.read_pods().equal(stream.pods)
+        applies, rederives = ctx.apply_stats()
+        assert applies == len(DIGESTS["pod_churn"]["rounds"]) and rederives <= 2
+
+
+@pytest.mark.parametrize("config,scenario", [("cfg2", "cold"), ("tiny", "cold"), ("cfg2", "tail")])
+def test_latency_mode_on_both_chains_with_resident_queue(config, scenario, bsa, soa, orc):
+    """BS_BATCH_HOST_RESULTS on the positional chain too (cold: first-pod captures), and combined with bs_pods_apply: the
+    cycle a shim runs in latency mode — patch the queue, run, poll the completion word — gives the bits of the plain calls."""
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
+    stream = fullsize.PodChurnStream(pods, 3)
+    snap = orc.Snapshot(nodes, fit)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        for it in range(5):
+            if it:
+                ctx.apply_pods(**stream.next_delta(20))
+            exp = orc.Sop(snap, groups).batch(stream.pods, soa.STAGE_ALL)
+            ctx.run(soa.STAGE_ALL | (soa.BATCH_HOST_RESULTS if it != 3 else 0))
+            out = soa.BatchOut.alloc(stream.pods.p, groups.g, nodes.n, bitmap=False, rows_cap=max(ctx.filter_rows_count(), 1))
+            ctx.read(out=out)
+            assert_batch_equal(out, exp, f"{config}/{scenario} latency cycle {it}", bitmap=False)
+            assert np.array_equal(out.bitmap_from_rows(), exp.fl_bitmap)
+        st = ctx.stats(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
+        assert st["chain"] == (2 if scenario == "cold" else 1)
