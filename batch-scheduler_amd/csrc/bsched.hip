@@ -1979,6 +1979,11 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   if ((rc = reserve_slots(c, run_filter))) return rc;
   const uint32_t scan_cap = c->scan_slots_cap, filter_cap = c->filter_slots_cap;
   (void)W;
+  // slot stamps are 1 + batch_seq % 65535: when the stamp starts over, a slot nobody wrote for 65535 batches would look live again
+  if (c->batch_seq % 65535u == 0) {
+    if (c->d_qstamp_s.p) HIPCHK(c, hipMemsetAsync(c->d_qstamp_s.p, 0, c->d_qstamp_s.cap, c->stream));
+    if (c->d_uflags.p) HIPCHK(c, hipMemsetAsync(c->d_uflags.p, 0, c->d_uflags.cap, c->stream));
+  }
 
   const bool captures_possible = c->n_uncaptured > 0 && P > 0;
   // request classes stand for the pods when nothing a pod derives can depend on its queue position:

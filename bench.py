@@ -180,6 +180,52 @@ def pct(xs, q):
     return float(np.percentile(xs, q)) if len(xs) else None
 
 
+def make_pod_deltas(bsa, pods, n_cycles, churn, seed=2):
+    """Prebuilt bs_pods_delta structs (the marshalling of ~100 pod records is the caller's and is not timed): every cycle
+    removes churn/2 random pods and appends as many new ones (clones of random queue members: same gangs, same templates),
+    so the queue length stays put and every cycle runs on the same amount of work."""
+    soa = bsa.soa
+    rng = np.random.default_rng(seed)
+    half = max(1, churn // 2)
+    keep, structs = [], []
+    for _ in range(n_cycles):
+        rem = np.sort(rng.choice(pods.p, half, replace=False)).astype(np.uint32)
+        ins = pods.take(rng.integers(0, pods.p, half))
+        d = soa.PodsDeltaStruct()
+        d.n_remove, d.remove = half, rem.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        d.n_flags = 0
+        d.insert = ins.as_struct()
+        keep.append((rem, ins))
+        structs.append(d)
+    return structs, keep
+
+
+def resident_cycle(bsa, ctx, groups, pods, nodes, stages, darr, ndeltas, out, iters):
+    soa = bsa.soa
+    churn = max(2, pods.p // 100)
+    structs, keep = make_pod_deltas(bsa, pods, iters + 5, churn)
+    ctx.load_pods(pods)
+    parts = {"groups_apply": [], "pods_apply": [], "run": [], "read": [], "total": []}
+    for it in range(iters + 5):
+        t0 = time.perf_counter()
+        ctx.apply_group_deltas_raw(darr, ndeltas)
+        t1 = time.perf_counter()
+        ctx.apply_pods_raw(structs[it])
+        t2 = time.perf_counter()
+        ctx.run(stages | soa.BATCH_HOST_RESULTS)
+        t3 = time.perf_counter()
+        ctx.read(out=out)
+        t4 = time.perf_counter()
+        if it >= 5:
+            for k, v in zip(("groups_apply", "pods_apply", "run", "read", "total"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)):
+                parts[k].append(v * 1e3)
+    applies, rederives = ctx.apply_stats()
+    r = {k: {"p50_ms": pct(v, 50), "p95_ms": pct(v, 95)} for k, v in parts.items()}
+    r["queue_churn_per_cycle"] = {"removed": churn // 2, "appended": churn // 2, "of": pods.p}
+    r["applies"], r["rederives"] = applies, rederives
+    return r
+
+
 def host_cycle(bsa, ctx, groups, pods, nodes, stages, iters=60):
     """One scheduling cycle as the Go shim would drive it, host-observed: patch the groups that changed (Permit /
     PostBind counters), hand over the pending pods, run the batch, read decisions + Filter rows back.
@@ -218,6 +264,10 @@ def host_cycle(bsa, ctx, groups, pods, nodes, stages, iters=60):
                 for k, v in zip(("groups_apply", "pods_load", "run", "read", "total"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)):
                     parts[k].append(v * 1e3)
         res[mode] = {k: {"p50_ms": pct(v, 50), "p95_ms": pct(v, 95)} for k, v in parts.items()}
+    # ---- the queue-resident cycle: the pending queue is NOT re-uploaded; bs_pods_apply patches 1 % of it per cycle on the
+    # device (half leave = a released gang's worth of pods, as many arrive), results in latency mode
+    res["resident"] = resident_cycle(bsa, ctx, groups, pods, nodes, stages, darr, len(deltas), out, iters)
+    ctx.load_pods(pods)
     full = []
     for it in range(iters // 2 + 5):
         t0 = time.perf_counter()

@@ -54,6 +54,33 @@ def main():
                 rows.append([ts[k + 1] - ts[k] for k in range(4)] + [ts[4] - ts[0]])
         med = np.median(np.array(rows), axis=0) * 1e6
         res[mode] = {n: round(float(m), 1) for n, m in zip(names + ["total"], med)}
+    # the queue-resident cycle: bs_pods_apply (1 % of the queue per cycle) instead of bs_pods_load, results in latency mode
+    sys.path.insert(0, ROOT)
+    import bench
+    structs, keep = bench.make_pod_deltas(bsa, pods, 120, max(2, pods.p // 100))
+    k = 0
+    for mode in ("resident_as_run", "resident_drained_after_each_call"):
+        rows = []
+        for it in range(50):
+            ts = [time.perf_counter()]
+            ctx.apply_group_deltas(deltas)
+            if mode.endswith("each_call"):
+                ctx.sync()
+            ts.append(time.perf_counter())
+            ctx.apply_pods_raw(structs[k]); k += 1
+            if mode.endswith("each_call"):
+                ctx.sync()
+            ts.append(time.perf_counter())
+            ctx.run(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
+            if mode.endswith("each_call"):
+                ctx.sync()
+            ts.append(time.perf_counter())
+            ctx.read(out=out)
+            ts.append(time.perf_counter())
+            if it >= 10:
+                rows.append([ts[j + 1] - ts[j] for j in range(4)] + [ts[4] - ts[0]])
+        med = np.median(np.array(rows), axis=0) * 1e6
+        res[mode] = {n: round(float(m), 1) for n, m in zip(["groups_apply", "pods_apply", "batch_run", "batch_read", "total"], med)}
     print(json.dumps({"workload": f"{config}/{scenario}", "us_p50": res,
                       "note": "drained_after_each_call: a stream wait after every call (only to split the phases; the cycle itself has one wait, inside bs_batch_read)"}))
 
