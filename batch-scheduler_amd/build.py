@@ -27,16 +27,17 @@ def hipcc() -> str:
 
 HOST_LIB_PATH = os.path.join(HERE, "libbsched_host.so")
 HOST_SRC = os.path.join(HERE, "host", "bs_host.cpp")
+HOST_SRCS = [HOST_SRC, os.path.join(HERE, "host", "bs_drain.cpp")]
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
     """The C++ host-side mirror of the reference's ScheduleOperation; links against libbsched.so."""
     build()
-    deps = [HOST_SRC, os.path.join(HERE, "..", "include", "bsched.h"), LIB_PATH]
+    deps = [*HOST_SRCS, os.path.join(HERE, "..", "include", "bsched.h"), LIB_PATH]
     if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
         return HOST_LIB_PATH
     cxx = shutil.which("g++") or "g++"
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB_PATH, HOST_SRC, "-L" + HERE, "-lbsched",
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB_PATH, *HOST_SRCS, "-L" + HERE, "-lbsched",
            "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))

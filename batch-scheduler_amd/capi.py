@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "bs_abi_version", "bs_strerror", "bs_last_error", "bs_create", "bs_destroy",
     "bs_nodes_load", "bs_fit_load", "bs_fit_build", "bs_fit_read", "bs_groups_load", "bs_groups_read", "bs_groups_apply", "bs_pods_map", "bs_pods_load",
     "bs_pods_apply", "bs_pods_count", "bs_pods_read", "bs_pods_apply_stats",
-    "bs_nodes_apply", "bs_nodes_count",
+    "bs_nodes_apply", "bs_nodes_count", "bs_nodes_assume",
     "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
     "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_filter_rows_count", "bs_queue_order_load", "bs_queue_sort",
     "bs_shard_set", "bs_reduce_external", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
@@ -48,6 +48,10 @@ class NodeDelta(C.Structure):
                 ("allocatable", C.c_int64 * soa.MAX_LANES), ("requested", C.c_int64 * soa.MAX_LANES),
                 ("allocatable_present", C.c_uint32), ("requested_present", C.c_uint32), ("flags", C.c_uint32),
                 ("fit_default", C.c_uint32), ("n_fit_exceptions", C.c_uint32), ("fit_exceptions", C.c_uint32 * 8)]
+
+
+class NodeRequest(C.Structure):
+    _fields_ = [("index", C.c_uint32), ("requested_present", C.c_uint32), ("requested", C.c_int64 * soa.MAX_LANES)]
 
 
 DELTA_UPDATE, DELTA_APPEND, DELTA_REMOVE = 0, 1, 2
@@ -106,6 +110,7 @@ def load_library(path: str | None = None):
     L.bs_queue_sort.argtypes = [vp, u32, P(i32), P(i32), P(C.c_int64), P(u32)]
     L.bs_nodes_apply.argtypes = [vp, P(NodeDelta), u32]
     L.bs_nodes_count.argtypes = [vp, P(u32)]
+    L.bs_nodes_assume.argtypes = [vp, P(NodeRequest), u32]
     L.bs_cluster_fits.argtypes = [vp, u32, C.c_float, P(C.c_int64), u32, P(u8), P(u32)]
     L.bs_node_left.argtypes = [vp, u32, C.c_float, P(C.c_int64), P(u32)]
     L.bs_scan_prefix.argtypes = [vp, u32, C.c_float, P(C.c_int64), P(u32), P(u32), P(u32)]
@@ -329,6 +334,16 @@ class Context:
         n = C.c_uint32(0)
         self._chk(self._lib.bs_nodes_count(self._h, C.byref(n)), "bs_nodes_count")
         self.n = int(n.value)
+
+    def assume_nodes(self, reqs):
+        """bs_nodes_assume: reqs = iterable of (node index, requested lanes, requested_present)"""
+        reqs = list(reqs)
+        arr = (NodeRequest * max(len(reqs), 1))()
+        for k, (idx, lanes, pres) in enumerate(reqs):
+            arr[k].index, arr[k].requested_present = int(idx), int(pres)
+            for j, v in enumerate(lanes):
+                arr[k].requested[j] = int(v)
+        self._chk(self._lib.bs_nodes_assume(self._h, arr, len(reqs)), "bs_nodes_assume")
 
     # -- single queries
     def cluster_fits(self, cls: int, pct: float, req, present: int = 0):

@@ -272,4 +272,28 @@ __global__ __launch_bounds__(kApplyBlock) void k_pods_apply(PodsDev old, const u
   }
 }
 
+// bs_nodes_assume: node `index` gets a new requested vector.  left4 (getLeftResource lanes, core.go:460-463) follows; the
+// cluster-wide bounds of left4 are only ever WIDENED here (they are pruning bounds: Filter skips a resource lane when even
+// the smallest left covers every request of a tile, and gives up on case 2 when the largest is below every request — a
+// bound that is too wide prunes less, never wrongly).  bs_nodes_load / bs_nodes_apply compute them exactly again.
+struct NodeRequest { uint32_t index, requested_present; int64_t requested[BS_MAX_LANES]; };
+__global__ void k_nodes_assume(const NodeRequest* reqs, uint32_t count, uint32_t L, uint32_t stride, const int64_t* alloc, int64_t* req, uint32_t* rpres,
+                               const uint8_t* flags, int64_t* left4, int64_t* lglob) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t n = reqs[t].index;
+  for (uint32_t j = 0; j < L; ++j) req[(size_t)j * stride + n] = reqs[t].requested[j];
+  rpres[n] = reqs[t].requested_present;
+  const bool ok = !(flags[n] & (BS_NODE_NIL | BS_NODE_NO_NODE));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t v = wsub(alloc[(size_t)j * stride + n], reqs[t].requested[j]);
+    left4[(size_t)j * stride + n] = v;
+    if (ok) {
+      atomicMin(reinterpret_cast<long long*>(&lglob[j]), (long long)v);
+      atomicMax(reinterpret_cast<long long*>(&lglob[4 + j]), (long long)v);
+    }
+  }
+}
+
 }  // namespace bs

@@ -151,6 +151,10 @@ struct bs_ctx {
   hipEvent_t ev_dstage = nullptr;
   bool dstage_busy = false;
   uint64_t n_applies = 0, n_rederives = 0;
+  void* h_nstage = nullptr;          // pinned: node requests of bs_nodes_assume
+  size_t h_nstage_cap = 0;
+  hipEvent_t ev_nstage = nullptr;
+  bool nstage_busy = false;
   size_t off_pf_code = 0, off_pf_first_k = 0, off_pf_leader = 0, off_fl_code = 0, off_fl_feasible = 0, off_fl_slot = 0, off_admit = 0, off_ready = 0, outpack_bytes = 0;
 
   // ---- batch scratch / outputs
@@ -985,6 +989,8 @@ int bs_destroy(bs_ctx* c) {
   if (c->h_hrows) (void)hipHostFree(c->h_hrows);
   if (c->h_gstage) (void)hipHostFree(c->h_gstage);
   if (c->h_dstage) (void)hipHostFree(c->h_dstage);
+  if (c->h_nstage) (void)hipHostFree(c->h_nstage);
+  if (c->ev_nstage) (void)hipEventDestroy(c->ev_nstage);
   if (c->ev_dstage) (void)hipEventDestroy(c->ev_dstage);
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   if (c->ev_query) (void)hipEventDestroy(c->ev_query);
@@ -2658,6 +2664,49 @@ int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
   rc = upload_fit(c);
   if (rc == BS_OK && c->have_groups) rc = analyse_groups(c);
   return rc;
+}
+
+int bs_nodes_assume(bs_ctx* c, const bs_node_request* reqs, uint32_t count) {
+  if (!c || (count && !reqs)) return BS_ERR_INVALID;
+  if (!c->have_nodes) { c->last_error = "bs_nodes_assume before bs_nodes_load"; return BS_ERR_STATE; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!count) return BS_OK;
+  const uint32_t N = c->N, L = c->L;
+  {
+    std::vector<uint32_t> seen(count);
+    for (uint32_t d = 0; d < count; ++d) {
+      if (reqs[d].index >= N) { c->last_error = "bs_nodes_assume: node index out of range"; return BS_ERR_INVALID; }
+      if (reqs[d].requested_present >> c->S) { c->last_error = "bs_nodes_assume: present bit beyond the scalar lanes"; return BS_ERR_INVALID; }
+      seen[d] = reqs[d].index;
+    }
+    std::sort(seen.begin(), seen.end());
+    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) { c->last_error = "bs_nodes_assume: a node index appears twice"; return BS_ERR_INVALID; }
+  }
+  static_assert(sizeof(bs_node_request) == sizeof(NodeRequest), "node request layout");
+  const size_t bytes = (size_t)count * sizeof(bs_node_request);
+  if (c->nstage_busy) { HIPCHK(c, hipEventSynchronize(c->ev_nstage)); c->nstage_busy = false; }
+  if (bytes > c->h_nstage_cap) {
+    if (c->h_nstage) (void)hipHostFree(c->h_nstage);
+    c->h_nstage = nullptr; c->h_nstage_cap = 0;
+    const size_t want = std::max<size_t>(2 * bytes, 16 << 10);
+    HIPCHK(c, hipHostMalloc(&c->h_nstage, want, hipHostMallocDefault));
+    c->h_nstage_cap = want;
+  }
+  std::memcpy(c->h_nstage, reqs, bytes);
+  for (uint32_t d = 0; d < count; ++d) {                          // the host mirror a later bs_nodes_apply starts from
+    for (uint32_t j = 0; j < L; ++j) c->h_nreq[(size_t)j * N + reqs[d].index] = reqs[d].requested[j];
+    c->h_rpres[reqs[d].index] = reqs[d].requested_present;
+  }
+  hipLaunchKernelGGL(k_nodes_assume, dim3(cdiv(count, 256)), dim3(256), 0, c->stream, reinterpret_cast<const NodeRequest*>(c->h_nstage), count, L, c->Ncap,
+                     c->d_alloc.as<int64_t>(), c->d_nreq.as<int64_t>(), c->d_rpres.as<uint32_t>(), c->d_nflags.as<uint8_t>(), c->d_left4.as<int64_t>(),
+                     c->d_lglob.as<int64_t>());
+  LAUNCHCHK(c, BS_KERNEL_PREPASS);
+  if (!c->ev_nstage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_nstage, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_nstage, c->stream));
+  c->nstage_busy = true;
+  c->bitmap_valid = false;
+  return BS_OK;
 }
 
 // -------------------------------------------------------------------------------------------------

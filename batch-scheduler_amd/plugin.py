@@ -21,7 +21,7 @@ PERMIT_READY, PERMIT_WAITING, PERMIT_NOT_MATCHED, PERMIT_NOT_FOUND = 0, 1, 2, 3
 HOST_SYMBOLS = ["bsh_create", "bsh_destroy", "bsh_set_time", "bsh_time", "bsh_gpu_calls", "bsh_add_group", "bsh_prefilter", "bsh_filter",
                 "bsh_permit", "bsh_postbind", "bsh_less", "bsh_start_batch", "bsh_sync", "bsh_group_matched", "bsh_group_status_scheduled",
                 "bsh_group_flags", "bsh_group_denied", "bsh_ttl_new", "bsh_ttl_free", "bsh_ttl_set", "bsh_ttl_add", "bsh_ttl_get",
-                "bsh_ttl_delete", "bsh_ttl_count"]
+                "bsh_ttl_delete", "bsh_ttl_count", "bsh_drain"]
 
 _hlib = None
 
@@ -66,8 +66,59 @@ def load_host_library():
         L.bsh_ttl_delete.argtypes = [vp, u64]
         L.bsh_ttl_count.restype = u32
         L.bsh_ttl_count.argtypes = [vp, i64]
+        L.bsh_drain.argtypes = [P(DrainIO)]
         _hlib = L
     return _hlib
+
+
+class DrainIO(C.Structure):
+    """bsh_drain_io of host/bs_drain.cpp"""
+    _fields_ = [("ctx", C.c_void_p), ("lanes", C.c_uint32),
+                ("n", C.c_uint32), ("allocatable", C.POINTER(C.c_int64)), ("requested", C.POINTER(C.c_int64)),
+                ("allocatable_present", C.POINTER(C.c_uint32)), ("requested_present", C.POINTER(C.c_uint32)), ("node_flags", C.POINTER(C.c_uint8)),
+                ("fit_bits", C.POINTER(C.c_uint32)), ("n_classes", C.c_uint32),
+                ("g", C.c_uint32), ("min_member", C.POINTER(C.c_uint32)), ("status_scheduled", C.POINTER(C.c_uint32)), ("matched", C.POINTER(C.c_uint32)),
+                ("group_flags", C.POINTER(C.c_uint8)),
+                ("pods", soa.PodsStruct), ("stages", C.c_uint32), ("max_cycles", C.c_uint32),
+                ("cap", C.c_uint32), ("admitted_group", C.POINTER(C.c_uint32)), ("admitted_pods", C.POINTER(C.c_uint32)),
+                ("admitted_ns", C.POINTER(C.c_int64)), ("cycle_ns", C.POINTER(C.c_int64)), ("pod_node", C.POINTER(C.c_int32)),
+                ("n_admitted", C.c_uint32), ("n_cycles", C.c_uint32), ("n_stuck", C.c_uint32), ("pods_left", C.c_uint32), ("total_ns", C.c_int64)]
+
+
+def drain(ctx: capi.Context, nodes: soa.Nodes, fit: soa.FitMasks, groups: soa.Groups, pods: soa.Pods, stages: int, max_cycles: int = 0) -> dict:
+    """The batched scheduling cycle until no gang is ready (host/bs_drain.cpp): score the queue, release the first ready gang,
+    assume its pods (first fit), patch nodes / groups / queue on the device, score again.  `ctx` must hold exactly this state;
+    nodes.requested / requested_present and the group counters are updated IN PLACE (pass copies to keep the originals)."""
+    lib = load_host_library()
+    u32p, i64p, u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
+    cap = max(groups.g, 1)
+    adm_g, adm_p = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    adm_ns, cyc_ns = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+    pod_node = np.full(max(pods.p, 1), -1, np.int32)
+    bits = np.ascontiguousarray(fit.bits, np.uint32)
+    io = DrainIO()
+    io.ctx, io.lanes = ctx._h, ctx.L
+    io.n = nodes.n
+    io.allocatable, io.requested = nodes.allocatable.ctypes.data_as(i64p), nodes.requested.ctypes.data_as(i64p)
+    io.allocatable_present, io.requested_present = nodes.allocatable_present.ctypes.data_as(u32p), nodes.requested_present.ctypes.data_as(u32p)
+    io.node_flags = nodes.flags.ctypes.data_as(u8p)
+    io.fit_bits, io.n_classes = bits.ctypes.data_as(u32p), fit.n_classes
+    io.g = groups.g
+    io.min_member, io.status_scheduled = groups.min_member.ctypes.data_as(u32p), groups.status_scheduled.ctypes.data_as(u32p)
+    io.matched, io.group_flags = groups.matched.ctypes.data_as(u32p), groups.flags.ctypes.data_as(u8p)
+    io.pods = pods.as_struct()
+    io.stages, io.max_cycles, io.cap = stages, max_cycles, cap
+    io.admitted_group, io.admitted_pods = adm_g.ctypes.data_as(u32p), adm_p.ctypes.data_as(u32p)
+    io.admitted_ns, io.cycle_ns = adm_ns.ctypes.data_as(i64p), cyc_ns.ctypes.data_as(i64p)
+    io.pod_node = pod_node.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = lib.bsh_drain(C.byref(io))
+    if rc != 0:
+        raise capi.BsError(rc, "bsh_drain", ctx._lib.bs_last_error(ctx._h).decode())
+    k = min(int(io.n_admitted), cap)
+    ctx.p = int(io.pods_left)
+    return dict(admitted_group=adm_g[:k].copy(), admitted_pods=adm_p[:k].copy(), admitted_ns=adm_ns[:k].copy(), cycle_ns=cyc_ns[:k].copy(),
+                pod_node=pod_node[: pods.p].copy(), n_admitted=int(io.n_admitted), n_cycles=int(io.n_cycles), n_stuck=int(io.n_stuck),
+                pods_left=int(io.pods_left), total_ns=int(io.total_ns))
 
 
 class ScheduleOperation:

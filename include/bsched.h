@@ -377,6 +377,17 @@ typedef struct bs_node_delta {
 } bs_node_delta;
 int bs_nodes_apply(bs_ctx* ctx, const bs_node_delta* deltas, uint32_t count);
 int bs_nodes_count(const bs_ctx* ctx, uint32_t* n_out);
+/* The scheduler's assume step for pods the plugin let through (upstream cache.AssumePod -> NodeInfo.AddPod ‡: the node's
+ * requested resources grow by the pod's request, its pod count by one) — what makes the next PreFilter (core.go:88) see a
+ * smaller cluster.  Node `index` gets a new requested vector (pods lane = podCount, as bs_nodes_soa.requested) and new
+ * requested-present bits; allocatable, flags, fit column and list position are unchanged.  Unlike bs_nodes_apply (list
+ * surgery, re-upload from the first changed node, a stream wait) this is a device-side scatter: ONE launch, the deltas read
+ * from pinned memory, nothing waited for.  A node index may appear only once per call; validated as a whole first. */
+typedef struct bs_node_request {
+  uint32_t index, requested_present;
+  int64_t  requested[BS_MAX_LANES];
+} bs_node_request;
+int bs_nodes_assume(bs_ctx* ctx, const bs_node_request* reqs, uint32_t count);
 
 /* ---- single queries: 1:1 drop-ins ------------------------------------------------- */
 /* compareClusterResourceAndRequire(pod of class `cls`, req, percent), core.go:595-632.

@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "libbs_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("bs_oracle.c", "bs_oracle_fit.c", "bs_oracle.h")] + [os.path.join(_ROOT, "include", "bsched.h")]
+    src = [os.path.join(_HERE, f) for f in ("bs_oracle.c", "bs_oracle_fit.c", "bs_oracle_seq.c", "bs_oracle.h")] + [os.path.join(_ROOT, "include", "bsched.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libbs_oracle.so"], stdout=subprocess.DEVNULL)
@@ -54,6 +54,14 @@ class SnapshotStruct(C.Structure):
 class SopStruct(C.Structure):
     _fields_ = [("snap", SnapshotStruct), ("groups", soa.GroupsStruct), ("max_finished_pg", C.c_int32),
                 ("has_max_status", C.c_int), ("faithful_cost", C.c_int), ("iters", C.c_uint64)]
+
+
+class SeqIO(C.Structure):
+    """orc_seq_io of bs_oracle_seq.c"""
+    _fields_ = [("sop", C.POINTER(SopStruct)), ("pods", C.POINTER(soa.PodsStruct)), ("stages", C.c_uint32),
+                ("pf_code", C.POINTER(C.c_uint8)), ("pod_node", C.POINTER(C.c_int32)), ("cap", C.c_uint32),
+                ("released_group", C.POINTER(C.c_uint32)), ("released_pods", C.POINTER(C.c_uint32)),
+                ("first_ns", C.POINTER(C.c_int64)), ("ready_ns", C.POINTER(C.c_int64)), ("n_released", C.c_uint32), ("total_ns", C.c_int64)]
 
 
 _lib = None
@@ -94,6 +102,8 @@ def lib():
         L.orc_filter_node.argtypes = [C.POINTER(SopStruct), C.POINTER(soa.PodsStruct), C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(C.c_uint8)]
         L.orc_batch.restype = None
         L.orc_batch.argtypes = [C.POINTER(SopStruct), C.POINTER(soa.PodsStruct), C.c_uint32, C.POINTER(soa.BatchOutStruct)]
+        L.orc_seq_replay.restype = None
+        L.orc_seq_replay.argtypes = [C.POINTER(SeqIO)]
         L.orc_ttl_new.restype = C.c_void_p
         L.orc_ttl_free.argtypes = [C.c_void_p]
         L.orc_ttl_set.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64]
@@ -246,6 +256,28 @@ class Sop:
         ps, os_ = pods.as_struct(), out.as_struct()
         lib().orc_batch(C.byref(self.struct), C.byref(ps), stages, C.byref(os_))
         return out
+
+
+def seq_replay(nodes, fit, groups, pods, stages: int = soa.STAGE_PREFILTER | soa.STAGE_TALLY) -> dict:
+    """One sequential scheduling pass over the queue, pod by pod (bs_oracle_seq.c): PreFilter, first-fit node choice, assume,
+    Permit, release at the quorum.  Works on COPIES of nodes / groups; returns them with the per-gang release records."""
+    nodes, groups = nodes.copy(), groups.copy()
+    snap = Snapshot(nodes, fit)
+    sop = Sop(snap, groups)                     # (Sop copies the groups once more: sop.groups is the mutated state)
+    cap = max(groups.g, 1)
+    pf = np.zeros(max(pods.p, 1), np.uint8)
+    pod_node = np.full(max(pods.p, 1), -1, np.int32)
+    rg, rp = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    t_first, t_ready = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+    ps = pods.as_struct()
+    io = SeqIO(C.pointer(sop.struct), C.pointer(ps), stages, pf.ctypes.data_as(C.POINTER(C.c_uint8)), pod_node.ctypes.data_as(C.POINTER(C.c_int32)), cap,
+               rg.ctypes.data_as(C.POINTER(C.c_uint32)), rp.ctypes.data_as(C.POINTER(C.c_uint32)),
+               t_first.ctypes.data_as(C.POINTER(C.c_int64)), t_ready.ctypes.data_as(C.POINTER(C.c_int64)), 0, 0)
+    lib().orc_seq_replay(C.byref(io))
+    k = min(int(io.n_released), cap)
+    return dict(released_group=rg[:k].copy(), released_pods=rp[:k].copy(), first_ns=t_first[:k].copy(), ready_ns=t_ready[:k].copy(),
+                pod_node=pod_node[: pods.p].copy(), pf_code=pf[: pods.p].copy(), n_released=int(io.n_released), total_ns=int(io.total_ns),
+                nodes=nodes, groups=sop.groups, iters=sop.iters)
 
 
 class TTL:

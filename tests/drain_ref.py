@@ -1,0 +1,110 @@
+"""Gang-granular reference drain (TEST INFRASTRUCTURE): the loop of batch-scheduler_amd/host/bs_drain.cpp with the oracle's
+sequential PreFilter / Filter replay (orc.Sop.batch) in place of bs_batch_run and numpy in place of the device patches.
+Same candidate order, same first-fit rule, same release bookkeeping — the GPU drain has to reproduce it gang by gang."""
+import importlib
+
+import numpy as np
+
+soa = importlib.import_module("batch-scheduler_amd.soa")
+
+
+def _holds(nodes, k, req, pres, S):
+    for j in range(3):
+        if req[j] > 0 and req[j] > nodes.allocatable[j, k] - nodes.requested[j, k]:
+            return False
+    if nodes.requested[3, k] + 1 > nodes.allocatable[3, k]:
+        return False
+    for s in range(S):
+        if not (pres >> s) & 1 or req[4 + s] <= 0:
+            continue
+        if not (int(nodes.allocatable_present[k]) >> s) & 1:
+            return False
+        rq = int(nodes.requested[4 + s, k]) if (int(nodes.requested_present[k]) >> s) & 1 else 0
+        if req[4 + s] > nodes.allocatable[4 + s, k] - rq:
+            return False
+    return True
+
+
+def _assume(nodes, k, req, pres, S):
+    nodes.requested[:3, k] += req[:3]
+    nodes.requested[3, k] += 1
+    for s in range(S):
+        if (pres >> s) & 1:
+            if not (int(nodes.requested_present[k]) >> s) & 1:
+                nodes.requested[4 + s, k] = 0
+            nodes.requested[4 + s, k] += req[4 + s]
+            nodes.requested_present[k] |= np.uint32(1 << s)
+
+
+def drain(orc, nodes, fit, groups, pods, stages, max_cycles=0):
+    nodes, groups = nodes.copy(), groups.copy()
+    S = nodes.lanes - 4
+    fitb = fit.to_bool()
+    cur = pods
+    orig = np.arange(pods.p)
+    pod_node = np.full(pods.p, -1, np.int64)
+    admitted, stuck = [], set()
+    cycles = 0
+    use_filter = bool(stages & soa.STAGE_FILTER)
+    def first_fit(trial, out, i):
+        req, pres, cls = cur.req[:, i], int(cur.req_present[i]), int(cur.cls[i])
+        for k in range(trial.n):
+            if trial.flags[k] or cls >= fitb.shape[0] or not fitb[cls, k]:
+                continue
+            if use_filter and not (int(out.fl_bitmap[k >> 6, i]) >> (k & 63)) & 1:
+                continue
+            if _holds(trial, k, req, pres, S):
+                _assume(trial, k, req, pres, S)
+                return k
+        return -1
+
+    while cur.p and not (max_cycles and cycles >= max_cycles):
+        out = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(cur, stages, bitmap=use_filter)
+        cycles += 1
+        passes = (out.pf_code < 16) & ((out.fl_feasible > 0) if use_filter else True)
+        trial = nodes.copy()
+        gone, gone_node, gang = [], [], None
+        for i0 in range(cur.p):
+            g = int(cur.group[i0])
+            if g == soa.POD_NOT_GROUPED:                       # unlabelled pods go through as they are met
+                if passes[i0]:
+                    at = first_fit(trial, out, i0)
+                    if at >= 0:
+                        gone.append(i0)
+                        gone_node.append(at)
+                continue
+            if g < 0 or g >= groups.g or not out.group_ready[g] or g in stuck or not passes[i0]:
+                continue
+            members = [i for i in range(i0, cur.p) if cur.group[i] == g and passes[i]]
+            attempt = trial.copy()
+            placed = []
+            for i in members:
+                at = first_fit(attempt, out, i)
+                if at < 0:
+                    break
+                placed.append(at)
+            if len(placed) < len(members):
+                stuck.add(g)
+                continue
+            trial = attempt
+            gang = (g, len(members))
+            gone += members
+            gone_node += placed
+            break
+        if gang is None and not gone:
+            break
+        nodes = trial
+        if gang is not None:
+            g, k = gang
+            groups.matched[g] += k
+            groups.flags[g] |= soa.GROUP_SCHEDULED_LATCH
+            groups.status_scheduled[g] += k
+            admitted.append(gang)
+        for i, at in zip(gone, gone_node):
+            pod_node[orig[i]] = at
+        keep = np.ones(cur.p, bool)
+        keep[gone] = False
+        cur, orig = cur.take(np.nonzero(keep)[0]), orig[keep]
+        if gang is None:
+            break
+    return dict(admitted=admitted, pod_node=pod_node, n_cycles=cycles, stuck=stuck, nodes=nodes, groups=groups, pods_left=cur.p)

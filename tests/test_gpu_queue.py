@@ -67,8 +67,6 @@ def test_pods_apply_equals_reload_and_oracle(seed, steady, bsa, soa, orc):
                 if rnd in (0, 4):
                     ref.load_pods(cur)
                     assert_batch_equal(ref.batch(soa.STAGE_ALL), exp, f"seed {seed} round {rnd} (reload)")
-                if steady:
-                    assert ctx.stats(soa.STAGE_ALL)["fast_path"] == 1
             d = random_delta(rng, cur, soa, novel_base=100 * rnd)
             ctx.apply_pods(**d)
             cur = cur.patched(**d)
@@ -123,6 +121,59 @@ def test_pods_apply_validates_and_is_atomic(bsa, soa, orc):
         assert_batch_equal(ctx.batch(soa.STAGE_ALL), orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL), "refilled queue")
 
 
+def test_nodes_assume_equals_node_update(bsa, soa, orc):
+    """bs_nodes_assume (device-side scatter of new requested vectors) == bs_nodes_apply UPDATE of the same nodes == the oracle
+    on the patched snapshot; validation is atomic."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "tail", seed=8)
+    rng = np.random.default_rng(8)
+    cur = nodes.copy()
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx, load_ctx(bsa, nodes, fit, groups, pods) as ref:
+        for rnd in range(5):
+            idx = rng.choice(cur.n, 9, replace=False)
+            reqs, deltas = [], []
+            for n in idx:
+                cur.requested[:3, n] += rng.integers(0, 1 + cur.allocatable[:3, n] // 8)
+                cur.requested[3, n] += 1
+                if cur.lanes > 4:
+                    cur.requested[4, n] += int(rng.integers(0, 2))
+                    cur.requested_present[n] |= 1
+                reqs.append((int(n), cur.requested[:, n].tolist(), int(cur.requested_present[n])))
+                d = bsa.capi.NodeDelta()
+                d.kind, d.index = bsa.capi.DELTA_UPDATE, int(n)
+                for j in range(cur.lanes):
+                    d.allocatable[j], d.requested[j] = int(cur.allocatable[j, n]), int(cur.requested[j, n])
+                d.allocatable_present, d.requested_present, d.flags = int(cur.allocatable_present[n]), int(cur.requested_present[n]), int(cur.flags[n])
+                fb = fit.to_bool()[:, n]
+                d.fit_default = 1
+                exc = np.nonzero(~fb)[0][:8]
+                d.n_fit_exceptions = len(exc)
+                for k, e in enumerate(exc):
+                    d.fit_exceptions[k] = int(e)
+                if (~fb).sum() > 8:
+                    continue
+                deltas.append(d)
+            ctx.assume_nodes(reqs)
+            exp = orc.Sop(orc.Snapshot(cur, fit), groups).batch(pods, soa.STAGE_ALL)
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"assume round {rnd}")
+            if len(deltas) == len(reqs):
+                ref.apply_node_deltas(deltas)
+                assert_batch_equal(ref.batch(soa.STAGE_ALL), exp, f"node update round {rnd}")
+            else:
+                ref.load_nodes(cur, fit)
+        for bad in ([(cur.n, [0] * cur.lanes, 0)], [(1, [0] * cur.lanes, 0), (1, [0] * cur.lanes, 0)], [(0, [0] * cur.lanes, 1 << (cur.lanes - 4))]):
+            with pytest.raises(bsa.BsError) as e:
+                ctx.assume_nodes(bad)
+            assert e.value.status == -1
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), orc.Sop(orc.Snapshot(cur, fit), groups).batch(pods, soa.STAGE_ALL), "after refused requests")
+        # a later list surgery starts from the assumed state (host mirror kept in step)
+        d = bsa.capi.NodeDelta()
+        d.kind, d.index = bsa.capi.DELTA_REMOVE, 0
+        ctx.apply_node_deltas([d])
+        cut = soa.Nodes(cur.allocatable[:, 1:], cur.requested[:, 1:], cur.allocatable_present[1:], cur.requested_present[1:], cur.flags[1:])
+        cfit = soa.FitMasks.from_bool(fit.to_bool()[:, 1:])
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), orc.Sop(orc.Snapshot(cut, cfit), groups).batch(pods, soa.STAGE_ALL), "remove after assume")
+
+
 def test_pods_apply_with_group_and_node_changes_in_between(bsa, soa, orc):
     """One scheduling cycle after another the way a shim drives them: group counters, node requests and the queue all move."""
     nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "tail", seed=5)
@@ -166,6 +217,7 @@ def test_pod_churn_stream_10000_events(bsa, soa, orc):
                 assert_batch_equal(got, exp, f"pod churn round {rnd}", bitmap=False)
             assert have == want["all"], f"pod churn round {rnd}: digest differs although the live oracle agrees -> stale golden file"
         assert ctx.read_pods().equal(stream.pods)
+        assert ctx.stats(st)["fast_path"] == 1, "the patched queue must still take the three-launch steady-state chain"
         applies, rederives = ctx.apply_stats()
         assert applies == len(DIGESTS["pod_churn"]["rounds"]) and rederives <= 2
 
