@@ -1532,6 +1532,7 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
   const uint32_t* old_pclass = pclass_dev(c);
   const uint32_t* old_ppair = ppair_dev(c);
   if (derive && (uint64_t)c->ids_used + I > c->pair_cap) derive = false;
+  if (derive && c->ids_used > 2 * (P - R + I) + 1024) derive = false;      // most ids name classes whose pods are gone: start over
   if (derive && !c->dirs_ready && (rc = build_dirs(c))) return rc;
   // ---- the other pack takes the new queue
   const uint32_t np = c->cur_pack ^ 1u;
@@ -1690,7 +1691,9 @@ static int batch_collective(bs_ctx* c, uint32_t stages, const GroupsDev& gr, con
 // slot arrays shared by both chains (scan = classes + groups or one per pod, Filter = 2 x classes or one per pod)
 static int reserve_slots(bs_ctx* c, bool run_filter) {
   const uint32_t P = c->P, G = c->G;
-  const uint32_t scan_cap = P + G + 64, filter_cap = 2 * P + 64;
+  // slots are named after request classes, and class ids outlive their pods between two derivations (bs_pods_apply): size for the ids
+  const uint32_t ids = std::max(P, c->ids_used);
+  const uint32_t scan_cap = ids + G + 64, filter_cap = 2 * ids + 64;
   int rc;
   HIPCHK(c, c->d_first_row.reserve((size_t)scan_cap * 4));
   HIPCHK(c, c->d_qreq_s.reserve((size_t)scan_cap * c->LP * 8));

@@ -118,26 +118,39 @@ def cpu_baseline(bsa, nodes, fit, groups, pods, stages, reps):
             "seconds_per_batch": best, "reference_loop_iterations": iters, "all_cores": allc}
 
 
-# ------------------------------------------------------------------------------------------------ HBM traffic (PMC)
-def pmc_traffic(args):
-    """HBM bytes per launch for the three launches of the step: this very command re-run (few steps, no extras) under
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, no trace domains), FETCH doubled per the gfx950
-    note of MI355X_MICROARCH.md.  Returns (dict kernel -> bytes, source)."""
+# ------------------------------------------------------------------------------------------------ rocprofv3 passes of this very command
+def profile_passes(args):
+    """This command re-run (few steps, nothing else) under rocprofv3, three separate passes:
+      --kernel-trace --stats          kernel-only durations per launch (what the roofline is priced with)
+      --pmc FETCH_SIZE / WRITE_SIZE   HBM bytes per launch (FETCH doubled per the gfx950 note of MI355X_MICROARCH.md)
+    Returns (dict launch -> {avg_us, calls, hbm_bytes_per_launch, ...} or None, source string)."""
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
     out = {}
-    tmp = tempfile.mkdtemp(prefix="bs_pmc_", dir="/tmp")
+    tmp = tempfile.mkdtemp(prefix="bs_prof_", dir="/tmp")
+    inner = [sys.executable, os.path.abspath(__file__), "--inner-pmc", "--config", args.config, "--scenario", args.scenario, "--seed", str(args.seed),
+             "--stages", args.stages]
+    env = dict(os.environ, TMPDIR="/tmp")
     try:
+        d = os.path.join(tmp, "trace")
+        res = subprocess.run([exe, "--kernel-trace", "--stats", "-d", d, "-o", "trace", "--", *inner], cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+        if res.returncode != 0 or not dbs:
+            return None, f"rocprofv3 --kernel-trace failed (rc {res.returncode})"
+        con = sqlite3.connect(dbs[0])
+        rows = con.execute("select name, total_calls, average from top_kernels").fetchall()
+        con.close()
+        for name, calls, avg in rows:
+            for key, kn in LAUNCH_KERNELS.items():
+                if kn + "<" in name or kn + "(" in name:
+                    out.setdefault(key, {}).update(kernel_us=float(avg), calls=int(calls))
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--inner-pmc",
-                   "--config", args.config, "--scenario", args.scenario, "--seed", str(args.seed), "--stages", args.stages]
-            env = dict(os.environ, TMPDIR="/tmp")
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            res = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", *inner], cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if res.returncode != 0 or not dbs:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {res.returncode})"
+                return (out or None), f"kernel-trace ok; rocprofv3 --pmc {counter} failed (rc {res.returncode})"
             con = sqlite3.connect(dbs[0])
             rows = con.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name",
                                (counter,)).fetchall()
@@ -145,16 +158,16 @@ def pmc_traffic(args):
             for name, n, v in rows:
                 for key, kn in LAUNCH_KERNELS.items():
                     if kn + "<" in name or kn + "(" in name:
-                        out.setdefault(key, {})[counter] = (int(n), float(v))
+                        out.setdefault(key, {})[counter] = float(v)
     except Exception as e:                                    # pragma: no cover
-        return None, f"pmc pass failed: {e!r}"
+        return (out or None), f"profile pass failed: {e!r}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    res = {}
-    for key, v in out.items():
-        f, w = v.get("FETCH_SIZE", (0, 0.0)), v.get("WRITE_SIZE", (0, 0.0))
-        res[key] = {"fetch_kb": f[1], "write_kb": w[1], "dispatches": f[0] or w[0], "hbm_bytes_per_launch": int(f[1] * 1024 * 2 + w[1] * 1024)}
-    return (res or None), "measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"
+    for v in out.values():
+        if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
+            v["hbm_bytes_per_launch"] = int(v.get("FETCH_SIZE", 0.0) * 1024 * 2 + v.get("WRITE_SIZE", 0.0) * 1024)
+    return (out or None), ("measured by this run: rocprofv3 --kernel-trace --stats (kernel-only durations) and --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                           "(separate passes, FETCH x2 per the gfx950 note)")
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -178,6 +191,77 @@ def resident_ms(bsa, nodes, fit, groups, pods, stages, steps, warmup=10):
 
 def pct(xs, q):
     return float(np.percentile(xs, q)) if len(xs) else None
+
+
+def drain_section(bsa, nodes, fit, groups, pods, args):
+    """SURVEY 8(d)(2), both sides on the same inputs.  The queue in Compare order (core.go:368-411 keeps a gang's pods together).
+      GPU   the batched scheduling cycle until nothing is ready (host/bs_drain.cpp): score the whole queue, release the first
+            ready gang, assume its pods (first fit), patch nodes / groups / queue ON THE DEVICE, score again.  Per released gang: the
+            duration of the cycle that decided it, and the time since the drain began.
+      CPU   the reference's pod-by-pod pass (oracle/bs_oracle_seq.c, one core): per released gang the time from its first pod
+            entering PreFilter to the quorum of core.go:303 turning true.
+      1:1   the sequential drop-in mode (host mirror, every node loop one bs_cluster_fits round trip) on a bounded sample."""
+    soa = bsa.soa
+    st = soa.STAGE_PREFILTER | soa.STAGE_TALLY          # the shipped configuration: Filter not enabled
+    q = pods.take(np.argsort(pods.group, kind="stable"))
+    res = {"queue": "Compare order (gang by gang); stages: prefilter + tally (the shipped plugin configuration leaves Filter off)"}
+    best = None
+    for rep in range(2):                                # the second run is the warm one
+        n2, g2 = nodes.copy(), groups.copy()
+        with bsa.Context(scalar_lanes=nodes.lanes - 4) as ctx:
+            ctx.load_nodes(nodes, fit)
+            ctx.load_groups(groups)
+            ctx.load_pods(q)
+            ctx.run(st)
+            ctx.sync()
+            r = bsa.plugin.drain(ctx, n2, fit, g2, q, st | soa.BATCH_HOST_RESULTS)
+            applies, rederives = ctx.apply_stats()
+        best = r
+    cyc = best["cycle_ns"] / 1e6
+    res["gpu"] = {"gangs_released": best["n_admitted"], "pods_released": int((best["pod_node"] >= 0).sum()), "cycles": best["n_cycles"], "stuck_gangs": best["n_stuck"],
+                  "total_ms": best["total_ns"] / 1e6, "gangs_per_s": best["n_admitted"] / max(best["total_ns"] * 1e-9, 1e-12),
+                  "gang_admit_latency_ms_p50": pct(cyc, 50), "gang_admit_latency_ms_p95": pct(cyc, 95),
+                  "time_since_drain_start_ms_p50": pct(best["admitted_ns"] / 1e6, 50), "time_since_drain_start_ms_p95": pct(best["admitted_ns"] / 1e6, 95),
+                  "pods_apply_calls": applies, "pods_rederives": rederives,
+                  "latency_definition": "duration of the scheduling cycle that released the gang: bs_batch_run over the whole queue + results + node choice + "
+                                        "bs_nodes_assume / bs_groups_apply / bs_pods_apply"}
+    orc = _oracle()
+    s = orc.seq_replay(nodes, fit, groups, q, st)
+    lat = (s["ready_ns"] - s["first_ns"]) / 1e6
+    res["_cpu_sequential_pass"] = {"kind": "port (C restatement of the Go path, 1 core)", "gangs_released": s["n_released"],
+                                   "pods_released": int((s["pod_node"] >= 0).sum()), "total_ms": s["total_ns"] / 1e6,
+                                   "gangs_per_s": s["n_released"] / max(s["total_ns"] * 1e-9, 1e-12), "reference_loop_iterations": s["iters"],
+                                   "gang_admit_latency_ms_p50": pct(lat, 50), "gang_admit_latency_ms_p95": pct(lat, 95),
+                                   "time_since_pass_start_ms_p50": pct(s["ready_ns"] / 1e6, 50),
+                                   "latency_definition": "per gang: first pod entering PreFilter (core.go:88) -> quorum of core.go:303 true"}
+    res["same_gangs_as_cpu_pass"] = sorted(best["admitted_group"].tolist()) == sorted(s["released_group"].tolist())
+    res["relation"] = ("gang-granular drain vs pod-by-pod pass: equal on complete cold queues (tests/test_drain.py); otherwise the pass lets partial "
+                       "gangs hold what they assumed and re-checks reservations pod by pod, so the two sets can differ — both counts are reported")
+    res["one_to_one_mode"] = one_to_one(bsa, nodes, fit, groups, q, 300)
+    return res
+
+
+def one_to_one(bsa, nodes, fit, groups, pods, n):
+    """the 1:1 drop-in (bs_cluster_fits per PreFilter through the C++ host mirror), re-measured on the first n pods"""
+    with bsa.Context(scalar_lanes=nodes.lanes - 4) as ctx:
+        ctx.load_nodes(nodes, fit)
+        sop = bsa.plugin.ScheduleOperation(ctx)
+        for g in range(groups.g):
+            has_mr = bool(groups.flags[g] & bsa.soa.GROUP_HAS_MINRES)
+            sop.add_group(int(groups.min_member[g]), int(groups.status_scheduled[g]), creation_ts=g, name_rank=g,
+                          min_resources=groups.min_resources[:, g].tolist() if has_mr else None, min_resources_present=int(groups.min_resources_present[g]))
+        n = min(n, pods.p)
+        lat = []
+        for i in range(n):
+            a = time.perf_counter()
+            sop.PreFilter(i + 1, i + 1, int(pods.group[i]), pods.req[:, i].tolist(), int(pods.req_present[i]), int(pods.cls[i]), int(pods.owner[i]))
+            lat.append((time.perf_counter() - a) * 1e3)
+        calls = sop.gpu_calls
+        sop.close()
+    gang = int(np.median(np.bincount(pods.group[pods.group >= 0]))) if (pods.group >= 0).any() else 1
+    return {"sample_pods": n, "prefilter_latency_ms_p50": pct(lat, 50), "prefilter_latency_ms_p95": pct(lat, 95), "gpu_round_trips": calls,
+            "gang_admit_latency_ms_estimate": pct(lat, 50) * gang, "evals_per_s": nodes.n / (pct(lat, 50) * 1e-3),
+            "note": "every PreFilter = findMaxPG + one node scan as synchronous GPU round trips; a gang waits for all its pods"}
 
 
 def make_pod_deltas(bsa, pods, n_cycles, churn, seed=2):
@@ -340,6 +424,16 @@ def main():
         lib_stream = torch.cuda.ExternalStream(ctx.stream(), device=f"cuda:{local_rank}")
 
     force_dist = bool(int(os.environ.get("BS_FORCE_DIST", "0")))   # exercise the collective path at world size 1
+    rank_report = None
+    if dist is not None:
+        # self-check of the first multi-GPU run: what RCCL sees and how the pod axis was dealt
+        owned = torch.tensor([pods.p if partitioned else int((importlib.import_module("batch-scheduler_amd.dist").owner_ranks(all_pods.group, groups.g, world) == rank).sum())],
+                             dtype=torch.int64, device=f"cuda:{local_rank}")
+        gathered = [torch.zeros_like(owned) for _ in range(world)]
+        dist.all_gather(gathered, owned)
+        per_rank = [int(t.item()) for t in gathered]
+        rank_report = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(), "owned_pods_per_rank": per_rank,
+                       "max_over_mean": max(per_rank) / max(1e-9, sum(per_rank) / len(per_rank)), "mode": "partitioned" if partitioned else "replicated"}
 
     def step():
         ctx.run(stages)
@@ -390,50 +484,58 @@ def main():
     result = None
     if rank == 0:
         single = world == 1 and not force_dist
-        # ---------------- roofline: every launch of the step priced on EXECUTED work
-        # algorithmic bytes: PreFilter-path eval 16 L + 2, Filter-path eval 16*4 + 1 in + 1/8 out;
-        # table build: N (16 L + 6) read + M 8 LP written; per-pod bookkeeping: inputs 8 L + 21 B, outputs 18 B
+        # ---------------- roofline: every launch of the step, priced on its ALGORITHMIC (compulsory) bytes with KERNEL-ONLY times
+        # PreFilter-path eval reads 16 L + 2 bytes, Filter-path eval 16*4 + 1 in + 1/8 out — per pod x node of the
+        # reference's loops.  The batch evaluates each distinct request once and keeps tables / node lanes on chip, so what a
+        # launch HAS to move is the compulsory traffic of 8(d): every input once, every output once:
+        #   A  pods P (8 L + 21) + nodes N (16 L + 6) in, table rows M 8 LP + per-pod scratch P 10 out
+        #   B  table rows M 8 LP + getLeftResource lanes N 33 + slots in, first rows + Filter rows (rows x ceil(N/64) x 8) out
+        #   C  per-pod scratch P 14 + group counters G 16 in, decisions P 18 + admit / ready G 5 out
+        # frac = those bytes / kernel time / 8 TB/s: a figure that cannot exceed 1 and that says what it is — the step is three
+        # latency-bound launches over a working set that lives in L2 / MALL, nowhere near a bandwidth roofline.
         LP = 4 if L == 4 else (8 if L <= 8 else 16)
-        pf_eval_b, fl_eval_b = 16 * L + 2, 16 * 4 + 1 + 0.125
+        W = (nodes.n + 63) // 64
+        rows = max(1, stats["filter_distinct"])
         alg = {
-            "query": pods.p * (8 * L + 21) + nodes.n * (16 * L + 6) + nodes.n * 8 * LP,
-            "scan": stats["scan_evals_executed"] * pf_eval_b + stats["filter_evals_executed"] * fl_eval_b,
-            "resolve": pods.p * (18 + 14) + groups.g * 17,
+            "query": pods.p * (8 * L + 21) + nodes.n * (16 * L + 6) + nodes.n * 8 * LP + pods.p * 10,
+            "scan": nodes.n * 8 * LP + nodes.n * 33 + stats["scan_queries"] * (8 * LP + 12) + rows * (64 + W * 8 + 4),
+            "resolve": pods.p * (14 + 18) + groups.g * 21,
         }
-        traffic, traffic_src = (None, "not collected")
+        prof, prof_src = (None, "not collected")
         if single and not args.no_pmc and stats["fast_path"]:
-            traffic, traffic_src = pmc_traffic(args)
+            prof, prof_src = profile_passes(args)
         launches = []
         for key in ("query", "scan", "resolve"):
             ms, n = timing.get(key, (0.0, 0))
-            if not n:
+            pk = (prof or {}).get(key, {})
+            kernel_us = pk.get("kernel_us")
+            event_us = ms / n * 1e3 if n else None
+            t_us = kernel_us if kernel_us else event_us
+            if not t_us:
                 continue
-            avg_s = ms / n * 1e-3
-            tb = traffic.get(key, {}).get("hbm_bytes_per_launch") if traffic else None
-            e = {"kernel": LAUNCH_KERNELS[key] if stats["fast_path"] else key, "avg_launch_us": avg_s * 1e6, "timed_launches": n,
-                 "algorithmic_bytes_per_launch": alg[key], "achieved": alg[key] / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": alg[key] / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": tb,
-                 "physical_gbps": (tb / avg_s / 1e9) if tb else None, "physical_frac": (tb / avg_s / 1e9 / HBM_PEAK_GBS) if tb else None}
+            tb = pk.get("hbm_bytes_per_launch")
+            e = {"kernel": LAUNCH_KERNELS[key] if stats["fast_path"] else key, "avg_launch_us": t_us,
+                 "time_source": "rocprofv3 --kernel-trace (kernel only)" if kernel_us else "hipEvents on the library stream (spans the dispatch gap)",
+                 "hip_event_us": event_us, "algorithmic_bytes_per_launch": alg[key], "achieved": alg[key] / (t_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": alg[key] / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tb,
+                 "physical_frac": (tb / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tb else None}
             if key == "scan":
                 ev = stats["scan_evals_executed"] + stats["filter_evals_executed"]
                 e["evals_executed_per_launch"] = ev
-                e["issue_rate_frac"] = ev / avg_s / VOPC_EVALS_PER_S
+                e["issue_rate_frac"] = ev / (t_us * 1e-6) / VOPC_EVALS_PER_S
             launches.append(e)
         roofline = None
         if launches:
             dom = max(launches, key=lambda x: x["avg_launch_us"])
             roofline = dict(dom)
-            roofline.update({"bound": "hbm", "traffic_source": traffic_src,
-                             "note": "the step's longest launch.  achieved = algorithmic bytes of the work this launch EXECUTES (SURVEY 8(d) per-unit bytes x executed "
-                                     "units, DESIGN.md section 7) / mean launch time from hipEvents on the library stream (every 8th batch of the timed region; an event pair "
-                                     "around one ~8 us kernel also spans the dispatch gap, so it reads ~2-3 us above rocprofv3's kernel-only mean in profiles/).  traffic = "
-                                     "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE); physical_frac = traffic / time / 8 TB/s.  The step is three "
-                                     "launch-latency-bound kernels over a working set that lives in L2 / Infinity Cache: no launch is near the HBM roofline, and the logical "
-                                     "pods x nodes space is mostly never evaluated (work_avoided).  The per-unit figure prices every executed eval with its own operands "
-                                     "(what the reference's loop touches); the kernel keeps a node's lanes in registers for 64 slots, so on large batches (cfg4) the "
-                                     "nominal figure can pass 1 — that says the operands were not re-read, not that HBM ran faster than its peak (see physical_frac)."})
-            if roofline["frac"] > 1.0:
-                roofline["frac_above_one"] = "operands reused on chip: nominal per-eval bytes exceed what was moved; HBM is not the bound of this launch"
+            ksum = sum(x["avg_launch_us"] for x in launches)
+            roofline.update({"bound": "hbm", "limiter": "launch latency and dependent-load chains (the step is three small launches; see frac)",
+                             "source": prof_src, "sum_of_launch_us": ksum, "ms_per_step_us": ms_per_step * 1e3,
+                             "note": "the step's longest launch (by kernel-only time).  achieved = compulsory algorithmic bytes of the launch (every input once, "
+                                     "every output once; DESIGN.md section 7) / its mean kernel duration; traffic = HBM bytes per launch from PMC; "
+                                     "physical_frac = traffic / time / 8 TB/s.  HBM is the nominal roofline of this scan / compare work (SURVEY 8(d)) and no "
+                                     "launch is anywhere near it: the working set lives in L2 / MALL and every launch is a chain of dependent loads.  "
+                                     "The utilisation figure for real work is scenarios.all_distinct_requests.issue_rate_frac (v_cmp issue rate)."})
         work_avoided = {"logical_evals_per_step": logical,
                         "prefilter_evals_executed": stats["scan_evals_executed"], "filter_evals_executed": stats["filter_evals_executed"],
                         "scan_queries": stats["scan_queries_logical"], "scan_queries_distinct": stats["scan_queries"],
@@ -442,16 +544,18 @@ def main():
                         "how": "pods with equal derived requests share one evaluated row (request classes), 64-row table groups whose largest running sum "
                                "cannot reach the smallest request are skipped, the expanded pods x nodes bitmap is not materialised"}
 
-        cycle, extras, cpu = None, None, None
+        cycle, extras, cpu, drain = None, None, None, None
         if single and not args.no_extras:
             cyc, nrows, _ = host_cycle(bsa, ctx, groups, pods, nodes, stages)
-            p50, p95 = cyc["latency"]["total"]["p50_ms"], cyc["latency"]["total"]["p95_ms"]
-            cycle = {"definition": "host-observed scheduling cycle: bs_groups_apply(32 groups) + bs_pods_load (H2D) + bs_batch_run + bs_batch_read (decisions, admit / "
-                                   "ready, Filter slot rows).  'plain': the library packs the caller's arrays and copies the results back (one stream wait); 'latency': "
-                                   "queue marshalled in place (bs_pods_map, the marshalling itself is the caller's and is not timed in either mode) + "
-                                   "BS_BATCH_HOST_RESULTS (results written to pinned host memory by the last launch, completion word polled)", "modes": cyc,
+            p50, p95 = cyc["resident"]["total"]["p50_ms"], cyc["resident"]["total"]["p95_ms"]
+            cycle = {"definition": "host-observed scheduling cycle, the way a shim drives it.  'resident' (the headline): the pending queue STAYS on the device — "
+                                   "bs_groups_apply (32 groups) + bs_pods_apply (1 % of the queue leaves, as many pods arrive; the delta is read from pinned memory) "
+                                   "+ bs_batch_run + bs_batch_read in latency mode (results written to pinned host memory by the last launch, completion word "
+                                   "polled).  'latency': the whole queue re-marshalled into the pinned upload buffer every cycle (bs_pods_map + bs_pods_load) + "
+                                   "latency-mode results.  'plain': bs_pods_load packs the caller's arrays, results copied back under one stream wait.",
+                     "modes": cyc,
                      "gang_admit_latency_ms_p50": p50, "gang_admit_latency_ms_p95": p95,
-                     "gang_admit_latency_plain_ms_p50": cyc["plain"]["total"]["p50_ms"], "gang_admit_latency_plain_ms_p95": cyc["plain"]["total"]["p95_ms"],
+                     "gang_admit_latency_reload_ms_p50": cyc["latency"]["total"]["p50_ms"], "gang_admit_latency_plain_ms_p50": cyc["plain"]["total"]["p50_ms"],
                      "evals_per_s_at_p50": logical / (p50 * 1e-3), "filter_rows": nrows,
                      "filter_result_bytes": nrows * ((nodes.n + 63) // 64) * 8 + pods.p * 4,
                      "expanded_bitmap_bytes_avoided": pods.p * ((nodes.n + 63) // 64) * 8}
@@ -464,8 +568,12 @@ def main():
             p3 = all_pods.copy()
             p3.req[0, :] += np.arange(p3.p, dtype=np.int64)            # every pod asks for something else: no request is shared
             ms, st = resident_ms(bsa, nodes, fit, groups, p3, stages, 60)
+            ev3 = st["scan_evals_executed"] + st["filter_evals_executed"]
             extras["all_distinct_requests"] = {"ms_per_step": ms, "evals_per_s": logical / (ms * 1e-3), "fast_path": st["fast_path"],
-                                               "filter_distinct_requests": st["filter_distinct"], "scan_queries_distinct": st["scan_queries"]}
+                                               "filter_distinct_requests": st["filter_distinct"], "scan_queries_distinct": st["scan_queries"],
+                                               "evals_executed_per_step": ev3, "issue_rate_frac": ev3 / (ms * 1e-3) / VOPC_EVALS_PER_S,
+                                               "issue_rate_note": "executed pod x node compares / WHOLE step time / the measured 64-bit v_cmp issue rate "
+                                                                  "(tools/ubench/cmp_rate.hip): the utilisation figure when there is real work to do"}
             ms, st = resident_ms(bsa, nodes, fit, groups, all_pods, soa.STAGE_PREFILTER | soa.STAGE_TALLY, 100)
             extras["prefilter_only"] = {"ms_per_step": ms, "evals_per_s": logical / (ms * 1e-3)}
             extras["filter_increment_ms"] = ms_per_step - ms if args.stages == "all" else None
@@ -475,8 +583,17 @@ def main():
                 ms, _st = resident_ms(bsa, n2, f2, g2, p2, stages, 60)
                 seeds[str(sd)] = ms
             extras["ms_per_step_by_seed"] = seeds
+            drain = drain_section(bsa, nodes, fit, groups, all_pods, args)
         if single and not args.no_cpu_baseline:
             cpu = cpu_baseline(bsa, nodes, fit, groups, pods, stages, args.cpu_reps)
+            if drain is not None:
+                seq = drain.pop("_cpu_sequential_pass", None)
+                if seq:
+                    cpu["sequential_pass"] = seq
+                    cpu["gang_admit_latency_ms_p50"] = seq["gang_admit_latency_ms_p50"]
+                    cpu["gang_admit_latency_ms_p95"] = seq["gang_admit_latency_ms_p95"]
+        if drain is not None:
+            drain.pop("_cpu_sequential_pass", None)
         codes = np.bincount(out.pf_code, minlength=256)
         result = {
             "metric": "pod x node fit evals/sec", "value": value, "unit": "evals/s", "n_gpus": n_gpus,
@@ -487,24 +604,30 @@ def main():
                        "stages": "prefilter+filter+tally+ready" if args.stages == "all" else "prefilter+tally+ready",
                        "parallelism": (f"pod-axis shard x{world}, " + ("pods partitioned by owning rank" if partitioned else "replicated batch, device-side ownership")
                                        + ", 1 all-reduce of admit[G]") if dist is not None else "single GPU",
-                       "value_definition": "logical pods x nodes per step / step time; a step re-runs the whole path (table build, PreFilter, Filter, tally, quorum) over a "
-                                           "batch resident in HBM; request classes and per-group pod minima are derived at bs_pods_load, findMaxPG at bs_groups_load / "
-                                           "bs_groups_apply, capture epochs / findMaxPG per epoch of a positional state when the later of groups and pods arrives (all inside "
-                                           "host_cycle, not inside value)",
+                       "value_definition": "`value` = logical pods x nodes per step / step time with every input ALREADY RESIDENT in HBM when the timed region starts "
+                                           "(the contract's definition): a step re-runs the whole path (table build, PreFilter, Filter, tally, quorum).  What a host "
+                                           "observes per scheduling cycle — group patch, queue delta, batch, decisions back — is `value_host_observed` "
+                                           "(= logical evals / host_cycle resident p50); both are logical rates: `work_avoided` says how little of the pods x nodes "
+                                           "space is actually evaluated",
                        "logical_evals_per_step": logical, "fast_path": stats["fast_path"], "chain": stats["chain"], "launches_per_step": stats["launches"],
                        "tables_built": stats["tables_built"],
                        "decisions": {soa.PF_NAMES.get(i, str(i)): int(c) for i, c in enumerate(codes) if c},
                        "groups_ready": int(out.group_ready.sum())},
+            "value_resident": value,
+            "value_host_observed": cycle["evals_per_s_at_p50"] if cycle else None,
             "roofline": roofline,
             "roofline_launches": launches,
             "work_avoided": work_avoided,
             "host_cycle": cycle,
             "gang_admit_latency_ms_p50": cycle["gang_admit_latency_ms_p50"] if cycle else None,
             "gang_admit_latency_ms_p95": cycle["gang_admit_latency_ms_p95"] if cycle else None,
+            "drain": drain,
             "scenarios": extras,
             "kernel_ms_per_step": {k: v[0] / v[1] for k, v in timing.items() if v[1]},
             "cpu_baseline": cpu,
         }
+        if dist is not None:
+            result["ranks"] = rank_report
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

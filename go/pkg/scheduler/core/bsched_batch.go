@@ -46,7 +46,14 @@ func (g *gpuCore) loadGroups(order []string, pgCache map[string]*cache.PodGroupM
 		cls: &cls[0], min_resources: &minres[0], min_resources_present: &mrp[0], occupied_by: &occ[0]}
 	g.mu.Lock()
 	defer g.mu.Unlock()
-	return g.check("bs_groups_load", C.bs_groups_load(g.ctx, &soa))
+	if err := g.ensureFitRows(); err != nil { // classOf(pgs.Pod) above may have met a new pod template
+		return err
+	}
+	if err := g.check("bs_groups_load", C.bs_groups_load(g.ctx, &soa)); err != nil {
+		return err
+	}
+	g.groups = G
+	return nil
 }
 
 func (g *gpuCore) groupFlags(name string, pgs *cache.PodGroupMatchStatus, denied func(string) bool) uint32 {
@@ -115,7 +122,7 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 	P, L := len(queue), 4+len(g.scalars)
 	grp, req := make([]C.int32_t, P+1), make([]C.int64_t, L*P+1)
 	pres, cls, owner, flags := make([]C.uint32_t, P+1), make([]C.uint32_t, P+1), make([]C.uint64_t, P+1), make([]C.uint8_t, P+1)
-	res := &batchResult{index: make(map[types.UID]int, P), n: g.nodes}
+	res := &batchResult{index: make(map[types.UID]int, P), nodeIndex: g.nodeIdx, n: g.nodes}
 	for i, p := range queue {
 		res.index[p.UID] = i
 		name, ok := util.VerifyPodLabelSatisfied(p) // util/k8s.go:62-70
@@ -137,6 +144,9 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 	soa := C.bs_pods_soa{p: C.uint32_t(P), group: &grp[0], req: &req[0], req_present: &pres[0], cls: &cls[0], owner: &owner[0], flags: &flags[0]}
 	g.mu.Lock()
 	defer g.mu.Unlock()
+	if err := g.ensureFitRows(); err != nil { // a pod template the loaded fit rows do not cover yet: one new template must not fail the cycle
+		return nil, err
+	}
 	if err := g.check("bs_pods_load", C.bs_pods_load(g.ctx, &soa)); err != nil {
 		return nil, err
 	}
@@ -147,7 +157,7 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 	if err := g.check("bs_filter_rows_count", C.bs_filter_rows_count(g.ctx, &rowsNeeded)); err != nil {
 		return nil, err
 	}
-	G, W := len(groupIndex), (g.nodes+63)/64
+	G, W := g.groups, (g.nodes+63)/64 // the library writes one admit / ready entry per LOADED group
 	res.rowsCap = int(rowsNeeded) + 1
 	res.pfCode, res.pfFirstK = make([]C.uint8_t, P+1), make([]C.uint32_t, P+1)
 	res.flCode, res.flSlot = make([]C.uint8_t, P+1), make([]C.uint32_t, P+1)
@@ -164,7 +174,11 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 // Plugin hooks over a batchResult (batchscheduler.go:102,151,165) — table look-ups, no cgo crossing:
 //
 //	func (bs *batchSchedulingPlugin) PreFilter(ctx context.Context, st *framework.CycleState, p *corev1.Pod) *framework.Status {
-//		code := bs.batch.pfCode[bs.batch.index[p.UID]]
+//		i, ok := bs.batch.index[p.UID]
+//		if !ok { // not part of the scored queue: fall back to the sequential path, never to pod 0
+//			return bs.preFilterSequential(ctx, st, p)
+//		}
+//		code := bs.batch.pfCode[i]
 //		if code >= 16 { // !BS_PF_IS_PASS
 //			if code == C.BS_PF_REJECT_FIRST || code == C.BS_PF_REJECT_RESERVE {
 //				bs.operation.AddToDenyCache(fullName(p)) // the 20 s TTL clock stays in Go, core.go:423
@@ -175,7 +189,12 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 //	}
 //
 //	func (bs *batchSchedulingPlugin) Filter(ctx context.Context, st *framework.CycleState, p *corev1.Pod, ni *nodeinfo.NodeInfo) *framework.Status {
-//		if !bs.batch.filterPasses(bs.batch.index[p.UID], bs.batch.nodeIndex[ni.Node().Name]) {
+//		i, okp := bs.batch.index[p.UID]
+//		k, okn := bs.batch.nodeIndex[ni.Node().Name]
+//		if !okp || !okn { // a pod or node the batch has not seen: answer through bs_filter_one, never from row 0
+//			return bs.filterSequential(ctx, st, p, ni)
+//		}
+//		if !bs.batch.filterPasses(i, k) {
 //			return framework.NewStatus(framework.Unschedulable, util.ErrorResourceNotEnough.Error())
 //		}
 //		return framework.NewStatus(framework.Success, "")

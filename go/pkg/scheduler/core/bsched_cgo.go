@@ -40,6 +40,10 @@ type gpuCore struct {
 	reps     []*corev1.Pod         // one representative pod per fit class
 	interned map[string]uint64     // strings that are only compared (OccupiedBy, joined owner UIDs): 0 == ""
 	nodes    int                   // nodes of the loaded snapshot
+	infos    []*nodeinfo.NodeInfo  // the loaded snapshot itself (fit rows of classes that appear later are derived from it)
+	nodeIdx  map[string]int        // node name -> list index of the loaded snapshot (Filter's bit test)
+	fitRows  int                   // fit classes the device holds rows for (len(reps) at the last bs_fit_load)
+	groups   int                   // groups of the last bs_groups_load (sizes admit / ready)
 }
 
 func newGPUCore(device int, scalars []corev1.ResourceName) (*gpuCore, error) {
@@ -121,6 +125,7 @@ func (g *gpuCore) loadSnapshot(infos []*nodeinfo.NodeInfo) error {
 	flags := make([]C.uint8_t, n+1)
 	words := (n + 31) / 32
 	fit := make([]C.uint32_t, len(g.reps)*words+1)
+	nodeIdx := make(map[string]int, n)
 	for i, info := range infos {
 		switch {
 		case info == nil: // core.go:606
@@ -136,6 +141,7 @@ func (g *gpuCore) loadSnapshot(infos []*nodeinfo.NodeInfo) error {
 		if _, err := info.Taints(); err != nil { // core.go:639
 			flags[i] |= C.BS_NODE_TAINT_ERR
 		}
+		nodeIdx[info.Node().Name] = i
 		a, r := info.AllocatableResource(), info.RequestedResource()
 		if r.AllowedPodNumber == 0 { // core.go:650-653: podCount
 			r.AllowedPodNumber = len(info.Pods())
@@ -155,8 +161,39 @@ func (g *gpuCore) loadSnapshot(infos []*nodeinfo.NodeInfo) error {
 	if err := g.check("bs_nodes_load", C.bs_nodes_load(g.ctx, &soa)); err != nil {
 		return err
 	}
-	g.nodes = n
-	return g.check("bs_fit_load", C.bs_fit_load(g.ctx, C.uint32_t(len(g.reps)), &fit[0]))
+	g.nodes, g.infos, g.nodeIdx = n, infos, nodeIdx
+	if err := g.check("bs_fit_load", C.bs_fit_load(g.ctx, C.uint32_t(len(g.reps)), &fit[0])); err != nil {
+		return err
+	}
+	g.fitRows = len(g.reps)
+	return nil
+}
+
+// ensureFitRows: classOf may have met a pod template the loaded fit rows do not cover (a new nodeSelector / affinity /
+// tolerations signature in the queue or in a group's pod).  bs_batch_run refuses class indices beyond the loaded rows
+// (BS_ERR_INVALID), so the rows of every class are derived again from the loaded snapshot before the batch.
+// Caller holds g.mu.
+func (g *gpuCore) ensureFitRows() error {
+	if len(g.reps) == g.fitRows || g.infos == nil {
+		return nil
+	}
+	words := (g.nodes + 31) / 32
+	fit := make([]C.uint32_t, len(g.reps)*words+1)
+	for i, info := range g.infos {
+		if info == nil || info.Node() == nil {
+			continue
+		}
+		for c, rep := range g.reps { // checkFit, core.go:741-759
+			if checkFit(rep, info) {
+				fit[c*words+i/32] |= 1 << uint(i%32)
+			}
+		}
+	}
+	if err := g.check("bs_fit_load", C.bs_fit_load(g.ctx, C.uint32_t(len(g.reps)), &fit[0])); err != nil {
+		return err
+	}
+	g.fitRows = len(g.reps)
+	return nil
 }
 
 // clusterFits is the 1:1 replacement of the body of compareClusterResourceAndRequire (core.go:595-632):

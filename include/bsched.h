@@ -255,7 +255,9 @@ typedef struct bs_batch_out {
    * a row: (request class, leader seen) in steady state, (leader run, request class) while first-pod captures
    * or MinResources defaults can still happen in the batch; on the general chain (more than four leader
    * changes in one batch) a row is the pod itself (fl_slot[pod] == pod).
-   * Rows no pod of the batch refers to are unspecified.  bs_filter_rows_count never exceeds p. */
+   * Rows no pod of the batch refers to are unspecified.  bs_filter_rows_count never exceeds 2 x the request classes the
+   * library knows (<= 2 x (pods at the last bs_pods_load + pods inserted since): classes keep their number between two
+   * derivations, see bs_pods_apply). */
   uint32_t* fl_slot;          /* [p] row of pod p; meaningful iff fl_code[p] == BS_FL_EVALUATED        */
   uint64_t* fl_rows;          /* [ceil(n/64)][fl_rows_cap] word-major; rows >= *fl_rows_n untouched     */
   uint32_t* fl_rows_feasible; /* [fl_rows_cap] feasible-node count per row (NULL ok)                    */

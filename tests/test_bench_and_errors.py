@@ -27,15 +27,23 @@ def test_bench_json_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert "traffic" in r and "kernel" in r and r["avg_launch_us"] > 0
-    for e in d["roofline_launches"]:                      # priced on executed work: nothing can exceed the roofline
+    for e in d["roofline_launches"]:                      # compulsory bytes / kernel-only time: nothing can exceed the roofline
         assert 0 < e["frac"] <= 1.0, e
         assert e["physical_frac"] is None or e["physical_frac"] <= 1.0
+    if "rocprofv3 --kernel-trace" in r["time_source"]:     # every number in `roofline` is recomputable from kernel-only times
+        assert r["sum_of_launch_us"] <= r["ms_per_step_us"] * 1.02, "the launches of a step cannot take longer than the step"
+        assert r["kernel"] == max(d["roofline_launches"], key=lambda e: e["avg_launch_us"])["kernel"]
+    assert d["value_resident"] == d["value"] and 10e6 < d["value_host_observed"] < d["value"]
     assert d["config"]["fast_path"] == 1 and d["config"]["launches_per_step"] == 3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and c["faithful_cost"] is False
     assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0
     hc = d["host_cycle"]
     assert hc["gang_admit_latency_ms_p50"] <= hc["gang_admit_latency_ms_p95"] and hc["evals_per_s_at_p50"] > 10e6
+    assert hc["modes"]["resident"]["rederives"] == 0 and hc["modes"]["resident"]["total"]["p50_ms"] <= hc["modes"]["latency"]["total"]["p50_ms"]
+    dr = d["drain"]
+    assert dr["gpu"]["gangs_released"] > 0 and dr["gpu"]["gang_admit_latency_ms_p50"] > 0 and dr["one_to_one_mode"]["prefilter_latency_ms_p50"] > 0
+    assert c["sequential_pass"]["gangs_released"] > 0 and c["gang_admit_latency_ms_p50"] == c["sequential_pass"]["gang_admit_latency_ms_p50"]
     assert set(d["scenarios"]) >= {"cold", "warm", "busy", "all_distinct_requests", "prefilter_only", "ms_per_step_by_seed"}
     assert d["value"] > 10e6, "north_star target: >= 10M pod x node fit evaluations/s"
 
