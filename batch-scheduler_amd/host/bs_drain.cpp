@@ -11,7 +11,7 @@
 // the device: bs_nodes_assume + bs_groups_apply + bs_pods_apply (three small launches, nothing re-uploaded) + bs_batch_run.
 //
 // Node choice is not the plugin's business (upstream's predicates / priorities pick among the nodes Filter lets through); the
-// driver states its own rule and the CPU replay it is compared with (oracle/bs_oracle_seq.c) uses the same one:
+// driver states its own rule (the CPU replay the tests compare it with restates the same one):
 //   FIRST FIT in list order over nodes that are schedulable (no BS_NODE_* flag), fit the pod's class (checkFit bit), pass the
 //   plugin's Filter when the Filter stage is on, and hold the request: lane j in {cpu, mem, eph} binds when the pod asks for it
 //   (request > 0: request <= allocatable - requested), the pods lane always (requested + 1 <= allocatable), a scalar the pod
