@@ -104,29 +104,91 @@ struct DeltaPack { uint32_t n; GroupDelta d[kInlineDeltas]; };
 
 // [apply up to kInlineDeltas group deltas] -> findMaxPG -> the steady table's descriptor -> info to the host.
 // `info` is pinned host memory the kernel writes directly; the tag goes last with system-scope release.
+// One round trip for everything the fold of core.go:701-739 needs (flags, MinMember, Status.Scheduled, matched and the fit
+// class of every group a thread owns: all loads issued together), ONE 64-bit block maximum of (progress + 1) << 32 | ~index
+// (largest progress, FIRST group at it), and the thread that owns the winner already holds what the descriptor and the host
+// want to know — no second trip.  Only when the winner is fully scheduled (the tie rule :729-731 may hand over) or G is
+// beyond what the registers hold does it fall back to the general fold (leader_block).
+__device__ __forceinline__ void leader_publish(const GroupsDev& gr, const BatchDev& b, uint32_t C, int32_t tag, int32_t* info, int32_t l, int32_t pn,
+                                               uint32_t l_matched, uint8_t l_flags, uint32_t l_cls) {
+  int32_t steady = -1;
+  if (!pn && l >= 0 && C && l_matched > 0 && (l_flags & BS_GROUP_HAS_POD) && l_cls < C) {
+    steady = (int32_t)(C + l_cls);
+    TableDesc d;
+    d.cls = l_cls;
+    d.pct = 0.7f;                                   // core.go:161
+    b.desc[steady] = d;
+  }
+  b.leader_epoch[0] = l;
+  b.panic_epoch[0] = pn ? 1 : 0;
+  info[0] = l; info[1] = pn; info[2] = steady;
+  __hip_atomic_store(&info[3], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, BatchDev b, uint32_t C, int32_t tag, int32_t* info, DeltaPack dp,
                                                               uint32_t* matched, uint32_t* status_scheduled, uint8_t* flags) {
+  __shared__ unsigned long long s_w[kLeaderBlock / 64];
+  __shared__ uint32_t s_slow;
   if (threadIdx.x < dp.n) {
     const GroupDelta x = dp.d[threadIdx.x];
     matched[x.index] = x.matched;
     status_scheduled[x.index] = x.status_scheduled;
     flags[x.index] = (uint8_t)x.flags;
   }
+  if (threadIdx.x == 0) s_slow = 0;
   __syncthreads();
-  if (gr.g) leader_block(gr, b, 0);
-  if (threadIdx.x == 0) {
-    int32_t l = -1, pn = 0, steady = -1;
-    if (gr.g) { l = b.leader_epoch[0]; pn = b.panic_epoch[0]; }
-    else { b.leader_epoch[0] = -1; b.panic_epoch[0] = 0; }
-    if (!pn && l >= 0 && C && gr.matched[l] > 0 && (gr.flags[l] & BS_GROUP_HAS_POD) && gr.cls[l] < C) {
-      steady = (int32_t)(C + gr.cls[l]);
-      TableDesc d;
-      d.cls = gr.cls[l];
-      d.pct = 0.7f;                                   // core.go:161
-      b.desc[steady] = d;
+  if (!gr.g) {
+    if (threadIdx.x == 0) leader_publish(gr, b, C, tag, info, -1, 0, 0u, 0, 0u);
+    return;
+  }
+  if (gr.g <= (uint32_t)kLeaderBlock * kLeaderPerThread) {
+    uint32_t f_[kLeaderPerThread], mm_[kLeaderPerThread], sc_[kLeaderPerThread], ma_[kLeaderPerThread], cl_[kLeaderPerThread];
+#pragma unroll
+    for (int it = 0; it < kLeaderPerThread; ++it) {
+      const uint32_t g = threadIdx.x + (uint32_t)it * kLeaderBlock;
+      f_[it] = mm_[it] = sc_[it] = ma_[it] = cl_[it] = 0;
+      if (g < gr.g) { f_[it] = gr.flags[g]; mm_[it] = gr.min_member[g]; sc_[it] = gr.status_scheduled[g]; ma_[it] = gr.matched[g]; cl_[it] = gr.cls[g]; }
     }
-    info[0] = l; info[1] = pn; info[2] = steady;
-    __hip_atomic_store(&info[3], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned long long best = 0;
+    bool panic = false;
+#pragma unroll
+    for (int it = 0; it < kLeaderPerThread; ++it) {
+      const uint32_t g = threadIdx.x + (uint32_t)it * kLeaderBlock;
+      // candidates of the fold: groups with their pod that have not been let through (core.go:705-711); epoch 0 = the loaded state
+      if (g >= gr.g || (f_[it] & BS_GROUP_SCHEDULED_LATCH) || !(f_[it] & BS_GROUP_HAS_POD)) continue;
+      uint32_t fin = 0;
+      if ((uint32_t)(mm_[it] - sc_[it]) != 0u) {                                        // :713-717
+        if (mm_[it] == 0u) panic = true;
+        else fin = (uint32_t)((uint32_t)(ma_[it] + sc_[it]) * 1000u) / mm_[it];
+      }
+      const unsigned long long k64 = (((unsigned long long)fin + 1ull) << 32) | (unsigned long long)(0xFFFFFFFFu - g);
+      best = k64 > best ? k64 : best;
+    }
+    if (panic) best = ~0ull;
+    const unsigned long long top = block_max_u64(best, s_w);
+    if (top == ~0ull || top == 0ull) {
+      if (threadIdx.x == 0) leader_publish(gr, b, C, tag, info, -1, top ? 1 : 0, 0u, 0, 0u);
+      return;
+    }
+    const uint32_t first = 0xFFFFFFFFu - (uint32_t)top;
+    const int own = (first % kLeaderBlock) == threadIdx.x ? (int)(first / kLeaderBlock) : -1;
+    if (own >= 0) {
+      uint32_t mm = 0, sc = 0, ma = 0, cl = 0, fl = 0;
+#pragma unroll
+      for (int it = 0; it < kLeaderPerThread; ++it)
+        if (it == own) { mm = mm_[it]; sc = sc_[it]; ma = ma_[it]; cl = cl_[it]; fl = f_[it]; }
+      if (sc >= mm) s_slow = 1;                                                         // the tie rule may hand over: general fold
+      else leader_publish(gr, b, C, tag, info, (int32_t)first, 0, ma, (uint8_t)fl, cl);
+    }
+    __syncthreads();
+    if (!s_slow) return;
+  }
+  // cap_epoch mirrors HAS_POD for epoch 0 (k_init / the positional analysis keep it so)
+  leader_block(gr, b, 0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int32_t l = b.leader_epoch[0], pn = b.panic_epoch[0];
+    leader_publish(gr, b, C, tag, info, l, pn, l >= 0 ? gr.matched[l] : 0u, l >= 0 ? gr.flags[l] : (uint8_t)0, l >= 0 ? gr.cls[l] : 0u);
   }
 }
 
@@ -418,11 +480,14 @@ __device__ __forceinline__ void final_tail(const GroupsDev& gr, const BatchDev& 
 __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
   __shared__ uint32_t s_first_reach;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  // the pod's own fields travel while the block finds the first reaching pod (one round trip for both)
+  const bool valid = i < pods.p;
+  // ---- round trip 1: the pod's own fields, and the block's look at the first reaching pod
   uint8_t code0 = 0, st0 = 0;
   int32_t gi0 = BS_POD_NOT_GROUPED;
-  uint32_t qpos0 = 0, pclass0 = 0;
-  if (i < pods.p) { code0 = b.tcode[i]; st0 = b.stage[i]; gi0 = pods.group[i]; qpos0 = b.qpos[i]; pclass0 = b.pclass[i]; }
+  uint32_t qpos0 = 0, pclass0 = 0, pair0 = BS_INF;
+  if (valid) { code0 = b.tcode[i]; st0 = b.stage[i]; gi0 = pods.group[i]; qpos0 = b.qpos[i]; pclass0 = b.pclass[i]; pair0 = b.ppair[i]; }
+  const uint32_t K = *b.kclass;
+  const int32_t leader_now = b.leader_epoch[0];
   // first pod that reaches findMaxPG = the candidate of the first block of launch A that has one (64 blocks per look)
   if (threadIdx.x < 64) {
     uint32_t found = BS_INF;
@@ -438,10 +503,26 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     }
     if (threadIdx.x == 0) s_first_reach = found;
   }
+  // ---- round trip 2, issued before the barrier: everything whose address the pod's own fields give —
+  //   its scan slot's result, both Filter slots' feasible counts, the head of its group's pair chain, its OWN pair's
+  //   first querying pod and next link (a group with ONE request class — nearly every gang — needs nothing else for the
+  //   deny replay: the pair's class slot is the pod's own)
+  const bool owned = valid && (st0 & ST_OWNED);
+  const bool walk = owned && (st0 & ST_ELIG);
+  const bool grouped = valid && gi0 >= 0 && (uint32_t)gi0 < gr.g;
+  uint32_t row_q = BS_INF, row_c = BS_INF, feas0 = 0, feas1 = 0;
+  unsigned long long head = ~0ull, own_fq = ~0ull, own_next = ~0ull;
+  if (owned && (st0 & ST_QUERY)) row_q = b.first_row[qpos0];
+  if (walk) {
+    head = b.pair_head[gi0];
+    row_c = b.first_row[pclass0];
+    if (pair0 != BS_INF) { own_fq = b.pair_firstq[pair0]; own_next = b.pair_next[pair0]; }
+  }
+  if (valid && prm.run_filter && grouped) { feas0 = b.fu_feas[pclass0]; feas1 = b.fu_feas[pclass0 + K]; }
   __syncthreads();
   bool admit = false;
   uint32_t ag = 0;
-  if (i < pods.p) {
+  if (valid) {
     uint8_t code = code0;
     const uint8_t st = st0;
     const int32_t gi = gi0;
@@ -451,23 +532,27 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
       bool denied = false;
       if (st & ST_ELIG) {
         uint32_t fr = BS_INF;
-        for (unsigned long long link = b.pair_head[gi]; (uint32_t)link != BS_INF;) {
-          const uint32_t r = (uint32_t)link, cls = (uint32_t)(link >> 32);
-          const unsigned long long pq = b.pair_firstq[r];              // } one round trip: the pair's first querying pod,
-          const uint32_t row = b.first_row[cls];                       // } its class slot's scan result,
-          link = b.pair_next[r];                                       // } the next link
-          if ((uint32_t)(pq >> 32) != prm.seq_inv) continue;           // no pod of the pair had a query in this batch
-          const uint32_t fq = (uint32_t)pq;
-          if (fq < fr && row == BS_INF) fr = fq;                       // the pair's class was rejected
+        if ((uint32_t)head == pair0 && (uint32_t)own_next == BS_INF) {
+          // one pair in the chain, and it is this pod's: rejected class <=> its slot found no row
+          if ((uint32_t)(own_fq >> 32) == prm.seq_inv && row_c == BS_INF) fr = (uint32_t)own_fq;
+        } else {
+          for (unsigned long long link = head; (uint32_t)link != BS_INF;) {
+            const uint32_t r = (uint32_t)link, cls = (uint32_t)(link >> 32);
+            const unsigned long long pq = b.pair_firstq[r];              // } one round trip: the pair's first querying pod,
+            const uint32_t row = b.first_row[cls];                       // } its class slot's scan result,
+            link = b.pair_next[r];                                       // } the next link
+            if ((uint32_t)(pq >> 32) != prm.seq_inv) continue;           // no pod of the pair had a query in this batch
+            const uint32_t fq = (uint32_t)pq;
+            if (fq < fr && row == BS_INF) fr = fq;                       // the pair's class was rejected
+          }
         }
         denied = fr < i;
         if (prm.commit && fr == i) b.fast_reject[gi] = fr;             // AddToDenyCache, kept for k_fast_commit
       }
       if (denied) code = BS_PF_ERR_DENIED;
       else if (st & ST_QUERY) {
-        const uint32_t row = b.first_row[qpos0];
-        if (row == BS_INF) { code = BS_PF_REJECT_RESERVE; fk = BS_K_NONE; }                // core.go:161-165
-        else fk = nd.kmap[row];
+        if (row_q == BS_INF) { code = BS_PF_REJECT_RESERVE; fk = BS_K_NONE; }                // core.go:161-165
+        else fk = nd.kmap[row_q];
       }
     } else {
       code = BS_PF_NOT_OWNED;
@@ -475,7 +560,7 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     b.pf_code[i] = code;
     b.pf_first_k[i] = fk;
     const bool reached = i >= first_reach;
-    const int32_t leader = reached ? b.leader_epoch[0] : prm.sop_leader0;
+    const int32_t leader = reached ? leader_now : prm.sop_leader0;
     b.pf_leader[i] = leader;
     if (prm.host_tag) { b.h_pf_code[i] = code; b.h_pf_first_k[i] = fk; b.h_pf_leader[i] = leader; }
     const bool pass = code != BS_PF_NOT_OWNED && BS_PF_IS_PASS(code);
@@ -487,9 +572,9 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
         else if (gi < 0 || (uint32_t)gi >= gr.g) fl = BS_FL_ERR_PG_NOT_FOUND;              // :177-180
         else if (leader < 0) fl = BS_FL_PANIC_NIL_MAX;                                     // :525
         else if (leader == gi) fl = BS_FL_PASS_IS_MAX;                                     // :531-535
-        else { fl = BS_FL_EVALUATED; slot = pclass0 + (reached ? 0u : *b.kclass); }        // every group has MinResources here
+        else { fl = BS_FL_EVALUATED; slot = pclass0 + (reached ? 0u : K); }                // every group has MinResources here
       }
-      feasible = fl == BS_FL_EVALUATED ? b.fu_feas[slot] : (fl < 16u ? nd.n : 0u);
+      feasible = fl == BS_FL_EVALUATED ? (reached ? feas0 : feas1) : (fl < 16u ? nd.n : 0u);
       b.fu_slot[i] = slot;
       b.fl_feasible[i] = feasible;
     } else {
@@ -501,7 +586,7 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) { admit = true; ag = (uint32_t)gi; }
   }
   if (prm.host_tag && prm.run_filter) {             // per-row feasible counts of the slots in use
-    const uint32_t U = min(2u * *b.kclass, b.hstride);
+    const uint32_t U = min(2u * K, b.hstride);
     for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
   }
   if (prm.do_tally) wave_aggregated_add(b.admit, ag, admit);

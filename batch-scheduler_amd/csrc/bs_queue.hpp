@@ -98,15 +98,26 @@ __device__ __forceinline__ unsigned long long ld_dir(const unsigned long long* p
 __device__ __forceinline__ void st_dir(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // The insert wave: class and pair ids of the inserted pods (written at their positions in the new pack).
+// Everything a lane needs from memory is fetched in as few dependent round trips as the data allows: the pod's request
+// (pinned host memory: one PCIe round trip for all lanes), the slot of its hash, all key lanes of the class the slot names
+// (issued together, compared afterwards — no short-circuit chain of loads), then the same for the pair.
 __device__ __forceinline__ void apply_insert_wave(const PodDeltaDev& d, const PodsMut& nw, uint32_t G, uint32_t L, const QueueDirs& q, uint32_t hash_keep) {
   const int lane = lane_id();
   for (uint32_t base = 0; base < d.n_insert; base += 64u) {
     const uint32_t k = base + (uint32_t)lane;
     const bool valid = k < d.n_insert;
+    // ---- the pod: request lanes, present bits, group, target position — one round trip
+    int64_t rq[BS_MAX_LANES];
+    uint32_t pres = 0, at = 0;
+    int32_t gi = -1;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) rq[j] = (valid && j < L) ? d.ins.req[(size_t)j * d.ins.p + k] : 0;
+    if (valid) { pres = d.ins.pres[k]; gi = d.ins.group[k]; at = d.insert_at[k]; }
     // ---- request class: equal (request lanes, present bits) <=> equal class
-    uint64_t h = 0;
-    uint32_t pres = 0;
-    if (valid) { h = class_hash(d.ins, k, L); pres = d.ins.pres[k]; }
+    uint64_t h = mix64((uint64_t)pres + 0x9e3779b97f4a7c15ull);
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < L) h = mix64(h ^ (uint64_t)rq[j]);
     const uint32_t tag = (((uint32_t)(h >> 32)) & hash_keep & 0x7FFFFFFFu) | 0x80000000u;
     uint32_t cls = BS_INF;
     bool pending = valid;
@@ -118,9 +129,13 @@ __device__ __forceinline__ void apply_insert_wave(const PodDeltaDev& d, const Po
           if (cur == 0ull) break;
           if ((uint32_t)(cur >> 32) != tag) continue;
           const uint32_t c = (uint32_t)cur;
-          bool same = q.cpres[c] == pres;
-          for (uint32_t j = 0; same && j < L; ++j)
-            same = (int64_t)ld_dir(reinterpret_cast<const unsigned long long*>(&q.ckeys[(size_t)j * q.kcap + c])) == d.ins.req[(size_t)j * d.ins.p + k];
+          unsigned long long kv[BS_MAX_LANES];
+          const uint32_t cp = __hip_atomic_load(&q.cpres[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (uint32_t j = 0; j < BS_MAX_LANES; ++j) kv[j] = j < L ? ld_dir(reinterpret_cast<const unsigned long long*>(&q.ckeys[(size_t)j * q.kcap + c])) : 0ull;
+          bool same = cp == pres;
+#pragma unroll
+          for (uint32_t j = 0; j < BS_MAX_LANES; ++j) same = same && (j >= L || (int64_t)kv[j] == rq[j]);
           if (same) { cls = c; pending = false; break; }
         }
       }
@@ -135,24 +150,25 @@ __device__ __forceinline__ void apply_insert_wave(const PodDeltaDev& d, const Po
         if (lane == leader) elected = true;
         todo &= ~__ballot(pending && h == h0);
       }
-      // elected lanes with DIFFERENT hashes can still end on the same empty slot: claim it with a CAS, losers look again
+      // elected lanes with DIFFERENT hashes can still end on the same empty slot: claim it with a CAS, losers probe on
       if (elected) {
         const uint32_t c = atomicAdd(q.kcount, 1u);
         if (c < q.kcap) {
-          for (uint32_t j = 0; j < L; ++j) st_dir(reinterpret_cast<unsigned long long*>(&q.ckeys[(size_t)j * q.kcap + c]), (unsigned long long)d.ins.req[(size_t)j * d.ins.p + k]);
-          q.cpres[c] = pres;
+#pragma unroll
+          for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+            if (j < L) st_dir(reinterpret_cast<unsigned long long*>(&q.ckeys[(size_t)j * q.kcap + c]), (unsigned long long)rq[j]);
+          __hip_atomic_store(&q.cpres[c], pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __threadfence();
           const unsigned long long mine = ((unsigned long long)tag << 32) | c;
           for (;; sl = (sl + 1u) & q.cmask)
             if (atomicCAS(&q.cdir[sl], 0ull, mine) == 0ull) break;
         }
-        cls = c;                                               // (c >= kcap cannot happen: the host rebuilds before the id space runs out)
+        cls = c;                                               // (c >= kcap cannot happen: the host re-derives before the id space runs out)
         pending = false;
       }
       __threadfence();
     }
     // ---- (group, request class) pair
-    const int32_t gi = valid ? d.ins.group[k] : -1;
     const bool grouped = valid && gi >= 0 && (uint32_t)gi < G;
     uint32_t pid = BS_INF;
     const uint64_t ph = grouped ? pair_hash((uint32_t)gi, cls) : 0ull;
@@ -192,7 +208,6 @@ __device__ __forceinline__ void apply_insert_wave(const PodDeltaDev& d, const Po
       __threadfence();
     }
     if (valid) {
-      const uint32_t at = d.insert_at[k];
       nw.pclass[at] = cls;
       nw.ppair[at] = pid;
     }

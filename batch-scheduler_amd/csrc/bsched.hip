@@ -1693,7 +1693,15 @@ static int reserve_slots(bs_ctx* c, bool run_filter) {
   const uint32_t P = c->P, G = c->G;
   // slots are named after request classes, and class ids outlive their pods between two derivations (bs_pods_apply): size for the ids
   const uint32_t ids = std::max(P, c->ids_used);
-  const uint32_t scan_cap = ids + G + 64, filter_cap = 2 * ids + 64;
+  uint32_t scan_cap = ids + G + 64, filter_cap = 2 * ids + 64;
+  // the id bound creeps up with every bs_pods_apply: keep the capacities once they suffice, grow them by half when they do not
+  // (a reallocation is a device-wide wait)
+  if (scan_cap <= c->scan_slots_cap && c->d_first_row.cap >= (size_t)c->scan_slots_cap * 4) scan_cap = c->scan_slots_cap; else scan_cap += scan_cap / 2;
+  if (filter_cap <= c->filter_slots_cap && (!run_filter || c->d_uflags.cap >= (size_t)c->filter_slots_cap * 4) &&
+      (!run_filter || c->d_fu_bitmap.cap >= (size_t)(cdiv(c->N, 64) + 1) * c->filter_slots_cap * 8))
+    filter_cap = c->filter_slots_cap;
+  else
+    filter_cap += filter_cap / 2;
   int rc;
   HIPCHK(c, c->d_first_row.reserve((size_t)scan_cap * 4));
   HIPCHK(c, c->d_qreq_s.reserve((size_t)scan_cap * c->LP * 8));
