@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "bs_pods_apply", "bs_pods_count", "bs_pods_read", "bs_pods_apply_stats",
     "bs_nodes_apply", "bs_nodes_count", "bs_nodes_assume",
     "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
-    "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_filter_rows_count", "bs_queue_order_load", "bs_queue_sort",
+    "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_batch_map", "bs_filter_rows_count", "bs_queue_order_load", "bs_queue_sort",
     "bs_shard_set", "bs_reduce_external", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
     "bs_timing_reset", "bs_timing_get", "bs_kernel_name", "bs_batch_stats_get",
 ]
@@ -120,6 +120,7 @@ def load_library(path: str | None = None):
     L.bs_batch_run.argtypes = [vp, u32]
     L.bs_batch_sync.argtypes = [vp]
     L.bs_batch_read.argtypes = [vp, P(soa.BatchOutStruct)]
+    L.bs_batch_map.argtypes = [vp, P(soa.BatchViewStruct)]
     L.bs_shard_set.argtypes = [vp, u32, u32]
     L.bs_group_admit_devptr.argtypes = [vp, P(vp), P(u32)]
     L.bs_reduce_external.argtypes = [vp, u32]
@@ -408,6 +409,28 @@ class Context:
             out = soa.BatchOut.alloc(self.p, self.g, self.n, bitmap=bitmap, rows_cap=max(self.filter_rows_count(), 1) if rows else 0)
         st = out.as_struct()
         self._chk(self._lib.bs_batch_read(self._h, C.byref(st)), "bs_batch_read")
+        return out
+
+    def map_raw(self, view: soa.BatchViewStruct | None = None) -> soa.BatchViewStruct:
+        """bs_batch_map: wait for the latency-mode batch and return the pointer view (no copy of any kind)."""
+        if view is None:
+            view = soa.BatchViewStruct()
+        self._chk(self._lib.bs_batch_map(self._h, C.byref(view)), "bs_batch_map")
+        return view
+
+    def map_results(self) -> dict:
+        """bs_batch_map as numpy views over the pinned result memory (valid until the next run)."""
+        v = self.map_raw()
+        arr = np.ctypeslib.as_array
+
+        def a(ptr, n):
+            return arr(ptr, shape=(n,)) if n and ptr else None
+        out = {"p": v.p, "g": v.g, "pf_code": a(v.pf_code, v.p), "pf_first_k": a(v.pf_first_k, v.p), "pf_leader": a(v.pf_leader, v.p),
+               "fl_code": a(v.fl_code, v.p), "fl_feasible": a(v.fl_feasible, v.p), "fl_slot": a(v.fl_slot, v.p),
+               "group_admit": a(v.group_admit, v.g), "group_ready": a(v.group_ready, v.g), "fl_rows_n": v.fl_rows_n, "fl_rows": None, "fl_rows_feasible": None}
+        if v.fl_rows and v.fl_rows_n:
+            out["fl_rows"] = arr(v.fl_rows, shape=(v.words, v.fl_rows_stride))[:, : v.fl_rows_n]
+            out["fl_rows_feasible"] = arr(v.fl_rows_feasible, shape=(v.fl_rows_n,))
         return out
 
     def batch(self, stages: int = soa.STAGE_ALL, bitmap: bool = True, rows: bool | None = None) -> soa.BatchOut:

@@ -2380,6 +2380,43 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   return BS_OK;
 }
 
+// Zero-copy results of a latency-mode batch: pointers into the pinned memory the last launch wrote.
+int bs_batch_map(bs_ctx* c, bs_batch_view* v) {
+  if (!c || !v) return BS_ERR_INVALID;
+  if (!c->have_pods || !c->have_groups) return BS_ERR_STATE;
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (!c->last_host_out || !c->batch_since_pods) {
+    c->last_error = "bs_batch_map: the last batch did not write host results (BS_BATCH_HOST_RESULTS on a three-launch chain of a single-rank context)";
+    return BS_ERR_STATE;
+  }
+  const uint32_t P = c->P, G = c->G, W = cdiv(c->N, 64);
+  const bool filtered = c->last_stages & BS_STAGE_FILTER;
+  uint32_t nrows = 0;
+  if (filtered && (rc = filter_rows_of(c, &nrows))) return rc;
+  if ((rc = wait_host_tag(c, 0, c->host_tag, reinterpret_cast<const int32_t*>(c->h_hout + c->off_htag)))) return rc;
+  const uint8_t* st = c->h_hout;
+  std::memset(v, 0, sizeof(*v));
+  v->p = P; v->g = G; v->words = W;
+  v->pf_code = st + c->off_pf_code;
+  v->pf_first_k = reinterpret_cast<const uint32_t*>(st + c->off_pf_first_k);
+  v->pf_leader = reinterpret_cast<const int32_t*>(st + c->off_pf_leader);
+  v->fl_code = st + c->off_fl_code;
+  v->fl_feasible = reinterpret_cast<const uint32_t*>(st + c->off_fl_feasible);
+  v->fl_slot = reinterpret_cast<const uint32_t*>(st + c->off_fl_slot);
+  if (c->last_stages & BS_STAGE_TALLY) {
+    v->group_admit = reinterpret_cast<const uint32_t*>(st + c->off_admit);
+    v->group_ready = st + c->off_ready;
+  }
+  v->fl_rows_n = nrows;
+  v->fl_rows_stride = c->hstride;
+  if (filtered && nrows && nrows <= c->hstride) {
+    v->fl_rows = c->h_hrows;
+    v->fl_rows_feasible = reinterpret_cast<const uint32_t*>(st + c->off_hfeas);
+  }
+  return BS_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 // single queries
 // -------------------------------------------------------------------------------------------------

@@ -100,6 +100,22 @@ class BatchOutStruct(C.Structure):
                 ("fl_rows_n", C.POINTER(C.c_uint32))]
 
 
+class BatchViewStruct(C.Structure):
+    """bs_batch_view: read-only pointers into the pinned result memory of a latency-mode batch (bs_batch_map)."""
+    _fields_ = [("p", C.c_uint32), ("g", C.c_uint32), ("words", C.c_uint32),
+                ("pf_code", C.POINTER(C.c_uint8)),
+                ("pf_first_k", C.POINTER(C.c_uint32)),
+                ("pf_leader", C.POINTER(C.c_int32)),
+                ("fl_code", C.POINTER(C.c_uint8)),
+                ("fl_feasible", C.POINTER(C.c_uint32)),
+                ("fl_slot", C.POINTER(C.c_uint32)),
+                ("group_admit", C.POINTER(C.c_uint32)),
+                ("group_ready", C.POINTER(C.c_uint8)),
+                ("fl_rows", C.POINTER(C.c_uint64)),
+                ("fl_rows_feasible", C.POINTER(C.c_uint32)),
+                ("fl_rows_stride", C.c_uint32), ("fl_rows_n", C.c_uint32)]
+
+
 class PodsDeltaStruct(C.Structure):
     """bs_pods_delta: stable removals, flag updates and insertions against the resident queue (bs_pods_apply)."""
     _fields_ = [("n_remove", C.c_uint32), ("remove", C.POINTER(C.c_uint32)),

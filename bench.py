@@ -284,8 +284,9 @@ def make_pod_deltas(bsa, pods, n_cycles, churn, seed=2):
     return structs, keep
 
 
-def resident_cycle(bsa, ctx, groups, pods, nodes, stages, darr, ndeltas, out, iters):
+def resident_cycle(bsa, ctx, groups, pods, nodes, stages, darr, ndeltas, out, iters, zero_copy=True):
     soa = bsa.soa
+    view = soa.BatchViewStruct()
     churn = max(2, pods.p // 100)
     structs, keep = make_pod_deltas(bsa, pods, iters + 5, churn)
     ctx.load_pods(pods)
@@ -298,7 +299,10 @@ def resident_cycle(bsa, ctx, groups, pods, nodes, stages, darr, ndeltas, out, it
         t2 = time.perf_counter()
         ctx.run(stages | soa.BATCH_HOST_RESULTS)
         t3 = time.perf_counter()
-        ctx.read(out=out)
+        if zero_copy:
+            ctx.map_raw(view)                       # bs_batch_map: completion word, then pointers into the pinned results
+        else:
+            ctx.read(out=out)                       # bs_batch_read: the same wait + a host-side copy of every array
         t4 = time.perf_counter()
         if it >= 5:
             for k, v in zip(("groups_apply", "pods_apply", "run", "read", "total"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)):
@@ -350,7 +354,8 @@ def host_cycle(bsa, ctx, groups, pods, nodes, stages, iters=60):
         res[mode] = {k: {"p50_ms": pct(v, 50), "p95_ms": pct(v, 95)} for k, v in parts.items()}
     # ---- the queue-resident cycle: the pending queue is NOT re-uploaded; bs_pods_apply patches 1 % of it per cycle on the
     # device (half leave = a released gang's worth of pods, as many arrive), results in latency mode
-    res["resident"] = resident_cycle(bsa, ctx, groups, pods, nodes, stages, darr, len(deltas), out, iters)
+    res["resident"] = resident_cycle(bsa, ctx, groups, pods, nodes, stages, darr, len(deltas), out, iters, zero_copy=True)
+    res["resident_copy_out"] = resident_cycle(bsa, ctx, groups, pods, nodes, stages, darr, len(deltas), out, iters, zero_copy=False)
     ctx.load_pods(pods)
     full = []
     for it in range(iters // 2 + 5):
@@ -550,8 +555,9 @@ def main():
             p50, p95 = cyc["resident"]["total"]["p50_ms"], cyc["resident"]["total"]["p95_ms"]
             cycle = {"definition": "host-observed scheduling cycle, the way a shim drives it.  'resident' (the headline): the pending queue STAYS on the device — "
                                    "bs_groups_apply (32 groups) + bs_pods_apply (1 % of the queue leaves, as many pods arrive; the delta is read from pinned memory) "
-                                   "+ bs_batch_run + bs_batch_read in latency mode (results written to pinned host memory by the last launch, completion word "
-                                   "polled).  'latency': the whole queue re-marshalled into the pinned upload buffer every cycle (bs_pods_map + bs_pods_load) + "
+                                   "+ bs_batch_run in latency mode (results written to pinned host memory by the last launch) + bs_batch_map (completion word "
+                                   "polled, results read in place: no copy of any kind).  'resident_copy_out': the same with bs_batch_read copying every "
+                                   "array out of the pinned memory.  'latency': the whole queue re-marshalled into the pinned upload buffer every cycle (bs_pods_map + bs_pods_load) + "
                                    "latency-mode results.  'plain': bs_pods_load packs the caller's arrays, results copied back under one stream wait.",
                      "modes": cyc,
                      "gang_admit_latency_ms_p50": p50, "gang_admit_latency_ms_p95": p95,

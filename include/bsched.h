@@ -275,9 +275,10 @@ typedef struct bs_batch_out {
 #define BS_BATCH_HOST_RESULTS 0x200u /* latency mode: the last launch of the batch also writes every result bs_batch_read
                                      returns (per-pod arrays, admit, ready, Filter rows) straight into pinned host memory;
                                      bs_batch_read then needs no device-to-host copy and no stream wait — it polls a
-                                     completion word.  Honoured on the steady-state chain of a single-rank context; a
-                                     no-op (results are copied as usual) elsewhere (positional and general chain).  Costs the batch a few microseconds
-                                     of PCIe writes, so throughput runs leave it off. */
+                                     completion word (bs_batch_map: not even a host-side copy).  Honoured on both three-launch
+                                     chains (steady state, positional) of a single-rank context; a no-op (results are copied
+                                     as usual) on the general chain.  Costs the batch a few microseconds of PCIe writes, so
+                                     throughput runs leave it off. */
 
 /* ---- lifecycle ------------------------------------------------------------------- */
 uint32_t    bs_abi_version(void);
@@ -424,6 +425,30 @@ int bs_find_max_pg(bs_ctx* ctx, int32_t* leader, uint32_t* finished, uint8_t* pa
 int bs_batch_run(bs_ctx* ctx, uint32_t stages);
 int bs_batch_sync(bs_ctx* ctx);
 int bs_batch_read(bs_ctx* ctx, const bs_batch_out* out);
+/* Zero-copy form of bs_batch_read for a batch that ran with BS_BATCH_HOST_RESULTS: waits for the batch's completion word
+ * and hands out read-only pointers into the pinned host memory the last launch wrote — no device-to-host copy, no stream
+ * wait and no host-side memcpy (bs_batch_read spends most of a latency-mode cycle copying ~40 bytes per pod out of that
+ * very memory).  The pointers stay valid, and their contents unchanged, until the next bs_batch_run on this context.
+ * BS_ERR_STATE when the last batch did not write host results (general chain, sharded / external-reduce contexts,
+ * BS_BATCH_COMMIT, or the flag not set): use bs_batch_read.  Per-pod arrays hold `p` entries, per-group arrays `g`.
+ * Filter rows: word-major with a row stride of `fl_rows_stride` rows (bit test as in bs_batch_out, with fl_rows_stride
+ * in place of fl_rows_cap); fl_rows is NULL when Filter did not run or the batch has more rows than the pinned window
+ * holds (fl_rows_n still tells how many: fetch them with bs_batch_read). */
+typedef struct bs_batch_view {
+  uint32_t p, g, words;               /* pods, groups, ceil(nodes / 64) of the batch                         */
+  const uint8_t*  pf_code;
+  const uint32_t* pf_first_k;
+  const int32_t*  pf_leader;
+  const uint8_t*  fl_code;
+  const uint32_t* fl_feasible;
+  const uint32_t* fl_slot;
+  const uint32_t* group_admit;        /* NULL unless the batch ran BS_STAGE_TALLY                            */
+  const uint8_t*  group_ready;
+  const uint64_t* fl_rows;            /* [words][fl_rows_stride]                                             */
+  const uint32_t* fl_rows_feasible;   /* [fl_rows_n]                                                         */
+  uint32_t fl_rows_stride, fl_rows_n;
+} bs_batch_view;
+int bs_batch_map(bs_ctx* ctx, bs_batch_view* view);
 /* Rows (distinct Filter requests) the last loaded pods can produce: sizes fl_rows / fl_rows_feasible. */
 int bs_filter_rows_count(bs_ctx* ctx, uint32_t* rows);
 

@@ -241,3 +241,54 @@ def test_latency_mode_on_both_chains_with_resident_queue(config, scenario, bsa, 
             assert np.array_equal(out.bitmap_from_rows(), exp.fl_bitmap)
         st = ctx.stats(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
         assert st["chain"] == (2 if scenario == "cold" else 1)
+
+
+@pytest.mark.parametrize("config,scenario", [("cfg2", "tail"), ("cfg2", "cold"), ("tiny", "warm")])
+def test_batch_map_is_the_read_without_a_copy(config, scenario, bsa, soa, orc):
+    """bs_batch_map: the pointers into the pinned result memory of a latency-mode batch hold exactly what bs_batch_read copies
+    out (both chains, resident queue patched in between), stay unchanged until the next run, and the call refuses batches
+    that did not write host results."""
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
+    stream = fullsize.PodChurnStream(pods, 5)
+    snap = orc.Snapshot(nodes, fit)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        ctx.run(soa.STAGE_ALL)
+        with pytest.raises(bsa.BsError) as e:
+            ctx.map_results()
+        assert e.value.status == -4                                              # BS_ERR_STATE: use bs_batch_read
+        for it in range(4):
+            if it:
+                ctx.apply_pods(**stream.next_delta(15))
+            exp = orc.Sop(snap, groups).batch(stream.pods, soa.STAGE_ALL)
+            ctx.run(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
+            v = ctx.map_results()
+            out = soa.BatchOut.alloc(stream.pods.p, groups.g, nodes.n, bitmap=False, rows_cap=max(ctx.filter_rows_count(), 1))
+            ctx.read(out=out)
+            assert v["p"] == stream.pods.p and v["g"] == groups.g
+            for name in ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible", "group_admit", "group_ready"):
+                assert np.array_equal(v[name], getattr(out, name)), f"{name} (cycle {it})"
+                assert np.array_equal(v[name], getattr(exp, name)), f"{name} vs oracle (cycle {it})"
+            ev = out.fl_code == 3
+            assert np.array_equal(v["fl_slot"][ev], out.fl_slot[ev])
+            n = int(out.fl_rows_n[0])
+            assert v["fl_rows_n"] == n
+            if n:
+                assert np.array_equal(v["fl_rows"], out.fl_rows[:, :n]) and np.array_equal(v["fl_rows_feasible"], out.fl_rows_feasible[:n])
+                # the Filter answer of a pod on a node is a bit test in the mapped rows
+                rng = np.random.default_rng(it)
+                for _ in range(200):
+                    p_, n_ = int(rng.integers(0, stream.pods.p)), int(rng.integers(0, nodes.n))
+                    if v["fl_code"][p_] == 3:
+                        got = bool((int(v["fl_rows"][n_ >> 6, v["fl_slot"][p_]]) >> (n_ & 63)) & 1)
+                        assert got == bool((int(exp.fl_bitmap[n_ >> 6, p_]) >> (n_ & 63)) & 1)
+        # prefilter + tally only: no rows, the rest as usual
+        ctx.run(soa.STAGE_PREFILTER | soa.STAGE_TALLY | soa.BATCH_HOST_RESULTS)
+        v = ctx.map_results()
+        e2 = orc.Sop(snap, groups).batch(stream.pods, soa.STAGE_PREFILTER | soa.STAGE_TALLY)
+        assert v["fl_rows"] is None and np.array_equal(v["pf_code"], e2.pf_code) and np.array_equal(v["group_ready"], e2.group_ready)
+        # a sharded context never writes host results
+        ctx.set_shard(0, 2)
+        ctx.run(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
+        ctx.finish()
+        with pytest.raises(bsa.BsError):
+            ctx.map_results()

@@ -34,6 +34,8 @@ def main():
         darr = (soa.GroupDelta * len(idx))(*[soa.GroupDelta(int(i), int(groups.matched[i]), int(groups.status_scheduled[i]), int(groups.flags[i])) for i in idx])
         structs, keep = bench.make_pod_deltas(bsa, pods, cycles + 10, max(2, pods.p // 100))
         parts = []
+        zero_copy = os.environ.get("PROBE_READ", "map") == "map"      # bs_batch_map (no host copy) | bs_batch_read
+        view = soa.BatchViewStruct()
         for it in range(cycles + 10):
             t0 = time.perf_counter()
             ctx.apply_group_deltas_raw(darr, len(idx))
@@ -42,13 +44,16 @@ def main():
             t2 = time.perf_counter()
             ctx.run(stages | soa.BATCH_HOST_RESULTS)
             t3 = time.perf_counter()
-            ctx.read(out=out)
+            if zero_copy:
+                ctx.map_raw(view)
+            else:
+                ctx.read(out=out)
             t4 = time.perf_counter()
             if it >= 10:
                 parts.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0))
         a = np.array(parts) * 1e6
         names = ("groups_apply", "pods_apply", "run", "read", "total")
-        print(json.dumps({"workload": f"{config}/{scenario}", "cycles": cycles, "stages": int(stages),
+        print(json.dumps({"workload": f"{config}/{scenario}", "cycles": cycles, "stages": int(stages), "results": "bs_batch_map" if zero_copy else "bs_batch_read",
                           "us_p50": {n: round(float(np.percentile(a[:, k], 50)), 1) for k, n in enumerate(names)},
                           "us_p95": {n: round(float(np.percentile(a[:, k], 95)), 1) for k, n in enumerate(names)},
                           "apply_stats": ctx.apply_stats()}))
