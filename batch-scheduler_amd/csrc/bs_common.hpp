@@ -14,6 +14,24 @@
 namespace bs {
 
 constexpr int kWave = 64;
+
+// Probe build only (-DBS_PROBE, tools/stamp_probe.py; never the shipped library): thread 0 of the first kProbeBlocks blocks of a
+// launch leaves constant-rate clock stamps (s_memrealtime, 100 MHz) at a few points, after draining what it has in flight —
+// where the microseconds of a latency-bound launch go (dispatch spread, depth of the dependent-load chains, store drain).
+#ifdef BS_PROBE
+constexpr int kProbeKernels = 8, kProbeBlocks = 128, kProbeStamps = 8;
+__device__ unsigned long long g_probe[kProbeKernels][kProbeBlocks][kProbeStamps];
+__device__ __forceinline__ void probe_stamp(int k, int s, uint32_t blk) {
+  if (threadIdx.x == 0 && blk < (uint32_t)kProbeBlocks) {
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    g_probe[k][blk][s] = t;
+  }
+}
+#define BS_STAMP(k, s) probe_stamp((k), (s), blockIdx.x)
+#else
+#define BS_STAMP(k, s) ((void)0)
+#endif
 constexpr int kScanBlock = 1024;   // single-block sequential-chunk scans
 
 __device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
@@ -195,30 +213,37 @@ __device__ __forceinline__ uint32_t wave_aggregated_inc(uint32_t* counters, uint
 }
 
 // One lane per distinct key among the active lanes of the wave (the first one): for work every holder of a key would
-// repeat identically (filling a shared slot).
+// repeat identically (filling a shared slot).  A queue is mostly gang-sorted, so a wave of pods holds a handful of keys;
+// the tail a resident queue grows (pods appended in arrival order) holds up to 64.  The loop costs one ballot + one
+// v_readlane per distinct key and gives up after kElectRounds keys: the lanes still waiting then all count as elected —
+// their keys are (nearly) all different anyway, and what they write is identical for equal keys.
+constexpr int kElectRounds = 8;
 __device__ __forceinline__ bool wave_elect_by_key(uint32_t key, bool active) {
   bool elected = false;
   unsigned long long todo = __ballot(active);
-  while (todo) {
+  for (int round = 0; todo && round < kElectRounds; ++round) {
     const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
     if (lane_id() == leader) elected = true;
     todo &= ~__ballot(active && key == k0);
   }
+  if (todo & (1ull << lane_id())) elected = true;
   return elected;
 }
 
 // Same aggregation when nobody needs the old counter value: the adds are fire-and-forget, so the loop over the distinct
-// keys of a wave does not wait for an atomic round trip per key (it did: ~15 distinct groups per wave of pods).
+// keys of a wave does not wait for an atomic round trip per key (it did: ~15 distinct groups per wave of pods).  After
+// kElectRounds keys the remaining lanes add for themselves (a wave of all-different keys is 64 independent atomics either way).
 __device__ __forceinline__ void wave_aggregated_add(uint32_t* counters, uint32_t key, bool active) {
   unsigned long long todo = __ballot(active);
-  while (todo) {
+  for (int round = 0; todo && round < kElectRounds; ++round) {
     const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
     const unsigned long long same = __ballot(active && key == k0) & todo;
     if (lane_id() == leader) (void)__hip_atomic_fetch_add(&counters[k0], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     todo &= ~same;
   }
+  if (todo & (1ull << lane_id())) (void)__hip_atomic_fetch_add(&counters[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace bs

@@ -121,12 +121,20 @@ __device__ __forceinline__ void leader_publish(const GroupsDev& gr, const BatchD
   }
   b.leader_epoch[0] = l;
   b.panic_epoch[0] = pn ? 1 : 0;
-  info[0] = l; info[1] = pn; info[2] = steady;
-  __hip_atomic_store(&info[3], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // to the host: three words, drained, then the tag — all system-scope stores that go straight out (posted PCIe writes to one
+  // destination arrive in order).  A release fence at system scope would also write this XCD's L2 back first (~1-2 us) for
+  // device-side words only the next launch reads.
+  __hip_atomic_store(&info[0], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&info[1], pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&info[2], steady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(&info[3], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, BatchDev b, uint32_t C, int32_t tag, int32_t* info, DeltaPack dp,
-                                                              uint32_t* matched, uint32_t* status_scheduled, uint8_t* flags) {
+// (a block of kLeaderBlock threads; k_leader_info is this and nothing else, k_pods_apply runs it in one extra block when a
+// group patch and a queue patch arrive in the same cycle)
+__device__ __forceinline__ void leader_info_block(const GroupsDev& gr, const BatchDev& b, uint32_t C, int32_t tag, int32_t* info, const DeltaPack& dp,
+                                                  uint32_t* matched, uint32_t* status_scheduled, uint8_t* flags) {
   __shared__ unsigned long long s_w[kLeaderBlock / 64];
   __shared__ uint32_t s_slow;
   if (threadIdx.x < dp.n) {
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, Batc
     flags[x.index] = (uint8_t)x.flags;
   }
   if (threadIdx.x == 0) s_slow = 0;
-  __syncthreads();
+  __syncthreads();                                     // (the stores are performed: every thread may load a patched group)
   if (!gr.g) {
     if (threadIdx.x == 0) leader_publish(gr, b, C, tag, info, -1, 0, 0u, 0, 0u);
     return;
@@ -192,6 +200,11 @@ __global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, Batc
   }
 }
 
+__global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, BatchDev b, uint32_t C, int32_t tag, int32_t* info, DeltaPack dp,
+                                                              uint32_t* matched, uint32_t* status_scheduled, uint8_t* flags) {
+  leader_info_block(gr, b, C, tag, info, dp, matched, status_scheduled, flags);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch A, table part: chunk-local running sums (core.go:602,621 restarted at every 256-row chunk), chunk
 // totals, per 64-row group max of the local sums, per chunk first row of every scalar key.
@@ -220,6 +233,7 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
   }
   const bool fit = valid && ((fw >> (n & 31u)) & 1u) && !(fl & BS_NODE_TAINT_ERR);
   const uint32_t pres = fit ? (ap & rp) : 0u;
+  BS_STAMP(1, 1);
   if (threadIdx.x < BS_MAX_SCALARS) s_kp[threadIdx.x] = BS_INF;
   unsigned long long incl[BS_MAX_LANES];
   const int w = wave_id();
@@ -341,6 +355,7 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
     b.tcode[i] = code;
     b.stage[i] = st;
   }
+  BS_STAMP(1, 1);
   {
     // First pod of the queue that reaches findMaxPG (it really does: a replayed deny needs an earlier, reaching, rejected
     // pod).  Blocks are in queue order, so it is the first reaching pod of the first block that has one: every block
@@ -353,6 +368,7 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
     __syncthreads();
     if (threadIdx.x == 0) b.first_reach64[blockIdx.x] = ((unsigned long long)prm.seq_inv << 32) | s_reach;
   }
+  BS_STAMP(1, 2);
   // Filter slots: class c with the batch's leader, class c + K with the leader carried into the batch.  Every pod of a
   // class that may pass and is not in the leader's own group derives the same slot contents: one lane per (wave, class)
   // is elected to fill it (tens of thousands of identical stores to a few hundred cache lines were a measurable part
@@ -365,6 +381,7 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
     if (wave_elect_by_key(c, may && prm.sop_leader0 >= 0 && prm.sop_leader0 != gi))
       filter_params_for<TS>(pods, gr, b, prm, i, code, prm.sop_leader0, c + *b.kclass, true, false);
   }
+  BS_STAMP(1, 3);
   const uint32_t qslot = has_q ? b.pclass[i] : 0u;
   const bool fill = wave_elect_by_key(qslot, has_q);   // one writer per (wave, class): ~10x fewer identical stores, no atomics
   if (has_q) {
@@ -401,8 +418,10 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
 template <int TS>
 __global__ __launch_bounds__(kTblChunk) void k_fast_query_tables(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm,
                                                                  const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks) {
+  BS_STAMP(1, 0);
   if (blockIdx.x < query_blocks) fast_query_thread<TS>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
   else tables_local_fast<TS>(nd, bt, prm, forced, blockIdx.x - query_blocks);
+  BS_STAMP(1, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -414,10 +433,12 @@ template <int S>
 __global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap,
                                                           uint32_t scan_blocks, uint32_t filter_waves, uint32_t ustride) {
   __shared__ int64_t s_rows[4][64][4 + S];
+  BS_STAMP(2, 0);
   if (blockIdx.x < scan_blocks)
     scan_loop<S, true>(bt, prm, m, jcap, 0u, 0u, 1u, blockIdx.x, scan_blocks, s_rows[wave_id()]);
   else
     filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - scan_blocks, gridDim.x - scan_blocks, prm.stamp);
+  BS_STAMP(2, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -479,6 +500,7 @@ __device__ __forceinline__ void final_tail(const GroupsDev& gr, const BatchDev& 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
   __shared__ uint32_t s_first_reach;
+  BS_STAMP(3, 0);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const bool valid = i < pods.p;
   // ---- round trip 1: the pod's own fields, and the block's look at the first reaching pod
@@ -520,6 +542,7 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
   }
   if (valid && prm.run_filter && grouped) { feas0 = b.fu_feas[pclass0]; feas1 = b.fu_feas[pclass0 + K]; }
   __syncthreads();
+  BS_STAMP(3, 1);
   bool admit = false;
   uint32_t ag = 0;
   if (valid) {
@@ -589,8 +612,11 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     const uint32_t U = min(2u * K, b.hstride);
     for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
   }
+  BS_STAMP(3, 2);
   if (prm.do_tally) wave_aggregated_add(b.admit, ag, admit);
+  BS_STAMP(3, 3);
   final_tail(gr, b, prm);
+  BS_STAMP(3, 7);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -18,11 +18,11 @@
 #pragma once
 
 #include "bs_kernels.hpp"
+#include "bs_fast.hpp"
 
 namespace bs {
 
-constexpr int kApplyBlock = 256;
-constexpr uint32_t kApplyLds = 1024;              // entries of each index list a block stages in LDS (more: searched in place)
+constexpr int kApplyBlock = kLeaderBlock;        // one block of this launch can be the findMaxPG block of a group patch (leader_info_block)
 
 struct PodsMut {                                  // a pod pack as a write target, with the derived per-pod ids
   int32_t* group; int64_t* req; uint32_t* pres; uint32_t* cls; uint64_t* owner; uint8_t* flags; uint32_t* pclass; uint32_t* ppair;
@@ -36,9 +36,12 @@ struct PodDeltaDev {
   const uint32_t* flag_index;                     // [n_flags] old queue indices, strictly ascending
   const uint8_t* flag_value;                      // [n_flags]
   PodsDev ins;                                    // the inserted pods (ins.p == n_insert)
+  const uint8_t* blob;                            // every pointer above points into this pinned blob: [lists | inserted records]
+  uint32_t blob_bytes, lists_bytes;               // both multiples of 16
 };
 
 struct QueueDirs {                                // hash -> id directories for the insert wave
+  uint32_t slot_keep;                             // test knob (BS_HASH_SLOT_BITS): probes start at hash & slot_keep & mask — long probe paths on demand
   unsigned long long* cdir; uint32_t cmask;       // request classes: slot = 1 << 63 | hash31 << 32 | class id
   int64_t* ckeys; uint32_t* cpres; uint32_t kcap; // [L][kcap] request lanes and [kcap] present bits by class id
   unsigned long long* pdir; uint32_t pmask;       // (group, class) pairs: slot = 1 << 63 | hash31 << 32 | pair id
@@ -54,7 +57,8 @@ __device__ __forceinline__ uint64_t class_hash(const PodsDev& pods, uint32_t i, 
   for (uint32_t j = 0; j < L; ++j) h = mix64(h ^ (uint64_t)pods.req[(size_t)j * pods.p + i]);
   return h;
 }
-__device__ __forceinline__ uint64_t pair_hash(uint32_t g, uint32_t c) { return mix64(((uint64_t)g << 32) | c); }
+// a pair is filed under (group, hash of the request), so its directory slot does not depend on the class id
+__device__ __forceinline__ uint64_t pair_hash(uint32_t g, uint64_t request_hash) { return mix64(request_hash ^ mix64((uint64_t)g + 0x632be59bd9b4e019ull)); }
 
 // entries <= x in an ascending list (the list itself, or the list minus its own index when SHIFT — see k_pods_apply)
 template <bool SHIFT>
@@ -80,15 +84,15 @@ __global__ void k_dirs_build(PodsDev pods, uint32_t G, uint32_t L, const uint32_
     for (uint32_t j = 0; j < L; ++j) q.ckeys[(size_t)j * q.kcap + c] = pods.req[(size_t)j * pods.p + i];
     q.cpres[c] = pods.pres[i];
     const unsigned long long mine = (1ull << 63) | ((unsigned long long)(((uint32_t)(h >> 32)) & hash_keep & 0x7FFFFFFFu) << 32) | c;
-    for (uint32_t sl = (uint32_t)h & q.cmask;; sl = (sl + 1u) & q.cmask)
+    for (uint32_t sl = (uint32_t)h & q.slot_keep & q.cmask;; sl = (sl + 1u) & q.cmask)
       if (atomicCAS(&q.cdir[sl], 0ull, mine) == 0ull) break;
   }
   if (ppair[i] == i) {
     const uint32_t g = (uint32_t)pods.group[i], c = id[rep[i]];
-    const uint64_t h = pair_hash(g, c);
+    const uint64_t h = pair_hash(g, class_hash(pods, i, L));      // the pair's representative carries the pair's request
     q.pkeys[i] = ((unsigned long long)g << 32) | c;
     const unsigned long long mine = (1ull << 63) | ((unsigned long long)(((uint32_t)(h >> 32)) & hash_keep & 0x7FFFFFFFu) << 32) | i;
-    for (uint32_t sl = (uint32_t)h & q.pmask;; sl = (sl + 1u) & q.pmask)
+    for (uint32_t sl = (uint32_t)h & q.slot_keep & q.pmask;; sl = (sl + 1u) & q.pmask)
       if (atomicCAS(&q.pdir[sl], 0ull, mine) == 0ull) break;
   }
 }
@@ -96,13 +100,21 @@ __global__ void k_dirs_build(PodsDev pods, uint32_t G, uint32_t L, const uint32_
 // agent-scope accessors for the directories: the insert wave reads back what its own lanes stored a moment ago
 __device__ __forceinline__ unsigned long long ld_dir(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_dir(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ONE wave reads and writes the directories: program order + "my stores have been performed" is all the ordering there is to
+// keep (directory words and keys are agent-scope accesses: they are performed at the coherence point, not in this XCD's L2).
+// A release / acquire fence here is an L2 write-back + invalidate per round — several microseconds of this launch.
+__device__ __forceinline__ void dir_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // The insert wave: class and pair ids of the inserted pods (written at their positions in the new pack).
-// Everything a lane needs from memory is fetched in as few dependent round trips as the data allows: the pod's request
-// (pinned host memory: one PCIe round trip for all lanes), the slot of its hash, all key lanes of the class the slot names
-// (issued together, compared afterwards — no short-circuit chain of loads), then the same for the pair.
+// The dependent chain is as short as the data allows: the pod's record (pinned host memory: one PCIe round trip for all
+// lanes), then class directory and pair directory are probed TOGETHER — a pair is filed under (group, request hash), not
+// (group, class id), so its slot is known before the class is — then the keys both slots name (class key lanes and the
+// pair's (group, class id) word, issued together, compared afterwards).  An insert of pods of known gangs and templates (the
+// per-cycle case) is three round trips deep.  Lanes that miss elect one lane per distinct key; that lane draws the next id
+// and files it in the slot its probe ended on; the others look again.
 __device__ __forceinline__ void apply_insert_wave(const PodDeltaDev& d, const PodsMut& nw, uint32_t G, uint32_t L, const QueueDirs& q, uint32_t hash_keep) {
   const int lane = lane_id();
+  enum : uint32_t { PROBE = 0, CAND = 1, MISS = 2, DONE = 3 };
   for (uint32_t base = 0; base < d.n_insert; base += 64u) {
     const uint32_t k = base + (uint32_t)lane;
     const bool valid = k < d.n_insert;
@@ -118,98 +130,121 @@ __device__ __forceinline__ void apply_insert_wave(const PodDeltaDev& d, const Po
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
       if (j < L) h = mix64(h ^ (uint64_t)rq[j]);
-    const uint32_t tag = (((uint32_t)(h >> 32)) & hash_keep & 0x7FFFFFFFu) | 0x80000000u;
-    uint32_t cls = BS_INF;
-    bool pending = valid;
-    while (__ballot(pending)) {
-      uint32_t sl = (uint32_t)h & q.cmask;
-      if (pending) {                                           // lookup: probe until the key or an empty slot
-        for (;; sl = (sl + 1u) & q.cmask) {
-          const unsigned long long cur = ld_dir(&q.cdir[sl]);
-          if (cur == 0ull) break;
-          if ((uint32_t)(cur >> 32) != tag) continue;
-          const uint32_t c = (uint32_t)cur;
-          unsigned long long kv[BS_MAX_LANES];
-          const uint32_t cp = __hip_atomic_load(&q.cpres[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t ctag = (((uint32_t)(h >> 32)) & hash_keep & 0x7FFFFFFFu) | 0x80000000u;
+    const bool grouped = valid && gi >= 0 && (uint32_t)gi < G;
+    const uint64_t ph = grouped ? pair_hash((uint32_t)gi, h) : 0ull;
+    const uint32_t ptag = (((uint32_t)(ph >> 32)) & hash_keep & 0x7FFFFFFFu) | 0x80000000u;
+    uint32_t cls = BS_INF, pid = BS_INF;
+    uint32_t cs = valid ? PROBE : DONE, ps = grouped ? PROBE : DONE;
+    uint32_t slc = (uint32_t)h & q.slot_keep & q.cmask, slp = (uint32_t)ph & q.slot_keep & q.pmask;
+    unsigned long long cand_pk = 0;                              // (group, class id) word of the pair candidate
+    for (;;) {
+      // ---- round trip 1: the directory words both probes stand on
+      unsigned long long curc = 0, curp = 0;
+      if (cs == PROBE) curc = ld_dir(&q.cdir[slc]);
+      if (ps == PROBE) curp = ld_dir(&q.pdir[slp]);
+      // ---- round trip 2: the keys those words name
+      const bool ccand = cs == PROBE && curc != 0ull && (uint32_t)(curc >> 32) == ctag;
+      const bool pcand = ps == PROBE && curp != 0ull && (uint32_t)(curp >> 32) == ptag;
+      unsigned long long kv[BS_MAX_LANES];
+      uint32_t cp = 0;
+      if (ccand) {
+        const uint32_t c = (uint32_t)curc;
+        cp = __hip_atomic_load(&q.cpres[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-          for (uint32_t j = 0; j < BS_MAX_LANES; ++j) kv[j] = j < L ? ld_dir(reinterpret_cast<const unsigned long long*>(&q.ckeys[(size_t)j * q.kcap + c])) : 0ull;
+        for (uint32_t j = 0; j < BS_MAX_LANES; ++j) kv[j] = j < L ? ld_dir(reinterpret_cast<const unsigned long long*>(&q.ckeys[(size_t)j * q.kcap + c])) : 0ull;
+      }
+      if (pcand) cand_pk = ld_dir(&q.pkeys[(uint32_t)curp]);
+      if (cs == PROBE) {
+        if (curc == 0ull) cs = MISS;
+        else if (!ccand) slc = (slc + 1u) & q.cmask;
+        else {
           bool same = cp == pres;
 #pragma unroll
           for (uint32_t j = 0; j < BS_MAX_LANES; ++j) same = same && (j >= L || (int64_t)kv[j] == rq[j]);
-          if (same) { cls = c; pending = false; break; }
+          if (same) { cls = (uint32_t)curc; cs = DONE; } else slc = (slc + 1u) & q.cmask;
         }
       }
-      // one lane per distinct hash among the lanes that missed draws the next class id and files it in the slot its probe
-      // ended on; lanes with the same hash look again (same key: they find it; another key behind the same hash: they miss
-      // again and one of them is elected in the next round)
-      unsigned long long todo = __ballot(pending);
-      bool elected = false;
-      while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint64_t h0 = bcast64(h, leader);
-        if (lane == leader) elected = true;
-        todo &= ~__ballot(pending && h == h0);
+      if (ps == PROBE) {
+        if (curp == 0ull) ps = MISS;
+        else if (!pcand) slp = (slp + 1u) & q.pmask;
+        else { ps = CAND; pid = (uint32_t)curp; }
       }
-      // elected lanes with DIFFERENT hashes can still end on the same empty slot: claim it with a CAS, losers probe on
-      if (elected) {
-        const uint32_t c = atomicAdd(q.kcount, 1u);
-        if (c < q.kcap) {
+      // a pair candidate is the pair iff it names this group and the class id the class probe ended on
+      if (ps == CAND && cs == DONE) {
+        if (cand_pk == (((unsigned long long)(uint32_t)gi << 32) | cls)) ps = DONE;
+        else { ps = PROBE; pid = BS_INF; slp = (slp + 1u) & q.pmask; }
+      }
+      if (__ballot(cs == PROBE || ps == PROBE)) continue;
+      // ---- nobody can probe on: classes that are not filed yet draw their ids (one lane per distinct request) ...
+      if (__ballot(cs == MISS)) {
+        unsigned long long todo = __ballot(cs == MISS);
+        bool elected = false;
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint64_t h0 = bcast64(h, leader);
+          if (lane == leader) elected = true;
+          todo &= ~__ballot(cs == MISS && h == h0);
+        }
+        if (elected) {
+          const uint32_t c = atomicAdd(q.kcount, 1u);
+          if (c < q.kcap) {                                      // (c >= kcap cannot happen: the host re-derives before the id space runs out)
 #pragma unroll
-          for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-            if (j < L) st_dir(reinterpret_cast<unsigned long long*>(&q.ckeys[(size_t)j * q.kcap + c]), (unsigned long long)rq[j]);
-          __hip_atomic_store(&q.cpres[c], pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __threadfence();
-          const unsigned long long mine = ((unsigned long long)tag << 32) | c;
-          for (;; sl = (sl + 1u) & q.cmask)
-            if (atomicCAS(&q.cdir[sl], 0ull, mine) == 0ull) break;
+            for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+              if (j < L) st_dir(reinterpret_cast<unsigned long long*>(&q.ckeys[(size_t)j * q.kcap + c]), (unsigned long long)rq[j]);
+            __hip_atomic_store(&q.cpres[c], pres, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dir_drain();
+            // elected lanes with DIFFERENT requests can end on the same empty slot: claim it with a CAS, losers probe on
+            const unsigned long long mine = ((unsigned long long)ctag << 32) | c;
+            for (;; slc = (slc + 1u) & q.cmask)
+              if (atomicCAS(&q.cdir[slc], 0ull, mine) == 0ull) break;
+          }
+          cls = c;
+          cs = DONE;
+        } else if (cs == MISS) {
+          cs = PROBE;                                            // same request as an elected lane, or another one behind the same hash: look again
         }
-        cls = c;                                               // (c >= kcap cannot happen: the host re-derives before the id space runs out)
-        pending = false;
-      }
-      __threadfence();
-    }
-    // ---- (group, request class) pair
-    const bool grouped = valid && gi >= 0 && (uint32_t)gi < G;
-    uint32_t pid = BS_INF;
-    const uint64_t ph = grouped ? pair_hash((uint32_t)gi, cls) : 0ull;
-    const uint32_t ptag = (((uint32_t)(ph >> 32)) & hash_keep & 0x7FFFFFFFu) | 0x80000000u;
-    const unsigned long long pkey = ((unsigned long long)(uint32_t)gi << 32) | cls;
-    pending = grouped;
-    while (__ballot(pending)) {
-      uint32_t sl = (uint32_t)ph & q.pmask;
-      if (pending) {
-        for (;; sl = (sl + 1u) & q.pmask) {
-          const unsigned long long cur = ld_dir(&q.pdir[sl]);
-          if (cur == 0ull) break;
-          if ((uint32_t)(cur >> 32) != ptag) continue;
-          if (ld_dir(&q.pkeys[(uint32_t)cur]) == pkey) { pid = (uint32_t)cur; pending = false; break; }
+        dir_drain();
+        // a pair of a class that was drawn just now cannot be filed: its candidate (if any) is somebody else's
+        if (ps == CAND && cs == DONE) {
+          if (cand_pk == (((unsigned long long)(uint32_t)gi << 32) | cls)) ps = DONE;
+          else { ps = PROBE; pid = BS_INF; slp = (slp + 1u) & q.pmask; }
         }
+        continue;
       }
-      unsigned long long todo = __ballot(pending);
-      bool elected = false;
-      while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint64_t k0 = bcast64(pkey, leader);
-        if (lane == leader) elected = true;
-        todo &= ~__ballot(pending && pkey == k0);
+      // ---- ... then the pairs (every class is known now)
+      if (__ballot(ps == MISS)) {
+        const unsigned long long pkey = ((unsigned long long)(uint32_t)gi << 32) | cls;
+        unsigned long long todo = __ballot(ps == MISS);
+        bool elected = false;
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint64_t k0 = bcast64(pkey, leader);
+          if (lane == leader) elected = true;
+          todo &= ~__ballot(ps == MISS && pkey == k0);
+        }
+        if (elected) {
+          const uint32_t np = atomicAdd(q.paircount, 1u);
+          st_dir(&q.pkeys[np], pkey);
+          // chain link: (class << 32) | pair id, pushed at the head of the group's chain (core.go:105-110 replay walks it)
+          q.pair_next[np] = atomicExch(&q.pair_head[gi], ((unsigned long long)cls << 32) | np);
+          dir_drain();
+          const unsigned long long mine = ((unsigned long long)ptag << 32) | np;
+          for (;; slp = (slp + 1u) & q.pmask)
+            if (atomicCAS(&q.pdir[slp], 0ull, mine) == 0ull) break;
+          pid = np;
+          ps = DONE;
+        } else if (ps == MISS) {
+          ps = PROBE;
+        }
+        dir_drain();
+        continue;
       }
-      if (elected) {
-        const uint32_t np = atomicAdd(q.paircount, 1u);
-        st_dir(&q.pkeys[np], pkey);
-        // chain link: (class << 32) | pair id, pushed at the head of the group's chain (core.go:105-110 replay walks it)
-        q.pair_next[np] = atomicExch(&q.pair_head[gi], ((unsigned long long)cls << 32) | np);
-        __threadfence();
-        const unsigned long long mine = ((unsigned long long)ptag << 32) | np;
-        for (;; sl = (sl + 1u) & q.pmask)
-          if (atomicCAS(&q.pdir[sl], 0ull, mine) == 0ull) break;
-        pid = np;
-        pending = false;
-      }
-      __threadfence();
+      break;                                                     // every lane: class DONE, pair DONE (or not grouped)
     }
     if (valid) {
       nw.pclass[at] = cls;
-      nw.ppair[at] = pid;
+      nw.ppair[at] = grouped ? pid : BS_INF;
     }
   }
 }
@@ -217,74 +252,130 @@ __device__ __forceinline__ void apply_insert_wave(const PodDeltaDev& d, const Po
 // gstat_new: [3][G] minima of the NEW queue (all ones on entry: the previous apply / load reset them);
 // gstat_next: the other buffer, reset here for the apply after this one.  derive == 0: copy only (the host re-derives
 // classes, pairs and minima from the resident queue afterwards).
+// A group patch that arrived in the same cycle (bs_groups_apply, deltas in `gp`) rides along: block gather_blocks + 1 applies it
+// and runs findMaxPG (leader_info_block) — one launch and one launch boundary less on the cycle's critical path.
+struct GroupPatch { uint32_t on, C; int32_t tag; int32_t* info; uint32_t* matched; uint32_t* status_scheduled; uint8_t* flags; DeltaPack dp; };
+
+// The delta as the kernel sees it in LDS: the host lays it out as ONE blob in pinned memory ([remove | insert_at | flag_index |
+// flag_value] = the lists every gather block needs, then the inserted pods' records, which only the insert block needs), and a
+// block fetches its part with ONE bulk read (16 bytes per lane, all lanes at once).  A kernel-side read of pinned host memory
+// is a PCIe round trip of ~4 us on this box however small it is — and field-by-field reads queue up behind each other (the
+// eight loads of a pod record took 9 us): one trip per block, everything else from LDS.
+constexpr uint32_t kDeltaLds = 32768;             // bytes of LDS a block stages the blob (or its list part) into; larger deltas are read in place
+
+template <class T>
+__device__ __forceinline__ const T* rebase(const T* p, const uint8_t* from, const uint8_t* to) {
+  return reinterpret_cast<const T*>(to + (reinterpret_cast<const uint8_t*>(p) - from));
+}
+__device__ __forceinline__ void stage_blob(uint4* dst, const uint8_t* src, uint32_t bytes) {      // bytes: a multiple of 16
+  const uint4* s4 = reinterpret_cast<const uint4*>(src);
+  for (uint32_t i = threadIdx.x; i < (bytes >> 4); i += kApplyBlock) dst[i] = s4[i];
+  __syncthreads();
+}
+__device__ __forceinline__ void group_minima(uint32_t* gstat_new, uint32_t G, int32_t gi, uint8_t fl, uint64_t own, uint32_t pn) {
+  if (gi < 0 || (uint32_t)gi >= G) return;             // per-group minima of the new queue (k_pod_pairs' rule)
+  atomicMin(&gstat_new[gi], pn);
+  if (!(fl & BS_POD_LAST_PERMITTED)) {
+    atomicMin(&gstat_new[(size_t)G + gi], pn);
+    if (own != 0) atomicMin(&gstat_new[(size_t)2 * G + gi], pn);
+  }
+}
+
 __global__ __launch_bounds__(kApplyBlock) void k_pods_apply(PodsDev old, const uint32_t* old_pclass, const uint32_t* old_ppair, PodsMut nw, PodDeltaDev d,
                                                            uint32_t G, uint32_t L, uint32_t* gstat_new, uint32_t* gstat_next, QueueDirs q, uint32_t hash_keep,
-                                                           uint32_t derive, uint32_t gather_blocks, int32_t tag, int32_t* hinfo) {
-  __shared__ uint32_t s_rem[kApplyLds], s_at[kApplyLds], s_fi[kApplyLds];
-  if (blockIdx.x >= gather_blocks) {                     // the insert block: wave 0 classifies, the block re-arms the spare minima
-    if (derive) {
-      for (uint32_t i = threadIdx.x; i < 3u * G; i += kApplyBlock) gstat_next[i] = BS_INF;
-      if (threadIdx.x < 64) {
-        apply_insert_wave(d, nw, G, L, q, hash_keep);
-        if (threadIdx.x == 0 && hinfo) {
-          hinfo[4] = (int32_t)__hip_atomic_load(q.kcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&hinfo[5], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-    }
+                                                           uint32_t derive, uint32_t gather_blocks, int32_t tag, int32_t* hinfo, GroupsDev gr, BatchDev bd,
+                                                           GroupPatch gp) {
+  __shared__ uint4 s_blob[kDeltaLds / 16];
+  const uint8_t* s_bytes = reinterpret_cast<const uint8_t*>(s_blob);
+  BS_STAMP(0, 0);
+  if (blockIdx.x == gather_blocks + 1) {                 // the group patch of this cycle + findMaxPG (only launched when gp.on)
+    leader_info_block(gr, bd, gp.C, gp.tag, gp.info, gp.dp, gp.matched, gp.status_scheduled, gp.flags);
+    BS_STAMP(0, 7);
     return;
   }
-  const bool lds_rem = d.n_remove <= kApplyLds, lds_at = d.n_insert <= kApplyLds, lds_fi = d.n_flags <= kApplyLds;
-  if (lds_rem) for (uint32_t i = threadIdx.x; i < d.n_remove; i += kApplyBlock) s_rem[i] = d.remove[i];
-  if (lds_at) for (uint32_t i = threadIdx.x; i < d.n_insert; i += kApplyBlock) s_at[i] = d.insert_at[i];
-  if (lds_fi) for (uint32_t i = threadIdx.x; i < d.n_flags; i += kApplyBlock) s_fi[i] = d.flag_index[i];
-  __syncthreads();
-  const uint32_t* rem = lds_rem ? s_rem : d.remove;
-  const uint32_t* at = lds_at ? s_at : d.insert_at;
-  const uint32_t* fi = lds_fi ? s_fi : d.flag_index;
-  const uint32_t pn = blockIdx.x * kApplyBlock + threadIdx.x;
-  if (pn >= nw.p) return;
-  // inserts at positions <= pn; the pod here is inserted iff the last of them sits exactly here
-  const uint32_t kk = upper_bound_u32<false>(at, d.n_insert, pn);
-  int32_t gi;
-  uint8_t fl;
-  uint64_t own;
-  if (kk && at[kk - 1] == pn) {
-    const uint32_t k = kk - 1;
-    gi = d.ins.group[k];
-    fl = d.ins.flags[k];
-    own = d.ins.owner[k];
-    nw.group[pn] = gi;
-    for (uint32_t j = 0; j < L; ++j) nw.req[(size_t)j * nw.p + pn] = d.ins.req[(size_t)j * d.ins.p + k];
-    nw.pres[pn] = d.ins.pres[k];
-    nw.cls[pn] = d.ins.cls[k];
-    nw.owner[pn] = own;
-    nw.flags[pn] = fl;                                   // pclass / ppair: the insert wave
-  } else {
-    // rank r among the retained pods -> old index o = r + (removed pods before o) = r + #{m : remove[m] - m <= r}
-    const uint32_t r = pn - kk;
-    const uint32_t o = r + upper_bound_u32<true>(rem, d.n_remove, r);
-    gi = old.group[o];
-    own = old.owner[o];
-    fl = old.flags[o];
-    const uint32_t f = upper_bound_u32<false>(fi, d.n_flags, o);
-    if (f && fi[f - 1] == o) fl = d.flag_value[f - 1];
-    nw.group[pn] = gi;
-    for (uint32_t j = 0; j < L; ++j) nw.req[(size_t)j * nw.p + pn] = old.req[(size_t)j * old.p + o];
-    nw.pres[pn] = old.pres[o];
-    nw.cls[pn] = old.cls[o];
-    nw.owner[pn] = own;
-    nw.flags[pn] = fl;
-    nw.pclass[pn] = old_pclass[o];
-    nw.ppair[pn] = old_ppair[o];
-  }
-  if (derive && gi >= 0 && (uint32_t)gi < G) {           // per-group minima of the new queue (k_pod_pairs' rule)
-    atomicMin(&gstat_new[gi], pn);
-    if (!(fl & BS_POD_LAST_PERMITTED)) {
-      atomicMin(&gstat_new[(size_t)G + gi], pn);
-      if (own != 0) atomicMin(&gstat_new[(size_t)2 * G + gi], pn);
+  if (blockIdx.x == gather_blocks) {
+    // the insert block: the inserted pods are its business alone — records into the new pack (all threads), class / pair ids
+    // (wave 0), their share of the per-group minima — and it re-arms the spare minima for the next apply
+    if (derive) for (uint32_t i = threadIdx.x; i < 3u * G; i += kApplyBlock) gstat_next[i] = BS_INF;
+    if (d.n_insert) {
+      PodDeltaDev dl = d;
+      if (d.blob_bytes <= kDeltaLds) {
+        stage_blob(s_blob, d.blob, d.blob_bytes);
+        dl.insert_at = rebase(d.insert_at, d.blob, s_bytes);
+        dl.ins.group = rebase(d.ins.group, d.blob, s_bytes);
+        dl.ins.req = rebase(d.ins.req, d.blob, s_bytes);
+        dl.ins.pres = rebase(d.ins.pres, d.blob, s_bytes);
+        dl.ins.cls = rebase(d.ins.cls, d.blob, s_bytes);
+        dl.ins.owner = rebase(d.ins.owner, d.blob, s_bytes);
+        dl.ins.flags = rebase(d.ins.flags, d.blob, s_bytes);
+      }
+      BS_STAMP(0, 1);
+      for (uint32_t k = threadIdx.x; k < d.n_insert; k += kApplyBlock) {
+        const uint32_t pn = dl.insert_at[k];
+        const int32_t gi = dl.ins.group[k];
+        const uint8_t fl = dl.ins.flags[k];
+        const uint64_t own = dl.ins.owner[k];
+        nw.group[pn] = gi;
+        for (uint32_t j = 0; j < L; ++j) nw.req[(size_t)j * nw.p + pn] = dl.ins.req[(size_t)j * d.ins.p + k];
+        nw.pres[pn] = dl.ins.pres[k];
+        nw.cls[pn] = dl.ins.cls[k];
+        nw.owner[pn] = own;
+        nw.flags[pn] = fl;
+        if (derive) group_minima(gstat_new, G, gi, fl, own, pn);
+      }
+      if (derive && threadIdx.x < 64) apply_insert_wave(dl, nw, G, L, q, hash_keep);
     }
+    BS_STAMP(0, 6);
+    if (derive && threadIdx.x == 0 && hinfo) {
+      hinfo[4] = (int32_t)__hip_atomic_load(q.kcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&hinfo[5], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    BS_STAMP(0, 7);
+    return;
   }
+  // ---- gather blocks: the index lists, staged in one bulk read when they fit
+  const uint32_t* rem = d.remove;
+  const uint32_t* at = d.insert_at;
+  const uint32_t* fi = d.flag_index;
+  const uint8_t* fv = d.flag_value;
+  if (d.lists_bytes && d.lists_bytes <= kDeltaLds) {
+    stage_blob(s_blob, d.blob, d.lists_bytes);
+    rem = rebase(d.remove, d.blob, s_bytes);
+    at = rebase(d.insert_at, d.blob, s_bytes);
+    fi = rebase(d.flag_index, d.blob, s_bytes);
+    fv = rebase(d.flag_value, d.blob, s_bytes);
+  }
+  BS_STAMP(0, 1);
+  const uint32_t pn = blockIdx.x * kApplyBlock + threadIdx.x;
+  if (pn >= nw.p) { BS_STAMP(0, 7); return; }
+  // inserts at positions <= pn; the pod here is an inserted one iff the last of them sits exactly here (the insert block's)
+  const uint32_t kk = upper_bound_u32<false>(at, d.n_insert, pn);
+  if (kk && at[kk - 1] == pn) { BS_STAMP(0, 7); return; }
+  // rank r among the retained pods -> old index o = r + (removed pods before o) = r + #{m : remove[m] - m <= r}
+  const uint32_t r = pn - kk;
+  const uint32_t o = r + upper_bound_u32<true>(rem, d.n_remove, r);
+  const int32_t gi = old.group[o];
+  const uint64_t own = old.owner[o];
+  uint8_t fl = old.flags[o];
+  const uint32_t pr = old.pres[o], cl = old.cls[o], pc = old_pclass[o], pp = old_ppair[o];
+  int64_t rq[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) rq[j] = j < L ? old.req[(size_t)j * old.p + o] : 0;     // every load of the pod in flight together
+  const uint32_t f = upper_bound_u32<false>(fi, d.n_flags, o);
+  if (f && fi[f - 1] == o) fl = fv[f - 1];
+  BS_STAMP(0, 2);
+  nw.group[pn] = gi;
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+    if (j < L) nw.req[(size_t)j * nw.p + pn] = rq[j];
+  nw.pres[pn] = pr;
+  nw.cls[pn] = cl;
+  nw.owner[pn] = own;
+  nw.flags[pn] = fl;
+  nw.pclass[pn] = pc;
+  nw.ppair[pn] = pp;
+  if (derive) group_minima(gstat_new, G, gi, fl, own, pn);
+  BS_STAMP(0, 7);
 }
 
 // bs_nodes_assume: node `index` gets a new requested vector.  left4 (getLeftResource lanes, core.go:460-463) follows; the

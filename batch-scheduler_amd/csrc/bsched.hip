@@ -148,7 +148,6 @@ struct bs_ctx {
   uint32_t serial_insert_max = 2048; // more inserted pods than this: re-derive in parallel instead of the insert wave
   void* h_dstage = nullptr;          // pinned: the delta the apply kernel reads in place
   size_t h_dstage_cap = 0;
-  hipEvent_t ev_dstage = nullptr;
   bool dstage_busy = false;
   uint64_t n_applies = 0, n_rederives = 0;
   void* h_nstage = nullptr;          // pinned: node requests of bs_nodes_assume
@@ -167,6 +166,7 @@ struct bs_ctx {
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
   // request slots (see BatchDev): classes of the loaded pods + per-batch slot arrays
   DevBuf d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_fu_bitmap, d_fu_feas;
+  uint32_t slot_keep = 0xFFFFFFFFu;   // BS_HASH_SLOT_BITS (tests): directory probes start at hash & slot_keep
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
   DevBuf d_fl_bitmap, d_admit, d_ready;
   // fast path (bs_fast.hpp)
@@ -204,6 +204,8 @@ struct bs_ctx {
   int32_t sop_leader0 = -1;
   uint32_t last_stages = 0, batch_seq = 0;
   bool batch_pending_finish = false;
+  bool groups_launch_pending = false; // bs_groups_apply left its (inline) deltas + findMaxPG for the next launch: k_pods_apply takes them along, anything else flushes
+  DeltaPack pending_dp{};
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   uint32_t general_waves = 4096;     // scan grid cap of the general chain (tools/cold_sweep.py)
   bs_batch_stats stats{};
@@ -293,8 +295,12 @@ int timer_collect(bs_ctx* c) {
   } while (0)
 #define TIMED(ctx, id, ...) TIMED_ON(ctx, id, (hipStream_t) nullptr, __VA_ARGS__)
 
-int use_device(bs_ctx* c) {
+int flush_groups(bs_ctx* c);
+// Every entry point starts here.  A group patch whose launch was deferred (bs_groups_apply) goes out now, unless the caller
+// is the one call that can take it along in its own launch (bs_pods_apply).
+int use_device(bs_ctx* c, bool flush = true) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
+  if (flush && c->groups_launch_pending) return flush_groups(c);
   return BS_OK;
 }
 
@@ -667,7 +673,8 @@ int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) 
 // for it at percent 0.7 against the leader's fit class (core.go:157-161) — and writes that table's descriptor.
 // Leader, panic flag and table id come back through pinned memory; nothing waits here (resolve_groups does, at
 // the next bs_batch_run, and then only if the copy has not landed yet).
-int analyse_groups(bs_ctx* c, bool rearm_scratch = true, const bs_group_delta* deltas = nullptr, uint32_t ndeltas = 0) {
+int analyse_groups(bs_ctx* c, bool rearm_scratch = true, const bs_group_delta* deltas = nullptr, uint32_t ndeltas = 0, bool defer = false) {
+  if (c->groups_launch_pending) { int rc = flush_groups(c); if (rc) return rc; }     // an earlier patch is still waiting: it goes first
   c->steady_table = -1;
   c->side_ready = false;
   c->info_pending = false;
@@ -683,11 +690,28 @@ int analyse_groups(bs_ctx* c, bool rearm_scratch = true, const bs_group_delta* d
   static_assert(sizeof(bs_group_delta) == sizeof(GroupDelta), "delta layout");
   if (ndeltas) std::memcpy(dp.d, deltas, (size_t)ndeltas * sizeof(GroupDelta));
   c->info_tag++;
+  c->info_pending = true;
+  c->epochs_ready = false;
+  if (defer) {                                       // the launch is left to whoever touches the stream next (k_pods_apply takes it along)
+    c->pending_dp = dp;
+    c->groups_launch_pending = true;
+    return BS_OK;
+  }
   hipLaunchKernelGGL(k_leader_info, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b, (c->have_fit && c->have_nodes) ? c->C : 0u, c->info_tag, c->h_info,
                      dp, const_cast<uint32_t*>(gr.matched), const_cast<uint32_t*>(gr.status_scheduled), const_cast<uint8_t*>(gr.flags));
   LAUNCHCHK(c, BS_KERNEL_LEADER);
-  c->info_pending = true;
-  c->epochs_ready = false;
+  return BS_OK;
+}
+
+// the deferred group patch as its own launch
+int flush_groups(bs_ctx* c) {
+  if (!c->groups_launch_pending) return BS_OK;
+  c->groups_launch_pending = false;
+  GroupsDev gr = groups_dev(c);
+  BatchDev b = batch_dev(c);
+  hipLaunchKernelGGL(k_leader_info, dim3(1), dim3(kLeaderBlock), 0, c->stream, gr, b, (c->have_fit && c->have_nodes) ? c->C : 0u, c->info_tag, c->h_info,
+                     c->pending_dp, const_cast<uint32_t*>(gr.matched), const_cast<uint32_t*>(gr.status_scheduled), const_cast<uint8_t*>(gr.flags));
+  LAUNCHCHK(c, BS_KERNEL_LEADER);
   return BS_OK;
 }
 
@@ -870,6 +894,7 @@ int maybe_analyse_epochs(bs_ctx* c) {
   if (c->epochs_ready || c->no_fast || c->no_epoch) return BS_OK;
   if (!c->have_groups || !c->have_pods || !c->have_fit || !c->have_nodes || !c->pairs_ready || !c->P || !c->G) return BS_OK;
   if (c->n_uncaptured == 0 && c->n_nominres == 0) return BS_OK;
+  if (c->groups_launch_pending) { int rc = flush_groups(c); if (rc) return rc; }
   return analyse_epochs(c);
 }
 
@@ -963,6 +988,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_FAST")) c->no_fast = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_EPOCH")) c->no_epoch = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
+  if (const char* e = std::getenv("BS_HASH_SLOT_BITS")) { const int hb = std::atoi(e); c->slot_keep = hb >= 32 ? 0xFFFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) { c->early_filter_min = std::strtoull(e, nullptr, 10); c->early_forced = 1; }
   if (const char* e = std::getenv("BS_SCAN_SHARE")) c->scan_share_override = (uint32_t)std::max(0, std::atoi(e));
@@ -991,7 +1017,6 @@ int bs_destroy(bs_ctx* c) {
   if (c->h_dstage) (void)hipHostFree(c->h_dstage);
   if (c->h_nstage) (void)hipHostFree(c->h_nstage);
   if (c->ev_nstage) (void)hipEventDestroy(c->ev_nstage);
-  if (c->ev_dstage) (void)hipEventDestroy(c->ev_dstage);
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   if (c->ev_query) (void)hipEventDestroy(c->ev_query);
   if (c->ev_filter) (void)hipEventDestroy(c->ev_filter);
@@ -1249,8 +1274,10 @@ int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
   // HAS_POD is unchanged, so the capture epochs the general chain's scratch holds stay valid: no re-arm.
   // Few deltas (the per-cycle case) ride in the arguments of the findMaxPG launch: ONE launch, no copy, no wait.
   if (count <= (uint32_t)kInlineDeltas) {
-    if ((rc = analyse_groups(c, false, deltas, count))) return rc;
-    return maybe_analyse_epochs(c);
+    // the launch itself is deferred: a bs_pods_apply in the same cycle takes the patch along in its own launch, any other
+    // call sends it first (use_device)
+    if ((rc = analyse_groups(c, false, deltas, count, true))) return rc;
+    return maybe_analyse_epochs(c);                  // (positional state: flushes the patch, the analysis reads the patched groups)
   }
   const size_t bytes = (size_t)count * sizeof(bs_group_delta);
   rc = ensure_gstage(c, std::max(bytes, c->gpack_bytes));
@@ -1386,7 +1413,10 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
 
 // ---- bs_pods_apply: the resident queue patched on the device (bs_queue.hpp) ----------------------------------------------
 static int ensure_dstage(bs_ctx* c, size_t bytes) {
-  if (c->dstage_busy) { HIPCHK(c, hipEventSynchronize(c->ev_dstage)); c->dstage_busy = false; }     // the previous apply may still be reading it
+  // the previous apply may still be reading the blob.  No event per apply (a record costs the cycle a microsecond of host time):
+  // the flag is cleared whenever the host has seen something later on the stream complete (the batch's completion word, a
+  // stream wait); two applies without that in between wait for the stream here.
+  if (c->dstage_busy) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->dstage_busy = false; }
   if (bytes <= c->h_dstage_cap) return BS_OK;
   if (c->h_dstage) { (void)hipHostFree(c->h_dstage); c->h_dstage = nullptr; c->h_dstage_cap = 0; }
   const size_t want = std::max<size_t>(bytes + bytes / 2, 64 << 10);
@@ -1397,6 +1427,7 @@ static int ensure_dstage(bs_ctx* c, size_t bytes) {
 
 static QueueDirs queue_dirs(const bs_ctx* c) {
   QueueDirs q{};
+  q.slot_keep = c->slot_keep;
   q.cdir = c->d_cdir.as<unsigned long long>();
   q.pdir = c->d_pdir.as<unsigned long long>();
   q.cmask = q.pmask = c->dir_slots ? c->dir_slots - 1 : 0;
@@ -1475,7 +1506,7 @@ int bs_pods_read(bs_ctx* c, const bs_pods_out* out) {
 int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
   if (!c || !d) return BS_ERR_INVALID;
   if (!c->have_pods) { c->last_error = "bs_pods_apply before bs_pods_load"; return BS_ERR_STATE; }
-  int rc = use_device(c);
+  int rc = use_device(c, false);                     // a deferred group patch rides in this call's launch when it can
   if (rc) return rc;
   const uint32_t P = c->P, L = c->L, R = d->n_remove, F = d->n_flags, I = d->insert.p;
   // ---- validate everything before touching anything
@@ -1496,28 +1527,34 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
   if (c->batch_pending_finish) { c->last_error = "bs_pods_apply between a sharded batch and bs_batch_finish"; return BS_ERR_STATE; }
   c->n_applies++;
 
-  // ---- the delta goes into pinned memory the kernel reads in place: index lists first, then the inserted pods (SoA)
+  // ---- the delta goes into pinned memory as ONE tightly packed blob the kernel stages into LDS with one bulk read per block:
+  // [remove | insert_at | flag_index | flag_value] (what every gather block needs), then the inserted pods (SoA)
+  auto a16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
   size_t o = 0;
-  const size_t o_rem = o; o = align256(o + (size_t)R * 4);
-  const size_t o_at = o; o = align256(o + (size_t)I * 4);
-  const size_t o_fi = o; o = align256(o + (size_t)F * 4);
-  const size_t o_fv = o; o = align256(o + (size_t)F);
-  const PodLayout il = pod_layout(I, L);
-  const size_t o_ins = o; o += il.in_bytes;
-  if ((rc = ensure_dstage(c, o))) return rc;
+  const size_t o_rem = o; o = a16(o + (size_t)R * 4);
+  const size_t o_at = o; o = a16(o + (size_t)I * 4);
+  const size_t o_fi = o; o = a16(o + (size_t)F * 4);
+  const size_t o_fv = o; o = a16(o + (size_t)F);
+  const size_t lists_bytes = o;
+  const size_t i_group = o; o = a16(o + (size_t)I * 4);
+  const size_t i_req = o; o = a16(o + (size_t)I * L * 8);
+  const size_t i_pres = o; o = a16(o + (size_t)I * 4);
+  const size_t i_cls = o; o = a16(o + (size_t)I * 4);
+  const size_t i_owner = o; o = a16(o + (size_t)I * 8);
+  const size_t i_flags = o; o = a16(o + (size_t)I);
+  if ((rc = ensure_dstage(c, o + 16))) return rc;
   uint8_t* st = reinterpret_cast<uint8_t*>(c->h_dstage);
   if (R) std::memcpy(st + o_rem, d->remove, (size_t)R * 4);
   if (I) {
     uint32_t* at = reinterpret_cast<uint32_t*>(st + o_at);
     if (d->insert_at) std::memcpy(at, d->insert_at, (size_t)I * 4);
     else for (uint32_t i = 0; i < I; ++i) at[i] = P - R + i;
-    uint8_t* ib = st + o_ins;
-    std::memcpy(ib + il.group, in.group, (size_t)I * 4);
-    std::memcpy(ib + il.req, in.req, (size_t)I * L * 8);
-    std::memcpy(ib + il.pres, in.req_present, (size_t)I * 4);
-    std::memcpy(ib + il.cls, in.cls, (size_t)I * 4);
-    std::memcpy(ib + il.owner, in.owner, (size_t)I * 8);
-    std::memcpy(ib + il.flags, in.flags, (size_t)I);
+    std::memcpy(st + i_group, in.group, (size_t)I * 4);
+    std::memcpy(st + i_req, in.req, (size_t)I * L * 8);
+    std::memcpy(st + i_pres, in.req_present, (size_t)I * 4);
+    std::memcpy(st + i_cls, in.cls, (size_t)I * 4);
+    std::memcpy(st + i_owner, in.owner, (size_t)I * 8);
+    std::memcpy(st + i_flags, in.flags, (size_t)I);
     for (uint32_t i = 0; i < I; ++i)
       if (in.group[i] >= 0) c->max_pod_cls = std::max(c->max_pod_cls, in.cls[i]);
   }
@@ -1525,6 +1562,7 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
 
   // ---- ids can be patched when the pairs are current, the directories can be had, the id space has room and the insert
   // wave is not asked to do a parallel job; otherwise: copy only, then derive everything from the new resident queue
+  if ((!c->pairs_ready || !c->dirs_ready) && c->groups_launch_pending && (rc = flush_groups(c))) return rc;   // other launches come first: the patch too
   if (!c->pairs_ready && c->have_groups && c->rep_valid && (rc = build_pairs(c))) return rc;       // (G changed since the pods were derived)
   bool derive = c->pairs_ready && c->have_groups && I <= c->serial_insert_max && (c->dirs_ready || c->rep_valid);
   const uint32_t old_pair_cap = c->pair_cap;
@@ -1559,21 +1597,35 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
   dd.flag_index = reinterpret_cast<const uint32_t*>(st + o_fi);
   dd.flag_value = st + o_fv;
   dd.ins.p = I;
-  dd.ins.group = reinterpret_cast<const int32_t*>(st + o_ins + il.group);
-  dd.ins.req = reinterpret_cast<const int64_t*>(st + o_ins + il.req);
-  dd.ins.pres = reinterpret_cast<const uint32_t*>(st + o_ins + il.pres);
-  dd.ins.cls = reinterpret_cast<const uint32_t*>(st + o_ins + il.cls);
-  dd.ins.owner = reinterpret_cast<const uint64_t*>(st + o_ins + il.owner);
-  dd.ins.flags = st + o_ins + il.flags;
+  dd.ins.group = reinterpret_cast<const int32_t*>(st + i_group);
+  dd.ins.req = reinterpret_cast<const int64_t*>(st + i_req);
+  dd.ins.pres = reinterpret_cast<const uint32_t*>(st + i_pres);
+  dd.ins.cls = reinterpret_cast<const uint32_t*>(st + i_cls);
+  dd.ins.owner = reinterpret_cast<const uint64_t*>(st + i_owner);
+  dd.ins.flags = st + i_flags;
+  dd.blob = st;
+  dd.blob_bytes = (uint32_t)std::min<size_t>(o, 0xFFFFFFF0u);
+  dd.lists_bytes = (uint32_t)std::min<size_t>(lists_bytes, 0xFFFFFFF0u);
   const uint32_t gb = cdiv(std::max<uint32_t>(Pn, 1), kApplyBlock);
   uint32_t* g_new = (c->gstat_cur ? c->d_gstat : c->d_gstat2).as<uint32_t>();
   uint32_t* g_next = (c->gstat_cur ? c->d_gstat2 : c->d_gstat).as<uint32_t>();
   if (derive) c->kinfo_tag++;
-  hipLaunchKernelGGL(k_pods_apply, dim3(gb + 1), dim3(kApplyBlock), 0, c->stream, old, old_pclass, old_ppair, nw, dd, c->G, L, g_new, g_next,
-                     derive ? queue_dirs(c) : QueueDirs{}, c->hash_keep, derive ? 1u : 0u, gb, c->kinfo_tag, c->h_info);
+  GroupPatch gp{};
+  const GroupsDev grp = c->have_groups ? groups_dev(c) : GroupsDev{};
+  if (c->groups_launch_pending) {                                    // this cycle's group patch + findMaxPG: one more block of this launch
+    c->groups_launch_pending = false;
+    gp.on = 1;
+    gp.C = (c->have_fit && c->have_nodes) ? c->C : 0u;
+    gp.tag = c->info_tag;
+    gp.info = c->h_info;
+    gp.matched = const_cast<uint32_t*>(grp.matched);
+    gp.status_scheduled = const_cast<uint32_t*>(grp.status_scheduled);
+    gp.flags = const_cast<uint8_t*>(grp.flags);
+    gp.dp = c->pending_dp;
+  }
+  hipLaunchKernelGGL(k_pods_apply, dim3(gb + 1 + gp.on), dim3(kApplyBlock), 0, c->stream, old, old_pclass, old_ppair, nw, dd, c->G, L, g_new, g_next,
+                     derive ? queue_dirs(c) : QueueDirs{}, c->hash_keep, derive ? 1u : 0u, gb, c->kinfo_tag, c->h_info, grp, gp.on ? batch_dev(c) : BatchDev{}, gp);
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
-  if (!c->ev_dstage) HIPCHK(c, hipEventCreateWithFlags(&c->ev_dstage, hipEventDisableTiming));
-  HIPCHK(c, hipEventRecord(c->ev_dstage, c->stream));
   c->dstage_busy = true;
   c->cur_pack = np;
   c->rep_valid = false;                                              // the queue was compacted: pod indices of the derivation are history
@@ -2258,6 +2310,7 @@ int bs_batch_sync(bs_ctx* c) {
   int rc = use_device(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->dstage_busy = false;
   return BS_OK;
 }
 
@@ -2314,6 +2367,7 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   if (c->last_host_out && c->batch_since_pods && !(P && out->fl_bitmap && W && filtered)) {
     rc = wait_host_tag(c, 0, c->host_tag, reinterpret_cast<const int32_t*>(c->h_hout + c->off_htag));
     if (rc) return rc;
+    c->dstage_busy = false;                            // (the batch ran behind every earlier apply)
     const uint8_t* st = c->h_hout;
     if (want_pod) {
       if (out->pf_code) std::memcpy(out->pf_code, st + c->off_pf_code, P);
@@ -2358,6 +2412,7 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
                                hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stage_busy = false;                             // (the stream is idle: the pod upload has left its buffer too)
+  c->dstage_busy = false;
   if (want_pod) {
     if (out->pf_code) std::memcpy(out->pf_code, st + c->off_pf_code, P);
     if (out->pf_first_k) std::memcpy(out->pf_first_k, st + c->off_pf_first_k, (size_t)P * 4);
@@ -2395,6 +2450,7 @@ int bs_batch_map(bs_ctx* c, bs_batch_view* v) {
   uint32_t nrows = 0;
   if (filtered && (rc = filter_rows_of(c, &nrows))) return rc;
   if ((rc = wait_host_tag(c, 0, c->host_tag, reinterpret_cast<const int32_t*>(c->h_hout + c->off_htag)))) return rc;
+  c->dstage_busy = false;                              // (the batch ran behind every earlier apply)
   const uint8_t* st = c->h_hout;
   std::memset(v, 0, sizeof(*v));
   v->p = P; v->g = G; v->words = W;
@@ -2802,6 +2858,20 @@ int bs_comm_init(bs_ctx* c, const uint8_t id[128], uint32_t rank, uint32_t nrank
 }
 
 // -------------------------------------------------------------------------------------------------
+#ifdef BS_PROBE
+// probe build only: the stamps of the launches since the last call ([kernel][block][stamp] clock ticks at 100 MHz; 0 = not written)
+int bs_probe_read(bs_ctx* c, unsigned long long* out) {
+  if (!c || !out) return BS_ERR_INVALID;
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(g_probe)));
+  static std::vector<unsigned long long> zero(sizeof(g_probe) / 8, 0ull);
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_probe), zero.data(), sizeof(g_probe)));
+  return BS_OK;
+}
+#endif
+
 int bs_timing_reset(bs_ctx* c) {
   if (!c) return BS_ERR_INVALID;
   int rc = use_device(c);

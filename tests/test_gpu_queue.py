@@ -76,10 +76,11 @@ def test_pods_apply_equals_reload_and_oracle(seed, steady, bsa, soa, orc):
         assert applies >= 6 and rederives == 0, "small deltas must be patched, not re-derived"
 
 
-@pytest.mark.parametrize("knob", ["BS_ID_ROOM=3", "BS_SERIAL_INSERT_MAX=0", "BS_HASH_BITS=2"])
+@pytest.mark.parametrize("knob", ["BS_ID_ROOM=3", "BS_SERIAL_INSERT_MAX=0", "BS_HASH_BITS=2", "BS_HASH_SLOT_BITS=2", "BS_HASH_SLOT_BITS=0"])
 def test_pods_apply_rederive_paths(knob, monkeypatch, bsa, soa, orc):
     """A used-up id space and a delta too large for the insert wave take the re-derivation path; a 2-bit hash makes every
-    directory probe collide.  Results stay those of a reload."""
+    directory probe collide, 2 (0) slot bits start every probe at one of four slots (the same slot): long probe paths, lanes
+    of one insert wave ending on the same empty slot.  Results stay those of a reload."""
     k, v = knob.split("=")
     monkeypatch.setenv(k, v)
     rng, nodes, fit, groups, pods = scene(9300, bsa, soa, True)
@@ -93,7 +94,7 @@ def test_pods_apply_rederive_paths(knob, monkeypatch, bsa, soa, orc):
             assert ctx.read_pods().equal(cur)
             assert_batch_equal(ctx.batch(soa.STAGE_ALL), orc.Sop(snap, groups).batch(cur, soa.STAGE_ALL), f"{knob} round {rnd}")
         applies, rederives = ctx.apply_stats()
-        assert (rederives > 0) == (k != "BS_HASH_BITS")
+        assert (rederives > 0) == (not k.startswith("BS_HASH"))
 
 
 def test_pods_apply_validates_and_is_atomic(bsa, soa, orc):
@@ -292,3 +293,70 @@ def test_batch_map_is_the_read_without_a_copy(config, scenario, bsa, soa, orc):
         ctx.finish()
         with pytest.raises(bsa.BsError):
             ctx.map_results()
+
+
+def test_deferred_group_patch_reaches_every_reader(bsa, soa, orc):
+    """bs_groups_apply leaves its launch to the next call (a bs_pods_apply of the same cycle takes the patch along in its own
+    launch): whatever comes next — another patch, findMaxPG, a read-back, a batch, a queue patch, an empty queue patch — sees
+    the patched groups."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "tail", seed=11)
+    stream = fullsize.PodChurnStream(pods, 11)
+    rng = np.random.default_rng(11)
+    cur = groups.copy()
+    snap = orc.Snapshot(nodes, fit)
+
+    def patch(ctx, n=6):
+        deltas = []
+        for i in rng.choice(cur.g, n, replace=False):
+            cur.matched[i] = rng.integers(0, cur.min_member[i] + 2)
+            cur.status_scheduled[i] = rng.integers(0, 2)
+            deltas.append((int(i), int(cur.matched[i]), int(cur.status_scheduled[i]), int(cur.flags[i])))
+        ctx.apply_group_deltas(deltas)
+
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        for rnd in range(12):
+            patch(ctx)
+            kind = rnd % 6
+            if kind == 0:                                                  # patch -> patch -> queue patch
+                patch(ctx)
+                ctx.apply_pods(**stream.next_delta(10))
+            elif kind == 1:                                                # patch -> findMaxPG
+                leader, panic = ctx.find_max_pg()
+                exp_leader, _fin, exp_panic = orc.find_max_pg(cur)
+                assert (leader, panic) == (exp_leader, exp_panic)
+            elif kind == 2:                                                # patch -> read-back
+                back = ctx.read_groups()
+                assert np.array_equal(back.matched, cur.matched) and np.array_equal(back.status_scheduled, cur.status_scheduled)
+            elif kind == 3:                                                # patch -> empty queue patch -> batch
+                ctx.apply_pods()
+            elif kind == 4:                                                # patch -> queue patch -> queue patch
+                ctx.apply_pods(**stream.next_delta(10))
+                ctx.apply_pods(**stream.next_delta(5))
+            exp = orc.Sop(snap, cur).batch(stream.pods, soa.STAGE_ALL)
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"round {rnd} kind {kind}")
+
+
+@pytest.mark.parametrize("n_ins,n_rem", [(700, 300), (1500, 9000), (3000, 100)])
+def test_pods_apply_deltas_beyond_the_lds_window(n_ins, n_rem, bsa, soa, orc):
+    """Deltas whose blob (700 inserted pods: > 32 KB), whose index lists (9000 removals: > 32 KB) or whose insert count (3000: the
+    insert wave is not asked, everything is re-derived) exceed what a block stages in LDS are read in place: same queue, same
+    batch as a reload."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg3", "tail", seed=3)
+    rng = np.random.default_rng(n_ins)
+    snap = orc.Snapshot(nodes, fit)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        cur = pods
+        for rnd in range(2):
+            remove = np.sort(rng.choice(cur.p, min(n_rem, cur.p), replace=False)).astype(np.uint32)
+            ins = cur.take(rng.integers(0, cur.p, n_ins))
+            ins.req[0, ::7] += 1 + rnd                                        # some requests nobody made before
+            pn = cur.p - len(remove) + n_ins
+            at = np.sort(rng.choice(pn, n_ins, replace=False)).astype(np.uint32) if rnd else None
+            d = dict(remove=remove, insert=ins, insert_at=at)
+            ctx.apply_pods(**d)
+            cur = cur.patched(**d)
+            assert ctx.read_pods().equal(cur)
+            got = ctx.batch(soa.STAGE_PREFILTER | soa.STAGE_TALLY, bitmap=False)
+            exp = orc.Sop(snap, groups).batch(cur, soa.STAGE_PREFILTER | soa.STAGE_TALLY)
+            for name in ("pf_code", "pf_first_k", "pf_leader", "group_admit", "group_ready"):
+                assert np.array_equal(getattr(got, name), getattr(exp, name)), f"{name} round {rnd}"
