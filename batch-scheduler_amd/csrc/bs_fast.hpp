@@ -299,52 +299,126 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
 // (one findMaxPG result for the batch, from the group load), the per-group minima come from the pod load,
 // every scan query is a reservation check -> slot = request class, slots are stamped, not reset.
 // ------------------------------------------------------------------------------------------------
+// What a steady-state batch needs from a leader group (the batch's, or the one carried into it): MinResources, MinMember,
+// Status.Scheduled, matched.  Wave-uniform addresses; loaded by every thread at the very top, together with the pod's own
+// fields, so that nothing the pod derives later waits for another round trip.
+struct LeaderPre { Res mr; bool have_mr; int64_t min_member, status_scheduled, matched; };
+template <int TS>
+__device__ __forceinline__ void leader_pre_load(const GroupsDev& gr, int32_t leader, Shape<TS> sh, LeaderPre& o) {
+  const uint32_t l = leader >= 0 ? (uint32_t)leader : 0u;           // (clamped: the values are only used when leader >= 0)
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) o.mr.v[j] = j < sh.L() ? gr.minres[(size_t)j * gr.g + l] : 0;
+  o.mr.present = gr.mrpres[l];
+  o.have_mr = (gr.flags[l] & BS_GROUP_HAS_MINRES) != 0;             // steady state: every group has it (bs_batch_run's chain choice)
+  o.min_member = (int64_t)gr.min_member[l];
+  o.status_scheduled = (int64_t)gr.status_scheduled[l];
+  o.matched = (int64_t)gr.matched[l];
+}
+// getPreAllocatedResource (core.go:774-793) from the preloaded leader
+template <int TS>
+__device__ __forceinline__ void pre_allocated_from(const LeaderPre& lp, Shape<TS> sh, uint32_t gate, Res& out) {
+  res_zero(out, sh);
+  const int64_t mm = lp.min_member;
+  const int64_t not_finished = lp.matched != 0 ? mm - lp.matched : mm - lp.status_scheduled;
+  if (not_finished > 0 && lp.have_mr) {
+    Res times;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < sh.L()) times.v[j] = wmul(lp.mr.v[j], not_finished);
+    times.present = lp.mr.present;
+    res_add(out, times, sh, gate);
+  }
+  if (out.v[BS_LANE_PODS] == 0) out.v[BS_LANE_PODS] = mm + 1;
+}
+// the Filter slot of (class of `cur`, leader `lp`): computeResourceSatisfied's R = pod + maxSingle, M = maxSingle (core.go:526-552)
+template <int TS>
+__device__ __forceinline__ void filter_slot_from(const BatchDev& b, const BatchParams& prm, const Res& cur_in, const LeaderPre& lp, Shape<TS> sh, uint32_t gate,
+                                                 uint32_t slot) {
+  if (!lp.have_mr) return;                                           // PASS_NO_MINRES (core.go:542-544): no slot to evaluate
+  Res ms, cur = cur_in;
+  res_zero(ms, sh);
+  res_add(ms, lp.mr, sh, gate);                                      // :526-527
+  res_add(cur, ms, sh, gate);                                        // :551-552
+  uint32_t ff = 0;
+#pragma unroll
+  for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+    if (s < sh.S()) {
+      if ((cur.present & (1u << s)) && cur.v[4 + s] != 0) ff |= 1u;  // case 2 can never hold
+      if ((ms.present & (1u << s)) && ms.v[4 + s] != 0) ff |= 2u;    // node "cannot hold" a leader member
+    }
+  }
+  b.uflags[slot] = ff | ((uint32_t)BS_FL_EVALUATED << 8) | (prm.stamp << 16);
+  b.fu_feas[slot] = 0;
+  int64_t* dst2 = b.uparams + (size_t)slot * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { dst2[j] = cur.v[j]; dst2[4 + j] = ms.v[j]; }
+}
+
+// Three rounds of loads, issued as early as their addresses are known, then arithmetic, then stores:
+//   round 1   the pod's own fields (group, flags, owner, request, class, pair) | the batch's leader and panic flag
+//   round 2   the pod's group (flags, OccupiedBy, first owner, first pod) | both leaders' resources (uniform)
+//   round 3   the owner of the group's first owning pod (only where OccupiedBy is still empty)
 template <int TS>
 __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i,
                                                   uint32_t nthreads) {
   const Shape<TS> sh(prm.S);
-  for (uint32_t g = i; g < gr.g; g += nthreads) b.admit[g] = 0;        // consumed by launch C
-  if (i < 8 && prm.collect_stats) b.stats[i] = 0;
   const bool valid = i < pods.p;
   const uint32_t gate = prm.eph_gate;
+  const uint32_t ii = valid ? i : 0u;                                 // (clamped loads: invalid lanes read pod 0 and store nothing)
+  // ---- round 1
+  const int32_t leader0 = b.leader_epoch[0];
+  const uint8_t panic0 = b.panic_epoch[0];
+  const uint32_t K = prm.run_filter ? *b.kclass : 0u;
+  const int32_t gi = pods.p ? pods.group[ii] : BS_POD_NOT_GROUPED;
+  const uint8_t pfl = pods.p ? pods.flags[ii] : (uint8_t)0;
+  const uint64_t own = pods.p ? pods.owner[ii] : 0ull;
+  const uint32_t pc = pods.p ? b.pclass[ii] : 0u;
+  const uint32_t pp = pods.p ? b.ppair[ii] : BS_INF;
+  Res cur;
+  if (pods.p) pod_require(pods, ii, sh, gate, cur); else res_zero(cur, sh);
+  for (uint32_t g = i; g < gr.g; g += nthreads) b.admit[g] = 0;        // consumed by launch C
+  if (i < 8 && prm.collect_stats) b.stats[i] = 0;
+  // ---- round 2
+  const bool grouped = valid && gi >= 0 && (uint32_t)gi < gr.g;
+  const uint32_t g = grouped ? (uint32_t)gi : 0u;
+  const uint8_t gfl = gr.g ? gr.flags[g] : (uint8_t)0;
+  const uint64_t occ0 = gr.g ? gr.occupied[g] : 0ull;
+  const uint32_t fo = gr.g ? b.first_owner_s[g] : BS_INF;
+  const uint32_t anchor = grouped ? b.first_pod_s[g] : i;
+  LeaderPre lp0{}, lp1{};
+  const bool two = prm.run_filter && prm.sop_leader0 >= 0 && prm.sop_leader0 != leader0;
+  if (gr.g) {
+    leader_pre_load(gr, leader0, sh, lp0);
+    if (two) leader_pre_load(gr, prm.sop_leader0, sh, lp1); else lp1 = lp0;
+  }
+  // ---- round 3
+  const bool need_fo = grouped && occ0 == 0 && fo != BS_INF && i > fo;
+  const uint64_t occ_fo = need_fo ? pods.owner[fo] : 0ull;
+
   uint8_t code = BS_PF_PASS_NOT_GROUPED, st = 0;
   bool has_q = false;
   Res q;
   res_zero(q, sh);
-  const int32_t leader0 = b.leader_epoch[0];
   if (valid) {
-    const int32_t gi = pods.group[i];
-    const bool grouped = gi >= 0 && (uint32_t)gi < gr.g;
     // shard ownership: all pods of a group live on the rank of the group's first pod
-    const uint32_t anchor = grouped ? b.first_pod_s[gi] : i;
     if ((uint32_t)(((uint64_t)anchor * prm.nranks) / pods.p) == prm.rank) st |= ST_OWNED;
     if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                         // core.go:89-92
-    else if (pods.flags[i] & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;      // :95-98
+    else if (pfl & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;                // :95-98
     else if (!grouped) code = BS_PF_ERR_PG_NOT_FOUND;                                      // :100-103
-    else if (gr.flags[gi] & BS_GROUP_DENIED) code = BS_PF_ERR_DENIED;                      // :105-110
+    else if (gfl & BS_GROUP_DENIED) code = BS_PF_ERR_DENIED;                               // :105-110
     else {
       st |= ST_ELIG;
-      const uint32_t g = (uint32_t)gi;
       bool occ_err = false;                                                                // :494-511 in queue order
-      const uint64_t own = pods.owner[i];
-      const uint64_t occ0 = gr.occupied[g];
       if (occ0 != 0) occ_err = (own == 0) || (own != occ0);
-      else {
-        const uint32_t fo = b.first_owner_s[g];          // the group is not denied: every non-permitted pod of it is eligible
-        if (fo != BS_INF && i > fo) { const uint64_t occ = pods.owner[fo]; occ_err = (own == 0) || (own != occ); }
-      }
+      else if (need_fo) occ_err = (own == 0) || (own != occ_fo);     // the group is not denied: every non-permitted pod of it is eligible
       if (occ_err) code = BS_PF_ERR_OCCUPIED;                                              // :113-115
-      else if (b.panic_epoch[0]) code = BS_PF_PANIC_DIV0;                                  // :716-717
+      else if (panic0) code = BS_PF_PANIC_DIV0;                                            // :716-717
       else {
         st |= ST_REACH6;                                                                   // :118-123
         if (leader0 < 0) code = BS_PF_PASS_NO_MAX;                                         // :127-130
         else if (leader0 == gi) code = BS_PF_PASS_IS_MAX;                                  // :150-155 (leader.matched > 0 on this path)
         else {                                                                             // :157-166
-          Res mr;
-          const bool have = group_minres_at(gr, pods, b, (uint32_t)leader0, i, sh, gate, mr);
-          pre_allocated(gr, (uint32_t)leader0, (int64_t)gr.matched[leader0], have, mr, sh, gate, q);
-          Res cur;
-          pod_require(pods, i, sh, gate, cur);
+          pre_allocated_from(lp0, sh, gate, q);
           res_add(q, cur, sh, gate);
           code = BS_PF_PASS_RESERVE_FITS;                                                  // tentative
           has_q = (st & ST_OWNED) != 0;
@@ -374,19 +448,16 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
   // is elected to fill it (tens of thousands of identical stores to a few hundred cache lines were a measurable part
   // of this launch; electing ONE writer per batch with an atomic swap of the stamp was worse: a hot-spot of returning atomics).
   if (prm.run_filter) {
-    const uint32_t c = valid ? b.pclass[i] : 0u;
-    const int32_t gi = valid ? pods.group[i] : BS_POD_NOT_GROUPED;
-    const bool may = valid && (st & ST_OWNED) && BS_PF_IS_PASS(code) && gi >= 0 && (uint32_t)gi < gr.g;
-    if (wave_elect_by_key(c, may && leader0 >= 0 && leader0 != gi)) filter_params_for<TS>(pods, gr, b, prm, i, code, leader0, c, true, false);
-    if (wave_elect_by_key(c, may && prm.sop_leader0 >= 0 && prm.sop_leader0 != gi))
-      filter_params_for<TS>(pods, gr, b, prm, i, code, prm.sop_leader0, c + *b.kclass, true, false);
+    const bool may = valid && (st & ST_OWNED) && BS_PF_IS_PASS(code) && grouped;
+    if (wave_elect_by_key(pc, may && leader0 >= 0 && leader0 != gi)) filter_slot_from(b, prm, cur, lp0, sh, gate, pc);
+    if (wave_elect_by_key(pc, may && prm.sop_leader0 >= 0 && prm.sop_leader0 != gi)) filter_slot_from(b, prm, cur, lp1, sh, gate, pc + K);
   }
   BS_STAMP(1, 3);
-  const uint32_t qslot = has_q ? b.pclass[i] : 0u;
+  const uint32_t qslot = has_q ? pc : 0u;
   const bool fill = wave_elect_by_key(qslot, has_q);   // one writer per (wave, class): ~10x fewer identical stores, no atomics
   if (has_q) {
     b.qpos[i] = qslot;
-    atomicMin(&b.pair_firstq[b.ppair[i]], ((unsigned long long)prm.seq_inv << 32) | i);
+    atomicMin(&b.pair_firstq[pp], ((unsigned long long)prm.seq_inv << 32) | i);
   }
   if (fill) {
     uint32_t absok = 0;

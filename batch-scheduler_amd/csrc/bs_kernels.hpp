@@ -1108,6 +1108,8 @@ template <int S>
 struct LocalPre {
   unsigned long long offl[4 + S], carry[4 + S];
   uint32_t kp[S > 0 ? S : 1];
+  int64_t gm[2][4 + S];          // per-group local maxima of groups lane and 64 + lane (the first 8192 rows): fetched with everything
+                                 // else a wave needs before it can look at a row, instead of one round trip later
 };
 template <int S>
 __device__ __forceinline__ void local_pre_load(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, LocalPre<S>& pre) {
@@ -1122,6 +1124,17 @@ __device__ __forceinline__ void local_pre_load(const BatchDev& b, const BatchPar
   uint32_t kv[S > 0 ? S : 1];
 #pragma unroll
   for (int s = 0; s < S; ++s) kv[s] = ch < nchunks ? b.chunk_kp[((size_t)slot * cstride + ch) * 16 + s] : BS_INF;
+  {
+    constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
+    const uint32_t ngroups = (m + 63u) >> 6, gstride = (prm.mcap + 63u) >> 6;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const uint32_t g = (uint32_t)w * 64u + (uint32_t)lane;
+      const int64_t* gm = b.gmax + ((size_t)slot * gstride + min(g, ngroups ? ngroups - 1u : 0u)) * LP;
+#pragma unroll
+      for (int j = 0; j < L; ++j) pre.gm[w][j] = gm[j];
+    }
+  }
 #pragma unroll
   for (int j = 0; j < L; ++j) {
     const unsigned long long incl = wave_incl_scan_add_u64(v[j]);
@@ -1142,7 +1155,7 @@ __device__ __forceinline__ void local_pre_load(const BatchDev& b, const BatchPar
 template <int S, bool LOCAL = false>
 __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, uint32_t pos, bool valid,
                                           const int64_t (&r)[1][4 + S], uint32_t qf, uint32_t share, uint32_t J, int64_t (*rows)[4 + S],
-                                          const LocalPre<S>* pre_in = nullptr) {
+                                          const LocalPre<S>* pre_in = nullptr, uint32_t sub = 0, uint32_t nsub = 1) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
   constexpr int U = 4;                           // rows per step: their LDS reads are issued together
@@ -1167,8 +1180,8 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   uint32_t win = BS_INF;
 #pragma unroll
   for (int j = 0; j < L; ++j) { offl[j] = 0; carry[j] = 0; }
+  LocalPre<S> mine_pre;                          // (lives as long as pre_in may point at it)
   if constexpr (LOCAL) {
-    LocalPre<S> mine_pre;
     if (!pre_in) { local_pre_load<S>(b, prm, m, slot, mine_pre); pre_in = &mine_pre; }
 #pragma unroll
     for (int j = 0; j < L; ++j) { offl[j] = pre_in->offl[j]; carry[j] = pre_in->carry[j]; }
@@ -1192,6 +1205,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
     }
   };
 
+  BS_STAMP(2, 2);
   for (uint32_t c0 = 0; c0 < ngroups; c0 += 64u) {
     // live mask of groups c0 .. c0+63 (lane l <-> group c0+l)
     bool dead = true;
@@ -1202,7 +1216,15 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 #pragma unroll
       for (int j = 0; j < L; ++j) og[j] = __shfl(offl[j], (int)((g >> 2) & 63u));
       if (g < ngroups) {
-        const int64_t* gm = b.gmax + ((size_t)slot * gstride + g) * LP;     // local max per lane, INT64_MAX = do not prune
+        int64_t gm[L];                                                       // local max per lane, INT64_MAX = do not prune
+        if (c0 < 128u) {
+#pragma unroll
+          for (int j = 0; j < L; ++j) gm[j] = c0 ? pre_in->gm[1][j] : pre_in->gm[0][j];
+        } else {
+          const int64_t* src = b.gmax + ((size_t)slot * gstride + g) * LP;
+#pragma unroll
+          for (int j = 0; j < L; ++j) gm[j] = src[j];
+        }
         constexpr long long kSafe = 1ll << 62;
         dead = false;
 #pragma unroll
@@ -1253,15 +1275,20 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 #pragma unroll
       for (int j = 0; j < L; ++j) rows[lane][j] = mine_row[j];
       __builtin_amdgcn_wave_barrier();
-      uint32_t a = g0;
+      BS_STAMP(2, 3);
+      // nsub waves share a group: wave `sub` looks at rows [g0 + sub * 64 / nsub, + 64 / nsub) — the row loop is one wave's
+      // dependent chain of LDS reads and compares (~50 ns per row), the longest thing a steady-state scan does
+      const uint32_t part = 64u / nsub;
+      uint32_t a = g0 + sub * part;
+      const uint32_t pend = min(gend, a + part);
       // lanes another wave already served with an earlier row need nothing from this group — nor from any later one (this
       // wave walks its groups in increasing row order)
       nf &= __ballot(seen >= a);
       if (nf == 0) { c0 = ngroups; break; }
       unsigned long long want = nf;
-      while (a < gend) {
+      while (a < pend) {
         // piece [a, e): no kp[s] strictly inside
-        uint32_t e = gend;
+        uint32_t e = pend;
 #pragma unroll
         for (int s = 0; s < S; ++s)
           if (kp[s] > a && kp[s] < e) e = kp[s];
@@ -1302,6 +1329,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
       if (nf == 0) { c0 = ngroups; break; }
     }
   }
+  BS_STAMP(2, 4);
   if (!loaded) return;
   if (myk[0] != BS_INF) atomicMin(&b.first_row[pos], myk[0]);
   if (prm.collect_stats && lane == 0) {
@@ -1334,16 +1362,21 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
   }
   const uint32_t ntl = t_hi - t_lo;
   // tsplit > 1 (several tables in use): the distinct tables of a tile are dealt over tsplit waves as well
-  const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (nblocks * 4u) / (ntl * tsplit)));
+  // steady state (one table for every item, stamped slots): the four waves of a block work on ONE item, a quarter of every
+  // group's rows each; elsewhere an item is one wave's
+  const bool uni = LOCAL && prm.stamp != 0;
+  const uint32_t nsub = uni ? 4u : 1u, sub = uni ? (uint32_t)__builtin_amdgcn_readfirstlane(wave_id()) : 0u;   // (wave-uniform: row numbers stay scalar)
+  const uint32_t wpb = 4u / nsub;                 // items a block works on at a time
+  const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (nblocks * wpb) / (ntl * tsplit)));
   const uint32_t items = ntl * tsplit * J;
   const int lane = lane_id();
-  // steady state (one table for every item, stamped slots): derive the table's offsets / key rows once per wave, now
+  const uint32_t w_first = __builtin_amdgcn_readfirstlane(uni ? bx : bx * 4u + (uint32_t)wave_id());
+  // ... and derive the table's offsets / key rows / first pruning bounds once per wave, now
   LocalPre<S> pre;
-  const bool uni = LOCAL && prm.stamp != 0;
   if constexpr (LOCAL) {
-    if (uni && __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()) < items) local_pre_load<S>(b, prm, m, 0u, pre);
+    if (uni && w_first < items) local_pre_load<S>(b, prm, m, 0u, pre);
   }
-  for (uint32_t w = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()); w < items; w += nblocks * 4u) {
+  for (uint32_t w = w_first; w < items; w += nblocks * wpb) {
     const uint32_t rest = w / ntl, tile = t_lo + (w - rest * ntl);
     const uint32_t share = rest / tsplit, ts = rest - share * tsplit;
     const uint32_t pos = tile * 64u + (uint32_t)lane;
@@ -1360,18 +1393,19 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
     uint32_t qf = b.qflags_s[ps];
     if (pos >= nslots || stp != prm.stamp) tab = -1;   // fast path: a slot is live iff a pod of THIS batch wrote it (stamp 0: every slot the pre-pass left >= 0)
     unsigned long long todo = __ballot(tab >= 0);
+    BS_STAMP(2, 1);
     if (!todo) continue;
     if (tab < 0) {
       qf = 0;
 #pragma unroll
       for (int j = 0; j < L; ++j) r[0][j] = INT64_MAX;
     }
-    if (prm.collect_stats && share == 0 && ts == 0 && lane == 0) atomicAdd((unsigned long long*)&b.stats[4], (unsigned long long)__popcll(todo));
+    if (prm.collect_stats && share == 0 && ts == 0 && sub == 0 && lane == 0) atomicAdd((unsigned long long*)&b.stats[4], (unsigned long long)__popcll(todo));
     uint32_t turn = 0;
     while (todo) {
       const int32_t t0 = __builtin_amdgcn_readlane(tab, __ffsll((long long)todo) - 1);
       const bool member = tab == t0;
-      if (turn == ts) scan_core<S, LOCAL>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows, uni ? &pre : (const LocalPre<S>*)nullptr);
+      if (turn == ts) scan_core<S, LOCAL>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows, uni ? &pre : (const LocalPre<S>*)nullptr, sub, nsub);
       turn = turn + 1u == tsplit ? 0u : turn + 1u;
       todo &= ~__ballot(member);
     }

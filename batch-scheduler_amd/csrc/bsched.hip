@@ -1876,7 +1876,8 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   const uint32_t k_est = std::min<uint32_t>(P, c->kinfo_pending ? std::max<uint32_t>(2 * c->h_K, 1024) : std::max<uint32_t>(c->h_K, 1));
   TIMED(c, BS_KERNEL_SCAN, {
     const uint32_t nseg = pick_scan_share(c);
-    const uint32_t scan_blocks = std::max<uint32_t>(1, cdiv(std::min<uint32_t>(c->target_waves, cdiv(k_est, 64) * std::min<uint32_t>(nseg, cdiv(c->M, 64))), 4));
+    // one scan item (tile of 64 class slots x share) per BLOCK: its four waves take a quarter of every group's rows each
+    const uint32_t scan_blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(c->target_waves, 4), cdiv(k_est, 64) * std::min<uint32_t>(nseg, cdiv(c->M, 64))));
     const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * k_est, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
     const dim3 grid(scan_blocks + fblocks);
     launch_fast_b(c, grid, pd, nd, bt, prm, nseg, scan_blocks);
