@@ -198,7 +198,7 @@ template <int TS>
 __device__ __forceinline__ void epoch_query_thread(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, const EpochDev& ep,
                                                    uint32_t i, uint32_t nthreads) {
   const Shape<TS> sh(prm.S);
-  for (uint32_t g = i; g < gr.g; g += nthreads) b.admit[g] = 0;        // consumed by launch C
+  arm_tally(gr, b, prm, i, nthreads);                                  // consumed by launch C
   if (i < 8 && prm.collect_stats) b.stats[i] = 0;
   const bool valid = i < pods.p;
   const uint32_t gate = prm.eph_gate;
@@ -617,7 +617,6 @@ __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr,
   }
   const uint32_t jp1 = max(max(v, off), prev);
   bool admit = false;
-  uint32_t ag = 0;
   if (i < pods.p) {
     int32_t leader = prm.sop_leader0;
     uint32_t rr = ep.R;
@@ -648,14 +647,14 @@ __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr,
     b.fl_code[i] = fl;
     b.fflags[i] = (uint32_t)fl << 8;
     if (prm.host_tag) { b.h_pf_leader[i] = leader; b.h_fl_code[i] = fl; b.h_fl_feasible[i] = prm.run_filter ? feasible : 0u; b.h_fl_slot[i] = slot; }
-    if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) { admit = true; ag = (uint32_t)gi; }
+    if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) admit = true;
   }
   if (prm.host_tag && prm.run_filter) {             // per-row feasible counts of the (run, class) slots in use
     const uint32_t U = min((ep.R + 1u) * ep.K, b.hstride);
     for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
   }
-  if (prm.do_tally) wave_aggregated_add(b.admit, ag, admit);
-  final_tail(gr, b, prm);
+  const bool grouped = i < pods.p && gi >= 0 && (uint32_t)gi < gr.g;
+  tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi : 0u, admit);
 }
 
 }  // namespace bs

@@ -37,15 +37,18 @@
 
 namespace bs {
 
+__device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i, uint32_t nthreads);
+
 // ------------------------------------------------------------------------------------------------
 // bs_pods_load: what the batch needs from the pods alone.
 //   gstat[0][g] first pod of group g (shard ownership)           gstat[1][g] first pod without LAST_PERMITTED
 //   gstat[2][g] first such pod with OwnerReferences              gstat[3][g] head of the group's pair chain
 // A pair = (group, request class); its id is the index of its representative pod.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_pods_prep(unsigned long long* tables, uint32_t ntab, uint32_t* gstat, uint32_t ngstat, uint32_t* kcount) {
+__global__ void k_pods_prep(unsigned long long* tables, uint32_t ntab, uint32_t* gstat, uint32_t ngstat, uint32_t* kcount, uint32_t* gcount, uint32_t G) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
   for (uint32_t i = t; i < ntab; i += nt) tables[i] = 0ull;
+  for (uint32_t i = t; i < G; i += nt) gcount[i] = 0;                // pods per group: counted by k_pod_pairs
   for (uint32_t i = t; i < ngstat; i += nt) gstat[i] = BS_INF;     // [3][G] minima + [G] 64-bit chain heads = 5 G words, all ones
   if (t == 0 && kcount) *kcount = 0;
 }
@@ -55,11 +58,16 @@ __global__ void k_pods_prep(unsigned long long* tables, uint32_t ntab, uint32_t*
 // (value, then the tag with system-scope release; the host only looks when it needs the row count).
 __global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* rep, const uint32_t* id, uint32_t* pclass, unsigned long long* slots, uint32_t mask,
                             uint32_t hash_keep, uint32_t* gstat, uint32_t* ppair, unsigned long long* pair_next, const uint32_t* kcount, int32_t tag,
-                            int32_t* hinfo) {
+                            int32_t* hinfo, uint32_t* gcount) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && hinfo) {
     hinfo[4] = (int32_t)*kcount;
     __hip_atomic_store(&hinfo[5], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  {
+    const int32_t gq = i < pods.p ? pods.group[i] : -1;
+    const bool in = gq >= 0 && (uint32_t)gq < G;
+    wave_aggregated_add(gcount, in ? (uint32_t)gq : 0u, in);          // (every lane of the wave gets here)
   }
   if (i >= pods.p) return;
   const uint32_t c = id[rep[i]];
@@ -376,7 +384,7 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
   const uint32_t pp = pods.p ? b.ppair[ii] : BS_INF;
   Res cur;
   if (pods.p) pod_require(pods, ii, sh, gate, cur); else res_zero(cur, sh);
-  for (uint32_t g = i; g < gr.g; g += nthreads) b.admit[g] = 0;        // consumed by launch C
+  arm_tally(gr, b, prm, i, nthreads);                                  // consumed by launch C
   if (i < 8 && prm.collect_stats) b.stats[i] = 0;
   // ---- round 2
   const bool grouped = valid && gi >= 0 && (uint32_t)gi < gr.g;
@@ -513,51 +521,88 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev
 }
 
 // ------------------------------------------------------------------------------------------------
-// The common end of a three-launch batch (k_fast_final, k_epoch_final; 256 threads per block): the LAST block to get here
-// evaluates the Permit quorum (core.go:303) from the admit counters and, in latency mode (BS_BATCH_HOST_RESULTS), mirrors
-// admit / ready into pinned host memory and publishes the completion word the host polls.
+// The common ends of a three-launch batch (k_fast_final, k_epoch_final; 256 threads per block).
+//   arm_tally    (launch A) zero the per-group counters of this batch; groups without a pod in the queue get their quorum
+//                answer right away (nobody will come by to close them)
+//   tally_tail   (launch C) per-group admit counts and the Permit quorum (core.go:303).  Single context: every wave adds
+//                (pods seen << 32 | pods admitted) to its groups' 64-bit counters with RETURNING atomics, all in flight
+//                together; the lane whose add brings "pods seen" up to the group's pod count closes the group — admit count,
+//                ready bit, host mirrors.  No ticket, no last block that walks all groups after everybody else is done.
+//                Sharded / external reduction: fire-and-forget adds into admit[] (the collective and k_ready follow).
+//   final_tail   latency mode only: the LAST block to get here publishes the completion word the host polls.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void final_tail(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm) {
+__device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i, uint32_t nthreads) {
+  for (uint32_t g = i; g < gr.g; g += nthreads) {
+    b.admit[g] = 0;
+    if (prm.do_ready) {
+      b.admit64[g] = 0ull;
+      if (b.gcount[g] == 0u) {
+        const uint8_t rd = gr.matched[g] >= (uint32_t)(gr.min_member[g] - gr.status_scheduled[g]) ? 1 : 0;
+        b.ready[g] = rd;
+        if (prm.host_tag) { b.h_admit[g] = 0; b.h_ready[g] = rd; }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void final_tail(const BatchDev& b, const BatchParams& prm) {
   __shared__ uint32_t s_last;
-  if (!prm.do_ready && !prm.host_tag) return;
-  // the admit counters are agent-scope atomics (performed at the coherence point, returned before vmcnt drains): a drained
-  // ticket orders them, the last block reads them back with agent-scope loads — no L2 write-back / invalidate per block
+  if (!prm.host_tag) return;
+  // every block drains its writes (host mirrors included) before it takes its ticket; the last one sends the completion
+  // word behind them with a system-scope store — the host polls it (bs_batch_read / bs_batch_map) instead of waiting on the stream
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  if (threadIdx.x == 0) __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // quorum pass: all loads of a batch of groups first, then the stores (one round trip per 8 x 256 groups, not one per 256)
-  constexpr int kQ = 8;
-  for (uint32_t g0 = 0; g0 < gr.g; g0 += kQ * 256u) {
-    uint32_t ad[kQ], ma[kQ], mm[kQ], sc[kQ];
-#pragma unroll
-    for (int u = 0; u < kQ; ++u) {
-      const uint32_t gg = g0 + (uint32_t)u * 256u + threadIdx.x;
-      ad[u] = ma[u] = mm[u] = sc[u] = 0;
-      if (gg < gr.g) {
-        ad[u] = __hip_atomic_load(&b.admit[gg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ma[u] = gr.matched[gg]; mm[u] = gr.min_member[gg]; sc[u] = gr.status_scheduled[gg];
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(b.h_tag, prm.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// grouped: the pod names a group of the loaded state (g valid); admit: it passes PreFilter and, if Filter ran, has a feasible node
+__device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, bool grouped, uint32_t g, bool admit) {
+  if (prm.do_tally && prm.do_ready) {
+    // what closing a group needs, fetched while the adds are in flight (the lane's own group: the leader of a key is one of its lanes)
+    uint32_t want = 0, ma = 0, mm = 0, sc = 0;
+    if (grouped) { want = b.gcount[g]; ma = gr.matched[g]; mm = gr.min_member[g]; sc = gr.status_scheduled[g]; }
+    // who adds what: one lane per distinct group of the wave (the first kElectRounds groups; lanes left over add for themselves)
+    unsigned long long mine = 0;
+    bool asked = false;
+    unsigned long long todo = __ballot(grouped);
+    const unsigned long long adm = __ballot(grouped && admit);
+    for (int round = 0; todo && round < kElectRounds; ++round) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)g, leader);
+      const unsigned long long same = __ballot(grouped && g == k0) & todo;
+      if (lane_id() == leader) {
+        mine = ((unsigned long long)__popcll(same) << 32) | (unsigned long long)__popcll(same & adm);
+        asked = true;
+      }
+      todo &= ~same;
+    }
+    if (todo & (1ull << lane_id())) {
+      mine = (1ull << 32) | (admit ? 1ull : 0ull);
+      asked = true;
+    }
+    // ONE returning atomic instruction for all of them (a returning atomic per round would wait for the previous round's result)
+    unsigned long long got = 0;
+    if (asked) got = __hip_atomic_fetch_add(&b.admit64[g], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (asked) {
+      const unsigned long long tot = got + mine;
+      if ((uint32_t)(tot >> 32) == want) {           // every pod of the group has been counted: this lane closes it
+        const uint32_t ad = (uint32_t)tot;
+        const uint8_t rd = (ma + ad) >= (uint32_t)(mm - sc) ? 1 : 0;
+        b.admit[g] = ad;
+        b.ready[g] = rd;
+        if (prm.host_tag) { b.h_admit[g] = ad; b.h_ready[g] = rd; }
       }
     }
-#pragma unroll
-    for (int u = 0; u < kQ; ++u) {
-      const uint32_t gg = g0 + (uint32_t)u * 256u + threadIdx.x;
-      if (gg < gr.g) {
-        const uint8_t rd = (ma[u] + ad[u]) >= (uint32_t)(mm[u] - sc[u]) ? 1 : 0;
-        if (prm.do_ready) b.ready[gg] = rd;
-        if (prm.host_tag) { b.h_admit[gg] = ad[u]; b.h_ready[gg] = rd; }
-      }
-    }
+  } else if (prm.do_tally) {
+    wave_aggregated_add(b.admit, g, grouped && admit);
   }
-  if (prm.host_tag) {
-    // every block drained its host writes before taking its ticket; this block's are drained here; then the completion
-    // word goes out with system-scope release — the host polls it (bs_batch_read) instead of waiting on the stream
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(b.h_tag, prm.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  final_tail(b, prm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -615,7 +660,6 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
   __syncthreads();
   BS_STAMP(3, 1);
   bool admit = false;
-  uint32_t ag = 0;
   if (valid) {
     uint8_t code = code0;
     const uint8_t st = st0;
@@ -677,16 +721,14 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     b.fl_code[i] = fl;
     b.fflags[i] = (uint32_t)fl << 8;
     if (prm.host_tag) { b.h_fl_code[i] = fl; b.h_fl_feasible[i] = prm.run_filter ? feasible : 0u; b.h_fl_slot[i] = slot; }
-    if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) { admit = true; ag = (uint32_t)gi; }
+    if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) admit = true;
   }
   if (prm.host_tag && prm.run_filter) {             // per-row feasible counts of the slots in use
     const uint32_t U = min(2u * K, b.hstride);
     for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
   }
   BS_STAMP(3, 2);
-  if (prm.do_tally) wave_aggregated_add(b.admit, ag, admit);
-  BS_STAMP(3, 3);
-  final_tail(gr, b, prm);
+  tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi0 : 0u, admit);
   BS_STAMP(3, 7);
 }
 

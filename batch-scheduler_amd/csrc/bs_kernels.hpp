@@ -146,6 +146,8 @@ struct BatchDev {
   uint32_t pair_stride;           // id space of the pairs (a pair's id is its representative pod at bs_pods_load, a drawn number after bs_pods_apply)
   unsigned long long* first_reach64;  // [blocks of launch A] (~batch_seq << 32) | first pod of the block that reaches findMaxPG
   uint32_t* fast_reject;    // [G] first rejected pod of the group (only maintained for BS_BATCH_COMMIT)
+  const uint32_t* gcount;   // [G] pods of the group in the resident queue (bs_pods_load / bs_pods_apply keep it): the thread whose add
+  unsigned long long* admit64;  // [G] brings (pods seen << 32 | pods admitted) up to gcount closes the group — quorum without a last-block pass
   // BS_BATCH_HOST_RESULTS: mirrors of the results in pinned host memory, written by the last launch (null = off)
   uint8_t* h_pf_code; uint32_t* h_pf_first_k; int32_t* h_pf_leader; uint8_t* h_fl_code; uint32_t* h_fl_feasible; uint32_t* h_fl_slot;
   uint32_t* h_admit; uint8_t* h_ready; uint32_t* h_feas; uint64_t* h_rows; int32_t* h_tag; uint32_t hstride;

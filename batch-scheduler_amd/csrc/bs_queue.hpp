@@ -284,7 +284,7 @@ __device__ __forceinline__ void group_minima(uint32_t* gstat_new, uint32_t G, in
 __global__ __launch_bounds__(kApplyBlock) void k_pods_apply(PodsDev old, const uint32_t* old_pclass, const uint32_t* old_ppair, PodsMut nw, PodDeltaDev d,
                                                            uint32_t G, uint32_t L, uint32_t* gstat_new, uint32_t* gstat_next, QueueDirs q, uint32_t hash_keep,
                                                            uint32_t derive, uint32_t gather_blocks, int32_t tag, int32_t* hinfo, GroupsDev gr, BatchDev bd,
-                                                           GroupPatch gp) {
+                                                           GroupPatch gp, uint32_t* gcount) {
   __shared__ uint4 s_blob[kDeltaLds / 16];
   const uint8_t* s_bytes = reinterpret_cast<const uint8_t*>(s_blob);
   BS_STAMP(0, 0);
@@ -321,7 +321,10 @@ __global__ __launch_bounds__(kApplyBlock) void k_pods_apply(PodsDev old, const u
         nw.cls[pn] = dl.ins.cls[k];
         nw.owner[pn] = own;
         nw.flags[pn] = fl;
-        if (derive) group_minima(gstat_new, G, gi, fl, own, pn);
+        if (derive) {
+          group_minima(gstat_new, G, gi, fl, own, pn);
+          if (gi >= 0 && (uint32_t)gi < G) atomicAdd(&gcount[gi], 1u);   // pods per group: + the inserted ones (here), - the removed ones (gather block 0)
+        }
       }
       if (derive && threadIdx.x < 64) apply_insert_wave(dl, nw, G, L, q, hash_keep);
     }
@@ -346,6 +349,12 @@ __global__ __launch_bounds__(kApplyBlock) void k_pods_apply(PodsDev old, const u
     fv = rebase(d.flag_value, d.blob, s_bytes);
   }
   BS_STAMP(0, 1);
+  if (derive && blockIdx.x == 0) {
+    for (uint32_t k = threadIdx.x; k < d.n_remove; k += kApplyBlock) {
+      const int32_t gq = old.group[rem[k]];
+      if (gq >= 0 && (uint32_t)gq < G) atomicSub(&gcount[gq], 1u);
+    }
+  }
   const uint32_t pn = blockIdx.x * kApplyBlock + threadIdx.x;
   if (pn >= nw.p) { BS_STAMP(0, 7); return; }
   // inserts at positions <= pn; the pod here is an inserted one iff the last of them sits exactly here (the insert block's)

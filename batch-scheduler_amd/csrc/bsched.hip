@@ -168,7 +168,7 @@ struct bs_ctx {
   DevBuf d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_fu_bitmap, d_fu_feas;
   uint32_t slot_keep = 0xFFFFFFFFu;   // BS_HASH_SLOT_BITS (tests): directory probes start at hash & slot_keep
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
-  DevBuf d_fl_bitmap, d_admit, d_ready;
+  DevBuf d_fl_bitmap, d_admit, d_ready, d_gcount, d_admit64;
   // fast path (bs_fast.hpp)
   DevBuf d_order_rank, d_sort;         // queue ordering: per-group order ranks; inputs | index ping-pong | permutation
   uint32_t order_g = 0;
@@ -373,6 +373,8 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.needed = c->d_needed.as<uint32_t>();
   b.qcount = c->d_qcount.as<uint32_t>();
   b.ticket = c->d_ticket.as<uint32_t>();
+  b.gcount = c->d_gcount.as<uint32_t>();
+  b.admit64 = c->d_admit64.as<unsigned long long>();
   b.desc = c->d_desc.as<TableDesc>();
   b.tables = c->d_tables.as<int64_t>();
   b.kp = c->d_kp.as<uint32_t>();
@@ -763,6 +765,10 @@ int derive_pods(bs_ctx* c, bool pairs_only) {
   const uint32_t G = c->G, P = c->P, L = c->L;
   HIPCHK(c, c->d_gstat.reserve((size_t)5 * std::max<uint32_t>(G, 1) * 4 + 16));
   HIPCHK(c, c->d_fast_reject.reserve((size_t)std::max<uint32_t>(G, 1) * 4));
+  HIPCHK(c, c->d_gcount.reserve((size_t)std::max<uint32_t>(G, 1) * 4));
+  HIPCHK(c, c->d_admit64.reserve((size_t)std::max<uint32_t>(G, 1) * 8));
+  uint32_t* gcount = c->d_gcount.as<uint32_t>();
+  const uint32_t gcn = c->have_groups ? G : 0u;                                              // (pods before groups: counted when the groups arrive)
   c->gstat_cur = 0;
   unsigned long long* ctab = c->d_cls_slots.as<unsigned long long>();
   unsigned long long* ptab = ctab + c->cls_cap;                                            // second half: the pair table
@@ -770,20 +776,21 @@ int derive_pods(bs_ctx* c, bool pairs_only) {
   const uint32_t ngstat = c->have_groups ? 5 * G + 1 : 0u;
   if (P) {
     if (pairs_only) {
-      hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, ptab, c->cls_cap, c->d_gstat.as<uint32_t>(), ngstat, (uint32_t*)nullptr);
+      hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, ptab, c->cls_cap, c->d_gstat.as<uint32_t>(), ngstat, (uint32_t*)nullptr, gcount, gcn);
     } else {
-      hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, ctab, 2 * c->cls_cap, c->d_gstat.as<uint32_t>(), ngstat, kcount);
+      hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, ctab, 2 * c->cls_cap, c->d_gstat.as<uint32_t>(), ngstat, kcount, gcount, gcn);
       hipLaunchKernelGGL(k_pod_class_a, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pods_dev(c), ctab, c->cls_cap - 1, c->hash_keep, L,
                          c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(), kcount);
     }
     LAUNCHCHK(c, BS_KERNEL_PREPASS);
-  } else if (!pairs_only) {
-    HIPCHK(c, hipMemsetAsync(kcount, 0, 4, c->stream));
+  } else {
+    if (!pairs_only) HIPCHK(c, hipMemsetAsync(kcount, 0, 4, c->stream));
+    if (gcn) HIPCHK(c, hipMemsetAsync(gcount, 0, (size_t)gcn * 4, c->stream));
   }
   c->kinfo_tag++;
   hipLaunchKernelGGL(k_pod_pairs, dim3(std::max<uint32_t>(1, cdiv(P, 256))), dim3(256), 0, c->stream, pods_dev(c), G, c->d_cls_rep.as<uint32_t>(),
                      c->d_cls_id.as<uint32_t>(), pclass_dev(c), ptab, c->cls_cap - 1, c->hash_keep, c->d_gstat.as<uint32_t>(),
-                     ppair_dev(c), c->d_pair_next.as<unsigned long long>(), kcount, c->kinfo_tag, c->h_info);
+                     ppair_dev(c), c->d_pair_next.as<unsigned long long>(), kcount, c->kinfo_tag, c->h_info, gcount);
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
   c->kinfo_pending = true;
   c->pairs_ready = c->have_groups;
@@ -1624,7 +1631,8 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
     gp.dp = c->pending_dp;
   }
   hipLaunchKernelGGL(k_pods_apply, dim3(gb + 1 + gp.on), dim3(kApplyBlock), 0, c->stream, old, old_pclass, old_ppair, nw, dd, c->G, L, g_new, g_next,
-                     derive ? queue_dirs(c) : QueueDirs{}, c->hash_keep, derive ? 1u : 0u, gb, c->kinfo_tag, c->h_info, grp, gp.on ? batch_dev(c) : BatchDev{}, gp);
+                     derive ? queue_dirs(c) : QueueDirs{}, c->hash_keep, derive ? 1u : 0u, gb, c->kinfo_tag, c->h_info, grp, gp.on ? batch_dev(c) : BatchDev{}, gp,
+                     c->d_gcount.as<uint32_t>());
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
   c->dstage_busy = true;
   c->cur_pack = np;
