@@ -14,7 +14,7 @@ import numpy as np
 from . import fitspec, soa
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbsched.so")
+LIB_PATH = os.path.join(os.environ.get("BS_LIB_DIR") or HERE, "libbsched.so")      # (BS_LIB_DIR: see build.py)
 
 KERNEL_COUNT = 8
 KERNEL_PREPASS, KERNEL_LEADER, KERNEL_QUERY, KERNEL_TABLES, KERNEL_SCAN, KERNEL_RESOLVE, KERNEL_FILTER, KERNEL_TALLY = range(8)

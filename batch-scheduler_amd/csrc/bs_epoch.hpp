@@ -211,9 +211,9 @@ __device__ __forceinline__ void epoch_query_thread(const PodsDev& pods, const Gr
   if (valid) {
     gi = pods.group[i];
     grouped = gi >= 0 && (uint32_t)gi < gr.g;
-    // shard ownership: all pods of a group live on the rank of the group's first pod
+    // shard ownership: all pods of a group live on one rank (owner_rank_of)
     const uint32_t anchor = grouped ? b.first_pod[gi] : i;
-    if ((uint32_t)(((uint64_t)anchor * prm.nranks) / pods.p) == prm.rank) st |= ST_OWNED;
+    if (owner_rank_of(b, prm, anchor, pods.p) == prm.rank) st |= ST_OWNED;
     if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                         // core.go:89-92
     else if (pods.flags[i] & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;      // :95-98
     else if (!grouped) code = BS_PF_ERR_PG_NOT_FOUND;                                      // :100-103

@@ -402,14 +402,15 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
   // ---- round 3
   const bool need_fo = grouped && occ0 == 0 && fo != BS_INF && i > fo;
   const uint64_t occ_fo = need_fo ? pods.owner[fo] : 0ull;
+  const uint32_t owner_rank = valid ? owner_rank_of(b, prm, anchor, pods.p) : 0u;     // (a load only on sharded contexts)
 
   uint8_t code = BS_PF_PASS_NOT_GROUPED, st = 0;
   bool has_q = false;
   Res q;
   res_zero(q, sh);
   if (valid) {
-    // shard ownership: all pods of a group live on the rank of the group's first pod
-    if ((uint32_t)(((uint64_t)anchor * prm.nranks) / pods.p) == prm.rank) st |= ST_OWNED;
+    // shard ownership: all pods of a group live on one rank (owner_rank_of)
+    if (owner_rank == prm.rank) st |= ST_OWNED;
     if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                         // core.go:89-92
     else if (pfl & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;                // :95-98
     else if (!grouped) code = BS_PF_ERR_PG_NOT_FOUND;                                      // :100-103

@@ -146,6 +146,7 @@ struct BatchDev {
   uint32_t pair_stride;           // id space of the pairs (a pair's id is its representative pod at bs_pods_load, a drawn number after bs_pods_apply)
   unsigned long long* first_reach64;  // [blocks of launch A] (~batch_seq << 32) | first pod of the block that reaches findMaxPG
   uint32_t* fast_reject;    // [G] first rejected pod of the group (only maintained for BS_BATCH_COMMIT)
+  const uint32_t* own_start;// [P] sharded contexts only: pods owned before queue position i (see k_owner_starts); owner = own_start[anchor] * nranks / P
   const uint32_t* gcount;   // [G] pods of the group in the resident queue (bs_pods_load / bs_pods_apply keep it): the thread whose add
   unsigned long long* admit64;  // [G] brings (pods seen << 32 | pods admitted) up to gcount closes the group — quorum without a last-block pass
   // BS_BATCH_HOST_RESULTS: mirrors of the results in pinned host memory, written by the last launch (null = off)
@@ -636,6 +637,36 @@ __device__ __forceinline__ void pre_allocated(const GroupsDev& gr, uint32_t g, i
   if (out.v[BS_LANE_PODS] == 0) out.v[BS_LANE_PODS] = mm + 1;
 }
 
+// Pod-axis sharding: which rank evaluates a pod.  Whole groups: the anchor of a grouped pod is its group's first pod in the
+// queue, an ungrouped pod is its own anchor.  Balanced by POD COUNT: walk the queue, give every anchor the weight of what hangs
+// on it (its group's pods, or 1), and cut the running weight into nranks equal shares — own_start[i] = weight before position i
+// (k_owner_starts).  Cutting the queue positions instead (round 2) put nearly every pod of a queue that is not gang-sorted on
+// rank 0: the first pods of all gangs sit early in such a queue.
+__device__ __forceinline__ uint32_t owner_rank_of(const BatchDev& b, const BatchParams& prm, uint32_t anchor, uint32_t P) {
+  if (prm.nranks <= 1u) return 0u;
+  return (uint32_t)(((uint64_t)b.own_start[anchor] * prm.nranks) / P);
+}
+// single block: exclusive prefix over the queue of w(i) = pods of the group whose first pod sits at i | 1 for a pod outside the
+// loaded groups | 0 otherwise
+__global__ __launch_bounds__(kScanBlock) void k_owner_starts(PodsDev pods, uint32_t G, const uint32_t* first_pod, const uint32_t* gcount, uint32_t* own_start) {
+  __shared__ uint32_t lds[kScanBlock / 64];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < pods.p; base += kScanBlock) {
+    const uint32_t i = base + threadIdx.x;
+    uint32_t w = 0;
+    if (i < pods.p) {
+      const int32_t gi = pods.group[i];
+      if (gi >= 0 && (uint32_t)gi < G) w = first_pod[gi] == i ? gcount[gi] : 0u;
+      else w = 1u;
+    }
+    uint32_t total = 0;
+    const uint32_t incl = block_incl_scan_add<uint32_t>(w, lds, total);
+    if (i < pods.p) own_start[i] = carry + incl - w;
+    carry += total;
+    __syncthreads();
+  }
+}
+
 template <int TS>
 __device__ __forceinline__ void filter_params_for(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm,
                                                   uint32_t i, uint8_t pf, int32_t leader, uint32_t slot, bool write_slot, bool write_pod);
@@ -653,11 +684,10 @@ __device__ __forceinline__ void query_thread(const PodsDev& pods, const GroupsDe
   if (valid) {
     st = b.stage[i];
     const int32_t gi = pods.group[i];
-    // shard ownership: all pods of a group live on the rank of the group's first pod
+    // shard ownership: all pods of a group live on one rank (owner_rank_of)
     uint32_t anchor = i;
     if (gi >= 0 && (uint32_t)gi < gr.g) anchor = b.first_pod[gi];
-    const uint32_t owner_rank = (uint32_t)(((uint64_t)anchor * prm.nranks) / pods.p);
-    if (owner_rank == prm.rank) st |= ST_OWNED;
+    if (owner_rank_of(b, prm, anchor, pods.p) == prm.rank) st |= ST_OWNED;
 
     if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                       // core.go:89-92
     else if (pods.flags[i] & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;    // :95-98

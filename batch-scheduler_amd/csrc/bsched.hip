@@ -58,6 +58,9 @@ struct FitArena {
 template <typename T> const T* at_dev(const void* base, size_t off) { return reinterpret_cast<const T*>((const uint8_t*)base + off); }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// element n of a device array that may not exist yet (null + n is undefined behaviour even if nobody follows the pointer)
+template <class T>
+T* at(T* p, size_t n) { return p ? p + n : nullptr; }
 
 // One pod pack = the arrays of bs_pods_soa for exactly `p` pods (the part a load uploads in ONE copy, `in_bytes`) followed by
 // the per-pod ids the library derives (request class, (group, class) pair): what travels with a pod when the queue is patched.
@@ -168,7 +171,8 @@ struct bs_ctx {
   DevBuf d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_fu_bitmap, d_fu_feas;
   uint32_t slot_keep = 0xFFFFFFFFu;   // BS_HASH_SLOT_BITS (tests): directory probes start at hash & slot_keep
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
-  DevBuf d_fl_bitmap, d_admit, d_ready, d_gcount, d_admit64;
+  DevBuf d_fl_bitmap, d_admit, d_ready, d_gcount, d_admit64, d_own_start;
+  bool owner_ready = false;          // own_start[] matches the resident queue and the group count (sharded contexts only)
   // fast path (bs_fast.hpp)
   DevBuf d_order_rank, d_sort;         // queue ordering: per-group order ranks; inputs | index ping-pong | permutation
   uint32_t order_g = 0;
@@ -326,14 +330,14 @@ GroupsDev groups_dev(const bs_ctx* c) {
   GroupsDev g{};
   g.g = c->G;
   uint8_t* pk = c->d_gpack.as<uint8_t>();
-  g.min_member = reinterpret_cast<uint32_t*>(pk + c->off_gmm);
-  g.status_scheduled = reinterpret_cast<uint32_t*>(pk + c->off_gsc);
-  g.matched = reinterpret_cast<uint32_t*>(pk + c->off_gmatched);
-  g.flags = pk + c->off_gflags;
-  g.cls = reinterpret_cast<uint32_t*>(pk + c->off_gcls);
-  g.minres = reinterpret_cast<int64_t*>(pk + c->off_gminres);
-  g.mrpres = reinterpret_cast<uint32_t*>(pk + c->off_gmrpres);
-  g.occupied = reinterpret_cast<uint64_t*>(pk + c->off_gocc);
+  g.min_member = reinterpret_cast<uint32_t*>(at(pk, c->off_gmm));
+  g.status_scheduled = reinterpret_cast<uint32_t*>(at(pk, c->off_gsc));
+  g.matched = reinterpret_cast<uint32_t*>(at(pk, c->off_gmatched));
+  g.flags = at(pk, c->off_gflags);
+  g.cls = reinterpret_cast<uint32_t*>(at(pk, c->off_gcls));
+  g.minres = reinterpret_cast<int64_t*>(at(pk, c->off_gminres));
+  g.mrpres = reinterpret_cast<uint32_t*>(at(pk, c->off_gmrpres));
+  g.occupied = reinterpret_cast<uint64_t*>(at(pk, c->off_gocc));
   return g;
 }
 PodsDev pods_dev(const bs_ctx* c) {
@@ -341,16 +345,16 @@ PodsDev pods_dev(const bs_ctx* c) {
   p.p = c->P;
   uint8_t* pk = c->d_pack[c->cur_pack].as<uint8_t>();
   const PodLayout& l = c->lay[c->cur_pack];
-  p.group = reinterpret_cast<int32_t*>(pk + l.group);
-  p.req = reinterpret_cast<int64_t*>(pk + l.req);
-  p.pres = reinterpret_cast<uint32_t*>(pk + l.pres);
-  p.cls = reinterpret_cast<uint32_t*>(pk + l.cls);
-  p.owner = reinterpret_cast<uint64_t*>(pk + l.owner);
-  p.flags = pk + l.flags;
+  p.group = reinterpret_cast<int32_t*>(at(pk, l.group));
+  p.req = reinterpret_cast<int64_t*>(at(pk, l.req));
+  p.pres = reinterpret_cast<uint32_t*>(at(pk, l.pres));
+  p.cls = reinterpret_cast<uint32_t*>(at(pk, l.cls));
+  p.owner = reinterpret_cast<uint64_t*>(at(pk, l.owner));
+  p.flags = at(pk, l.flags);
   return p;
 }
-uint32_t* pclass_dev(const bs_ctx* c) { return reinterpret_cast<uint32_t*>(c->d_pack[c->cur_pack].as<uint8_t>() + c->lay[c->cur_pack].pclass); }
-uint32_t* ppair_dev(const bs_ctx* c) { return reinterpret_cast<uint32_t*>(c->d_pack[c->cur_pack].as<uint8_t>() + c->lay[c->cur_pack].ppair); }
+uint32_t* pclass_dev(const bs_ctx* c) { uint8_t* p = c->d_pack[c->cur_pack].as<uint8_t>(); return p ? reinterpret_cast<uint32_t*>(p + c->lay[c->cur_pack].pclass) : nullptr; }
+uint32_t* ppair_dev(const bs_ctx* c) { uint8_t* p = c->d_pack[c->cur_pack].as<uint8_t>(); return p ? reinterpret_cast<uint32_t*>(p + c->lay[c->cur_pack].ppair) : nullptr; }
 uint32_t* gstat_dev(const bs_ctx* c) { return (c->gstat_cur ? c->d_gstat2 : c->d_gstat).as<uint32_t>(); }
 BatchDev batch_dev(const bs_ctx* c) {
   BatchDev b{};
@@ -374,6 +378,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.qcount = c->d_qcount.as<uint32_t>();
   b.ticket = c->d_ticket.as<uint32_t>();
   b.gcount = c->d_gcount.as<uint32_t>();
+  b.own_start = c->d_own_start.as<uint32_t>();
   b.admit64 = c->d_admit64.as<unsigned long long>();
   b.desc = c->d_desc.as<TableDesc>();
   b.tables = c->d_tables.as<int64_t>();
@@ -386,7 +391,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.fparams = c->d_fparams.as<int64_t>();
   b.fflags = c->d_fflags.as<uint32_t>();
   b.pclass = pclass_dev(c);
-  b.kclass = c->d_nepochs.as<uint32_t>() + 2;
+  b.kclass = at(c->d_nepochs.as<uint32_t>(), 2);
   b.cls_slots = c->d_cls_slots.as<unsigned long long>();
   b.cls_mask = c->cls_cap ? c->cls_cap - 1 : 0;
   b.qtab_s = c->d_qtab_s.as<int32_t>();
@@ -394,12 +399,12 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.uflags = c->d_uflags.as<uint32_t>();
   b.fu_bitmap = c->d_fu_bitmap.as<uint64_t>();
   // per-slot feasible counts sit right behind the last row of the slot bitmap: one 2-D copy returns rows + counts
-  b.fu_feas = reinterpret_cast<uint32_t*>(c->d_fu_bitmap.as<uint64_t>() + (size_t)cdiv(c->N, 64) * c->filter_slots_cap);
+  b.fu_feas = reinterpret_cast<uint32_t*>(at(c->d_fu_bitmap.as<uint64_t>(), (size_t)cdiv(c->N, 64) * c->filter_slots_cap));
   b.qstamp_s = c->d_qstamp_s.as<uint32_t>();
   b.first_pod_s = gstat_dev(c);
-  b.first_np_s = gstat_dev(c) + (size_t)c->G;
-  b.first_owner_s = gstat_dev(c) + (size_t)2 * c->G;
-  b.pair_head = reinterpret_cast<const unsigned long long*>(c->d_gstat.as<uint32_t>() + (((size_t)3 * c->G + 1) & ~(size_t)1));
+  b.first_np_s = at(gstat_dev(c), (size_t)c->G);
+  b.first_owner_s = at(gstat_dev(c), (size_t)2 * c->G);
+  b.pair_head = reinterpret_cast<const unsigned long long*>(at(c->d_gstat.as<uint32_t>(), ((size_t)3 * c->G + 1) & ~(size_t)1));
   b.ppair = ppair_dev(c);
   b.pair_stride = c->pair_cap;
   b.pair_next = c->d_pair_next.as<unsigned long long>();
@@ -408,15 +413,15 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.fast_reject = c->d_fast_reject.as<uint32_t>();
   b.epoch_group = c->d_epoch_group.as<uint32_t>();
   uint8_t* ok = c->d_outpack.as<uint8_t>();
-  b.pf_code = ok + c->off_pf_code;
-  b.pf_first_k = reinterpret_cast<uint32_t*>(ok + c->off_pf_first_k);
-  b.pf_leader = reinterpret_cast<int32_t*>(ok + c->off_pf_leader);
-  b.fl_code = ok + c->off_fl_code;
-  b.fl_feasible = reinterpret_cast<uint32_t*>(ok + c->off_fl_feasible);
-  b.fu_slot = reinterpret_cast<uint32_t*>(ok + c->off_fl_slot);     // per-pod Filter slot travels with the other per-pod results
+  b.pf_code = at(ok, c->off_pf_code);
+  b.pf_first_k = reinterpret_cast<uint32_t*>(at(ok, c->off_pf_first_k));
+  b.pf_leader = reinterpret_cast<int32_t*>(at(ok, c->off_pf_leader));
+  b.fl_code = at(ok, c->off_fl_code);
+  b.fl_feasible = reinterpret_cast<uint32_t*>(at(ok, c->off_fl_feasible));
+  b.fu_slot = reinterpret_cast<uint32_t*>(at(ok, c->off_fl_slot));     // per-pod Filter slot travels with the other per-pod results
   b.fl_bitmap = c->d_fl_bitmap.as<uint64_t>();
-  b.admit = c->ext_admit ? c->ext_admit : reinterpret_cast<uint32_t*>(ok + c->off_admit);
-  b.ready = ok + c->off_ready;
+  b.admit = c->ext_admit ? c->ext_admit : reinterpret_cast<uint32_t*>(at(ok, c->off_admit));
+  b.ready = at(ok, c->off_ready);
   return b;
 }
 BatchParams batch_params(const bs_ctx* c) {
@@ -794,6 +799,7 @@ int derive_pods(bs_ctx* c, bool pairs_only) {
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
   c->kinfo_pending = true;
   c->pairs_ready = c->have_groups;
+  c->owner_ready = false;
   c->epochs_ready = false;
   c->rep_valid = true;
   c->dirs_ready = false;
@@ -1636,6 +1642,7 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
   c->dstage_busy = true;
   c->cur_pack = np;
+  c->owner_ready = false;
   c->rep_valid = false;                                              // the queue was compacted: pod indices of the derivation are history
   c->epochs_ready = false;
   c->batch_since_pods = false;
@@ -2052,6 +2059,13 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   }
   if ((rc = resolve_groups(c))) return rc;
   if (!c->pairs_ready && (rc = build_pairs(c))) return rc;
+  if (c->nranks > 1 && !c->owner_ready && P) {       // sharded: who owns what (balanced by pod count, whole groups)
+    HIPCHK(c, c->d_own_start.reserve((size_t)P * 4));
+    hipLaunchKernelGGL(k_owner_starts, dim3(1), dim3(kScanBlock), 0, c->stream, pods_dev(c), G, gstat_dev(c), c->d_gcount.as<uint32_t>(),
+                       c->d_own_start.as<uint32_t>());
+    LAUNCHCHK(c, BS_KERNEL_PREPASS);
+    c->owner_ready = true;
+  }
   const uint32_t W = cdiv(N, 64);
   const bool run_filter = stages & BS_STAGE_FILTER;
   if ((rc = reserve_slots(c, run_filter))) return rc;

@@ -465,11 +465,13 @@ int bs_queue_sort(bs_ctx* ctx, uint32_t p, const int32_t* priority, const int32_
                   uint32_t* perm_out);
 
 /* ---- pod-axis sharding (one process per GPU) -------------------------------------- */
-/* Rank `rank` of `nranks` evaluates only the pods it owns: every pod of a group belongs to the rank
- * whose block of the queue ([rank*P/nranks, (rank+1)*P/nranks)) holds the group's FIRST pod; ungrouped
- * pods go by their own index.  Groups never straddle ranks, so the deny replay stays exact and the
- * per-group admit counters of different ranks are disjoint (one all-reduce(sum) merges them).
- * Pods of other ranks report pf_code 0xFF (BS_PF_NOT_OWNED).  The whole batch is loaded on every rank. */
+/* Rank `rank` of `nranks` evaluates only the pods it owns.  Whole groups, balanced by pod count: walking the queue, the
+ * first pod of every group carries the weight of the group's pods (an ungrouped pod carries 1), and the running weight W is
+ * cut into nranks equal shares — a group (or ungrouped pod) whose weight starts at w belongs to rank floor(w * nranks / P).
+ * Groups never straddle ranks, so the deny replay stays exact and the per-group admit counters of different ranks are
+ * disjoint (one all-reduce(sum) merges them); no rank holds more than P / nranks pods plus one group, whatever the queue
+ * order.  Pods of other ranks report pf_code 0xFF (BS_PF_NOT_OWNED).  The whole batch is loaded on every rank.
+ * (batch-scheduler_amd/dist.py owner_ranks is the host mirror of the rule.) */
 #define BS_PF_NOT_OWNED 0xFFu
 int bs_shard_set(bs_ctx* ctx, uint32_t rank, uint32_t nranks);
 /* Device address of the per-group admit counters (uint32[g]) so the caller's collective

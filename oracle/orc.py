@@ -20,10 +20,12 @@ if _ROOT not in sys.path:
 soa = importlib.import_module("batch-scheduler_amd.soa")
 fitspec = importlib.import_module("batch-scheduler_amd.fitspec")
 
-LIB_PATH = os.path.join(_HERE, "libbs_oracle.so")
+LIB_PATH = os.environ.get("BS_ORACLE_LIB") or os.path.join(_HERE, "libbs_oracle.so")     # BS_ORACLE_LIB: a sanitizer build (tests/test_sanitizers.py)
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("BS_ORACLE_LIB"):
+        return LIB_PATH
     src = [os.path.join(_HERE, f) for f in ("bs_oracle.c", "bs_oracle_fit.c", "bs_oracle_seq.c", "bs_oracle.h")] + [os.path.join(_ROOT, "include", "bsched.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     if force or stale:

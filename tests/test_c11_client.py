@@ -1,0 +1,98 @@
+"""The cgo shim's call sequence as a plain C11 program (go/c11_client/shim_client.c) — the closest thing to compiling
+go/pkg/scheduler/core/*.go that an image without a Go toolchain allows.
+
+CPU: include/bsched.h is valid C11 (-std=c11 -Wall -Wextra -Wpedantic -Werror), every entry point the shim binds links against
+libbsched.so.  GPU: the program runs the shim's cycle (newGPUCore, loadSnapshot, loadGroups, runBatch, clusterFits, then a
+patched cycle in latency mode read through bs_batch_map) on a scene file; its results equal the CPU oracle's."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SRC = os.path.join(ROOT, "go", "c11_client", "shim_client.c")
+
+
+def build_client(tmp_path):
+    bsa = importlib.import_module("batch-scheduler_amd")
+    bsa.build.build()
+    libdir = os.path.join(ROOT, "batch-scheduler_amd")
+    exe = str(tmp_path / "shim_client")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Wpedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", exe, SRC,
+                    "-L", libdir, "-lbsched", "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_c11_client_compiles_and_links(tmp_path):
+    exe = build_client(tmp_path)
+    res = subprocess.run([exe], capture_output=True, text=True)           # no arguments: usage, before any device call
+    assert res.returncode == 1 and "usage" in res.stderr
+    # every bs_* symbol the Go files call is one the C client calls too, or is declared in the header the client compiled against
+    header = open(os.path.join(ROOT, "include", "bsched.h")).read()
+    import re
+    go_calls = set()
+    for name in ("bsched_cgo.go", "bsched_batch.go"):
+        go_calls |= set(re.findall(r"C\.(bs_[a-z_0-9]+)\(", open(os.path.join(ROOT, "go", "pkg", "scheduler", "core", name)).read()))
+    assert go_calls, "no cgo calls found"
+    for sym in sorted(go_calls):
+        assert re.search(r"\b%s\(" % sym, header), f"{sym} is called by the Go shim but not declared in include/bsched.h"
+    client_calls = set(re.findall(r"\b(bs_[a-z_0-9]+)\(", open(SRC).read()))
+    missing = {s for s in go_calls if s not in client_calls}
+    assert missing <= {"bs_fit_build", "bs_fit_read", "bs_find_max_pg", "bs_nodes_apply", "bs_filter_one", "bs_last_error", "bs_strerror"}, missing
+
+
+def write_scene(path, nodes, fit, groups, pods):
+    L = nodes.lanes
+    with open(path, "wb") as f:
+        np.array([0x42534331, L, nodes.n, fit.bits.shape[0], groups.g, pods.p, fit.bits.shape[1]], np.uint32).tofile(f)
+        for a, dt in ((nodes.allocatable, np.int64), (nodes.requested, np.int64), (nodes.allocatable_present, np.uint32),
+                      (nodes.requested_present, np.uint32), (nodes.flags, np.uint8), (fit.bits, np.uint32),
+                      (groups.min_member, np.uint32), (groups.status_scheduled, np.uint32), (groups.matched, np.uint32), (groups.flags, np.uint8),
+                      (groups.cls, np.uint32), (groups.min_resources, np.int64), (groups.min_resources_present, np.uint32), (groups.occupied_by, np.uint64),
+                      (pods.group, np.int32), (pods.req, np.int64), (pods.req_present, np.uint32), (pods.cls, np.uint32), (pods.owner, np.uint64),
+                      (pods.flags, np.uint8)):
+            np.ascontiguousarray(a, dtype=dt).tofile(f)
+
+
+def read_cycle(buf, off, P, G):
+    out = {}
+    for name, dt, n in (("pf_code", np.uint8, P), ("pf_first_k", np.uint32, P), ("pf_leader", np.int32, P), ("fl_code", np.uint8, P),
+                        ("fl_feasible", np.uint32, P), ("group_admit", np.uint32, G), ("group_ready", np.uint8, G)):
+        nb = n * np.dtype(dt).itemsize
+        out[name] = np.frombuffer(buf[off:off + nb], dt)
+        off += nb
+    return out, off
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,scenario", [("cfg2", "tail"), ("cfg2", "cold"), ("tiny", "warm")])
+def test_c11_client_runs_the_shim_cycle(config, scenario, tmp_path, bsa, soa, orc):
+    exe = build_client(tmp_path)
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
+    scene, result = str(tmp_path / "scene.bin"), str(tmp_path / "result.bin")
+    write_scene(scene, nodes, fit, groups, pods)
+    res = subprocess.run([exe, scene, result], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    buf = open(result, "rb").read()
+    snap = orc.Snapshot(nodes, fit)
+    exp1 = orc.Sop(snap, groups).batch(pods, soa.STAGE_ALL)
+    got1, off = read_cycle(buf, 0, pods.p, groups.g)
+    for k, v in got1.items():
+        assert np.array_equal(v, getattr(exp1, k)), f"cycle 1: {k}"
+    # cycle 2: pods 0..2 left the queue, clones of pods 3..5 were appended
+    nmove = 3 if pods.p >= 6 else 0
+    pods2 = pods.patched(remove=np.arange(nmove, dtype=np.uint32), insert=pods.take(np.arange(3, 3 + nmove)), insert_at=None) if nmove else pods
+    exp2 = orc.Sop(snap, groups).batch(pods2, soa.STAGE_ALL)
+    got2, off = read_cycle(buf, off, pods.p, groups.g)
+    for k, v in got2.items():
+        assert np.array_equal(v, getattr(exp2, k)), f"cycle 2: {k}"
+    nq = min(pods.p, 8)
+    fits = np.frombuffer(buf[off:off + nq], np.uint8)
+    fk = np.frombuffer(buf[off + nq:off + nq + 4 * nq], np.uint32)
+    for i in range(nq):
+        ok, k = snap.compare_cluster(int(pods.cls[i]), pods.req[:, i], int(pods.req_present[i]), 1.0)[:2]
+        assert bool(fits[i]) == bool(ok) and (not ok or int(fk[i]) == int(k)), f"clusterFits pod {i}"

@@ -97,6 +97,23 @@ def test_owner_ranks_partition(bsa):
         assert counts.min() > 0.5 * pods.p / nranks
 
 
+def test_owner_ranks_balance_on_any_queue_order(bsa):
+    """Ownership is balanced by pod count: max / mean <= 1.2 on the cfg4 queue — gang-sorted as generated, shuffled (every
+    gang's first pod early in the queue: cutting queue positions gave rank 0 nearly everything) and reversed — groups intact."""
+    dist = importlib.import_module("batch-scheduler_amd.dist")
+    _, _, groups, pods, _ = bsa.synth.make("cfg4", "tail")
+    rng = np.random.default_rng(4)
+    for order in (np.arange(pods.p), rng.permutation(pods.p), np.arange(pods.p)[::-1]):
+        g = pods.group[order]
+        for nranks in (2, 4, 8):
+            own = dist.owner_ranks(g, groups.g, nranks)
+            counts = np.bincount(own, minlength=nranks)
+            assert counts.max() / counts.mean() <= 1.2, (nranks, counts)
+            first = np.full(groups.g, -1)
+            first[g[::-1][g[::-1] >= 0]] = own[::-1][g[::-1] >= 0]          # owner of each group's first pod
+            assert np.array_equal(own[g >= 0], first[g[g >= 0]]), "a group never straddles ranks"
+
+
 WORKER = r'''
 import importlib, os, sys
 import numpy as np, torch, torch.distributed as dist

@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage: tools/build_sanitized.sh [outdir=tools/ubench/san]
+# Host-side hardening builds (never the shipped libraries; same file names in their own directory so that $ORIGIN pairs them):
+#   libbsched.so       host code of csrc/bsched.hip with UBSAN in trap mode (no runtime needed: UB = SIGILL) + _GLIBCXX_ASSERTIONS
+#                      (bounds-checked std::vector / std::string); device code unchanged
+#   libbsched_host.so  host/bs_host.cpp + bs_drain.cpp with gcc's UBSAN, no recovery
+# Run the GPU suite against them with  BS_LIB_DIR=<outdir> python -m pytest tests -m gpu  (tools/r03_san.sh does, on the GPU box).
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${1:-$ROOT/tools/ubench/san}
+mkdir -p "$OUT"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
+  -Xarch_host -fsanitize=undefined -Xarch_host -fsanitize-trap=undefined -D_GLIBCXX_ASSERTIONS \
+  -o "$OUT/libbsched.so" "$ROOT/batch-scheduler_amd/csrc/bsched.hip" -ldl
+g++ -O1 -g -std=c++17 -fPIC -shared -Wall -fsanitize=undefined -fno-sanitize-recover=all -D_GLIBCXX_ASSERTIONS \
+  -o "$OUT/libbsched_host.so" "$ROOT/batch-scheduler_amd/host/bs_host.cpp" "$ROOT/batch-scheduler_amd/host/bs_drain.cpp" \
+  -L"$OUT" -lbsched -Wl,-rpath,'$ORIGIN'
+ls -la "$OUT"

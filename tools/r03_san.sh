@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage (GPU box): bash tools/r03_san.sh <tag> — the whole GPU suite against the hardening builds of tools/build_sanitized.sh
+# (host code: UBSAN + bounds-checked containers; UB = SIGILL / abort = a failed run)
+TAG=${1:-san}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+export BS_SKIP_SLOW_LIVE=1
+BS_LIB_DIR=$GRAFT_REPO_ROOT/tools/ubench/san UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $OUT/pytest_gpu_sanitized.log 2>&1
+echo "rc $?" >> $OUT/pytest_gpu_sanitized.log
+tail -5 $OUT/pytest_gpu_sanitized.log
