@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr,
     for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
   }
   const bool grouped = i < pods.p && gi >= 0 && (uint32_t)gi < gr.g;
-  tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi : 0u, admit);
+  tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi : 0u, admit, gridDim.x);
 }
 
 }  // namespace bs

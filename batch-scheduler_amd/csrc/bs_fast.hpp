@@ -1,4 +1,4 @@
-// bs_fast.hpp — the steady-state batch in THREE launches.
+// bs_fast.hpp — the steady-state batch in TWO launches (three dependency levels; the last two share a launch).
 //
 // Steady state = every group already has its pod and its MinResources (nothing a pod derives can depend on
 // its queue position: request classes stand for the pods) and the leader findMaxPG returns has matched pods
@@ -26,11 +26,12 @@
 //   * Filter's answer per (pod, node) is a bit of the pod's slot row; the pods x nodes bitmap is not
 //     materialised (k_filter_expand runs only when a caller asks for it).
 //
-//   launch A  k_fast_query_tables   per pod: decisions that need no scan, its scan query and Filter
-//                                   parameters into the class slots | chunk-local running sums of the table
-//   launch B  k_fast_scan_filter    node scan per scan slot | computeResourceSatisfied per Filter slot x node
-//   launch C  k_fast_final          REJECT / deny replay / stale leader, Filter code + slot + feasible count
-//                                   per pod, per-group admit counts, last block: quorum predicate core.go:303
+//   launch A    k_fast_query_tables        per pod: decisions that need no scan, its scan query and Filter parameters into
+//                                          the class slots | chunk-local running sums of the table
+//   launch B+C  k_fast_scan_filter_final   producer blocks: node scan per scan slot | computeResourceSatisfied per Filter
+//                                          slot x node; final blocks (same launch, handed the producers' count): REJECT / deny
+//                                          replay / stale leader, Filter code + slot + feasible count per pod, per-group admit
+//                                          counts and the quorum predicate core.go:303 (the lane that completes a group)
 #pragma once
 
 #include "bs_kernels.hpp"
@@ -376,7 +377,7 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
   // ---- round 1
   const int32_t leader0 = b.leader_epoch[0];
   const uint8_t panic0 = b.panic_epoch[0];
-  const uint32_t K = prm.run_filter ? *b.kclass : 0u;
+  const uint32_t K = prm.run_filter ? (prm.k_host ? prm.k_host : *b.kclass) : 0u;
   const int32_t gi = pods.p ? pods.group[ii] : BS_POD_NOT_GROUPED;
   const uint8_t pfl = pods.p ? pods.flags[ii] : (uint8_t)0;
   const uint64_t own = pods.p ? pods.owner[ii] : 0ull;
@@ -505,23 +506,6 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_query_tables(PodsDev pods, G
 }
 
 // ------------------------------------------------------------------------------------------------
-// launch B: node scan over the class slots of this batch (chunk-local table + offsets) and Filter
-// evaluation over the Filter slots of this batch.  `bt` = the batch view with the table arrays shifted to
-// the steady table's slot.
-// ------------------------------------------------------------------------------------------------
-template <int S>
-__global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap,
-                                                          uint32_t scan_blocks, uint32_t filter_waves, uint32_t ustride) {
-  __shared__ int64_t s_rows[4][64][4 + S];
-  BS_STAMP(2, 0);
-  if (blockIdx.x < scan_blocks)
-    scan_loop<S, true>(bt, prm, m, jcap, 0u, 0u, 1u, blockIdx.x, scan_blocks, s_rows[wave_id()]);
-  else
-    filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - scan_blocks, gridDim.x - scan_blocks, prm.stamp);
-  BS_STAMP(2, 7);
-}
-
-// ------------------------------------------------------------------------------------------------
 // The common ends of a three-launch batch (k_fast_final, k_epoch_final; 256 threads per block).
 //   arm_tally    (launch A) zero the per-group counters of this batch; groups without a pod in the queue get their quorum
 //                answer right away (nobody will come by to close them)
@@ -533,6 +517,7 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev
 //   final_tail   latency mode only: the LAST block to get here publishes the completion word the host polls.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i, uint32_t nthreads) {
+  if (i == 0) __hip_atomic_store(&b.ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // hand-over counter of the fused scan / final launch
   for (uint32_t g = i; g < gr.g; g += nthreads) {
     b.admit[g] = 0;
     if (prm.do_ready) {
@@ -546,14 +531,14 @@ __device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b
   }
 }
 
-__device__ __forceinline__ void final_tail(const BatchDev& b, const BatchParams& prm) {
+__device__ __forceinline__ void final_tail(const BatchDev& b, const BatchParams& prm, uint32_t nblocks) {
   __shared__ uint32_t s_last;
   if (!prm.host_tag) return;
   // every block drains its writes (host mirrors included) before it takes its ticket; the last one sends the completion
   // word behind them with a system-scope store — the host polls it (bs_batch_read / bs_batch_map) instead of waiting on the stream
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1 ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
   if (threadIdx.x == 0) {
@@ -563,7 +548,8 @@ __device__ __forceinline__ void final_tail(const BatchDev& b, const BatchParams&
 }
 
 // grouped: the pod names a group of the loaded state (g valid); admit: it passes PreFilter and, if Filter ran, has a feasible node
-__device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, bool grouped, uint32_t g, bool admit) {
+__device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, bool grouped, uint32_t g, bool admit,
+                                           uint32_t nblocks) {
   if (prm.do_tally && prm.do_ready) {
     // what closing a group needs, fetched while the adds are in flight (the lane's own group: the leader of a key is one of its lanes)
     uint32_t want = 0, ma = 0, mm = 0, sc = 0;
@@ -603,7 +589,7 @@ __device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& 
   } else if (prm.do_tally) {
     wave_aggregated_add(b.admit, g, grouped && admit);
   }
-  final_tail(b, prm);
+  final_tail(b, prm, nblocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -615,17 +601,24 @@ __device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& 
 //   Filter        code, slot and feasible-node count of the pod from its class slot
 //   Permit        per-group admit counts; last block: quorum predicate core.go:303
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
+// what launch B left behind, read by a block of the SAME launch: performed at the coherence point (its writers used agent-scope
+// atomics), not looked up in this XCD's L2
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// block `bx` of `nblocks` final blocks; producers > 0: they run in this very launch (k_fast_scan_filter_final) and count themselves
+// into ticket[1] when their results are out — everything that does not depend on them is fetched first
+__device__ __forceinline__ void fast_final_block(const PodsDev& pods, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchParams& prm,
+                                                 uint32_t query_blocks, uint32_t bx, uint32_t nblocks, uint32_t producers) {
   __shared__ uint32_t s_first_reach;
   BS_STAMP(3, 0);
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t i = bx * 256u + threadIdx.x;
   const bool valid = i < pods.p;
   // ---- round trip 1: the pod's own fields, and the block's look at the first reaching pod
   uint8_t code0 = 0, st0 = 0;
   int32_t gi0 = BS_POD_NOT_GROUPED;
   uint32_t qpos0 = 0, pclass0 = 0, pair0 = BS_INF;
   if (valid) { code0 = b.tcode[i]; st0 = b.stage[i]; gi0 = pods.group[i]; qpos0 = b.qpos[i]; pclass0 = b.pclass[i]; pair0 = b.ppair[i]; }
-  const uint32_t K = *b.kclass;
+  const uint32_t K = prm.k_host ? prm.k_host : *b.kclass;
   const int32_t leader_now = b.leader_epoch[0];
   // first pod that reaches findMaxPG = the candidate of the first block of launch A that has one (64 blocks per look)
   if (threadIdx.x < 64) {
@@ -642,24 +635,29 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
     }
     if (threadIdx.x == 0) s_first_reach = found;
   }
-  // ---- round trip 2, issued before the barrier: everything whose address the pod's own fields give —
-  //   its scan slot's result, both Filter slots' feasible counts, the head of its group's pair chain, its OWN pair's
-  //   first querying pod and next link (a group with ONE request class — nearly every gang — needs nothing else for the
-  //   deny replay: the pair's class slot is the pod's own)
+  // ---- round trip 2a (still nothing of launch B): the head of the group's pair chain, the pod's OWN pair's first querying pod
+  //   and next link (a group with ONE request class — nearly every gang — needs nothing else for the deny replay: the pair's
+  //   class slot is the pod's own)
   const bool owned = valid && (st0 & ST_OWNED);
   const bool walk = owned && (st0 & ST_ELIG);
   const bool grouped = valid && gi0 >= 0 && (uint32_t)gi0 < gr.g;
   uint32_t row_q = BS_INF, row_c = BS_INF, feas0 = 0, feas1 = 0;
   unsigned long long head = ~0ull, own_fq = ~0ull, own_next = ~0ull;
-  if (owned && (st0 & ST_QUERY)) row_q = b.first_row[qpos0];
   if (walk) {
     head = b.pair_head[gi0];
-    row_c = b.first_row[pclass0];
     if (pair0 != BS_INF) { own_fq = b.pair_firstq[pair0]; own_next = b.pair_next[pair0]; }
   }
-  if (valid && prm.run_filter && grouped) { feas0 = b.fu_feas[pclass0]; feas1 = b.fu_feas[pclass0 + K]; }
+  if (producers) {                                   // the scan / Filter blocks of this launch have to be through
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (our own loads first: they overlap the producers, not the wait)
+    if (threadIdx.x == 0)
+      while (ld_agent(&b.ticket[1]) < producers) __builtin_amdgcn_s_sleep(1);
+  }
   __syncthreads();
   BS_STAMP(3, 1);
+  // ---- round trip 2b: the pod's scan slot's result, both Filter slots' feasible counts
+  if (owned && (st0 & ST_QUERY)) row_q = ld_agent(&b.first_row[qpos0]);
+  if (walk) row_c = ld_agent(&b.first_row[pclass0]);
+  if (valid && prm.run_filter && grouped) { feas0 = ld_agent(&b.fu_feas[pclass0]); feas1 = ld_agent(&b.fu_feas[pclass0 + K]); }
   bool admit = false;
   if (valid) {
     uint8_t code = code0;
@@ -678,7 +676,7 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
           for (unsigned long long link = head; (uint32_t)link != BS_INF;) {
             const uint32_t r = (uint32_t)link, cls = (uint32_t)(link >> 32);
             const unsigned long long pq = b.pair_firstq[r];              // } one round trip: the pair's first querying pod,
-            const uint32_t row = b.first_row[cls];                       // } its class slot's scan result,
+            const uint32_t row = ld_agent(&b.first_row[cls]);            // } its class slot's scan result,
             link = b.pair_next[r];                                       // } the next link
             if ((uint32_t)(pq >> 32) != prm.seq_inv) continue;           // no pod of the pair had a query in this batch
             const uint32_t fq = (uint32_t)pq;
@@ -726,12 +724,41 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
   }
   if (prm.host_tag && prm.run_filter) {             // per-row feasible counts of the slots in use
     const uint32_t U = min(2u * K, b.hstride);
-    for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
+    for (uint32_t k = i; k < U; k += nblocks * 256u) b.h_feas[k] = ld_agent(&b.fu_feas[k]);
   }
   BS_STAMP(3, 2);
-  tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi0 : 0u, admit);
+  tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi0 : 0u, admit, nblocks);
   BS_STAMP(3, 7);
 }
+
+// ------------------------------------------------------------------------------------------------
+// launches B and C as ONE launch: [0, scan_blocks) node scan | [.., + filter_blocks) Filter evaluation | the rest: final
+// blocks.  Blocks are handed out in index order, so every producer has started before a final block does; a final block
+// fetches what it needs from launch A while the producers run, then waits for their count.  One launch boundary (~1.5 us)
+// and the final blocks' first round trips (~2 us) come off the step's critical path.
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void k_fast_scan_filter_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm, uint32_t m,
+                                                                uint32_t jcap, uint32_t scan_blocks, uint32_t filter_blocks, uint32_t filter_waves,
+                                                                uint32_t ustride, uint32_t query_blocks) {
+  __shared__ int64_t s_rows[4][64][4 + S];
+  const uint32_t producers = scan_blocks + filter_blocks;
+  if (blockIdx.x < producers) {
+    BS_STAMP(2, 0);
+    if (blockIdx.x < scan_blocks)
+      scan_loop<S, true>(bt, prm, m, jcap, 0u, 0u, 1u, blockIdx.x, scan_blocks, s_rows[wave_id()]);
+    else
+      filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - scan_blocks, filter_blocks, prm.stamp, 2u * prm.k_host);
+    // results out (atomics performed, row stores drained), then count this block in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    BS_STAMP(2, 7);
+    return;
+  }
+  fast_final_block(pods, gr, nd, b, prm, query_blocks, blockIdx.x - producers, gridDim.x - producers, producers);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // General chain, tables without the fix-up pass: block (table, chunk) of every table some query of the batch uses builds

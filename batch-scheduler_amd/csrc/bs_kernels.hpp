@@ -182,6 +182,7 @@ struct BatchParams {
   uint32_t commit;             // fast path: keep fast_reject for k_fast_commit
   uint32_t do_tally, do_ready; // fast path: stages of the final launch
   int32_t host_tag;            // BS_BATCH_HOST_RESULTS: completion word the final launch publishes (0 = off)
+  uint32_t k_host;             // request classes, when the host already knows the count (0: read *kclass — a dependent load in front of the first round trip)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1143,45 +1144,67 @@ struct LocalPre {
   int64_t gm[2][4 + S];          // per-group local maxima of groups lane and 64 + lane (the first 8192 rows): fetched with everything
                                  // else a wave needs before it can look at a row, instead of one round trip later
 };
+// raw pieces of LocalPre as they come from memory: lane l <-> chunk l (totals, first key rows) and groups l, 64 + l (maxima)
 template <int S>
-__device__ __forceinline__ void local_pre_load(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, LocalPre<S>& pre) {
+struct LocalRaw {
+  unsigned long long v[4 + S];
+  uint32_t kv[S > 0 ? S : 1];
+  int64_t gm[2][4 + S];
+};
+template <int S>
+__device__ __forceinline__ void local_fetch_chunks(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, LocalRaw<S>& raw) {
+  constexpr int L = 4 + S;
+  const uint32_t nchunks = (m + kTblChunk - 1u) / kTblChunk, cstride = (prm.mcap + kTblChunk - 1u) / kTblChunk;
+  const uint32_t ch = (uint32_t)lane_id();
+  const unsigned long long* ct = b.chunk_tot + ((size_t)slot * cstride + ch) * 16;
+#pragma unroll
+  for (int j = 0; j < L; ++j) raw.v[j] = ch < nchunks ? ct[j] : 0ull;
+#pragma unroll
+  for (int s = 0; s < S; ++s) raw.kv[s] = ch < nchunks ? b.chunk_kp[((size_t)slot * cstride + ch) * 16 + s] : BS_INF;
+}
+template <int S>
+__device__ __forceinline__ void local_fetch_gmax(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, int w, int64_t (&gm)[4 + S]) {
+  constexpr int L = 4 + S;
+  constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
+  const uint32_t ngroups = (m + 63u) >> 6, gstride = (prm.mcap + 63u) >> 6;
+  const uint32_t g = (uint32_t)w * 64u + (uint32_t)lane_id();
+  const int64_t* src = b.gmax + ((size_t)slot * gstride + min(g, ngroups ? ngroups - 1u : 0u)) * LP;
+#pragma unroll
+  for (int j = 0; j < L; ++j) gm[j] = src[j];
+}
+// wave scans over what was fetched: chunk offsets, carry, first key rows
+template <int S>
+__device__ __forceinline__ void local_pre_finish(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, const LocalRaw<S>& raw, LocalPre<S>& pre) {
   constexpr int L = 4 + S;
   const int lane = lane_id();
   const uint32_t nchunks = (m + kTblChunk - 1u) / kTblChunk, cstride = (prm.mcap + kTblChunk - 1u) / kTblChunk;
-  const uint32_t ch = (uint32_t)lane;
-  const unsigned long long* ct = b.chunk_tot + ((size_t)slot * cstride + ch) * 16;
-  unsigned long long v[L];
 #pragma unroll
-  for (int j = 0; j < L; ++j) v[j] = ch < nchunks ? ct[j] : 0ull;
-  uint32_t kv[S > 0 ? S : 1];
+  for (int w = 0; w < 2; ++w)
 #pragma unroll
-  for (int s = 0; s < S; ++s) kv[s] = ch < nchunks ? b.chunk_kp[((size_t)slot * cstride + ch) * 16 + s] : BS_INF;
-  {
-    constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
-    const uint32_t ngroups = (m + 63u) >> 6, gstride = (prm.mcap + 63u) >> 6;
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-      const uint32_t g = (uint32_t)w * 64u + (uint32_t)lane;
-      const int64_t* gm = b.gmax + ((size_t)slot * gstride + min(g, ngroups ? ngroups - 1u : 0u)) * LP;
-#pragma unroll
-      for (int j = 0; j < L; ++j) pre.gm[w][j] = gm[j];
-    }
-  }
+    for (int j = 0; j < L; ++j) pre.gm[w][j] = raw.gm[w][j];
 #pragma unroll
   for (int j = 0; j < L; ++j) {
-    const unsigned long long incl = wave_incl_scan_add_u64(v[j]);
-    pre.offl[j] = incl - v[j];
+    const unsigned long long incl = wave_incl_scan_add_u64(raw.v[j]);
+    pre.offl[j] = incl - raw.v[j];
     pre.carry[j] = (unsigned long long)readlane63_i64((long long)incl);
   }
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    uint32_t mn = wave_min_u32(kv[s]);
+    uint32_t mn = wave_min_u32(raw.kv[s]);
     for (uint32_t w0 = 64u; w0 < nchunks; w0 += 64u) {          // tables beyond 16 384 rows: the remaining chunks' key rows
       const uint32_t c2 = w0 + (uint32_t)lane;
       mn = min(mn, wave_min_u32(c2 < nchunks ? b.chunk_kp[((size_t)slot * cstride + c2) * 16 + s] : BS_INF));
     }
     pre.kp[s] = __builtin_amdgcn_readfirstlane(mn);               // wave-uniform by construction: keep it scalar (it cuts row pieces)
   }
+}
+template <int S>
+__device__ __forceinline__ void local_pre_load(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, LocalPre<S>& pre) {
+  LocalRaw<S> raw;
+  local_fetch_chunks<S>(b, prm, m, slot, raw);
+  local_fetch_gmax<S>(b, prm, m, slot, 0, raw.gm[0]);
+  local_fetch_gmax<S>(b, prm, m, slot, 1, raw.gm[1]);
+  local_pre_finish<S>(b, prm, m, slot, raw, pre);
 }
 
 template <int S, bool LOCAL = false>
@@ -1380,7 +1403,7 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
   // slots: [request classes | groups] or [pods | groups] (the group slots carry the first checks, core.go:136-147)
-  const uint32_t nslots = (prm.use_classes ? __builtin_amdgcn_readfirstlane(*b.kclass) : nslots_fixed) + ngroups_g;
+  const uint32_t nslots = (prm.use_classes ? (prm.k_host ? prm.k_host : __builtin_amdgcn_readfirstlane(*b.kclass)) : nslots_fixed) + ngroups_g;
   const uint32_t ntiles = (nslots + 63u) >> 6;
   if (!ntiles || !m) return;
   // tiles that can hold a query: all of them with request classes; otherwise the per-pod slots only if some pod has a query
@@ -1403,26 +1426,81 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
   const uint32_t items = ntl * tsplit * J;
   const int lane = lane_id();
   const uint32_t w_first = __builtin_amdgcn_readfirstlane(uni ? bx : bx * 4u + (uint32_t)wave_id());
-  // ... and derive the table's offsets / key rows / first pruning bounds once per wave, now
+  // table, stamp, request and flags of a tile's slots in ONE round trip (a dead slot's request is loaded for nothing)
+  struct SlotLoad { int32_t tab; uint32_t stp, qf; int64_t r[L]; };
+  auto load_slots = [&](uint32_t w, SlotLoad& sl) {
+    const uint32_t rest = w / ntl, tile = t_lo + (w - rest * ntl);
+    const uint32_t ps = min(tile * 64u + (uint32_t)lane, nslots - 1u);
+    sl.tab = b.qtab_s[ps];
+    sl.stp = prm.stamp ? b.qstamp_s[ps] : 0u;
+    const int64_t* src = b.qreq_s + (size_t)ps * LP;
+#pragma unroll
+    for (int j = 0; j < L; ++j) sl.r[j] = src[j];
+    sl.qf = b.qflags_s[ps];
+  };
+  // the first item's slots are asked for BEFORE the table's offsets / key rows / first pruning bounds are derived (once per
+  // wave: loads, then wave scans that wait for them): one round trip for both, not two in a row
+  SlotLoad first;
   LocalPre<S> pre;
   if constexpr (LOCAL) {
-    if (uni && w_first < items) local_pre_load<S>(b, prm, m, 0u, pre);
+    if (uni) {
+      // The four waves of the block work on ONE item and need the SAME first fetch (the tile's slots, the table's chunk
+      // totals / key rows, the maxima of its first 128 groups): 64 lanes x 64-byte strides, ~900 cache lines per wave — four
+      // waves asking for all of it keep this CU's L1 busy for longer than the memory latency.  Each wave fetches a quarter,
+      // leaves it in LDS, everybody reads it back.
+      if (w_first < items) {                                    // (block-uniform: w_first = block index)
+        __shared__ int64_t sh_req[64][L];
+        __shared__ uint32_t sh_meta[3][64];
+        __shared__ int64_t sh_gm[2][64][L];
+        __shared__ unsigned long long sh_ct[64][L];
+        __shared__ uint32_t sh_kv[S > 0 ? S : 1][64];
+        const int wv = wave_id();
+        if (wv == 0) {
+          SlotLoad sl;
+          load_slots(w_first, sl);
+          sh_meta[0][lane] = (uint32_t)sl.tab; sh_meta[1][lane] = sl.stp; sh_meta[2][lane] = sl.qf;
+#pragma unroll
+          for (int j = 0; j < L; ++j) sh_req[lane][j] = sl.r[j];
+        } else if (wv == 3) {
+          LocalRaw<S> raw;
+          local_fetch_chunks<S>(b, prm, m, 0u, raw);
+#pragma unroll
+          for (int j = 0; j < L; ++j) sh_ct[lane][j] = raw.v[j];
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) sh_kv[s2][lane] = raw.kv[s2];
+        } else {
+          int64_t gm[L];
+          local_fetch_gmax<S>(b, prm, m, 0u, wv - 1, gm);
+#pragma unroll
+          for (int j = 0; j < L; ++j) sh_gm[wv - 1][lane][j] = gm[j];
+        }
+        __syncthreads();
+        first.tab = (int32_t)sh_meta[0][lane]; first.stp = sh_meta[1][lane]; first.qf = sh_meta[2][lane];
+        LocalRaw<S> raw;
+#pragma unroll
+        for (int j = 0; j < L; ++j) { first.r[j] = sh_req[lane][j]; raw.v[j] = sh_ct[lane][j]; raw.gm[0][j] = sh_gm[0][lane][j]; raw.gm[1][j] = sh_gm[1][lane][j]; }
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) raw.kv[s2] = sh_kv[s2][lane];
+        local_pre_finish<S>(b, prm, m, 0u, raw, pre);
+      }
+    } else if (w_first < items) {
+      load_slots(w_first, first);
+    }
+  } else if (w_first < items) {
+    load_slots(w_first, first);
   }
   for (uint32_t w = w_first; w < items; w += nblocks * wpb) {
     const uint32_t rest = w / ntl, tile = t_lo + (w - rest * ntl);
     const uint32_t share = rest / tsplit, ts = rest - share * tsplit;
     const uint32_t pos = tile * 64u + (uint32_t)lane;
-    // table, stamp, request and flags of the slot in ONE round trip (a dead slot's request is loaded for nothing)
-    const uint32_t ps = min(pos, nslots - 1u);
-    int32_t tab = b.qtab_s[ps];
-    const uint32_t stp = prm.stamp ? b.qstamp_s[ps] : 0u;
+    SlotLoad cur;
+    if (w == w_first) cur = first; else load_slots(w, cur);
+    int32_t tab = cur.tab;
+    const uint32_t stp = cur.stp;
     int64_t r[1][L];
-    {
-      const int64_t* src = b.qreq_s + (size_t)ps * LP;
 #pragma unroll
-      for (int j = 0; j < L; ++j) r[0][j] = src[j];
-    }
-    uint32_t qf = b.qflags_s[ps];
+    for (int j = 0; j < L; ++j) r[0][j] = cur.r[j];
+    uint32_t qf = cur.qf;
     if (pos >= nslots || stp != prm.stamp) tab = -1;   // fast path: a slot is live iff a pod of THIS batch wrote it (stamp 0: every slot the pre-pass left >= 0)
     unsigned long long todo = __ballot(tab >= 0);
     BS_STAMP(2, 1);

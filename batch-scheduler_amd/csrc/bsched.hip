@@ -611,27 +611,27 @@ void launch_tables_nofix(bs_ctx* c, dim3 grid, const NodesDev& nd, const BatchDe
 }
 
 template <int S>
-static void launch_fast_b_s(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg,
-                            uint32_t scan_blocks) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter<S>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->M, nseg, scan_blocks, c->filter_waves,
-                     c->filter_slots_cap);
+static void launch_fast_bc_s(bs_ctx* c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
+                             const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks, uint32_t filter_blocks) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter_final<S>), grid, dim3(256), 0, c->stream, pd, gr, nd, b, bt, prm, c->M, nseg, scan_blocks, filter_blocks,
+                     c->filter_waves, c->filter_slots_cap, cdiv(c->P, kTblChunk));
 }
-static void launch_fast_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg,
-                          uint32_t scan_blocks) {
+static void launch_fast_bc(bs_ctx* c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
+                           const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks, uint32_t filter_blocks) {
   switch (c->S) {
-    case 0: launch_fast_b_s<0>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 1: launch_fast_b_s<1>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 2: launch_fast_b_s<2>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 3: launch_fast_b_s<3>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 4: launch_fast_b_s<4>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 5: launch_fast_b_s<5>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 6: launch_fast_b_s<6>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 7: launch_fast_b_s<7>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 8: launch_fast_b_s<8>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 9: launch_fast_b_s<9>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 10: launch_fast_b_s<10>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 11: launch_fast_b_s<11>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    default: launch_fast_b_s<12>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 0: launch_fast_bc_s<0>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 1: launch_fast_bc_s<1>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 2: launch_fast_bc_s<2>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 3: launch_fast_bc_s<3>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 4: launch_fast_bc_s<4>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 5: launch_fast_bc_s<5>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 6: launch_fast_bc_s<6>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 7: launch_fast_bc_s<7>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 8: launch_fast_bc_s<8>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 9: launch_fast_bc_s<9>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 10: launch_fast_bc_s<10>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    case 11: launch_fast_bc_s<11>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
+    default: launch_fast_bc_s<12>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
   }
 }
 
@@ -644,9 +644,11 @@ void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const NodesDev&
                      c->filter_slots_cap, c->collect_stats);
 }
 
-// Cap on the waves that share the live 64-row groups of one tile pair (k_scan picks the actual share
-// from the number of tiles it finds).
-uint32_t pick_scan_share(const bs_ctx* c) { return c->scan_share_override ? c->scan_share_override : 64u; }
+// Cap on the shares (blocks of four waves, a quarter of every group's rows each) that deal the live 64-row groups of one tile
+// of class slots among themselves.  Measured (tools/share_sweep.sh, cfg3, step in us at 8 / 16 / 32 / 64 shares): tail 23.7 / 24.2 /
+// 23.8 / 24.2, busy 23.3 / 23.4 / 23.7 / 23.8, warm 23.5 / 24.2 / 27.4 / 28.6 — a share that has no group of its own still pays
+// the launch's first round trip, and with many live groups the shares re-read each other's results: eight is enough.
+uint32_t pick_scan_share(const bs_ctx* c) { return c->scan_share_override ? c->scan_share_override : 8u; }
 
 // Build the running-sum table for (cls, pct) in the scratch slot (last one) — single queries.
 int build_scratch_table(bs_ctx* c, uint32_t cls, float pct, uint32_t* slot_out) {
@@ -1871,6 +1873,10 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   const int ts = c->S <= 4 ? (int)c->S : -1;
   if (commit && G) HIPCHK(c, hipMemsetAsync(c->d_fast_reject.p, 0xFF, (size_t)G * 4, c->stream));
 
+  // K is known on the host once its copy from the pod load / queue patch has landed — never waited for here; when it is, the
+  // kernels need not fetch it in front of everything else
+  if (c->kinfo_pending && ((volatile int32_t*)c->h_info)[5] == c->kinfo_tag && (rc = resolve_pods(c))) return rc;
+  prm.k_host = c->kinfo_pending ? 0u : c->h_K;
   // ---- launch A: per-pod decisions, scan / Filter slots | chunk-local running sums of the table
   TIMED(c, BS_KERNEL_QUERY, {
     const uint32_t qb = cdiv(P, kTblChunk);
@@ -1885,21 +1891,18 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     }
   });
   // ---- launch B: node scan over the class slots | Filter evaluation over the Filter slots
-  // The work loops size themselves on the device (the class count lives there); the grid only has to be large
-  // enough.  K is known on the host once its copy from the pod load has landed — never waited for here.
-  if (c->kinfo_pending && ((volatile int32_t*)c->h_info)[5] == c->kinfo_tag && (rc = resolve_pods(c))) return rc;
+  // The work loops size themselves on the device (the class count lives there); the grid only has to be large enough.
   const uint32_t k_est = std::min<uint32_t>(P, c->kinfo_pending ? std::max<uint32_t>(2 * c->h_K, 1024) : std::max<uint32_t>(c->h_K, 1));
   TIMED(c, BS_KERNEL_SCAN, {
     const uint32_t nseg = pick_scan_share(c);
     // one scan item (tile of 64 class slots x share) per BLOCK: its four waves take a quarter of every group's rows each
     const uint32_t scan_blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(c->target_waves, 4), cdiv(k_est, 64) * std::min<uint32_t>(nseg, cdiv(c->M, 64))));
     const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * k_est, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
-    const dim3 grid(scan_blocks + fblocks);
-    launch_fast_b(c, grid, pd, nd, bt, prm, nseg, scan_blocks);
+    // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
+    const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
+    launch_fast_bc(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
   });
-  // ---- launch C: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
-  TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
-  c->launches = 3;
+  c->launches = 2;
   if (commit) {
     if (G) hipLaunchKernelGGL(k_fast_commit, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, pd, b, const_cast<uint8_t*>(gr.flags),
                               const_cast<uint64_t*>(gr.occupied), G);

@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (~6.3 TB/s achievable)
 VOPC_EVALS_PER_S = 4.1e12   # 64-bit v_cmp issue rate x 64 lanes, measured by tools/ubench/cmp_rate.hip (profiles/r01*)
-LAUNCH_KERNELS = {"query": "k_fast_query_tables", "scan": "k_fast_scan_filter", "resolve": "k_fast_final"}
+LAUNCH_KERNELS = {"query": "k_fast_query_tables", "scan": "k_fast_scan_filter_final"}
 
 
 def parse():
@@ -121,7 +121,8 @@ def cpu_baseline(bsa, nodes, fit, groups, pods, stages, reps):
 # ------------------------------------------------------------------------------------------------ rocprofv3 passes of this very command
 def profile_passes(args):
     """This command re-run (few steps, nothing else) under rocprofv3, three separate passes:
-      --kernel-trace --stats          kernel-only durations per launch (what the roofline is priced with)
+      --kernel-trace --stats          kernel-only durations per launch (what the roofline is priced with): median over the steady
+                                      two thirds of the launches
       --pmc FETCH_SIZE / WRITE_SIZE   HBM bytes per launch (FETCH doubled per the gfx950 note of MI355X_MICROARCH.md)
     Returns (dict launch -> {avg_us, calls, hbm_bytes_per_launch, ...} or None, source string)."""
     exe = shutil.which("rocprofv3")
@@ -139,12 +140,16 @@ def profile_passes(args):
         if res.returncode != 0 or not dbs:
             return None, f"rocprofv3 --kernel-trace failed (rc {res.returncode})"
         con = sqlite3.connect(dbs[0])
-        rows = con.execute("select name, total_calls, average from top_kernels").fetchall()
+        rows = con.execute("select name, dispatch_id, duration, grid_x from kernels order by dispatch_id").fetchall()
         con.close()
-        for name, calls, avg in rows:
+        per = {}
+        for name, _disp, dur, grid in rows:
             for key, kn in LAUNCH_KERNELS.items():
                 if kn + "<" in name or kn + "(" in name:
-                    out.setdefault(key, {}).update(kernel_us=float(avg), calls=int(calls))
+                    per.setdefault(key, []).append((float(dur) / 1e3, int(grid)))
+        for key, lst in per.items():
+            steady = lst[len(lst) // 3:]                         # the first launches after a load size their grids on estimates (K not back yet)
+            out.setdefault(key, {}).update(kernel_us=float(np.median([d for d, _ in steady])), calls=len(steady), grid_threads=int(np.median([g for _, g in steady])))
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             res = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", *inner], cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
@@ -152,13 +157,15 @@ def profile_passes(args):
             if res.returncode != 0 or not dbs:
                 return (out or None), f"kernel-trace ok; rocprofv3 --pmc {counter} failed (rc {res.returncode})"
             con = sqlite3.connect(dbs[0])
-            rows = con.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name",
-                               (counter,)).fetchall()
+            rows = con.execute("select kernel_name, dispatch_id, value from counters_collection where counter_name=? order by dispatch_id", (counter,)).fetchall()
             con.close()
-            for name, n, v in rows:
+            per = {}
+            for name, _disp, v in rows:
                 for key, kn in LAUNCH_KERNELS.items():
                     if kn + "<" in name or kn + "(" in name:
-                        out.setdefault(key, {})[counter] = float(v)
+                        per.setdefault(key, []).append(float(v))
+            for key, lst in per.items():
+                out.setdefault(key, {})[counter] = float(np.median(lst[len(lst) // 3:]))
     except Exception as e:                                    # pragma: no cover
         return (out or None), f"profile pass failed: {e!r}"
     finally:
@@ -453,8 +460,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    if args.inner_pmc:                         # the PMC passes: a few plain steps, nothing else
-        for _ in range(12):
+    if args.inner_pmc:                         # the PMC passes: a few dozen plain steps, nothing else
+        for _ in range(45):
             step()
         fence()
         ctx.close()
@@ -496,21 +503,21 @@ def main():
         #   A  pods P (8 L + 21) + nodes N (16 L + 6) in, table rows M 8 LP + per-pod scratch P 10 out
         #   B  table rows M 8 LP + getLeftResource lanes N 33 + slots in, first rows + Filter rows (rows x ceil(N/64) x 8) out
         #   C  per-pod scratch P 14 + group counters G 16 in, decisions P 18 + admit / ready G 5 out
-        # frac = those bytes / kernel time / 8 TB/s: a figure that cannot exceed 1 and that says what it is — the step is three
+        # frac = those bytes / kernel time / 8 TB/s: a figure that cannot exceed 1 and that says what it is — the step is two
         # latency-bound launches over a working set that lives in L2 / MALL, nowhere near a bandwidth roofline.
         LP = 4 if L == 4 else (8 if L <= 8 else 16)
         W = (nodes.n + 63) // 64
         rows = max(1, stats["filter_distinct"])
         alg = {
             "query": pods.p * (8 * L + 21) + nodes.n * (16 * L + 6) + nodes.n * 8 * LP + pods.p * 10,
-            "scan": nodes.n * 8 * LP + nodes.n * 33 + stats["scan_queries"] * (8 * LP + 12) + rows * (64 + W * 8 + 4),
-            "resolve": pods.p * (14 + 18) + groups.g * 21,
+            # launches B and C share ONE launch (k_fast_scan_filter_final): scan / Filter blocks + final blocks
+            "scan": nodes.n * 8 * LP + nodes.n * 33 + stats["scan_queries"] * (8 * LP + 12) + rows * (64 + W * 8 + 4) + pods.p * (14 + 18) + groups.g * 21,
         }
         prof, prof_src = (None, "not collected")
         if single and not args.no_pmc and stats["fast_path"]:
             prof, prof_src = profile_passes(args)
         launches = []
-        for key in ("query", "scan", "resolve"):
+        for key in ("query", "scan"):
             ms, n = timing.get(key, (0.0, 0))
             pk = (prof or {}).get(key, {})
             kernel_us = pk.get("kernel_us")
@@ -534,7 +541,7 @@ def main():
             dom = max(launches, key=lambda x: x["avg_launch_us"])
             roofline = dict(dom)
             ksum = sum(x["avg_launch_us"] for x in launches)
-            roofline.update({"bound": "hbm", "limiter": "launch latency and dependent-load chains (the step is three small launches; see frac)",
+            roofline.update({"bound": "hbm", "limiter": "launch latency and dependent-load chains (the step is two small launches, three dependency levels; see frac)",
                              "source": prof_src, "sum_of_launch_us": ksum, "ms_per_step_us": ms_per_step * 1e3,
                              "note": "the step's longest launch (by kernel-only time).  achieved = compulsory algorithmic bytes of the launch (every input once, "
                                      "every output once; DESIGN.md section 7) / its mean kernel duration; traffic = HBM bytes per launch from PMC; "

@@ -34,7 +34,7 @@ def test_bench_json_contract():
         assert r["sum_of_launch_us"] <= r["ms_per_step_us"] * 1.02, "the launches of a step cannot take longer than the step"
         assert r["kernel"] == max(d["roofline_launches"], key=lambda e: e["avg_launch_us"])["kernel"]
     assert d["value_resident"] == d["value"] and 10e6 < d["value_host_observed"] < d["value"]
-    assert d["config"]["fast_path"] == 1 and d["config"]["launches_per_step"] == 3
+    assert d["config"]["fast_path"] == 1 and d["config"]["launches_per_step"] == 2
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c and c["faithful_cost"] is False
     assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["value"] > 0

@@ -18,7 +18,7 @@ def test_fast_path_is_taken_and_equals_general_chain(config, scenario, monkeypat
         for _ in range(3):                                         # nothing is reset between batches: stamps / inverted sequence keys
             assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"{config}/{scenario} fast")
         st = ctx.stats(soa.STAGE_ALL)
-        assert st["fast_path"] == 1 and st["launches"] == 3 and st["class_mode"] == 1
+        assert st["fast_path"] == 1 and st["launches"] == 2 and st["class_mode"] == 1
         assert 0 < st["filter_distinct"] and st["filter_evals_executed"] == st["filter_distinct"] * nodes.n
         for stages in (soa.STAGE_PREFILTER, soa.STAGE_PREFILTER | soa.STAGE_TALLY, soa.STAGE_PREFILTER | soa.STAGE_FILTER):
             e = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, stages)
