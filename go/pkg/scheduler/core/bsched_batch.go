@@ -10,6 +10,8 @@ package core
 import "C"
 
 import (
+	"unsafe"
+
 	corev1 "k8s.io/api/core/v1"
 	"k8s.io/apimachinery/pkg/types"
 	"k8s.io/kubernetes/pkg/scheduler/nodeinfo"
@@ -167,6 +169,115 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 	out := C.bs_batch_out{pf_code: &res.pfCode[0], pf_first_k: &res.pfFirstK[0], fl_code: &res.flCode[0], fl_slot: &res.flSlot[0],
 		fl_rows: &res.rows[0], fl_rows_cap: C.uint32_t(res.rowsCap), fl_rows_n: &rowsN, group_admit: &res.admit[0], group_ready: &res.ready[0]}
 	return res, g.check("bs_batch_read", C.bs_batch_read(g.ctx, &out)) // the one stream wait of the cycle
+}
+
+// queueDelta: what changed in the pending queue since the last cycle, in queue positions (bs_pods_delta): pods that left
+// (bound, deleted: strictly ascending indices of the OLD queue), pods whose lastPermittedPod entry appeared or expired, new
+// pods with their positions in the NEW queue (nil = appended).  The scheduling queue is a heap ordered by Less, so the shim
+// keeps the drained order of the previous cycle and diffs against it.
+type queueDelta struct {
+	remove    []uint32
+	flagIndex []uint32
+	flagValue []uint8
+	insert    []*corev1.Pod
+	insertAt  []uint32
+}
+
+// cycleView: the results of a latency-mode batch, read IN PLACE from the pinned memory the last launch wrote (bs_batch_map):
+// no device-to-host copy, no stream wait, no host-side copy.  Valid until the next cycle runs.
+type cycleView struct {
+	v C.bs_batch_view
+}
+
+func (c *cycleView) pfCode(i int) uint8 {
+	return uint8(*(*C.uint8_t)(unsafe.Pointer(uintptr(unsafe.Pointer(c.v.pf_code)) + uintptr(i))))
+}
+func (c *cycleView) groupReady(g int) bool {
+	return *(*C.uint8_t)(unsafe.Pointer(uintptr(unsafe.Pointer(c.v.group_ready)) + uintptr(g))) != 0
+}
+func (c *cycleView) filterPasses(i, k int) bool { // Filter(pod i, node k), core.go:170-191, as a bit test in the mapped rows
+	code := *(*C.uint8_t)(unsafe.Pointer(uintptr(unsafe.Pointer(c.v.fl_code)) + uintptr(i)))
+	if code != C.BS_FL_EVALUATED {
+		return code < 16
+	}
+	slot := *(*C.uint32_t)(unsafe.Pointer(uintptr(unsafe.Pointer(c.v.fl_slot)) + uintptr(i)*4))
+	word := *(*C.uint64_t)(unsafe.Pointer(uintptr(unsafe.Pointer(c.v.fl_rows)) + (uintptr(k>>6)*uintptr(c.v.fl_rows_stride)+uintptr(slot))*8))
+	return word>>(uint(k)&63)&1 == 1
+}
+
+// runCycle: one scheduling cycle on the RESIDENT queue — patch the groups whose counters moved (patchGroups; its launch rides
+// in the queue patch's), patch the queue (bs_pods_apply: stable removal, flag flips, insertion, all on the device), run the
+// batch in latency mode, map the results.  tests/test_c11_client.py performs this very sequence through the same header.
+func (g *gpuCore) runCycle(d *queueDelta, groupIndex map[string]uint32, permitted func(*corev1.Pod) bool) (*cycleView, error) {
+	I, L := len(d.insert), 4+len(g.scalars)
+	grp, req := make([]C.int32_t, I+1), make([]C.int64_t, L*I+1)
+	pres, cls, owner, flags := make([]C.uint32_t, I+1), make([]C.uint32_t, I+1), make([]C.uint64_t, I+1), make([]C.uint8_t, I+1)
+	for i, p := range d.insert {
+		name, ok := util.VerifyPodLabelSatisfied(p)
+		switch gi, found := groupIndex[p.Namespace+"/"+name]; {
+		case !ok:
+			grp[i] = C.BS_POD_NOT_GROUPED
+		case !found:
+			grp[i] = C.BS_POD_GROUP_MISSING
+		default:
+			grp[i] = C.int32_t(gi)
+		}
+		pres[i] = g.lanes(getPodResourceRequire(p), req, I, i)
+		cls[i] = C.uint32_t(g.classOf(p))
+		owner[i] = C.uint64_t(g.intern64(joinedOwnerUIDs(p)))
+		if permitted(p) {
+			flags[i] |= C.BS_POD_LAST_PERMITTED
+		}
+	}
+	var delta C.bs_pods_delta
+	delta.n_remove = C.uint32_t(len(d.remove))
+	if len(d.remove) > 0 {
+		delta.remove = (*C.uint32_t)(unsafe.Pointer(&d.remove[0]))
+	}
+	delta.n_flags = C.uint32_t(len(d.flagIndex))
+	if len(d.flagIndex) > 0 {
+		delta.flag_index = (*C.uint32_t)(unsafe.Pointer(&d.flagIndex[0]))
+		delta.flag_value = (*C.uint8_t)(unsafe.Pointer(&d.flagValue[0]))
+	}
+	delta.insert = C.bs_pods_soa{p: C.uint32_t(I), group: &grp[0], req: &req[0], req_present: &pres[0], cls: &cls[0], owner: &owner[0], flags: &flags[0]}
+	if len(d.insertAt) > 0 {
+		delta.insert_at = (*C.uint32_t)(unsafe.Pointer(&d.insertAt[0]))
+	}
+	g.mu.Lock()
+	defer g.mu.Unlock()
+	if err := g.ensureFitRows(); err != nil {
+		return nil, err
+	}
+	if err := g.check("bs_pods_apply", C.bs_pods_apply(g.ctx, &delta)); err != nil {
+		return nil, err
+	}
+	if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, C.BS_STAGE_PREFILTER|C.BS_STAGE_TALLY|C.BS_BATCH_HOST_RESULTS)); err != nil {
+		return nil, err
+	}
+	res := &cycleView{}
+	if err := g.check("bs_batch_map", C.bs_batch_map(g.ctx, &res.v)); err != nil {
+		return nil, err // BS_ERR_STATE: the batch took the general chain (more than four leader changes): read it with bs_batch_read
+	}
+	return res, nil
+}
+
+// replayFilterDeny: Filter's deny entry (core.go:183-185) applied to a Filter-on batch in one forward pass (see bsched.h,
+// bs_batch_run): the first evaluated pod of a group whose Filter fails on some node (flCode == BS_FL_EVALUATED, feasible < nodes)
+// deny-lists the group; every later pod of it that reaches the deny check (core.go:105-110) is ERR_DENIED and never filtered.
+// batch-scheduler_amd/plugin.py replay_filter_deny is the tested twin (tests/test_batch_vs_sequential.py R1F).
+func (r *batchResult) replayFilterDeny(group []int32, feasible []uint32, nGroups int) {
+	first := make(map[int32]int)
+	for i := range r.pfCode {
+		g, code := group[i], r.pfCode[i]
+		reaches := g >= 0 && int(g) < nGroups && code != C.BS_PF_PASS_NOT_GROUPED && code != C.BS_PF_PASS_LAST_PERMITTED && code != C.BS_PF_ERR_PG_NOT_FOUND
+		if _, hit := first[g]; hit && reaches {
+			r.pfCode[i], r.flCode[i], feasible[i] = C.BS_PF_ERR_DENIED, C.BS_FL_NOT_RUN, 0
+		} else if r.flCode[i] == C.BS_FL_EVALUATED && int(feasible[i]) < r.n && g >= 0 && int(g) < nGroups {
+			if _, seen := first[g]; !seen {
+				first[g] = i
+			}
+		}
+	}
 }
 
 // All slices live only for the duration of the calls (cgo pointer rules: the library copies and keeps no Go pointer).

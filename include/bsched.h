@@ -275,8 +275,8 @@ typedef struct bs_batch_out {
 #define BS_BATCH_HOST_RESULTS 0x200u /* latency mode: the last launch of the batch also writes every result bs_batch_read
                                      returns (per-pod arrays, admit, ready, Filter rows) straight into pinned host memory;
                                      bs_batch_read then needs no device-to-host copy and no stream wait — it polls a
-                                     completion word (bs_batch_map: not even a host-side copy).  Honoured on both three-launch
-                                     chains (steady state, positional) of a single-rank context; a no-op (results are copied
+                                     completion word (bs_batch_map: not even a host-side copy).  Honoured on the steady-state
+                                     chain (two launches) and the positional chain (three) of a single-rank context; a no-op (results are copied
                                      as usual) on the general chain.  Costs the batch a few microseconds of PCIe writes, so
                                      throughput runs leave it off. */
 
@@ -419,8 +419,17 @@ int bs_find_max_pg(bs_ctx* ctx, int32_t* leader, uint32_t* finished, uint8_t* pa
  * frozen snapshot and group counters, with the in-batch side effects of core.go:113
  * (first-pod capture, MinResources default, occupancy) and :142,:163 (deny cache) replayed
  * in queue order.  Filter is evaluated for pods that passed, with sop.maxPGStatus as that
- * pod's PreFilter left it; Filter's own TTL side effects (core.go:184,188) are not replayed
- * (the shipped config does not enable Filter: deploy/scheduler/config/batch_scheduler_config.json).
+ * pod's PreFilter left it.  Filter's own TTL writes are NOT replayed inside the batch (the shipped config does not enable
+ * Filter: deploy/scheduler/config/batch_scheduler_config.json):
+ *   core.go:188 (lastPermittedPod.Add on a passing node) only ever concerns the SAME pod's next PreFilter — no other pod of the
+ *     batch can see it;
+ *   core.go:183-185 (AddToDenyCache when Filter fails on a node) would turn every later pod of the group that reaches the deny
+ *     check into ERR_DENIED.  The event is visible in the results (fl_code == BS_FL_EVALUATED && fl_feasible < nodes), and the
+ *     batch is exactly the sequential PreFilter + Filter run up to and including, per group, the first such pod; what follows
+ *     is a mechanical forward pass over the queue on the host (batch-scheduler_amd/plugin.py replay_filter_deny, the Go shim's
+ *     replayFilterDeny; tests/test_batch_vs_sequential.py R1F: batch + pass == the host mirror's PreFilter and Filter-on-every-
+ *     node calls in queue order), exact unless a pod let through on the lastPermittedPod entry fails Filter ahead of the batch's
+ *     first findMaxPG call.
  * Asynchronous on the context stream; bs_batch_sync waits. */
 int bs_batch_run(bs_ctx* ctx, uint32_t stages);
 int bs_batch_sync(bs_ctx* ctx);
@@ -533,7 +542,7 @@ typedef struct bs_batch_stats {
   uint64_t filter_evals_executed;   /* filter_distinct x nodes                                */
   uint64_t scan_queries_logical;    /* pods that needed a node scan (scan_queries = distinct ones scanned) */
   uint64_t class_mode;              /* 1: the batch worked on request classes, 0: one slot per pod        */
-  uint64_t fast_path;               /* 1: the three-launch steady-state chain ran                          */
+  uint64_t fast_path;               /* 1: the steady-state chain ran (two launches)                          */
   uint64_t launches;                /* kernel launches of the batch                                        */
   uint64_t chain;                   /* 0 general chain, 1 steady-state chain, 2 positional three-launch chain */
 } bs_batch_stats;

@@ -15,6 +15,9 @@ pods behind it) and PERMITS it (matched counters move, findMaxPG may elect anoth
                  induction over the queue the deny entries follow) — hence admit_seq <= admit_batch per group
                  and every gang the sequential run releases is ready in the batch.  On a tight cluster the
                  inclusion is strict: the batch over-admits, it is a pre-screen, not a reservation.
+  R1F equality, Filter on   batch (PREFILTER|FILTER|TALLY) + the host-side pass that applies Filter's deny entry
+                 (plugin.replay_filter_deny: core.go:183-185 is not replayed inside the batch) == the host mirror's PreFilter
+                 followed by Filter on EVERY node, pod by pod, with the real TTL deny cache.
   R3  the README race (README.md:78-188): frozen, both gangs of 5 fit the node on their own -> the batch
       reports both ready; sequentially the second gang is denied.  The canonical over-admission.
 """
@@ -29,7 +32,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GI = 1 << 30
 
 
-def _scene(soa, n_nodes, seed, n_groups=24, size=5):
+def _scene(soa, n_nodes, seed, n_groups=24, size=5, cpu_choices=(1000, 1500, 2000)):
     rng = np.random.default_rng(seed)
     alloc = np.zeros((4, n_nodes), np.int64)
     alloc[0], alloc[1], alloc[3] = 8000, 32 * GI, 40
@@ -39,7 +42,7 @@ def _scene(soa, n_nodes, seed, n_groups=24, size=5):
     req[3] = rng.integers(0, 10, n_nodes)
     nodes = soa.Nodes(alloc, req, np.zeros(n_nodes, np.uint32), np.zeros(n_nodes, np.uint32), np.zeros(n_nodes, np.uint8))
     fit = soa.FitMasks.from_bool(np.ones((2, n_nodes), bool))
-    gcpu = rng.choice([1000, 1500, 2000], n_groups)
+    gcpu = rng.choice(list(cpu_choices), n_groups)
     gmem = rng.choice([1, 2, 4], n_groups) * GI
     order = rng.permutation(n_groups * size)
     pgroup = (order // size).astype(np.int32) + 1              # group 0 is the leader: none of its pods is in the queue
@@ -168,3 +171,57 @@ def test_readme_race_is_the_canonical_over_admission(bsa, soa, orc):
     assert set(out.pf_code.tolist()) == {soa.PF_PASS_FIRST_FITS}
     assert out.group_admit.tolist() == [5, 5] and out.group_ready.tolist() == [1, 1]
     assert scene["expected_end_state"] == {"group1": "5/5 admitted", "group2": "0/5"}   # the sequential outcome (tests/test_host_mirror.py)
+
+
+@pytest.mark.parametrize("n_nodes,seed,big", [(36, 1, True), (40, 2, True), (64, 5, True), (48, 7, False), (160, 3, False)])
+def test_filter_on_batch_plus_deny_pass_equals_sequential_prefilter_and_filter(n_nodes, seed, big, bsa, soa, orc):
+    """R1F.  Sequential: PreFilter(pod) and, if it passes, Filter(pod, node) for every node (a failing node deny-lists the group,
+    core.go:183-185; the first pod of a gang whose Filter fails somewhere turns every later pod of the gang into ERR_DENIED).
+    Batch: one bs_batch_run with Filter on, then plugin.replay_filter_deny on the host.  Code by code, Filter code by Filter code,
+    feasible count by feasible count, admit / ready."""
+    # big: pods of 4.5 - 6.5 cores on nodes with 5 - 8 cores left: pod + a leader member does not fit many nodes that could still
+    # take the leader member alone -> Filter fails there (neither case 2 nor case 3 of core.go:551-561)
+    nodes, fit, pods, gcpu, gmem, size = _scene(soa, n_nodes, seed, cpu_choices=(4500, 5500, 6500) if big else (1000, 1500, 2000))
+    with bsa.Context(scalar_lanes=0) as ctx:
+        ctx.load_nodes(nodes, fit)
+        sop = _mirror_with_leader(bsa, ctx, gcpu, gmem, size)
+        ctx.g = len(gcpu) + 1
+        groups0 = ctx.read_groups()
+        seq_pf, seq_fl, seq_feas = [], [], []
+        for i in range(pods.p):
+            g, rq = int(pods.group[i]), pods.req[:, i].tolist()
+            code, _ = sop.PreFilter(i + 1, i + 1, g, rq)
+            seq_pf.append(code)
+            if code >= 16:
+                seq_fl.append(soa.FL_NOT_RUN)
+                seq_feas.append(0)
+                continue
+            fl, feas = soa.FL_NOT_RUN, 0
+            for k in range(nodes.n):
+                fl, fn = sop.Filter(i + 1, g, rq, 0, k)
+                feas += 1 if (fl != soa.FL_EVALUATED and fl < 16) or (fl == soa.FL_EVALUATED and fn < 16) else 0
+            seq_fl.append(fl)
+            seq_feas.append(feas)
+        sop.close()
+    with bsa.Context(scalar_lanes=0) as ctx:
+        ctx.load_nodes(nodes, fit)
+        ctx.load_groups(groups0)
+        ctx.load_pods(pods)
+        raw = ctx.batch(soa.STAGE_ALL, bitmap=False)
+    out = bsa.plugin.replay_filter_deny(raw, pods, groups0, nodes.n)
+    seq_pf, seq_fl, seq_feas = np.array(seq_pf, np.uint8), np.array(seq_fl, np.uint8), np.array(seq_feas, np.uint32)
+    assert np.array_equal(out.pf_code, seq_pf)
+    assert np.array_equal(out.fl_code, seq_fl)
+    assert np.array_equal(out.fl_feasible, seq_feas)
+    passed = (seq_pf < 16) & (seq_feas > 0)
+    assert np.array_equal(out.group_admit, np.bincount(pods.group[passed], minlength=groups0.g).astype(np.uint32))
+    denied_by_filter = int(((raw.pf_code < 16) & (out.pf_code == soa.PF_ERR_DENIED)).sum())
+    if big:
+        assert denied_by_filter > 0, "big pods: some gang's Filter fails on a node and the deny entry bites"
+    # the untouched batch is exact up to and including each group's first failing pod
+    for g in range(groups0.g):
+        idx = np.nonzero(pods.group == g)[0]
+        ev = [i for i in idx if raw.fl_code[i] == soa.FL_EVALUATED and raw.fl_feasible[i] < nodes.n]
+        upto = ev[0] if ev else (idx[-1] if len(idx) else -1)
+        sel = idx[idx <= upto]
+        assert np.array_equal(raw.pf_code[sel], seq_pf[sel]) and np.array_equal(raw.fl_feasible[sel], seq_feas[sel])

@@ -6,7 +6,8 @@ Needs the PROBE build of the library (never the shipped one):
         -o tools/ubench/libbsched_probe.so batch-scheduler_amd/csrc/bsched.hip -ldl
   python tools/stamp_probe.py [cycle|step] [config=cfg3] [scenario=tail] [reps=40]
 
-Thread 0 of the first 128 blocks of k_pods_apply (0), launch A (1), B (2), C (3) stamps s_memrealtime (100 MHz) at entry (0),
+Thread 0 of the first 128 blocks of k_pods_apply (0), launch A (1), the scan / Filter blocks (2) and the final blocks (3) of
+the second launch stamps s_memrealtime (100 MHz) at entry (0),
 at a few points inside (after draining its outstanding memory operations) and at exit (7).  Printed per launch, in microseconds
 relative to the FIRST block entry of the cycle's first launch, median over the repetitions:
   first / last block entry, last block exit, and per stamp the median / maximum over the blocks of (stamp - block entry)."""
@@ -24,7 +25,7 @@ import bench  # noqa: E402
 
 bsa = importlib.import_module("batch-scheduler_amd")
 soa = bsa.soa
-NAMES = {0: "k_pods_apply", 1: "A k_fast_query_tables", 2: "B k_fast_scan_filter", 3: "C k_fast_final"}
+NAMES = {0: "k_pods_apply", 1: "A k_fast_query_tables", 2: "B producer blocks of k_fast_scan_filter_final", 3: "C final blocks of k_fast_scan_filter_final"}
 
 
 def main():
