@@ -500,7 +500,7 @@ __device__ __forceinline__ void epoch_scan_loop(const BatchDev& b, const BatchPa
     while (todo) {
       const int32_t t0 = __builtin_amdgcn_readlane(tab, __ffsll((long long)todo) - 1);
       const bool member = tab == t0;
-      if (turn == ts) scan_core<S, true>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows);
+      if (turn == ts) scan_core<S, true, false>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows, LocalPre<S>{});   // (no shared pre-fetch: every tile has its own table)
       turn = 1u;
       todo &= ~__ballot(member);
       if (ts == 0) break;                            // (the first table was this wave's)

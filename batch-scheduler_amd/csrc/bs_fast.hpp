@@ -731,6 +731,22 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
   BS_STAMP(3, 7);
 }
 
+// The same two levels as separate launches, for batches with MANY tiles of class slots (thousands of distinct requests: the
+// throughput regime).  There a scan item is one wave's, nothing is gained by overlapping the final blocks' first fetch, and the
+// fused kernel's register footprint (every role's maximum) halves the waves a SIMD can hold.
+template <int S>
+__global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap,
+                                                          uint32_t scan_blocks, uint32_t filter_waves, uint32_t ustride) {
+  __shared__ int64_t s_rows[4][64][4 + S];
+  if (blockIdx.x < scan_blocks)
+    scan_loop<S, true, 1>(bt, prm, m, jcap, 0u, 0u, 1u, blockIdx.x, scan_blocks, s_rows[wave_id()]);
+  else
+    filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - scan_blocks, gridDim.x - scan_blocks, prm.stamp, 2u * prm.k_host);
+}
+__global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
+  fast_final_block(pods, gr, nd, b, prm, query_blocks, blockIdx.x, gridDim.x, 0u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launches B and C as ONE launch: [0, scan_blocks) node scan | [.., + filter_blocks) Filter evaluation | the rest: final
 // blocks.  Blocks are handed out in index order, so every producer has started before a final block does; a final block
@@ -746,7 +762,7 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter_final(PodsDev pods, Gr
   if (blockIdx.x < producers) {
     BS_STAMP(2, 0);
     if (blockIdx.x < scan_blocks)
-      scan_loop<S, true>(bt, prm, m, jcap, 0u, 0u, 1u, blockIdx.x, scan_blocks, s_rows[wave_id()]);
+      scan_loop<S, true, 2>(bt, prm, m, jcap, 0u, 0u, 1u, blockIdx.x, scan_blocks, s_rows[wave_id()]);
     else
       filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - scan_blocks, filter_blocks, prm.stamp, 2u * prm.k_host);
     // results out (atomics performed, row stores drained), then count this block in

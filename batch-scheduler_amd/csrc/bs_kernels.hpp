@@ -182,6 +182,7 @@ struct BatchParams {
   uint32_t commit;             // fast path: keep fast_reject for k_fast_commit
   uint32_t do_tally, do_ready; // fast path: stages of the final launch
   int32_t host_tag;            // BS_BATCH_HOST_RESULTS: completion word the final launch publishes (0 = off)
+  uint32_t scan_nsub;          // steady-state scan: waves of a block that share one item's groups (4: latency regime, few tiles; 1: many tiles)
   uint32_t k_host;             // request classes, when the host already knows the count (0: read *kclass — a dependent load in front of the first round trip)
 };
 
@@ -1207,10 +1208,10 @@ __device__ __forceinline__ void local_pre_load(const BatchDev& b, const BatchPar
   local_pre_finish<S>(b, prm, m, slot, raw, pre);
 }
 
-template <int S, bool LOCAL = false>
+template <int S, bool LOCAL = false, bool HAVE_PRE = false>
 __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, uint32_t pos, bool valid,
                                           const int64_t (&r)[1][4 + S], uint32_t qf, uint32_t share, uint32_t J, int64_t (*rows)[4 + S],
-                                          const LocalPre<S>* pre_in = nullptr, uint32_t sub = 0, uint32_t nsub = 1) {
+                                          const LocalPre<S>& given, uint32_t sub = 0, uint32_t nsub = 1) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
   constexpr int L = 4 + S;
   constexpr int U = 4;                           // rows per step: their LDS reads are issued together
@@ -1235,13 +1236,25 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   uint32_t win = BS_INF;
 #pragma unroll
   for (int j = 0; j < L; ++j) { offl[j] = 0; carry[j] = 0; }
-  LocalPre<S> mine_pre;                          // (lives as long as pre_in may point at it)
+  int64_t gmw[2][L];                             // maxima of the first 128 groups, by VALUE (see below)
+#pragma unroll
+  for (int j = 0; j < L; ++j) gmw[0][j] = gmw[1][j] = 0;
   if constexpr (LOCAL) {
-    if (!pre_in) { local_pre_load<S>(b, prm, m, slot, mine_pre); pre_in = &mine_pre; }
+    // everything is copied out of the struct here, with constant indices: a pointer that may name either of two structs and is
+    // followed inside the loop keeps both in scratch memory (it did: 336 bytes per lane, and a launch that uses scratch pays for it)
+    if constexpr (HAVE_PRE) {                        // steady state: the caller derived it once per wave (one table for every item)
 #pragma unroll
-    for (int j = 0; j < L; ++j) { offl[j] = pre_in->offl[j]; carry[j] = pre_in->carry[j]; }
+      for (int j = 0; j < L; ++j) { gmw[0][j] = given.gm[0][j]; gmw[1][j] = given.gm[1][j]; offl[j] = given.offl[j]; carry[j] = given.carry[j]; }
 #pragma unroll
-    for (int s = 0; s < S; ++s) kp[s] = __builtin_amdgcn_readfirstlane(pre_in->kp[s]);
+      for (int s = 0; s < S; ++s) kp[s] = __builtin_amdgcn_readfirstlane(given.kp[s]);
+    } else {
+      LocalPre<S> mine_pre;
+      local_pre_load<S>(b, prm, m, slot, mine_pre);
+#pragma unroll
+      for (int j = 0; j < L; ++j) { gmw[0][j] = mine_pre.gm[0][j]; gmw[1][j] = mine_pre.gm[1][j]; offl[j] = mine_pre.offl[j]; carry[j] = mine_pre.carry[j]; }
+#pragma unroll
+      for (int s = 0; s < S; ++s) kp[s] = __builtin_amdgcn_readfirstlane(mine_pre.kp[s]);
+    }
     win = 0;
   }
   auto ensure_window = [&](uint32_t w) {
@@ -1261,6 +1274,9 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   };
 
   BS_STAMP(2, 2);
+  int64_t gm[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) gm[j] = gmw[0][j];
   for (uint32_t c0 = 0; c0 < ngroups; c0 += 64u) {
     // live mask of groups c0 .. c0+63 (lane l <-> group c0+l)
     bool dead = true;
@@ -1270,16 +1286,17 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
       unsigned long long og[L];
 #pragma unroll
       for (int j = 0; j < L; ++j) og[j] = __shfl(offl[j], (int)((g >> 2) & 63u));
+      // local max per lane (INT64_MAX = do not prune) of this window's groups: the first two windows came with the wave's first
+      // fetch (kept as VALUES — a runtime choice between the two arrays turns into an indexed load and the struct into scratch)
+      if (c0 == 64u) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) gm[j] = gmw[1][j];
+      } else if (c0 >= 128u && g < ngroups) {
+        const int64_t* src = b.gmax + ((size_t)slot * gstride + g) * LP;
+#pragma unroll
+        for (int j = 0; j < L; ++j) gm[j] = src[j];
+      }
       if (g < ngroups) {
-        int64_t gm[L];                                                       // local max per lane, INT64_MAX = do not prune
-        if (c0 < 128u) {
-#pragma unroll
-          for (int j = 0; j < L; ++j) gm[j] = c0 ? pre_in->gm[1][j] : pre_in->gm[0][j];
-        } else {
-          const int64_t* src = b.gmax + ((size_t)slot * gstride + g) * LP;
-#pragma unroll
-          for (int j = 0; j < L; ++j) gm[j] = src[j];
-        }
         constexpr long long kSafe = 1ll << 62;
         dead = false;
 #pragma unroll
@@ -1397,7 +1414,9 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 // Work loop: item = (tile of 64 request slots, share j of J).  The slots of a tile that use the same
 // table are scanned together (steady state: one table for everything); consecutive waves take different
 // tiles with the same share.  The grid is fixed; the slot count is read on the device.
-template <int S, bool LOCAL = false>
+// MODE 0: an item's table is whatever its slots ask for (general chain); 1: steady state, one table for every item, an item per wave;
+// 2: steady state, an item per BLOCK (its four waves share the first fetch and take a quarter of every group's rows each)
+template <int S, bool LOCAL = false, int MODE = 0>
 __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t jcap, uint32_t nslots_fixed,
                                           uint32_t ngroups_g, uint32_t tsplit, uint32_t bx, uint32_t nblocks, int64_t (*rows)[4 + S]) {
   constexpr int LP = (S == 0) ? 4 : (S <= 4 ? 8 : 16);
@@ -1419,13 +1438,15 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
   // tsplit > 1 (several tables in use): the distinct tables of a tile are dealt over tsplit waves as well
   // steady state (one table for every item, stamped slots): the four waves of a block work on ONE item, a quarter of every
   // group's rows each; elsewhere an item is one wave's
-  const bool uni = LOCAL && prm.stamp != 0;
-  const uint32_t nsub = uni ? 4u : 1u, sub = uni ? (uint32_t)__builtin_amdgcn_readfirstlane(wave_id()) : 0u;   // (wave-uniform: row numbers stay scalar)
+  constexpr bool uni = LOCAL && MODE != 0;
+  constexpr bool split = uni && MODE == 2;          // few tiles: a block = one item; many tiles (every pod its own request): a wave = one item,
+                                                   // as everywhere else — four waves per item would fetch every group four times
+  const uint32_t nsub = split ? 4u : 1u, sub = split ? (uint32_t)__builtin_amdgcn_readfirstlane(wave_id()) : 0u;   // (wave-uniform: row numbers stay scalar)
   const uint32_t wpb = 4u / nsub;                 // items a block works on at a time
   const uint32_t J = max(1u, min(min(jcap, (m + 63u) >> 6), (nblocks * wpb) / (ntl * tsplit)));
   const uint32_t items = ntl * tsplit * J;
   const int lane = lane_id();
-  const uint32_t w_first = __builtin_amdgcn_readfirstlane(uni ? bx : bx * 4u + (uint32_t)wave_id());
+  const uint32_t w_first = __builtin_amdgcn_readfirstlane(split ? bx : bx * 4u + (uint32_t)wave_id());
   // table, stamp, request and flags of a tile's slots in ONE round trip (a dead slot's request is loaded for nothing)
   struct SlotLoad { int32_t tab; uint32_t stp, qf; int64_t r[L]; };
   auto load_slots = [&](uint32_t w, SlotLoad& sl) {
@@ -1441,9 +1462,11 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
   // the first item's slots are asked for BEFORE the table's offsets / key rows / first pruning bounds are derived (once per
   // wave: loads, then wave scans that wait for them): one round trip for both, not two in a row
   SlotLoad first;
-  LocalPre<S> pre;
+  LocalPre<S> pre = {};
   if constexpr (LOCAL) {
-    if (uni) {
+    if constexpr (uni && !split) {
+      if (w_first < items) { load_slots(w_first, first); local_pre_load<S>(b, prm, m, 0u, pre); }
+    } else if constexpr (split) {
       // The four waves of the block work on ONE item and need the SAME first fetch (the tile's slots, the table's chunk
       // totals / key rows, the maxima of its first 128 groups): 64 lanes x 64-byte strides, ~900 cache lines per wave — four
       // waves asking for all of it keep this CU's L1 busy for longer than the memory latency.  Each wave fetches a quarter,
@@ -1515,7 +1538,7 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
     while (todo) {
       const int32_t t0 = __builtin_amdgcn_readlane(tab, __ffsll((long long)todo) - 1);
       const bool member = tab == t0;
-      if (turn == ts) scan_core<S, LOCAL>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows, uni ? &pre : (const LocalPre<S>*)nullptr, sub, nsub);
+      if (turn == ts) scan_core<S, LOCAL, uni>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows, pre, sub, nsub);
       turn = turn + 1u == tsplit ? 0u : turn + 1u;
       todo &= ~__ballot(member);
     }

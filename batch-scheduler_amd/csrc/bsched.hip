@@ -616,6 +616,30 @@ static void launch_fast_bc_s(bs_ctx* c, dim3 grid, const PodsDev& pd, const Grou
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter_final<S>), grid, dim3(256), 0, c->stream, pd, gr, nd, b, bt, prm, c->M, nseg, scan_blocks, filter_blocks,
                      c->filter_waves, c->filter_slots_cap, cdiv(c->P, kTblChunk));
 }
+template <int S>
+static void launch_fast_b_s(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg,
+                            uint32_t scan_blocks) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter<S>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->M, nseg, scan_blocks, c->filter_waves,
+                     c->filter_slots_cap);
+}
+static void launch_fast_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg,
+                          uint32_t scan_blocks) {
+  switch (c->S) {
+    case 0: launch_fast_b_s<0>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 1: launch_fast_b_s<1>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 2: launch_fast_b_s<2>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 3: launch_fast_b_s<3>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 4: launch_fast_b_s<4>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 5: launch_fast_b_s<5>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 6: launch_fast_b_s<6>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 7: launch_fast_b_s<7>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 8: launch_fast_b_s<8>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 9: launch_fast_b_s<9>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 10: launch_fast_b_s<10>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    case 11: launch_fast_b_s<11>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+    default: launch_fast_b_s<12>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+  }
+}
 static void launch_fast_bc(bs_ctx* c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                            const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks, uint32_t filter_blocks) {
   switch (c->S) {
@@ -1895,14 +1919,26 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   const uint32_t k_est = std::min<uint32_t>(P, c->kinfo_pending ? std::max<uint32_t>(2 * c->h_K, 1024) : std::max<uint32_t>(c->h_K, 1));
   TIMED(c, BS_KERNEL_SCAN, {
     const uint32_t nseg = pick_scan_share(c);
-    // one scan item (tile of 64 class slots x share) per BLOCK: its four waves take a quarter of every group's rows each
-    const uint32_t scan_blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(c->target_waves, 4), cdiv(k_est, 64) * std::min<uint32_t>(nseg, cdiv(c->M, 64))));
+    // few tiles (the latency regime): one scan item (tile of 64 class slots x share) per BLOCK, its four waves take a quarter of
+    // every group's rows each; many tiles (thousands of distinct requests): one item per wave, 4 per block
+    const uint32_t tiles = cdiv(k_est, 64);
+    prm.scan_nsub = tiles <= 16 ? 4u : 1u;
+    const uint32_t scan_items = tiles * std::min<uint32_t>(prm.scan_nsub == 4u ? nseg : 64u, cdiv(c->M, 64));
+    const uint32_t scan_blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(c->target_waves, 4), prm.scan_nsub == 4u ? scan_items : cdiv(scan_items, 4)));
     const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * k_est, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
-    // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
-    const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
-    launch_fast_bc(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
+    if (prm.scan_nsub == 4u) {
+      // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
+      const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
+      launch_fast_bc(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
+    } else {
+      launch_fast_b(c, dim3(scan_blocks + fblocks), pd, nd, bt, prm, 64u, scan_blocks);
+    }
   });
   c->launches = 2;
+  if (prm.scan_nsub != 4u) {                         // the throughput regime: launch C on its own
+    TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
+    c->launches = 3;
+  }
   if (commit) {
     if (G) hipLaunchKernelGGL(k_fast_commit, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, pd, b, const_cast<uint8_t*>(gr.flags),
                               const_cast<uint64_t*>(gr.occupied), G);
