@@ -428,7 +428,7 @@ int bs_find_max_pg(bs_ctx* ctx, int32_t* leader, uint32_t* finished, uint8_t* pa
  *     batch is exactly the sequential PreFilter + Filter run up to and including, per group, the first such pod; what follows
  *     is a mechanical forward pass over the queue on the host (batch-scheduler_amd/plugin.py replay_filter_deny, the Go shim's
  *     replayFilterDeny; tests/test_batch_vs_sequential.py R1F: batch + pass == the host mirror's PreFilter and Filter-on-every-
- *     node calls in queue order), exact unless a pod let through on the lastPermittedPod entry fails Filter ahead of the batch's
+ *     node calls in queue order; tests/test_filter_deny_pass.py: == an independent object-level sequential replay on 200+ random scenes), exact unless a pod let through on the lastPermittedPod entry fails Filter ahead of the batch's
  *     first findMaxPG call.
  * Asynchronous on the context stream; bs_batch_sync waits. */
 int bs_batch_run(bs_ctx* ctx, uint32_t stages);
