@@ -69,22 +69,10 @@ def _oracle():
     return orc
 
 
-_MP = {}
-
-
-def _mp_worker(r):
-    orc, snap, groups, pods, stages, own = _MP["a"]
-    sub = pods.take(np.nonzero(own == r)[0])
-    sop = orc.Sop(snap, groups)
-    t0 = time.perf_counter()
-    sop.batch(sub, stages, bitmap=bool(stages & 2))
-    return time.perf_counter() - t0, sop.iters
-
-
 def cpu_baseline(bsa, nodes, fit, groups, pods, stages, reps):
     """The oracle (C port of the Go path) on the same inputs and stages — checker code, timed as the baseline only.
-    1 core: upstream runs PreFilter on the single scheduling goroutine.  All cores: whole groups dealt over forked
-    workers (exact here: no pod's decision depends on a pod of another group in this scenario)."""
+    1 core: upstream runs PreFilter on the single scheduling goroutine.  All cores: whole groups dealt over one thread per
+    host core (exact here: no pod's decision depends on a pod of another group in this scenario)."""
     orc = _oracle()
     snap = orc.Snapshot(nodes, fit)
     best, iters = None, 0
@@ -99,16 +87,13 @@ def cpu_baseline(bsa, nodes, fit, groups, pods, stages, reps):
     ncores = os.cpu_count() or 1
     allc = None
     try:
-        import multiprocessing as mp
+        # all host cores: whole groups dealt over one thread per core inside the C oracle (orc_batch_threads), best of 3
         bdist = importlib.import_module("batch-scheduler_amd.dist")
         own = bdist.owner_ranks(pods.group, groups.g, ncores)
-        _MP["a"] = (orc, snap, groups, pods, stages, own)
-        with mp.get_context("fork").Pool(ncores) as pool:
-            pool.map(abs, range(ncores))                     # workers are up
-            t0 = time.perf_counter()
-            pool.map(_mp_worker, range(ncores))
-            wall = time.perf_counter() - t0
-        allc = {"value": logical / wall, "cores": ncores, "seconds_per_batch": wall}
+        subsets = [pods.take(np.nonzero(own == r)[0]) for r in range(ncores)]
+        wall = min(orc.batch_threads(snap, groups, subsets, stages, bitmap=bool(stages & bsa.soa.STAGE_FILTER))[0] for _ in range(3))
+        allc = {"value": logical / wall, "cores": ncores, "seconds_per_batch": wall,
+                "how": "one pthread per host core, whole groups per thread (exact in this scenario: no pod's decision depends on a pod of another group)"}
     except Exception as e:                                    # pragma: no cover
         allc = {"error": repr(e)}
     return {"value": logical / best, "unit": "pod x node fit evals/s", "cores": 1, "kind": "port", "faithful_cost": False,

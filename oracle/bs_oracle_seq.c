@@ -144,3 +144,42 @@ void orc_seq_replay(orc_seq_io* io) {
   io->total_ns = mono_ns() - t0;
   free(t_first); free(nwait); free(slot_of); free(head); free(next_wait); free(assumed_on);
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * All host cores as the CPU baseline of bench.py: n independent batches — disjoint pod subsets, WHOLE groups each (exact
+ * whenever no pod's decision depends on a pod of another group: the steady state), each with its own orc_sop — on n
+ * threads.  Returns the wall time in nanoseconds from the first thread's creation to the last join.  (Forked Python workers
+ * measured 0.25 s for what 256 threads do in a few tens of milliseconds: process start-up and pickling, not arithmetic.)
+ * ------------------------------------------------------------------------------------------------------------------- */
+#include <pthread.h>
+
+typedef struct {
+  orc_sop* sop;
+  const bs_pods_soa* pods;
+  uint32_t stages;
+  const bs_batch_out* out;
+} orc_job;
+
+static void* orc_job_run(void* arg) {
+  orc_job* j = (orc_job*)arg;
+  if (j->pods->p) orc_batch(j->sop, j->pods, j->stages, j->out);
+  return NULL;
+}
+
+int64_t orc_batch_threads(orc_job* jobs, uint32_t n) {
+  pthread_t* th = (pthread_t*)calloc(n ? n : 1, sizeof(pthread_t));
+  unsigned char* started = (unsigned char*)calloc(n ? n : 1, 1);
+  if (!th || !started) { free(th); free(started); return -1; }
+  const int64_t t0 = mono_ns();
+  for (uint32_t i = 0; i < n; ++i) {
+    if (pthread_create(&th[i], NULL, orc_job_run, &jobs[i]) == 0) started[i] = 1;
+    else orc_job_run(&jobs[i]);                                   /* no thread to be had: run it here */
+  }
+  for (uint32_t i = 0; i < n; ++i)
+    if (started[i]) pthread_join(th[i], NULL);
+  const int64_t dt = mono_ns() - t0;
+  free(th);
+  free(started);
+  return dt;
+}

@@ -260,6 +260,33 @@ class Sop:
         return out
 
 
+class JobStruct(C.Structure):
+    """orc_job of bs_oracle_seq.c"""
+    _fields_ = [("sop", C.POINTER(SopStruct)), ("pods", C.POINTER(soa.PodsStruct)), ("stages", C.c_uint32), ("out", C.POINTER(soa.BatchOutStruct))]
+
+
+def batch_threads(snap: Snapshot, groups, subsets, stages: int, bitmap: bool = False):
+    """n independent batches (pod subsets holding WHOLE groups) on n threads (orc_batch_threads): returns (wall seconds, sum of the
+    reference's node-loop iterations, the Sop / BatchOut pairs).  The all-cores CPU baseline of bench.py."""
+    L = lib()
+    L.orc_batch_threads.restype = C.c_int64
+    L.orc_batch_threads.argtypes = [C.POINTER(JobStruct), C.c_uint32]
+    sops = [Sop(snap, groups) for _ in subsets]
+    outs = [soa.BatchOut.alloc(sub.p, groups.g, snap.nodes.n, bitmap=bitmap) for sub in subsets]
+    pstructs = [sub.as_struct() for sub in subsets]
+    ostructs = [o.as_struct() for o in outs]
+    jobs = (JobStruct * max(len(subsets), 1))()
+    for i in range(len(subsets)):
+        jobs[i].sop = C.pointer(sops[i].struct)
+        jobs[i].pods = C.pointer(pstructs[i])
+        jobs[i].stages = stages
+        jobs[i].out = C.pointer(ostructs[i])
+    ns = L.orc_batch_threads(jobs, len(subsets))
+    if ns < 0:
+        raise MemoryError("orc_batch_threads")
+    return ns * 1e-9, sum(s.iters for s in sops), list(zip(sops, outs))
+
+
 def seq_replay(nodes, fit, groups, pods, stages: int = soa.STAGE_PREFILTER | soa.STAGE_TALLY) -> dict:
     """One sequential scheduling pass over the queue, pod by pod (bs_oracle_seq.c): PreFilter, first-fit node choice, assume,
     Permit, release at the quorum.  Works on COPIES of nodes / groups; returns them with the per-gang release records."""

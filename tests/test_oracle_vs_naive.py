@@ -150,3 +150,23 @@ def test_permitted_queue_and_panic_epoch_oracle_equals_naive(seed, orc, soa):
     out = _check_scene(sc, orc, soa, f"scene {seed}")
     if seed % 2 == 0 and any(p.group == "ns/g3" for p in sc["pods"]):
         assert (out.pf_code == soa.PF_PANIC_DIV0).any()
+
+
+def test_threaded_group_subsets_equal_the_single_batch(bsa, soa, orc):
+    """bench.py's all-cores CPU baseline (orc_batch_threads: whole groups per thread, one orc_sop each) computes exactly what the
+    single sequential batch computes in the steady state: per-pod codes, first_k, Filter results, per-group admit counts."""
+    import numpy as np
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "tail")
+    snap = orc.Snapshot(nodes, fit)
+    full = orc.Sop(snap, groups).batch(pods, soa.STAGE_ALL, bitmap=False)
+    for n in (3, 8):
+        own = bsa.dist.owner_ranks(pods.group, groups.g, n)
+        idx = [np.nonzero(own == r)[0] for r in range(n)]
+        wall, iters, pairs = orc.batch_threads(snap, groups, [pods.take(i) for i in idx], soa.STAGE_ALL)
+        assert wall > 0 and iters > 0
+        admit = np.zeros(groups.g, np.uint32)
+        for i, (_sop, out) in zip(idx, pairs):
+            for name in ("pf_code", "pf_first_k", "fl_code", "fl_feasible"):
+                assert np.array_equal(getattr(out, name), getattr(full, name)[i]), (n, name)
+            admit += out.group_admit
+        assert np.array_equal(admit, full.group_admit)

@@ -17,7 +17,7 @@ def test_oracle_under_asan_and_ubsan(tmp_path):
     lib = str(tmp_path / "libbs_oracle_san.so")
     srcs = [os.path.join(ROOT, "oracle", f) for f in ("bs_oracle.c", "bs_oracle_fit.c", "bs_oracle_seq.c")]
     subprocess.run(["gcc", "-O1", "-g", "-std=c11", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off", "-fno-fast-math", "-msse2", "-mfpmath=sse",
-                    "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-o", lib, *srcs], check=True)
+                    "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-pthread", "-o", lib, *srcs], check=True)
     asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
     env = dict(os.environ, BS_ORACLE_LIB=lib, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     tests = ["tests/test_oracle_golden.py", "tests/test_oracle_vs_naive.py", "tests/test_drain.py", "tests/test_fit_build.py", "tests/test_queue_sort.py"]
