@@ -92,8 +92,15 @@ def cpu_baseline(bsa, nodes, fit, groups, pods, stages, reps):
         own = bdist.owner_ranks(pods.group, groups.g, ncores)
         subsets = [pods.take(np.nonzero(own == r)[0]) for r in range(ncores)]
         wall = min(orc.batch_threads(snap, groups, subsets, stages, bitmap=bool(stages & bsa.soa.STAGE_FILTER))[0] for _ in range(3))
-        allc = {"value": logical / wall, "cores": ncores, "seconds_per_batch": wall,
-                "how": "one pthread per host core, whole groups per thread (exact in this scenario: no pod's decision depends on a pod of another group)"}
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except AttributeError:                                # pragma: no cover
+            usable = ncores
+        allc = {"value": logical / wall, "cores": ncores, "cores_in_affinity_mask": usable, "seconds_per_batch": wall,
+                "speedup_over_one_core": best / wall,
+                "how": "one pthread per host core (os.cpu_count()), whole groups per thread (exact in this scenario: no pod's decision depends on a pod "
+                       "of another group); speedup_over_one_core says how many cores the box really gave the run (a container can report 256 and "
+                       "schedule on a handful)"}
     except Exception as e:                                    # pragma: no cover
         allc = {"error": repr(e)}
     return {"value": logical / best, "unit": "pod x node fit evals/s", "cores": 1, "kind": "port", "faithful_cost": False,
