@@ -32,7 +32,7 @@
 //                                    sums of every table the loaded state can ask for (known at analysis time)
 //   launch B  k_epoch_scan_filter    node scan per live scan slot | computeResourceSatisfied per Filter slot x node
 //   launch C  k_epoch_final          REJECT / deny replay / stale leader, Filter code + slot + feasible count per
-//                                    pod, per-group admit counts, last block: quorum predicate core.go:303
+//                                    pod, per-group admit counts and the quorum predicate core.go:303 (tally_tail)
 //   (BS_BATCH_COMMIT: + k_epoch_reject_groups + k_commit, then the analysis is redone for the committed state)
 #pragma once
 

@@ -6,7 +6,7 @@
 // state a scheduler lives in once each gang has been seen; everything else takes the general chain of
 // bs_kernels.hpp.
 //
-// What makes three launches enough:
+// What makes three dependency levels (two launches) enough:
 //   * everything that depends on the pods alone is derived when the pods are loaded (bs_pods_load,
 //     k_pod_pairs): request classes, per-group first pod / first non-permitted pod / first owner, and the
 //     (group, request class) pairs of each group.  The per-batch pre-pass with its grid-wide minima is gone.
@@ -506,7 +506,8 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_query_tables(PodsDev pods, G
 }
 
 // ------------------------------------------------------------------------------------------------
-// The common ends of a three-launch batch (k_fast_final, k_epoch_final; 256 threads per block).
+// The common ends of a steady-state / positional batch (final blocks of k_fast_scan_filter_final, k_fast_final, k_epoch_final;
+// 256 threads per block).
 //   arm_tally    (launch A) zero the per-group counters of this batch; groups without a pod in the queue get their quorum
 //                answer right away (nobody will come by to close them)
 //   tally_tail   (launch C) per-group admit counts and the Permit quorum (core.go:303).  Single context: every wave adds
@@ -599,7 +600,7 @@ __device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& 
 //   stale leader  sop.maxFinishedPG after the pod's PreFilter = the batch's findMaxPG result from the first
 //                 pod that reaches findMaxPG on, the value carried into the batch before it (core.go:121)
 //   Filter        code, slot and feasible-node count of the pod from its class slot
-//   Permit        per-group admit counts; last block: quorum predicate core.go:303
+//   Permit        per-group admit counts and the quorum predicate core.go:303 (tally_tail)
 // ------------------------------------------------------------------------------------------------
 // what launch B left behind, read by a block of the SAME launch: performed at the coherence point (its writers used agent-scope
 // atomics), not looked up in this XCD's L2

@@ -544,7 +544,7 @@ typedef struct bs_batch_stats {
   uint64_t class_mode;              /* 1: the batch worked on request classes, 0: one slot per pod        */
   uint64_t fast_path;               /* 1: the steady-state chain ran (two launches)                          */
   uint64_t launches;                /* kernel launches of the batch                                        */
-  uint64_t chain;                   /* 0 general chain, 1 steady-state chain, 2 positional three-launch chain */
+  uint64_t chain;                   /* 0 general chain, 1 steady-state chain, 2 positional chain              */
 } bs_batch_stats;
 int bs_batch_stats_get(bs_ctx* ctx, bs_batch_stats* out);
 /* bs_pods_apply calls so far, and how many of them (plus later batches) had to re-derive classes and pairs from the
