@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_batch_map", "bs_filter_rows_count", "bs_queue_order_load", "bs_queue_sort",
     "bs_shard_set", "bs_reduce_external", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
     "bs_timing_reset", "bs_timing_get", "bs_kernel_name", "bs_batch_stats_get",
+    "bs_seq_run", "bs_nodes_read",
 ]
 
 
@@ -67,6 +68,14 @@ class BatchStats(C.Structure):
                 ("filter_distinct", C.c_uint64), ("filter_evals_executed", C.c_uint64),
                 ("scan_queries_logical", C.c_uint64), ("class_mode", C.c_uint64), ("fast_path", C.c_uint64), ("launches", C.c_uint64),
                 ("chain", C.c_uint64)]
+
+
+class SeqOut(C.Structure):
+    """bs_seq_out"""
+    _fields_ = [("pf_code", C.POINTER(C.c_uint8)), ("pf_first_k", C.POINTER(C.c_uint32)), ("pf_leader", C.POINTER(C.c_int32)),
+                ("pod_node", C.POINTER(C.c_int32)), ("cap", C.c_uint32), ("released_group", C.POINTER(C.c_uint32)),
+                ("released_pods", C.POINTER(C.c_uint32)), ("first_ns", C.POINTER(C.c_int64)), ("ready_ns", C.POINTER(C.c_int64)),
+                ("n_released", C.c_uint32), ("total_ns", C.c_int64), ("node_passes", C.c_uint64), ("node_scans", C.c_uint64)]
 
 
 _lib = None
@@ -132,6 +141,8 @@ def load_library(path: str | None = None):
     L.bs_timing_reset.argtypes = [vp]
     L.bs_timing_get.argtypes = [vp, P(Timing)]
     L.bs_batch_stats_get.argtypes = [vp, P(BatchStats)]
+    L.bs_seq_run.argtypes = [vp, u32, P(SeqOut)]
+    L.bs_nodes_read.argtypes = [vp, P(C.c_int64), P(u32)]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:
@@ -436,6 +447,31 @@ class Context:
     def batch(self, stages: int = soa.STAGE_ALL, bitmap: bool = True, rows: bool | None = None) -> soa.BatchOut:
         self.run(stages)
         return self.read(bitmap=bitmap, rows=rows)
+
+    # -- the sequential pass
+    def seq_run(self, stages: int = soa.STAGE_PREFILTER, cap: int | None = None) -> dict:
+        """bs_seq_run: the reference's pod-by-pod cycle (PreFilter -> node choice -> assume -> Permit -> release) over the
+        resident queue, on the device.  The context's node requests and group state are what the pass left."""
+        p, cap = self.pods_count(), max(self.g if cap is None else cap, 1)
+        n = max(p, 1)
+        pf, fk = np.zeros(n, np.uint8), np.zeros(n, np.uint32)
+        ld, node = np.zeros(n, np.int32), np.full(n, -1, np.int32)
+        rg, rp = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+        t0, t1 = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+        o = SeqOut(pf.ctypes.data_as(C.POINTER(C.c_uint8)), _u32p(fk), ld.ctypes.data_as(C.POINTER(C.c_int32)), node.ctypes.data_as(C.POINTER(C.c_int32)),
+                   cap, _u32p(rg), _u32p(rp), _i64p(t0), _i64p(t1), 0, 0, 0, 0)
+        self._chk(self._lib.bs_seq_run(self._h, stages, C.byref(o)), "bs_seq_run")
+        k = min(int(o.n_released), cap)
+        return dict(pf_code=pf[:p], pf_first_k=fk[:p], pf_leader=ld[:p], pod_node=node[:p], released_group=rg[:k], released_pods=rp[:k],
+                    first_ns=t0[:k], ready_ns=t1[:k], n_released=int(o.n_released), total_ns=int(o.total_ns), node_passes=int(o.node_passes),
+                    node_scans=int(o.node_scans))
+
+    def read_node_requests(self):
+        """bs_nodes_read: (requested [L][n], requested_present [n]) as the context holds them"""
+        req = np.zeros((self.L, max(self.n, 1)), np.int64) if self.n == 0 else np.zeros((self.L, self.n), np.int64)
+        pres = np.zeros(max(self.n, 1), np.uint32)
+        self._chk(self._lib.bs_nodes_read(self._h, _i64p(req), _u32p(pres)), "bs_nodes_read")
+        return req[:, : self.n], pres[: self.n]
 
     # -- sharding / measurement
     def set_shard(self, rank: int, nranks: int):

@@ -21,6 +21,7 @@
 #include "bs_sort.hpp"
 #include "bs_fit.hpp"
 #include "bs_queue.hpp"
+#include "bs_seq.hpp"
 
 using namespace bs;
 
@@ -200,6 +201,7 @@ struct bs_ctx {
   uint32_t last_rows = 0;            // Filter slot rows of the last positional batch
   // single-query scratch
   DevBuf d_sq;
+  DevBuf d_seq;                      // bs_seq_run: scaled allocatables, keys, per-gang / per-pod bookkeeping, results
   uint32_t table_slots = 0, table_mcap = 0;
 
   uint32_t rank = 0, nranks = 1;
@@ -948,6 +950,11 @@ void launch_epoch_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd,
                            uint32_t nseg, uint32_t scan_blocks, uint32_t filter_slots) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epoch_scan_filter<S>), grid, dim3(256), 0, c->stream, pd, nd, b, prm, ep, c->M, nseg, c->G, scan_blocks,
                      c->filter_waves, c->filter_slots_cap, filter_slots);
+}
+
+template <int TS>
+void launch_seq_s(bs_ctx* c, size_t lds, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const SeqDev& sq, const SeqParams& prm) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seq_pass<TS>), dim3(1), dim3(kSeqBlock), lds, c->stream, pd, gr, nd, sq, prm);
 }
 
 int resolve_epochs(bs_ctx* c) {
@@ -2872,6 +2879,174 @@ int bs_nodes_assume(bs_ctx* c, const bs_node_request* reqs, uint32_t count) {
   HIPCHK(c, hipEventRecord(c->ev_nstage, c->stream));
   c->nstage_busy = true;
   c->bitmap_valid = false;
+  return BS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// the sequential scheduling pass (bs_seq.hpp): one persistent workgroup walks the resident queue
+// -------------------------------------------------------------------------------------------------
+int bs_nodes_read(bs_ctx* c, int64_t* requested, uint32_t* requested_present) {
+  if (!c || !requested || !requested_present) return BS_ERR_INVALID;
+  if (!c->have_nodes) { c->last_error = "bs_nodes_read before bs_nodes_load"; return BS_ERR_STATE; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t N = c->N, L = c->L;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (N) {
+    HIPCHK(c, hipMemcpy2D(requested, (size_t)N * 8, c->d_nreq.p, (size_t)c->Ncap * 8, (size_t)N * 8, L, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(requested_present, c->d_rpres.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+  }
+  return BS_OK;
+}
+
+int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
+  if (!c || !out) return BS_ERR_INVALID;
+  if (!c->have_nodes || !c->have_fit || !c->have_groups || !c->have_pods) {
+    c->last_error = "bs_seq_run needs nodes, fit, groups and pods loaded";
+    return BS_ERR_STATE;
+  }
+  if (!(stages & BS_STAGE_PREFILTER)) { c->last_error = "PREFILTER stage is mandatory"; return BS_ERR_INVALID; }
+  if (c->nranks > 1 || c->reduce_external) { c->last_error = "bs_seq_run is single-rank only (a sequential pass does not shard)"; return BS_ERR_STATE; }
+  int rc = use_device(c);
+  if (rc) return rc;
+  const uint32_t P = c->P, G = c->G, N = c->N, C = c->C, L = c->L;
+  if ((G > c->n_uncaptured && c->max_group_cls >= C) || (P && c->max_pod_cls >= C)) {
+    c->last_error = "fit class index out of range (groups.cls / pods.cls vs the loaded fit classes)";
+    return BS_ERR_INVALID;
+  }
+  if (G > 0x7FFFFFF0u) return BS_ERR_CAPACITY;
+  out->n_released = 0;
+  out->total_ns = 0;
+  out->node_passes = out->node_scans = 0;
+  // ---- scratch: one allocation
+  const size_t nP = std::max<uint32_t>(P, 1), nG = std::max<uint32_t>(G, 1), cap = std::max<uint32_t>(out->cap, 1), stride = std::max<uint32_t>(c->Ncap, 1);
+  size_t o = 0;
+  const size_t o_sc07 = o; o = align256(o + stride * L * 8);
+  const size_t o_sc10 = o; o = align256(o + stride * L * 8);
+  const size_t o_keys = o; o = align256(o + nG * 8);
+  const size_t o_wait = o; o = align256(o + nP * 8);
+  const size_t o_head = o; o = align256(o + nG * 4);
+  const size_t o_nwait = o; o = align256(o + nG * 4);
+  const size_t o_slot = o; o = align256(o + nG * 4);
+  const size_t o_tfirst = o; o = align256(o + nG * 8);
+  const size_t o_res = o;                                   // results: one D2H
+  const size_t o_code = o; o = align256(o + nP);
+  const size_t o_node = o; o = align256(o + nP * 4);
+  const size_t o_fk = o; o = align256(o + nP * 4);
+  const size_t o_leader = o; o = align256(o + nP * 4);
+  const size_t o_rg = o; o = align256(o + cap * 4);
+  const size_t o_rp = o; o = align256(o + cap * 4);
+  const size_t o_ft = o; o = align256(o + cap * 8);
+  const size_t o_rt = o; o = align256(o + cap * 8);
+  const size_t o_info = o; o = align256(o + 64);
+  HIPCHK(c, c->d_seq.reserve(o));
+  uint8_t* base = c->d_seq.as<uint8_t>();
+  GroupsDev gr = groups_dev(c);
+  SeqDev sq{};
+  sq.nreq = c->d_nreq.as<int64_t>();
+  sq.rpres = c->d_rpres.as<uint32_t>();
+  sq.g_matched = const_cast<uint32_t*>(gr.matched);
+  sq.g_sc = const_cast<uint32_t*>(gr.status_scheduled);
+  sq.g_flags = const_cast<uint8_t*>(gr.flags);
+  sq.g_cls = const_cast<uint32_t*>(gr.cls);
+  sq.g_minres = const_cast<int64_t*>(gr.minres);
+  sq.g_mrpres = const_cast<uint32_t*>(gr.mrpres);
+  sq.g_occ = const_cast<uint64_t*>(gr.occupied);
+  sq.sc07 = reinterpret_cast<int64_t*>(base + o_sc07);
+  sq.sc10 = reinterpret_cast<int64_t*>(base + o_sc10);
+  sq.keys = reinterpret_cast<unsigned long long*>(base + o_keys);
+  sq.wait_rec = reinterpret_cast<unsigned long long*>(base + o_wait);
+  sq.head = reinterpret_cast<uint32_t*>(base + o_head);
+  sq.nwait = reinterpret_cast<uint32_t*>(base + o_nwait);
+  sq.slot_of = reinterpret_cast<uint32_t*>(base + o_slot);
+  sq.t_first = reinterpret_cast<unsigned long long*>(base + o_tfirst);
+  sq.pf_code = base + o_code;
+  sq.pod_node = reinterpret_cast<int32_t*>(base + o_node);
+  sq.pf_first_k = reinterpret_cast<uint32_t*>(base + o_fk);
+  sq.pf_leader = reinterpret_cast<int32_t*>(base + o_leader);
+  sq.released_group = reinterpret_cast<uint32_t*>(base + o_rg);
+  sq.released_pods = reinterpret_cast<uint32_t*>(base + o_rp);
+  sq.first_tick = reinterpret_cast<unsigned long long*>(base + o_ft);
+  sq.ready_tick = reinterpret_cast<unsigned long long*>(base + o_rt);
+  sq.cap = out->cap;
+  sq.info = reinterpret_cast<unsigned long long*>(base + o_info);
+  SeqParams prm{};
+  prm.S = c->S;
+  prm.eph_gate = c->cfg.eph_gate;
+  prm.run_filter = (stages & BS_STAGE_FILTER) ? 1u : 0u;
+  prm.C = C;
+  prm.sop_leader0 = c->sop_leader0;
+  prm.keys_in_lds = G <= kSeqKeysLds ? 1u : 0u;
+  const size_t lds = prm.keys_in_lds ? (size_t)nG * 8 : 0;
+  HIPCHK(c, hipMemsetAsync(base + o_info, 0, 64, c->stream));
+  const PodsDev pd = pods_dev(c);
+  const NodesDev nd = nodes_dev(c);
+  switch (c->S <= 4 ? (int)c->S : -1) {
+    case 0: launch_seq_s<0>(c, lds, pd, gr, nd, sq, prm); break;
+    case 1: launch_seq_s<1>(c, lds, pd, gr, nd, sq, prm); break;
+    case 2: launch_seq_s<2>(c, lds, pd, gr, nd, sq, prm); break;
+    case 3: launch_seq_s<3>(c, lds, pd, gr, nd, sq, prm); break;
+    case 4: launch_seq_s<4>(c, lds, pd, gr, nd, sq, prm); break;
+    default: launch_seq_s<-1>(c, lds, pd, gr, nd, sq, prm); break;
+  }
+  LAUNCHCHK(c, BS_KERNEL_QUERY);
+  // ---- results: one copy of the whole result block, then the caller's arrays
+  std::vector<uint8_t> res(o - o_res);
+  HIPCHK(c, hipMemcpyAsync(res.data(), base + o_res, res.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint8_t* rb = res.data() - o_res;
+  const unsigned long long* info = reinterpret_cast<const unsigned long long*>(rb + o_info);
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
+  auto to_ns = [&](unsigned long long ticks) { return (int64_t)((long double)ticks * 1.0e6L / (long double)khz); };
+  out->n_released = (uint32_t)info[0];
+  out->total_ns = to_ns(info[1]);
+  out->node_passes = info[2];
+  out->node_scans = info[3];
+  if (P) {
+    if (out->pf_code) std::memcpy(out->pf_code, rb + o_code, P);
+    if (out->pod_node) std::memcpy(out->pod_node, rb + o_node, (size_t)P * 4);
+    if (out->pf_first_k) std::memcpy(out->pf_first_k, rb + o_fk, (size_t)P * 4);
+    if (out->pf_leader) std::memcpy(out->pf_leader, rb + o_leader, (size_t)P * 4);
+    c->sop_leader0 = (int32_t)(uint32_t)info[4] - 1;         // sop.maxFinishedPG as the pass left it
+  }
+  const uint32_t k = std::min(out->n_released, out->cap);
+  if (k) {
+    if (out->released_group) std::memcpy(out->released_group, rb + o_rg, (size_t)k * 4);
+    if (out->released_pods) std::memcpy(out->released_pods, rb + o_rp, (size_t)k * 4);
+    const unsigned long long* ft = reinterpret_cast<const unsigned long long*>(rb + o_ft);
+    const unsigned long long* rt = reinterpret_cast<const unsigned long long*>(rb + o_rt);
+    for (uint32_t i = 0; i < k; ++i) {
+      if (out->first_ns) out->first_ns[i] = to_ns(ft[i]);
+      if (out->ready_ns) out->ready_ns[i] = to_ns(rt[i]);
+    }
+  }
+  // ---- the host mirrors and everything derived from the state the pass rewrote
+  if (N && P) {
+    HIPCHK(c, hipMemcpy2D(c->h_nreq.data(), (size_t)N * 8, c->d_nreq.p, (size_t)c->Ncap * 8, (size_t)N * 8, L, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(c->h_rpres.data(), c->d_rpres.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_nodes_derive, dim3(1), dim3(kScanBlock), 0, c->stream, nd, c->d_kmap.as<uint32_t>(), c->d_m.as<uint32_t>(), c->d_left4.as<int64_t>(),
+                       c->d_lglob.as<int64_t>(), 0u, 0u);   // left4 / cluster bounds follow the requests (flags, hence kmap, are unchanged)
+    LAUNCHCHK(c, BS_KERNEL_PREPASS);
+  }
+  c->bitmap_valid = false;
+  if (G && P) {
+    const BatchDev b = batch_dev(c);
+    std::vector<uint32_t> cls(G);
+    HIPCHK(c, hipMemcpy(c->h_gflags.data(), gr.flags, G, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cls.data(), gr.cls, (size_t)G * 4, hipMemcpyDeviceToHost));
+    (void)b;
+    c->n_uncaptured = 0;
+    c->n_nominres = 0;
+    c->max_group_cls = 0;
+    for (uint32_t i = 0; i < G; ++i) {
+      if (!(c->h_gflags[i] & BS_GROUP_HAS_POD)) c->n_uncaptured++;
+      else c->max_group_cls = std::max(c->max_group_cls, cls[i]);
+      if (!(c->h_gflags[i] & BS_GROUP_HAS_MINRES)) c->n_nominres++;
+    }
+    if ((rc = analyse_groups(c))) return rc;
+    if ((rc = maybe_analyse_epochs(c))) return rc;
+  }
   return BS_OK;
 }
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BS_ABI_VERSION 3u
+#define BS_ABI_VERSION 4u
 
 enum {
   BS_LANE_CPU = 0,       /* Resource.MilliCPU          */
@@ -460,6 +460,46 @@ typedef struct bs_batch_view {
 int bs_batch_map(bs_ctx* ctx, bs_batch_view* view);
 /* Rows (distinct Filter requests) the last loaded pods can produce: sizes fl_rows / fl_rows_feasible. */
 int bs_filter_rows_count(bs_ctx* ctx, uint32_t* rows);
+
+/* ---- the sequential scheduling pass on the device -------------------------------------------------------------------
+ * The reference decides POD BY POD: upstream's scheduleOne calls PreFilter (core.go:88-167) for the next pod of the queue
+ * against the CURRENT cluster, [Filter, core.go:170-191, on every node when the stage is on,] picks a node and assumes the
+ * pod on it, then Permit (core.go:268-309) counts it into its gang and, at the quorum of core.go:303, the waiting pods of
+ * the gang are released (batchscheduler.go:254-344) and PostBind (core.go:327) counts them into Status.Scheduled — before
+ * the next pod's PreFilter runs.  bs_batch_run answers every pod against a FROZEN snapshot (a pre-screen); bs_seq_run is the
+ * reference's own order of events, one pod at a time, with everything resident on the device and no host round trip in
+ * between: ONE launch walks the resident queue (bs_pods_load / bs_pods_apply) and for every pod runs PreFilter with the
+ * node requests and group counters as the pods before it left them (first-pod capture, MinResources default, OccupiedBy,
+ * deny entries, findMaxPG, the node scan), the node choice, the assume step, Permit and the release.
+ * Node choice is upstream's business, not the plugin's; the rule here is the one host/bs_drain.cpp and the CPU replay
+ * (oracle/bs_oracle_seq.c) state: FIRST FIT in list order over nodes without a BS_NODE_* flag whose checkFit bit is set for
+ * the pod's class, that pass the plugin's Filter when BS_STAGE_FILTER is on, and that hold the request (lane j in {cpu, mem,
+ * eph} binds when the pod asks for it; pods lane: requested + 1 <= allocatable; a requested scalar needs the allocatable
+ * key).  Assume: requested += request, pods lane + 1.  A pod that passes PreFilter but finds no node holds nothing; pods of
+ * a gang that never reaches its quorum keep what they assumed (as the reference does until the Permit timeout).
+ * `stages`: BS_STAGE_PREFILTER (mandatory) [| BS_STAGE_FILTER].  Single-rank contexts only.
+ * On return the context's node requests, group counters / flags / MinResources / OccupiedBy ARE the state the pass left
+ * (bs_groups_read, bs_nodes_read; later batches and passes start from it); the queue itself is unchanged (remove the released
+ * pods with bs_pods_apply).  Results are bit-identical to the reference's sequential pass on the same inputs
+ * (tests/test_gpu_seq.py against oracle/bs_oracle_seq.c).  Synchronous: returns when the pass is done. */
+typedef struct bs_seq_out {
+  uint8_t*  pf_code;         /* [p] BS_PF_* of every pod's PreFilter call (NULL ok)                                    */
+  uint32_t* pf_first_k;      /* [p] as bs_batch_out.pf_first_k (NULL ok)                                               */
+  int32_t*  pf_leader;       /* [p] sop.maxFinishedPG as the pod's PreFilter call left it, -1 none (NULL ok)           */
+  int32_t*  pod_node;        /* [p] node of every RELEASED pod (its gang reached the quorum, or it has no gang), else -1 (NULL ok) */
+  uint32_t  cap;             /* capacity of the four per-gang arrays below                                             */
+  uint32_t* released_group;  /* [cap] gangs in the order their quorum turned true                                      */
+  uint32_t* released_pods;   /* [cap] pods released with each (late members of a gang that is through are added)       */
+  int64_t*  first_ns;        /* [cap] device clock, ns since the pass began: the gang's first pod entered PreFilter    */
+  int64_t*  ready_ns;        /* [cap] ... the quorum of core.go:303 turned true (NULL ok for all four)                 */
+  uint32_t  n_released;      /* out: gangs released (may exceed cap: the first cap are recorded)                       */
+  int64_t   total_ns;        /* out: device time of the whole pass                                                     */
+  uint64_t  node_passes, node_scans;   /* out: sweeps over the node list, and how many of them carried a PreFilter scan */
+} bs_seq_out;
+int bs_seq_run(bs_ctx* ctx, uint32_t stages, bs_seq_out* out);
+/* The node requests as the context holds them (after bs_nodes_load / bs_nodes_apply / bs_nodes_assume / bs_seq_run):
+ * requested[L][n] lane-major, requested_present[n]; n = bs_nodes_count. */
+int bs_nodes_read(bs_ctx* ctx, int64_t* requested, uint32_t* requested_present);
 
 /* ---- batched queue ordering ---------------------------------------- */
 /* The permutation that sorts the pending pods the way the scheduling queue does through ScheduleOperation.Compare

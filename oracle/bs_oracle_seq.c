@@ -37,6 +37,8 @@ typedef struct orc_seq_io {
   int64_t* ready_ns;         /* [cap] quorum turned true */
   uint32_t n_released;
   int64_t total_ns;
+  uint32_t* pf_first_k;      /* [p] optional: first_k of the pod's node scan (as bs_batch_out.pf_first_k)                 */
+  int32_t* pf_leader;        /* [p] optional: sop.maxFinishedPG as the pod's PreFilter left it (-1 none)                  */
 } orc_seq_io;
 
 static int64_t mono_ns(void) {
@@ -87,8 +89,10 @@ void orc_seq_replay(orc_seq_io* io) {
     uint32_t fk;
     const uint8_t code = orc_prefilter(sop, pods, i, &fk);
     io->pf_code[i] = code;
-    if (!BS_PF_IS_PASS(code)) continue;
     const int32_t leader = sop->has_max_status ? sop->max_finished_pg : -1;
+    if (io->pf_first_k) io->pf_first_k[i] = fk;
+    if (io->pf_leader) io->pf_leader[i] = leader;
+    if (!BS_PF_IS_PASS(code)) continue;
     int64_t req[BS_MAX_LANES];
     for (uint32_t j = 0; j < L; ++j) req[j] = pods->req[(size_t)j * P + i];
     const uint32_t pres = pods->req_present[i], cls = pods->cls[i];

@@ -1,0 +1,224 @@
+"""GPU tests of bs_seq_run — the reference's scheduling cycle POD BY POD on the device (csrc/bs_seq.hpp) — against the CPU
+restatement of the same pass (oracle/bs_oracle_seq.c: PreFilter core.go:88-167 with the deny / capture / occupancy side
+effects, [Filter core.go:170-191, :514-564,] first-fit node choice, assume, Permit core.go:268-309, release + PostBind
+core.go:327).  Everything through the C ABI; bit-exact: every pod's code, first_k and stale leader, the node of every released
+pod, the gangs in release order, and the node requests and the whole group state the pass leaves behind."""
+import numpy as np
+import pytest
+
+import naive_ref as nv
+from scenarios import random_objects
+from test_drain import compare_order, complete_gangs, readme_scene
+from test_gpu_parity import load_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_groups_equal(got, exp, soa, where=""):
+    assert np.array_equal(got.min_member, exp.min_member), where
+    assert np.array_equal(got.status_scheduled, exp.status_scheduled), f"{where}: status_scheduled"
+    assert np.array_equal(got.matched, exp.matched), f"{where}: matched"
+    assert np.array_equal(got.flags, exp.flags), f"{where}: flags {got.flags} vs {exp.flags}"
+    has_pod = (exp.flags & soa.GROUP_HAS_POD) != 0
+    assert np.array_equal(got.cls[has_pod], exp.cls[has_pod]), f"{where}: cls"
+    has_mr = (exp.flags & soa.GROUP_HAS_MINRES) != 0
+    assert np.array_equal(got.min_resources[:, has_mr], exp.min_resources[:, has_mr]), f"{where}: MinResources"
+    assert np.array_equal(got.min_resources_present[has_mr], exp.min_resources_present[has_mr]), f"{where}: MinResources keys"
+    assert np.array_equal(got.occupied_by, exp.occupied_by), f"{where}: OccupiedBy"
+
+
+def check_pass(ctx, s, soa, where=""):
+    """one bs_seq_run on `ctx` against the oracle's record `s` of the same pass"""
+    r = ctx.seq_run(soa.STAGE_PREFILTER | (s["stages"] & soa.STAGE_FILTER))
+    bad = np.nonzero(r["pf_code"] != s["pf_code"])[0]
+    assert bad.size == 0, f"{where}: pf_code differs first at pod {bad[0]}: {r['pf_code'][bad[0]]} vs {s['pf_code'][bad[0]]}"
+    assert np.array_equal(r["pf_first_k"], s["pf_first_k"]), f"{where}: first_k"
+    assert np.array_equal(r["pf_leader"], s["pf_leader"]), f"{where}: stale leader"
+    assert np.array_equal(r["pod_node"], s["pod_node"]), f"{where}: pod_node"
+    assert r["n_released"] == s["n_released"]
+    assert r["released_group"].tolist() == s["released_group"].tolist(), f"{where}: gangs in release order"
+    assert r["released_pods"].tolist() == s["released_pods"].tolist(), f"{where}: pods per gang"
+    req, pres = ctx.read_node_requests()
+    assert np.array_equal(req, s["nodes"].requested), f"{where}: node requests after the pass"
+    assert np.array_equal(pres, s["nodes"].requested_present), f"{where}: node request keys after the pass"
+    assert_groups_equal(ctx.read_groups(), s["groups"], soa, where)
+    if r["n_released"]:
+        assert np.all(r["ready_ns"] >= r["first_ns"]) and np.all(np.diff(r["ready_ns"]) >= 0) and r["total_ns"] >= r["ready_ns"][-1]
+    return r
+
+
+def oracle_pass(orc, nodes, fit, groups, pods, stages):
+    s = orc.seq_replay(nodes, fit, groups, pods, stages)
+    s["stages"] = stages
+    return s
+
+
+def gang_scene(seed, soa, n_nodes=48, n_groups=10, n_pods=140, filter_on=False):
+    """random object scene shaped so that gangs really get through: roomy nodes, gangs of 2..6 with their pods in the queue"""
+    rng = np.random.default_rng(seed)
+    sc = random_objects(seed, n_nodes=n_nodes, n_groups=n_groups, n_pods=n_pods, n_scalars=seed % 3, n_classes=3)
+    nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"], denied=sc["denied"], permitted=sc["permitted"])
+    if seed % 4 != 3:                                       # most scenes: make room (the raw scenes are 0-110 % utilised)
+        nodes.requested[:3] = (nodes.requested[:3] * rng.uniform(0.0, 0.6, nodes.n)).astype(np.int64)
+        nodes.requested[3] = np.minimum(nodes.requested[3], np.maximum(nodes.allocatable[3] - rng.integers(1, 30, nodes.n), 0))
+    if seed % 3 == 0:
+        pods = compare_order(pods)
+    return nodes, fit, groups, pods
+
+
+@pytest.mark.parametrize("filter_on", [False, True], ids=["prefilter", "prefilter+filter"])
+@pytest.mark.parametrize("seed", range(4200, 4260))
+def test_seq_pass_random_object_scenes(seed, filter_on, bsa, soa, orc):
+    st = soa.STAGE_PREFILTER | soa.STAGE_TALLY | (soa.STAGE_FILTER if filter_on else 0)
+    nodes, fit, groups, pods = gang_scene(seed, soa)
+    s = oracle_pass(orc, nodes, fit, groups, pods, st)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        check_pass(ctx, s, soa, f"seed {seed}")
+
+
+@pytest.mark.parametrize("seed", range(4300, 4330))
+def test_seq_pass_raw_edge_scenes(seed, bsa, soa, orc):
+    """the unshaped scenes: nil / unschedulable / taint-error nodes, missing groups, permitted pods, MinMember 0 (the uint32
+    division of core.go:716-717), fully scheduled leaders (the tie rule :729-731), negative scalar requests"""
+    sc = random_objects(seed)
+    nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"], denied=sc["denied"], permitted=sc["permitted"])
+    for st in (soa.STAGE_PREFILTER, soa.STAGE_PREFILTER | soa.STAGE_FILTER):
+        s = oracle_pass(orc, nodes, fit, groups, pods, st)
+        with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+            check_pass(ctx, s, soa, f"seed {seed} stages {st}")
+
+
+def test_seq_pass_readme_race_scene(bsa, soa, orc):
+    """README.md:78-188 (BASELINE config 1): group1 5/5 through, group2's first pod rejected (:140-144), the rest denied"""
+    nodes, fit, groups, pods = readme_scene(soa)
+    st = soa.STAGE_PREFILTER
+    s = oracle_pass(orc, nodes, fit, groups, pods, st)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        r = check_pass(ctx, s, soa, "readme")
+    assert r["released_group"].tolist() == [0] and r["released_pods"].tolist() == [5]
+    assert (r["pod_node"] >= 0).tolist() == [True] * 5 + [False] * 5
+    assert r["pf_code"][5] == soa.PF_REJECT_FIRST and np.all(r["pf_code"][6:] == soa.PF_ERR_DENIED)
+
+
+@pytest.mark.parametrize("config,scenario", [("tiny", "cold"), ("tiny", "warm"), ("tiny", "tail"), ("tiny", "busy"),
+                                             ("cfg2", "cold"), ("cfg2", "warm"), ("cfg2", "tail"), ("cfg2", "busy")])
+@pytest.mark.parametrize("order", ["as-is", "compare"])
+@pytest.mark.parametrize("filter_on", [False, True], ids=["prefilter", "prefilter+filter"])
+def test_seq_pass_synthetic_configs(config, scenario, order, filter_on, bsa, soa, orc):
+    st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if filter_on else 0)
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
+    if order == "compare":
+        pods = compare_order(pods)
+    s = oracle_pass(orc, nodes, fit, groups, pods, st)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        r = check_pass(ctx, s, soa, f"{config}/{scenario}/{order}")
+    if scenario == "cold" and order == "compare":
+        assert r["n_released"] > 0
+
+
+@pytest.mark.parametrize("scenario,filter_on", [("tail", False), ("cold", False), ("tail", True)])
+def test_seq_pass_cfg3_full_size(scenario, filter_on, bsa, soa, orc):
+    """BASELINE config 3 (10k pods / 2k groups / 5k nodes, 5 lanes), the whole pass against the oracle's"""
+    st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if filter_on else 0)
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg3", scenario)
+    pods = compare_order(pods)
+    s = oracle_pass(orc, nodes, fit, groups, pods, st)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        r = check_pass(ctx, s, soa, f"cfg3/{scenario}")
+    assert r["n_released"] > 100
+
+
+def test_state_after_a_pass_feeds_batches_and_the_next_pass(bsa, soa, orc):
+    """bs_seq_run leaves the context in the state the pass produced: a batch on it == the oracle's batch on the oracle's
+    post-pass state; released pods leave the queue (bs_pods_apply), new pods arrive, and a second pass == the oracle's."""
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "cold")
+    pods = compare_order(pods)
+    st = soa.STAGE_PREFILTER
+    s1 = oracle_pass(orc, nodes, fit, groups, pods, st)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        r1 = check_pass(ctx, s1, soa, "first pass")
+        exp = orc.Sop(orc.Snapshot(s1["nodes"], fit), s1["groups"]).batch(pods, soa.STAGE_ALL, bitmap=False)
+        got = ctx.batch(soa.STAGE_ALL, bitmap=False)
+        for name in ("pf_code", "pf_first_k", "fl_code", "fl_feasible", "group_admit", "group_ready"):
+            assert np.array_equal(getattr(got, name), getattr(exp, name)), f"batch after the pass: {name}"
+        gone = np.nonzero(r1["pod_node"] >= 0)[0].astype(np.uint32)
+        assert gone.size
+        ctx.apply_pods(remove=gone)
+        left = pods.take(np.nonzero(r1["pod_node"] < 0)[0])
+        assert ctx.read_pods().equal(left)
+        s2 = oracle_pass(orc, s1["nodes"], fit, s1["groups"], left, st)
+        check_pass(ctx, s2, soa, "second pass")
+
+
+def test_seq_pass_many_groups_keys_in_global_memory(bsa, soa, orc):
+    """more groups than the LDS key window holds (8192): the findMaxPG keys live in global memory"""
+    rng = np.random.default_rng(77)
+    nodes, fit, _, _, _ = bsa.synth.make("cfg2", "cold")
+    G, per = 9000, 2
+    groups = soa.Groups.empty(G, nodes.lanes)
+    groups.min_member[:] = per
+    group = np.repeat(np.arange(G, dtype=np.int32), per)
+    req = np.zeros((nodes.lanes, G * per), np.int64)
+    req[0] = rng.choice([100, 250, 500], G * per)
+    req[1] = rng.choice([1, 2], G * per) * (1 << 28)
+    pods = soa.Pods(group, req, np.zeros(G * per, np.uint32), rng.integers(0, fit.n_classes, G * per).astype(np.uint32), np.zeros(G * per, np.uint64),
+                    np.zeros(G * per, np.uint8))
+    s = oracle_pass(orc, nodes, fit, groups, pods, soa.STAGE_PREFILTER)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        r = check_pass(ctx, s, soa, "9000 groups")
+    assert r["n_released"] > 50
+
+
+@pytest.mark.parametrize("lanes", [9, 16])
+def test_seq_pass_many_scalar_lanes(lanes, bsa, soa, orc):
+    """S > 4: the kernel variant with a run-time lane count"""
+    rng = np.random.default_rng(lanes)
+    S = lanes - 4
+    N, G, per = 70, 12, 4
+    alloc = np.zeros((lanes, N), np.int64)
+    alloc[0], alloc[1], alloc[2], alloc[3] = 32000, 64 << 30, 100 << 30, 110
+    alloc[4:] = rng.integers(0, 9, (S, N))
+    ap = rng.integers(0, 1 << S, N).astype(np.uint32)
+    reqd = np.zeros((lanes, N), np.int64)
+    reqd[0] = rng.integers(0, 20000, N)
+    reqd[1] = rng.integers(0, 30 << 30, N)
+    reqd[3] = rng.integers(0, 40, N)
+    reqd[4:] = rng.integers(0, 4, (S, N))
+    rp = (rng.integers(0, 1 << S, N) & ap).astype(np.uint32)
+    nodes = soa.Nodes(alloc, reqd, ap, rp, np.zeros(N, np.uint8))
+    fit = soa.FitMasks.from_bool(rng.random((2, N)) < 0.9)
+    groups = soa.Groups.empty(G, lanes)
+    groups.min_member[:] = per
+    P = G * per
+    req = np.zeros((lanes, P), np.int64)
+    req[0] = rng.choice([500, 1000, 2000], P)
+    req[1] = rng.choice([1, 2, 4], P) << 30
+    pres = rng.integers(0, 1 << S, P).astype(np.uint32) * (rng.random(P) < 0.5)
+    req[4:] = rng.integers(0, 3, (S, P)) * ((pres[None, :] >> np.arange(S)[:, None]) & 1)
+    pods = soa.Pods(np.repeat(np.arange(G, dtype=np.int32), per), req, pres.astype(np.uint32), rng.integers(0, 2, P).astype(np.uint32), np.zeros(P, np.uint64),
+                    np.zeros(P, np.uint8))
+    for st in (soa.STAGE_PREFILTER, soa.STAGE_PREFILTER | soa.STAGE_FILTER):
+        s = oracle_pass(orc, nodes, fit, groups, pods, st)
+        with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+            check_pass(ctx, s, soa, f"{lanes} lanes")
+
+
+def test_seq_pass_refusals_and_empty_inputs(bsa, soa, orc):
+    nodes, fit, groups, pods, _ = bsa.synth.make("tiny", "cold")
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        with pytest.raises(bsa.BsError) as e:
+            ctx.seq_run(soa.STAGE_FILTER)                     # PREFILTER is mandatory
+        assert e.value.status == -1
+        ctx.set_shard(0, 2)
+        with pytest.raises(bsa.BsError) as e:
+            ctx.seq_run(soa.STAGE_PREFILTER)                  # a sequential pass does not shard
+        assert e.value.status == -4
+    empty = pods.take(np.zeros(0, np.int64))
+    with load_ctx(bsa, nodes, fit, groups, empty) as ctx:
+        r = ctx.seq_run(soa.STAGE_PREFILTER)
+        assert r["n_released"] == 0 and r["pf_code"].size == 0
+    none = soa.Nodes(np.zeros((nodes.lanes, 0), np.int64), np.zeros((nodes.lanes, 0), np.int64), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint8))
+    fit0 = soa.FitMasks.from_bool(np.ones((fit.n_classes, 0), bool))
+    s = oracle_pass(orc, none, fit0, groups, pods, soa.STAGE_PREFILTER)
+    with load_ctx(bsa, none, fit0, groups, pods) as ctx:
+        check_pass(ctx, s, soa, "no nodes")

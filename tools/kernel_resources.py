@@ -1,0 +1,34 @@
+"""Per-kernel resource usage of the built libbsched.so: VGPRs, SGPRs, LDS, scratch (`.private_segment_fixed_size` must be 0 for
+the hot kernels: a kernel that uses scratch pays for the scratch set-up on every launch).  Usage: python tools/kernel_resources.py [substring ...]"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "batch-scheduler_amd", "libbsched.so")
+
+
+def resources(lib=LIB):
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat"), os.path.join(d, "co")
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib], check=True)
+        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if not name:
+            continue
+        get = lambda k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1))
+        out[name.group(1)] = dict(vgpr=get("vgpr_count"), sgpr=get("sgpr_count"), lds=get("group_segment_fixed_size"), scratch=get("private_segment_fixed_size"),
+                                  agpr=int(blk.split()[0]))
+    return out
+
+
+if __name__ == "__main__":
+    pats = sys.argv[1:]
+    for k, v in sorted(resources().items()):
+        if not pats or any(p in k for p in pats):
+            print(f"{k[:90]:90s} vgpr {v['vgpr']:3d} sgpr {v['sgpr']:3d} lds {v['lds']:6d} scratch {v['scratch']}")
