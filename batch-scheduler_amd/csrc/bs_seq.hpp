@@ -4,7 +4,7 @@
 //   PreFilter  core.go:88-167    deny / permitted entries, fillOccupiedObj (:477-512), findMaxPG (:701-739), the node scan
 //                                compareClusterResourceAndRequire (:595-632) against the CURRENT node requests
 //   [Filter    core.go:170-191, :514-564 on every node, when the stage is on]
-//   node choice + assume         first fit in list order (the rule host/bs_drain.cpp and oracle/bs_oracle_seq.c state),
+//   node choice + assume         first fit in list order (the rule host/bs_drain.cpp states; the CPU replay the tests use restates it),
 //                                requested += request
 //   Permit     core.go:268-309   matched + 1 (:290), quorum (:303), latch (:305)
 //   release    batchscheduler.go:254-344 + PostBind core.go:327: the waiting pods of the gang bind, Status.Scheduled += k
