@@ -4,26 +4,34 @@
 //   PreFilter  core.go:88-167    deny / permitted entries, fillOccupiedObj (:477-512), findMaxPG (:701-739), the node scan
 //                                compareClusterResourceAndRequire (:595-632) against the CURRENT node requests
 //   [Filter    core.go:170-191, :514-564 on every node, when the stage is on]
-//   node choice + assume         first fit in list order (the rule host/bs_drain.cpp states; the CPU replay the tests use restates it),
-//                                requested += request
+//   node choice + assume         first fit in list order (the rule host/bs_drain.cpp states; the CPU replay the tests use
+//                                restates it), requested += request
 //   Permit     core.go:268-309   matched + 1 (:290), quorum (:303), latch (:305)
 //   release    batchscheduler.go:254-344 + PostBind core.go:327: the waiting pods of the gang bind, Status.Scheduled += k
 // Every pod's decision depends on what the pods before it did to the nodes and the group counters, so the pass is ONE
 // persistent workgroup (1024 threads, 16 waves) that walks the queue; the O(nodes) and O(groups) parts of a step are
 // data-parallel inside it:
 //   * findMaxPG is a block maximum over 64-bit keys (progress + 1) << 32 | (inverted index << 1) | "fully scheduled" kept in
-//     LDS (one key changes per Permit / capture / release); the tie rule of :729-731 is walked exactly only when the
-//     winner is fully scheduled.
-//   * the node scan and the first-fit choice are ONE pass over the nodes: wave w owns a contiguous range of the list,
-//     sums singleNodeResource over it (phase 1), the 16 totals are exchanged through LDS, and phase 2 forms the running
-//     sums of core.go:621 with DPP wave scans and finds the first row that covers the request (:623) — EXEC-free ballots.
-//     int64(float32(allocatable) * percent) (:656-659,667) does not depend on the requests: both percents are derived
-//     once at the start of the pass (allocatable never changes during a pass).
+//     LDS; one key changes per Permit / capture / release, and the fold is only repeated after such a change.  The tie rule
+//     of :729-731 is walked exactly only when the winner is fully scheduled.
+//   * singleNodeResource (:634-670) is kept as two resident arrays left07 / left10 = int64(float32(allocatable) * percent) -
+//     requested (allocatable never changes during a pass; an assume step patches one node), so the node scan reads ONE
+//     int64 per resource lane and node.  The scan goes over the list in ROUNDS of 16 tiles of 64 nodes (one tile per wave):
+//     DPP wave scans give the running sums inside a tile (v_add_co_u32_dpp / v_addc_co_u32_dpp: the shift rides on the add),
+//     the 16 tile totals are exchanged through LDS (one barrier per round, LDS-only fences so that the next round's loads
+//     stay in flight across it), and the pass stops at the round of the first row that covers the request — the reference's
+//     early exit (:623-627).
+//   * the first-fit choice looks only at tiles whose per-tile bound (max free cpu / memory over schedulable nodes, kept in
+//     LDS, tightened whenever a tile was looked at in vain) can hold the pod; the lane that owns the chosen node performs the
+//     assume step from the registers it already holds.
 //   * the control flow of a pod (a few dozen scalar decisions) runs redundantly in every wave from wave-uniform loads:
 //     no broadcast step, and the block only meets at the barriers the reductions need anyway.
-// Mutable state (node requests, group counters / flags / MinResources / OccupiedBy) is read with vector loads only
-// (relaxed atomics at workgroup scope: never through the scalar cache, which this kernel's own stores do not update) and
-// written by one thread; all waves of a workgroup share the CU's L1, so __syncthreads() orders them.
+// Mutable state read at wave-uniform addresses (group counters / flags / MinResources / OccupiedBy) is read with vector loads
+// only (relaxed atomics at workgroup scope: never through the scalar cache, which this kernel's own stores do not update) and
+// written by one thread; all waves of a workgroup share the CU's L1, so a barrier orders them.  READ PHASE / WRITE PHASE
+// discipline: between the barrier at the top of a pod and the end of its node scan nothing is written (except inside the
+// barrier-bracketed capture step); behind it only thread 0 (and the lane that owns the chosen node) write, and nobody else
+// reads mutable global state until the next pod's top barrier.
 #pragma once
 
 #include "bs_kernels.hpp"
@@ -33,6 +41,8 @@ namespace bs {
 constexpr int kSeqBlock = 1024;
 constexpr int kSeqWaves = kSeqBlock / 64;
 constexpr uint32_t kSeqKeysLds = 8192;     // groups whose findMaxPG keys fit the LDS window (64 KB)
+constexpr uint32_t kSeqPruneTiles = 1024;  // 64-node tiles whose first-fit bounds fit the LDS window (65 536 nodes)
+constexpr uint32_t kSeqWaitList = 512;     // waiting pods of the current gang kept in LDS
 
 struct SeqDev {
   // resident state the pass mutates
@@ -40,7 +50,8 @@ struct SeqDev {
   uint32_t* rpres;               // [n]
   uint32_t* g_matched; uint32_t* g_sc; uint8_t* g_flags; uint32_t* g_cls; int64_t* g_minres; uint32_t* g_mrpres; uint64_t* g_occ;
   // scratch
-  int64_t* sc07; int64_t* sc10;  // [L][stride] int64(float32(allocatable) * 0.7 | 1.0)
+  int64_t* left07; int64_t* left10;  // [L][stride] int64(float32(allocatable) * 0.7 | 1.0) - requested (core.go:656-659,667)
+  uint32_t* nmeta;               // [n] bit 0: a row of the scan (not skipped, core.go:606-617), bit 1: taint error (:639-641), bits 4..: scalar keys of singleNodeResource (:662-668)
   unsigned long long* keys;      // [G] findMaxPG keys when G > kSeqKeysLds
   unsigned long long* wait_rec;  // [P] waiting pod: (next waiting pod of its gang + 1) << 32 | node it was assumed on
   uint32_t* head;                // [G] last waiting pod of the gang + 1, 0 = none
@@ -51,32 +62,81 @@ struct SeqDev {
   uint8_t* pf_code; int32_t* pod_node; uint32_t* pf_first_k; int32_t* pf_leader;
   uint32_t* released_group; uint32_t* released_pods; unsigned long long* first_tick; unsigned long long* ready_tick;
   uint32_t cap;
-  unsigned long long* info;      // [0] gangs released [1] clock ticks of the pass [2] node passes [3] node scans [4] sop leader at the end + 1
+  unsigned long long* info;      // [0] gangs released [1] clock ticks of the pass [2] first-fit searches [3] node scans [4] sop leader at the end + 1
+                                 // [5] scan rounds executed [6] tiles the first-fit searches looked at [7] findMaxPG folds
 };
+
+// Probe build only (-DBS_SEQ_PROBE, tools/seq_bench.py --probe; never the shipped library): shader-clock cycles per phase of a
+// pod, summed over the pass, in info[8..15]: control (state in registers / group loads), capture, findMaxPG fold, scan,
+// first fit + assume, Permit / release, the top barrier.
+#ifdef BS_SEQ_PROBE
+#define BS_SEQ_T(k) do { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); ph[k] += _t - tl; tl = _t; } while (0)
+#else
+#define BS_SEQ_T(k) ((void)0)
+#endif
 
 struct SeqParams {
   uint32_t S, eph_gate, run_filter, C;
   int32_t sop_leader0;           // sop.maxFinishedPG carried into the pass (-1 none)
-  uint32_t keys_in_lds;
+  uint32_t keys_in_lds, prune;
 };
 
 // ---- wave-uniform loads of state this kernel itself writes: vector loads, value moved to SGPRs ---------------------
-__device__ __forceinline__ uint32_t seq_ld32(const uint32_t* p) {
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-}
-__device__ __forceinline__ uint32_t seq_ld8(const uint8_t* p) {
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-}
-__device__ __forceinline__ uint64_t seq_ld64(const uint64_t* p) {
-  const uint64_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-  return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ int64_t seq_ldi64(const int64_t* p) { return (int64_t)seq_ld64(reinterpret_cast<const uint64_t*>(p)); }
+__device__ __forceinline__ uint32_t seq_raw32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t seq_raw8(const uint8_t* p) { return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint64_t seq_raw64(const void* p) { return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
   const uint32_t lo = uni32((uint32_t)v), hi = uni32((uint32_t)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+#ifdef BS_SEQ_UNSAFE_BARRIERS   // timing experiment only: every barrier LDS-only
+#define BS_SEQ_FULL_BARRIER() lds_barrier()
+#else
+#define BS_SEQ_FULL_BARRIER() __syncthreads()
+#endif
+// a barrier that orders LDS only: the global loads a wave has in flight (the next round's tile) stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// 64-bit add with the DPP shift riding on the add itself (two instructions per step instead of two moves + two adds).
+// Lanes without a source, and rows masked out, are not written.  The leading s_nop covers the "VALU write -> DPP read"
+// hazard of whatever produced the operands (the assembler does not see into inline asm).
+#define BS_DPP_ADD64(lo, hi, CTRL) \
+  asm volatile("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL : "+v"(lo), "+v"(hi) : : "vcc")
+__device__ __forceinline__ unsigned long long seq_wave_scan64(unsigned long long v) {        // inclusive, all 64 lanes active
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  BS_DPP_ADD64(lo, hi, "row_shr:1 row_mask:0xf bank_mask:0xf");
+  BS_DPP_ADD64(lo, hi, "row_shr:2 row_mask:0xf bank_mask:0xf");
+  BS_DPP_ADD64(lo, hi, "row_shr:4 row_mask:0xf bank_mask:0xf");
+  BS_DPP_ADD64(lo, hi, "row_shr:8 row_mask:0xf bank_mask:0xf");
+  BS_DPP_ADD64(lo, hi, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+  BS_DPP_ADD64(lo, hi, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long seq_row_scan64(unsigned long long v) {         // inclusive inside each row of 16 lanes
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  BS_DPP_ADD64(lo, hi, "row_shr:1 row_mask:0xf bank_mask:0xf");
+  BS_DPP_ADD64(lo, hi, "row_shr:2 row_mask:0xf bank_mask:0xf");
+  BS_DPP_ADD64(lo, hi, "row_shr:4 row_mask:0xf bank_mask:0xf");
+  BS_DPP_ADD64(lo, hi, "row_shr:8 row_mask:0xf bank_mask:0xf");
+  return ((unsigned long long)hi << 32) | lo;
+}
+// minimum over lanes 0..15 (one value per wave of the block), wave-uniform result
+__device__ __forceinline__ uint32_t seq_row_min_u32(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)BS_INF, (int)v, 0x111, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)BS_INF, (int)v, 0x112, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)BS_INF, (int)v, 0x114, 0xF, 0xF, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)BS_INF, (int)v, 0x118, 0xF, 0xF, false));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
 }
 
 // findMaxPG key of one group (core.go:705-717): 0 = not a candidate, ~0 = the uint32 division by zero of :716-717
@@ -100,178 +160,267 @@ __device__ __forceinline__ unsigned long long wave_max_u64_all(unsigned long lon
 struct SeqShared {
   unsigned long long kmax[kSeqWaves];
   uint32_t red[kSeqWaves];
-  unsigned long long tot[kSeqWaves][BS_MAX_LANES];
-  uint32_t wpres[kSeqWaves];
-  uint32_t fk[kSeqWaves];
-  uint32_t pick[kSeqWaves];
+  unsigned long long tot[2][BS_MAX_LANES][kSeqWaves];   // per round parity: tile totals, lane-major so that lanes 0..15 read one row
+  uint32_t wpres[2][kSeqWaves];
+  uint32_t fk[2][kSeqWaves];
+  unsigned long long cmask[kSeqWaves];                   // first fit: candidate tiles of a chunk of 1024
+  uint32_t pick[2][kSeqWaves];
+  long long pmax[2][kSeqPruneTiles];                     // per tile: max of allocatable - requested (cpu, memory) over schedulable nodes
+  uint32_t wl_pod[kSeqWaitList], wl_node[kSeqWaitList];  // waiting pods of the CURRENT gang (released in parallel; the chain in global memory is the fallback)
 };
 
-// What one node pass is asked: the PreFilter scan (table = fit class + percent, request) and / or the first-fit choice.
-struct SeqQuery {
-  bool scan, pick;
-  uint32_t tcls; bool pct07;
-  Res R;                         // scan request (Resource.Add-normalised)
-  uint32_t pcls;                 // pick: the pod's own fit class
-  int64_t preq[BS_MAX_LANES];    // pick: raw request lanes of the pod
+// ---------------------------------------------------------------------------------------------------------------------
+// compareClusterResourceAndRequire (core.go:595-632) against the resident left arrays.  Returns the node index of the
+// first row whose running sum covers R (first_k), BS_INF if none; wave-uniform, identical in every wave.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TS>
+__device__ __forceinline__ uint32_t seq_scan(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, uint32_t tcls, bool pct07,
+                                             const Res& R, unsigned long long& rounds_done) {
+  const Shape<TS> sh(prm.S);
+  const uint32_t L = sh.L(), S = sh.S();
+  const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
+  const uint32_t N = nd.n;
+  if (!N) return BS_INF;
+  const uint32_t ntiles = (N + 63u) >> 6, rounds = (ntiles + kSeqWaves - 1u) / kSeqWaves;
+  const int64_t* lf = pct07 ? sq.left07 : sq.left10;
+  const uint32_t* fitrow = nd.fit + (size_t)tcls * nd.fit_words;
+  BS_SEQ_FULL_BARRIER();                                            // the assume steps of earlier pods (left arrays, meta words) have landed
+  struct Tile { int64_t v[BS_MAX_LANES]; uint32_t meta, fitw; };
+  auto load_tile = [&](uint32_t r, Tile& t) {
+    const uint32_t n = ((r * kSeqWaves + (uint32_t)w) << 6) + (uint32_t)lane;
+    const uint32_t nn = n < N ? n : N - 1u;
+    t.meta = n < N ? sq.nmeta[nn] : 0u;
+    t.fitw = fitrow[nn >> 5];
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < L) t.v[j] = lf[(size_t)j * nd.stride + nn];
+  };
+  Tile cur, nxt;
+  load_tile(0, cur);
+  nxt = cur;
+  unsigned long long carry[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) carry[j] = 0;
+  uint32_t pcarry = 0, found = BS_INF;
+  uint32_t r = 0;
+  for (; r < rounds; ++r) {
+    if (r + 1 < rounds) load_tile(r + 1, nxt);
+    const uint32_t b = r & 1u;
+    const uint32_t n = ((r * kSeqWaves + (uint32_t)w) << 6) + (uint32_t)lane;
+    const bool row = n < N && (cur.meta & 1u);                                                        // core.go:606-617
+    const bool fit = row && !(cur.meta & 2u) && ((cur.fitw >> (n & 31u)) & 1u);                        // :639-645
+    const uint32_t pres = fit ? (cur.meta >> 4) : 0u;                                                 // :662-668
+    unsigned long long x[BS_MAX_LANES];
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+      if (j < L) {
+        const bool live = fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
+        x[j] = seq_wave_scan64(live ? (unsigned long long)cur.v[j] : 0ull);                           // running sums inside the tile (:621)
+        if (lane == 63) sh_.tot[b][j][w] = x[j];
+      }
+    }
+    unsigned long long km[BS_MAX_SCALARS];
+    uint32_t wp = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+      km[s] = 0;
+      if (s < S) {
+        km[s] = __ballot((pres >> s) & 1u);
+        if (km[s]) wp |= 1u << s;
+      }
+    }
+    if (lane == 0) sh_.wpres[b][w] = wp;
+    lds_barrier();
+    // a hit of the PREVIOUS round is visible now: the reference's loop ended there (early exit, :623-627)
+    if (r > 0) {
+      const uint32_t prev = seq_row_min_u32(lane < kSeqWaves ? sh_.fk[b ^ 1u][lane] : BS_INF);
+      if (prev != BS_INF) { found = prev; break; }
+    }
+    // offsets: lanes 0..15 hold the 16 tile totals of this round
+    bool ok = row;
+    const uint32_t pw = lane < kSeqWaves ? sh_.wpres[b][lane] : 0u;
+    uint32_t pbefore = pcarry, pround = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+      if (j < L) {
+        const unsigned long long t = lane < kSeqWaves ? sh_.tot[b][j][lane] : 0ull;
+        const unsigned long long inc = seq_row_scan64(t);
+        const unsigned long long off = carry[j] + (w ? readlane_u64(inc, w - 1) : 0ull);
+        carry[j] += readlane_u64(inc, kSeqWaves - 1);
+        const int64_t sum = (int64_t)(x[j] + off);
+        if (j < 4) {
+          ok = ok && sum >= R.v[j];                                                                    // :673-685
+        } else {
+          const uint32_t s = j - 4;
+          const unsigned long long bal = __ballot(lane < kSeqWaves && ((pw >> s) & 1u));
+          if (bal & ((1ull << w) - 1ull)) pbefore |= 1u << s;
+          if (bal) pround |= 1u << s;
+          const bool have = ((pbefore >> s) & 1u) || (km[s] & ((2ull << lane) - 1ull));              // the key exists in the running sum
+          if ((R.present >> s) & 1u) ok = ok && (have ? !(R.v[j] > sum) : R.v[j] == 0);              // :686-697
+        }
+      }
+    }
+    pcarry |= pround;
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) sh_.fk[b][w] = m ? ((r * kSeqWaves + (uint32_t)w) << 6) + (uint32_t)(__ffsll((long long)m) - 1) : BS_INF;
+    cur = nxt;
+  }
+  rounds_done += r < rounds ? r + 1 : rounds;
+  if (found == BS_INF) {                                      // the last round's hits
+    lds_barrier();
+    found = seq_row_min_u32(lane < kSeqWaves ? sh_.fk[(rounds - 1u) & 1u][lane] : BS_INF);
+  }
+  // (the next writer of tot / wpres / fk is the next scan: the first-fit search's barriers or the next pod's top barrier lie between)
+  return found;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// first fit in list order + the assume step (upstream's node choice / cache.AssumePod, restated; see bs_drain.cpp).
+// Returns the node (BS_INF none), wave-uniform, identical in every wave.  WRITE PHASE: the lane that owns the chosen node
+// rewrites its request lanes, the left arrays and the node's meta word.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SeqPick {
+  uint32_t pcls;                 // the pod's own fit class
+  int64_t preq[BS_MAX_LANES];    // raw request lanes of the pod
   uint32_t ppres;
-  // Filter (computeResourceSatisfied) of the pod, when the stage is on
-  uint32_t fl;                   // BS_FL_*
+  uint32_t fl;                   // Filter (computeResourceSatisfied) of the pod, BS_FL_* (PASS_NOT_GROUPED when the stage is off)
   uint32_t ff;                   // bit0: case 2 impossible, bit1: the leader's member cannot be "held" (scalar key)
   int64_t FR[4], FM[4];
 };
 
-// One pass over the node list.  Returns (wave-uniform, same in every wave) first_k of the scan (BS_K_NONE) and the first
-// node that takes the pod (BS_INF).
 template <int TS>
-__device__ __forceinline__ void seq_node_pass(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqQuery& q,
-                                              uint32_t& first_k, uint32_t& at) {
+__device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqPick& q,
+                                             unsigned long long& tiles_looked) {
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L(), S = sh.S();
-  const int lane = lane_id(), w = wave_id();
+  const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
   const uint32_t N = nd.n;
-  const uint32_t cw = ((((N + 63u) >> 6) + kSeqWaves - 1u) / kSeqWaves) << 6;     // nodes per wave, a multiple of 64
-  const uint32_t lo = min(N, (uint32_t)w * cw), hi = min(N, lo + cw);
-  const int64_t* scp = q.pct07 ? sq.sc07 : sq.sc10;
-  const uint32_t* fit_scan = nd.fit + (size_t)q.tcls * nd.fit_words;
-  const bool pick_cls_ok = q.pcls < nd.n_classes;
-  const uint32_t* fit_pick = nd.fit + (size_t)(pick_cls_ok ? q.pcls : 0u) * nd.fit_words;
-  const bool fl_all = q.fl < 16u && q.fl != BS_FL_EVALUATED;       // Filter passes on every node
-  const bool fl_none = q.fl >= 16u;                                // ... on none (ERR_PG_NOT_FOUND, the nil-leader panic)
-
-  // ---- phase 1: the wave's total of singleNodeResource over its range; first node of the range that takes the pod
-  unsigned long long acc[BS_MAX_LANES];
+  if (!N || q.pcls >= nd.n_classes || q.fl >= 16u) return BS_INF;          // (ERR_PG_NOT_FOUND / the nil-leader panic: Filter fails everywhere)
+  const bool fl_all = q.fl != BS_FL_EVALUATED;                              // Filter passes on every node
+  const uint32_t ntiles = (N + 63u) >> 6;
+  const uint32_t* fitrow = nd.fit + (size_t)q.pcls * nd.fit_words;
+  uint32_t found = BS_INF, pb = 0;
+  for (uint32_t chunk = 0; chunk < ntiles && found == BS_INF; chunk += kSeqBlock) {
+    if (chunk) lds_barrier();                                 // cmask of the previous chunk has been read by everybody
+    const uint32_t t = chunk + threadIdx.x;
+    bool cand = t < ntiles;
+    if (cand && prm.prune)
+      cand = !(q.preq[0] > 0 && sh_.pmax[0][t] < q.preq[0]) && !(q.preq[1] > 0 && sh_.pmax[1][t] < q.preq[1]);
+    const unsigned long long cm = __ballot(cand);
+    if (lane == 0) sh_.cmask[w] = cm;
+    BS_SEQ_FULL_BARRIER();                                          // (also: the assume steps of earlier pods have landed before a tile is read)
+    unsigned long long masks[kSeqWaves];
+    uint32_t total = 0;
 #pragma unroll
-  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) acc[j] = 0;
-  uint32_t por = 0, mypick = BS_INF;
-  const bool want_pick = q.pick && pick_cls_ok && !fl_none;
-  for (uint32_t base = lo; base < hi; base += 64u) {
-    const uint32_t n = base + (uint32_t)lane;
-    const bool valid = n < hi;
-    const uint32_t nn = valid ? n : lo;
-    const uint32_t fl = nd.flags[nn];
-    const uint32_t rp = __hip_atomic_load(&sq.rpres[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint32_t ap = nd.apres[nn];
-    int64_t rq[BS_MAX_LANES];
+    for (int ww = 0; ww < kSeqWaves; ++ww) { masks[ww] = uni64(sh_.cmask[ww]); total += (uint32_t)__popcll(masks[ww]); }
+    for (uint32_t base = 0; base < total && found == BS_INF; base += kSeqWaves) {
+      // this wave takes the (base + w)-th candidate tile of the chunk
+      uint32_t idx = base + (uint32_t)w, tile = BS_INF;
+      if (idx < total) {
 #pragma unroll
-    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-      if (j < L) rq[j] = __hip_atomic_load(&sq.nreq[(size_t)j * nd.stride + nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (q.scan) {
-      const bool fit = valid && !(fl & BS_NODE_SKIP_MASK) && !(fl & BS_NODE_TAINT_ERR) && ((fit_scan[nn >> 5] >> (nn & 31u)) & 1u);
-      const uint32_t pres = fit ? (ap & rp) : 0u;                                                   // core.go:662-668
-      por |= pres;
-#pragma unroll
-      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-        if (j < L) {
-          const bool live = fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
-          if (live) acc[j] += (unsigned long long)wsub(scp[(size_t)j * nd.stride + nn], rq[j]);      // :656-659,667
-        }
-      }
-    }
-    if (want_pick && mypick == BS_INF) {
-      bool ok = valid && fl == 0u && ((fit_pick[nn >> 5] >> (nn & 31u)) & 1u);
-      int64_t al[BS_MAX_LANES];
-#pragma unroll
-      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-        if (j < L) al[j] = nd.alloc[(size_t)j * nd.stride + nn];
-      if (!fl_all) {                                           // computeResourceSatisfied on this node (core.go:545-563)
-        bool c2 = !(q.ff & 1u), c3h = !(q.ff & 2u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int64_t left = wsub(al[j], rq[j]);                                                   // getLeftResource :460-463
-          c2 = c2 && left >= q.FR[j];
-          c3h = c3h && left >= q.FM[j];
-        }
-        ok = ok && (c2 || !c3h);                                                                     // case 2 | case 3
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) ok = ok && !(q.preq[j] > 0 && q.preq[j] > wsub(al[j], rq[j]));
-      ok = ok && !(wadd(rq[3], 1) > al[3]);
-#pragma unroll
-      for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
-        if (s < S && ((q.ppres >> s) & 1u) && q.preq[4 + s] > 0) {
-          const int64_t r0 = ((rp >> s) & 1u) ? rq[4 + s] : 0;
-          ok = ok && ((ap >> s) & 1u) && !(q.preq[4 + s] > wsub(al[4 + s], r0));
-        }
-      }
-      const unsigned long long m = __ballot(ok);
-      if (m) mypick = base + (uint32_t)(__ffsll((long long)m) - 1);
-    }
-  }
-  if (q.scan) {
-#pragma unroll
-    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-      if (j < L) {
-        const unsigned long long t = wave_incl_scan_add_u64(acc[j]);
-        if (lane == 63) sh_.tot[w][j] = t;
-      }
-    }
-    uint32_t wp = 0;
-#pragma unroll
-    for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s)
-      if (s < S && __ballot((por >> s) & 1u)) wp |= 1u << s;
-    if (lane == 0) sh_.wpres[w] = wp;
-  }
-  if (lane == 0) sh_.pick[w] = mypick;
-  __syncthreads();
-
-  // ---- phase 2: running sums inside the range on top of the ranges before it; first row that covers the request
-  uint32_t myfk = BS_INF;
-  if (q.scan) {
-    unsigned long long carry[BS_MAX_LANES];
-    uint32_t pcarry = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) carry[j] = 0;
-    for (int ww = 0; ww < w; ++ww) {
-#pragma unroll
-      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-        if (j < L) carry[j] += sh_.tot[ww][j];
-      pcarry |= sh_.wpres[ww];
-    }
-    for (uint32_t base = lo; base < hi && myfk == BS_INF; base += 64u) {
-      const uint32_t n = base + (uint32_t)lane;
-      const bool valid = n < hi;
-      const uint32_t nn = valid ? n : lo;
-      const uint32_t fl = nd.flags[nn];
-      const uint32_t rp = __hip_atomic_load(&sq.rpres[nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const uint32_t ap = nd.apres[nn];
-      const bool row = valid && !(fl & BS_NODE_SKIP_MASK);                                            // core.go:606-617
-      const bool fit = row && !(fl & BS_NODE_TAINT_ERR) && ((fit_scan[nn >> 5] >> (nn & 31u)) & 1u);
-      const uint32_t pres = fit ? (ap & rp) : 0u;
-      bool ok = row;
-#pragma unroll
-      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-        if (j < L) {
-          const bool live = fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
-          unsigned long long left = 0;
-          if (live) left = (unsigned long long)wsub(scp[(size_t)j * nd.stride + nn],
-                                                    __hip_atomic_load(&sq.nreq[(size_t)j * nd.stride + nn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-          const unsigned long long incl = wave_incl_scan_add_u64(left) + carry[j];
-          carry[j] = (unsigned long long)readlane63_i64((long long)incl);
-          if (j < 4) {
-            ok = ok && (int64_t)incl >= q.R.v[j];                                                      // core.go:673-685
-          } else {
-            const uint32_t s = j - 4;
-            const unsigned long long km = __ballot((pres >> s) & 1u);
-            const bool have = ((pcarry >> s) & 1u) || (km & ((2ull << lane) - 1ull));                 // key exists in the running sum
-            if ((q.R.present >> s) & 1u) ok = ok && (have ? !(q.R.v[j] > (int64_t)incl) : q.R.v[j] == 0);   // :686-697
-            if (km) pcarry |= 1u << s;
+        for (int ww = 0; ww < kSeqWaves; ++ww) {
+          const uint32_t c = (uint32_t)__popcll(masks[ww]);
+          if (tile == BS_INF) {
+            if (idx < c) {
+              unsigned long long mm = masks[ww];
+              for (uint32_t k = 0; k < idx; ++k) mm &= mm - 1ull;
+              tile = chunk + (uint32_t)ww * 64u + (uint32_t)(__ffsll((long long)mm) - 1);
+            } else idx -= c;
           }
         }
       }
-      const unsigned long long m = __ballot(ok);
-      if (m) myfk = base + (uint32_t)(__ffsll((long long)m) - 1);
+      uint32_t mine = BS_INF;
+      int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES];
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { al[j] = 0; rq[j] = 0; }
+      uint32_t ap = 0, rp = 0;
+      if (tile != BS_INF) {
+        tiles_looked++;
+        const uint32_t n = (tile << 6) + (uint32_t)lane;
+        const bool valid = n < N;
+        const uint32_t nn = valid ? n : N - 1u;
+        const uint32_t fl = nd.flags[nn];
+        ap = nd.apres[nn];
+        rp = sq.rpres[nn];
+        const uint32_t fw = fitrow[nn >> 5];
+#pragma unroll
+        for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+          if (j < L) {
+            al[j] = nd.alloc[(size_t)j * nd.stride + nn];
+            rq[j] = sq.nreq[(size_t)j * nd.stride + nn];
+          }
+        }
+        const bool sched = valid && fl == 0u;
+        bool ok = sched && ((fw >> (nn & 31u)) & 1u);
+        const int64_t f0 = wsub(al[0], rq[0]), f1 = wsub(al[1], rq[1]);
+        if (!fl_all) {                                         // computeResourceSatisfied on this node (core.go:545-563)
+          bool c2 = !(q.ff & 1u), c3h = !(q.ff & 2u);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t left = wsub(al[j], rq[j]);                                                   // getLeftResource :460-463
+            c2 = c2 && left >= q.FR[j];
+            c3h = c3h && left >= q.FM[j];
+          }
+          ok = ok && (c2 || !c3h);                                                                     // case 2 | case 3
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ok = ok && !(q.preq[j] > 0 && q.preq[j] > wsub(al[j], rq[j]));
+        ok = ok && !(wadd(rq[3], 1) > al[3]);
+#pragma unroll
+        for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+          if (s < S && ((q.ppres >> s) & 1u) && q.preq[4 + s] > 0) {
+            const int64_t r0 = ((rp >> s) & 1u) ? rq[4 + s] : 0;
+            ok = ok && ((ap >> s) & 1u) && !(q.preq[4 + s] > wsub(al[4 + s], r0));
+          }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
+        else if (prm.prune) {                                  // looked at in vain: tighten the tile's bounds to what is really there
+          const long long m0 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f0 : INT64_MIN));
+          const long long m1 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f1 : INT64_MIN));
+          if (lane == 0) { sh_.pmax[0][tile] = m0; sh_.pmax[1][tile] = m1; }
+        }
+      }
+      if (lane == 0) sh_.pick[pb][w] = mine;
+      lds_barrier();
+      found = seq_row_min_u32(lane < kSeqWaves ? sh_.pick[pb][lane] : BS_INF);
+      pb ^= 1u;
+      if (found != BS_INF && tile == (found >> 6) && (uint32_t)lane == (found & 63u)) {
+        // ---- assume (NodeInfo.AddPod): requested += request, pods lane + 1; the left arrays and the meta word follow
+        const uint32_t at = found;
+        uint32_t nrp = rp;
+#pragma unroll
+        for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+          if (j < L) {
+            int64_t nr = rq[j];
+            bool touched = false;
+            if (j < 3) { nr = wadd(rq[j], q.preq[j]); touched = true; }
+            else if (j == 3) { nr = wadd(rq[j], 1); touched = true; }
+            else if ((q.ppres >> (j - 4)) & 1u) {
+              nr = wadd(((rp >> (j - 4)) & 1u) ? rq[j] : 0, q.preq[j]);
+              nrp |= 1u << (j - 4);
+              touched = true;
+            }
+            if (touched) {
+              sq.nreq[(size_t)j * nd.stride + at] = nr;
+              sq.left07[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 0.7f), nr);
+              sq.left10[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 1.0f), nr);
+            }
+          }
+        }
+        if (nrp != rp) {
+          sq.rpres[at] = nrp;
+          sq.nmeta[at] = (sq.nmeta[at] & 0xFu) | ((ap & nrp) << 4);
+        }
+        if (prm.prune) {                                       // a negative request frees capacity: the bounds must stay upper bounds
+          const int64_t n0 = wsub(al[0], wadd(rq[0], q.preq[0])), n1 = wsub(al[1], wadd(rq[1], q.preq[1]));
+          if (n0 > sh_.pmax[0][at >> 6]) sh_.pmax[0][at >> 6] = n0;
+          if (n1 > sh_.pmax[1][at >> 6]) sh_.pmax[1][at >> 6] = n1;
+        }
+      }
     }
   }
-  if (lane == 0) sh_.fk[w] = myfk;
-  __syncthreads();
-  uint32_t fk = BS_INF, pk = BS_INF;
-#pragma unroll
-  for (int ww = 0; ww < kSeqWaves; ++ww) {
-    fk = min(fk, sh_.fk[ww]);
-    pk = min(pk, sh_.pick[ww]);
-  }
-  first_k = uni32(fk);
-  at = uni32(pk);
+  return found;
 }
 
 // findMaxPG (core.go:701-739) over the keys.  Wave-uniform result: leader (-1 none), panic.
@@ -281,6 +430,7 @@ __device__ __forceinline__ void seq_find_max(const GroupsDev& gr, const SeqDev& 
   auto key_at = [&](uint32_t g) -> unsigned long long {
     return prm.keys_in_lds ? lkeys[g] : __hip_atomic_load(&sq.keys[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
+  if (!prm.keys_in_lds) BS_SEQ_FULL_BARRIER();                      // keys in global memory: thread 0's stores of earlier pods have landed
   unsigned long long best = 0;
   for (uint32_t g = threadIdx.x; g < G; g += kSeqBlock) {
     const unsigned long long k = key_at(g);
@@ -288,7 +438,7 @@ __device__ __forceinline__ void seq_find_max(const GroupsDev& gr, const SeqDev& 
   }
   best = wave_max_u64_all(best);
   if (lane_id() == 0) sh_.kmax[wave_id()] = best;
-  __syncthreads();
+  BS_SEQ_FULL_BARRIER();
   unsigned long long top = 0;
 #pragma unroll
   for (int ww = 0; ww < kSeqWaves; ++ww) top = sh_.kmax[ww] > top ? sh_.kmax[ww] : top;
@@ -308,9 +458,9 @@ __device__ __forceinline__ void seq_find_max(const GroupsDev& gr, const SeqDev& 
       if (__hip_atomic_load(&sq.g_sc[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) nxt = g;
     }
     nxt = wave_min_u32(nxt);
-    __syncthreads();
+    BS_SEQ_FULL_BARRIER();
     if (lane_id() == 0) sh_.red[wave_id()] = nxt;
-    __syncthreads();
+    BS_SEQ_FULL_BARRIER();
     uint32_t r = BS_INF;
 #pragma unroll
     for (int ww = 0; ww < kSeqWaves; ++ww) r = min(r, sh_.red[ww]);
@@ -320,6 +470,40 @@ __device__ __forceinline__ void seq_find_max(const GroupsDev& gr, const SeqDev& 
     full = uni64(key_at(cur)) & 1ull;
   }
   leader = (int32_t)cur;
+}
+
+// Everything the pass reads from one group, loaded in ONE round trip.  The state of the pod's own group and of the leader
+// then stays in registers (wave-uniform, every wave applies the same updates): consecutive pods of a gang, and pods that
+// reserve for the same leader, read nothing from global memory.
+struct SeqGroup {
+  uint32_t flags, matched, sc, cls, head, nwait;
+  bool seen;                     // a pod of the gang has entered PreFilter in this pass (t_first is set)
+  uint64_t occ;
+  Res mr;
+};
+template <int TS>
+__device__ __forceinline__ void seq_group_load(const SeqDev& sq, uint32_t G, uint32_t g, Shape<TS> sh, SeqGroup& o) {
+  const uint32_t f = seq_raw8(&sq.g_flags[g]), m = seq_raw32(&sq.g_matched[g]), s = seq_raw32(&sq.g_sc[g]), c = seq_raw32(&sq.g_cls[g]),
+                 p = seq_raw32(&sq.g_mrpres[g]), h = seq_raw32(&sq.head[g]), nw = seq_raw32(&sq.nwait[g]);
+  const uint64_t oc = seq_raw64(&sq.g_occ[g]), tf = seq_raw64(&sq.t_first[g]);
+  uint64_t mr[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+    if (j < sh.L()) mr[j] = seq_raw64(&sq.g_minres[(size_t)j * G + g]);
+  o.flags = uni32(f); o.matched = uni32(m); o.sc = uni32(s); o.cls = uni32(c); o.head = uni32(h); o.nwait = uni32(nw);
+  o.occ = uni64(oc);
+  o.seen = uni64(tf) != ~0ull;
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+    if (j < sh.L()) o.mr.v[j] = (int64_t)uni64(mr[j]);
+  o.mr.present = uni32(p);
+}
+template <int TS>
+__device__ __forceinline__ void seq_group_zero(SeqGroup& o, Shape<TS> sh) {
+  o.flags = o.matched = o.sc = o.cls = o.head = o.nwait = 0;
+  o.seen = false;
+  o.occ = 0;
+  res_zero(o.mr, sh);
 }
 
 template <int TS>
@@ -332,7 +516,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
   const uint32_t gate = prm.eph_gate;
   const bool t0 = threadIdx.x == 0;
 
-  // ---- prologue: keys, scaled allocatables, per-gang bookkeeping
+  // ---- prologue: keys, left arrays, meta words, first-fit bounds, per-gang bookkeeping
   for (uint32_t g = threadIdx.x; g < G; g += kSeqBlock) {
     const unsigned long long k = seq_key(g, gr.flags[g], gr.min_member[g], gr.status_scheduled[g], gr.matched[g]);
     if (prm.keys_in_lds) s_keys[g] = k; else sq.keys[g] = k;
@@ -342,293 +526,341 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     sq.t_first[g] = ~0ull;
   }
   for (uint32_t i = threadIdx.x; i < P; i += kSeqBlock) sq.pod_node[i] = -1;
-  for (uint32_t n = threadIdx.x; n < N; n += kSeqBlock) {
+  for (uint32_t base = 0; base < N; base += kSeqBlock) {
+    const uint32_t n = base + threadIdx.x;
+    const bool valid = n < N;
+    const uint32_t nn = valid ? n : N - 1u;
+    const uint32_t fl = nd.flags[nn], ap = nd.apres[nn], rp = sq.rpres[nn];
+    long long f0 = INT64_MIN, f1 = INT64_MIN;
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
       if (j < L) {
-        const int64_t a = nd.alloc[(size_t)j * nd.stride + n];
-        sq.sc07[(size_t)j * nd.stride + n] = scale_f32(a, 0.7f);
-        sq.sc10[(size_t)j * nd.stride + n] = scale_f32(a, 1.0f);
+        const int64_t a = nd.alloc[(size_t)j * nd.stride + nn], q = sq.nreq[(size_t)j * nd.stride + nn];
+        if (valid) {
+          sq.left07[(size_t)j * nd.stride + n] = wsub(scale_f32(a, 0.7f), q);
+          sq.left10[(size_t)j * nd.stride + n] = wsub(scale_f32(a, 1.0f), q);
+        }
+        if (valid && fl == 0u) {
+          if (j == 0) f0 = wsub(a, q);
+          if (j == 1) f1 = wsub(a, q);
+        }
       }
+    }
+    if (valid) sq.nmeta[n] = ((fl & BS_NODE_SKIP_MASK) ? 0u : 1u) | ((fl & BS_NODE_TAINT_ERR) ? 2u : 0u) | ((ap & rp) << 4);
+    if (prm.prune) {
+      const long long m0 = readlane63_i64(wave_max_i64_lane63(f0)), m1 = readlane63_i64(wave_max_i64_lane63(f1));
+      if (lane_id() == 0 && n < N) { sh_.pmax[0][n >> 6] = m0; sh_.pmax[1][n >> 6] = m1; }
     }
   }
   int32_t sop_leader = prm.sop_leader0;                      // sop.maxFinishedPG / maxPGStatus (core.go:58-59), stale between calls
   uint32_t n_released = 0;
-  unsigned long long n_pass = 0, n_scan = 0;
+  unsigned long long n_pick = 0, n_scan = 0, n_rounds = 0, n_tiles = 0, n_folds = 0;
+  // findMaxPG's answer is kept until a key changes (capture, Permit, release)
+  bool fold_valid = false, fold_panic = false;
+  int32_t fold_leader = -1;
+  // register-resident group state: the pod's own group (own_of) and the leader's (ldr_of); -1 = nothing cached
+  SeqGroup own, ldr;
+  seq_group_zero(own, sh);
+  seq_group_zero(ldr, sh);
+  int32_t own_of = -1, ldr_of = -1;
+  uint32_t wl_cnt = 0;                                       // waiting pods of group own_of recorded in the LDS list
+  bool wl_ok = true;                                         // ... and the list holds ALL of them (nothing waited before the group became current)
   const unsigned long long clk0 = (unsigned long long)wall_clock64();
+  BS_SEQ_FULL_BARRIER();
+#ifdef BS_SEQ_PROBE
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = (unsigned long long)__builtin_readcyclecounter();
+#endif
 
   for (uint32_t i = 0; i < P; ++i) {
-    __syncthreads();                                         // what the previous pod wrote (global state, keys) is in place
+    lds_barrier();                                           // keys / bounds / wait list as the previous pod left them
+    BS_SEQ_T(6);
     const int32_t gi = pods.group[i];
     const uint32_t pflags = pods.flags[i];
     const bool grouped = gi >= 0 && (uint32_t)gi < G;
-    if (grouped && t0 && sq.t_first[gi] == ~0ull) sq.t_first[gi] = (unsigned long long)wall_clock64() - clk0;
     uint32_t code;
     uint32_t fk = BS_K_NOT_SCANNED;
-    SeqQuery q;
-    q.scan = false;
-    q.pick = false;
-    q.tcls = 0;
-    q.pct07 = false;
-    bool deny = false;
-    // READ PHASE: from here to the end of the node pass every wave loads the same mutable state (nothing is written except
-    // inside the bracketed capture step below); thread 0 writes in the WRITE PHASE behind the node pass, where no other
-    // wave reads mutable state any more.
-    uint32_t gflags = 0, gmatched = 0, gsc = 0;              // of the pod's own group; gflags as this PreFilter call leaves them
-    if (grouped) {
-      gflags = seq_ld8(&sq.g_flags[gi]);
-      gmatched = seq_ld32(&sq.g_matched[gi]);
-      gsc = seq_ld32(&sq.g_sc[gi]);
+    bool scan = false, pct07 = false, deny = false;
+    uint32_t tcls = 0;
+    Res R;
+    res_zero(R, sh);
+    // READ PHASE.  A group that is not in registers costs one round trip (behind a full barrier: thread 0's stores of
+    // earlier pods have landed); the leader the previous call left behind is fetched in the same trip.
+    {
+      const bool miss_own = grouped && gi != own_of;
+      const bool miss_ldr = sop_leader >= 0 && sop_leader != gi && sop_leader != ldr_of;
+      if (miss_own || miss_ldr) {
+        BS_SEQ_FULL_BARRIER();
+        if (miss_own) {
+          if (gi == ldr_of) { const uint32_t h = seq_raw32(&sq.head[gi]), nw = seq_raw32(&sq.nwait[gi]); const uint64_t tf = seq_raw64(&sq.t_first[gi]);
+                              own = ldr; own.head = uni32(h); own.nwait = uni32(nw); own.seen = uni64(tf) != ~0ull; }
+          else seq_group_load(sq, G, (uint32_t)gi, sh, own);
+          own_of = gi;
+          wl_cnt = 0;
+          wl_ok = own.nwait == 0;
+        }
+        if (miss_ldr) { seq_group_load(sq, G, (uint32_t)sop_leader, sh, ldr); ldr_of = sop_leader; }
+      }
     }
+    if (grouped && !own.seen) {
+      if (t0) sq.t_first[gi] = (unsigned long long)wall_clock64() - clk0;
+      own.seen = true;
+    }
+    BS_SEQ_T(0);
+    uint32_t gflags = grouped ? own.flags : 0u;              // of the pod's own group, as this PreFilter call leaves them
+    const uint32_t gmatched = grouped ? own.matched : 0u, gsc = grouped ? own.sc : 0u;
 
     if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                                    // core.go:89-92
     else if (pflags & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;                      // :95-98
     else if (!grouped) code = BS_PF_ERR_PG_NOT_FOUND;                                               // :100-103
+    else if (gflags & BS_GROUP_DENIED) code = BS_PF_ERR_DENIED;                                     // :105-110
     else {
-      if (gflags & BS_GROUP_DENIED) code = BS_PF_ERR_DENIED;                                        // :105-110
-      else {
-        // fillOccupiedObj, core.go:477-512
-        const uint32_t mm = gr.min_member[gi];
-        const uint32_t sc = gsc;
-        uint32_t nf = gflags;
-        uint32_t gcls;
-        Res own_mr;                                          // Spec.MinResources of the pod's group after :489-493
-        if (!(gflags & BS_GROUP_HAS_POD)) {                  // :486-488
-          nf |= BS_GROUP_HAS_POD;
-          gcls = pods.cls[i];
-        } else gcls = seq_ld32(&sq.g_cls[gi]);
-        if (!(gflags & BS_GROUP_HAS_MINRES)) {               // :489-493
-          nf |= BS_GROUP_HAS_MINRES;
-          pod_require(pods, i, sh, gate, own_mr);
-        } else {
+      // fillOccupiedObj, core.go:477-512
+      const uint32_t mm = gr.min_member[gi];
+      uint32_t nf = gflags;
+      if (!(gflags & BS_GROUP_HAS_POD)) { nf |= BS_GROUP_HAS_POD; own.cls = pods.cls[i]; }           // :486-488
+      if (!(gflags & BS_GROUP_HAS_MINRES)) { nf |= BS_GROUP_HAS_MINRES; pod_require(pods, i, sh, gate, own.mr); }   // :489-493
+      const uint64_t occ = own.occ, refs = pods.owner[i];
+      const bool take_owner = occ == 0 && refs != 0;                                                 // :494-501
+      const bool occupied = occ != 0 && (refs == 0 || refs != occ);                                  // :503-510
+      if (nf != gflags || take_owner) {
+        if (t0) {                                            // (nobody reads these words from memory while the group is current)
+          if (!(gflags & BS_GROUP_HAS_POD)) sq.g_cls[gi] = own.cls;
+          if (!(gflags & BS_GROUP_HAS_MINRES)) {
 #pragma unroll
-          for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-            if (j < L) own_mr.v[j] = seq_ldi64(&sq.g_minres[(size_t)j * G + gi]);
-          own_mr.present = seq_ld32(&sq.g_mrpres[gi]);
-        }
-        const uint64_t occ = seq_ld64(&sq.g_occ[gi]), refs = pods.owner[i];
-        bool occupied = false;
-        const bool take_owner = occ == 0 && refs != 0;                                               // :494-501
-        if (occ != 0 && (refs == 0 || refs != occ)) occupied = true;                                 // :503-510
-        if (nf != gflags || take_owner) {
-          __syncthreads();                                   // every wave has read the state this step rewrites
-          if (t0) {
-            if (!(gflags & BS_GROUP_HAS_POD)) sq.g_cls[gi] = gcls;
-            if (!(gflags & BS_GROUP_HAS_MINRES)) {
-#pragma unroll
-              for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-                if (j < L) sq.g_minres[(size_t)j * G + gi] = own_mr.v[j];
-              sq.g_mrpres[gi] = own_mr.present;
-            }
-            if (take_owner) sq.g_occ[gi] = refs;
-            if (nf != gflags) {
-              sq.g_flags[gi] = (uint8_t)nf;
-              const unsigned long long k = seq_key((uint32_t)gi, nf, mm, sc, gmatched);
-              if (prm.keys_in_lds) s_keys[gi] = k; else sq.keys[gi] = k;
-            }
+            for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+              if (j < L) sq.g_minres[(size_t)j * G + gi] = own.mr.v[j];
+            sq.g_mrpres[gi] = own.mr.present;
           }
-          gflags = nf;
-          __syncthreads();                                   // the capture is a candidate of this very findMaxPG
+          if (take_owner) sq.g_occ[gi] = refs;
+          if (nf != gflags) sq.g_flags[gi] = (uint8_t)nf;
         }
-        if (occupied) code = BS_PF_ERR_OCCUPIED;                                                     // :113-115
+        if (take_owner) own.occ = refs;
+        if (nf != gflags) {
+          if (t0) {
+            const unsigned long long k = seq_key((uint32_t)gi, nf, mm, gsc, gmatched);
+            if (prm.keys_in_lds) s_keys[gi] = k; else sq.keys[gi] = k;
+          }
+          fold_valid = false;                                // the capture is a candidate of this very findMaxPG
+          gflags = nf;
+          own.flags = nf;
+          if (prm.keys_in_lds) lds_barrier(); else BS_SEQ_FULL_BARRIER();
+        }
+      }
+      BS_SEQ_T(1);
+      if (occupied) code = BS_PF_ERR_OCCUPIED;                                                       // :113-115
+      else {
+        if (!fold_valid) {
+          seq_find_max(gr, sq, prm, sh_, s_keys, fold_leader, fold_panic);                           // :118-123
+          fold_valid = true;
+          n_folds++;
+        }
+        BS_SEQ_T(2);
+        const int32_t leader = fold_leader;
+        if (fold_panic) code = BS_PF_PANIC_DIV0;
         else {
-          int32_t leader;
-          bool panic;
-          seq_find_max(gr, sq, prm, sh_, s_keys, leader, panic);                                     // :118-123
-          if (panic) code = BS_PF_PANIC_DIV0;
+          sop_leader = leader;                                                                       // :121-122
+          if (leader < 0) code = BS_PF_PASS_NO_MAX;                                                  // :127-130
           else {
-            sop_leader = leader;                                                                     // :121-122
-            if (leader < 0) code = BS_PF_PASS_NO_MAX;                                                // :127-130
-            else {
-              const uint32_t lmatched = leader == gi ? gmatched : seq_ld32(&sq.g_matched[leader]);  // :132-135
-              if (lmatched == 0) {                                                                   // :136-147
-                // getPreAllocatedResource(pgs, 0), core.go:774-793
-                res_zero(q.R, sh);
-                const int64_t nfin = (int64_t)mm - (int64_t)sc;
-                if (nfin > 0) {
-                  Res times;
-#pragma unroll
-                  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-                    if (j < L) times.v[j] = wmul(own_mr.v[j], nfin);
-                  times.present = own_mr.present;
-                  res_add(q.R, times, sh, gate);
-                }
-                if (q.R.v[BS_LANE_PODS] == 0) q.R.v[BS_LANE_PODS] = (int64_t)mm + 1;
-                q.scan = true;
-                q.tcls = gcls;
-                q.pct07 = false;
-                code = BS_PF_PASS_FIRST_FITS;
-              } else if (leader == gi) code = BS_PF_PASS_IS_MAX;                                     // :150-155
-              else {                                                                                 // :157-166
-                const uint32_t lmm = gr.min_member[leader];
-                const uint32_t lfl = seq_ld8(&sq.g_flags[leader]);
-                Res lmr;
+            if (leader != gi && leader != ldr_of) {          // (the leader changed: one more round trip)
+              BS_SEQ_FULL_BARRIER();
+              seq_group_load(sq, G, (uint32_t)leader, sh, ldr);
+              ldr_of = leader;
+            }
+            const uint32_t lmatched = leader == gi ? gmatched : ldr.matched;                         // :132-135
+            if (lmatched == 0) {                                                                     // :136-147
+              // getPreAllocatedResource(pgs, 0), core.go:774-793
+              const int64_t nfin = (int64_t)mm - (int64_t)gsc;
+              if (nfin > 0) {
+                Res times;
 #pragma unroll
                 for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-                  if (j < L) lmr.v[j] = seq_ldi64(&sq.g_minres[(size_t)j * G + leader]);
-                lmr.present = seq_ld32(&sq.g_mrpres[leader]);
-                res_zero(q.R, sh);
-                const int64_t nfin = (int64_t)lmm - (int64_t)lmatched;                               // matched != 0: :778-779
-                if (nfin > 0 && (lfl & BS_GROUP_HAS_MINRES)) {
-                  Res times;
-#pragma unroll
-                  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-                    if (j < L) times.v[j] = wmul(lmr.v[j], nfin);
-                  times.present = lmr.present;
-                  res_add(q.R, times, sh, gate);
-                }
-                if (q.R.v[BS_LANE_PODS] == 0) q.R.v[BS_LANE_PODS] = (int64_t)lmm + 1;
-                Res cur;
-                pod_require(pods, i, sh, gate, cur);                                                 // :158
-                res_add(q.R, cur, sh, gate);                                                         // :159
-                q.scan = true;
-                q.tcls = seq_ld32(&sq.g_cls[leader]);
-                q.pct07 = true;
-                code = BS_PF_PASS_RESERVE_FITS;
+                  if (j < L) times.v[j] = wmul(own.mr.v[j], nfin);
+                times.present = own.mr.present;
+                res_add(R, times, sh, gate);
               }
+              if (R.v[BS_LANE_PODS] == 0) R.v[BS_LANE_PODS] = (int64_t)mm + 1;
+              scan = true;
+              tcls = own.cls;
+              pct07 = false;
+              code = BS_PF_PASS_FIRST_FITS;
+            } else if (leader == gi) code = BS_PF_PASS_IS_MAX;                                       // :150-155
+            else {                                                                                   // :157-166
+              const uint32_t lmm = gr.min_member[leader];
+              const int64_t nfin = (int64_t)lmm - (int64_t)lmatched;                                 // matched != 0: :778-779
+              if (nfin > 0 && (ldr.flags & BS_GROUP_HAS_MINRES)) {
+                Res times;
+#pragma unroll
+                for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+                  if (j < L) times.v[j] = wmul(ldr.mr.v[j], nfin);
+                times.present = ldr.mr.present;
+                res_add(R, times, sh, gate);
+              }
+              if (R.v[BS_LANE_PODS] == 0) R.v[BS_LANE_PODS] = (int64_t)lmm + 1;
+              Res cur;
+              pod_require(pods, i, sh, gate, cur);                                                   // :158
+              res_add(R, cur, sh, gate);                                                             // :159
+              scan = true;
+              tcls = ldr.cls;
+              pct07 = true;
+              code = BS_PF_PASS_RESERVE_FITS;
             }
           }
         }
       }
     }
 
-    // ---- the node pass: scan of this PreFilter call and (speculatively, in the same sweep) the node the pod would take
+    // ---- Filter's per-pod half (core.go:170-180, :524-544) with sop.maxPGStatus as this PreFilter call left it
+    SeqPick q;
+    q.fl = BS_FL_PASS_NOT_GROUPED;
+    q.ff = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { q.FR[j] = 0; q.FM[j] = 0; }
+    if (BS_PF_IS_PASS(code) && prm.run_filter) {
+      if (gi == BS_POD_NOT_GROUPED) q.fl = BS_FL_PASS_NOT_GROUPED;
+      else if (!grouped) q.fl = BS_FL_ERR_PG_NOT_FOUND;
+      else if (sop_leader < 0) q.fl = BS_FL_PANIC_NIL_MAX;
+      else if (sop_leader == gi) q.fl = BS_FL_PASS_IS_MAX;
+      else {
+        // (sop_leader is in ldr: fetched at the top, or by the fold branch above)
+        if (!(ldr.flags & BS_GROUP_HAS_MINRES)) q.fl = BS_FL_PASS_NO_MINRES;
+        else {
+          Res ms, cur;
+          res_zero(ms, sh);
+          res_add(ms, ldr.mr, sh, gate);                                                             // :526-527
+          pod_require(pods, i, sh, gate, cur);                                                       // :551
+          res_add(cur, ms, sh, gate);                                                                // :552
+          q.fl = BS_FL_EVALUATED;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { q.FR[j] = cur.v[j]; q.FM[j] = ms.v[j]; }
+#pragma unroll
+          for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+            if (s < S) {
+              if ((cur.present & (1u << s)) && cur.v[4 + s] != 0) q.ff |= 1u;
+              if ((ms.present & (1u << s)) && ms.v[4 + s] != 0) q.ff |= 2u;
+            }
+          }
+        }
+      }
+    }
+
+    // ---- the node scan of this PreFilter call
+    BS_SEQ_T(0);
+    if (scan) {
+      const uint32_t first_k = seq_scan<TS>(nd, sq, prm, sh_, tcls, pct07, R, n_rounds);
+      n_scan++;
+      fk = first_k == BS_INF ? BS_K_NONE : first_k;
+      if (first_k == BS_INF) {                               // compareClusterResourceAndRequire false: AddToDenyCache (:142,:163)
+        code = code == BS_PF_PASS_FIRST_FITS ? BS_PF_REJECT_FIRST : BS_PF_REJECT_RESERVE;
+        deny = true;
+      }
+    }
+    // ---- node choice + assume (WRITE PHASE from here on)
+    BS_SEQ_T(3);
     uint32_t at = BS_INF;
     if (BS_PF_IS_PASS(code)) {
-      q.pick = true;
       q.pcls = pods.cls[i];
       q.ppres = pods.pres[i];
 #pragma unroll
       for (uint32_t j = 0; j < BS_MAX_LANES; ++j) q.preq[j] = j < L ? pods.req[(size_t)j * P + i] : 0;
-      q.fl = BS_FL_PASS_NOT_GROUPED;
-      q.ff = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { q.FR[j] = 0; q.FM[j] = 0; }
-      if (prm.run_filter) {                                  // Filter's per-pod half, core.go:170-180, :524-544
-        if (gi == BS_POD_NOT_GROUPED) q.fl = BS_FL_PASS_NOT_GROUPED;
-        else if (!grouped) q.fl = BS_FL_ERR_PG_NOT_FOUND;
-        else if (sop_leader < 0) q.fl = BS_FL_PANIC_NIL_MAX;
-        else {
-          const uint32_t lfl = seq_ld8(&sq.g_flags[sop_leader]);
-          const bool have = lfl & BS_GROUP_HAS_MINRES;
-          if (sop_leader == gi) q.fl = BS_FL_PASS_IS_MAX;
-          else if (!have) q.fl = BS_FL_PASS_NO_MINRES;
-          else {
-            Res mr, ms, cur;
-#pragma unroll
-            for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-              if (j < L) mr.v[j] = seq_ldi64(&sq.g_minres[(size_t)j * G + sop_leader]);
-            mr.present = seq_ld32(&sq.g_mrpres[sop_leader]);
-            res_zero(ms, sh);
-            res_add(ms, mr, sh, gate);                                                               // :526-527
-            pod_require(pods, i, sh, gate, cur);                                                     // :551
-            res_add(cur, ms, sh, gate);                                                              // :552
-            q.fl = BS_FL_EVALUATED;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { q.FR[j] = cur.v[j]; q.FM[j] = ms.v[j]; }
-#pragma unroll
-            for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
-              if (s < S) {
-                if ((cur.present & (1u << s)) && cur.v[4 + s] != 0) q.ff |= 1u;
-                if ((ms.present & (1u << s)) && ms.v[4 + s] != 0) q.ff |= 2u;
-              }
-            }
-          }
-        }
-      }
-      uint32_t first_k;
-      seq_node_pass<TS>(nd, sq, prm, sh_, q, first_k, at);
-      n_pass++;
-      if (q.scan) {
-        n_scan++;
-        fk = first_k == BS_INF ? BS_K_NONE : first_k;
-        if (first_k == BS_INF) {                             // compareClusterResourceAndRequire false: AddToDenyCache (:142,:163)
-          code = code == BS_PF_PASS_FIRST_FITS ? BS_PF_REJECT_FIRST : BS_PF_REJECT_RESERVE;
-          deny = true;
-          at = BS_INF;
-        }
-      }
+      at = seq_pick<TS>(nd, sq, prm, sh_, q, n_tiles);
+      n_pick++;
     }
+    BS_SEQ_T(4);
+    if (deny) { gflags |= BS_GROUP_DENIED; own.flags = gflags; }
     if (t0) {
       sq.pf_code[i] = (uint8_t)code;
       if (sq.pf_first_k) sq.pf_first_k[i] = fk;
       if (sq.pf_leader) sq.pf_leader[i] = sop_leader;
-      if (deny) sq.g_flags[gi] = (uint8_t)(gflags | BS_GROUP_DENIED);
+      if (deny) sq.g_flags[gi] = (uint8_t)gflags;
     }
-    if (at == BS_INF) continue;                              // rejected, or no node takes the pod: it holds nothing
-
-    // ---- assume (NodeInfo.AddPod): the thread that owns nothing in particular does it — one thread, a handful of words
-    if (t0) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) sq.nreq[(size_t)j * nd.stride + at] = wadd(sq.nreq[(size_t)j * nd.stride + at], q.preq[j]);
-      sq.nreq[(size_t)3 * nd.stride + at] = wadd(sq.nreq[(size_t)3 * nd.stride + at], 1);
-      uint32_t rp = sq.rpres[at];
-#pragma unroll
-      for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
-        if (s < S && ((q.ppres >> s) & 1u)) {
-          const int64_t old = ((rp >> s) & 1u) ? sq.nreq[(size_t)(4 + s) * nd.stride + at] : 0;
-          sq.nreq[(size_t)(4 + s) * nd.stride + at] = wadd(old, q.preq[4 + s]);
-          rp |= 1u << s;
-        }
-      }
-      sq.rpres[at] = rp;
-    }
-    if (!grouped) {                                          // core.go:269-272: Permit lets it through at once
+    if (at != BS_INF && !grouped) {                          // core.go:269-272: Permit lets it through at once
       if (t0) sq.pod_node[i] = (int32_t)at;
-      continue;
-    }
-    // ---- Permit, core.go:268-309 (WRITE PHASE: thread 0 only; the inputs were loaded before the node pass)
-    const uint32_t mm = gr.min_member[gi];
-    const uint32_t sc0 = gsc;
-    const uint32_t m1 = gmatched + 1u;                                                               // :290
-    const bool ready = m1 >= (uint32_t)(mm - sc0);                                                   // :303
-    if (t0) {
-      sq.g_matched[gi] = m1;
-      const uint32_t prev = sq.head[gi];
-      sq.wait_rec[i] = ((unsigned long long)prev << 32) | at;
-      uint32_t nf = gflags, scn = sc0;
+    } else if (at != BS_INF) {
+      // ---- Permit, core.go:268-309.  Every wave applies the update to its copy of the group; thread 0 writes it out.
+      const uint32_t mm = gr.min_member[gi];
+      const uint32_t m1 = gmatched + 1u;                                                             // :290
+      const bool ready = m1 >= (uint32_t)(mm - gsc);                                                 // :303
+      const bool first_time = ready && !(gflags & BS_GROUP_SCHEDULED_LATCH);
+      const uint32_t prev = own.head, k = own.nwait + 1u;
+      fold_valid = false;                                    // matched moved: the group's progress changed
+      own.matched = m1;
       if (!ready) {
-        sq.head[gi] = i + 1u;
-        sq.nwait[gi] = sq.nwait[gi] + 1u;
+        if (t0) {
+          sq.g_matched[gi] = m1;
+          sq.wait_rec[i] = ((unsigned long long)prev << 32) | at;
+          sq.head[gi] = i + 1u;
+          sq.nwait[gi] = k;
+          if (wl_ok && wl_cnt < kSeqWaitList) { sh_.wl_pod[wl_cnt] = i; sh_.wl_node[wl_cnt] = at; }
+        }
+        own.head = i + 1u;
+        own.nwait = k;
+        if (wl_cnt < kSeqWaitList) wl_cnt++; else wl_ok = false;
       } else {
-        const bool first_time = !(gflags & BS_GROUP_SCHEDULED_LATCH);
-        nf |= BS_GROUP_SCHEDULED_LATCH;                                                              // :305
-        const uint32_t k = sq.nwait[gi] + 1u;
-        sq.pod_node[i] = (int32_t)at;
-        for (uint32_t wv = prev; wv != 0u;) {                // the waiting pods of the gang bind (batchscheduler.go:254-344)
-          const unsigned long long rec = sq.wait_rec[wv - 1u];
-          sq.pod_node[wv - 1u] = (int32_t)(uint32_t)rec;
-          wv = (uint32_t)(rec >> 32);
+        // the waiting pods of the gang bind (batchscheduler.go:254-344): in parallel from the LDS list when it holds them all
+        const bool from_list = wl_ok && wl_cnt == own.nwait;
+        if (from_list) {
+          for (uint32_t e = threadIdx.x; e < wl_cnt; e += kSeqBlock) sq.pod_node[sh_.wl_pod[e]] = (int32_t)sh_.wl_node[e];
         }
-        sq.head[gi] = 0;
-        sq.nwait[gi] = 0;
-        scn = sc0 + k;                                                                               // PostBind, core.go:327
-        sq.g_sc[gi] = scn;
-        sq.g_flags[gi] = (uint8_t)nf;
-        if (first_time) {
-          if (n_released < sq.cap) {
-            sq.released_group[n_released] = (uint32_t)gi;
-            sq.released_pods[n_released] = k;
-            sq.first_tick[n_released] = sq.t_first[gi];
-            sq.ready_tick[n_released] = (unsigned long long)wall_clock64() - clk0;
-            sq.slot_of[gi] = n_released;
+        gflags |= BS_GROUP_SCHEDULED_LATCH;                                                          // :305
+        const uint32_t scn = gsc + k;                                                                // PostBind, core.go:327
+        if (t0) {
+          sq.g_matched[gi] = m1;
+          sq.pod_node[i] = (int32_t)at;
+          if (!from_list)
+            for (uint32_t wv = prev; wv != 0u;) {
+              const unsigned long long rec = sq.wait_rec[wv - 1u];
+              sq.pod_node[wv - 1u] = (int32_t)(uint32_t)rec;
+              wv = (uint32_t)(rec >> 32);
+            }
+          sq.head[gi] = 0;
+          sq.nwait[gi] = 0;
+          sq.g_sc[gi] = scn;
+          sq.g_flags[gi] = (uint8_t)gflags;
+          if (first_time) {
+            if (n_released < sq.cap) {
+              sq.released_group[n_released] = (uint32_t)gi;
+              sq.released_pods[n_released] = k;
+              sq.first_tick[n_released] = sq.t_first[gi];
+              sq.ready_tick[n_released] = (unsigned long long)wall_clock64() - clk0;
+              sq.slot_of[gi] = n_released;
+            }
+          } else if (sq.slot_of[gi] != BS_INF) {
+            sq.released_pods[sq.slot_of[gi]] += k;           // a late member of a gang that is already through
           }
-        } else if (sq.slot_of[gi] != BS_INF) {
-          sq.released_pods[sq.slot_of[gi]] += k;             // a late member of a gang that is already through
         }
+        own.head = 0;
+        own.nwait = 0;
+        own.sc = scn;
+        own.flags = gflags;
+        wl_cnt = 0;
+        wl_ok = true;
+        if (first_time) n_released++;
       }
-      const unsigned long long key = seq_key((uint32_t)gi, nf, mm, scn, m1);
-      if (prm.keys_in_lds) s_keys[gi] = key; else sq.keys[gi] = key;
+      if (t0) {
+        const unsigned long long key = seq_key((uint32_t)gi, own.flags, mm, own.sc, m1);
+        if (prm.keys_in_lds) s_keys[gi] = key; else sq.keys[gi] = key;
+      }
     }
-    if (ready && !(gflags & BS_GROUP_SCHEDULED_LATCH)) n_released++;
+    if (grouped && gi == ldr_of) {                           // the leader's copy follows what this pod did to its group
+      const uint32_t h = ldr.head;
+      ldr = own;
+      ldr.head = h;
+    }
+    BS_SEQ_T(5);
   }
-  __syncthreads();
+  BS_SEQ_FULL_BARRIER();
   if (t0) {
     sq.info[0] = n_released;
     sq.info[1] = (unsigned long long)wall_clock64() - clk0;
-    sq.info[2] = n_pass;
+    sq.info[2] = n_pick;
     sq.info[3] = n_scan;
     sq.info[4] = (unsigned long long)(uint32_t)(sop_leader + 1);
+    sq.info[5] = n_rounds;
+    sq.info[6] = n_tiles;
+    sq.info[7] = n_folds;
+#ifdef BS_SEQ_PROBE
+    for (int k = 0; k < 8; ++k) sq.info[8 + k] = ph[k];
+#endif
   }
 }
 

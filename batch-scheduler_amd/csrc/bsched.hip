@@ -954,6 +954,8 @@ void launch_epoch_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd,
 
 template <int TS>
 void launch_seq_s(bs_ctx* c, size_t lds, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const SeqDev& sq, const SeqParams& prm) {
+  // static LDS (first-fit bounds, reduction slots) + the key window can exceed the default 64 KB of dynamic LDS
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_pass<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seq_pass<TS>), dim3(1), dim3(kSeqBlock), lds, c->stream, pd, gr, nd, sq, prm);
 }
 
@@ -2917,12 +2919,13 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   if (G > 0x7FFFFFF0u) return BS_ERR_CAPACITY;
   out->n_released = 0;
   out->total_ns = 0;
-  out->node_passes = out->node_scans = 0;
+  out->node_picks = out->node_scans = out->scan_rounds = out->pick_rounds = out->leader_folds = 0;
   // ---- scratch: one allocation
   const size_t nP = std::max<uint32_t>(P, 1), nG = std::max<uint32_t>(G, 1), cap = std::max<uint32_t>(out->cap, 1), stride = std::max<uint32_t>(c->Ncap, 1);
   size_t o = 0;
   const size_t o_sc07 = o; o = align256(o + stride * L * 8);
   const size_t o_sc10 = o; o = align256(o + stride * L * 8);
+  const size_t o_meta = o; o = align256(o + stride * 4);
   const size_t o_keys = o; o = align256(o + nG * 8);
   const size_t o_wait = o; o = align256(o + nP * 8);
   const size_t o_head = o; o = align256(o + nG * 4);
@@ -2938,7 +2941,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   const size_t o_rp = o; o = align256(o + cap * 4);
   const size_t o_ft = o; o = align256(o + cap * 8);
   const size_t o_rt = o; o = align256(o + cap * 8);
-  const size_t o_info = o; o = align256(o + 64);
+  const size_t o_info = o; o = align256(o + 128);
   HIPCHK(c, c->d_seq.reserve(o));
   uint8_t* base = c->d_seq.as<uint8_t>();
   GroupsDev gr = groups_dev(c);
@@ -2952,8 +2955,9 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   sq.g_minres = const_cast<int64_t*>(gr.minres);
   sq.g_mrpres = const_cast<uint32_t*>(gr.mrpres);
   sq.g_occ = const_cast<uint64_t*>(gr.occupied);
-  sq.sc07 = reinterpret_cast<int64_t*>(base + o_sc07);
-  sq.sc10 = reinterpret_cast<int64_t*>(base + o_sc10);
+  sq.left07 = reinterpret_cast<int64_t*>(base + o_sc07);
+  sq.left10 = reinterpret_cast<int64_t*>(base + o_sc10);
+  sq.nmeta = reinterpret_cast<uint32_t*>(base + o_meta);
   sq.keys = reinterpret_cast<unsigned long long*>(base + o_keys);
   sq.wait_rec = reinterpret_cast<unsigned long long*>(base + o_wait);
   sq.head = reinterpret_cast<uint32_t*>(base + o_head);
@@ -2977,8 +2981,9 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   prm.C = C;
   prm.sop_leader0 = c->sop_leader0;
   prm.keys_in_lds = G <= kSeqKeysLds ? 1u : 0u;
+  prm.prune = cdiv(N, 64) <= kSeqPruneTiles ? 1u : 0u;
   const size_t lds = prm.keys_in_lds ? (size_t)nG * 8 : 0;
-  HIPCHK(c, hipMemsetAsync(base + o_info, 0, 64, c->stream));
+  HIPCHK(c, hipMemsetAsync(base + o_info, 0, 128, c->stream));
   const PodsDev pd = pods_dev(c);
   const NodesDev nd = nodes_dev(c);
   switch (c->S <= 4 ? (int)c->S : -1) {
@@ -3001,8 +3006,15 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   auto to_ns = [&](unsigned long long ticks) { return (int64_t)((long double)ticks * 1.0e6L / (long double)khz); };
   out->n_released = (uint32_t)info[0];
   out->total_ns = to_ns(info[1]);
-  out->node_passes = info[2];
+  out->node_picks = info[2];
   out->node_scans = info[3];
+  out->scan_rounds = info[5];
+  out->pick_rounds = info[6];
+  out->leader_folds = info[7];
+  if (const char* e = std::getenv("BS_SEQ_PROBE_PRINT")) {   // probe build: cycles per phase (see bs_seq.hpp)
+    if (std::atoi(e)) std::fprintf(stderr, "seq probe cycles: control %llu capture %llu fold %llu scan %llu pick %llu permit %llu top-barrier %llu\n", info[8], info[9],
+                                   info[10], info[11], info[12], info[13], info[14]);
+  }
   if (P) {
     if (out->pf_code) std::memcpy(out->pf_code, rb + o_code, P);
     if (out->pod_node) std::memcpy(out->pod_node, rb + o_node, (size_t)P * 4);

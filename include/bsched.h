@@ -494,7 +494,10 @@ typedef struct bs_seq_out {
   int64_t*  ready_ns;        /* [cap] ... the quorum of core.go:303 turned true (NULL ok for all four)                 */
   uint32_t  n_released;      /* out: gangs released (may exceed cap: the first cap are recorded)                       */
   int64_t   total_ns;        /* out: device time of the whole pass                                                     */
-  uint64_t  node_passes, node_scans;   /* out: sweeps over the node list, and how many of them carried a PreFilter scan */
+  /* out, work counters: first-fit searches; PreFilter node scans; rounds of 1024 nodes those scans went through (they stop at
+   * the reference's early exit); rounds of up to 16 candidate tiles of 64 nodes the first-fit searches looked at; findMaxPG
+   * folds (the fold is only repeated after a capture / Permit / release changed a group's progress) */
+  uint64_t  node_picks, node_scans, scan_rounds, pick_rounds, leader_folds;
 } bs_seq_out;
 int bs_seq_run(bs_ctx* ctx, uint32_t stages, bs_seq_out* out);
 /* The node requests as the context holds them (after bs_nodes_load / bs_nodes_apply / bs_nodes_assume / bs_seq_run):
