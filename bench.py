@@ -233,9 +233,43 @@ def drain_section(bsa, nodes, fit, groups, pods, args):
                                    "gang_admit_latency_ms_p50": pct(lat, 50), "gang_admit_latency_ms_p95": pct(lat, 95),
                                    "time_since_pass_start_ms_p50": pct(s["ready_ns"] / 1e6, 50),
                                    "latency_definition": "per gang: first pod entering PreFilter (core.go:88) -> quorum of core.go:303 true"}
-    res["same_gangs_as_cpu_pass"] = sorted(best["admitted_group"].tolist()) == sorted(s["released_group"].tolist())
-    res["relation"] = ("gang-granular drain vs pod-by-pod pass: equal on complete cold queues (tests/test_drain.py); otherwise the pass lets partial "
-                       "gangs hold what they assumed and re-checks reservations pod by pod, so the two sets can differ — both counts are reported")
+    res["gang_granular_drain_same_gangs_as_cpu_pass"] = sorted(best["admitted_group"].tolist()) == sorted(s["released_group"].tolist())
+    res["relation"] = ("gang-granular drain (a pre-screen loop over frozen snapshots) vs pod-by-pod pass: equal on complete cold queues (tests/test_drain.py); "
+                       "otherwise the pass lets partial gangs hold what they assumed and re-checks reservations pod by pod, so the two sets can differ.  "
+                       "sequential_on_device IS the pod-by-pod pass (bs_seq_run): same gangs, same nodes, same codes as the CPU port's")
+    # ---- the reference's own order of events on the device: bs_seq_run (PreFilter -> node choice -> assume -> Permit -> release, pod by pod)
+    runs = []
+    for rep in range(3):
+        with bsa.Context(scalar_lanes=nodes.lanes - 4) as ctx:
+            ctx.load_nodes(nodes, fit)
+            ctx.load_groups(groups)
+            ctx.load_pods(q)
+            ctx.sync()
+            t = time.perf_counter()
+            r = ctx.seq_run(soa.STAGE_PREFILTER)
+            runs.append((time.perf_counter() - t, r))
+    wall, r = min(runs, key=lambda x: x[0])
+    dlat = (r["ready_ns"] - r["first_ns"]) / 1e6
+    identical = (r["released_group"].tolist() == s["released_group"].tolist() and r["released_pods"].tolist() == s["released_pods"].tolist()
+                 and np.array_equal(r["pod_node"], s["pod_node"]) and np.array_equal(r["pf_code"], s["pf_code"]) and np.array_equal(r["pf_first_k"], s["pf_first_k"]))
+    p50_dev, p50_cpu = pct(dlat, 50), pct(lat, 50)
+    res["sequential_on_device"] = {
+        "what": "bs_seq_run: ONE persistent workgroup walks the resident queue pod by pod with the reference's semantics (core.go:88-167, :268-309, "
+                "batchscheduler.go:254-344): PreFilter against the CURRENT node requests and group counters, first-fit node choice, assume, Permit, release at the quorum",
+        "same_gangs_as_cpu_pass": r["released_group"].tolist() == s["released_group"].tolist(),
+        "bit_identical_to_cpu_pass": bool(identical),
+        "gangs_released": r["n_released"], "pods_released": int((r["pod_node"] >= 0).sum()),
+        "total_ms_host_observed": wall * 1e3, "total_ms_device": r["total_ns"] / 1e6, "us_per_pod": r["total_ns"] / 1e3 / max(q.p, 1),
+        "gangs_per_s": r["n_released"] / max(wall, 1e-12),
+        "gang_admit_latency_ms_p50": p50_dev, "gang_admit_latency_ms_p95": pct(dlat, 95),
+        "latency_definition": "per gang, device clock: first pod entering PreFilter (core.go:88) -> quorum of core.go:303 true (the same definition as the CPU pass)",
+        "speedup_vs_cpu_port": {"gang_admit_latency_p50": p50_cpu / p50_dev if p50_dev else None, "whole_pass": s["total_ns"] / 1e9 / max(wall, 1e-12)},
+        "work": {"node_scans": r["node_scans"], "scan_rounds_of_1024_nodes": r["scan_rounds"], "first_fit_searches": r["node_picks"],
+                 "first_fit_rounds_of_16_tiles": r["pick_rounds"], "findMaxPG_folds": r["leader_folds"],
+                 "evals_executed": r["scan_rounds"] * 1024, "evals_per_s": r["scan_rounds"] * 1024 / max(r["total_ns"] * 1e-9, 1e-12),
+                 "cpu_port_reference_loop_iterations": s["iters"]},
+    }
+    res["same_gangs_as_cpu_pass"] = res["sequential_on_device"]["same_gangs_as_cpu_pass"]
     res["one_to_one_mode"] = one_to_one(bsa, nodes, fit, groups, q, 300)
     return res
 
@@ -533,7 +567,14 @@ def main():
             dom = max(launches, key=lambda x: x["avg_launch_us"])
             roofline = dict(dom)
             ksum = sum(x["avg_launch_us"] for x in launches)
-            roofline.update({"bound": "hbm", "limiter": "launch latency and dependent-load chains (the step is two small launches, three dependency levels; see frac)",
+            bpe = (16 * L + 2) + ((16 * 4 + 1 + 0.125) if args.stages == "all" else 0.0)       # bytes per logical pod x node eval
+            ev_exec = stats["scan_evals_executed"] + stats["filter_evals_executed"]
+            roofline.update({"bound": "latency", "nominal_bound": "hbm",
+                             "frac_per_eval_logical": value * bpe / (HBM_PEAK_GBS * 1e9), "frac_per_eval_executed": ev_exec / (ms_per_step * 1e-3) * bpe / (HBM_PEAK_GBS * 1e9),
+                             "bytes_per_eval": bpe,
+                             "frac_note": "SURVEY 8(d)'s formula evals/s x bytes/eval / 8 TB/s, on the LOGICAL rate (> 1: the step does not do per-eval work — request "
+                                          "classes and pruning, see work_avoided) and on the EXECUTED rate; `frac` above is compulsory bytes / kernel time / 8 TB/s",
+                             "limiter": "launch latency and dependent-load chains (the step is two small launches, three dependency levels; see frac)",
                              "source": prof_src, "sum_of_launch_us": ksum, "ms_per_step_us": ms_per_step * 1e3,
                              "note": "the step's longest launch (by kernel-only time).  achieved = compulsory algorithmic bytes of the launch (every input once, "
                                      "every output once; DESIGN.md section 7) / its mean kernel duration; traffic = HBM bytes per launch from PMC; "
@@ -619,13 +660,20 @@ def main():
                        "decisions": {soa.PF_NAMES.get(i, str(i)): int(c) for i, c in enumerate(codes) if c},
                        "groups_ready": int(out.group_ready.sum())},
             "value_resident": value,
+            "value_executed": (stats["scan_evals_executed"] + stats["filter_evals_executed"]) / (ms_per_step * 1e-3),
+            "value_note": "`value` is a LOGICAL rate (pods x nodes / step time); `value_executed` = pod x node compares the step really executed / step time",
             "value_host_observed": cycle["evals_per_s_at_p50"] if cycle else None,
             "roofline": roofline,
             "roofline_launches": launches,
             "work_avoided": work_avoided,
             "host_cycle": cycle,
-            "gang_admit_latency_ms_p50": cycle["gang_admit_latency_ms_p50"] if cycle else None,
-            "gang_admit_latency_ms_p95": cycle["gang_admit_latency_ms_p95"] if cycle else None,
+            # the reference's semantics (pod-by-pod pass on the device, bit-identical to the CPU port's pass) — NOT the batched cycle
+            "gang_admit_latency_ms_p50": drain["sequential_on_device"]["gang_admit_latency_ms_p50"] if drain else None,
+            "gang_admit_latency_ms_p95": drain["sequential_on_device"]["gang_admit_latency_ms_p95"] if drain else None,
+            "gang_admit_latency_definition": "drain.sequential_on_device (bs_seq_run): first pod of the gang entering PreFilter -> quorum, reference semantics; "
+                                             "compare with cpu_baseline.gang_admit_latency_ms_p50 (the CPU port's pass on the same queue)",
+            "batched_cycle_latency_ms_p50": cycle["gang_admit_latency_ms_p50"] if cycle else None,
+            "batched_cycle_latency_ms_p95": cycle["gang_admit_latency_ms_p95"] if cycle else None,
             "drain": drain,
             "scenarios": extras,
             "kernel_ms_per_step": {k: v[0] / v[1] for k, v in timing.items() if v[1]},

@@ -25,7 +25,11 @@ def test_bench_json_contract():
     assert d["vs_baseline"] is None and d["dtype"] == "int64" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - d["config"]["logical_evals_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # the step is two latency-bound launches; HBM stays the nominal roofline the bytes are priced against
+    assert r["bound"] == "latency" and r["nominal_bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["frac_per_eval_logical"] - d["value"] * r["bytes_per_eval"] / 8e12) < 1e-9 * r["frac_per_eval_logical"]
+    assert abs(r["frac_per_eval_executed"] - d["value_executed"] * r["bytes_per_eval"] / 8e12) < 1e-9 * max(r["frac_per_eval_executed"], 1e-30)
+    assert 0 < d["value_executed"] <= d["value"]
     assert "traffic" in r and "kernel" in r and r["avg_launch_us"] > 0
     for e in d["roofline_launches"]:                      # compulsory bytes / kernel-only time: nothing can exceed the roofline
         assert 0 < e["frac"] <= 1.0, e
@@ -44,6 +48,11 @@ def test_bench_json_contract():
     dr = d["drain"]
     assert dr["gpu"]["gangs_released"] > 0 and dr["gpu"]["gang_admit_latency_ms_p50"] > 0 and dr["one_to_one_mode"]["prefilter_latency_ms_p50"] > 0
     assert c["sequential_pass"]["gangs_released"] > 0 and c["gang_admit_latency_ms_p50"] == c["sequential_pass"]["gang_admit_latency_ms_p50"]
+    # the pod-by-pod pass on the device is the CPU pass, gang for gang; it is the headline gang-admit latency
+    sd = dr["sequential_on_device"]
+    assert sd["same_gangs_as_cpu_pass"] is True and sd["bit_identical_to_cpu_pass"] is True and dr["same_gangs_as_cpu_pass"] is True
+    assert sd["gangs_released"] == c["sequential_pass"]["gangs_released"] and sd["pods_released"] == c["sequential_pass"]["pods_released"]
+    assert d["gang_admit_latency_ms_p50"] == sd["gang_admit_latency_ms_p50"] > 0 and d["batched_cycle_latency_ms_p50"] == hc["gang_admit_latency_ms_p50"]
     assert set(d["scenarios"]) >= {"cold", "warm", "busy", "all_distinct_requests", "prefilter_only", "ms_per_step_by_seed"}
     assert d["value"] > 10e6, "north_star target: >= 10M pod x node fit evaluations/s"
 
