@@ -30,6 +30,8 @@ ABI_SYMBOLS = [
     "bs_shard_set", "bs_reduce_external", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
     "bs_timing_reset", "bs_timing_get", "bs_kernel_name", "bs_batch_stats_get",
     "bs_seq_run", "bs_nodes_read",
+    "bs_nodes_load_flat", "bs_groups_load_flat", "bs_groups_read_flat", "bs_pods_load_flat", "bs_pods_apply_flat", "bs_pods_read_flat",
+    "bs_batch_read_flat", "bs_seq_run_flat", "bs_fit_build_flat",
 ]
 
 

@@ -3063,6 +3063,96 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// flat-argument forms (cgo: no Go-allocated struct of Go pointers crosses by pointer): the structs are built HERE, on the C stack
+// -------------------------------------------------------------------------------------------------
+int bs_nodes_load_flat(bs_ctx* c, uint32_t n, const int64_t* allocatable, const int64_t* requested, const uint32_t* allocatable_present,
+                       const uint32_t* requested_present, const uint8_t* flags) {
+  bs_nodes_soa s{};
+  s.n = n; s.allocatable = allocatable; s.requested = requested; s.allocatable_present = allocatable_present; s.requested_present = requested_present;
+  s.flags = flags;
+  return bs_nodes_load(c, &s);
+}
+int bs_groups_load_flat(bs_ctx* c, uint32_t g, const uint32_t* min_member, const uint32_t* status_scheduled, const uint32_t* matched, const uint8_t* flags,
+                        const uint32_t* cls, const int64_t* min_resources, const uint32_t* min_resources_present, const uint64_t* occupied_by) {
+  bs_groups_soa s{};                                   // (the struct serves bs_groups_read too, hence non-const members: the load only reads)
+  s.g = g;
+  s.min_member = const_cast<uint32_t*>(min_member); s.status_scheduled = const_cast<uint32_t*>(status_scheduled); s.matched = const_cast<uint32_t*>(matched);
+  s.flags = const_cast<uint8_t*>(flags); s.cls = const_cast<uint32_t*>(cls); s.min_resources = const_cast<int64_t*>(min_resources);
+  s.min_resources_present = const_cast<uint32_t*>(min_resources_present); s.occupied_by = const_cast<uint64_t*>(occupied_by);
+  return bs_groups_load(c, &s);
+}
+int bs_groups_read_flat(bs_ctx* c, uint32_t g, uint32_t* min_member, uint32_t* status_scheduled, uint32_t* matched, uint8_t* flags, uint32_t* cls,
+                        int64_t* min_resources, uint32_t* min_resources_present, uint64_t* occupied_by) {
+  bs_groups_soa s{};
+  s.g = g; s.min_member = min_member; s.status_scheduled = status_scheduled; s.matched = matched; s.flags = flags; s.cls = cls;
+  s.min_resources = min_resources; s.min_resources_present = min_resources_present; s.occupied_by = occupied_by;
+  return bs_groups_read(c, &s);
+}
+int bs_pods_load_flat(bs_ctx* c, uint32_t p, const int32_t* group, const int64_t* req, const uint32_t* req_present, const uint32_t* cls, const uint64_t* owner,
+                      const uint8_t* flags) {
+  bs_pods_soa s{};
+  s.p = p; s.group = group; s.req = req; s.req_present = req_present; s.cls = cls; s.owner = owner; s.flags = flags;
+  return bs_pods_load(c, &s);
+}
+int bs_pods_apply_flat(bs_ctx* c, uint32_t n_remove, const uint32_t* remove, uint32_t n_flags, const uint32_t* flag_index, const uint8_t* flag_value,
+                       uint32_t n_insert, const int32_t* group, const int64_t* req, const uint32_t* req_present, const uint32_t* cls, const uint64_t* owner,
+                       const uint8_t* flags, const uint32_t* insert_at) {
+  bs_pods_delta d{};
+  d.n_remove = n_remove; d.remove = remove; d.n_flags = n_flags; d.flag_index = flag_index; d.flag_value = flag_value;
+  d.insert.p = n_insert; d.insert.group = group; d.insert.req = req; d.insert.req_present = req_present; d.insert.cls = cls; d.insert.owner = owner;
+  d.insert.flags = flags;
+  d.insert_at = insert_at;
+  return bs_pods_apply(c, &d);
+}
+int bs_pods_read_flat(bs_ctx* c, uint32_t p, int32_t* group, int64_t* req, uint32_t* req_present, uint32_t* cls, uint64_t* owner, uint8_t* flags) {
+  bs_pods_out o{};
+  o.p = p; o.group = group; o.req = req; o.req_present = req_present; o.cls = cls; o.owner = owner; o.flags = flags;
+  return bs_pods_read(c, &o);
+}
+int bs_batch_read_flat(bs_ctx* c, uint8_t* pf_code, uint32_t* pf_first_k, int32_t* pf_leader, uint8_t* fl_code, uint32_t* fl_feasible, uint64_t* fl_bitmap,
+                       uint32_t* group_admit, uint8_t* group_ready, uint32_t* fl_slot, uint64_t* fl_rows, uint32_t* fl_rows_feasible, uint32_t fl_rows_cap,
+                       uint32_t* fl_rows_n) {
+  bs_batch_out o{};
+  o.pf_code = pf_code; o.pf_first_k = pf_first_k; o.pf_leader = pf_leader; o.fl_code = fl_code; o.fl_feasible = fl_feasible; o.fl_bitmap = fl_bitmap;
+  o.group_admit = group_admit; o.group_ready = group_ready; o.fl_slot = fl_slot; o.fl_rows = fl_rows; o.fl_rows_feasible = fl_rows_feasible;
+  o.fl_rows_cap = fl_rows_cap; o.fl_rows_n = fl_rows_n;
+  return bs_batch_read(c, &o);
+}
+int bs_seq_run_flat(bs_ctx* c, uint32_t stages, uint8_t* pf_code, uint32_t* pf_first_k, int32_t* pf_leader, int32_t* pod_node, uint32_t cap,
+                    uint32_t* released_group, uint32_t* released_pods, int64_t* first_ns, int64_t* ready_ns, int64_t* scalars_out) {
+  bs_seq_out o{};
+  o.pf_code = pf_code; o.pf_first_k = pf_first_k; o.pf_leader = pf_leader; o.pod_node = pod_node; o.cap = cap; o.released_group = released_group;
+  o.released_pods = released_pods; o.first_ns = first_ns; o.ready_ns = ready_ns;
+  const int rc = bs_seq_run(c, stages, &o);
+  if (scalars_out) {
+    scalars_out[0] = o.n_released; scalars_out[1] = o.total_ns; scalars_out[2] = (int64_t)o.node_picks; scalars_out[3] = (int64_t)o.node_scans;
+    scalars_out[4] = (int64_t)o.scan_rounds; scalars_out[5] = (int64_t)o.pick_rounds; scalars_out[6] = (int64_t)o.leader_folds;
+  }
+  return rc;
+}
+int bs_fit_build_flat(bs_ctx* c, uint32_t n, const uint32_t* name, const uint32_t* label_off, const uint32_t* label_key, const uint32_t* label_val,
+                      const int64_t* label_int, const uint8_t* label_int_ok, const uint32_t* taint_off, const uint32_t* taint_key, const uint32_t* taint_val,
+                      const uint8_t* taint_effect, uint32_t cn, uint32_t field_name_key, const uint8_t* tpl_flags, const uint32_t* sel_off,
+                      const uint32_t* sel_key, const uint32_t* sel_val, const uint32_t* term_off, const uint32_t* term_expr_off, const uint32_t* term_field_off,
+                      uint32_t ex_count, const uint32_t* ex_key, const uint8_t* ex_op, const uint32_t* ex_val_off, const uint32_t* ex_val,
+                      const int64_t* ex_val_int, const uint8_t* ex_val_int_ok, uint32_t fd_count, const uint32_t* fd_key, const uint8_t* fd_op,
+                      const uint32_t* fd_val_off, const uint32_t* fd_val, const int64_t* fd_val_int, const uint8_t* fd_val_int_ok, const uint32_t* tol_off,
+                      const uint32_t* tol_key, const uint32_t* tol_val, const uint8_t* tol_op, const uint8_t* tol_effect) {
+  bs_node_labels nl{};
+  nl.n = n; nl.name = name; nl.label_off = label_off; nl.label_key = label_key; nl.label_val = label_val; nl.label_int = label_int;
+  nl.label_int_ok = label_int_ok; nl.taint_off = taint_off; nl.taint_key = taint_key; nl.taint_val = taint_val; nl.taint_effect = taint_effect;
+  bs_fit_templates tp{};
+  tp.c = cn; tp.field_name_key = field_name_key; tp.flags = tpl_flags; tp.sel_off = sel_off; tp.sel_key = sel_key; tp.sel_val = sel_val;
+  tp.term_off = term_off; tp.term_expr_off = term_expr_off; tp.term_field_off = term_field_off;
+  tp.exprs.count = ex_count; tp.exprs.key = ex_key; tp.exprs.op = ex_op; tp.exprs.val_off = ex_val_off; tp.exprs.val = ex_val; tp.exprs.val_int = ex_val_int;
+  tp.exprs.val_int_ok = ex_val_int_ok;
+  tp.fields.count = fd_count; tp.fields.key = fd_key; tp.fields.op = fd_op; tp.fields.val_off = fd_val_off; tp.fields.val = fd_val;
+  tp.fields.val_int = fd_val_int; tp.fields.val_int_ok = fd_val_int_ok;
+  tp.tol_off = tol_off; tp.tol_key = tol_key; tp.tol_val = tol_val; tp.tol_op = tol_op; tp.tol_effect = tol_effect;
+  return bs_fit_build(c, &nl, &tp);
+}
+
+// -------------------------------------------------------------------------------------------------
 // native RCCL (for hosts without torch): librccl is dlopen'ed on first use
 // -------------------------------------------------------------------------------------------------
 static void* open_rccl() {

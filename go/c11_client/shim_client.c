@@ -5,12 +5,14 @@
  * does exactly that, in the shim's order, through the same header and the same shared library:
  *
  *   newGPUCore      bs_abi_version, bs_create                                   (bsched_cgo.go: newGPUCore)
- *   loadSnapshot    bs_nodes_load, bs_fit_load                                  (bsched_cgo.go: loadSnapshot, core.go:437,567,597)
- *   loadGroups      bs_groups_load                                              (bsched_batch.go: loadGroups)
- *   runBatch        bs_pods_load, bs_batch_run(BS_STAGE_ALL), bs_filter_rows_count, bs_batch_read   (bsched_batch.go: runBatch)
+ *   loadSnapshot    bs_nodes_load_flat, bs_fit_load                             (bsched_cgo.go: loadSnapshot, core.go:437,567,597)
+ *   loadGroups      bs_groups_load_flat                                         (bsched_batch.go: loadGroups)
+ *   runBatch        bs_pods_load_flat, bs_batch_run(BS_STAGE_ALL), bs_filter_rows_count, bs_batch_read_flat   (bsched_batch.go: runBatch)
  *   clusterFits     bs_cluster_fits for the first pods of the queue              (bsched_cgo.go: clusterFits, core.go:595-632)
- *   next cycle      bs_groups_apply (patchGroups), bs_pods_apply, bs_batch_run(| BS_BATCH_HOST_RESULTS), bs_batch_map
+ *   next cycle      bs_groups_apply (patchGroups), bs_pods_apply_flat, bs_batch_run(| BS_BATCH_HOST_RESULTS), bs_batch_map
  *   close           bs_destroy
+ * The struct-taking entry points are reached through their *_flat forms only, exactly as the Go files do (cgo pointer rule: no
+ * Go-allocated struct of Go pointers crosses by pointer) — so the forms the shim binds are compiled, linked and run here.
  *
  * Built with  gcc -std=c11 -Wall -Wextra -Wpedantic -Werror  (tests/test_c11_client.py: header is valid C11, every symbol
  * the shim binds resolves against libbsched.so); run on a GPU box against a scene file written by the test, whose results
@@ -89,7 +91,7 @@ int main(int argc, char** argv) {
   nodes.requested_present = rd(f, (size_t)N * 4);
   nodes.flags = rd(f, N);
   const uint32_t* fit = rd(f, (size_t)C * FW * 4);
-  CHECK(bs_nodes_load(ctx, &nodes));
+  CHECK(bs_nodes_load_flat(ctx, nodes.n, nodes.allocatable, nodes.requested, nodes.allocatable_present, nodes.requested_present, nodes.flags));
   CHECK(bs_fit_load(ctx, C, fit));
   uint32_t n_back = 0;
   CHECK(bs_nodes_count(ctx, &n_back));
@@ -106,7 +108,8 @@ int main(int argc, char** argv) {
   groups.min_resources = rd(f, (size_t)L * G * 8);
   groups.min_resources_present = rd(f, (size_t)G * 4);
   groups.occupied_by = rd(f, (size_t)G * 8);
-  CHECK(bs_groups_load(ctx, &groups));
+  CHECK(bs_groups_load_flat(ctx, groups.g, groups.min_member, groups.status_scheduled, groups.matched, groups.flags, groups.cls, groups.min_resources,
+                            groups.min_resources_present, groups.occupied_by));
 
   /* ---- runBatch */
   bs_pods_soa pods;
@@ -119,7 +122,7 @@ int main(int argc, char** argv) {
   uint8_t* pflags = rd(f, P);
   fclose(f);
   pods.group = pgroup; pods.req = preq; pods.req_present = ppres; pods.cls = pcls; pods.owner = powner; pods.flags = pflags;
-  CHECK(bs_pods_load(ctx, &pods));
+  CHECK(bs_pods_load_flat(ctx, pods.p, pods.group, pods.req, pods.req_present, pods.cls, pods.owner, pods.flags));
   CHECK(bs_batch_run(ctx, BS_STAGE_ALL));
   uint32_t rows_needed = 0;
   CHECK(bs_filter_rows_count(ctx, &rows_needed));
@@ -134,11 +137,7 @@ int main(int argc, char** argv) {
   uint32_t* admit = calloc(G + 1, 4);
   uint8_t* ready = calloc(G + 1, 1);
   uint32_t rows_n = 0;
-  bs_batch_out out;
-  memset(&out, 0, sizeof out);
-  out.pf_code = pf_code; out.pf_first_k = pf_first_k; out.pf_leader = pf_leader; out.fl_code = fl_code; out.fl_feasible = fl_feasible;
-  out.fl_slot = fl_slot; out.fl_rows = rows; out.fl_rows_cap = rows_cap; out.fl_rows_n = &rows_n; out.group_admit = admit; out.group_ready = ready;
-  CHECK(bs_batch_read(ctx, &out));
+  CHECK(bs_batch_read_flat(ctx, pf_code, pf_first_k, pf_leader, fl_code, fl_feasible, NULL, admit, ready, fl_slot, rows, NULL, rows_cap, &rows_n));
   /* batchResult.filterPasses: the Filter answer is a bit test in the rows — it has to agree with the per-pod feasible count */
   for (uint32_t i = 0; i < P; ++i) {
     if (fl_code[i] != BS_FL_EVALUATED) continue;
@@ -180,13 +179,7 @@ int main(int argc, char** argv) {
     ig[k] = pgroup[s]; ipres[k] = ppres[s]; icls[k] = pcls[s]; iown[k] = powner[s]; ifl[k] = pflags[s];
     for (uint32_t j = 0; j < L; ++j) ireq[(size_t)j * nmove + k] = preq[(size_t)j * P + s];
   }
-  bs_pods_delta pd;
-  memset(&pd, 0, sizeof pd);
-  pd.n_remove = nmove; pd.remove = remove;
-  pd.insert.p = nmove; pd.insert.group = ig; pd.insert.req = ireq; pd.insert.req_present = ipres; pd.insert.cls = icls; pd.insert.owner = iown;
-  pd.insert.flags = ifl;
-  pd.insert_at = NULL; /* append */
-  CHECK(bs_pods_apply(ctx, &pd));
+  CHECK(bs_pods_apply_flat(ctx, nmove, remove, 0, NULL, NULL, nmove, ig, ireq, ipres, icls, iown, ifl, NULL /* append */));
   uint32_t p2 = 0;
   CHECK(bs_pods_count(ctx, &p2));
   if (p2 != P) return 6;

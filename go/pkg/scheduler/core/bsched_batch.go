@@ -44,14 +44,14 @@ func (g *gpuCore) loadGroups(order []string, pgCache map[string]*cache.PodGroupM
 		}
 		occ[i] = C.uint64_t(g.intern64(pgs.PodGroup.Status.OccupiedBy)) // 0 == ""
 	}
-	soa := C.bs_groups_soa{g: C.uint32_t(G), min_member: &mm[0], status_scheduled: &sc[0], matched: &matched[0], flags: &flags[0],
-		cls: &cls[0], min_resources: &minres[0], min_resources_present: &mrp[0], occupied_by: &occ[0]}
 	g.mu.Lock()
 	defer g.mu.Unlock()
 	if err := g.ensureFitRows(); err != nil { // classOf(pgs.Pod) above may have met a new pod template
 		return err
 	}
-	if err := g.check("bs_groups_load", C.bs_groups_load(g.ctx, &soa)); err != nil {
+	// flat form: every array its own argument (cgo pointer rule, see bsched_cgo.go)
+	if err := g.check("bs_groups_load_flat", C.bs_groups_load_flat(g.ctx, C.uint32_t(G), &mm[0], &sc[0], &matched[0], &flags[0], &cls[0],
+		&minres[0], &mrp[0], &occ[0])); err != nil {
 		return err
 	}
 	g.groups = G
@@ -143,13 +143,12 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 			flags[i] |= C.BS_POD_LAST_PERMITTED
 		}
 	}
-	soa := C.bs_pods_soa{p: C.uint32_t(P), group: &grp[0], req: &req[0], req_present: &pres[0], cls: &cls[0], owner: &owner[0], flags: &flags[0]}
 	g.mu.Lock()
 	defer g.mu.Unlock()
 	if err := g.ensureFitRows(); err != nil { // a pod template the loaded fit rows do not cover yet: one new template must not fail the cycle
 		return nil, err
 	}
-	if err := g.check("bs_pods_load", C.bs_pods_load(g.ctx, &soa)); err != nil {
+	if err := g.check("bs_pods_load_flat", C.bs_pods_load_flat(g.ctx, C.uint32_t(P), &grp[0], &req[0], &pres[0], &cls[0], &owner[0], &flags[0])); err != nil {
 		return nil, err
 	}
 	if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, C.BS_STAGE_ALL)); err != nil {
@@ -166,9 +165,9 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 	res.rows = make([]C.uint64_t, W*res.rowsCap+1)
 	res.admit, res.ready = make([]C.uint32_t, G+1), make([]C.uint8_t, G+1)
 	var rowsN C.uint32_t
-	out := C.bs_batch_out{pf_code: &res.pfCode[0], pf_first_k: &res.pfFirstK[0], fl_code: &res.flCode[0], fl_slot: &res.flSlot[0],
-		fl_rows: &res.rows[0], fl_rows_cap: C.uint32_t(res.rowsCap), fl_rows_n: &rowsN, group_admit: &res.admit[0], group_ready: &res.ready[0]}
-	return res, g.check("bs_batch_read", C.bs_batch_read(g.ctx, &out)) // the one stream wait of the cycle
+	// (pf_leader, fl_feasible, fl_bitmap, fl_rows_feasible not wanted: NULL)
+	return res, g.check("bs_batch_read_flat", C.bs_batch_read_flat(g.ctx, &res.pfCode[0], &res.pfFirstK[0], nil, &res.flCode[0], nil, nil,
+		&res.admit[0], &res.ready[0], &res.flSlot[0], &res.rows[0], nil, C.uint32_t(res.rowsCap), &rowsN)) // the one stream wait of the cycle
 }
 
 // queueDelta: what changed in the pending queue since the last cycle, in queue positions (bs_pods_delta): pods that left
@@ -229,26 +228,26 @@ func (g *gpuCore) runCycle(d *queueDelta, groupIndex map[string]uint32, permitte
 			flags[i] |= C.BS_POD_LAST_PERMITTED
 		}
 	}
-	var delta C.bs_pods_delta
-	delta.n_remove = C.uint32_t(len(d.remove))
+	// every array of the delta its own argument (bs_pods_apply_flat): no Go-allocated bs_pods_delta, no Go pointer to Go pointers
+	var remove, flagIndex, insertAt *C.uint32_t
+	var flagValue *C.uint8_t
 	if len(d.remove) > 0 {
-		delta.remove = (*C.uint32_t)(unsafe.Pointer(&d.remove[0]))
+		remove = (*C.uint32_t)(unsafe.Pointer(&d.remove[0]))
 	}
-	delta.n_flags = C.uint32_t(len(d.flagIndex))
 	if len(d.flagIndex) > 0 {
-		delta.flag_index = (*C.uint32_t)(unsafe.Pointer(&d.flagIndex[0]))
-		delta.flag_value = (*C.uint8_t)(unsafe.Pointer(&d.flagValue[0]))
+		flagIndex = (*C.uint32_t)(unsafe.Pointer(&d.flagIndex[0]))
+		flagValue = (*C.uint8_t)(unsafe.Pointer(&d.flagValue[0]))
 	}
-	delta.insert = C.bs_pods_soa{p: C.uint32_t(I), group: &grp[0], req: &req[0], req_present: &pres[0], cls: &cls[0], owner: &owner[0], flags: &flags[0]}
 	if len(d.insertAt) > 0 {
-		delta.insert_at = (*C.uint32_t)(unsafe.Pointer(&d.insertAt[0]))
+		insertAt = (*C.uint32_t)(unsafe.Pointer(&d.insertAt[0]))
 	}
 	g.mu.Lock()
 	defer g.mu.Unlock()
 	if err := g.ensureFitRows(); err != nil {
 		return nil, err
 	}
-	if err := g.check("bs_pods_apply", C.bs_pods_apply(g.ctx, &delta)); err != nil {
+	if err := g.check("bs_pods_apply_flat", C.bs_pods_apply_flat(g.ctx, C.uint32_t(len(d.remove)), remove, C.uint32_t(len(d.flagIndex)), flagIndex, flagValue,
+		C.uint32_t(I), &grp[0], &req[0], &pres[0], &cls[0], &owner[0], &flags[0], insertAt)); err != nil {
 		return nil, err
 	}
 	if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, C.BS_STAGE_PREFILTER|C.BS_STAGE_TALLY|C.BS_BATCH_HOST_RESULTS)); err != nil {
@@ -259,6 +258,38 @@ func (g *gpuCore) runCycle(d *queueDelta, groupIndex map[string]uint32, permitte
 		return nil, err // BS_ERR_STATE: the batch took the general chain (more than four leader changes): read it with bs_batch_read
 	}
 	return res, nil
+}
+
+// seqPass: the reference's own order of events on the device (bs_seq_run): PreFilter -> node choice -> assume -> Permit -> release,
+// pod by pod over the resident queue, one launch.  The decisions are the ones core.go:88-167 / :268-309 would take in sequence
+// (bit-identical to the CPU replay, tests/test_gpu_seq.py); the plugin binds the released pods to podNode[i].
+type seqResult struct {
+	pfCode        []C.uint8_t
+	podNode       []C.int32_t
+	releasedGroup []C.uint32_t
+	releasedPods  []C.uint32_t
+	readyNs       []C.int64_t
+	nReleased     int
+}
+
+func (g *gpuCore) seqPass(P int, withFilter bool) (*seqResult, error) {
+	cap := g.groups + 1
+	r := &seqResult{pfCode: make([]C.uint8_t, P+1), podNode: make([]C.int32_t, P+1), releasedGroup: make([]C.uint32_t, cap),
+		releasedPods: make([]C.uint32_t, cap), readyNs: make([]C.int64_t, cap)}
+	firstNs := make([]C.int64_t, cap)
+	var scalars [7]C.int64_t
+	stages := C.uint32_t(C.BS_STAGE_PREFILTER)
+	if withFilter {
+		stages |= C.BS_STAGE_FILTER
+	}
+	g.mu.Lock()
+	defer g.mu.Unlock()
+	if err := g.check("bs_seq_run_flat", C.bs_seq_run_flat(g.ctx, stages, &r.pfCode[0], nil, nil, &r.podNode[0], C.uint32_t(cap),
+		&r.releasedGroup[0], &r.releasedPods[0], &firstNs[0], &r.readyNs[0], &scalars[0])); err != nil {
+		return nil, err
+	}
+	r.nReleased = int(scalars[0])
+	return r, nil
 }
 
 // replayFilterDeny: Filter's deny entry (core.go:183-185) applied to a Filter-on batch in one forward pass (see bsched.h,

@@ -1,4 +1,4 @@
-// Package core — cgo binding of libbsched.so (include/bsched.h, ABI v3) for tenstack/batch-scheduler.
+// Package core — cgo binding of libbsched.so (include/bsched.h, ABI v4) for tenstack/batch-scheduler.
 //
 // SOURCE ONLY.  The image this library is developed in has no Go toolchain and k8s.io/kubernetes v1.17.5 is
 // not vendored, so this file has been through neither `go build` nor `go vet`; it is kept as a real file
@@ -9,6 +9,12 @@
 //	CGO_LDFLAGS="-L$BSCHED/batch-scheduler_amd -lbsched -Wl,-rpath,$BSCHED/batch-scheduler_amd" go build ./...
 //
 // (the reference builds with CGO_ENABLED=0, Makefile:28).
+//
+// cgo pointer rules, both halves: (1) the library keeps no pointer after a call returns; (2) no Go pointer passed to C points at
+// Go memory that holds Go pointers — so the struct-taking entry points of bsched.h (bs_nodes_load, bs_groups_load, bs_pods_load,
+// bs_pods_apply, bs_batch_read, bs_seq_run, bs_fit_build) are NEVER called from Go: their *_flat forms take every array as its
+// own argument (tests/test_c11_client.py fails on any `C.bs_*(… &soa|&delta|&out …)` in this directory).  The only struct passed
+// by pointer is bs_config (no pointers inside) and bs_batch_view (filled BY the library with pointers into ITS pinned memory).
 //
 // What stays in Go: the plugin surface (batchscheduler.go:102-216), label lookup (util/k8s.go:62), the TTL caches
 // (core.go:71-72, cache.go:57-59 — they cross as flags and counts), resource.Quantity parsing, string interning,
@@ -154,11 +160,11 @@ func (g *gpuCore) loadSnapshot(infos []*nodeinfo.NodeInfo) error {
 			}
 		}
 	}
-	soa := C.bs_nodes_soa{n: C.uint32_t(n), allocatable: &alloc[0], requested: &req[0],
-		allocatable_present: &ap[0], requested_present: &rp[0], flags: &flags[0]}
+	// cgo pointer rule: every array crosses as its OWN argument (bs_nodes_load_flat) — a Go-allocated C.bs_nodes_soa holding
+	// these slice pointers, passed by pointer, would be a Go pointer to Go memory that holds Go pointers (cgocheck panic).
 	g.mu.Lock()
 	defer g.mu.Unlock()
-	if err := g.check("bs_nodes_load", C.bs_nodes_load(g.ctx, &soa)); err != nil {
+	if err := g.check("bs_nodes_load_flat", C.bs_nodes_load_flat(g.ctx, C.uint32_t(n), &alloc[0], &req[0], &ap[0], &rp[0], &flags[0])); err != nil {
 		return err
 	}
 	g.nodes, g.infos, g.nodeIdx = n, infos, nodeIdx

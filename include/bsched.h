@@ -18,8 +18,11 @@
  *    S (scalar lanes) is fixed per context (bs_config.scalar_lanes <= BS_MAX_SCALARS).
  *  - 2-D arrays are lane-major SoA: x[lane * count + index].
  *  - The caller owns every buffer it passes; the library copies during the call and
- *    keeps no caller pointer after return (cgo pointer rules).  The library owns device
- *    memory, its HIP stream and events.
+ *    keeps no caller pointer after return.  That is one half of the cgo pointer rules; the other
+ *    half — a Go pointer passed to C may not point at Go memory holding Go pointers — rules out
+ *    passing a Go-allocated struct of slice pointers BY POINTER: Go callers use the *_flat entry
+ *    points (every array its own argument; see "flat-argument forms" below), C / C++ / ctypes
+ *    callers may use either form.  The library owns device memory, its HIP stream and events.
  *  - Every function returns BS_OK (0) or a negative bs_status; nothing throws or aborts
  *    across the ABI.  Reference panics (uint32 divide by zero core.go:716-717, nil
  *    maxPGStatus core.go:525) are reported as decision codes, not crashes.
@@ -558,6 +561,48 @@ int bs_comm_unique_id(uint8_t id[128]);
 int bs_comm_init(bs_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t nranks);
 /* Second half after the all-reduce: ready bits from the (reduced) admit counters. */
 int bs_batch_finish(bs_ctx* ctx);
+
+/* ---- flat-argument forms (the cgo binding) -----------------------------------------------------------------------
+ * cgo's pointer-passing rule: a Go pointer handed to C may not point at Go memory that itself holds Go pointers.  A
+ * Go-allocated C.bs_nodes_soa / bs_groups_soa / bs_pods_soa / bs_pods_delta / bs_batch_out / bs_seq_out / bs_node_labels /
+ * bs_fit_templates whose fields point at Go slices is exactly that, and `C.bs_nodes_load(ctx, &soa)` panics under the default
+ * cgocheck ("cgo argument has Go pointer to Go pointer").  The entry points below take every array as its OWN argument —
+ * scalars and direct pointers to pointer-free arrays only — and forward to the struct forms on the C side; semantics, return
+ * codes and NULL conventions are those of the struct forms.  The Go shim (go/pkg/scheduler/core) calls only these for the
+ * struct-taking entry points; go/c11_client/shim_client.c goes through them as well, so they are compiled and run here.
+ * (bs_group_delta / bs_node_delta / bs_node_request arrays hold no pointers and cross as they are; bs_batch_map fills a
+ * caller struct with pointers into the LIBRARY's pinned memory — C pointers, allowed.) */
+int bs_nodes_load_flat(bs_ctx* ctx, uint32_t n, const int64_t* allocatable, const int64_t* requested, const uint32_t* allocatable_present,
+                       const uint32_t* requested_present, const uint8_t* flags);
+int bs_groups_load_flat(bs_ctx* ctx, uint32_t g, const uint32_t* min_member, const uint32_t* status_scheduled, const uint32_t* matched,
+                        const uint8_t* flags, const uint32_t* cls, const int64_t* min_resources, const uint32_t* min_resources_present,
+                        const uint64_t* occupied_by);
+int bs_groups_read_flat(bs_ctx* ctx, uint32_t g, uint32_t* min_member, uint32_t* status_scheduled, uint32_t* matched, uint8_t* flags, uint32_t* cls,
+                        int64_t* min_resources, uint32_t* min_resources_present, uint64_t* occupied_by);
+int bs_pods_load_flat(bs_ctx* ctx, uint32_t p, const int32_t* group, const int64_t* req, const uint32_t* req_present, const uint32_t* cls,
+                      const uint64_t* owner, const uint8_t* flags);
+int bs_pods_apply_flat(bs_ctx* ctx, uint32_t n_remove, const uint32_t* remove, uint32_t n_flags, const uint32_t* flag_index, const uint8_t* flag_value,
+                       uint32_t n_insert, const int32_t* group, const int64_t* req, const uint32_t* req_present, const uint32_t* cls,
+                       const uint64_t* owner, const uint8_t* flags, const uint32_t* insert_at);
+int bs_pods_read_flat(bs_ctx* ctx, uint32_t p, int32_t* group, int64_t* req, uint32_t* req_present, uint32_t* cls, uint64_t* owner, uint8_t* flags);
+int bs_batch_read_flat(bs_ctx* ctx, uint8_t* pf_code, uint32_t* pf_first_k, int32_t* pf_leader, uint8_t* fl_code, uint32_t* fl_feasible,
+                       uint64_t* fl_bitmap, uint32_t* group_admit, uint8_t* group_ready, uint32_t* fl_slot, uint64_t* fl_rows,
+                       uint32_t* fl_rows_feasible, uint32_t fl_rows_cap, uint32_t* fl_rows_n);
+/* bs_seq_run: the five scalar results come back through `scalars_out` = {n_released, total_ns, node_picks, node_scans, scan_rounds,
+ * pick_rounds, leader_folds} (int64[7], NULL ok) */
+int bs_seq_run_flat(bs_ctx* ctx, uint32_t stages, uint8_t* pf_code, uint32_t* pf_first_k, int32_t* pf_leader, int32_t* pod_node, uint32_t cap,
+                    uint32_t* released_group, uint32_t* released_pods, int64_t* first_ns, int64_t* ready_ns, int64_t* scalars_out);
+/* bs_fit_build: node tables, then the template tables; `ex_*` = bs_fit_templates.exprs, `fd_*` = bs_fit_templates.fields */
+int bs_fit_build_flat(bs_ctx* ctx, uint32_t n, const uint32_t* name, const uint32_t* label_off, const uint32_t* label_key, const uint32_t* label_val,
+                      const int64_t* label_int, const uint8_t* label_int_ok, const uint32_t* taint_off, const uint32_t* taint_key,
+                      const uint32_t* taint_val, const uint8_t* taint_effect,
+                      uint32_t c, uint32_t field_name_key, const uint8_t* tpl_flags, const uint32_t* sel_off, const uint32_t* sel_key,
+                      const uint32_t* sel_val, const uint32_t* term_off, const uint32_t* term_expr_off, const uint32_t* term_field_off,
+                      uint32_t ex_count, const uint32_t* ex_key, const uint8_t* ex_op, const uint32_t* ex_val_off, const uint32_t* ex_val,
+                      const int64_t* ex_val_int, const uint8_t* ex_val_int_ok,
+                      uint32_t fd_count, const uint32_t* fd_key, const uint8_t* fd_op, const uint32_t* fd_val_off, const uint32_t* fd_val,
+                      const int64_t* fd_val_int, const uint8_t* fd_val_int_ok,
+                      const uint32_t* tol_off, const uint32_t* tol_key, const uint32_t* tol_val, const uint8_t* tol_op, const uint8_t* tol_effect);
 
 /* ---- measurement ------------------------------------------------------------------ */
 #define BS_KERNEL_PREPASS   0u

@@ -17,7 +17,7 @@ PAIRS = [
     ("bs_config", capi.Config), ("bs_node_delta", capi.NodeDelta), ("bs_timing", capi.Timing), ("bs_batch_stats", capi.BatchStats),
     ("bs_nodes_soa", soa.NodesStruct), ("bs_groups_soa", soa.GroupsStruct), ("bs_pods_soa", soa.PodsStruct),
     ("bs_batch_out", soa.BatchOutStruct), ("bs_batch_view", soa.BatchViewStruct), ("bs_group_delta", soa.GroupDelta), ("bs_pods_delta", soa.PodsDeltaStruct), ("bs_pods_out", soa.PodsOutStruct),
-    ("bs_node_request", capi.NodeRequest),
+    ("bs_node_request", capi.NodeRequest), ("bs_seq_out", capi.SeqOut),
     ("bs_node_labels", fitspec.NodeLabelsStruct), ("bs_requirements", fitspec.RequirementsStruct), ("bs_fit_templates", fitspec.FitTemplatesStruct),
 ]
 

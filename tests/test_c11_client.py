@@ -42,7 +42,40 @@ def test_c11_client_compiles_and_links(tmp_path):
         assert re.search(r"\b%s\(" % sym, header), f"{sym} is called by the Go shim but not declared in include/bsched.h"
     client_calls = set(re.findall(r"\b(bs_[a-z_0-9]+)\(", open(SRC).read()))
     missing = {s for s in go_calls if s not in client_calls}
-    assert missing <= {"bs_fit_build", "bs_fit_read", "bs_find_max_pg", "bs_nodes_apply", "bs_filter_one", "bs_last_error", "bs_strerror"}, missing
+    assert missing <= {"bs_fit_build_flat", "bs_fit_read", "bs_find_max_pg", "bs_nodes_apply", "bs_filter_one", "bs_last_error", "bs_strerror", "bs_seq_run_flat"}, missing
+
+
+# entry points whose arguments are structs that hold pointers: a Go-allocated one passed by pointer breaks the cgo pointer rule
+STRUCT_FORMS = ("bs_nodes_load", "bs_groups_load", "bs_groups_read", "bs_pods_load", "bs_pods_apply", "bs_pods_read", "bs_batch_read", "bs_seq_run",
+                "bs_fit_build", "bs_pods_map")
+POINTER_STRUCTS = ("bs_nodes_soa", "bs_groups_soa", "bs_pods_soa", "bs_pods_delta", "bs_pods_out", "bs_batch_out", "bs_seq_out", "bs_node_labels",
+                   "bs_fit_templates", "bs_requirements")
+
+
+def test_go_shim_obeys_the_cgo_pointer_rule():
+    """'no pointers-to-pointers'.  cgo: a Go pointer passed to C may not point at Go memory that holds Go pointers, so
+    the Go files may neither build a pointer-holding C struct nor call a struct-taking entry point — only the *_flat forms
+    (every array its own argument), which the C11 client goes through as well."""
+    import glob
+    import re
+    header = open(os.path.join(ROOT, "include", "bsched.h")).read()
+    files = [f for f in glob.glob(os.path.join(ROOT, "go", "**", "*.go"), recursive=True)]
+    assert files
+    for path in files:
+        text = re.sub(r"//[^\n]*", "", open(path).read())            # comments may mention the struct forms
+        assert not re.search(r"C\.bs_\w+\([^)]*&(soa|delta|out)\b", text), f"{path}: a struct of Go pointers is passed by pointer"
+        for st in POINTER_STRUCTS:
+            assert not re.search(r"C\.%s\b" % st, text), f"{path}: builds a C.{st} (holds pointers) in Go memory"
+        for fn in STRUCT_FORMS:
+            assert not re.search(r"C\.%s\(" % fn, text), f"{path}: calls the struct form {fn}; use {fn}_flat"
+        for fn in set(re.findall(r"C\.(bs_\w+_flat)\(", text)):
+            assert re.search(r"\bint %s\(" % fn, header), f"{fn} is not declared in include/bsched.h"
+    # and the C client really goes through the same flat forms
+    client = open(SRC).read()
+    for fn in ("bs_nodes_load_flat", "bs_groups_load_flat", "bs_pods_load_flat", "bs_batch_read_flat", "bs_pods_apply_flat"):
+        assert re.search(r"\b%s\(" % fn, client), fn
+    for fn in ("bs_nodes_load", "bs_groups_load", "bs_pods_load", "bs_batch_read", "bs_pods_apply"):
+        assert not re.search(r"\b%s\(" % fn, re.sub(r"/\*.*?\*/", "", client, flags=re.S)), f"shim_client.c still calls the struct form {fn}"
 
 
 def write_scene(path, nodes, fit, groups, pods):
