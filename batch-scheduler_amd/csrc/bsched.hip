@@ -208,7 +208,15 @@ struct bs_ctx {
   bool reduce_external = false;      // partitioned mode: tally only, the caller reduces and calls bs_batch_finish
   uint32_t* ext_admit = nullptr;     // caller-owned device memory for the admit counters
   int32_t sop_leader0 = -1;
-  uint32_t last_stages = 0, batch_seq = 0;
+  uint32_t last_stages = 0;
+  // Batch counters.  batch_seq: monotonic, 64 bit (timing sampling, statistics).  stamp_ctr in [0, 65534]: slot stamps are
+  // 1 + stamp_ctr (16 bits in the slot words); when it comes round to 0 the stamped arrays are zeroed, so a slot nobody wrote
+  // for 65535 batches cannot look live again.  key_seq in [1, 0xFFFFFFFE]: the 64-bit atomicMin keys carry ~key_seq in the
+  // high word ("a newer batch always wins", never all-ones = the 'none' the arrays are born with); when it runs out it
+  // restarts at 1 behind a re-fill of the keyed arrays with 'none' (once per 2^32 - 2 batches).
+  uint64_t batch_seq = 0;
+  uint32_t stamp_ctr = 1, key_seq = 1;
+  bool rekey_pending = false;
   bool batch_pending_finish = false;
   bool groups_launch_pending = false; // bs_groups_apply left its (inline) deltas + findMaxPG for the next launch: k_pods_apply takes them along, anything else flushes
   DeltaPack pending_dp{};
@@ -250,7 +258,7 @@ int timer_begin(bs_ctx* c, uint32_t id, size_t* slot, hipStream_t st = nullptr) 
   // mode 1: only the two dominant kernels, and only every 8th batch — an event pair costs a few
   // microseconds of stream time, sampling keeps the timed region representative
   if (c->cfg.enable_timing == 1 &&
-      ((id != BS_KERNEL_QUERY && id != BS_KERNEL_SCAN && id != BS_KERNEL_RESOLVE && id != BS_KERNEL_FILTER) || (c->batch_seq & 7u) != 0))
+      ((id != BS_KERNEL_QUERY && id != BS_KERNEL_SCAN && id != BS_KERNEL_RESOLVE && id != BS_KERNEL_FILTER) || (c->batch_seq & 7ull) != 0))
     return BS_OK;
   if (c->events_used == c->events.size()) {
     EventPair ep{};
@@ -300,6 +308,14 @@ int timer_collect(bs_ctx* c) {
     if (_rc) return _rc;                                       \
   } while (0)
 #define TIMED(ctx, id, ...) TIMED_ON(ctx, id, (hipStream_t) nullptr, __VA_ARGS__)
+
+// one batch done: advance the three counters (see bs_ctx)
+void advance_batch_seq(bs_ctx* c) {
+  c->batch_seq++;
+  c->stamp_ctr = (c->stamp_ctr + 1u) % 65535u;
+  if (c->key_seq >= 0xFFFFFFFEu) { c->key_seq = 1; c->rekey_pending = true; }
+  else c->key_seq++;
+}
 
 int flush_groups(bs_ctx* c);
 // Every entry point starts here.  A group patch whose launch was deferred (bs_groups_apply) goes out now, unless the caller
@@ -1032,7 +1048,10 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
     return BS_ERR_NOMEM;
   }
   std::memset(c->h_info, 0, 64);
-  c->batch_seq = 1;                  // 64-bit atomicMin keys carry ~batch_seq: never all-ones
+  c->batch_seq = 1;
+  // test hooks (tests/test_gpu_soak.py): start the wrapping counters just below their wrap points
+  if (const char* e = std::getenv("BS_STAMP_START")) c->stamp_ctr = (uint32_t)(std::strtoul(e, nullptr, 0) % 65535u);
+  if (const char* e = std::getenv("BS_KEYSEQ_START")) { c->key_seq = (uint32_t)std::strtoul(e, nullptr, 0); if (c->key_seq == 0u || c->key_seq == 0xFFFFFFFFu) c->key_seq = 1; }
   if (const char* e = std::getenv("BS_NO_FAST")) c->no_fast = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_EPOCH")) c->no_epoch = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
@@ -1888,8 +1907,8 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   prm.fuse_filter = run_filter ? 1u : 0u;
   prm.scan_slots_cap = c->scan_slots_cap;
   prm.filter_slots_cap = c->filter_slots_cap;
-  prm.stamp = 1u + (c->batch_seq % 65535u);
-  prm.seq_inv = ~c->batch_seq;
+  prm.stamp = 1u + c->stamp_ctr;
+  prm.seq_inv = ~c->key_seq;
   prm.commit = commit ? 1u : 0u;
   prm.do_tally = (stages & BS_STAGE_TALLY) ? 1u : 0u;
   prm.do_ready = (prm.do_tally && c->nranks == 1 && !c->reduce_external) ? 1u : 0u;
@@ -2014,8 +2033,8 @@ static int run_epoch(bs_ctx* c, uint32_t stages, bool* taken) {
   prm.fuse_filter = run_filter ? 1u : 0u;
   prm.scan_slots_cap = c->scan_slots_cap;
   prm.filter_slots_cap = c->filter_slots_cap;
-  prm.stamp = 1u + (c->batch_seq % 65535u);
-  prm.seq_inv = ~c->batch_seq;
+  prm.stamp = 1u + c->stamp_ctr;
+  prm.seq_inv = ~c->key_seq;
   prm.do_tally = (stages & BS_STAGE_TALLY) ? 1u : 0u;
   prm.do_ready = (prm.do_tally && c->nranks == 1 && !c->reduce_external) ? 1u : 0u;
   EpochDev ep{};
@@ -2119,10 +2138,17 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   if ((rc = reserve_slots(c, run_filter))) return rc;
   const uint32_t scan_cap = c->scan_slots_cap, filter_cap = c->filter_slots_cap;
   (void)W;
-  // slot stamps are 1 + batch_seq % 65535: when the stamp starts over, a slot nobody wrote for 65535 batches would look live again
-  if (c->batch_seq % 65535u == 0) {
+  // slot stamps are 1 + stamp_ctr: when the stamp starts over, a slot nobody wrote for 65535 batches would look live again
+  if (c->stamp_ctr == 0) {
     if (c->d_qstamp_s.p) HIPCHK(c, hipMemsetAsync(c->d_qstamp_s.p, 0, c->d_qstamp_s.cap, c->stream));
     if (c->d_uflags.p) HIPCHK(c, hipMemsetAsync(c->d_uflags.p, 0, c->d_uflags.cap, c->stream));
+  }
+  // the key sequence ran out: every keyed 64-bit minimum goes back to 'none' before ~key_seq starts over
+  if (c->rekey_pending) {
+    if (c->d_pair_firstq.p) HIPCHK(c, hipMemsetAsync(c->d_pair_firstq.p, 0xFF, c->d_pair_firstq.cap, c->stream));
+    if (c->d_first_reach.p) HIPCHK(c, hipMemsetAsync(c->d_first_reach.p, 0xFF, c->d_first_reach.cap, c->stream));
+    if (c->d_gfirstq.p) HIPCHK(c, hipMemsetAsync(c->d_gfirstq.p, 0xFF, c->d_gfirstq.cap, c->stream));
+    c->rekey_pending = false;
   }
 
   const bool captures_possible = c->n_uncaptured > 0 && P > 0;
@@ -2146,7 +2172,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   c->last_chain = c->last_fast ? 1u : 0u;
   if (c->last_fast) {
     rc = run_fast(c, stages);
-    c->batch_seq++;
+    advance_batch_seq(c);
     return rc;
   }
   // ---- positional state: the three-launch chain over (view, class) and group slots
@@ -2156,7 +2182,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     if (rc) return rc;
     if (taken) {
       c->last_chain = 2;
-      c->batch_seq++;
+      advance_batch_seq(c);
       return BS_OK;
     }
   }
@@ -2354,7 +2380,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     commit_dirty = true;
   }
   c->launches = launches;
-  c->batch_seq++;
+  advance_batch_seq(c);
   if (do_tally) {
     c->scratch_armed = rearm;
     c->side_ready = rearm && inline_tables;
