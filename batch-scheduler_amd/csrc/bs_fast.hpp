@@ -650,8 +650,21 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
   }
   if (producers) {                                   // the scan / Filter blocks of this launch have to be through
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (our own loads first: they overlap the producers, not the wait)
-    if (threadIdx.x == 0)
-      while (ld_agent(&b.ticket[1]) < producers) __builtin_amdgcn_s_sleep(1);
+    // What crosses this hand-over: first_row[] and fu_feas[] — written by the producers with agent-scope atomics (performed at the
+    // coherence point, never parked in an XCD's L2), drained (s_waitcnt vmcnt(0)) before their ticket add, and read here with
+    // agent-scope loads: no fence is needed for them, and a release / acquire pair would cost every block an L2 write-back /
+    // invalidate.  The producers' PLAIN stores (Filter rows, host mirrors) are read by nobody in this launch.
+    // Forward progress: the host only takes the fused launch when the WHOLE grid is resident at once (run_fast), so a producer
+    // can never be waiting for a slot a spinning final block holds; the spin is bounded all the same (CU masking, a profiler
+    // serialising blocks): on time-out the block raises the context's error word and goes on — the batch is then refused by
+    // bs_batch_sync / read / map instead of hanging the GPU.
+    if (threadIdx.x == 0) {
+      uint32_t spins = 0;
+      while (ld_agent(&b.ticket[1]) < producers) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) { if (b.h_err) __hip_atomic_store(b.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+      }
+    }
   }
   __syncthreads();
   BS_STAMP(3, 1);
@@ -750,9 +763,11 @@ __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, 
 
 // ------------------------------------------------------------------------------------------------
 // launches B and C as ONE launch: [0, scan_blocks) node scan | [.., + filter_blocks) Filter evaluation | the rest: final
-// blocks.  Blocks are handed out in index order, so every producer has started before a final block does; a final block
-// fetches what it needs from launch A while the producers run, then waits for their count.  One launch boundary (~1.5 us)
-// and the final blocks' first round trips (~2 us) come off the step's critical path.
+// blocks.  A final block fetches what it needs from launch A while the producers run, then waits for their count (bounded
+// spin, see fast_final_block).  One launch boundary (~1.5 us) and the final blocks' first round trips (~2 us) come off the
+// step's critical path.  Taken only when the WHOLE grid is resident at once (run_fast asks the occupancy API): HIP promises
+// no dispatch order, so "producers start first" is never relied on; BS_NO_FUSE_FINAL=1 (or a grid beyond residency) runs
+// the two levels as k_fast_scan_filter + k_fast_final.
 // ------------------------------------------------------------------------------------------------
 template <int S>
 __global__ __launch_bounds__(256) void k_fast_scan_filter_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm, uint32_t m,

@@ -152,6 +152,7 @@ struct BatchDev {
   // BS_BATCH_HOST_RESULTS: mirrors of the results in pinned host memory, written by the last launch (null = off)
   uint8_t* h_pf_code; uint32_t* h_pf_first_k; int32_t* h_pf_leader; uint8_t* h_fl_code; uint32_t* h_fl_feasible; uint32_t* h_fl_slot;
   uint32_t* h_admit; uint8_t* h_ready; uint32_t* h_feas; uint64_t* h_rows; int32_t* h_tag; uint32_t hstride;
+  int32_t* h_err;           // pinned host word: a final block of the fused launch gave up waiting for the producers (see fast_final_block)
   uint32_t* epoch_group;    // [E+1] group captured at epoch e (e >= 1)
   // outputs
   uint8_t* pf_code;

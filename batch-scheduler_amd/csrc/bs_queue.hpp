@@ -50,6 +50,10 @@ struct QueueDirs {                                // hash -> id directories for 
   uint32_t* paircount;                            // pair ids drawn so far
   unsigned long long* pair_head;                  // [G] chain heads (class << 32 | pair id), low word BS_INF = none
   unsigned long long* pair_next;                  // [pair cap]
+  uint32_t pcap;                                  // pair ids the arrays hold
+  int32_t* overflow;                              // pinned host word: the insert wave drew an id beyond kcap / pcap (the host's accounting
+                                                  // makes that impossible; if it ever happens nothing is written out of bounds and the host
+                                                  // refuses the next results and re-derives classes and pairs from the resident queue)
 };
 
 __device__ __forceinline__ uint64_t class_hash(const PodsDev& pods, uint32_t i, uint32_t L) {
@@ -187,8 +191,11 @@ __device__ __forceinline__ void apply_insert_wave(const PodDeltaDev& d, const Po
           todo &= ~__ballot(cs == MISS && h == h0);
         }
         if (elected) {
-          const uint32_t c = atomicAdd(q.kcount, 1u);
-          if (c < q.kcap) {                                      // (c >= kcap cannot happen: the host re-derives before the id space runs out)
+          uint32_t c = atomicAdd(q.kcount, 1u);
+          if (c >= q.kcap) {                                     // (cannot happen: the host re-derives before the id space runs out — guarded all the same)
+            if (q.overflow) __hip_atomic_store(q.overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            c = 0;                                               // an id inside the arrays; the results of the next batch are refused by the host
+          } else {
 #pragma unroll
             for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
               if (j < L) st_dir(reinterpret_cast<unsigned long long*>(&q.ckeys[(size_t)j * q.kcap + c]), (unsigned long long)rq[j]);
@@ -224,14 +231,19 @@ __device__ __forceinline__ void apply_insert_wave(const PodDeltaDev& d, const Po
           todo &= ~__ballot(ps == MISS && pkey == k0);
         }
         if (elected) {
-          const uint32_t np = atomicAdd(q.paircount, 1u);
-          st_dir(&q.pkeys[np], pkey);
-          // chain link: (class << 32) | pair id, pushed at the head of the group's chain (core.go:105-110 replay walks it)
-          q.pair_next[np] = atomicExch(&q.pair_head[gi], ((unsigned long long)cls << 32) | np);
-          dir_drain();
-          const unsigned long long mine = ((unsigned long long)ptag << 32) | np;
-          for (;; slp = (slp + 1u) & q.pmask)
-            if (atomicCAS(&q.pdir[slp], 0ull, mine) == 0ull) break;
+          uint32_t np = atomicAdd(q.paircount, 1u);
+          if (np >= q.pcap) {                                    // (the same guard for the pair ids)
+            if (q.overflow) __hip_atomic_store(q.overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            np = 0;
+          } else {
+            st_dir(&q.pkeys[np], pkey);
+            // chain link: (class << 32) | pair id, pushed at the head of the group's chain (core.go:105-110 replay walks it)
+            q.pair_next[np] = atomicExch(&q.pair_head[gi], ((unsigned long long)cls << 32) | np);
+            dir_drain();
+            const unsigned long long mine = ((unsigned long long)ptag << 32) | np;
+            for (;; slp = (slp + 1u) & q.pmask)
+              if (atomicCAS(&q.pdir[slp], 0ull, mine) == 0ull) break;
+          }
           pid = np;
           ps = DONE;
         } else if (ps == MISS) {

@@ -220,6 +220,8 @@ struct bs_ctx {
   bool batch_pending_finish = false;
   bool groups_launch_pending = false; // bs_groups_apply left its (inline) deltas + findMaxPG for the next launch: k_pods_apply takes them along, anything else flushes
   DeltaPack pending_dp{};
+  uint32_t no_fuse_final = 0;        // BS_NO_FUSE_FINAL: launches B and C always as separate launches
+  int fused_blocks_resident = -1;    // whole-chip residency of k_fast_scan_filter_final (blocks), -1 = not asked yet
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   uint32_t general_waves = 4096;     // scan grid cap of the general chain (tools/cold_sweep.py)
   bs_batch_stats stats{};
@@ -430,6 +432,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.first_reach64 = c->d_first_reach.as<unsigned long long>();
   b.fast_reject = c->d_fast_reject.as<uint32_t>();
   b.epoch_group = c->d_epoch_group.as<uint32_t>();
+  b.h_err = c->h_info ? c->h_info + 12 : nullptr;
   uint8_t* ok = c->d_outpack.as<uint8_t>();
   b.pf_code = at(ok, c->off_pf_code);
   b.pf_first_k = reinterpret_cast<uint32_t*>(at(ok, c->off_pf_first_k));
@@ -657,6 +660,30 @@ static void launch_fast_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDe
     case 11: launch_fast_b_s<11>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
     default: launch_fast_b_s<12>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
   }
+}
+// How many blocks of the fused launch the chip holds at once (occupancy API, minus one block per CU: the API can be one high,
+// MI355X_MICROARCH.md "Residency").  The fused launch is only taken when its whole grid fits: then no producer block can be
+// waiting for a slot that a spinning final block occupies, whatever order the dispatcher hands blocks out in.
+template <int S>
+static int fused_residency_s(bs_ctx* c) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fast_scan_filter_final<S>, 256, 0) != hipSuccess || per_cu <= 0) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->cfg.device) != hipSuccess) return 0;
+  return std::max(0, per_cu - 1) * prop.multiProcessorCount;
+}
+static int fused_residency(bs_ctx* c) {
+  if (c->fused_blocks_resident >= 0) return c->fused_blocks_resident;
+  int r = 0;
+  switch (c->S) {
+    case 0: r = fused_residency_s<0>(c); break;   case 1: r = fused_residency_s<1>(c); break;   case 2: r = fused_residency_s<2>(c); break;
+    case 3: r = fused_residency_s<3>(c); break;   case 4: r = fused_residency_s<4>(c); break;   case 5: r = fused_residency_s<5>(c); break;
+    case 6: r = fused_residency_s<6>(c); break;   case 7: r = fused_residency_s<7>(c); break;   case 8: r = fused_residency_s<8>(c); break;
+    case 9: r = fused_residency_s<9>(c); break;   case 10: r = fused_residency_s<10>(c); break; case 11: r = fused_residency_s<11>(c); break;
+    default: r = fused_residency_s<12>(c); break;
+  }
+  c->fused_blocks_resident = r;
+  return r;
 }
 static void launch_fast_bc(bs_ctx* c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                            const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks, uint32_t filter_blocks) {
@@ -1055,6 +1082,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_FAST")) c->no_fast = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_EPOCH")) c->no_epoch = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
+  if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_SLOT_BITS")) { const int hb = std::atoi(e); c->slot_keep = hb >= 32 ? 0xFFFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) { c->early_filter_min = std::strtoull(e, nullptr, 10); c->early_forced = 1; }
@@ -1506,6 +1534,8 @@ static QueueDirs queue_dirs(const bs_ctx* c) {
   q.paircount = c->d_nepochs.as<uint32_t>() + 4;
   q.pair_head = reinterpret_cast<unsigned long long*>(c->d_gstat.as<uint32_t>() + (((size_t)3 * c->G + 1) & ~(size_t)1));
   q.pair_next = c->d_pair_next.as<unsigned long long>();
+  q.pcap = c->pair_cap;
+  q.overflow = c->h_info ? c->h_info + 13 : nullptr;
   return q;
 }
 
@@ -1644,6 +1674,11 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
   const PodLayout nl = pod_layout(Pn, L);
   if (c->d_pack[np].cap < nl.bytes) HIPCHK(c, c->d_pack[np].reserve(nl.bytes + nl.bytes / 4));
   c->lay[np] = nl;
+  // from here to the launch the context describes the NEW queue length; a failure on the way puts the old one back
+  struct Restore {
+    bs_ctx* c; uint32_t P; bool armed;
+    ~Restore() { if (armed) { c->P = P; (void)layout_out(c); } }
+  } restore{c, P, true};
   if ((rc = resize_queue(c, Pn))) return rc;
   if (c->pair_cap != old_pair_cap) derive = false;                   // the id space was re-sized: directories are gone
   PodsMut nw{};
@@ -1680,7 +1715,6 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
   GroupPatch gp{};
   const GroupsDev grp = c->have_groups ? groups_dev(c) : GroupsDev{};
   if (c->groups_launch_pending) {                                    // this cycle's group patch + findMaxPG: one more block of this launch
-    c->groups_launch_pending = false;
     gp.on = 1;
     gp.C = (c->have_fit && c->have_nodes) ? c->C : 0u;
     gp.tag = c->info_tag;
@@ -1694,6 +1728,8 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
                      derive ? queue_dirs(c) : QueueDirs{}, c->hash_keep, derive ? 1u : 0u, gb, c->kinfo_tag, c->h_info, grp, gp.on ? batch_dev(c) : BatchDev{}, gp,
                      c->d_gcount.as<uint32_t>());
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
+  restore.armed = false;                                             // the launch is out: the new queue is the queue
+  if (gp.on) c->groups_launch_pending = false;                       // (the group patch went with it)
   c->dstage_busy = true;
   c->cur_pack = np;
   c->owner_ready = false;
@@ -1942,6 +1978,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<-1>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
     }
   });
+  bool fused = false;
   // ---- launch B: node scan over the class slots | Filter evaluation over the Filter slots
   // The work loops size themselves on the device (the class count lives there); the grid only has to be large enough.
   const uint32_t k_est = std::min<uint32_t>(P, c->kinfo_pending ? std::max<uint32_t>(2 * c->h_K, 1024) : std::max<uint32_t>(c->h_K, 1));
@@ -1950,11 +1987,17 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     // few tiles (the latency regime): one scan item (tile of 64 class slots x share) per BLOCK, its four waves take a quarter of
     // every group's rows each; many tiles (thousands of distinct requests): one item per wave, 4 per block
     const uint32_t tiles = cdiv(k_est, 64);
-    prm.scan_nsub = tiles <= 16 ? 4u : 1u;
-    const uint32_t scan_items = tiles * std::min<uint32_t>(prm.scan_nsub == 4u ? nseg : 64u, cdiv(c->M, 64));
-    const uint32_t scan_blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(c->target_waves, 4), prm.scan_nsub == 4u ? scan_items : cdiv(scan_items, 4)));
     const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * k_est, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
-    if (prm.scan_nsub == 4u) {
+    auto scan_grid = [&](uint32_t nsub) {
+      const uint32_t items = tiles * std::min<uint32_t>(nsub == 4u ? nseg : 64u, cdiv(c->M, 64));
+      return std::max<uint32_t>(1, std::min<uint32_t>(cdiv(c->target_waves, 4), nsub == 4u ? items : cdiv(items, 4)));
+    };
+    // the fused form (final blocks wait for the producers INSIDE the launch) only in the latency regime, and only when every block
+    // of its grid is resident at once (see fused_residency); BS_NO_FUSE_FINAL=1 forces the separate launches
+    fused = tiles <= 16 && !c->no_fuse_final && (int)(scan_grid(4u) + fblocks + cdiv(P, 256)) <= fused_residency(c);
+    prm.scan_nsub = fused ? 4u : 1u;
+    const uint32_t scan_blocks = scan_grid(prm.scan_nsub);
+    if (fused) {
       // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
       const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
       launch_fast_bc(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
@@ -1963,7 +2006,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     }
   });
   c->launches = 2;
-  if (prm.scan_nsub != 4u) {                         // the throughput regime: launch C on its own
+  if (!fused) {                                      // the throughput regime (or a grid the chip cannot hold at once): launch C on its own
     TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
     c->launches = 3;
   }
@@ -2402,13 +2445,35 @@ int bs_batch_finish(bs_ctx* c) {
   return BS_OK;
 }
 
+// a final block of a fused launch gave up waiting for its producers: the batch's results are not to be trusted
+static int check_handover(bs_ctx* c) {
+  if (c->h_info && ((volatile int32_t*)c->h_info)[13]) {   // the insert wave of a queue patch ran out of ids (the accounting should make that impossible)
+    ((volatile int32_t*)c->h_info)[13] = 0;
+    c->pairs_ready = false;                            // classes, pairs and directories are derived again from the resident queue
+    c->dirs_ready = false;
+    c->rep_valid = false;
+    c->ids_used = c->pair_cap;
+    const int rc2 = derive_pods(c, false);
+    c->n_rederives++;
+    c->last_error = "bs_pods_apply: class / pair id space overflowed on the device; the queue was re-derived, run the batch again";
+    return rc2 ? rc2 : BS_ERR_STATE;
+  }
+  if (c->h_info && ((volatile int32_t*)c->h_info)[12]) {
+    ((volatile int32_t*)c->h_info)[12] = 0;
+    c->no_fuse_final = 1;                              // from now on: separate launches
+    c->last_error = "in-launch hand-over timed out (producer blocks not resident): batch refused, re-run it (the context now uses separate launches)";
+    return BS_ERR_HIP;
+  }
+  return BS_OK;
+}
+
 int bs_batch_sync(bs_ctx* c) {
   if (!c) return BS_ERR_INVALID;
   int rc = use_device(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->dstage_busy = false;
-  return BS_OK;
+  return check_handover(c);
 }
 
 // rows the last batch's Filter slots occupy: 2 x request classes (the batch's leader | the leader carried into
@@ -2464,6 +2529,7 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   if (c->last_host_out && c->batch_since_pods && !(P && out->fl_bitmap && W && filtered)) {
     rc = wait_host_tag(c, 0, c->host_tag, reinterpret_cast<const int32_t*>(c->h_hout + c->off_htag));
     if (rc) return rc;
+    if ((rc = check_handover(c))) return rc;
     c->dstage_busy = false;                            // (the batch ran behind every earlier apply)
     const uint8_t* st = c->h_hout;
     if (want_pod) {
@@ -2510,6 +2576,7 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stage_busy = false;                             // (the stream is idle: the pod upload has left its buffer too)
   c->dstage_busy = false;
+  if ((rc = check_handover(c))) return rc;
   if (want_pod) {
     if (out->pf_code) std::memcpy(out->pf_code, st + c->off_pf_code, P);
     if (out->pf_first_k) std::memcpy(out->pf_first_k, st + c->off_pf_first_k, (size_t)P * 4);
@@ -2547,6 +2614,7 @@ int bs_batch_map(bs_ctx* c, bs_batch_view* v) {
   uint32_t nrows = 0;
   if (filtered && (rc = filter_rows_of(c, &nrows))) return rc;
   if ((rc = wait_host_tag(c, 0, c->host_tag, reinterpret_cast<const int32_t*>(c->h_hout + c->off_htag)))) return rc;
+  if ((rc = check_handover(c))) return rc;
   c->dstage_busy = false;                              // (the batch ran behind every earlier apply)
   const uint8_t* st = c->h_hout;
   std::memset(v, 0, sizeof(*v));

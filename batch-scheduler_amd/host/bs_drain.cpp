@@ -17,7 +17,15 @@
 //   (request > 0: request <= allocatable - requested), the pods lane always (requested + 1 <= allocatable), a scalar the pod
 //   asks for needs the allocatable key and request <= allocatable - requested.
 //   Assume (NodeInfo.AddPod ‡): requested += request on every lane the pod has, pods lane + 1.
-// A gang whose pods cannot all be placed is rolled back and skipped for the rest of the drain ("stuck").
+// ALL OR NOTHING per gang: a ready gang is released only when EVERY member of it that passes in this batch finds a node; a gang
+// whose pods cannot all be placed is rolled back and skipped for the rest of the drain ("stuck").  That is this driver's rule, not
+// the reference's: core.go:303 turns true as soon as matched reaches MinMember - Scheduled, so the reference (and bs_seq_run, the
+// pod-by-pod pass on the device) releases an over-subscribed gang — more pending pods than its quorum — when the quorum's worth
+// of pods is placed and leaves the rest pending, and lets partial gangs hold what they assumed.  Use bs_seq_run for the
+// reference's semantics; this loop is the pre-screen-and-recheck form (tests/test_drain.py pins it gang by gang against
+// tests/drain_ref.py, which states the same rule, including over-subscribed gangs).
+// A failing device call leaves the caller's arrays as they were before the cycle: every placement of a cycle is journalled and
+// undone, and the group counters are only written after the three patches went through.
 // No arithmetic of the hot path happens here: every PreFilter / Filter / quorum answer comes from bs_batch_run.
 #include <algorithm>
 #include <chrono>
@@ -125,7 +133,9 @@ int bsh_drain(bsh_drain_io* io) {
   std::vector<uint32_t> orig(P0);
   for (uint32_t i = 0; i < P0; ++i) orig[i] = i;
   std::vector<uint8_t> pf_code(std::max<uint32_t>(P0, 1)), fl_code(std::max<uint32_t>(P0, 1)), ready(std::max<uint32_t>(G, 1)), stuck(std::max<uint32_t>(G, 1), 0);
-  std::vector<uint32_t> feasible(std::max<uint32_t>(P0, 1)), fl_slot(std::max<uint32_t>(P0, 1)), members, placed_node, prev_rp, rows_n(1);
+  std::vector<uint32_t> feasible(std::max<uint32_t>(P0, 1)), fl_slot(std::max<uint32_t>(P0, 1)), members, placed_node, rows_n(1);
+  struct Placed { uint32_t i, node, old_rp; };
+  std::vector<Placed> journal;                             // every placement of the current cycle, in the order it was made
   std::vector<uint64_t> rows;
   Placer pl(*io);
   uint32_t rows_cap = 0;
@@ -175,7 +185,7 @@ int bsh_drain(bsh_drain_io* io) {
           if (io->node_flags[k]) continue;
           if (cls >= io->n_classes || !((io->fit_bits[(size_t)cls * fw + (k >> 5)] >> (k & 31u)) & 1u)) continue;
           if (!filter_ok(i, k) || !pl.holds(k, req, pres)) continue;
-          prev_rp.push_back(io->requested_present[k]);
+          journal.push_back({i, k, io->requested_present[k]});
           pl.assume(k, req, pres, +1);
           *node_out = k;
           return true;
@@ -193,7 +203,12 @@ int bsh_drain(bsh_drain_io* io) {
     std::vector<uint32_t> gone, gone_node;                  // queue positions leaving in this cycle (ascending), and their nodes
     int32_t gang = -1;
     uint32_t gang_pods = 0;
-    prev_rp.clear();
+    journal.clear();
+    // undo of everything this cycle placed, should a device call fail
+    auto undo_cycle = [&]() {
+      for (size_t m = journal.size(); m-- > 0;) unplace(journal[m].i, journal[m].node, journal[m].old_rp);
+      journal.clear();
+    };
     for (uint32_t i0 = 0; i0 < P && gang < 0; ++i0) {
       const int32_t gi = io->pods.group[orig[i0]];
       if (gi == BS_POD_NOT_GROUPED) {
@@ -204,7 +219,7 @@ int bsh_drain(bsh_drain_io* io) {
       if (gi < 0 || (uint32_t)gi >= G || !ready[gi] || stuck[gi] || !passes(i0)) continue;
       members.clear();
       placed_node.clear();
-      const size_t rp_mark = prev_rp.size();
+      const size_t mark = journal.size();
       for (uint32_t i = i0; i < P; ++i)
         if (io->pods.group[orig[i]] == gi && passes(i)) members.push_back(i);
       bool ok = true;
@@ -214,8 +229,8 @@ int bsh_drain(bsh_drain_io* io) {
         placed_node.push_back(at);
       }
       if (!ok) {                                             // roll the partial gang back: it holds nothing
-        for (size_t m = placed_node.size(); m-- > 0;) unplace(members[m], placed_node[m], prev_rp[rp_mark + m]);
-        prev_rp.resize(rp_mark);
+        for (size_t m = journal.size(); m-- > mark;) unplace(journal[m].i, journal[m].node, journal[m].old_rp);
+        journal.resize(mark);
         stuck[gi] = 1;
         io->n_stuck++;
         continue;
@@ -224,7 +239,11 @@ int bsh_drain(bsh_drain_io* io) {
       gang_pods = (uint32_t)members.size();
     }
     if (gang < 0 && gone.empty()) break;
-    // ---- release: Permit for every member (core.go:290), quorum latch (:305), PostBind (:327), then patch the device
+    // ---- release: Permit for every member (core.go:290), quorum latch (:305), PostBind (:327), then patch the device.
+    // Order of the three patches: node requests first (its own launch), then the group patch — whose launch is deferred — and the
+    // queue patch, which takes the group patch along in ITS launch.  The caller's group counters are written after all three
+    // succeeded; on a failure the cycle's placements are undone and the arrays are what they were before the cycle.
+    bs_group_delta gd{0, 0, 0, 0};
     if (gang >= 0) {
       // unlabelled pods BEHIND the gang's first pod wait for the next cycle; the gang's members are merged in queue order
       std::vector<uint32_t> all(gone.size() + members.size()), alln(all.size());
@@ -236,11 +255,8 @@ int bsh_drain(bsh_drain_io* io) {
       }
       gone.swap(all);
       gone_node.swap(alln);
-      io->matched[gang] += gang_pods;
-      io->group_flags[gang] |= BS_GROUP_SCHEDULED_LATCH;
-      io->status_scheduled[gang] += gang_pods;
-      bs_group_delta gd{(uint32_t)gang, io->matched[gang], io->status_scheduled[gang], io->group_flags[gang]};
-      if ((rc = bs_groups_apply(ctx, &gd, 1))) return rc;
+      gd = bs_group_delta{(uint32_t)gang, io->matched[gang] + gang_pods, io->status_scheduled[gang] + gang_pods,
+                          (uint32_t)(io->group_flags[gang] | BS_GROUP_SCHEDULED_LATCH)};
     }
     {
       std::vector<uint32_t> touched(gone_node);
@@ -253,12 +269,19 @@ int bsh_drain(bsh_drain_io* io) {
         std::memset(nr[t].requested, 0, sizeof(nr[t].requested));
         for (uint32_t j = 0; j < L; ++j) nr[t].requested[j] = io->requested[(size_t)j * N + touched[t]];
       }
-      if ((rc = bs_nodes_assume(ctx, nr.data(), (uint32_t)nr.size()))) return rc;
       bs_pods_delta pd;
       std::memset(&pd, 0, sizeof(pd));
       pd.n_remove = (uint32_t)gone.size();
       pd.remove = gone.data();                                // ascending queue positions
-      if ((rc = bs_pods_apply(ctx, &pd))) return rc;
+      if ((rc = bs_nodes_assume(ctx, nr.data(), (uint32_t)nr.size())) || (gang >= 0 && (rc = bs_groups_apply(ctx, &gd, 1))) || (rc = bs_pods_apply(ctx, &pd))) {
+        undo_cycle();                                         // the caller's node requests are what they were before the cycle
+        return rc;
+      }
+      if (gang >= 0) {
+        io->matched[gang] = gd.matched;
+        io->status_scheduled[gang] = gd.status_scheduled;
+        io->group_flags[gang] = (uint8_t)gd.flags;
+      }
       for (size_t m = 0; m < gone.size(); ++m) io->pod_node[orig[gone[m]]] = (int32_t)gone_node[m];
       uint32_t w = 0;                                         // the host's view of the queue follows the device's
       size_t m = 0;

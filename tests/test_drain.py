@@ -122,6 +122,27 @@ def test_gpu_drain_equals_reference_drain(config, scenario, ordered, mode, bsa, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("config,scenario", [("tiny", "cold"), ("cfg2", "cold"), ("cfg2", "tail")])
+def test_gpu_drain_over_subscribed_gangs(config, scenario, bsa, soa, orc):
+    """gangs with MORE pending pods than their quorum (MinMember lowered under the queue's pod count): the drain's stated rule is
+    all-or-nothing per gang — every passing member is placed or the gang is rolled back and marked stuck — identically in
+    host/bs_drain.cpp and in tests/drain_ref.py; the reference's own rule (release at the quorum, the rest stays pending) is
+    bs_seq_run's (tests/test_gpu_seq.py)."""
+    st = soa.STAGE_PREFILTER | soa.STAGE_TALLY
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
+    pods = compare_order(pods)
+    rng = np.random.default_rng(3)
+    cut = rng.random(groups.g) < 0.5
+    groups.min_member[cut] = np.maximum(groups.min_member[cut].astype(np.int64) - rng.integers(1, 3, int(cut.sum())), 1).astype(np.uint32)
+    d = drain_ref.drain(orc, nodes, fit, groups, pods, st)
+    r, n2, g2, left, back = run_gpu_drain(bsa, nodes, fit, groups, pods, st)
+    assert r["admitted_group"].tolist() == [g for g, _ in d["admitted"]] and r["admitted_pods"].tolist() == [k for _, k in d["admitted"]]
+    assert np.array_equal(r["pod_node"], d["pod_node"]) and np.array_equal(n2.requested, d["nodes"].requested)
+    assert counters_equal(g2, d["groups"], soa) and counters_equal(back, d["groups"], soa) and r["n_stuck"] == len(d["stuck"])
+    assert any(k > int(groups.min_member[g]) for g, k in d["admitted"]), "the scene must release a gang with more pods than its quorum"
+
+
+@pytest.mark.gpu
 def test_gpu_drain_readme_scene_and_sequential_pass(bsa, soa, orc):
     nodes, fit, groups, pods = readme_scene(soa)
     st = soa.STAGE_PREFILTER | soa.STAGE_TALLY

@@ -209,3 +209,30 @@ def test_latency_mode_zero_copy_in_and_out(config, scenario, distinct, bsa, soa,
     with load_ctx(bsa, n2, f2, g2, p2) as ctx:
         ctx.run(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
         assert_batch_equal(ctx.read(), e2, "cold batch with the latency flag")
+
+
+@pytest.mark.parametrize("config,scenario", [("cfg2", "tail"), ("cfg2", "warm"), ("cfg3", "tail")])
+def test_unfused_final_launch_is_selectable_and_equal(config, scenario, bsa, soa, orc, monkeypatch):
+    """BS_NO_FUSE_FINAL=1: the final blocks run as their own launch (k_fast_scan_filter + k_fast_final) instead of waiting for the
+    producer blocks inside one launch — the form the library also falls back to by itself when the fused grid would not be resident
+    at once.  Same results, three launches."""
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL, bitmap=False)
+    monkeypatch.setenv("BS_NO_FUSE_FINAL", "1")
+    with bsa.Context(scalar_lanes=nodes.lanes - 4) as ctx:
+        ctx.load_nodes(nodes, fit)
+        ctx.load_groups(groups)
+        ctx.load_pods(pods)
+        st = ctx.stats(soa.STAGE_ALL)
+        assert st["chain"] == 1 and st["launches"] == 3
+        for mode in (soa.STAGE_ALL, soa.STAGE_ALL | soa.BATCH_HOST_RESULTS):
+            ctx.run(mode)
+            got = ctx.read(bitmap=False, rows=False)
+            for name in ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible", "group_admit", "group_ready"):
+                assert np.array_equal(getattr(got, name), getattr(exp, name)), name
+    monkeypatch.delenv("BS_NO_FUSE_FINAL")
+    with bsa.Context(scalar_lanes=nodes.lanes - 4) as ctx:
+        ctx.load_nodes(nodes, fit)
+        ctx.load_groups(groups)
+        ctx.load_pods(pods)
+        assert ctx.stats(soa.STAGE_ALL)["launches"] == 2          # the fused form: the whole grid is resident on this chip
