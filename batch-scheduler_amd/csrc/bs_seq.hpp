@@ -38,11 +38,16 @@
 
 namespace bs {
 
-constexpr int kSeqBlock = 1024;
+#ifndef BS_SEQ_BLOCK
+#define BS_SEQ_BLOCK 1024
+#endif
+constexpr int kSeqBlock = BS_SEQ_BLOCK;      // threads of the one workgroup (a multiple of 64, at most 1024)
 constexpr int kSeqWaves = kSeqBlock / 64;
 constexpr uint32_t kSeqKeysLds = 8192;     // groups whose findMaxPG keys fit the LDS window (64 KB)
 constexpr uint32_t kSeqPruneTiles = 1024;  // 64-node tiles whose first-fit bounds fit the LDS window (65 536 nodes)
 constexpr uint32_t kSeqWaitList = 512;     // waiting pods of the current gang kept in LDS
+constexpr uint32_t kSeqCacheSlots = 4;     // table summaries (fit class x percent) kept in LDS at most
+constexpr uint32_t kSeqDirtyMax = 32;      // tiles of a cached table that may wait for a refresh before the table is dropped
 
 struct SeqDev {
   // resident state the pass mutates
@@ -75,10 +80,19 @@ struct SeqDev {
 #define BS_SEQ_T(k) ((void)0)
 #endif
 
+#ifdef BS_SEQ_PROBE
+__device__ unsigned long long g_seq_scan_ph[8];
+#define BS_SCAN_T(k) do { if (threadIdx.x == 0) { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); g_seq_scan_ph[k] += _t - stl; stl = _t; } } while (0)
+#else
+#define BS_SCAN_T(k) ((void)0)
+#endif
+
 struct SeqParams {
   uint32_t S, eph_gate, run_filter, C;
   int32_t sop_leader0;           // sop.maxFinishedPG carried into the pass (-1 none)
   uint32_t keys_in_lds, prune;
+  uint32_t cache_slots;          // table summaries kept in LDS (0: every scan walks the node list in rounds)
+  uint32_t cache_off;            // byte offset of the summary area in dynamic LDS (behind the key window)
 };
 
 // ---- wave-uniform loads of state this kernel itself writes: vector loads, value moved to SGPRs ---------------------
@@ -121,6 +135,28 @@ __device__ __forceinline__ unsigned long long seq_wave_scan64(unsigned long long
   BS_DPP_ADD64(lo, hi, "row_bcast:15 row_mask:0xa bank_mask:0xf");
   BS_DPP_ADD64(lo, hi, "row_bcast:31 row_mask:0xc bank_mask:0xf");
   return ((unsigned long long)hi << 32) | lo;
+}
+// The same scan for the L resource lanes of a tile at once, STEP-major: the six DPP steps of one lane are a dependent chain
+// (each ~10 cycles of issue + hazard), the L chains are independent — interleaved, one chain's wait is the others' issue
+// time (the hazard "VALU write -> DPP read" is covered by the 2 L - 1 instructions between two steps of one lane).
+#define BS_DPP_ADD64_NN(lo, hi, CTRL) \
+  asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL : "+v"(lo), "+v"(hi) : : "vcc")
+#define BS_DPP_STEP_ALL(CTRL)                                  \
+  _Pragma("unroll") for (uint32_t j = 0; j < BS_MAX_LANES; ++j) \
+    if (j < L) BS_DPP_ADD64_NN(lo[j], hi[j], CTRL)
+__device__ __forceinline__ void seq_wave_scan64_lanes(unsigned long long (&x)[BS_MAX_LANES], uint32_t L) {   // L >= 4
+  uint32_t lo[BS_MAX_LANES], hi[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { lo[j] = (uint32_t)x[j]; hi[j] = (uint32_t)(x[j] >> 32); }
+  asm volatile("s_nop 1" ::: "memory");
+  BS_DPP_STEP_ALL("row_shr:1 row_mask:0xf bank_mask:0xf");
+  BS_DPP_STEP_ALL("row_shr:2 row_mask:0xf bank_mask:0xf");
+  BS_DPP_STEP_ALL("row_shr:4 row_mask:0xf bank_mask:0xf");
+  BS_DPP_STEP_ALL("row_shr:8 row_mask:0xf bank_mask:0xf");
+  BS_DPP_STEP_ALL("row_bcast:15 row_mask:0xa bank_mask:0xf");
+  BS_DPP_STEP_ALL("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) x[j] = ((unsigned long long)hi[j] << 32) | lo[j];
 }
 __device__ __forceinline__ unsigned long long seq_row_scan64(unsigned long long v) {         // inclusive inside each row of 16 lanes
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
@@ -167,6 +203,7 @@ struct SeqShared {
   uint32_t pick[2][kSeqWaves];
   long long pmax[2][kSeqPruneTiles];                     // per tile: max of allocatable - requested (cpu, memory) over schedulable nodes
   uint32_t wl_pod[kSeqWaitList], wl_node[kSeqWaitList];  // waiting pods of the CURRENT gang (released in parallel; the chain in global memory is the fallback)
+  uint32_t dirty[kSeqCacheSlots][kSeqDirtyMax];          // per cached table: tiles an assume step touched since their summary was taken
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -203,8 +240,12 @@ __device__ __forceinline__ uint32_t seq_scan(const NodesDev& nd, const SeqDev& s
   for (uint32_t j = 0; j < BS_MAX_LANES; ++j) carry[j] = 0;
   uint32_t pcarry = 0, found = BS_INF;
   uint32_t r = 0;
+#ifdef BS_SEQ_PROBE
+  unsigned long long stl = (unsigned long long)__builtin_readcyclecounter();
+#endif
   for (; r < rounds; ++r) {
     if (r + 1 < rounds) load_tile(r + 1, nxt);
+    BS_SCAN_T(0);
     const uint32_t b = r & 1u;
     const uint32_t n = ((r * kSeqWaves + (uint32_t)w) << 6) + (uint32_t)lane;
     const bool row = n < N && (cur.meta & 1u);                                                        // core.go:606-617
@@ -213,11 +254,16 @@ __device__ __forceinline__ uint32_t seq_scan(const NodesDev& nd, const SeqDev& s
     unsigned long long x[BS_MAX_LANES];
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-      if (j < L) {
-        const bool live = fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
-        x[j] = seq_wave_scan64(live ? (unsigned long long)cur.v[j] : 0ull);                           // running sums inside the tile (:621)
-        if (lane == 63) sh_.tot[b][j][w] = x[j];
-      }
+      const bool live = j < L && fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
+      x[j] = live ? (unsigned long long)cur.v[j] : 0ull;
+    }
+    BS_SCAN_T(1);
+    seq_wave_scan64_lanes(x, L);                                                                      // running sums inside the tile (:621)
+    BS_SCAN_T(2);
+    if (lane == 63) {
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+        if (j < L) sh_.tot[b][j][w] = x[j];
     }
     unsigned long long km[BS_MAX_SCALARS];
     uint32_t wp = 0;
@@ -230,23 +276,35 @@ __device__ __forceinline__ uint32_t seq_scan(const NodesDev& nd, const SeqDev& s
       }
     }
     if (lane == 0) sh_.wpres[b][w] = wp;
+    BS_SCAN_T(3);
     lds_barrier();
+    BS_SCAN_T(4);
     // a hit of the PREVIOUS round is visible now: the reference's loop ended there (early exit, :623-627)
     if (r > 0) {
       const uint32_t prev = seq_row_min_u32(lane < kSeqWaves ? sh_.fk[b ^ 1u][lane] : BS_INF);
       if (prev != BS_INF) { found = prev; break; }
     }
-    // offsets: lanes 0..15 hold the 16 tile totals of this round
+    BS_SCAN_T(5);
+    // offsets: row r of the wave (16 lanes) holds the tile totals of resource lane 4 q + r — ONE row scan serves four lanes
     bool ok = row;
     const uint32_t pw = lane < kSeqWaves ? sh_.wpres[b][lane] : 0u;
     uint32_t pbefore = pcarry, pround = 0;
+    unsigned long long inc4[BS_MAX_LANES / 4];
+#pragma unroll
+    for (uint32_t qd = 0; qd < BS_MAX_LANES / 4; ++qd) {
+      inc4[qd] = 0;
+      if (qd * 4u < L) {
+        const uint32_t jr = qd * 4u + ((uint32_t)lane >> 4), wi = (uint32_t)lane & 15u;
+        inc4[qd] = seq_row_scan64((jr < L && wi < (uint32_t)kSeqWaves) ? sh_.tot[b][jr][wi] : 0ull);
+      }
+    }
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
       if (j < L) {
-        const unsigned long long t = lane < kSeqWaves ? sh_.tot[b][j][lane] : 0ull;
-        const unsigned long long inc = seq_row_scan64(t);
-        const unsigned long long off = carry[j] + (w ? readlane_u64(inc, w - 1) : 0ull);
-        carry[j] += readlane_u64(inc, kSeqWaves - 1);
+        const unsigned long long inc = inc4[j >> 2];
+        const int rl = (int)((j & 3u) << 4);
+        const unsigned long long off = carry[j] + (w ? readlane_u64(inc, rl + w - 1) : 0ull);
+        carry[j] += readlane_u64(inc, rl + kSeqWaves - 1);
         const int64_t sum = (int64_t)(x[j] + off);
         if (j < 4) {
           ok = ok && sum >= R.v[j];                                                                    // :673-685
@@ -261,9 +319,11 @@ __device__ __forceinline__ uint32_t seq_scan(const NodesDev& nd, const SeqDev& s
       }
     }
     pcarry |= pround;
+    BS_SCAN_T(6);
     const unsigned long long m = __ballot(ok);
     if (lane == 0) sh_.fk[b][w] = m ? ((r * kSeqWaves + (uint32_t)w) << 6) + (uint32_t)(__ffsll((long long)m) - 1) : BS_INF;
     cur = nxt;
+    BS_SCAN_T(7);
   }
   rounds_done += r < rounds ? r + 1 : rounds;
   if (found == BS_INF) {                                      // the last round's hits
@@ -271,6 +331,232 @@ __device__ __forceinline__ uint32_t seq_scan(const NodesDev& nd, const SeqDev& s
     found = seq_row_min_u32(lane < kSeqWaves ? sh_.fk[(rounds - 1u) & 1u][lane] : BS_INF);
   }
   // (the next writer of tot / wpres / fk is the next scan: the first-fit search's barriers or the next pod's top barrier lie between)
+  return found;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Table summaries.  For a (fit class, percent) table the scan only has to look INSIDE a tile of 64 nodes when the tile can
+// hold the first covering row: with the running sum in front of the tile (the exclusive prefix of the tile TOTALS) and the
+// largest running sum inside it per resource lane (MAX LOCAL PREFIX over the rows the reference compares at), a tile is a
+// candidate iff offset + max >= request on every lane.  Totals, maxima and the scalar keys a tile introduces are kept in LDS
+// for up to four tables; an assume step changes ONE tile of each (marked dirty, re-summarised by one wave at the next use).
+// A scan is then: refresh dirty tiles -> prefix over <= 1024 tile totals (one thread per tile) -> candidate test -> the
+// exact DPP scan of the candidate tiles in list order, 16 at a time.  A rejected request (no candidate) never touches the
+// node list.  Sums wrap (Go semantics): a tile whose local sums leave (-2^62, 2^62), or an offset outside it, is never pruned.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SeqCache {
+  uint32_t T, K;                 // tiles, slots
+  unsigned long long* tt;        // [K][L][T] tile totals
+  long long* mp;                 // [K][L][T] max local prefix per lane (INT64_MIN: no row in the tile, INT64_MAX: not prunable)
+  uint32_t* pr;                  // [K][T] scalar keys the tile's nodes bring into the running sum
+  unsigned long long* off;       // [L][T] exclusive prefix of the totals, for the query in flight
+  uint32_t* pb;                  // [T] scalar keys present in front of the tile, for the query in flight
+};
+template <int TS>
+__device__ __forceinline__ SeqCache seq_cache_view(unsigned char* base, uint32_t T, uint32_t K, Shape<TS> sh) {
+  SeqCache c;
+  const size_t L = sh.L();
+  c.T = T; c.K = K;
+  c.tt = reinterpret_cast<unsigned long long*>(base);
+  c.mp = reinterpret_cast<long long*>(c.tt + (size_t)K * L * T);
+  c.off = reinterpret_cast<unsigned long long*>(c.mp + (size_t)K * L * T);
+  c.pr = reinterpret_cast<uint32_t*>(c.off + L * T);
+  c.pb = c.pr + (size_t)K * T;
+  return c;
+}
+
+// One tile (64 nodes, one wave): live values -> running sums inside the tile.  x[j] = inclusive local sums, row / pres per lane.
+template <int TS>
+__device__ __forceinline__ void seq_tile_local(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, const int64_t* lf, const uint32_t* fitrow,
+                                               uint32_t tile, unsigned long long (&x)[BS_MAX_LANES], bool& row, uint32_t& pres) {
+  const Shape<TS> sh(prm.S);
+  const uint32_t L = sh.L(), N = nd.n;
+  const uint32_t n = (tile << 6) + (uint32_t)lane_id();
+  const uint32_t nn = n < N ? n : N - 1u;
+  const uint32_t meta = n < N ? sq.nmeta[nn] : 0u, fitw = fitrow[nn >> 5];
+  int64_t v[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+    if (j < L) v[j] = lf[(size_t)j * nd.stride + nn];
+  row = n < N && (meta & 1u);                                                                        // core.go:606-617
+  const bool fit = row && !(meta & 2u) && ((fitw >> (n & 31u)) & 1u);                                 // :639-645
+  pres = fit ? (meta >> 4) : 0u;                                                                     // :662-668
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    const bool live = j < L && fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
+    x[j] = live ? (unsigned long long)v[j] : 0ull;
+  }
+  seq_wave_scan64_lanes(x, L);
+}
+
+// (re)summarise one tile of the table in slot `slot`: one wave
+template <int TS>
+__device__ __forceinline__ void seq_cache_tile(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, const SeqCache& ch, uint32_t slot, uint32_t tcls,
+                                               bool pct07, uint32_t tile) {
+  const Shape<TS> sh(prm.S);
+  const uint32_t L = sh.L(), S = sh.S();
+  unsigned long long x[BS_MAX_LANES];
+  bool row;
+  uint32_t pres;
+  seq_tile_local<TS>(nd, sq, prm, pct07 ? sq.left07 : sq.left10, nd.fit + (size_t)tcls * nd.fit_words, tile, x, row, pres);
+  constexpr long long kSafe = 1ll << 62;
+  uint32_t wp = 0;
+#pragma unroll
+  for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2)
+    if (s2 < S && __ballot((pres >> s2) & 1u)) wp |= 1u << s2;
+  const bool anyrow = __ballot(row) != 0ull;
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    if (j < L) {
+      const long long xi = (long long)x[j];
+      const bool risky = __ballot(xi >= kSafe || xi <= -kSafe) != 0ull;
+      const long long mx = readlane63_i64(wave_max_i64_lane63(row ? xi : INT64_MIN));
+      if (lane_id() == 63) {
+        ch.tt[((size_t)slot * L + j) * ch.T + tile] = x[j];
+        ch.mp[((size_t)slot * L + j) * ch.T + tile] = !anyrow ? INT64_MIN : (risky ? INT64_MAX : mx);
+      }
+    }
+  }
+  if (lane_id() == 0) ch.pr[(size_t)slot * ch.T + tile] = wp;
+}
+
+// compareClusterResourceAndRequire through the summaries of slot `slot` (every tile of it is up to date).  first_k or BS_INF.
+template <int TS>
+__device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqCache& ch, uint32_t slot,
+                                                    uint32_t tcls, bool pct07, const Res& R, unsigned long long& rounds_done) {
+  const Shape<TS> sh(prm.S);
+  const uint32_t L = sh.L(), S = sh.S();
+  const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
+  const uint32_t T = ch.T, t = threadIdx.x;                     // T <= kSeqBlock: one thread per tile
+  const uint32_t nw = (T + 63u) >> 6;                           // waves that own tiles
+  constexpr long long kSafe = 1ll << 62;
+  // ---- level 1: running sums in front of every tile
+  unsigned long long v[BS_MAX_LANES], inc[BS_MAX_LANES];
+  uint32_t mypr = 0;
+  if ((uint32_t)w < nw) {
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { v[j] = (j < L && t < T) ? ch.tt[((size_t)slot * L + j) * T + t] : 0ull; inc[j] = v[j]; }
+    mypr = t < T ? ch.pr[(size_t)slot * T + t] : 0u;
+    seq_wave_scan64_lanes(inc, L);
+    if (lane == 63) {
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+        if (j < L) sh_.tot[0][j][w] = inc[j];
+    }
+    uint32_t wp = 0;
+#pragma unroll
+    for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2)
+      if (s2 < S && __ballot((mypr >> s2) & 1u)) wp |= 1u << s2;
+    if (lane == 0) sh_.wpres[0][w] = wp;
+  }
+  lds_barrier();
+  bool cand = false;
+  if ((uint32_t)w < nw) {
+    unsigned long long inc4[BS_MAX_LANES / 4];
+#pragma unroll
+    for (uint32_t qd = 0; qd < BS_MAX_LANES / 4; ++qd) {
+      inc4[qd] = 0;
+      if (qd * 4u < L) {
+        const uint32_t jr = qd * 4u + ((uint32_t)lane >> 4), wi = (uint32_t)lane & 15u;
+        inc4[qd] = seq_row_scan64((jr < L && wi < nw) ? sh_.tot[0][jr][wi] : 0ull);
+      }
+    }
+    const uint32_t pw = (uint32_t)lane < nw ? sh_.wpres[0][lane] : 0u;
+    uint32_t pbefore_w = 0;
+    cand = t < T;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+      if (j < L) {
+        const unsigned long long woff = w ? readlane_u64(inc4[j >> 2], (int)((j & 3u) << 4) + w - 1) : 0ull;
+        const long long off = (long long)(inc[j] - v[j] + woff);                  // exclusive: the running sum in front of tile t
+        if (t < T) ch.off[(size_t)j * T + t] = (unsigned long long)off;
+        const long long m = t < T ? ch.mp[((size_t)slot * L + j) * T + t] : INT64_MIN;
+        const bool open = m == INT64_MAX || off >= kSafe || off <= -kSafe;         // not prunable on this lane
+        const bool reach = m != INT64_MIN && (open || off + m >= R.v[j]);
+        if (j < 4) cand = cand && reach;
+        else {
+          const uint32_t s2 = j - 4;
+          const unsigned long long bal = __ballot((uint32_t)lane < nw && ((pw >> s2) & 1u));
+          if (bal & ((1ull << w) - 1ull)) pbefore_w |= 1u << s2;
+          const unsigned long long km = __ballot((mypr >> s2) & 1u);
+          const bool before = ((pbefore_w >> s2) & 1u) || (km & ((1ull << lane) - 1ull));      // a tile in FRONT of this one brought the key
+          if ((R.present >> s2) & 1u) {
+            if (before) cand = cand && reach;
+            else if (!((mypr >> s2) & 1u)) cand = cand && R.v[j] == 0 && m != INT64_MIN;      // no key at any row of the tile
+            else cand = cand && m != INT64_MIN;                                               // the key appears inside the tile: look
+          } else cand = cand && m != INT64_MIN;
+        }
+      }
+    }
+    // keys present in front of tile t (all scalar lanes at once)
+    if (t < T) {
+      uint32_t pbt = pbefore_w;
+#pragma unroll
+      for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
+        if (s2 < S) {
+          const unsigned long long km = __ballot((mypr >> s2) & 1u);
+          if (km & ((1ull << lane) - 1ull)) pbt |= 1u << s2;
+        }
+      }
+      ch.pb[t] = pbt;
+    }
+  }
+  const unsigned long long cm = __ballot(cand);
+  if (lane == 0) sh_.cmask[w] = cm;
+  lds_barrier();
+  // ---- level 2: the candidate tiles, in list order, one per wave and round
+  unsigned long long masks[kSeqWaves];
+  uint32_t total = 0;
+#pragma unroll
+  for (int ww = 0; ww < kSeqWaves; ++ww) { masks[ww] = uni64(sh_.cmask[ww]); total += (uint32_t)__popcll(masks[ww]); }
+  const int64_t* lf = pct07 ? sq.left07 : sq.left10;
+  const uint32_t* fitrow = nd.fit + (size_t)tcls * nd.fit_words;
+  uint32_t found = BS_INF, pbuf = 0;
+  for (uint32_t base = 0; base < total && found == BS_INF; base += kSeqWaves) {
+    uint32_t idx = base + (uint32_t)w, tile = BS_INF;
+    if (idx < total) {
+#pragma unroll
+      for (int ww = 0; ww < kSeqWaves; ++ww) {
+        const uint32_t c = (uint32_t)__popcll(masks[ww]);
+        if (tile == BS_INF) {
+          if (idx < c) {
+            unsigned long long mm = masks[ww];
+            for (uint32_t k = 0; k < idx; ++k) mm &= mm - 1ull;
+            tile = (uint32_t)ww * 64u + (uint32_t)(__ffsll((long long)mm) - 1);
+          } else idx -= c;
+        }
+      }
+    }
+    uint32_t mine = BS_INF;
+    if (tile != BS_INF) {
+      unsigned long long x[BS_MAX_LANES];
+      bool row;
+      uint32_t pres;
+      seq_tile_local<TS>(nd, sq, prm, lf, fitrow, tile, x, row, pres);
+      const uint32_t pbt = ch.pb[tile];
+      bool ok = row;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+        if (j < L) {
+          const int64_t sum = (int64_t)(x[j] + ch.off[(size_t)j * T + tile]);
+          if (j < 4) ok = ok && sum >= R.v[j];                                                       // core.go:673-685
+          else {
+            const uint32_t s2 = j - 4;
+            const unsigned long long km = __ballot((pres >> s2) & 1u);
+            const bool have = ((pbt >> s2) & 1u) || (km & ((2ull << lane) - 1ull));
+            if ((R.present >> s2) & 1u) ok = ok && (have ? !(R.v[j] > sum) : R.v[j] == 0);          // :686-697
+          }
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (m) mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
+    }
+    if (lane == 0) sh_.pick[pbuf][w] = mine;
+    lds_barrier();
+    found = seq_row_min_u32(lane < kSeqWaves ? sh_.pick[pbuf][lane] : BS_INF);
+    pbuf ^= 1u;
+    rounds_done++;
+  }
   return found;
 }
 
@@ -403,8 +689,14 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
             }
             if (touched) {
               sq.nreq[(size_t)j * nd.stride + at] = nr;
-              sq.left07[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 0.7f), nr);
-              sq.left10[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 1.0f), nr);
+              if (j < 4 || ((rp >> (j - 4)) & 1u)) {             // left = scaled allocatable - requested: it moves by what requested moves by
+                const int64_t dlt = wsub(nr, rq[j]);
+                sq.left07[(size_t)j * nd.stride + at] = wsub(sq.left07[(size_t)j * nd.stride + at], dlt);
+                sq.left10[(size_t)j * nd.stride + at] = wsub(sq.left10[(size_t)j * nd.stride + at], dlt);
+              } else {                                           // a scalar key the node's requests did not have: the lane starts to exist
+                sq.left07[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 0.7f), nr);
+                sq.left10[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 1.0f), nr);
+              }
             }
           }
         }
@@ -552,9 +844,15 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       if (lane_id() == 0 && n < N) { sh_.pmax[0][n >> 6] = m0; sh_.pmax[1][n >> 6] = m1; }
     }
   }
+  // table summaries (see seq_scan_cached): which table sits in which slot, how many of its tiles wait for a refresh
+  const uint32_t ntiles = (N + 63u) >> 6;
+  const SeqCache ch = seq_cache_view(reinterpret_cast<unsigned char*>(s_keys) + prm.cache_off, ntiles, prm.cache_slots, sh);
+  uint32_t slot_key[kSeqCacheSlots], slot_nd[kSeqCacheSlots], slot_age[kSeqCacheSlots], slot_last[kSeqCacheSlots], age_ctr = 0;
+#pragma unroll
+  for (uint32_t c = 0; c < kSeqCacheSlots; ++c) { slot_key[c] = BS_INF; slot_nd[c] = 0; slot_age[c] = 0; slot_last[c] = BS_INF; }
   int32_t sop_leader = prm.sop_leader0;                      // sop.maxFinishedPG / maxPGStatus (core.go:58-59), stale between calls
   uint32_t n_released = 0;
-  unsigned long long n_pick = 0, n_scan = 0, n_rounds = 0, n_tiles = 0, n_folds = 0;
+  unsigned long long n_pick = 0, n_scan = 0, n_rounds = 0, n_tiles = 0, n_folds = 0, n_builds = 0;
   // findMaxPG's answer is kept until a key changes (capture, Permit, release)
   bool fold_valid = false, fold_panic = false;
   int32_t fold_leader = -1;
@@ -746,7 +1044,51 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     // ---- the node scan of this PreFilter call
     BS_SEQ_T(0);
     if (scan) {
-      const uint32_t first_k = seq_scan<TS>(nd, sq, prm, sh_, tcls, pct07, R, n_rounds);
+      uint32_t first_k;
+      if (prm.cache_slots) {
+        const uint32_t key = (tcls << 1) | (pct07 ? 1u : 0u);
+        uint32_t sel = BS_INF;
+#pragma unroll
+        for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
+          if (c < prm.cache_slots && slot_key[c] == key) sel = c;
+        if (sel == BS_INF) {                                 // not cached: the least recently used slot takes the table (every tile summarised)
+          uint32_t best_age = BS_INF;
+#pragma unroll
+          for (uint32_t c = 0; c < kSeqCacheSlots; ++c) {
+            if (c < prm.cache_slots) {
+              const uint32_t a = slot_key[c] == BS_INF ? 0u : slot_age[c] + 1u;
+              if (a < best_age) { best_age = a; sel = c; }
+            }
+          }
+          __syncthreads();                                   // assume steps of earlier pods have landed in the left arrays
+          for (uint32_t tile = (uint32_t)wave_id(); tile < ntiles; tile += kSeqWaves) seq_cache_tile<TS>(nd, sq, prm, ch, sel, tcls, pct07, tile);
+#pragma unroll
+          for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
+            if (c == sel) { slot_key[c] = key; slot_nd[c] = 0; slot_last[c] = BS_INF; }
+          n_builds++;
+          lds_barrier();
+        } else {
+          uint32_t ndirty = 0;
+#pragma unroll
+          for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
+            if (c == sel) ndirty = slot_nd[c];
+          if (ndirty) {                                      // tiles an assume step touched since: one wave each
+            __syncthreads();
+            for (uint32_t k = (uint32_t)wave_id(); k < ndirty; k += kSeqWaves) seq_cache_tile<TS>(nd, sq, prm, ch, sel, tcls, pct07, sh_.dirty[sel][k]);
+#pragma unroll
+            for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
+              if (c == sel) { slot_nd[c] = 0; slot_last[c] = BS_INF; }
+            lds_barrier();
+          }
+        }
+        age_ctr++;
+#pragma unroll
+        for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
+          if (c == sel) slot_age[c] = age_ctr;
+        first_k = seq_scan_cached<TS>(nd, sq, prm, sh_, ch, sel, tcls, pct07, R, n_rounds);
+      } else {
+        first_k = seq_scan<TS>(nd, sq, prm, sh_, tcls, pct07, R, n_rounds);
+      }
       n_scan++;
       fk = first_k == BS_INF ? BS_K_NONE : first_k;
       if (first_k == BS_INF) {                               // compareClusterResourceAndRequire false: AddToDenyCache (:142,:163)
@@ -764,6 +1106,21 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       for (uint32_t j = 0; j < BS_MAX_LANES; ++j) q.preq[j] = j < L ? pods.req[(size_t)j * P + i] : 0;
       at = seq_pick<TS>(nd, sq, prm, sh_, q, n_tiles);
       n_pick++;
+    }
+    if (at != BS_INF && prm.cache_slots) {                   // the assume step changed one tile of every cached table
+      const uint32_t tile = at >> 6;
+#pragma unroll
+      for (uint32_t c = 0; c < kSeqCacheSlots; ++c) {
+        if (c < prm.cache_slots && slot_key[c] != BS_INF && slot_last[c] != tile) {
+          if (slot_nd[c] < kSeqDirtyMax) {
+            if (t0) sh_.dirty[c][slot_nd[c]] = tile;
+            slot_nd[c]++;
+            slot_last[c] = tile;
+          } else {
+            slot_key[c] = BS_INF;                            // too many stale tiles: the table is summarised afresh at its next use
+          }
+        }
+      }
     }
     BS_SEQ_T(4);
     if (deny) { gflags |= BS_GROUP_DENIED; own.flags = gflags; }
@@ -857,9 +1214,10 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     sq.info[4] = (unsigned long long)(uint32_t)(sop_leader + 1);
     sq.info[5] = n_rounds;
     sq.info[6] = n_tiles;
-    sq.info[7] = n_folds;
+    sq.info[7] = n_folds | (n_builds << 40);
 #ifdef BS_SEQ_PROBE
     for (int k = 0; k < 8; ++k) sq.info[8 + k] = ph[k];
+    for (int k = 0; k < 8; ++k) { sq.info[16 + k] = g_seq_scan_ph[k]; g_seq_scan_ph[k] = 0; }
 #endif
   }
 }

@@ -3013,7 +3013,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   if (G > 0x7FFFFFF0u) return BS_ERR_CAPACITY;
   out->n_released = 0;
   out->total_ns = 0;
-  out->node_picks = out->node_scans = out->scan_rounds = out->pick_rounds = out->leader_folds = 0;
+  out->node_picks = out->node_scans = out->scan_rounds = out->pick_rounds = out->leader_folds = out->table_builds = 0;
   // ---- scratch: one allocation
   const size_t nP = std::max<uint32_t>(P, 1), nG = std::max<uint32_t>(G, 1), cap = std::max<uint32_t>(out->cap, 1), stride = std::max<uint32_t>(c->Ncap, 1);
   size_t o = 0;
@@ -3035,7 +3035,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   const size_t o_rp = o; o = align256(o + cap * 4);
   const size_t o_ft = o; o = align256(o + cap * 8);
   const size_t o_rt = o; o = align256(o + cap * 8);
-  const size_t o_info = o; o = align256(o + 128);
+  const size_t o_info = o; o = align256(o + 256);
   HIPCHK(c, c->d_seq.reserve(o));
   uint8_t* base = c->d_seq.as<uint8_t>();
   GroupsDev gr = groups_dev(c);
@@ -3076,8 +3076,19 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   prm.sop_leader0 = c->sop_leader0;
   prm.keys_in_lds = G <= kSeqKeysLds ? 1u : 0u;
   prm.prune = cdiv(N, 64) <= kSeqPruneTiles ? 1u : 0u;
-  const size_t lds = prm.keys_in_lds ? (size_t)nG * 8 : 0;
-  HIPCHK(c, hipMemsetAsync(base + o_info, 0, 128, c->stream));
+  size_t lds = prm.keys_in_lds ? align256((size_t)nG * 8) : 0;
+  {
+    // table summaries: as many slots as the CU's LDS holds behind the static arrays and the key window (one thread per tile: <= 1024 tiles)
+    const size_t T = cdiv(N, 64), per_slot = T * ((size_t)L * 16 + 4), query = T * ((size_t)L * 8 + 4);
+    const size_t budget = (size_t)160 * 1024 - sizeof(SeqShared) - 2048;
+    uint32_t K = 0;
+    if (T && T <= (size_t)kSeqBlock && budget > lds + query + per_slot) K = (uint32_t)std::min<size_t>(kSeqCacheSlots, (budget - lds - query) / per_slot);
+    if (const char* e = std::getenv("BS_SEQ_CACHE_SLOTS")) K = std::min<uint32_t>(K, (uint32_t)std::max(0, std::atoi(e)));   // tests: 0 = the round scan, 1 = thrash one slot
+    prm.cache_slots = K;
+    prm.cache_off = (uint32_t)lds;
+    if (K) lds += align256(K * per_slot + query + 64);
+  }
+  HIPCHK(c, hipMemsetAsync(base + o_info, 0, 256, c->stream));
   const PodsDev pd = pods_dev(c);
   const NodesDev nd = nodes_dev(c);
   switch (c->S <= 4 ? (int)c->S : -1) {
@@ -3104,10 +3115,13 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   out->node_scans = info[3];
   out->scan_rounds = info[5];
   out->pick_rounds = info[6];
-  out->leader_folds = info[7];
+  out->leader_folds = info[7] & ((1ull << 40) - 1ull);
+  out->table_builds = info[7] >> 40;
   if (const char* e = std::getenv("BS_SEQ_PROBE_PRINT")) {   // probe build: cycles per phase (see bs_seq.hpp)
     if (std::atoi(e)) std::fprintf(stderr, "seq probe cycles: control %llu capture %llu fold %llu scan %llu pick %llu permit %llu top-barrier %llu\n", info[8], info[9],
                                    info[10], info[11], info[12], info[13], info[14]);
+    if (std::atoi(e)) std::fprintf(stderr, "  scan rounds (thread 0): issue-next-loads %llu select %llu wave-scans %llu lds-writes %llu barrier %llu fk-check %llu offsets+compare %llu tail %llu\n",
+                                   info[16], info[17], info[18], info[19], info[20], info[21], info[22], info[23]);
   }
   if (P) {
     if (out->pf_code) std::memcpy(out->pf_code, rb + o_code, P);
@@ -3221,6 +3235,7 @@ int bs_seq_run_flat(bs_ctx* c, uint32_t stages, uint8_t* pf_code, uint32_t* pf_f
   if (scalars_out) {
     scalars_out[0] = o.n_released; scalars_out[1] = o.total_ns; scalars_out[2] = (int64_t)o.node_picks; scalars_out[3] = (int64_t)o.node_scans;
     scalars_out[4] = (int64_t)o.scan_rounds; scalars_out[5] = (int64_t)o.pick_rounds; scalars_out[6] = (int64_t)o.leader_folds;
+    scalars_out[7] = (int64_t)o.table_builds;
   }
   return rc;
 }

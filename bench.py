@@ -265,7 +265,7 @@ def drain_section(bsa, nodes, fit, groups, pods, args):
         "latency_definition": "per gang, device clock: first pod entering PreFilter (core.go:88) -> quorum of core.go:303 true (the same definition as the CPU pass)",
         "speedup_vs_cpu_port": {"gang_admit_latency_p50": p50_cpu / p50_dev if p50_dev else None, "whole_pass": s["total_ns"] / 1e9 / max(wall, 1e-12)},
         "work": {"node_scans": r["node_scans"], "scan_rounds_of_1024_nodes": r["scan_rounds"], "first_fit_searches": r["node_picks"],
-                 "first_fit_rounds_of_16_tiles": r["pick_rounds"], "findMaxPG_folds": r["leader_folds"],
+                 "first_fit_rounds_of_16_tiles": r["pick_rounds"], "findMaxPG_folds": r["leader_folds"], "table_summary_builds": r["table_builds"],
                  "evals_executed": r["scan_rounds"] * 1024, "evals_per_s": r["scan_rounds"] * 1024 / max(r["total_ns"] * 1e-9, 1e-12),
                  "cpu_port_reference_loop_iterations": s["iters"]},
     }

@@ -277,7 +277,7 @@ func (g *gpuCore) seqPass(P int, withFilter bool) (*seqResult, error) {
 	r := &seqResult{pfCode: make([]C.uint8_t, P+1), podNode: make([]C.int32_t, P+1), releasedGroup: make([]C.uint32_t, cap),
 		releasedPods: make([]C.uint32_t, cap), readyNs: make([]C.int64_t, cap)}
 	firstNs := make([]C.int64_t, cap)
-	var scalars [7]C.int64_t
+	var scalars [8]C.int64_t
 	stages := C.uint32_t(C.BS_STAGE_PREFILTER)
 	if withFilter {
 		stages |= C.BS_STAGE_FILTER

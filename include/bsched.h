@@ -499,8 +499,11 @@ typedef struct bs_seq_out {
   int64_t   total_ns;        /* out: device time of the whole pass                                                     */
   /* out, work counters: first-fit searches; PreFilter node scans; rounds of 1024 nodes those scans went through (they stop at
    * the reference's early exit); rounds of up to 16 candidate tiles of 64 nodes the first-fit searches looked at; findMaxPG
-   * folds (the fold is only repeated after a capture / Permit / release changed a group's progress) */
+   * folds (the fold is only repeated after a capture / Permit / release changed a group's progress).  With table summaries in LDS
+   * (clusters of up to 65 536 nodes) a scan "round" is 16 candidate tiles of 64 nodes looked at exactly; a rejected request
+   * usually needs none. */
   uint64_t  node_picks, node_scans, scan_rounds, pick_rounds, leader_folds;
+  uint64_t  table_builds;    /* out: (fit class, percent) tables whose tile summaries were taken from scratch (LDS cache misses) */
 } bs_seq_out;
 int bs_seq_run(bs_ctx* ctx, uint32_t stages, bs_seq_out* out);
 /* The node requests as the context holds them (after bs_nodes_load / bs_nodes_apply / bs_nodes_assume / bs_seq_run):
@@ -589,7 +592,7 @@ int bs_batch_read_flat(bs_ctx* ctx, uint8_t* pf_code, uint32_t* pf_first_k, int3
                        uint64_t* fl_bitmap, uint32_t* group_admit, uint8_t* group_ready, uint32_t* fl_slot, uint64_t* fl_rows,
                        uint32_t* fl_rows_feasible, uint32_t fl_rows_cap, uint32_t* fl_rows_n);
 /* bs_seq_run: the five scalar results come back through `scalars_out` = {n_released, total_ns, node_picks, node_scans, scan_rounds,
- * pick_rounds, leader_folds} (int64[7], NULL ok) */
+ * pick_rounds, leader_folds, table_builds} (int64[8], NULL ok) */
 int bs_seq_run_flat(bs_ctx* ctx, uint32_t stages, uint8_t* pf_code, uint32_t* pf_first_k, int32_t* pf_leader, int32_t* pod_node, uint32_t cap,
                     uint32_t* released_group, uint32_t* released_pods, int64_t* first_ns, int64_t* ready_ns, int64_t* scalars_out);
 /* bs_fit_build: node tables, then the template tables; `ex_*` = bs_fit_templates.exprs, `fd_*` = bs_fit_templates.fields */

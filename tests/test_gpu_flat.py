@@ -64,7 +64,7 @@ def test_flat_forms_equal_struct_forms(bsa, soa, orc):
         cap = groups.g
         pf, node = np.zeros(p, np.uint8), np.zeros(p, np.int32)
         rg, rp = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
-        t0, t1, sc = np.zeros(cap, np.int64), np.zeros(cap, np.int64), np.zeros(7, np.int64)
+        t0, t1, sc = np.zeros(cap, np.int64), np.zeros(cap, np.int64), np.zeros(8, np.int64)
         i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
         u32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
         chk(lib.bs_seq_run_flat(ctx._h, soa.STAGE_PREFILTER, pf.ctypes.data_as(C.POINTER(C.c_uint8)), None, None, node.ctypes.data_as(C.POINTER(C.c_int32)), cap,

@@ -222,3 +222,26 @@ def test_seq_pass_refusals_and_empty_inputs(bsa, soa, orc):
     s = oracle_pass(orc, none, fit0, groups, pods, soa.STAGE_PREFILTER)
     with load_ctx(bsa, none, fit0, groups, pods) as ctx:
         check_pass(ctx, s, soa, "no nodes")
+
+
+@pytest.mark.parametrize("slots", ["0", "1"], ids=["round-scan", "one-slot"])
+@pytest.mark.parametrize("seed", range(4200, 4230))
+def test_seq_pass_scan_variants(seed, slots, bsa, soa, orc, monkeypatch):
+    """the node scan without table summaries (rounds over the node list: what clusters beyond 65 536 nodes get) and with ONE summary
+    slot (every change of the table in use rebuilds it): same pass, bit for bit"""
+    monkeypatch.setenv("BS_SEQ_CACHE_SLOTS", slots)
+    st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if seed % 2 else 0)
+    nodes, fit, groups, pods = gang_scene(seed, soa, n_nodes=150)
+    s = oracle_pass(orc, nodes, fit, groups, pods, st)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        check_pass(ctx, s, soa, f"seed {seed} slots {slots}")
+
+
+@pytest.mark.parametrize("slots", ["0", "1"], ids=["round-scan", "one-slot"])
+def test_seq_pass_scan_variants_cfg3(slots, bsa, soa, orc, monkeypatch):
+    monkeypatch.setenv("BS_SEQ_CACHE_SLOTS", slots)
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg3", "cold")
+    pods = compare_order(pods)
+    s = oracle_pass(orc, nodes, fit, groups, pods, soa.STAGE_PREFILTER)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        check_pass(ctx, s, soa, f"cfg3/cold slots {slots}")

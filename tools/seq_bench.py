@@ -20,7 +20,7 @@ def main():
     scenario = args[1] if len(args) > 1 else "tail"
     st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if "--filter" in sys.argv else 0)
     if "--probe" in sys.argv:            # the -DBS_SEQ_PROBE build: cycles per phase go to stderr
-        bsa.capi.LIB_PATH = os.path.join(ROOT, "tools", "ubench", "libbsched_seqprobe.so")
+        bsa.capi.LIB_PATH = os.environ.get("BS_SEQ_PROBE_LIB") or os.path.join(ROOT, "tools", "ubench", "libbsched_seqprobe.so")
         os.environ["BS_SEQ_PROBE_PRINT"] = "1"
     nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
     pods = pods.take(np.argsort(pods.group, kind="stable"))           # Compare order
@@ -39,7 +39,7 @@ def main():
     print(json.dumps({
         "config": f"{config}/{scenario}", "filter": bool(st & soa.STAGE_FILTER), "pods": int(pods.p), "nodes": int(nodes.n), "groups": int(groups.g),
         "gangs_released": r["n_released"],
-        "gpu": {"wall_ms": wall * 1e3, "device_ms": r["total_ns"] * 1e-6, "us_per_pod": r["total_ns"] * 1e-3 / max(pods.p, 1), "node_picks": r["node_picks"], "node_scans": r["node_scans"], "scan_rounds": r["scan_rounds"], "pick_rounds": r["pick_rounds"], "leader_folds": r["leader_folds"],
+        "gpu": {"wall_ms": wall * 1e3, "device_ms": r["total_ns"] * 1e-6, "us_per_pod": r["total_ns"] * 1e-3 / max(pods.p, 1), "node_picks": r["node_picks"], "node_scans": r["node_scans"], "scan_rounds": r["scan_rounds"], "pick_rounds": r["pick_rounds"], "leader_folds": r["leader_folds"], "table_builds": r["table_builds"],
                 "gang_admit_latency_ms_p50": float(np.median(lat)) if lat.size else None, "gang_admit_latency_ms_p95": float(np.percentile(lat, 95)) if lat.size else None},
     }))
 
