@@ -47,7 +47,6 @@ constexpr uint32_t kSeqKeysLds = 8192;     // groups whose findMaxPG keys fit th
 constexpr uint32_t kSeqPruneTiles = 1024;  // 64-node tiles whose first-fit bounds fit the LDS window (65 536 nodes)
 constexpr uint32_t kSeqWaitList = 512;     // waiting pods of the current gang kept in LDS
 constexpr uint32_t kSeqCacheSlots = 4;     // table summaries (fit class x percent) kept in LDS at most
-constexpr uint32_t kSeqDirtyMax = 32;      // tiles of a cached table that may wait for a refresh before the table is dropped
 
 struct SeqDev {
   // resident state the pass mutates
@@ -203,7 +202,7 @@ struct SeqShared {
   uint32_t pick[2][kSeqWaves];
   long long pmax[2][kSeqPruneTiles];                     // per tile: max of allocatable - requested (cpu, memory) over schedulable nodes
   uint32_t wl_pod[kSeqWaitList], wl_node[kSeqWaitList];  // waiting pods of the CURRENT gang (released in parallel; the chain in global memory is the fallback)
-  uint32_t dirty[kSeqCacheSlots][kSeqDirtyMax];          // per cached table: tiles an assume step touched since their summary was taken
+  uint32_t asm_ap[2][kSeqWaves], asm_rp[2][kSeqWaves], asm_fit[2][kSeqWaves];   // first fit: keys / fit bits of each wave's node (see SeqAssumed)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -336,21 +335,28 @@ __device__ __forceinline__ uint32_t seq_scan(const NodesDev& nd, const SeqDev& s
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Table summaries.  For a (fit class, percent) table the scan only has to look INSIDE a tile of 64 nodes when the tile can
-// hold the first covering row: with the running sum in front of the tile (the exclusive prefix of the tile TOTALS) and the
-// largest running sum inside it per resource lane (MAX LOCAL PREFIX over the rows the reference compares at), a tile is a
-// candidate iff offset + max >= request on every lane.  Totals, maxima and the scalar keys a tile introduces are kept in LDS
-// for up to four tables; an assume step changes ONE tile of each (marked dirty, re-summarised by one wave at the next use).
-// A scan is then: refresh dirty tiles -> prefix over <= 1024 tile totals (one thread per tile) -> candidate test -> the
-// exact DPP scan of the candidate tiles in list order, 16 at a time.  A rejected request (no candidate) never touches the
-// node list.  Sums wrap (Go semantics): a tile whose local sums leave (-2^62, 2^62), or an offset outside it, is never pruned.
+// hold the first covering row: with the running sum in front of the tile (OFFSET: the exclusive prefix of the tile totals)
+// and the largest running sum inside it per resource lane (MAX LOCAL PREFIX over the rows the reference compares at), a tile
+// is a candidate iff offset + max >= request on every lane.  Offsets, totals, maxima and the scalar keys in front of / inside
+// a tile are kept in LDS for up to four tables, one thread per tile.  They are MAINTAINED, not recomputed:
+//   * an assume step moves the chosen node's left values by the pod's request (the same delta in every table the node
+//     counts in): every thread subtracts it from the offsets of the tiles behind the node's — one LDS subtract per lane;
+//   * maxima are left alone (requests only grow in a pass, so an old maximum is still an upper bound: more candidates, never
+//     fewer) and are TIGHTENED to the exact value by the wave that looked into a candidate tile in vain;
+//   * the rare events that would break a bound (a negative request, a scalar key the node's requests did not have) drop the
+//     table; it is summarised afresh at its next use.
+// A scan is then: candidate test (one thread per tile, LDS only) -> every wave looks into ITS OWN candidate tiles in list order
+// until it has a hit (DPP scan of the tile's 64 rows on top of the tile's offset) -> one barrier -> the smallest hit wins.
+// A rejected request (no candidate) never touches the node list.  Sums wrap (Go semantics): a tile whose local sums leave
+// (-2^62, 2^62), or an offset outside it, is never pruned.
 // ---------------------------------------------------------------------------------------------------------------------
 struct SeqCache {
-  uint32_t T, K;                 // tiles, slots
+  uint32_t T, K;                 // tiles (<= kSeqBlock: one thread per tile), slots
   unsigned long long* tt;        // [K][L][T] tile totals
+  unsigned long long* off;       // [K][L][T] running sum in front of the tile
   long long* mp;                 // [K][L][T] max local prefix per lane (INT64_MIN: no row in the tile, INT64_MAX: not prunable)
   uint32_t* pr;                  // [K][T] scalar keys the tile's nodes bring into the running sum
-  unsigned long long* off;       // [L][T] exclusive prefix of the totals, for the query in flight
-  uint32_t* pb;                  // [T] scalar keys present in front of the tile, for the query in flight
+  uint32_t* pb;                  // [K][T] scalar keys present in front of the tile
 };
 template <int TS>
 __device__ __forceinline__ SeqCache seq_cache_view(unsigned char* base, uint32_t T, uint32_t K, Shape<TS> sh) {
@@ -358,9 +364,9 @@ __device__ __forceinline__ SeqCache seq_cache_view(unsigned char* base, uint32_t
   const size_t L = sh.L();
   c.T = T; c.K = K;
   c.tt = reinterpret_cast<unsigned long long*>(base);
-  c.mp = reinterpret_cast<long long*>(c.tt + (size_t)K * L * T);
-  c.off = reinterpret_cast<unsigned long long*>(c.mp + (size_t)K * L * T);
-  c.pr = reinterpret_cast<uint32_t*>(c.off + L * T);
+  c.off = c.tt + (size_t)K * L * T;
+  c.mp = reinterpret_cast<long long*>(c.off + (size_t)K * L * T);
+  c.pr = reinterpret_cast<uint32_t*>(c.mp + (size_t)K * L * T);
   c.pb = c.pr + (size_t)K * T;
   return c;
 }
@@ -389,21 +395,13 @@ __device__ __forceinline__ void seq_tile_local(const NodesDev& nd, const SeqDev&
   seq_wave_scan64_lanes(x, L);
 }
 
-// (re)summarise one tile of the table in slot `slot`: one wave
+// exact maxima of a tile's local sums -> the slot's mp (and, when `totals`, its totals and keys): the calling wave holds x / row / pres
 template <int TS>
-__device__ __forceinline__ void seq_cache_tile(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, const SeqCache& ch, uint32_t slot, uint32_t tcls,
-                                               bool pct07, uint32_t tile) {
+__device__ __forceinline__ void seq_cache_put(const SeqParams& prm, const SeqCache& ch, uint32_t slot, uint32_t tile, const unsigned long long (&x)[BS_MAX_LANES],
+                                              bool row, uint32_t pres, bool totals) {
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L(), S = sh.S();
-  unsigned long long x[BS_MAX_LANES];
-  bool row;
-  uint32_t pres;
-  seq_tile_local<TS>(nd, sq, prm, pct07 ? sq.left07 : sq.left10, nd.fit + (size_t)tcls * nd.fit_words, tile, x, row, pres);
   constexpr long long kSafe = 1ll << 62;
-  uint32_t wp = 0;
-#pragma unroll
-  for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2)
-    if (s2 < S && __ballot((pres >> s2) & 1u)) wp |= 1u << s2;
   const bool anyrow = __ballot(row) != 0ull;
 #pragma unroll
   for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
@@ -412,25 +410,39 @@ __device__ __forceinline__ void seq_cache_tile(const NodesDev& nd, const SeqDev&
       const bool risky = __ballot(xi >= kSafe || xi <= -kSafe) != 0ull;
       const long long mx = readlane63_i64(wave_max_i64_lane63(row ? xi : INT64_MIN));
       if (lane_id() == 63) {
-        ch.tt[((size_t)slot * L + j) * ch.T + tile] = x[j];
+        if (totals) ch.tt[((size_t)slot * L + j) * ch.T + tile] = x[j];
         ch.mp[((size_t)slot * L + j) * ch.T + tile] = !anyrow ? INT64_MIN : (risky ? INT64_MAX : mx);
       }
     }
   }
-  if (lane_id() == 0) ch.pr[(size_t)slot * ch.T + tile] = wp;
+  if (totals) {
+    uint32_t wp = 0;
+#pragma unroll
+    for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2)
+      if (s2 < S && __ballot((pres >> s2) & 1u)) wp |= 1u << s2;
+    if (lane_id() == 0) ch.pr[(size_t)slot * ch.T + tile] = wp;
+  }
 }
 
-// compareClusterResourceAndRequire through the summaries of slot `slot` (every tile of it is up to date).  first_k or BS_INF.
+// Summarise a table from scratch into slot `slot`: every tile's totals / maxima / keys, then the offsets and the keys in
+// front of every tile (a two-level prefix over the tile totals: one thread per tile).
 template <int TS>
-__device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqCache& ch, uint32_t slot,
-                                                    uint32_t tcls, bool pct07, const Res& R, unsigned long long& rounds_done) {
+__device__ __forceinline__ void seq_cache_build(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqCache& ch, uint32_t slot,
+                                                uint32_t tcls, bool pct07) {
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L(), S = sh.S();
   const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
-  const uint32_t T = ch.T, t = threadIdx.x;                     // T <= kSeqBlock: one thread per tile
-  const uint32_t nw = (T + 63u) >> 6;                           // waves that own tiles
-  constexpr long long kSafe = 1ll << 62;
-  // ---- level 1: running sums in front of every tile
+  const uint32_t T = ch.T, t = threadIdx.x, nw = (T + 63u) >> 6;
+  const int64_t* lf = pct07 ? sq.left07 : sq.left10;
+  const uint32_t* fitrow = nd.fit + (size_t)tcls * nd.fit_words;
+  for (uint32_t tile = (uint32_t)w; tile < T; tile += kSeqWaves) {
+    unsigned long long x[BS_MAX_LANES];
+    bool row;
+    uint32_t pres;
+    seq_tile_local<TS>(nd, sq, prm, lf, fitrow, tile, x, row, pres);
+    seq_cache_put<TS>(prm, ch, slot, tile, x, row, pres, true);
+  }
+  lds_barrier();
   unsigned long long v[BS_MAX_LANES], inc[BS_MAX_LANES];
   uint32_t mypr = 0;
   if ((uint32_t)w < nw) {
@@ -450,7 +462,6 @@ __device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const Se
     if (lane == 0) sh_.wpres[0][w] = wp;
   }
   lds_barrier();
-  bool cand = false;
   if ((uint32_t)w < nw) {
     unsigned long long inc4[BS_MAX_LANES / 4];
 #pragma unroll
@@ -461,109 +472,100 @@ __device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const Se
         inc4[qd] = seq_row_scan64((jr < L && wi < nw) ? sh_.tot[0][jr][wi] : 0ull);
       }
     }
-    const uint32_t pw = (uint32_t)lane < nw ? sh_.wpres[0][lane] : 0u;
-    uint32_t pbefore_w = 0;
-    cand = t < T;
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
       if (j < L) {
         const unsigned long long woff = w ? readlane_u64(inc4[j >> 2], (int)((j & 3u) << 4) + w - 1) : 0ull;
-        const long long off = (long long)(inc[j] - v[j] + woff);                  // exclusive: the running sum in front of tile t
-        if (t < T) ch.off[(size_t)j * T + t] = (unsigned long long)off;
-        const long long m = t < T ? ch.mp[((size_t)slot * L + j) * T + t] : INT64_MIN;
+        if (t < T) ch.off[((size_t)slot * L + j) * T + t] = inc[j] - v[j] + woff;
+      }
+    }
+    const uint32_t pw = (uint32_t)lane < nw ? sh_.wpres[0][lane] : 0u;
+    uint32_t pbt = 0;
+#pragma unroll
+    for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
+      if (s2 < S) {
+        const unsigned long long bal = __ballot((uint32_t)lane < nw && ((pw >> s2) & 1u));
+        const unsigned long long km = __ballot((mypr >> s2) & 1u);
+        if ((bal & ((1ull << w) - 1ull)) || (km & ((1ull << lane) - 1ull))) pbt |= 1u << s2;
+      }
+    }
+    if (t < T) ch.pb[(size_t)slot * T + t] = pbt;
+  }
+  lds_barrier();
+}
+
+// compareClusterResourceAndRequire through the summaries of slot `slot`.  first_k or BS_INF; wave-uniform, same in every wave.
+template <int TS>
+__device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqCache& ch, uint32_t slot,
+                                                    uint32_t tcls, bool pct07, const Res& R, unsigned long long& rounds_done) {
+  const Shape<TS> sh(prm.S);
+  const uint32_t L = sh.L();
+  const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
+  const uint32_t T = ch.T, t = threadIdx.x;                     // T <= kSeqBlock: one thread per tile
+  constexpr long long kSafe = 1ll << 62;
+  // ---- candidate test, LDS only
+  bool cand = t < T;
+  if (t < T) {
+    const uint32_t mypr = ch.pr[(size_t)slot * T + t], mypb = ch.pb[(size_t)slot * T + t];
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+      if (j < L) {
+        const long long off = (long long)ch.off[((size_t)slot * L + j) * T + t];
+        const long long m = ch.mp[((size_t)slot * L + j) * T + t];
         const bool open = m == INT64_MAX || off >= kSafe || off <= -kSafe;         // not prunable on this lane
         const bool reach = m != INT64_MIN && (open || off + m >= R.v[j]);
         if (j < 4) cand = cand && reach;
-        else {
-          const uint32_t s2 = j - 4;
-          const unsigned long long bal = __ballot((uint32_t)lane < nw && ((pw >> s2) & 1u));
-          if (bal & ((1ull << w) - 1ull)) pbefore_w |= 1u << s2;
-          const unsigned long long km = __ballot((mypr >> s2) & 1u);
-          const bool before = ((pbefore_w >> s2) & 1u) || (km & ((1ull << lane) - 1ull));      // a tile in FRONT of this one brought the key
-          if ((R.present >> s2) & 1u) {
-            if (before) cand = cand && reach;
-            else if (!((mypr >> s2) & 1u)) cand = cand && R.v[j] == 0 && m != INT64_MIN;      // no key at any row of the tile
-            else cand = cand && m != INT64_MIN;                                               // the key appears inside the tile: look
-          } else cand = cand && m != INT64_MIN;
-        }
+        else if ((R.present >> (j - 4)) & 1u) {
+          if ((mypb >> (j - 4)) & 1u) cand = cand && reach;                         // the key is in the running sum in front of the tile
+          else if (!((mypr >> (j - 4)) & 1u)) cand = cand && R.v[j] == 0 && m != INT64_MIN;   // ... at no row of the tile
+          else cand = cand && m != INT64_MIN;                                       // ... appears inside the tile: look
+        } else cand = cand && m != INT64_MIN;
       }
-    }
-    // keys present in front of tile t (all scalar lanes at once)
-    if (t < T) {
-      uint32_t pbt = pbefore_w;
-#pragma unroll
-      for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
-        if (s2 < S) {
-          const unsigned long long km = __ballot((mypr >> s2) & 1u);
-          if (km & ((1ull << lane) - 1ull)) pbt |= 1u << s2;
-        }
-      }
-      ch.pb[t] = pbt;
     }
   }
-  const unsigned long long cm = __ballot(cand);
-  if (lane == 0) sh_.cmask[w] = cm;
-  lds_barrier();
-  // ---- level 2: the candidate tiles, in list order, one per wave and round
-  unsigned long long masks[kSeqWaves];
-  uint32_t total = 0;
-#pragma unroll
-  for (int ww = 0; ww < kSeqWaves; ++ww) { masks[ww] = uni64(sh_.cmask[ww]); total += (uint32_t)__popcll(masks[ww]); }
+  unsigned long long cm = __ballot(cand);
+  // ---- this wave's candidate tiles, in list order, until one holds a covering row
   const int64_t* lf = pct07 ? sq.left07 : sq.left10;
   const uint32_t* fitrow = nd.fit + (size_t)tcls * nd.fit_words;
-  uint32_t found = BS_INF, pbuf = 0;
-  for (uint32_t base = 0; base < total && found == BS_INF; base += kSeqWaves) {
-    uint32_t idx = base + (uint32_t)w, tile = BS_INF;
-    if (idx < total) {
-#pragma unroll
-      for (int ww = 0; ww < kSeqWaves; ++ww) {
-        const uint32_t c = (uint32_t)__popcll(masks[ww]);
-        if (tile == BS_INF) {
-          if (idx < c) {
-            unsigned long long mm = masks[ww];
-            for (uint32_t k = 0; k < idx; ++k) mm &= mm - 1ull;
-            tile = (uint32_t)ww * 64u + (uint32_t)(__ffsll((long long)mm) - 1);
-          } else idx -= c;
-        }
-      }
-    }
-    uint32_t mine = BS_INF;
-    if (tile != BS_INF) {
-      unsigned long long x[BS_MAX_LANES];
-      bool row;
-      uint32_t pres;
-      seq_tile_local<TS>(nd, sq, prm, lf, fitrow, tile, x, row, pres);
-      const uint32_t pbt = ch.pb[tile];
-      bool ok = row;
-#pragma unroll
-      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-        if (j < L) {
-          const int64_t sum = (int64_t)(x[j] + ch.off[(size_t)j * T + tile]);
-          if (j < 4) ok = ok && sum >= R.v[j];                                                       // core.go:673-685
-          else {
-            const uint32_t s2 = j - 4;
-            const unsigned long long km = __ballot((pres >> s2) & 1u);
-            const bool have = ((pbt >> s2) & 1u) || (km & ((2ull << lane) - 1ull));
-            if ((R.present >> s2) & 1u) ok = ok && (have ? !(R.v[j] > sum) : R.v[j] == 0);          // :686-697
-          }
-        }
-      }
-      const unsigned long long m = __ballot(ok);
-      if (m) mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
-    }
-    if (lane == 0) sh_.pick[pbuf][w] = mine;
-    lds_barrier();
-    found = seq_row_min_u32(lane < kSeqWaves ? sh_.pick[pbuf][lane] : BS_INF);
-    pbuf ^= 1u;
+  uint32_t mine = BS_INF;
+  while (cm && mine == BS_INF) {
+    const uint32_t tile = ((uint32_t)w << 6) + (uint32_t)(__ffsll((long long)cm) - 1);
+    cm &= cm - 1ull;
     rounds_done++;
+    unsigned long long x[BS_MAX_LANES];
+    bool row;
+    uint32_t pres;
+    seq_tile_local<TS>(nd, sq, prm, lf, fitrow, tile, x, row, pres);
+    const uint32_t pbt = ch.pb[(size_t)slot * T + tile];
+    bool ok = row;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+      if (j < L) {
+        const int64_t sum = (int64_t)(x[j] + ch.off[((size_t)slot * L + j) * T + tile]);
+        if (j < 4) ok = ok && sum >= R.v[j];                                                         // core.go:673-685
+        else {
+          const uint32_t s2 = j - 4;
+          const unsigned long long km = __ballot((pres >> s2) & 1u);
+          const bool have = ((pbt >> s2) & 1u) || (km & ((2ull << lane) - 1ull));
+          if ((R.present >> s2) & 1u) ok = ok && (have ? !(R.v[j] > sum) : R.v[j] == 0);            // :686-697
+        }
+      }
+    }
+    const unsigned long long m = __ballot(ok);
+    if (m) mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
+    else seq_cache_put<TS>(prm, ch, slot, tile, x, row, pres, false);        // looked at in vain: the tile's maxima become exact
   }
-  return found;
+  if (lane == 0) sh_.fk[0][w] = mine;
+  lds_barrier();
+  return seq_row_min_u32(lane < kSeqWaves ? sh_.fk[0][lane] : BS_INF);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // first fit in list order + the assume step (upstream's node choice / cache.AssumePod, restated; see bs_drain.cpp).
-// Returns the node (BS_INF none), wave-uniform, identical in every wave.  WRITE PHASE: the lane that owns the chosen node
-// rewrites its request lanes, the left arrays and the node's meta word.
+// Returns the node (BS_INF none), wave-uniform, identical in every wave.  Every wave looks into ITS OWN candidate tiles
+// (per-tile bound on free cpu / memory, LDS) in list order until it has a node; the smallest one wins; the lane that owns
+// it rewrites the node's request lanes, left values and meta word, and what the other waves need to follow the change in the
+// table summaries (the node's keys and fit bits) has been published before the barrier that decides.
 // ---------------------------------------------------------------------------------------------------------------------
 struct SeqPick {
   uint32_t pcls;                 // the pod's own fit class
@@ -573,142 +575,136 @@ struct SeqPick {
   uint32_t ff;                   // bit0: case 2 impossible, bit1: the leader's member cannot be "held" (scalar key)
   int64_t FR[4], FM[4];
 };
+struct SeqAssumed { uint32_t ap, rp, fitbits; };     // of the chosen node: allocatable keys, request keys BEFORE the step, bit c = fits the class of slot c
 
 template <int TS>
 __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqPick& q,
-                                             unsigned long long& tiles_looked) {
+                                             const uint32_t (&slot_key)[kSeqCacheSlots], bool drained, SeqAssumed& out, unsigned long long& tiles_looked) {
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L(), S = sh.S();
   const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
   const uint32_t N = nd.n;
+  out.ap = out.rp = out.fitbits = 0;
   if (!N || q.pcls >= nd.n_classes || q.fl >= 16u) return BS_INF;          // (ERR_PG_NOT_FOUND / the nil-leader panic: Filter fails everywhere)
   const bool fl_all = q.fl != BS_FL_EVALUATED;                              // Filter passes on every node
   const uint32_t ntiles = (N + 63u) >> 6;
   const uint32_t* fitrow = nd.fit + (size_t)q.pcls * nd.fit_words;
   uint32_t found = BS_INF, pb = 0;
+  if (!drained) __syncthreads();                                            // the assume steps of earlier pods have landed before a tile is read
   for (uint32_t chunk = 0; chunk < ntiles && found == BS_INF; chunk += kSeqBlock) {
-    if (chunk) lds_barrier();                                 // cmask of the previous chunk has been read by everybody
     const uint32_t t = chunk + threadIdx.x;
     bool cand = t < ntiles;
     if (cand && prm.prune)
       cand = !(q.preq[0] > 0 && sh_.pmax[0][t] < q.preq[0]) && !(q.preq[1] > 0 && sh_.pmax[1][t] < q.preq[1]);
-    const unsigned long long cm = __ballot(cand);
-    if (lane == 0) sh_.cmask[w] = cm;
-    BS_SEQ_FULL_BARRIER();                                          // (also: the assume steps of earlier pods have landed before a tile is read)
-    unsigned long long masks[kSeqWaves];
-    uint32_t total = 0;
+    unsigned long long cm = __ballot(cand);
+    uint32_t mine = BS_INF;
+    int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES];
 #pragma unroll
-    for (int ww = 0; ww < kSeqWaves; ++ww) { masks[ww] = uni64(sh_.cmask[ww]); total += (uint32_t)__popcll(masks[ww]); }
-    for (uint32_t base = 0; base < total && found == BS_INF; base += kSeqWaves) {
-      // this wave takes the (base + w)-th candidate tile of the chunk
-      uint32_t idx = base + (uint32_t)w, tile = BS_INF;
-      if (idx < total) {
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { al[j] = 0; rq[j] = 0; }
+    uint32_t ap = 0, rp = 0, fbits = 0;
+    while (cm && mine == BS_INF) {
+      const uint32_t tile = ((chunk + ((uint32_t)w << 6))) + (uint32_t)(__ffsll((long long)cm) - 1);
+      cm &= cm - 1ull;
+      tiles_looked++;
+      const uint32_t n = (tile << 6) + (uint32_t)lane;
+      const bool valid = n < N;
+      const uint32_t nn = valid ? n : N - 1u;
+      const uint32_t fl = nd.flags[nn];
+      ap = nd.apres[nn];
+      rp = sq.rpres[nn];
+      const uint32_t fw = fitrow[nn >> 5];
+      uint32_t fws[kSeqCacheSlots];
 #pragma unroll
-        for (int ww = 0; ww < kSeqWaves; ++ww) {
-          const uint32_t c = (uint32_t)__popcll(masks[ww]);
-          if (tile == BS_INF) {
-            if (idx < c) {
-              unsigned long long mm = masks[ww];
-              for (uint32_t k = 0; k < idx; ++k) mm &= mm - 1ull;
-              tile = chunk + (uint32_t)ww * 64u + (uint32_t)(__ffsll((long long)mm) - 1);
-            } else idx -= c;
-          }
+      for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
+        fws[c] = (c < prm.cache_slots && slot_key[c] != BS_INF) ? nd.fit[(size_t)(slot_key[c] >> 1) * nd.fit_words + (nn >> 5)] : 0u;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+        if (j < L) {
+          al[j] = nd.alloc[(size_t)j * nd.stride + nn];
+          rq[j] = sq.nreq[(size_t)j * nd.stride + nn];
         }
       }
-      uint32_t mine = BS_INF;
-      int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES];
+      fbits = 0;
 #pragma unroll
-      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { al[j] = 0; rq[j] = 0; }
-      uint32_t ap = 0, rp = 0;
-      if (tile != BS_INF) {
-        tiles_looked++;
-        const uint32_t n = (tile << 6) + (uint32_t)lane;
-        const bool valid = n < N;
-        const uint32_t nn = valid ? n : N - 1u;
-        const uint32_t fl = nd.flags[nn];
-        ap = nd.apres[nn];
-        rp = sq.rpres[nn];
-        const uint32_t fw = fitrow[nn >> 5];
+      for (uint32_t c = 0; c < kSeqCacheSlots; ++c) fbits |= ((fws[c] >> (nn & 31u)) & 1u) << c;
+      const bool sched = valid && fl == 0u;
+      bool ok = sched && ((fw >> (nn & 31u)) & 1u);
+      const int64_t f0 = wsub(al[0], rq[0]), f1 = wsub(al[1], rq[1]);
+      if (!fl_all) {                                         // computeResourceSatisfied on this node (core.go:545-563)
+        bool c2 = !(q.ff & 1u), c3h = !(q.ff & 2u);
 #pragma unroll
-        for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-          if (j < L) {
-            al[j] = nd.alloc[(size_t)j * nd.stride + nn];
-            rq[j] = sq.nreq[(size_t)j * nd.stride + nn];
-          }
+        for (int j = 0; j < 4; ++j) {
+          const int64_t left = wsub(al[j], rq[j]);                                                   // getLeftResource :460-463
+          c2 = c2 && left >= q.FR[j];
+          c3h = c3h && left >= q.FM[j];
         }
-        const bool sched = valid && fl == 0u;
-        bool ok = sched && ((fw >> (nn & 31u)) & 1u);
-        const int64_t f0 = wsub(al[0], rq[0]), f1 = wsub(al[1], rq[1]);
-        if (!fl_all) {                                         // computeResourceSatisfied on this node (core.go:545-563)
-          bool c2 = !(q.ff & 1u), c3h = !(q.ff & 2u);
+        ok = ok && (c2 || !c3h);                                                                     // case 2 | case 3
+      }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int64_t left = wsub(al[j], rq[j]);                                                   // getLeftResource :460-463
-            c2 = c2 && left >= q.FR[j];
-            c3h = c3h && left >= q.FM[j];
-          }
-          ok = ok && (c2 || !c3h);                                                                     // case 2 | case 3
-        }
+      for (int j = 0; j < 3; ++j) ok = ok && !(q.preq[j] > 0 && q.preq[j] > wsub(al[j], rq[j]));
+      ok = ok && !(wadd(rq[3], 1) > al[3]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) ok = ok && !(q.preq[j] > 0 && q.preq[j] > wsub(al[j], rq[j]));
-        ok = ok && !(wadd(rq[3], 1) > al[3]);
-#pragma unroll
-        for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
-          if (s < S && ((q.ppres >> s) & 1u) && q.preq[4 + s] > 0) {
-            const int64_t r0 = ((rp >> s) & 1u) ? rq[4 + s] : 0;
-            ok = ok && ((ap >> s) & 1u) && !(q.preq[4 + s] > wsub(al[4 + s], r0));
-          }
-        }
-        const unsigned long long m = __ballot(ok);
-        if (m) mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
-        else if (prm.prune) {                                  // looked at in vain: tighten the tile's bounds to what is really there
-          const long long m0 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f0 : INT64_MIN));
-          const long long m1 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f1 : INT64_MIN));
-          if (lane == 0) { sh_.pmax[0][tile] = m0; sh_.pmax[1][tile] = m1; }
+      for (uint32_t s = 0; s < BS_MAX_SCALARS; ++s) {
+        if (s < S && ((q.ppres >> s) & 1u) && q.preq[4 + s] > 0) {
+          const int64_t r0 = ((rp >> s) & 1u) ? rq[4 + s] : 0;
+          ok = ok && ((ap >> s) & 1u) && !(q.preq[4 + s] > wsub(al[4 + s], r0));
         }
       }
-      if (lane == 0) sh_.pick[pb][w] = mine;
-      lds_barrier();
-      found = seq_row_min_u32(lane < kSeqWaves ? sh_.pick[pb][lane] : BS_INF);
-      pb ^= 1u;
-      if (found != BS_INF && tile == (found >> 6) && (uint32_t)lane == (found & 63u)) {
-        // ---- assume (NodeInfo.AddPod): requested += request, pods lane + 1; the left arrays and the meta word follow
-        const uint32_t at = found;
-        uint32_t nrp = rp;
+      const unsigned long long m = __ballot(ok);
+      if (m) mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
+      else if (prm.prune) {                                  // looked at in vain: tighten the tile's bounds to what is really there
+        const long long m0 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f0 : INT64_MIN));
+        const long long m1 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f1 : INT64_MIN));
+        if (lane == 0) { sh_.pmax[0][tile] = m0; sh_.pmax[1][tile] = m1; }
+      }
+    }
+    const bool owner = mine != BS_INF && (uint32_t)lane == (mine & 63u);
+    if (owner) { sh_.pick[pb][w] = mine; sh_.asm_ap[pb][w] = ap; sh_.asm_rp[pb][w] = rp; sh_.asm_fit[pb][w] = fbits; }
+    if (mine == BS_INF && lane == 0) sh_.pick[pb][w] = BS_INF;
+    lds_barrier();
+    found = seq_row_min_u32(lane < kSeqWaves ? sh_.pick[pb][lane] : BS_INF);
+    if (found != BS_INF) {
+      const uint32_t ww = ((found >> 6) - chunk) >> 6;       // the wave that owns the chosen node's tile
+      out.ap = sh_.asm_ap[pb][ww]; out.rp = sh_.asm_rp[pb][ww]; out.fitbits = sh_.asm_fit[pb][ww];
+    }
+    pb ^= 1u;
+    if (found != BS_INF && owner && mine == found) {
+      // ---- assume (NodeInfo.AddPod): requested += request, pods lane + 1; the left arrays and the meta word follow
+      const uint32_t at = found;
+      uint32_t nrp = rp;
 #pragma unroll
-        for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-          if (j < L) {
-            int64_t nr = rq[j];
-            bool touched = false;
-            if (j < 3) { nr = wadd(rq[j], q.preq[j]); touched = true; }
-            else if (j == 3) { nr = wadd(rq[j], 1); touched = true; }
-            else if ((q.ppres >> (j - 4)) & 1u) {
-              nr = wadd(((rp >> (j - 4)) & 1u) ? rq[j] : 0, q.preq[j]);
-              nrp |= 1u << (j - 4);
-              touched = true;
-            }
-            if (touched) {
-              sq.nreq[(size_t)j * nd.stride + at] = nr;
-              if (j < 4 || ((rp >> (j - 4)) & 1u)) {             // left = scaled allocatable - requested: it moves by what requested moves by
-                const int64_t dlt = wsub(nr, rq[j]);
-                sq.left07[(size_t)j * nd.stride + at] = wsub(sq.left07[(size_t)j * nd.stride + at], dlt);
-                sq.left10[(size_t)j * nd.stride + at] = wsub(sq.left10[(size_t)j * nd.stride + at], dlt);
-              } else {                                           // a scalar key the node's requests did not have: the lane starts to exist
-                sq.left07[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 0.7f), nr);
-                sq.left10[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 1.0f), nr);
-              }
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+        if (j < L) {
+          int64_t nr = rq[j];
+          bool touched = false;
+          if (j < 3) { nr = wadd(rq[j], q.preq[j]); touched = true; }
+          else if (j == 3) { nr = wadd(rq[j], 1); touched = true; }
+          else if ((q.ppres >> (j - 4)) & 1u) {
+            nr = wadd(((rp >> (j - 4)) & 1u) ? rq[j] : 0, q.preq[j]);
+            nrp |= 1u << (j - 4);
+            touched = true;
+          }
+          if (touched) {
+            sq.nreq[(size_t)j * nd.stride + at] = nr;
+            if (j < 4 || ((rp >> (j - 4)) & 1u)) {             // left = scaled allocatable - requested: it moves by what requested moves by
+              const int64_t dlt = wsub(nr, rq[j]);
+              sq.left07[(size_t)j * nd.stride + at] = wsub(sq.left07[(size_t)j * nd.stride + at], dlt);
+              sq.left10[(size_t)j * nd.stride + at] = wsub(sq.left10[(size_t)j * nd.stride + at], dlt);
+            } else {                                           // a scalar key the node's requests did not have: the lane starts to exist
+              sq.left07[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 0.7f), nr);
+              sq.left10[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 1.0f), nr);
             }
           }
         }
-        if (nrp != rp) {
-          sq.rpres[at] = nrp;
-          sq.nmeta[at] = (sq.nmeta[at] & 0xFu) | ((ap & nrp) << 4);
-        }
-        if (prm.prune) {                                       // a negative request frees capacity: the bounds must stay upper bounds
-          const int64_t n0 = wsub(al[0], wadd(rq[0], q.preq[0])), n1 = wsub(al[1], wadd(rq[1], q.preq[1]));
-          if (n0 > sh_.pmax[0][at >> 6]) sh_.pmax[0][at >> 6] = n0;
-          if (n1 > sh_.pmax[1][at >> 6]) sh_.pmax[1][at >> 6] = n1;
-        }
+      }
+      if (nrp != rp) {
+        sq.rpres[at] = nrp;
+        sq.nmeta[at] = (sq.nmeta[at] & 0xFu) | ((ap & nrp) << 4);
+      }
+      if (prm.prune) {                                       // a negative request frees capacity: the bounds must stay upper bounds
+        const int64_t n0 = wsub(al[0], wadd(rq[0], q.preq[0])), n1 = wsub(al[1], wadd(rq[1], q.preq[1]));
+        if (n0 > sh_.pmax[0][at >> 6]) sh_.pmax[0][at >> 6] = n0;
+        if (n1 > sh_.pmax[1][at >> 6]) sh_.pmax[1][at >> 6] = n1;
       }
     }
   }
@@ -847,9 +843,10 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
   // table summaries (see seq_scan_cached): which table sits in which slot, how many of its tiles wait for a refresh
   const uint32_t ntiles = (N + 63u) >> 6;
   const SeqCache ch = seq_cache_view(reinterpret_cast<unsigned char*>(s_keys) + prm.cache_off, ntiles, prm.cache_slots, sh);
-  uint32_t slot_key[kSeqCacheSlots], slot_nd[kSeqCacheSlots], slot_age[kSeqCacheSlots], slot_last[kSeqCacheSlots], age_ctr = 0;
+  uint32_t slot_key[kSeqCacheSlots], slot_age[kSeqCacheSlots], age_ctr = 0;
 #pragma unroll
-  for (uint32_t c = 0; c < kSeqCacheSlots; ++c) { slot_key[c] = BS_INF; slot_nd[c] = 0; slot_age[c] = 0; slot_last[c] = BS_INF; }
+  for (uint32_t c = 0; c < kSeqCacheSlots; ++c) { slot_key[c] = BS_INF; slot_age[c] = 0; }
+  bool stores_pending = true;                                // an assume step (or the prologue) stored node state nobody has waited for yet
   int32_t sop_leader = prm.sop_leader0;                      // sop.maxFinishedPG / maxPGStatus (core.go:58-59), stale between calls
   uint32_t n_released = 0;
   unsigned long long n_pick = 0, n_scan = 0, n_rounds = 0, n_tiles = 0, n_folds = 0, n_builds = 0;
@@ -1043,15 +1040,18 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
 
     // ---- the node scan of this PreFilter call
     BS_SEQ_T(0);
+    bool drained = false;                                    // this pod has already waited for the stores of earlier assume steps
     if (scan) {
       uint32_t first_k;
+      if (stores_pending) { __syncthreads(); stores_pending = false; }
+      drained = true;
       if (prm.cache_slots) {
         const uint32_t key = (tcls << 1) | (pct07 ? 1u : 0u);
         uint32_t sel = BS_INF;
 #pragma unroll
         for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
           if (c < prm.cache_slots && slot_key[c] == key) sel = c;
-        if (sel == BS_INF) {                                 // not cached: the least recently used slot takes the table (every tile summarised)
+        if (sel == BS_INF) {                                 // not cached: the least recently used slot takes the table (summarised from scratch)
           uint32_t best_age = BS_INF;
 #pragma unroll
           for (uint32_t c = 0; c < kSeqCacheSlots; ++c) {
@@ -1060,26 +1060,11 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
               if (a < best_age) { best_age = a; sel = c; }
             }
           }
-          __syncthreads();                                   // assume steps of earlier pods have landed in the left arrays
-          for (uint32_t tile = (uint32_t)wave_id(); tile < ntiles; tile += kSeqWaves) seq_cache_tile<TS>(nd, sq, prm, ch, sel, tcls, pct07, tile);
+          seq_cache_build<TS>(nd, sq, prm, sh_, ch, sel, tcls, pct07);
 #pragma unroll
           for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
-            if (c == sel) { slot_key[c] = key; slot_nd[c] = 0; slot_last[c] = BS_INF; }
+            if (c == sel) slot_key[c] = key;
           n_builds++;
-          lds_barrier();
-        } else {
-          uint32_t ndirty = 0;
-#pragma unroll
-          for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
-            if (c == sel) ndirty = slot_nd[c];
-          if (ndirty) {                                      // tiles an assume step touched since: one wave each
-            __syncthreads();
-            for (uint32_t k = (uint32_t)wave_id(); k < ndirty; k += kSeqWaves) seq_cache_tile<TS>(nd, sq, prm, ch, sel, tcls, pct07, sh_.dirty[sel][k]);
-#pragma unroll
-            for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
-              if (c == sel) { slot_nd[c] = 0; slot_last[c] = BS_INF; }
-            lds_barrier();
-          }
         }
         age_ctr++;
 #pragma unroll
@@ -1104,20 +1089,46 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       q.ppres = pods.pres[i];
 #pragma unroll
       for (uint32_t j = 0; j < BS_MAX_LANES; ++j) q.preq[j] = j < L ? pods.req[(size_t)j * P + i] : 0;
-      at = seq_pick<TS>(nd, sq, prm, sh_, q, n_tiles);
+      SeqAssumed as;
+      at = seq_pick<TS>(nd, sq, prm, sh_, q, slot_key, drained || !stores_pending, as, n_tiles);
+      if (!drained) stores_pending = false;                  // (the search drained them itself)
       n_pick++;
-    }
-    if (at != BS_INF && prm.cache_slots) {                   // the assume step changed one tile of every cached table
-      const uint32_t tile = at >> 6;
+      if (at != BS_INF) {
+        stores_pending = true;
+        // ---- the table summaries follow the assume step: the node's left values moved by the pod's request in every table the
+        // node counts in (it is schedulable — no flag — so it is a row and has no taint error; what is left is the class's fit bit)
+        if (prm.cache_slots) {
+          int64_t dlt[BS_MAX_LANES];
+          bool drop = false;                                 // a bound would break: negative request, or a scalar key the node's requests did not have
 #pragma unroll
-      for (uint32_t c = 0; c < kSeqCacheSlots; ++c) {
-        if (c < prm.cache_slots && slot_key[c] != BS_INF && slot_last[c] != tile) {
-          if (slot_nd[c] < kSeqDirtyMax) {
-            if (t0) sh_.dirty[c][slot_nd[c]] = tile;
-            slot_nd[c]++;
-            slot_last[c] = tile;
-          } else {
-            slot_key[c] = BS_INF;                            // too many stale tiles: the table is summarised afresh at its next use
+          for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+            dlt[j] = 0;
+            if (j < L) {
+              if (j < 3) dlt[j] = (j == BS_LANE_EPH && !gate) ? 0 : q.preq[j];
+              else if (j == 3) dlt[j] = 1;
+              else if ((q.ppres >> (j - 4)) & 1u) {
+                if (!((as.ap >> (j - 4)) & 1u)) dlt[j] = 0;                        // allocatable lacks the key: the lane never exists for this node
+                else if ((as.rp >> (j - 4)) & 1u) dlt[j] = q.preq[j];
+                else drop = true;                                                  // the lane starts to exist at this node
+              }
+              if (dlt[j] < 0) drop = true;
+            }
+          }
+          const uint32_t ta = at >> 6, t = threadIdx.x;
+#pragma unroll
+          for (uint32_t c = 0; c < kSeqCacheSlots; ++c) {
+            if (c < prm.cache_slots && slot_key[c] != BS_INF && ((as.fitbits >> c) & 1u)) {
+              if (drop) slot_key[c] = BS_INF;                // summarised afresh at its next use
+              else if (t < ch.T && t >= ta) {
+#pragma unroll
+                for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+                  if (j < L && dlt[j] != 0) {
+                    unsigned long long* pw = (t == ta ? ch.tt : ch.off) + ((size_t)c * L + j) * ch.T + t;
+                    *pw -= (unsigned long long)dlt[j];
+                  }
+                }
+              }
+            }
           }
         }
       }

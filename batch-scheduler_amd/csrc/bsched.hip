@@ -3079,7 +3079,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   size_t lds = prm.keys_in_lds ? align256((size_t)nG * 8) : 0;
   {
     // table summaries: as many slots as the CU's LDS holds behind the static arrays and the key window (one thread per tile: <= 1024 tiles)
-    const size_t T = cdiv(N, 64), per_slot = T * ((size_t)L * 16 + 4), query = T * ((size_t)L * 8 + 4);
+    const size_t T = cdiv(N, 64), per_slot = T * ((size_t)L * 24 + 8), query = 0;
     const size_t budget = (size_t)160 * 1024 - sizeof(SeqShared) - 2048;
     uint32_t K = 0;
     if (T && T <= (size_t)kSeqBlock && budget > lds + query + per_slot) K = (uint32_t)std::min<size_t>(kSeqCacheSlots, (budget - lds - query) / per_slot);
