@@ -174,6 +174,17 @@ __device__ __forceinline__ uint32_t seq_row_min_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
 }
 
+// A node holds a request for cpu AND memory only if min(free cpu << 20, free memory) >= min(cpu << 20, memory): one number per
+// node (1000 millicores ~ 1 GiB) whose tile maximum rules out the tiles in which the free cpu and the free memory sit on
+// DIFFERENT nodes — the per-lane maxima alone let those through for ever.
+__device__ __forceinline__ long long seq_shl20_sat(long long v) {
+  return v > (1ll << 42) ? INT64_MAX : (v < -(1ll << 42) ? INT64_MIN : v * (1ll << 20));
+}
+__device__ __forceinline__ long long seq_joint(long long cpu, long long mem) {
+  const long long c = seq_shl20_sat(cpu);
+  return c < mem ? c : mem;
+}
+
 // findMaxPG key of one group (core.go:705-717): 0 = not a candidate, ~0 = the uint32 division by zero of :716-717
 __device__ __forceinline__ unsigned long long seq_key(uint32_t g, uint32_t flags, uint32_t mm, uint32_t sc, uint32_t matched) {
   if ((flags & BS_GROUP_SCHEDULED_LATCH) || !(flags & BS_GROUP_HAS_POD)) return 0ull;                 // :706-711
@@ -200,7 +211,9 @@ struct SeqShared {
   uint32_t fk[2][kSeqWaves];
   unsigned long long cmask[kSeqWaves];                   // first fit: candidate tiles of a chunk of 1024
   uint32_t pick[2][kSeqWaves];
-  long long pmax[2][kSeqPruneTiles];                     // per tile: max of allocatable - requested (cpu, memory) over schedulable nodes
+  long long pmax[3][kSeqPruneTiles];                     // per tile, over schedulable nodes: max free cpu, max free memory, max of min(free cpu << 20, free memory)
+  uint32_t hit_w[2];                                     // first fit / scan: lowest wave that has a hit (higher waves stop looking); searches alternate
+                                                         // between the two words, so that a word is re-armed a whole search (a barrier) before its next use
   uint32_t wl_pod[kSeqWaitList], wl_node[kSeqWaitList];  // waiting pods of the CURRENT gang (released in parallel; the chain in global memory is the fallback)
   uint32_t asm_ap[2][kSeqWaves], asm_rp[2][kSeqWaves], asm_fit[2][kSeqWaves];   // first fit: keys / fit bits of each wave's node (see SeqAssumed)
 };
@@ -497,11 +510,13 @@ __device__ __forceinline__ void seq_cache_build(const NodesDev& nd, const SeqDev
 // compareClusterResourceAndRequire through the summaries of slot `slot`.  first_k or BS_INF; wave-uniform, same in every wave.
 template <int TS>
 __device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqCache& ch, uint32_t slot,
-                                                    uint32_t tcls, bool pct07, const Res& R, unsigned long long& rounds_done) {
+                                                    uint32_t tcls, bool pct07, const Res& R, uint32_t& hit_par, unsigned long long& rounds_done) {
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L();
   const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
   const uint32_t T = ch.T, t = threadIdx.x;                     // T <= kSeqBlock: one thread per tile
+  const uint32_t hp = hit_par;
+  hit_par ^= 1u;
   constexpr long long kSafe = 1ll << 62;
   // ---- candidate test, LDS only
   bool cand = t < T;
@@ -529,6 +544,7 @@ __device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const Se
   const uint32_t* fitrow = nd.fit + (size_t)tcls * nd.fit_words;
   uint32_t mine = BS_INF;
   while (cm && mine == BS_INF) {
+    if (uni32(__hip_atomic_load(&sh_.hit_w[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (uint32_t)w) break;     // a covering row in front of this wave's tiles exists
     const uint32_t tile = ((uint32_t)w << 6) + (uint32_t)(__ffsll((long long)cm) - 1);
     cm &= cm - 1ull;
     rounds_done++;
@@ -552,11 +568,14 @@ __device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const Se
       }
     }
     const unsigned long long m = __ballot(ok);
-    if (m) mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
-    else seq_cache_put<TS>(prm, ch, slot, tile, x, row, pres, false);        // looked at in vain: the tile's maxima become exact
+    if (m) {
+      mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
+      if (lane == 0) __hip_atomic_fetch_min(&sh_.hit_w[hp], (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else seq_cache_put<TS>(prm, ch, slot, tile, x, row, pres, false);      // looked at in vain: the tile's maxima become exact
   }
   if (lane == 0) sh_.fk[0][w] = mine;
   lds_barrier();
+  if (threadIdx.x == 0) sh_.hit_w[hp] = BS_INF;               // (re-armed behind the barrier; the NEXT search uses the other word)
   return seq_row_min_u32(lane < kSeqWaves ? sh_.fk[0][lane] : BS_INF);
 }
 
@@ -579,7 +598,8 @@ struct SeqAssumed { uint32_t ap, rp, fitbits; };     // of the chosen node: allo
 
 template <int TS>
 __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqPick& q,
-                                             const uint32_t (&slot_key)[kSeqCacheSlots], bool drained, SeqAssumed& out, unsigned long long& tiles_looked) {
+                                             const uint32_t (&slot_key)[kSeqCacheSlots], bool drained, uint32_t& hit_par, SeqAssumed& out,
+                                             unsigned long long& tiles_looked) {
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L(), S = sh.S();
   const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
@@ -589,13 +609,15 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
   const bool fl_all = q.fl != BS_FL_EVALUATED;                              // Filter passes on every node
   const uint32_t ntiles = (N + 63u) >> 6;
   const uint32_t* fitrow = nd.fit + (size_t)q.pcls * nd.fit_words;
-  uint32_t found = BS_INF, pb = 0;
+  uint32_t found = BS_INF, pb = 0, hp = hit_par;
   if (!drained) __syncthreads();                                            // the assume steps of earlier pods have landed before a tile is read
   for (uint32_t chunk = 0; chunk < ntiles && found == BS_INF; chunk += kSeqBlock) {
     const uint32_t t = chunk + threadIdx.x;
     bool cand = t < ntiles;
-    if (cand && prm.prune)
+    if (cand && prm.prune) {
       cand = !(q.preq[0] > 0 && sh_.pmax[0][t] < q.preq[0]) && !(q.preq[1] > 0 && sh_.pmax[1][t] < q.preq[1]);
+      if (q.preq[0] > 0 && q.preq[1] > 0) cand = cand && !(sh_.pmax[2][t] < seq_joint(q.preq[0], q.preq[1]));
+    }
     unsigned long long cm = __ballot(cand);
     uint32_t mine = BS_INF;
     int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES];
@@ -603,6 +625,7 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { al[j] = 0; rq[j] = 0; }
     uint32_t ap = 0, rp = 0, fbits = 0;
     while (cm && mine == BS_INF) {
+      if (uni32(__hip_atomic_load(&sh_.hit_w[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (uint32_t)w) break;   // a wave in front of this one has a node: first fit is its
       const uint32_t tile = ((chunk + ((uint32_t)w << 6))) + (uint32_t)(__ffsll((long long)cm) - 1);
       cm &= cm - 1ull;
       tiles_looked++;
@@ -651,11 +674,14 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
         }
       }
       const unsigned long long m = __ballot(ok);
-      if (m) mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
-      else if (prm.prune) {                                  // looked at in vain: tighten the tile's bounds to what is really there
+      if (m) {
+        mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
+        if (lane == 0) __hip_atomic_fetch_min(&sh_.hit_w[hp], (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (prm.prune) {                                // looked at in vain: tighten the tile's bounds to what is really there
         const long long m0 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f0 : INT64_MIN));
         const long long m1 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f1 : INT64_MIN));
-        if (lane == 0) { sh_.pmax[0][tile] = m0; sh_.pmax[1][tile] = m1; }
+        const long long m2 = readlane63_i64(wave_max_i64_lane63(sched ? seq_joint(f0, f1) : INT64_MIN));
+        if (lane == 0) { sh_.pmax[0][tile] = m0; sh_.pmax[1][tile] = m1; sh_.pmax[2][tile] = m2; }
       }
     }
     const bool owner = mine != BS_INF && (uint32_t)lane == (mine & 63u);
@@ -668,6 +694,8 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
       out.ap = sh_.asm_ap[pb][ww]; out.rp = sh_.asm_rp[pb][ww]; out.fitbits = sh_.asm_fit[pb][ww];
     }
     pb ^= 1u;
+    if (threadIdx.x == 0) sh_.hit_w[hp] = BS_INF;             // (re-armed behind the barrier; the NEXT search uses the other word)
+    hp ^= 1u;
     if (found != BS_INF && owner && mine == found) {
       // ---- assume (NodeInfo.AddPod): requested += request, pods lane + 1; the left arrays and the meta word follow
       const uint32_t at = found;
@@ -705,16 +733,19 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
         const int64_t n0 = wsub(al[0], wadd(rq[0], q.preq[0])), n1 = wsub(al[1], wadd(rq[1], q.preq[1]));
         if (n0 > sh_.pmax[0][at >> 6]) sh_.pmax[0][at >> 6] = n0;
         if (n1 > sh_.pmax[1][at >> 6]) sh_.pmax[1][at >> 6] = n1;
+        if (seq_joint(n0, n1) > sh_.pmax[2][at >> 6]) sh_.pmax[2][at >> 6] = seq_joint(n0, n1);
       }
     }
   }
+  hit_par = hp;
   return found;
 }
 
 // findMaxPG (core.go:701-739) over the keys.  Wave-uniform result: leader (-1 none), panic.
 __device__ __forceinline__ void seq_find_max(const GroupsDev& gr, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const unsigned long long* lkeys,
-                                             int32_t& leader, bool& panic) {
+                                             int32_t& leader, bool& panic, unsigned long long& top_out) {
   const uint32_t G = gr.g;
+  top_out = 0;
   auto key_at = [&](uint32_t g) -> unsigned long long {
     return prm.keys_in_lds ? lkeys[g] : __hip_atomic_load(&sq.keys[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
@@ -737,6 +768,7 @@ __device__ __forceinline__ void seq_find_max(const GroupsDev& gr, const SeqDev& 
   const uint32_t F1 = (uint32_t)(top >> 32);
   uint32_t cur = 0x7FFFFFFFu - ((uint32_t)top >> 1);
   bool full = top & 1ull;
+  if (!full) top_out = top;                                  // (a fully scheduled winner may hand over: its key is no bound for the others)
   while (full) {                                             // the tie rule :729-731 may hand over (rare: exact walk)
     uint32_t nxt = BS_INF;
     for (uint32_t g = threadIdx.x; g < G; g += kSeqBlock) {
@@ -814,6 +846,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     sq.t_first[g] = ~0ull;
   }
   for (uint32_t i = threadIdx.x; i < P; i += kSeqBlock) sq.pod_node[i] = -1;
+  if (t0) { sh_.hit_w[0] = BS_INF; sh_.hit_w[1] = BS_INF; }
   for (uint32_t base = 0; base < N; base += kSeqBlock) {
     const uint32_t n = base + threadIdx.x;
     const bool valid = n < N;
@@ -837,7 +870,8 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     if (valid) sq.nmeta[n] = ((fl & BS_NODE_SKIP_MASK) ? 0u : 1u) | ((fl & BS_NODE_TAINT_ERR) ? 2u : 0u) | ((ap & rp) << 4);
     if (prm.prune) {
       const long long m0 = readlane63_i64(wave_max_i64_lane63(f0)), m1 = readlane63_i64(wave_max_i64_lane63(f1));
-      if (lane_id() == 0 && n < N) { sh_.pmax[0][n >> 6] = m0; sh_.pmax[1][n >> 6] = m1; }
+      const long long m2 = readlane63_i64(wave_max_i64_lane63(f0 == INT64_MIN ? INT64_MIN : seq_joint(f0, f1)));
+      if (lane_id() == 0 && n < N) { sh_.pmax[0][n >> 6] = m0; sh_.pmax[1][n >> 6] = m1; sh_.pmax[2][n >> 6] = m2; }
     }
   }
   // table summaries (see seq_scan_cached): which table sits in which slot, how many of its tiles wait for a refresh
@@ -846,13 +880,16 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
   uint32_t slot_key[kSeqCacheSlots], slot_age[kSeqCacheSlots], age_ctr = 0;
 #pragma unroll
   for (uint32_t c = 0; c < kSeqCacheSlots; ++c) { slot_key[c] = BS_INF; slot_age[c] = 0; }
+  uint32_t hit_par = 0;                                      // which of the two early-stop words the next search uses
   bool stores_pending = true;                                // an assume step (or the prologue) stored node state nobody has waited for yet
   int32_t sop_leader = prm.sop_leader0;                      // sop.maxFinishedPG / maxPGStatus (core.go:58-59), stale between calls
   uint32_t n_released = 0;
   unsigned long long n_pick = 0, n_scan = 0, n_rounds = 0, n_tiles = 0, n_folds = 0, n_builds = 0;
   // findMaxPG's answer is kept until a key changes (capture, Permit, release)
+  // ... and a change of ONE key only matters when it beats the winner's (fold_top = the winner's key, 0 = repeat the fold on any change)
   bool fold_valid = false, fold_panic = false;
   int32_t fold_leader = -1;
+  unsigned long long fold_top = 0;
   // register-resident group state: the pod's own group (own_of) and the leader's (ldr_of); -1 = nothing cached
   SeqGroup own, ldr;
   seq_group_zero(own, sh);
@@ -931,11 +968,9 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
         }
         if (take_owner) own.occ = refs;
         if (nf != gflags) {
-          if (t0) {
-            const unsigned long long k = seq_key((uint32_t)gi, nf, mm, gsc, gmatched);
-            if (prm.keys_in_lds) s_keys[gi] = k; else sq.keys[gi] = k;
-          }
-          fold_valid = false;                                // the capture is a candidate of this very findMaxPG
+          const unsigned long long k = seq_key((uint32_t)gi, nf, mm, gsc, gmatched);
+          if (t0) { if (prm.keys_in_lds) s_keys[gi] = k; else sq.keys[gi] = k; }
+          if (fold_top == 0ull || k > fold_top) fold_valid = false;   // the capture is a candidate of this very findMaxPG: it only matters if it wins
           gflags = nf;
           own.flags = nf;
           if (prm.keys_in_lds) lds_barrier(); else BS_SEQ_FULL_BARRIER();
@@ -945,7 +980,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       if (occupied) code = BS_PF_ERR_OCCUPIED;                                                       // :113-115
       else {
         if (!fold_valid) {
-          seq_find_max(gr, sq, prm, sh_, s_keys, fold_leader, fold_panic);                           // :118-123
+          seq_find_max(gr, sq, prm, sh_, s_keys, fold_leader, fold_panic, fold_top);                 // :118-123
           fold_valid = true;
           n_folds++;
         }
@@ -1070,7 +1105,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
 #pragma unroll
         for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
           if (c == sel) slot_age[c] = age_ctr;
-        first_k = seq_scan_cached<TS>(nd, sq, prm, sh_, ch, sel, tcls, pct07, R, n_rounds);
+        first_k = seq_scan_cached<TS>(nd, sq, prm, sh_, ch, sel, tcls, pct07, R, hit_par, n_rounds);
       } else {
         first_k = seq_scan<TS>(nd, sq, prm, sh_, tcls, pct07, R, n_rounds);
       }
@@ -1090,7 +1125,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
 #pragma unroll
       for (uint32_t j = 0; j < BS_MAX_LANES; ++j) q.preq[j] = j < L ? pods.req[(size_t)j * P + i] : 0;
       SeqAssumed as;
-      at = seq_pick<TS>(nd, sq, prm, sh_, q, slot_key, drained || !stores_pending, as, n_tiles);
+      at = seq_pick<TS>(nd, sq, prm, sh_, q, slot_key, drained || !stores_pending, hit_par, as, n_tiles);
       if (!drained) stores_pending = false;                  // (the search drained them itself)
       n_pick++;
       if (at != BS_INF) {
@@ -1150,7 +1185,6 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       const bool ready = m1 >= (uint32_t)(mm - gsc);                                                 // :303
       const bool first_time = ready && !(gflags & BS_GROUP_SCHEDULED_LATCH);
       const uint32_t prev = own.head, k = own.nwait + 1u;
-      fold_valid = false;                                    // matched moved: the group's progress changed
       own.matched = m1;
       if (!ready) {
         if (t0) {
@@ -1204,9 +1238,16 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
         wl_ok = true;
         if (first_time) n_released++;
       }
-      if (t0) {
+      {
+        // matched moved: the group's progress changed.  findMaxPG's answer stands unless this key now beats the winner's, or the
+        // winner itself fell back (released: no candidate any more).
         const unsigned long long key = seq_key((uint32_t)gi, own.flags, mm, own.sc, m1);
-        if (prm.keys_in_lds) s_keys[gi] = key; else sq.keys[gi] = key;
+        if (t0) { if (prm.keys_in_lds) s_keys[gi] = key; else sq.keys[gi] = key; }
+        if (fold_valid) {
+          if (fold_top == 0ull || fold_panic) fold_valid = false;
+          else if (gi == fold_leader) { if (key < fold_top || (key & 1ull) || key == ~0ull) fold_valid = false; else fold_top = key; }
+          else if (key > fold_top) fold_valid = false;
+        }
       }
     }
     if (grouped && gi == ldr_of) {                           // the leader's copy follows what this pod did to its group
