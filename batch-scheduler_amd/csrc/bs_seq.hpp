@@ -212,6 +212,7 @@ struct SeqShared {
   unsigned long long cmask[kSeqWaves];                   // first fit: candidate tiles of a chunk of 1024
   uint32_t pick[2][kSeqWaves];
   long long pmax[3][kSeqPruneTiles];                     // per tile, over schedulable nodes: max free cpu, max free memory, max of min(free cpu << 20, free memory)
+  uint32_t tight[kSeqPruneTiles / 32];                   // first fit: the tile's bounds are exact (set by the wave that tightened them, cleared by an assume step in the tile)
   uint32_t hit_w[2];                                     // first fit / scan: lowest wave that has a hit (higher waves stop looking); searches alternate
                                                          // between the two words, so that a word is re-armed a whole search (a barrier) before its next use
   uint32_t wl_pod[kSeqWaitList], wl_node[kSeqWaitList];  // waiting pods of the CURRENT gang (released in parallel; the chain in global memory is the fallback)
@@ -620,10 +621,10 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
     }
     unsigned long long cm = __ballot(cand);
     uint32_t mine = BS_INF;
-    int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES];
+    int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES], l07[BS_MAX_LANES], l10[BS_MAX_LANES];
 #pragma unroll
-    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { al[j] = 0; rq[j] = 0; }
-    uint32_t ap = 0, rp = 0, fbits = 0;
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { al[j] = 0; rq[j] = 0; l07[j] = 0; l10[j] = 0; }
+    uint32_t ap = 0, rp = 0, fbits = 0, meta = 0;
     while (cm && mine == BS_INF) {
       if (uni32(__hip_atomic_load(&sh_.hit_w[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (uint32_t)w) break;   // a wave in front of this one has a node: first fit is its
       const uint32_t tile = ((chunk + ((uint32_t)w << 6))) + (uint32_t)(__ffsll((long long)cm) - 1);
@@ -645,8 +646,11 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
         if (j < L) {
           al[j] = nd.alloc[(size_t)j * nd.stride + nn];
           rq[j] = sq.nreq[(size_t)j * nd.stride + nn];
+          l07[j] = sq.left07[(size_t)j * nd.stride + nn];       // (for the assume step: no second round trip behind the decision)
+          l10[j] = sq.left10[(size_t)j * nd.stride + nn];
         }
       }
+      meta = sq.nmeta[nn];
       fbits = 0;
 #pragma unroll
       for (uint32_t c = 0; c < kSeqCacheSlots; ++c) fbits |= ((fws[c] >> (nn & 31u)) & 1u) << c;
@@ -677,11 +681,11 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
       if (m) {
         mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
         if (lane == 0) __hip_atomic_fetch_min(&sh_.hit_w[hp], (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else if (prm.prune) {                                // looked at in vain: tighten the tile's bounds to what is really there
+      } else if (prm.prune && !((sh_.tight[tile >> 5] >> (tile & 31u)) & 1u)) {   // looked at in vain: tighten the tile's bounds to what is really there
         const long long m0 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f0 : INT64_MIN));
         const long long m1 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f1 : INT64_MIN));
         const long long m2 = readlane63_i64(wave_max_i64_lane63(sched ? seq_joint(f0, f1) : INT64_MIN));
-        if (lane == 0) { sh_.pmax[0][tile] = m0; sh_.pmax[1][tile] = m1; sh_.pmax[2][tile] = m2; }
+        if (lane == 0) { sh_.pmax[0][tile] = m0; sh_.pmax[1][tile] = m1; sh_.pmax[2][tile] = m2; atomicOr(&sh_.tight[tile >> 5], 1u << (tile & 31u)); }
       }
     }
     const bool owner = mine != BS_INF && (uint32_t)lane == (mine & 63u);
@@ -716,8 +720,8 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
             sq.nreq[(size_t)j * nd.stride + at] = nr;
             if (j < 4 || ((rp >> (j - 4)) & 1u)) {             // left = scaled allocatable - requested: it moves by what requested moves by
               const int64_t dlt = wsub(nr, rq[j]);
-              sq.left07[(size_t)j * nd.stride + at] = wsub(sq.left07[(size_t)j * nd.stride + at], dlt);
-              sq.left10[(size_t)j * nd.stride + at] = wsub(sq.left10[(size_t)j * nd.stride + at], dlt);
+              sq.left07[(size_t)j * nd.stride + at] = wsub(l07[j], dlt);
+              sq.left10[(size_t)j * nd.stride + at] = wsub(l10[j], dlt);
             } else {                                           // a scalar key the node's requests did not have: the lane starts to exist
               sq.left07[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 0.7f), nr);
               sq.left10[(size_t)j * nd.stride + at] = wsub(scale_f32(al[j], 1.0f), nr);
@@ -727,13 +731,14 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
       }
       if (nrp != rp) {
         sq.rpres[at] = nrp;
-        sq.nmeta[at] = (sq.nmeta[at] & 0xFu) | ((ap & nrp) << 4);
+        sq.nmeta[at] = (meta & 0xFu) | ((ap & nrp) << 4);
       }
       if (prm.prune) {                                       // a negative request frees capacity: the bounds must stay upper bounds
         const int64_t n0 = wsub(al[0], wadd(rq[0], q.preq[0])), n1 = wsub(al[1], wadd(rq[1], q.preq[1]));
         if (n0 > sh_.pmax[0][at >> 6]) sh_.pmax[0][at >> 6] = n0;
         if (n1 > sh_.pmax[1][at >> 6]) sh_.pmax[1][at >> 6] = n1;
         if (seq_joint(n0, n1) > sh_.pmax[2][at >> 6]) sh_.pmax[2][at >> 6] = seq_joint(n0, n1);
+        atomicAnd(&sh_.tight[at >> 11], ~(1u << ((at >> 6) & 31u)));     // the node that held a maximum may be the one that just filled up
       }
     }
   }
@@ -847,6 +852,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
   }
   for (uint32_t i = threadIdx.x; i < P; i += kSeqBlock) sq.pod_node[i] = -1;
   if (t0) { sh_.hit_w[0] = BS_INF; sh_.hit_w[1] = BS_INF; }
+  if (threadIdx.x < kSeqPruneTiles / 32) sh_.tight[threadIdx.x] = 0;
   for (uint32_t base = 0; base < N; base += kSeqBlock) {
     const uint32_t n = base + threadIdx.x;
     const bool valid = n < N;
@@ -903,11 +909,18 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = (unsigned long long)__builtin_readcyclecounter();
 #endif
 
+  int32_t gi_next = P ? pods.group[0] : BS_POD_NOT_GROUPED;
+  uint32_t pflags_next = P ? pods.flags[0] : 0u;
   for (uint32_t i = 0; i < P; ++i) {
     lds_barrier();                                           // keys / bounds / wait list as the previous pod left them
     BS_SEQ_T(6);
-    const int32_t gi = pods.group[i];
-    const uint32_t pflags = pods.flags[i];
+    const int32_t gi = gi_next;
+    const uint32_t pflags = pflags_next;
+    {                                                        // the next pod's first fields are on their way while this one is decided
+      const uint32_t i1 = i + 1 < P ? i + 1 : i;
+      gi_next = pods.group[i1];
+      pflags_next = pods.flags[i1];
+    }
     const bool grouped = gi >= 0 && (uint32_t)gi < G;
     uint32_t code;
     uint32_t fk = BS_K_NOT_SCANNED;
