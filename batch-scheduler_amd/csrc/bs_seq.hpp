@@ -9,7 +9,7 @@
 //   Permit     core.go:268-309   matched + 1 (:290), quorum (:303), latch (:305)
 //   release    batchscheduler.go:254-344 + PostBind core.go:327: the waiting pods of the gang bind, Status.Scheduled += k
 // Every pod's decision depends on what the pods before it did to the nodes and the group counters, so the pass is ONE
-// persistent workgroup (1024 threads, 16 waves) that walks the queue; the O(nodes) and O(groups) parts of a step are
+// persistent workgroup (512 threads, 8 waves) that walks the queue; the O(nodes) and O(groups) parts of a step are
 // data-parallel inside it:
 //   * findMaxPG is a block maximum over 64-bit keys (progress + 1) << 32 | (inverted index << 1) | "fully scheduled" kept in
 //     LDS; one key changes per Permit / capture / release, and the fold is only repeated after such a change.  The tie rule
@@ -39,9 +39,13 @@
 namespace bs {
 
 #ifndef BS_SEQ_BLOCK
-#define BS_SEQ_BLOCK 1024
+#define BS_SEQ_BLOCK 512
 #endif
-constexpr int kSeqBlock = BS_SEQ_BLOCK;      // threads of the one workgroup (a multiple of 64, at most 1024)
+// Threads of the one workgroup (a multiple of 64, at most 1024).  Measured (tools/seq_bench.py --probe, profiles/r04_*): the pass is
+// instruction-issue bound on ONE CU — every wave repeats the pod's control flow, and rocprofv3 counts ~11 000 wave-instructions per
+// pod at 16 waves — so fewer waves win until the parallel parts (tile checks, table builds) run short of them: 16 waves 98 ms,
+// 8 waves 48 ms, 4 waves 47 ms for cfg3/tail, 8 ahead of 4 on cfg4.
+constexpr int kSeqBlock = BS_SEQ_BLOCK;
 constexpr int kSeqWaves = kSeqBlock / 64;
 constexpr uint32_t kSeqKeysLds = 8192;     // groups whose findMaxPG keys fit the LDS window (64 KB)
 constexpr uint32_t kSeqPruneTiles = 1024;  // 64-node tiles whose first-fit bounds fit the LDS window (65 536 nodes)
@@ -213,7 +217,7 @@ struct SeqShared {
   uint32_t pick[2][kSeqWaves];
   long long pmax[3][kSeqPruneTiles];                     // per tile, over schedulable nodes: max free cpu, max free memory, max of min(free cpu << 20, free memory)
   uint32_t tight[kSeqPruneTiles / 32];                   // first fit: the tile's bounds are exact (set by the wave that tightened them, cleared by an assume step in the tile)
-  uint32_t hit_w[2];                                     // first fit / scan: lowest wave that has a hit (higher waves stop looking); searches alternate
+  uint32_t hit_w[2];                                     // first fit / scan: lowest TILE with a hit so far (nobody looks behind it); searches alternate
                                                          // between the two words, so that a word is re-armed a whole search (a barrier) before its next use
   uint32_t wl_pod[kSeqWaitList], wl_node[kSeqWaitList];  // waiting pods of the CURRENT gang (released in parallel; the chain in global memory is the fallback)
   uint32_t asm_ap[2][kSeqWaves], asm_rp[2][kSeqWaves], asm_fit[2][kSeqWaves];   // first fit: keys / fit bits of each wave's node (see SeqAssumed)
@@ -446,7 +450,7 @@ __device__ __forceinline__ void seq_cache_build(const NodesDev& nd, const SeqDev
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L(), S = sh.S();
   const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
-  const uint32_t T = ch.T, t = threadIdx.x, nw = (T + 63u) >> 6;
+  const uint32_t T = ch.T;
   const int64_t* lf = pct07 ? sq.left07 : sq.left10;
   const uint32_t* fitrow = nd.fit + (size_t)tcls * nd.fit_words;
   for (uint32_t tile = (uint32_t)w; tile < T; tile += kSeqWaves) {
@@ -457,12 +461,17 @@ __device__ __forceinline__ void seq_cache_build(const NodesDev& nd, const SeqDev
     seq_cache_put<TS>(prm, ch, slot, tile, x, row, pres, true);
   }
   lds_barrier();
-  unsigned long long v[BS_MAX_LANES], inc[BS_MAX_LANES];
-  uint32_t mypr = 0;
-  if ((uint32_t)w < nw) {
+  // offsets and keys in front of every tile: chunks of one tile per thread, the running sums carried from chunk to chunk
+  unsigned long long carry[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) carry[j] = 0;
+  uint32_t pcarry = 0;
+  for (uint32_t chunk = 0; chunk < T; chunk += kSeqBlock) {
+    const uint32_t t = chunk + threadIdx.x;
+    unsigned long long v[BS_MAX_LANES], inc[BS_MAX_LANES];
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { v[j] = (j < L && t < T) ? ch.tt[((size_t)slot * L + j) * T + t] : 0ull; inc[j] = v[j]; }
-    mypr = t < T ? ch.pr[(size_t)slot * T + t] : 0u;
+    const uint32_t mypr = t < T ? ch.pr[(size_t)slot * T + t] : 0u;
     seq_wave_scan64_lanes(inc, L);
     if (lane == 63) {
 #pragma unroll
@@ -474,38 +483,40 @@ __device__ __forceinline__ void seq_cache_build(const NodesDev& nd, const SeqDev
     for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2)
       if (s2 < S && __ballot((mypr >> s2) & 1u)) wp |= 1u << s2;
     if (lane == 0) sh_.wpres[0][w] = wp;
-  }
-  lds_barrier();
-  if ((uint32_t)w < nw) {
+    lds_barrier();
     unsigned long long inc4[BS_MAX_LANES / 4];
 #pragma unroll
     for (uint32_t qd = 0; qd < BS_MAX_LANES / 4; ++qd) {
       inc4[qd] = 0;
       if (qd * 4u < L) {
         const uint32_t jr = qd * 4u + ((uint32_t)lane >> 4), wi = (uint32_t)lane & 15u;
-        inc4[qd] = seq_row_scan64((jr < L && wi < nw) ? sh_.tot[0][jr][wi] : 0ull);
+        inc4[qd] = seq_row_scan64((jr < L && wi < (uint32_t)kSeqWaves) ? sh_.tot[0][jr][wi] : 0ull);
       }
     }
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
       if (j < L) {
-        const unsigned long long woff = w ? readlane_u64(inc4[j >> 2], (int)((j & 3u) << 4) + w - 1) : 0ull;
-        if (t < T) ch.off[((size_t)slot * L + j) * T + t] = inc[j] - v[j] + woff;
+        const int rl = (int)((j & 3u) << 4);
+        const unsigned long long woff = w ? readlane_u64(inc4[j >> 2], rl + w - 1) : 0ull;
+        if (t < T) ch.off[((size_t)slot * L + j) * T + t] = carry[j] + inc[j] - v[j] + woff;
+        carry[j] += readlane_u64(inc4[j >> 2], rl + kSeqWaves - 1);
       }
     }
-    const uint32_t pw = (uint32_t)lane < nw ? sh_.wpres[0][lane] : 0u;
-    uint32_t pbt = 0;
+    const uint32_t pw = (uint32_t)lane < (uint32_t)kSeqWaves ? sh_.wpres[0][lane] : 0u;
+    uint32_t pbt = pcarry, pround = 0;
 #pragma unroll
     for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
       if (s2 < S) {
-        const unsigned long long bal = __ballot((uint32_t)lane < nw && ((pw >> s2) & 1u));
+        const unsigned long long bal = __ballot((uint32_t)lane < (uint32_t)kSeqWaves && ((pw >> s2) & 1u));
         const unsigned long long km = __ballot((mypr >> s2) & 1u);
         if ((bal & ((1ull << w) - 1ull)) || (km & ((1ull << lane) - 1ull))) pbt |= 1u << s2;
+        if (bal) pround |= 1u << s2;
       }
     }
     if (t < T) ch.pb[(size_t)slot * T + t] = pbt;
+    pcarry |= pround;
+    lds_barrier();
   }
-  lds_barrier();
 }
 
 // compareClusterResourceAndRequire through the summaries of slot `slot`.  first_k or BS_INF; wave-uniform, same in every wave.
@@ -515,64 +526,67 @@ __device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const Se
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L();
   const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
-  const uint32_t T = ch.T, t = threadIdx.x;                     // T <= kSeqBlock: one thread per tile
+  const uint32_t T = ch.T;                                       // tiles; thread tid tests tiles tid, tid + block, ...
   const uint32_t hp = hit_par;
   hit_par ^= 1u;
   constexpr long long kSafe = 1ll << 62;
-  // ---- candidate test, LDS only
-  bool cand = t < T;
-  if (t < T) {
-    const uint32_t mypr = ch.pr[(size_t)slot * T + t], mypb = ch.pb[(size_t)slot * T + t];
-#pragma unroll
-    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-      if (j < L) {
-        const long long off = (long long)ch.off[((size_t)slot * L + j) * T + t];
-        const long long m = ch.mp[((size_t)slot * L + j) * T + t];
-        const bool open = m == INT64_MAX || off >= kSafe || off <= -kSafe;         // not prunable on this lane
-        const bool reach = m != INT64_MIN && (open || off + m >= R.v[j]);
-        if (j < 4) cand = cand && reach;
-        else if ((R.present >> (j - 4)) & 1u) {
-          if ((mypb >> (j - 4)) & 1u) cand = cand && reach;                         // the key is in the running sum in front of the tile
-          else if (!((mypr >> (j - 4)) & 1u)) cand = cand && R.v[j] == 0 && m != INT64_MIN;   // ... at no row of the tile
-          else cand = cand && m != INT64_MIN;                                       // ... appears inside the tile: look
-        } else cand = cand && m != INT64_MIN;
-      }
-    }
-  }
-  unsigned long long cm = __ballot(cand);
-  // ---- this wave's candidate tiles, in list order, until one holds a covering row
   const int64_t* lf = pct07 ? sq.left07 : sq.left10;
   const uint32_t* fitrow = nd.fit + (size_t)tcls * nd.fit_words;
   uint32_t mine = BS_INF;
-  while (cm && mine == BS_INF) {
-    if (uni32(__hip_atomic_load(&sh_.hit_w[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (uint32_t)w) break;     // a covering row in front of this wave's tiles exists
-    const uint32_t tile = ((uint32_t)w << 6) + (uint32_t)(__ffsll((long long)cm) - 1);
-    cm &= cm - 1ull;
-    rounds_done++;
-    unsigned long long x[BS_MAX_LANES];
-    bool row;
-    uint32_t pres;
-    seq_tile_local<TS>(nd, sq, prm, lf, fitrow, tile, x, row, pres);
-    const uint32_t pbt = ch.pb[(size_t)slot * T + tile];
-    bool ok = row;
+  for (uint32_t chunk = 0; chunk < T && mine == BS_INF; chunk += kSeqBlock) {
+    // ---- candidate test, LDS only
+    const uint32_t t = chunk + threadIdx.x;
+    bool cand = t < T;
+    if (t < T) {
+      const uint32_t mypr = ch.pr[(size_t)slot * T + t], mypb = ch.pb[(size_t)slot * T + t];
 #pragma unroll
-    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-      if (j < L) {
-        const int64_t sum = (int64_t)(x[j] + ch.off[((size_t)slot * L + j) * T + tile]);
-        if (j < 4) ok = ok && sum >= R.v[j];                                                         // core.go:673-685
-        else {
-          const uint32_t s2 = j - 4;
-          const unsigned long long km = __ballot((pres >> s2) & 1u);
-          const bool have = ((pbt >> s2) & 1u) || (km & ((2ull << lane) - 1ull));
-          if ((R.present >> s2) & 1u) ok = ok && (have ? !(R.v[j] > sum) : R.v[j] == 0);            // :686-697
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+        if (j < L) {
+          const long long off = (long long)ch.off[((size_t)slot * L + j) * T + t];
+          const long long m = ch.mp[((size_t)slot * L + j) * T + t];
+          const bool open = m == INT64_MAX || off >= kSafe || off <= -kSafe;         // not prunable on this lane
+          const bool reach = m != INT64_MIN && (open || off + m >= R.v[j]);
+          if (j < 4) cand = cand && reach;
+          else if ((R.present >> (j - 4)) & 1u) {
+            if ((mypb >> (j - 4)) & 1u) cand = cand && reach;                         // the key is in the running sum in front of the tile
+            else if (!((mypr >> (j - 4)) & 1u)) cand = cand && R.v[j] == 0 && m != INT64_MIN;   // ... at no row of the tile
+            else cand = cand && m != INT64_MIN;                                       // ... appears inside the tile: look
+          } else cand = cand && m != INT64_MIN;
         }
       }
     }
-    const unsigned long long m = __ballot(ok);
-    if (m) {
-      mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
-      if (lane == 0) __hip_atomic_fetch_min(&sh_.hit_w[hp], (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else seq_cache_put<TS>(prm, ch, slot, tile, x, row, pres, false);      // looked at in vain: the tile's maxima become exact
+    unsigned long long cm = __ballot(cand);
+    // ---- this wave's candidate tiles of the chunk, in list order, until one holds a covering row
+    while (cm && mine == BS_INF) {
+      const uint32_t tile = chunk + ((uint32_t)w << 6) + (uint32_t)(__ffsll((long long)cm) - 1);
+      cm &= cm - 1ull;
+      if (uni32(__hip_atomic_load(&sh_.hit_w[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < tile) { cm = 0; chunk = T; break; }   // a covering row in front of this tile exists
+      rounds_done++;
+      unsigned long long x[BS_MAX_LANES];
+      bool row;
+      uint32_t pres;
+      seq_tile_local<TS>(nd, sq, prm, lf, fitrow, tile, x, row, pres);
+      const uint32_t pbt = ch.pb[(size_t)slot * T + tile];
+      bool ok = row;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+        if (j < L) {
+          const int64_t sum = (int64_t)(x[j] + ch.off[((size_t)slot * L + j) * T + tile]);
+          if (j < 4) ok = ok && sum >= R.v[j];                                                         // core.go:673-685
+          else {
+            const uint32_t s2 = j - 4;
+            const unsigned long long km = __ballot((pres >> s2) & 1u);
+            const bool have = ((pbt >> s2) & 1u) || (km & ((2ull << lane) - 1ull));
+            if ((R.present >> s2) & 1u) ok = ok && (have ? !(R.v[j] > sum) : R.v[j] == 0);            // :686-697
+          }
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (m) {
+        mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
+        if (lane == 0) __hip_atomic_fetch_min(&sh_.hit_w[hp], tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else seq_cache_put<TS>(prm, ch, slot, tile, x, row, pres, false);      // looked at in vain: the tile's maxima become exact
+    }
   }
   if (lane == 0) sh_.fk[0][w] = mine;
   lds_barrier();
@@ -610,9 +624,16 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
   const bool fl_all = q.fl != BS_FL_EVALUATED;                              // Filter passes on every node
   const uint32_t ntiles = (N + 63u) >> 6;
   const uint32_t* fitrow = nd.fit + (size_t)q.pcls * nd.fit_words;
-  uint32_t found = BS_INF, pb = 0, hp = hit_par;
+  uint32_t found = BS_INF;
+  const uint32_t pb = 0, hp = hit_par;
+  hit_par ^= 1u;
   if (!drained) __syncthreads();                                            // the assume steps of earlier pods have landed before a tile is read
-  for (uint32_t chunk = 0; chunk < ntiles && found == BS_INF; chunk += kSeqBlock) {
+  uint32_t mine = BS_INF;
+  int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES], l07[BS_MAX_LANES], l10[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { al[j] = 0; rq[j] = 0; l07[j] = 0; l10[j] = 0; }
+  uint32_t ap = 0, rp = 0, fbits = 0, meta = 0;
+  for (uint32_t chunk = 0; chunk < ntiles && mine == BS_INF; chunk += kSeqBlock) {
     const uint32_t t = chunk + threadIdx.x;
     bool cand = t < ntiles;
     if (cand && prm.prune) {
@@ -620,15 +641,10 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
       if (q.preq[0] > 0 && q.preq[1] > 0) cand = cand && !(sh_.pmax[2][t] < seq_joint(q.preq[0], q.preq[1]));
     }
     unsigned long long cm = __ballot(cand);
-    uint32_t mine = BS_INF;
-    int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES], l07[BS_MAX_LANES], l10[BS_MAX_LANES];
-#pragma unroll
-    for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { al[j] = 0; rq[j] = 0; l07[j] = 0; l10[j] = 0; }
-    uint32_t ap = 0, rp = 0, fbits = 0, meta = 0;
     while (cm && mine == BS_INF) {
-      if (uni32(__hip_atomic_load(&sh_.hit_w[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (uint32_t)w) break;   // a wave in front of this one has a node: first fit is its
-      const uint32_t tile = ((chunk + ((uint32_t)w << 6))) + (uint32_t)(__ffsll((long long)cm) - 1);
+      const uint32_t tile = chunk + ((uint32_t)w << 6) + (uint32_t)(__ffsll((long long)cm) - 1);
       cm &= cm - 1ull;
+      if (uni32(__hip_atomic_load(&sh_.hit_w[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < tile) { cm = 0; chunk = ntiles; break; }   // a node in front of this tile takes the pod
       tiles_looked++;
       const uint32_t n = (tile << 6) + (uint32_t)lane;
       const bool valid = n < N;
@@ -680,7 +696,7 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
       const unsigned long long m = __ballot(ok);
       if (m) {
         mine = (tile << 6) + (uint32_t)(__ffsll((long long)m) - 1);
-        if (lane == 0) __hip_atomic_fetch_min(&sh_.hit_w[hp], (uint32_t)w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_fetch_min(&sh_.hit_w[hp], tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (prm.prune && !((sh_.tight[tile >> 5] >> (tile & 31u)) & 1u)) {   // looked at in vain: tighten the tile's bounds to what is really there
         const long long m0 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f0 : INT64_MIN));
         const long long m1 = readlane63_i64(wave_max_i64_lane63(sched ? (long long)f1 : INT64_MIN));
@@ -688,18 +704,20 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
         if (lane == 0) { sh_.pmax[0][tile] = m0; sh_.pmax[1][tile] = m1; sh_.pmax[2][tile] = m2; atomicOr(&sh_.tight[tile >> 5], 1u << (tile & 31u)); }
       }
     }
+  }
+  {
     const bool owner = mine != BS_INF && (uint32_t)lane == (mine & 63u);
     if (owner) { sh_.pick[pb][w] = mine; sh_.asm_ap[pb][w] = ap; sh_.asm_rp[pb][w] = rp; sh_.asm_fit[pb][w] = fbits; }
     if (mine == BS_INF && lane == 0) sh_.pick[pb][w] = BS_INF;
     lds_barrier();
-    found = seq_row_min_u32(lane < kSeqWaves ? sh_.pick[pb][lane] : BS_INF);
+    const uint32_t mypick = lane < kSeqWaves ? sh_.pick[pb][lane] : BS_INF;
+    found = seq_row_min_u32(mypick);
     if (found != BS_INF) {
-      const uint32_t ww = ((found >> 6) - chunk) >> 6;       // the wave that owns the chosen node's tile
+      const unsigned long long wm = __ballot(mypick == found);               // the wave that holds the chosen node
+      const uint32_t ww = (uint32_t)(__ffsll((long long)wm) - 1);
       out.ap = sh_.asm_ap[pb][ww]; out.rp = sh_.asm_rp[pb][ww]; out.fitbits = sh_.asm_fit[pb][ww];
     }
-    pb ^= 1u;
     if (threadIdx.x == 0) sh_.hit_w[hp] = BS_INF;             // (re-armed behind the barrier; the NEXT search uses the other word)
-    hp ^= 1u;
     if (found != BS_INF && owner && mine == found) {
       // ---- assume (NodeInfo.AddPod): requested += request, pods lane + 1; the left arrays and the meta word follow
       const uint32_t at = found;
@@ -742,7 +760,6 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
       }
     }
   }
-  hit_par = hp;
   return found;
 }
 
@@ -1162,17 +1179,19 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
               if (dlt[j] < 0) drop = true;
             }
           }
-          const uint32_t ta = at >> 6, t = threadIdx.x;
+          const uint32_t ta = at >> 6;
 #pragma unroll
           for (uint32_t c = 0; c < kSeqCacheSlots; ++c) {
             if (c < prm.cache_slots && slot_key[c] != BS_INF && ((as.fitbits >> c) & 1u)) {
               if (drop) slot_key[c] = BS_INF;                // summarised afresh at its next use
-              else if (t < ch.T && t >= ta) {
+              else {
+                for (uint32_t t = ta + threadIdx.x; t < ch.T; t += kSeqBlock) {       // the node's tile (its total) and every tile behind it (their offsets)
 #pragma unroll
-                for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-                  if (j < L && dlt[j] != 0) {
-                    unsigned long long* pw = (t == ta ? ch.tt : ch.off) + ((size_t)c * L + j) * ch.T + t;
-                    *pw -= (unsigned long long)dlt[j];
+                  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+                    if (j < L && dlt[j] != 0) {
+                      unsigned long long* pw = (t == ta ? ch.tt : ch.off) + ((size_t)c * L + j) * ch.T + t;
+                      *pw -= (unsigned long long)dlt[j];
+                    }
                   }
                 }
               }

@@ -3082,7 +3082,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
     const size_t T = cdiv(N, 64), per_slot = T * ((size_t)L * 24 + 8), query = 0;
     const size_t budget = (size_t)160 * 1024 - sizeof(SeqShared) - 2048;
     uint32_t K = 0;
-    if (T && T <= (size_t)kSeqBlock && budget > lds + query + per_slot) K = (uint32_t)std::min<size_t>(kSeqCacheSlots, (budget - lds - query) / per_slot);
+    if (T && T <= (size_t)kSeqPruneTiles && budget > lds + query + per_slot) K = (uint32_t)std::min<size_t>(kSeqCacheSlots, (budget - lds - query) / per_slot);
     if (const char* e = std::getenv("BS_SEQ_CACHE_SLOTS")) K = std::min<uint32_t>(K, (uint32_t)std::max(0, std::atoi(e)));   // tests: 0 = the round scan, 1 = thrash one slot
     prm.cache_slots = K;
     prm.cache_off = (uint32_t)lds;

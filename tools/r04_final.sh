@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage (on the GPU box, via gpurun): bash tools/r04_final.sh — the round-4 evidence: default bench line, rocprofv3 kernel-trace + PMC passes of
+# the bench workload and of the sequential pass (bs_seq_run), the launch-chain microbenchmark.  Everything lands in gpurun_out/r04/.
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/r04
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. the bench line (self-profiling: its own rocprofv3 passes for the roofline block)
+( cd $R && timeout 900 python bench.py > $OUT/bench_default_N1.json.log 2> $OUT/bench_default_N1.err )
+# 2. kernel trace + PMC of the batched step (as in earlier rounds)
+BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-pmc"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+# 3. the sequential pass: kernel trace, then counters in passes of their own
+SEQ="python $R/tools/seq_bench.py cfg3 tail"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/seq_trace -o trace -- $SEQ > $OUT/seq_trace.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY -d $OUT/seq_pmc_sq -o pmc -- $SEQ > $OUT/seq_pmc_sq.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/seq_pmc_fetch -o pmc -- $SEQ > $OUT/seq_pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/seq_pmc_write -o pmc -- $SEQ > $OUT/seq_pmc_write.log 2>&1
+for a in "cfg3 cold" "cfg3 tail --filter" "cfg2 tail" "cfg4 tail"; do ( cd $R && timeout 280 python tools/seq_bench.py $a 2>&1 | tail -1 ); done > $OUT/seq_bench_all.log
+( cd $R && timeout 280 python tools/seq_bench.py cfg3 tail --probe > $OUT/seq_probe_cfg3_tail.log 2>&1 )
+# 4. launch-chain floor numbers (profiles/r03_launch_chain_ubench.txt was committed empty)
+( cd $R/tools/ubench && hipcc --offload-arch=gfx950 -O3 -o launch_chain launch_chain.hip 2> $OUT/launch_chain_build.log && timeout 120 ./launch_chain > $OUT/launch_chain_ubench.txt 2>&1 )
+find $OUT -name "*stats*.csv" | head
