@@ -40,7 +40,8 @@
 
 namespace bs {
 
-constexpr uint32_t kMaxRuns = 4;            // leader runs a batch may have on this chain (more: general chain)
+constexpr uint32_t kMaxRuns = 16;           // leader runs a batch may have on this chain (= the run_leader array; more: general chain).  Round 3 stopped at 4;
+                                            // the slot spaces ((view, class) scan slots 2 R K, Filter slots (R + 1) K) are checked against their capacities per batch
 constexpr uint32_t kEpochHistCap = 8192;    // fit classes + 1 the counting sort holds in LDS
 
 struct EpochDev {

@@ -281,14 +281,22 @@ def _ladder_scene(bsa, soa, steps, seed=4):
 
 
 # (the stretch before the first capture, with no leader at all, is a run of its own: `steps` leaders = steps + 1 runs)
-@pytest.mark.parametrize("steps,chain", [(2, 2), (3, 2), (4, 0), (9, 0)])
-def test_leader_ladder_and_the_run_limit(steps, chain, bsa, soa, orc):
+@pytest.mark.parametrize("steps,chain", [(2, 2), (3, 2), (4, 2), (9, 2), (14, 2), (15, 2), (16, 0), (24, 0)])
+def test_leader_ladder_and_the_run_limit(steps, chain, bsa, soa, orc, monkeypatch):
+    """round 4: the positional chain takes up to SIXTEEN leader runs (round 3: four — a queue with more leader changes fell back to
+    the eleven-launch general chain); beyond that the general chain still takes the batch.  Every ladder also against the general
+    chain itself (BS_NO_EPOCH=1)."""
     nodes, fit, groups, pods = _ladder_scene(bsa, soa, steps)
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
     assert len(set(exp.pf_leader[exp.pf_leader >= 0].tolist())) >= steps - 1
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
         assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"ladder {steps}")
-        assert ctx.stats(soa.STAGE_ALL)["chain"] == chain           # more than four leader runs: the general chain takes the batch
+        assert ctx.stats(soa.STAGE_ALL)["chain"] == chain           # more than sixteen leader runs: the general chain takes the batch
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS), exp, f"ladder {steps}, latency mode")
+    monkeypatch.setenv("BS_NO_EPOCH", "1")
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"ladder {steps}, general chain")
+        assert ctx.stats(soa.STAGE_ALL)["chain"] == 0
 
 
 def test_every_pod_back_from_permit_and_a_panic_epoch(bsa, soa, orc):
