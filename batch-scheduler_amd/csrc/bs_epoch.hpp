@@ -61,10 +61,13 @@ __global__ void k_epoch_groups(GroupsDev gr, BatchDev b) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= gr.g) return;
   const uint8_t fl = gr.flags[g];
-  const bool denied = fl & BS_GROUP_DENIED;
+  // (BS_BATCH_FILTER_DENY re-runs: a group deny-listed in front of its first eligible pod never gets one; an owner behind the
+  // position never writes OccupiedBy)
+  const uint32_t fdp = b.fd_in ? b.fd_in[g] : BS_INF;
+  const bool denied = (fl & BS_GROUP_DENIED) || fdp < b.first_np_s[g];
   b.first_pod[g] = b.first_pod_s[g];
   b.first_elig[g] = denied ? BS_INF : b.first_np_s[g];
-  b.first_owner[g] = (denied || gr.occupied[g] != 0) ? BS_INF : b.first_owner_s[g];
+  b.first_owner[g] = (denied || gr.occupied[g] != 0 || fdp < b.first_owner_s[g]) ? BS_INF : b.first_owner_s[g];
   b.first_reject[g] = BS_INF;
   b.cap_epoch[g] = (fl & BS_GROUP_HAS_POD) ? 0u : BS_INF;
 }
@@ -218,7 +221,7 @@ __device__ __forceinline__ void epoch_query_thread(const PodsDev& pods, const Gr
     if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                         // core.go:89-92
     else if (pods.flags[i] & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;      // :95-98
     else if (!grouped) code = BS_PF_ERR_PG_NOT_FOUND;                                      // :100-103
-    else if (gr.flags[gi] & BS_GROUP_DENIED) code = BS_PF_ERR_DENIED;                      // :105-110
+    else if ((gr.flags[gi] & BS_GROUP_DENIED) || fd_denied(b, (uint32_t)gi, i)) code = BS_PF_ERR_DENIED;   // :105-110
     else {
       st |= ST_ELIG;
       const uint32_t g = (uint32_t)gi;
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(256) void k_epoch_final(PodsDev pods, GroupsDev gr,
     for (uint32_t k = i; k < U; k += gridDim.x * 256u) b.h_feas[k] = b.fu_feas[k];
   }
   const bool grouped = i < pods.p && gi >= 0 && (uint32_t)gi < gr.g;
-  tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi : 0u, admit, gridDim.x);
+  if (!prm.filter_deny) tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi : 0u, admit, gridDim.x);       // (else: k_fd_apply, bs_fdeny.hpp)
 }
 
 }  // namespace bs

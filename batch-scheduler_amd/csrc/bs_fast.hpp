@@ -415,7 +415,7 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
     if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                         // core.go:89-92
     else if (pfl & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;                // :95-98
     else if (!grouped) code = BS_PF_ERR_PG_NOT_FOUND;                                      // :100-103
-    else if (gfl & BS_GROUP_DENIED) code = BS_PF_ERR_DENIED;                               // :105-110
+    else if ((gfl & BS_GROUP_DENIED) || fd_denied(b, (uint32_t)gi, i)) code = BS_PF_ERR_DENIED;   // :105-110
     else {
       st |= ST_ELIG;
       bool occ_err = false;                                                                // :494-511 in queue order
@@ -741,7 +741,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
     for (uint32_t k = i; k < U; k += nblocks * 256u) b.h_feas[k] = ld_agent(&b.fu_feas[k]);
   }
   BS_STAMP(3, 2);
-  tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi0 : 0u, admit, nblocks);
+  if (!prm.filter_deny) tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi0 : 0u, admit, nblocks);      // (else: k_fd_apply, bs_fdeny.hpp)
   BS_STAMP(3, 7);
 }
 
@@ -897,11 +897,12 @@ __global__ __launch_bounds__(kLeaderBlock) void k_leader_scan(GroupsDev gr, Batc
 
 // BS_BATCH_COMMIT on the fast path: every group has its pod and MinResources already, so what sequential
 // PreFilter calls would leave behind is OccupiedBy (core.go:494-500) and the deny entries (:142,:163).
-__global__ void k_fast_commit(PodsDev pods, BatchDev b, uint8_t* gflags, uint64_t* gocc, uint32_t G) {
+// gate: BS_BATCH_FILTER_DENY's flag word — a run that is not the fixed point (bs_fdeny.hpp) commits nothing
+__global__ void k_fast_commit(PodsDev pods, BatchDev b, uint8_t* gflags, uint64_t* gocc, uint32_t G, const uint32_t* gate) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G) return;
+  if (g >= G || (gate && *gate)) return;
   uint8_t fl = gflags[g];
-  const uint32_t fe = (fl & BS_GROUP_DENIED) ? BS_INF : b.first_np_s[g];
+  const uint32_t fe = ((fl & BS_GROUP_DENIED) || (b.fd_in && b.fd_in[g] < b.first_np_s[g])) ? BS_INF : b.first_np_s[g];
   const uint32_t fr = b.fast_reject[g];
   if (fe != BS_INF && gocc[g] == 0) {
     const uint32_t fo = b.first_owner_s[g];

@@ -154,6 +154,11 @@ struct BatchDev {
   uint32_t* h_admit; uint8_t* h_ready; uint32_t* h_feas; uint64_t* h_rows; int32_t* h_tag; uint32_t hstride;
   int32_t* h_err;           // pinned host word: a final block of the fused launch gave up waiting for the producers (see fast_final_block)
   uint32_t* epoch_group;    // [E+1] group captured at epoch e (e >= 1)
+  // BS_BATCH_FILTER_DENY (bs_fdeny.hpp)
+  unsigned long long* fd_event;   // [G] (~key sequence << 32) | first pod of the group whose Filter failed on a node
+  uint32_t* fd_in;          // [G] fixed-point re-runs: pods of the group behind this queue position are turned away at the deny check (BS_INF: nobody); null = off
+  uint32_t* fd_flag;        // [1] bit 0: a pod somebody else needed was turned away, bit 1: events found != events given
+  int32_t* h_fd;            // pinned [2]: the same two bits for the host
   // outputs
   uint8_t* pf_code;
   uint32_t* pf_first_k;
@@ -185,7 +190,12 @@ struct BatchParams {
   int32_t host_tag;            // BS_BATCH_HOST_RESULTS: completion word the final launch publishes (0 = off)
   uint32_t scan_nsub;          // steady-state scan: waves of a block that share one item's groups (4: latency regime, few tiles; 1: many tiles)
   uint32_t k_host;             // request classes, when the host already knows the count (0: read *kclass — a dependent load in front of the first round trip)
+  uint32_t filter_deny;        // BS_BATCH_FILTER_DENY: the chain's last launch leaves tally and completion word to k_fd_apply
+  uint32_t fd_iter;            // > 0: a fixed-point re-run (fd_in holds the events of the run before)
 };
+
+// BS_BATCH_FILTER_DENY re-runs: the pod stands behind the position at which its group was deny-listed by a failing Filter
+__device__ __forceinline__ bool fd_denied(const BatchDev& b, uint32_t g, uint32_t i) { return b.fd_in && b.fd_in[g] < i; }
 
 // ------------------------------------------------------------------------------------------------
 // snapshot-derived data (at bs_nodes_load / bs_nodes_apply)
@@ -376,7 +386,7 @@ __device__ __forceinline__ void prepass_thread(const PodsDev& pods, const Groups
   if (gi >= 0 && (uint32_t)gi < gr.g) {
     atomicMin(&b.first_pod[gi], i);
     const bool permitted = pods.flags[i] & BS_POD_LAST_PERMITTED;
-    const bool denied0 = gr.flags[gi] & BS_GROUP_DENIED;
+    const bool denied0 = (gr.flags[gi] & BS_GROUP_DENIED) || fd_denied(b, (uint32_t)gi, i);
     if (!permitted && !denied0) {
       st = ST_ELIG;
       atomicMin(&b.first_elig[gi], i);
@@ -695,7 +705,7 @@ __device__ __forceinline__ void query_thread(const PodsDev& pods, const GroupsDe
     if (gi == BS_POD_NOT_GROUPED) code = BS_PF_PASS_NOT_GROUPED;                       // core.go:89-92
     else if (pods.flags[i] & BS_POD_LAST_PERMITTED) code = BS_PF_PASS_LAST_PERMITTED;    // :95-98
     else if (gi < 0 || (uint32_t)gi >= gr.g) code = BS_PF_ERR_PG_NOT_FOUND;              // :100-103
-    else if (gr.flags[gi] & BS_GROUP_DENIED) code = BS_PF_ERR_DENIED;                    // :105-110
+    else if ((gr.flags[gi] & BS_GROUP_DENIED) || fd_denied(b, (uint32_t)gi, i)) code = BS_PF_ERR_DENIED;   // :105-110
     else {
       const uint32_t g = (uint32_t)gi;
       // fillOccupiedObj occupancy rule (core.go:494-511) replayed in queue order
@@ -2198,9 +2208,9 @@ __global__ void k_filter_one(NodesDev nd, BatchDev b, uint32_t node, uint8_t* fn
 // first-pod capture and MinResources default (core.go:486-493), OccupiedBy (:494-500), deny entry
 // (:142,:163).  A pod behind its group's first rejection never reaches fillOccupiedObj.
 __global__ void k_commit(PodsDev pods, BatchDev b, BatchParams prm, uint8_t* gflags, uint32_t* gcls, int64_t* gminres,
-                         uint32_t* gmrpres, uint64_t* gocc, uint32_t G) {
+                         uint32_t* gmrpres, uint64_t* gocc, uint32_t G, const uint32_t* gate) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= G) return;
+  if (g >= G || (gate && *gate)) return;            // (gate: BS_BATCH_FILTER_DENY's flag word — only the fixed point commits, bs_fdeny.hpp)
   const uint32_t fe = b.first_elig[g], fr = b.first_reject[g];
   uint8_t fl = gflags[g];
   if (fe != BS_INF) {

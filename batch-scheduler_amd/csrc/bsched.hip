@@ -21,6 +21,7 @@
 #include "bs_sort.hpp"
 #include "bs_fit.hpp"
 #include "bs_queue.hpp"
+#include "bs_fdeny.hpp"
 #include "bs_seq.hpp"
 
 using namespace bs;
@@ -237,6 +238,13 @@ struct bs_ctx {
   decltype(&ncclAllReduce) rccl_allreduce = nullptr;
   decltype(&ncclCommDestroy) rccl_destroy = nullptr;
   uint32_t launches = 0;             // kernel launches of the last batch
+  // BS_BATCH_FILTER_DENY (bs_fdeny.hpp)
+  DevBuf d_fd_event, d_fd_in, d_fd_flag;
+  bool fd_on = false;                // the run being launched replays Filter's deny entry
+  bool fd_active = false;            // the last batch did, and nobody has looked at its flag words yet (fd_settle)
+  bool fd_in_live = false;           // a fixed-point re-run: the chains honour d_fd_in
+  uint32_t fd_iter = 0, fd_stages = 0, fd_seq_inv = 0;
+  uint64_t n_fd_reruns = 0;          // fixed-point re-runs so far (bs_batch_stats_get)
 };
 
 namespace {
@@ -433,6 +441,10 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.fast_reject = c->d_fast_reject.as<uint32_t>();
   b.epoch_group = c->d_epoch_group.as<uint32_t>();
   b.h_err = c->h_info ? c->h_info + 12 : nullptr;
+  b.fd_event = c->d_fd_event.as<unsigned long long>();
+  b.fd_in = c->fd_in_live ? c->d_fd_in.as<uint32_t>() : nullptr;
+  b.fd_flag = c->d_fd_flag.as<uint32_t>();
+  b.h_fd = c->h_info ? c->h_info + 14 : nullptr;
   uint8_t* ok = c->d_outpack.as<uint8_t>();
   b.pf_code = at(ok, c->off_pf_code);
   b.pf_first_k = reinterpret_cast<uint32_t*>(at(ok, c->off_pf_first_k));
@@ -460,6 +472,8 @@ BatchParams batch_params(const bs_ctx* c) {
   p.filter_slots_cap = 0;
   p.collect_stats = c->collect_stats;
   p.mcap = c->table_mcap;
+  p.filter_deny = c->fd_on ? 1u : 0u;
+  p.fd_iter = c->fd_iter;
   return p;
 }
 
@@ -1926,6 +1940,37 @@ static int setup_host_out(bs_ctx* c, uint32_t stages, bool run_filter, BatchDev&
   return BS_OK;
 }
 
+// BS_BATCH_FILTER_DENY | BS_BATCH_COMMIT, after the stream has been waited for: did the device gate this run's commit kernels off
+// (its flag word is non-zero: the run is not the fixed point, fd_resolve runs the batch again)?
+static bool fd_commit_gated(const bs_ctx* c) {
+  volatile const int32_t* hf = c->h_info + 14;
+  return c->fd_on && (hf[0] || hf[1]);
+}
+
+// BS_BATCH_FILTER_DENY: the two launches behind a chain's last one (bs_fdeny.hpp).  tail: this chain left tally and completion
+// word to k_fd_apply.
+static int launch_filter_deny(bs_ctx* c, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, BatchParams prm, bool tail) {
+  if (!c->P) return BS_OK;
+  prm.seq_inv = ~c->key_seq;
+  c->fd_seq_inv = prm.seq_inv;
+  const dim3 grid(cdiv(c->P, 256)), blk(256);
+  TIMED(c, BS_KERNEL_RESOLVE, {
+    hipLaunchKernelGGL(k_fd_events, grid, blk, 0, c->stream, pd, gr, nd, b, prm);
+    hipLaunchKernelGGL(k_fd_apply, grid, blk, 0, c->stream, pd, gr, nd, b, prm, tail ? 1u : 0u);
+  });
+  c->launches += 2;
+  return BS_OK;
+}
+// ... and in front of a chain's commit kernel: Filter's deny entries join the group's first rejected pod
+static int launch_filter_deny_marks(bs_ctx* c, const BatchDev& b, BatchParams prm, uint32_t* reject) {
+  if (!c->G) return BS_OK;
+  prm.seq_inv = c->fd_seq_inv;
+  hipLaunchKernelGGL(k_fd_reject, dim3(cdiv(c->G, 256)), dim3(256), 0, c->stream, b, prm, reject, c->G);
+  LAUNCHCHK(c, BS_KERNEL_RESOLVE);
+  c->launches++;
+  return BS_OK;
+}
+
 // The steady-state chain (bs_fast.hpp): three launches, nothing reset, no wait.
 static int run_fast(bs_ctx* c, uint32_t stages) {
   int rc;
@@ -2010,15 +2055,17 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
     c->launches = 3;
   }
+  if (prm.filter_deny && (rc = launch_filter_deny(c, pd, gr, nd, b, prm, true))) return rc;
   if (commit) {
+    if (prm.filter_deny && (rc = launch_filter_deny_marks(c, b, prm, b.fast_reject))) return rc;
     if (G) hipLaunchKernelGGL(k_fast_commit, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, pd, b, const_cast<uint8_t*>(gr.flags),
-                              const_cast<uint64_t*>(gr.occupied), G);
+                              const_cast<uint64_t*>(gr.occupied), G, prm.filter_deny ? b.fd_flag : nullptr);
     LAUNCHCHK(c, BS_KERNEL_RESOLVE);
     int32_t last = -1;
     HIPCHK(c, hipMemcpyAsync(&last, b.pf_leader + (P - 1), 4, hipMemcpyDeviceToHost, c->stream));
     if (G) HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), gr.flags, G, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->sop_leader0 = last;            // findMaxPG ignores deny entries and OccupiedBy: the group analysis stays valid
+    if (!fd_commit_gated(c)) c->sop_leader0 = last;   // findMaxPG ignores deny entries and OccupiedBy: the group analysis stays valid
     c->launches++;
   }
   return batch_collective(c, stages, gr, b);
@@ -2036,6 +2083,7 @@ static int commit_readback(bs_ctx* c, const GroupsDev& gr, const BatchDev& b) {
     int32_t last = -1;
     HIPCHK(c, hipMemcpyAsync(&last, b.pf_leader + (P - 1), 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (fd_commit_gated(c)) return BS_OK;            // this run is not the fixed point: nothing was committed, nothing is carried over
     c->sop_leader0 = last;
   }
   if (G) {
@@ -2137,30 +2185,33 @@ static int run_epoch(bs_ctx* c, uint32_t stages, bool* taken) {
   // ---- launch C: final codes, stale leader, Filter code / slot / feasible count per pod, admit counts, quorum
   TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_epoch_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, ep));
   c->launches = 3;
+  if (prm.filter_deny && (rc = launch_filter_deny(c, pd, gr, nd, b, prm, true))) return rc;
   if (stages & BS_BATCH_COMMIT) {
     // persist what the sequential PreFilter calls would have left behind (k_commit): captures and MinResources defaults from
     // the analysis, OccupiedBy, and the deny entries = every group's first rejected pod
     hipLaunchKernelGGL(k_epoch_reject_groups, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, gr, b, prm, ep, P);
+    if (prm.filter_deny && (rc = launch_filter_deny_marks(c, b, prm, b.first_reject))) return rc;
     hipLaunchKernelGGL(k_commit, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, pd, b, prm, const_cast<uint8_t*>(gr.flags), const_cast<uint32_t*>(gr.cls),
-                       const_cast<int64_t*>(gr.minres), const_cast<uint32_t*>(gr.mrpres), const_cast<uint64_t*>(gr.occupied), G);
+                       const_cast<int64_t*>(gr.minres), const_cast<uint32_t*>(gr.mrpres), const_cast<uint64_t*>(gr.occupied), G,
+                       prm.filter_deny ? b.fd_flag : nullptr);
     LAUNCHCHK(c, BS_KERNEL_RESOLVE);
-    c->launches = 5;
+    c->launches += 2;
     if ((rc = commit_readback(c, gr, b))) return rc;
     if ((rc = analyse_groups(c))) return rc;              // (findMaxPG for the committed state; the positional analysis is redone by whoever needs it)
   }
   return batch_collective(c, stages, gr, b);
 }
 
-int bs_batch_run(bs_ctx* c, uint32_t stages) {
-  if (!c) return BS_ERR_INVALID;
-  if (!c->have_nodes || !c->have_fit || !c->have_groups || !c->have_pods) {
-    c->last_error = "bs_batch_run needs nodes, fit, groups and pods loaded";
-    return BS_ERR_STATE;
+static int batch_run_inner(bs_ctx* c, uint32_t stages) {
+  int rc = BS_OK;
+  c->fd_on = (stages & BS_BATCH_FILTER_DENY) != 0;
+  if (c->fd_on) {
+    const size_t g1 = std::max<uint32_t>(c->G, 1);
+    if ((rc = reserve_filled(c, c->d_fd_event, g1 * 8, 0xFF)) || (rc = reserve_filled(c, c->d_fd_in, g1 * 4, 0xFF)) || (rc = reserve_filled(c, c->d_fd_flag, 16, 0))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_fd_flag.p, 0, 4, c->stream));
+    ((volatile int32_t*)c->h_info)[14] = 0;
+    ((volatile int32_t*)c->h_info)[15] = 0;
   }
-  if (!(stages & BS_STAGE_PREFILTER)) { c->last_error = "PREFILTER stage is mandatory"; return BS_ERR_INVALID; }
-  if ((stages & BS_BATCH_COMMIT) && c->nranks > 1) { c->last_error = "COMMIT is single-rank only"; return BS_ERR_STATE; }
-  int rc = use_device(c);
-  if (rc) return rc;
   const uint32_t P = c->P, G = c->G, N = c->N, C = c->C;
   // fit-class indices address fit rows and running-sum tables on the device: out of range = refuse the batch
   if ((G > c->n_uncaptured && c->max_group_cls >= C) || (P && c->max_pod_cls >= C)) {
@@ -2191,6 +2242,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     if (c->d_pair_firstq.p) HIPCHK(c, hipMemsetAsync(c->d_pair_firstq.p, 0xFF, c->d_pair_firstq.cap, c->stream));
     if (c->d_first_reach.p) HIPCHK(c, hipMemsetAsync(c->d_first_reach.p, 0xFF, c->d_first_reach.cap, c->stream));
     if (c->d_gfirstq.p) HIPCHK(c, hipMemsetAsync(c->d_gfirstq.p, 0xFF, c->d_gfirstq.cap, c->stream));
+    if (c->d_fd_event.p) HIPCHK(c, hipMemsetAsync(c->d_fd_event.p, 0xFF, c->d_fd_event.cap, c->stream));
     c->rekey_pending = false;
   }
 
@@ -2405,6 +2457,12 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   } else if (P) {
     HIPCHK(c, hipMemsetAsync(b.fl_code, BS_FL_NOT_RUN, P, c->stream));
   }
+  // ---- BS_BATCH_FILTER_DENY: Filter's deny entries, in front of the tally
+  if (prm.filter_deny && P) {
+    c->launches = launches;
+    if ((rc = launch_filter_deny(c, pd, gr, nd, b, prm, false))) return rc;
+    launches = c->launches;
+  }
   // ---- per-pod feasible counts from the slots, per-group admit counts, quorum (last block), re-arm
   const bool do_tally = stages & BS_STAGE_TALLY;
   if (P ? (run_filter || do_tally) : do_tally) {
@@ -2415,8 +2473,14 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
     launches++;
   }
   if (stages & BS_BATCH_COMMIT) {
+    if (prm.filter_deny && P) {
+      c->launches = launches;
+      if ((rc = launch_filter_deny_marks(c, b, prm, b.first_reject))) return rc;
+      launches = c->launches;
+    }
     if (G) hipLaunchKernelGGL(k_commit, dim3(cdiv(G, 256)), blk, 0, c->stream, pd, b, prm, const_cast<uint8_t*>(gr.flags), const_cast<uint32_t*>(gr.cls),
-                              const_cast<int64_t*>(gr.minres), const_cast<uint32_t*>(gr.mrpres), const_cast<uint64_t*>(gr.occupied), G);
+                              const_cast<int64_t*>(gr.minres), const_cast<uint32_t*>(gr.mrpres), const_cast<uint64_t*>(gr.occupied), G,
+                              (prm.filter_deny && P) ? b.fd_flag : nullptr);
     LAUNCHCHK(c, BS_KERNEL_RESOLVE);
     launches++;
     if ((rc = commit_readback(c, gr, b))) return rc;      // the committed capture may have given every group a pod
@@ -2432,6 +2496,87 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   if (rc) return rc;
   if (commit_dirty) return analyse_groups(c);
   return BS_OK;
+}
+
+// BS_BATCH_FILTER_DENY, the rare half (bs_fdeny.hpp): the run that just completed turned away a pod somebody else needed (bit 0 of
+// its flag words), so its results are not the sequential ones.  Fixed-point iteration: the events a run found are the input of
+// the next (k_fd_next -> fd_in, honoured by every chain's classification and by the positional analysis) until a run finds
+// exactly the events it was given.  A verdict only depends on events in FRONT of the pod, so positions settle in queue order;
+// P + 2 runs is the bound nobody gets near (two runs in practice: one that finds, one that confirms).  A committing batch's
+// commit kernels are gated on the device by the same flag word: only the run that is the fixed point commits.
+static int fd_resolve(bs_ctx* c) {
+  if (!c->fd_active) return BS_OK;
+  c->fd_active = false;
+  volatile int32_t* hf = c->h_info + 14;
+  if (!hf[0]) return BS_OK;
+  int rc = BS_OK;
+  bool settled = false;
+  const uint32_t stages = c->fd_stages;
+  for (uint32_t iter = 1; iter <= c->P + 2 && !settled; ++iter) {
+    BatchDev b = batch_dev(c);
+    b.fd_in = c->d_fd_in.as<uint32_t>();
+    BatchParams prm = batch_params(c);
+    prm.seq_inv = c->fd_seq_inv;
+    hipLaunchKernelGGL(k_fd_next, dim3(cdiv(std::max<uint32_t>(c->G, 1), 256)), dim3(256), 0, c->stream, b, prm, c->G);
+    LAUNCHCHK(c, BS_KERNEL_RESOLVE);
+    c->fd_in_live = true;
+    c->fd_iter = iter;
+    c->epochs_ready = false;                         // the positional analysis depends on fd_in
+    rc = batch_run_inner(c, stages);
+    if (rc == BS_OK) rc = hipStreamSynchronize(c->stream) == hipSuccess ? BS_OK : BS_ERR_HIP;
+    c->n_fd_reruns++;
+    if (rc) break;
+    settled = !hf[1];
+  }
+  c->fd_in_live = false;
+  c->fd_iter = 0;
+  c->fd_on = false;
+  c->epochs_ready = false;                           // (analysed against fd_in: the next batch derives its own)
+  if (rc) return rc;
+  if (!settled) { c->last_error = "BS_BATCH_FILTER_DENY: the fixed-point iteration did not settle"; return BS_ERR_STATE; }
+  return BS_OK;
+}
+
+// Every reader of a batch's results comes through here first: wait for a BS_BATCH_FILTER_DENY batch and look at its flag words.
+static int fd_settle(bs_ctx* c) {
+  if (!c->fd_active) return BS_OK;
+  if (!c->batch_since_pods) { c->fd_active = false; return BS_OK; }      // the queue changed since: those results are history
+  if (c->last_host_out) {
+    int rc = wait_host_tag(c, 0, c->host_tag, reinterpret_cast<const int32_t*>(c->h_hout + c->off_htag));
+    if (rc) return rc;
+  } else {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return fd_resolve(c);
+}
+
+int bs_batch_run(bs_ctx* c, uint32_t stages) {
+  if (!c) return BS_ERR_INVALID;
+  if (!c->have_nodes || !c->have_fit || !c->have_groups || !c->have_pods) {
+    c->last_error = "bs_batch_run needs nodes, fit, groups and pods loaded";
+    return BS_ERR_STATE;
+  }
+  if (!(stages & BS_STAGE_PREFILTER)) { c->last_error = "PREFILTER stage is mandatory"; return BS_ERR_INVALID; }
+  if ((stages & BS_BATCH_COMMIT) && c->nranks > 1) { c->last_error = "COMMIT is single-rank only"; return BS_ERR_STATE; }
+  if (stages & BS_BATCH_FILTER_DENY) {
+    if (!(stages & BS_STAGE_FILTER)) { c->last_error = "BS_BATCH_FILTER_DENY needs BS_STAGE_FILTER"; return BS_ERR_INVALID; }
+    if (c->nranks > 1 || c->reduce_external) { c->last_error = "BS_BATCH_FILTER_DENY is single-rank only"; return BS_ERR_STATE; }
+  }
+  int rc = use_device(c);
+  if (rc) return rc;
+  c->fd_active = false;
+  c->fd_iter = 0;
+  c->fd_in_live = false;
+  rc = batch_run_inner(c, stages);
+  if (rc == BS_OK && (stages & BS_BATCH_FILTER_DENY) && c->P) {
+    c->fd_active = true;
+    c->fd_stages = stages;
+    if (stages & BS_BATCH_COMMIT) {                  // a committing batch has already waited for its results (commit_readback): settle it now
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      rc = fd_resolve(c);
+    }
+  }
+  return rc;
 }
 
 int bs_batch_finish(bs_ctx* c) {
@@ -2471,6 +2616,7 @@ int bs_batch_sync(bs_ctx* c) {
   if (!c) return BS_ERR_INVALID;
   int rc = use_device(c);
   if (rc) return rc;
+  if ((rc = fd_settle(c))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->dstage_busy = false;
   return check_handover(c);
@@ -2501,6 +2647,7 @@ int bs_batch_read(bs_ctx* c, const bs_batch_out* out) {
   if (!c->have_pods || !c->have_groups) return BS_ERR_STATE;
   int rc = use_device(c);
   if (rc) return rc;
+  if ((rc = fd_settle(c))) return rc;
   const uint32_t P = c->P, G = c->G, W = cdiv(c->N, 64);
   const bool filtered = c->last_stages & BS_STAGE_FILTER;
   const bool want_pod = P && (out->pf_code || out->pf_first_k || out->pf_leader || out->fl_code || out->fl_feasible || out->fl_slot);
@@ -2605,6 +2752,7 @@ int bs_batch_map(bs_ctx* c, bs_batch_view* v) {
   if (!c->have_pods || !c->have_groups) return BS_ERR_STATE;
   int rc = use_device(c);
   if (rc) return rc;
+  if ((rc = fd_settle(c))) return rc;                  // (a BS_BATCH_FILTER_DENY batch that had to be re-run may have left the three-launch chains)
   if (!c->last_host_out || !c->batch_since_pods) {
     c->last_error = "bs_batch_map: the last batch did not write host results (BS_BATCH_HOST_RESULTS on a three-launch chain of a single-rank context)";
     return BS_ERR_STATE;
@@ -3336,6 +3484,12 @@ int bs_timing_get(bs_ctx* c, bs_timing* out) {
   rc = timer_collect(c);
   *out = c->timing;
   return rc;
+}
+
+int bs_filter_deny_stats(const bs_ctx* c, uint64_t* reruns) {
+  if (!c || !reruns) return BS_ERR_INVALID;
+  *reruns = c->n_fd_reruns;
+  return BS_OK;
 }
 
 int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {

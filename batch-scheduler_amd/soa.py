@@ -36,6 +36,7 @@ FL_ERR_PG_NOT_FOUND, FL_PANIC_NIL_MAX, FL_NOT_RUN = 16, 32, 64
 FN_PASS_CASE2, FN_PASS_CASE3, FN_ERR_NOT_ENOUGH, FN_ERR_SNAPSHOT = 0, 1, 16, 17
 K_NONE, K_NOT_SCANNED = 0xFFFFFFFF, 0xFFFFFFFE
 STAGE_PREFILTER, STAGE_FILTER, STAGE_TALLY, STAGE_ALL, BATCH_COMMIT, BATCH_HOST_RESULTS = 1, 2, 4, 7, 0x100, 0x200
+BATCH_FILTER_DENY = 0x400        # Filter's deny entry (core.go:183-185) replayed inside the batch
 
 PF_NAMES = {0: "PASS_NOT_GROUPED", 1: "PASS_LAST_PERMITTED", 2: "PASS_NO_MAX", 3: "PASS_FIRST_FITS",
             4: "PASS_IS_MAX", 5: "PASS_RESERVE_FITS", 16: "ERR_PG_NOT_FOUND", 17: "ERR_DENIED",

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BS_ABI_VERSION 4u
+#define BS_ABI_VERSION 5u
 
 enum {
   BS_LANE_CPU = 0,       /* Resource.MilliCPU          */
@@ -282,6 +282,14 @@ typedef struct bs_batch_out {
                                      chain (two launches) and the positional chain (three) of a single-rank context; a no-op (results are copied
                                      as usual) on the general chain.  Costs the batch a few microseconds of PCIe writes, so
                                      throughput runs leave it off. */
+
+#define BS_BATCH_FILTER_DENY 0x400u /* with BS_STAGE_FILTER: the deny entry a FAILING Filter writes (core.go:183-185: computeResourceSatisfied
+                                     errors on some node -> AddToDenyCache(group)) is replayed inside the batch, on the device: every
+                                     later pod of the group that gets to the deny check (core.go:105-110) returns BS_PF_ERR_DENIED and
+                                     is never offered to Filter.  The batch then equals PreFilter(pod) + Filter(pod, node) for every
+                                     node, pod by pod in queue order — the reference's behaviour with the Filter extension point
+                                     enabled.  Without the flag Filter is a what-if (its verdicts are reported, the entry is not
+                                     written).  Single-rank contexts.  See bs_batch_run. */
 
 /* ---- lifecycle ------------------------------------------------------------------- */
 uint32_t    bs_abi_version(void);
@@ -641,6 +649,9 @@ int bs_batch_stats_get(bs_ctx* ctx, bs_batch_stats* out);
 /* bs_pods_apply calls so far, and how many of them (plus later batches) had to re-derive classes and pairs from the
  * resident queue instead of patching them (id space used up, very large deltas, group count changed). */
 int bs_pods_apply_stats(const bs_ctx* ctx, uint64_t* applies, uint64_t* rederives);
+/* BS_BATCH_FILTER_DENY batches that had to be run again so far (see bs_batch_run: a pod turned away by a failing Filter's deny
+ * entry was needed by somebody else; the batch is then settled by fixed-point iteration when its results are first asked for). */
+int bs_filter_deny_stats(const bs_ctx* ctx, uint64_t* reruns);
 
 #ifdef __cplusplus
 }

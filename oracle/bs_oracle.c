@@ -422,6 +422,10 @@ void orc_batch(orc_sop* sop, const bs_pods_soa* pods, uint32_t stages, const bs_
     if (out->fl_code) out->fl_code[i] = fl;
     if (out->fl_feasible) out->fl_feasible[i] = feasible;
     int32_t gi = pods->group[i];
+    /* core.go:183-185: Filter returned an error on some node (computeResourceSatisfied: neither case 2 nor case 3) ->
+     * AddToDenyCache(fullName).  Every later pod of the group that gets to :105 is turned away there. */
+    if ((stages & BS_BATCH_FILTER_DENY) && fl == BS_FL_EVALUATED && feasible < N && gi >= 0 && (uint32_t)gi < G)
+      sop->groups.flags[gi] |= BS_GROUP_DENIED;
     if (gi >= 0 && (uint32_t)gi < G && BS_PF_IS_PASS(code) &&
         (!(stages & BS_STAGE_FILTER) || feasible > 0))
       admit[gi]++;

@@ -98,3 +98,43 @@ def test_batch_plus_deny_pass_equals_sequential_prefilter_and_filter(steady, bsa
         bit += int(((raw.pf_code < 16) & (out.pf_code == soa.PF_ERR_DENIED)).sum() > 0)
     assert checked >= 100 and set_aside <= 40, (checked, set_aside)
     assert bit >= 10, f"the deny entry of a failing Filter has to matter in a good share of the scenes ({bit})"
+
+
+@pytest.mark.parametrize("steady", [False, True], ids=["positional", "steady"])
+def test_oracle_batch_with_filter_deny_equals_the_sequential_replay_everywhere(steady, bsa, soa, orc):
+    """BS_BATCH_FILTER_DENY (round 4): the C oracle's batch writes the entry itself (oracle/bs_oracle.c orc_batch) — it is what the
+    device batch with the flag is compared with (-m gpu, tests/test_gpu_filter_deny.py).  Pinned here on EVERY scene, the
+    lastPermittedPod corner included (no scene is set aside), against the same independent object-level replay."""
+    from test_gpu_parity import _force_class_mode
+    corner = bites = 0
+    for seed in range(7000, 7140):
+        sc = random_objects(seed, n_nodes=6 + seed % 40, n_groups=7, n_pods=60, n_scalars=seed % 3, n_classes=3)
+        if seed % 4 == 1:
+            sc["permitted"] = set()
+        nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"], denied=sc["denied"], permitted=sc["permitted"])
+        if steady:
+            rng = np.random.default_rng(seed)
+            _force_class_mode(groups, rng, sc["n_classes"])
+            groups.matched[:] = rng.integers(1, 4, groups.g)
+            for gi, nm in enumerate(sc["cache"].keys()):
+                pgs = sc["cache"][nm]
+                pgs.matched = int(groups.matched[gi])
+                if pgs.pod is None:
+                    pgs.pod = nv.Pod(nm + "-rep", nm, {"cpu": 1}, cls=int(groups.cls[gi]))
+                pgs.pod.cls = int(groups.cls[gi])
+                lanes = ["cpu", "memory", "ephemeral-storage", "pods"] + sc["names"]
+                mr = {}
+                for j, key in enumerate(lanes):
+                    if j < 4 or (int(groups.min_resources_present[gi]) >> (j - 4)) & 1:
+                        mr[key] = int(groups.min_resources[j, gi])
+                pgs.pod_group.min_resources = mr
+        raw = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL, bitmap=False)
+        out = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL | soa.BATCH_FILTER_DENY, bitmap=False)
+        codes, flc, feas, admit = sequential_with_filter(sc)
+        assert np.array_equal(out.pf_code, codes), f"seed {seed}: pf_code"
+        assert np.array_equal(out.fl_code, flc), f"seed {seed}: fl_code"
+        assert np.array_equal(out.fl_feasible, feas), f"seed {seed}: fl_feasible"
+        assert np.array_equal(out.group_admit, admit), f"seed {seed}: group_admit"
+        corner += int(((raw.pf_code == soa.PF_PASS_LAST_PERMITTED) & (raw.fl_code == soa.FL_EVALUATED) & (raw.fl_feasible < nodes.n)).any())
+        bites += int(not np.array_equal(raw.pf_code, out.pf_code))
+    assert corner >= 20 and bites >= 30, (corner, bites)
