@@ -735,6 +735,8 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
     b.fflags[i] = (uint32_t)fl << 8;
     if (prm.host_tag) { b.h_fl_code[i] = fl; b.h_fl_feasible[i] = prm.run_filter ? feasible : 0u; b.h_fl_slot[i] = slot; }
     if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) admit = true;
+    // BS_BATCH_FILTER_DENY: Filter fails on some node -> the group's first such pod (k_fd_apply takes it from here, bs_fdeny.hpp)
+    if (prm.filter_deny && fl == BS_FL_EVALUATED && feasible < nd.n) atomicMin(&b.fd_event[gi], ((unsigned long long)prm.seq_inv << 32) | i);
   }
   if (prm.host_tag && prm.run_filter) {             // per-row feasible counts of the slots in use
     const uint32_t U = min(2u * K, b.hstride);

@@ -7,9 +7,11 @@
 //
 // The three chains compute the batch as if that entry were never written, and their results already hold the event: a pod with
 // fl_code == EVALUATED and fewer feasible nodes than the list has.  Per group, the FIRST such pod in queue order is real (nothing in
-// front of it turns it away) and what lies behind it is mechanical, so two short launches behind the chain's last one finish the job:
+// front of it turns it away) and what lies behind it is mechanical, so one short launch behind the chain's last one
+// (two behind the general chain) finishes the job:
 //
-//   k_fd_events   per pod: an event -> 64-bit keyed minimum per group (~key sequence << 32 | queue position: never reset)
+//   k_fd_events   per pod: an event -> 64-bit keyed minimum per group (~key sequence << 32 | queue position: never reset);
+//                 general chain only — the final blocks of the steady-state and positional chains do it themselves
 //   k_fd_apply    per pod: behind the group's first event and at the deny check -> ERR_DENIED, Filter not run, no feasible node
 //                 (device results and the pinned host mirrors); then the tally the chain's last launch left to this one
 //                 (tally_tail: admit counts, quorum, completion word).

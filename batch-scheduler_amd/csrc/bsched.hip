@@ -1955,10 +1955,11 @@ static int launch_filter_deny(bs_ctx* c, const PodsDev& pd, const GroupsDev& gr,
   c->fd_seq_inv = prm.seq_inv;
   const dim3 grid(cdiv(c->P, 256)), blk(256);
   TIMED(c, BS_KERNEL_RESOLVE, {
-    hipLaunchKernelGGL(k_fd_events, grid, blk, 0, c->stream, pd, gr, nd, b, prm);
+    // (the final blocks of the steady-state and positional chains have already taken the event minima)
+    if (!tail) hipLaunchKernelGGL(k_fd_events, grid, blk, 0, c->stream, pd, gr, nd, b, prm);
     hipLaunchKernelGGL(k_fd_apply, grid, blk, 0, c->stream, pd, gr, nd, b, prm, tail ? 1u : 0u);
   });
-  c->launches += 2;
+  c->launches += tail ? 1 : 2;
   return BS_OK;
 }
 // ... and in front of a chain's commit kernel: Filter's deny entries join the group's first rejected pod

@@ -215,37 +215,3 @@ class ScheduleOperation:
         return dict(matched=int(self._lib.bsh_group_matched(self._h, g)), status_scheduled=int(self._lib.bsh_group_status_scheduled(self._h, g)),
                     scheduled_latch=bool(f & 1), has_pod=bool(f & 2), has_minres=bool(f & 4), phase=f >> 8,
                     denied=bool(self._lib.bsh_group_denied(self._h, g)))
-
-
-def replay_filter_deny(out, pods, groups, n_nodes: int):
-    """Filter's deny entry (core.go:183-185) applied to the results of a Filter-on batch, on the host, in one pass over the queue.
-
-    bs_batch_run replays what PreFilter writes (first-pod capture, OccupiedBy, its own deny entries); it does not replay the deny
-    entry a FAILING Filter writes for the pod's group — that event is visible in the results (fl_code == BS_FL_EVALUATED and
-    fl_feasible < nodes: Filter returns an error on some node; the framework's fan-out over the nodes is parallel, every
-    interleaving ends with the entry written), and its consequence is mechanical: every later pod of the group that reaches the
-    deny check (core.go:105-110: grouped, group known, not let through on the lastPermittedPod entry) gets ERR_DENIED and is never
-    offered to Filter.  The first event of a group is real (nothing before it denies its pod), everything behind it is moot, so
-    one forward pass is exact — PROVIDED the batch's first pod that reaches findMaxPG is not among the denied ones (then the stale
-    sop.maxPGStatus of the pods between it and the next reaching pod would change too; only possible when a pod let through on the
-    lastPermittedPod entry fails Filter ahead of it).  Returns a copy of `out` with pf_code / fl_code / fl_feasible / group_admit /
-    group_ready rewritten; == the host mirror's sequential PreFilter + Filter calls (tests/test_batch_vs_sequential.py R1F)."""
-    import copy
-    res = copy.copy(out)
-    res.pf_code, res.fl_code, res.fl_feasible = out.pf_code.copy(), out.fl_code.copy(), out.fl_feasible.copy()
-    first_event = {}
-    for i in range(pods.p):
-        g = int(pods.group[i])
-        code = int(res.pf_code[i])
-        reaches_deny_check = 0 <= g < groups.g and code not in (soa.PF_PASS_NOT_GROUPED, soa.PF_PASS_LAST_PERMITTED, soa.PF_ERR_PG_NOT_FOUND)
-        if g in first_event and reaches_deny_check:
-            res.pf_code[i] = soa.PF_ERR_DENIED
-            res.fl_code[i] = soa.FL_NOT_RUN
-            res.fl_feasible[i] = 0
-        elif int(res.fl_code[i]) == soa.FL_EVALUATED and int(res.fl_feasible[i]) < n_nodes and 0 <= g < groups.g:
-            first_event.setdefault(g, i)
-    grouped = (pods.group >= 0) & (pods.group < groups.g)
-    admitted = grouped & (res.pf_code < 16) & (res.fl_feasible > 0)
-    res.group_admit = np.bincount(pods.group[admitted], minlength=groups.g).astype(np.uint32)
-    res.group_ready = ((groups.matched + res.group_admit) >= (groups.min_member - groups.status_scheduled)).astype(np.uint8)
-    return res

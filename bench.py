@@ -623,6 +623,19 @@ def main():
             ms, st = resident_ms(bsa, nodes, fit, groups, all_pods, soa.STAGE_PREFILTER | soa.STAGE_TALLY, 100)
             extras["prefilter_only"] = {"ms_per_step": ms, "evals_per_s": logical / (ms * 1e-3)}
             extras["filter_increment_ms"] = ms_per_step - ms if args.stages == "all" else None
+            if args.stages == "all":
+                # Filter's deny entry (core.go:183-185) replayed inside the batch: the reference's behaviour with the Filter extension point enabled
+                ms_fd, st = resident_ms(bsa, nodes, fit, groups, all_pods, stages | soa.BATCH_FILTER_DENY, 100)
+                with bsa.Context(scalar_lanes=nodes.lanes - 4) as c2:
+                    c2.load_nodes(nodes, fit)
+                    c2.load_groups(groups)
+                    c2.load_pods(all_pods)
+                    fd = c2.batch(stages | soa.BATCH_FILTER_DENY, bitmap=False, rows=False)
+                    reruns = c2.filter_deny_reruns()
+                extras["filter_deny_on_device"] = {"ms_per_step": ms_fd, "extra_ms_over_the_what_if_filter": ms_fd - ms_per_step, "launches": st["launches"], "chain": st["chain"],
+                                                   "pods_turned_away_by_filters_entry": int(((fd.pf_code == soa.PF_ERR_DENIED) & (out.pf_code != soa.PF_ERR_DENIED)).sum()),
+                                                   "groups_ready": int(fd.group_ready.sum()), "fixed_point_reruns": reruns,
+                                                   "note": "BS_BATCH_FILTER_DENY: results == PreFilter + Filter-on-every-node pod by pod (tests/test_gpu_filter_deny.py)"}
             seeds = {}
             for sd in (1, 2, 3):
                 n2, f2, g2, p2, _ = synth.make(args.config, args.scenario, seed=sd)

@@ -151,7 +151,9 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 	if err := g.check("bs_pods_load_flat", C.bs_pods_load_flat(g.ctx, C.uint32_t(P), &grp[0], &req[0], &pres[0], &cls[0], &owner[0], &flags[0])); err != nil {
 		return nil, err
 	}
-	if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, C.BS_STAGE_ALL)); err != nil {
+	// Filter is on in this form: BS_BATCH_FILTER_DENY replays the deny entry a failing Filter writes (core.go:183-185) inside the
+	// batch, on the device — the codes are those of PreFilter + Filter-on-every-node, pod by pod (round 3 did that in a Go pass here)
+	if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, C.BS_STAGE_ALL|C.BS_BATCH_FILTER_DENY)); err != nil {
 		return nil, err
 	}
 	var rowsNeeded C.uint32_t
@@ -255,7 +257,7 @@ func (g *gpuCore) runCycle(d *queueDelta, groupIndex map[string]uint32, permitte
 	}
 	res := &cycleView{}
 	if err := g.check("bs_batch_map", C.bs_batch_map(g.ctx, &res.v)); err != nil {
-		return nil, err // BS_ERR_STATE: the batch took the general chain (more than four leader changes): read it with bs_batch_read
+		return nil, err // BS_ERR_STATE: the batch took the general chain (more than sixteen leader runs): read it with bs_batch_read
 	}
 	return res, nil
 }
@@ -290,25 +292,6 @@ func (g *gpuCore) seqPass(P int, withFilter bool) (*seqResult, error) {
 	}
 	r.nReleased = int(scalars[0])
 	return r, nil
-}
-
-// replayFilterDeny: Filter's deny entry (core.go:183-185) applied to a Filter-on batch in one forward pass (see bsched.h,
-// bs_batch_run): the first evaluated pod of a group whose Filter fails on some node (flCode == BS_FL_EVALUATED, feasible < nodes)
-// deny-lists the group; every later pod of it that reaches the deny check (core.go:105-110) is ERR_DENIED and never filtered.
-// batch-scheduler_amd/plugin.py replay_filter_deny is the tested twin (tests/test_batch_vs_sequential.py R1F).
-func (r *batchResult) replayFilterDeny(group []int32, feasible []uint32, nGroups int) {
-	first := make(map[int32]int)
-	for i := range r.pfCode {
-		g, code := group[i], r.pfCode[i]
-		reaches := g >= 0 && int(g) < nGroups && code != C.BS_PF_PASS_NOT_GROUPED && code != C.BS_PF_PASS_LAST_PERMITTED && code != C.BS_PF_ERR_PG_NOT_FOUND
-		if _, hit := first[g]; hit && reaches {
-			r.pfCode[i], r.flCode[i], feasible[i] = C.BS_PF_ERR_DENIED, C.BS_FL_NOT_RUN, 0
-		} else if r.flCode[i] == C.BS_FL_EVALUATED && int(feasible[i]) < r.n && g >= 0 && int(g) < nGroups {
-			if _, seen := first[g]; !seen {
-				first[g] = i
-			}
-		}
-	}
 }
 
 // All slices live only for the duration of the calls (cgo pointer rules: the library copies and keeps no Go pointer).

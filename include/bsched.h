@@ -430,17 +430,23 @@ int bs_find_max_pg(bs_ctx* ctx, int32_t* leader, uint32_t* finished, uint8_t* pa
  * frozen snapshot and group counters, with the in-batch side effects of core.go:113
  * (first-pod capture, MinResources default, occupancy) and :142,:163 (deny cache) replayed
  * in queue order.  Filter is evaluated for pods that passed, with sop.maxPGStatus as that
- * pod's PreFilter left it.  Filter's own TTL writes are NOT replayed inside the batch (the shipped config does not enable
- * Filter: deploy/scheduler/config/batch_scheduler_config.json):
+ * pod's PreFilter left it.  Filter's own TTL writes:
  *   core.go:188 (lastPermittedPod.Add on a passing node) only ever concerns the SAME pod's next PreFilter — no other pod of the
- *     batch can see it;
- *   core.go:183-185 (AddToDenyCache when Filter fails on a node) would turn every later pod of the group that reaches the deny
- *     check into ERR_DENIED.  The event is visible in the results (fl_code == BS_FL_EVALUATED && fl_feasible < nodes), and the
- *     batch is exactly the sequential PreFilter + Filter run up to and including, per group, the first such pod; what follows
- *     is a mechanical forward pass over the queue on the host (batch-scheduler_amd/plugin.py replay_filter_deny, the Go shim's
- *     replayFilterDeny; tests/test_batch_vs_sequential.py R1F: batch + pass == the host mirror's PreFilter and Filter-on-every-
- *     node calls in queue order; tests/test_filter_deny_pass.py: == an independent object-level sequential replay on 200+ random scenes), exact unless a pod let through on the lastPermittedPod entry fails Filter ahead of the batch's
- *     first findMaxPG call.
+ *     batch can see it; not replayed.
+ *   core.go:183-185 (AddToDenyCache when Filter fails on a node) turns every later pod of the group that reaches the deny
+ *     check into ERR_DENIED.  Without BS_BATCH_FILTER_DENY Filter is a what-if: the event is visible in the results (fl_code ==
+ *     BS_FL_EVALUATED && fl_feasible < nodes), the entry is not written, and the batch is the sequential PreFilter + Filter run up
+ *     to and including, per group, the first such pod (the shipped config does not enable Filter:
+ *     deploy/scheduler/config/batch_scheduler_config.json).  WITH the flag the entry is replayed inside the batch, on the device,
+ *     on every chain (csrc/bs_fdeny.hpp): the results equal PreFilter(pod) followed by Filter(pod, node) on every node, pod by pod
+ *     in queue order — every output, the stale leader included (tests/test_gpu_filter_deny.py against the oracle's batch with the
+ *     flag; tests/test_batch_vs_sequential.py R1F against the host mirror's calls; tests/test_filter_deny_pass.py pins the oracle
+ *     on an independent object-level replay).  One short launch behind the chain does it (two on the general chain); when a pod it
+ *     turns away was needed by somebody else (it would have brought a changed findMaxPG result into sop.maxFinishedPG, or been its
+ *     group's first-pod capture — only behind a pod let through on its lastPermittedPod entry that failed Filter), the batch is
+ *     settled by fixed-point re-runs the first time its results are asked for (bs_batch_sync / read / map; at once for a
+ *     committing batch) — bs_filter_deny_stats counts them; after a re-run that left the three-launch chains bs_batch_map
+ *     answers BS_ERR_STATE (read it with bs_batch_read).  BS_BATCH_COMMIT persists the entries with PreFilter's own.
  * Asynchronous on the context stream; bs_batch_sync waits. */
 int bs_batch_run(bs_ctx* ctx, uint32_t stages);
 int bs_batch_sync(bs_ctx* ctx);

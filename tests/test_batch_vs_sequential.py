@@ -15,8 +15,8 @@ pods behind it) and PERMITS it (matched counters move, findMaxPG may elect anoth
                  induction over the queue the deny entries follow) — hence admit_seq <= admit_batch per group
                  and every gang the sequential run releases is ready in the batch.  On a tight cluster the
                  inclusion is strict: the batch over-admits, it is a pre-screen, not a reservation.
-  R1F equality, Filter on   batch (PREFILTER|FILTER|TALLY) + the host-side pass that applies Filter's deny entry
-                 (plugin.replay_filter_deny: core.go:183-185 is not replayed inside the batch) == the host mirror's PreFilter
+  R1F equality, Filter on   batch (PREFILTER|FILTER|TALLY|BS_BATCH_FILTER_DENY: Filter's deny entry, core.go:183-185, replayed
+                 inside the batch on the device — round 3 needed a host-side pass for it) == the host mirror's PreFilter
                  followed by Filter on EVERY node, pod by pod, with the real TTL deny cache.
   R3  the README race (README.md:78-188): frozen, both gangs of 5 fit the node on their own -> the batch
       reports both ready; sequentially the second gang is denied.  The canonical over-admission.
@@ -177,7 +177,7 @@ def test_readme_race_is_the_canonical_over_admission(bsa, soa, orc):
 def test_filter_on_batch_plus_deny_pass_equals_sequential_prefilter_and_filter(n_nodes, seed, big, bsa, soa, orc):
     """R1F.  Sequential: PreFilter(pod) and, if it passes, Filter(pod, node) for every node (a failing node deny-lists the group,
     core.go:183-185; the first pod of a gang whose Filter fails somewhere turns every later pod of the gang into ERR_DENIED).
-    Batch: one bs_batch_run with Filter on, then plugin.replay_filter_deny on the host.  Code by code, Filter code by Filter code,
+    Batch: ONE bs_batch_run with Filter on and BS_BATCH_FILTER_DENY — plain equality.  Code by code, Filter code by Filter code,
     feasible count by feasible count, admit / ready."""
     # big: pods of 4.5 - 6.5 cores on nodes with 5 - 8 cores left: pod + a leader member does not fit many nodes that could still
     # take the leader member alone -> Filter fails there (neither case 2 nor case 3 of core.go:551-561)
@@ -207,8 +207,8 @@ def test_filter_on_batch_plus_deny_pass_equals_sequential_prefilter_and_filter(n
         ctx.load_nodes(nodes, fit)
         ctx.load_groups(groups0)
         ctx.load_pods(pods)
-        raw = ctx.batch(soa.STAGE_ALL, bitmap=False)
-    out = bsa.plugin.replay_filter_deny(raw, pods, groups0, nodes.n)
+        raw = ctx.batch(soa.STAGE_ALL, bitmap=False)                                   # Filter as a what-if: the entry is not written
+        out = ctx.batch(soa.STAGE_ALL | soa.BATCH_FILTER_DENY, bitmap=False)
     seq_pf, seq_fl, seq_feas = np.array(seq_pf, np.uint8), np.array(seq_fl, np.uint8), np.array(seq_feas, np.uint32)
     assert np.array_equal(out.pf_code, seq_pf)
     assert np.array_equal(out.fl_code, seq_fl)
@@ -218,7 +218,7 @@ def test_filter_on_batch_plus_deny_pass_equals_sequential_prefilter_and_filter(n
     denied_by_filter = int(((raw.pf_code < 16) & (out.pf_code == soa.PF_ERR_DENIED)).sum())
     if big:
         assert denied_by_filter > 0, "big pods: some gang's Filter fails on a node and the deny entry bites"
-    # the untouched batch is exact up to and including each group's first failing pod
+    # the batch WITHOUT the flag is exact up to and including each group's first failing pod
     for g in range(groups0.g):
         idx = np.nonzero(pods.group == g)[0]
         ev = [i for i in idx if raw.fl_code[i] == soa.FL_EVALUATED and raw.fl_feasible[i] < nodes.n]

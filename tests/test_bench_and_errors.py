@@ -54,6 +54,8 @@ def test_bench_json_contract():
     assert sd["gangs_released"] == c["sequential_pass"]["gangs_released"] and sd["pods_released"] == c["sequential_pass"]["pods_released"]
     assert d["gang_admit_latency_ms_p50"] == sd["gang_admit_latency_ms_p50"] > 0 and d["batched_cycle_latency_ms_p50"] == hc["gang_admit_latency_ms_p50"]
     assert set(d["scenarios"]) >= {"cold", "warm", "busy", "all_distinct_requests", "prefilter_only", "ms_per_step_by_seed"}
+    fd = d["scenarios"]["filter_deny_on_device"]                # Filter's deny entry inside the batch: one more launch, a few microseconds
+    assert fd["ms_per_step"] > 0 and fd["launches"] == d["config"]["launches_per_step"] + 1 and fd["pods_turned_away_by_filters_entry"] > 0
     assert d["value"] > 10e6, "north_star target: >= 10M pod x node fit evaluations/s"
 
 

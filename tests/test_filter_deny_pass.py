@@ -1,12 +1,12 @@
-"""Filter's deny entry (core.go:183-185) as a host-side forward pass — CPU pin.
+"""Filter's deny entry (core.go:183-185) inside the batch — CPU pin of the ORACLE.
 
-bs_batch_run does not replay the deny entry a FAILING Filter writes (include/bsched.h, bs_batch_run); plugin.replay_filter_deny
-applies it to the batch's results in one pass over the queue.  Here, without a GPU: the C oracle's batch (bit-identical to the
-device batch by the -m gpu parity tests) + that pass has to equal an independent, object-level SEQUENTIAL replay of the reference
-(oracle/naive_ref.py: PreFilter, then Filter on every node, a failing node deny-lists the group) on random scenes — steady and
-positional, with denied groups, OccupiedBy, permitted pods, nil nodes.  The documented exception (a pod let through on the
-lastPermittedPod entry whose Filter fails: its deny entry can precede the group's first-pod capture / the batch's first
-findMaxPG call) is detected and those scenes are set aside; they must stay a small minority."""
+BS_BATCH_FILTER_DENY makes bs_batch_run replay the deny entry a FAILING Filter writes (include/bsched.h; on the device:
+csrc/bs_fdeny.hpp, compared with the C oracle's batch with the same flag by tests/test_gpu_filter_deny.py).  Here, without a GPU,
+that oracle batch has to equal an independent, object-level SEQUENTIAL replay of the reference (oracle/naive_ref.py: PreFilter, then
+Filter on every node, a failing node deny-lists the group) on random scenes — steady and positional, with denied groups,
+OccupiedBy, permitted pods, nil nodes — EVERY scene, the pods let through on lastPermittedPod entries whose Filter fails in front of
+their group's first-pod capture / the batch's first findMaxPG call included (round 3 set those aside: its host-side forward pass,
+plugin.replay_filter_deny, could not do them; the pass is gone)."""
 import copy
 import importlib
 import os
@@ -58,53 +58,8 @@ def sequential_with_filter(sc):
 
 
 @pytest.mark.parametrize("steady", [False, True], ids=["positional", "steady"])
-def test_batch_plus_deny_pass_equals_sequential_prefilter_and_filter(steady, bsa, soa, orc):
-    from test_gpu_parity import _force_class_mode                 # (pure host helper: makes every group captured + MinResources set)
-    checked = bit = set_aside = 0
-    for seed in range(7000, 7140):
-        sc = random_objects(seed, n_nodes=6 + seed % 40, n_groups=7, n_pods=60, n_scalars=seed % 3, n_classes=3)
-        if seed % 4:
-            sc["permitted"] = set()                                  # three scenes in four without lastPermittedPod entries (see the exception)
-        nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"], denied=sc["denied"], permitted=sc["permitted"])
-        if steady:
-            rng = np.random.default_rng(seed)
-            _force_class_mode(groups, rng, sc["n_classes"])
-            groups.matched[:] = rng.integers(1, 4, groups.g)
-            # mirror the forced state into the objects the sequential replay runs on
-            for gi, nm in enumerate(sc["cache"].keys()):
-                pgs = sc["cache"][nm]
-                pgs.matched = int(groups.matched[gi])
-                if pgs.pod is None:
-                    pgs.pod = nv.Pod(nm + "-rep", nm, {"cpu": 1}, cls=int(groups.cls[gi]))
-                pgs.pod.cls = int(groups.cls[gi])
-                lanes = ["cpu", "memory", "ephemeral-storage", "pods"] + sc["names"]
-                mr = {}
-                for j, key in enumerate(lanes):
-                    if j < 4 or (int(groups.min_resources_present[gi]) >> (j - 4)) & 1:
-                        mr[key] = int(groups.min_resources[j, gi])
-                pgs.pod_group.min_resources = mr
-        raw = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL, bitmap=False)
-        lp_fails = (raw.pf_code == soa.PF_PASS_LAST_PERMITTED) & (raw.fl_code == soa.FL_EVALUATED) & (raw.fl_feasible < nodes.n)
-        if lp_fails.any():
-            set_aside += 1                                           # the documented exception
-            continue
-        out = bsa.plugin.replay_filter_deny(raw, pods, groups, nodes.n)
-        codes, flc, feas, admit = sequential_with_filter(sc)
-        assert np.array_equal(out.pf_code, codes), f"seed {seed}: pf_code"
-        assert np.array_equal(out.fl_code, flc), f"seed {seed}: fl_code"
-        assert np.array_equal(out.fl_feasible, feas), f"seed {seed}: fl_feasible"
-        assert np.array_equal(out.group_admit, admit), f"seed {seed}: group_admit"
-        checked += 1
-        bit += int(((raw.pf_code < 16) & (out.pf_code == soa.PF_ERR_DENIED)).sum() > 0)
-    assert checked >= 100 and set_aside <= 40, (checked, set_aside)
-    assert bit >= 10, f"the deny entry of a failing Filter has to matter in a good share of the scenes ({bit})"
-
-
-@pytest.mark.parametrize("steady", [False, True], ids=["positional", "steady"])
 def test_oracle_batch_with_filter_deny_equals_the_sequential_replay_everywhere(steady, bsa, soa, orc):
-    """BS_BATCH_FILTER_DENY (round 4): the C oracle's batch writes the entry itself (oracle/bs_oracle.c orc_batch) — it is what the
-    device batch with the flag is compared with (-m gpu, tests/test_gpu_filter_deny.py).  Pinned here on EVERY scene, the
-    lastPermittedPod corner included (no scene is set aside), against the same independent object-level replay."""
+    """the C oracle's batch writes the entry itself (oracle/bs_oracle.c orc_batch); no scene is set aside"""
     from test_gpu_parity import _force_class_mode
     corner = bites = 0
     for seed in range(7000, 7140):
