@@ -23,7 +23,7 @@ KERNEL_PREPASS, KERNEL_LEADER, KERNEL_QUERY, KERNEL_TABLES, KERNEL_SCAN, KERNEL_
 ABI_SYMBOLS = [
     "bs_abi_version", "bs_strerror", "bs_last_error", "bs_create", "bs_destroy",
     "bs_nodes_load", "bs_fit_load", "bs_fit_build", "bs_fit_read", "bs_groups_load", "bs_groups_read", "bs_groups_apply", "bs_pods_map", "bs_pods_load",
-    "bs_pods_apply", "bs_pods_count", "bs_pods_read", "bs_pods_apply_stats", "bs_filter_deny_stats",
+    "bs_pods_apply", "bs_pods_count", "bs_pods_read", "bs_pods_apply_stats", "bs_filter_deny_stats", "bs_speculation_stats",
     "bs_nodes_apply", "bs_nodes_count", "bs_nodes_assume",
     "bs_cluster_fits", "bs_node_left", "bs_scan_prefix", "bs_cluster_total", "bs_filter_one", "bs_find_max_pg",
     "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_batch_map", "bs_filter_rows_count", "bs_queue_order_load", "bs_queue_sort",
@@ -118,6 +118,7 @@ def load_library(path: str | None = None):
     L.bs_pods_count.argtypes = [vp, P(u32)]
     L.bs_pods_apply_stats.argtypes = [vp, P(C.c_uint64), P(C.c_uint64)]
     L.bs_filter_deny_stats.argtypes = [vp, P(C.c_uint64)]
+    L.bs_speculation_stats.argtypes = [vp, P(C.c_uint64), P(C.c_uint64)]
     L.bs_pods_read.argtypes = [vp, P(soa.PodsOutStruct)]
     L.bs_queue_order_load.argtypes = [vp, u32, P(u32)]
     L.bs_queue_sort.argtypes = [vp, u32, P(i32), P(i32), P(C.c_int64), P(u32)]
@@ -325,6 +326,12 @@ class Context:
         a, r = C.c_uint64(0), C.c_uint64(0)
         self._chk(self._lib.bs_pods_apply_stats(self._h, C.byref(a), C.byref(r)), "bs_pods_apply_stats")
         return int(a.value), int(r.value)
+
+    def speculation_stats(self) -> tuple[int, int]:
+        """(batches launched on a guessed findMaxPG answer, wrong guesses that were re-run) — bs_speculation_stats"""
+        a, m = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._lib.bs_speculation_stats(self._h, C.byref(a), C.byref(m)), "bs_speculation_stats")
+        return int(a.value), int(m.value)
 
     def filter_deny_reruns(self) -> int:
         """BS_BATCH_FILTER_DENY batches that had to be run again so far (fixed-point iteration, bs_filter_deny_stats)"""

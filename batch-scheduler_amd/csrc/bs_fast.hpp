@@ -535,9 +535,13 @@ __device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b
 __device__ __forceinline__ void final_tail(const BatchDev& b, const BatchParams& prm, uint32_t nblocks) {
   __shared__ uint32_t s_last;
   if (!prm.host_tag) return;
-  // every block drains its writes (host mirrors included) before it takes its ticket; the last one sends the completion
-  // word behind them with a system-scope store — the host polls it (bs_batch_read / bs_batch_map) instead of waiting on the stream
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Every block makes its writes (host mirrors included) VISIBLE AT SYSTEM SCOPE before it takes its ticket; the last one sends the
+  // completion word behind them with a system-scope release store — the host polls it (bs_batch_read / bs_batch_map) instead of
+  // waiting on the stream.  A bare s_waitcnt vmcnt(0) is not enough here (round 3 had that): the mirrors are posted writes that
+  // leave through eight XCDs' separate paths, the counter only says they left the CU, and the completion word of the last block
+  // could overtake another XCD's mirrors — a host that copied the results out at once (bs_batch_read) saw the previous cycle's
+  // values in a few of them, one run in three (tests/test_gpu_speculate.py::test_latency_mode_results_are_complete_when_the_word_arrives).  The release fence costs the latency mode about a microsecond.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __syncthreads();
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1 ? 1u : 0u;
   __syncthreads();

@@ -113,6 +113,16 @@ struct bs_ctx {
   std::vector<uint32_t> h_gmatched, h_gcls;
   std::vector<uint8_t> h_gflags;
   int32_t steady_table = -1;        // the one table every reservation query uses when no capture can occur, -1 unknown
+  // Speculation (bs_batch_run): a group patch re-runs findMaxPG on the device, and the host would have to wait for its answer (the
+  // table id) before it can launch the chain — ~4 us of idle GPU and ~10 us of spinning per cycle.  In a steady state the answer is
+  // nearly always the one of the cycle before, so the chain is launched on THAT and checked when the results are first asked for
+  // (batch_settle): a wrong guess costs one re-run, a right one nothing.
+  int32_t steady_prev = -1;          // steady_table of the last resolved analysis
+  bool spec_active = false;          // the last batch ran on a guessed table that nobody has checked yet
+  int32_t spec_table = -1;
+  uint32_t spec_stages = 0;
+  uint32_t no_spec = 0;              // BS_NO_SPECULATE=1
+  uint64_t n_spec = 0, n_spec_miss = 0;
   uint64_t early_filter_min = 200000000ull;   // pod x node pairs from which Filter overlaps the scan
   hipStream_t stream3 = nullptr;    // early Filter: runs beside the node scan when no capture can occur
   hipEvent_t ev_query = nullptr, ev_filter = nullptr;
@@ -825,6 +835,7 @@ int resolve_groups(bs_ctx* c) {
   if (rc) return rc;
   c->info_pending = false;
   c->steady_table = (c->n_uncaptured == 0 && c->h_info[2] >= 0) ? c->h_info[2] : -1;
+  c->steady_prev = c->steady_table;
   return BS_OK;
 }
 
@@ -1097,6 +1108,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_EPOCH")) c->no_epoch = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
+  if (const char* e = std::getenv("BS_NO_SPECULATE")) c->no_spec = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_SLOT_BITS")) { const int hb = std::atoi(e); c->slot_keep = hb >= 32 ? 0xFFFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) { c->early_filter_min = std::strtoull(e, nullptr, 10); c->early_forced = 1; }
@@ -2219,7 +2231,20 @@ static int batch_run_inner(bs_ctx* c, uint32_t stages) {
     c->last_error = "fit class index out of range (groups.cls / pods.cls vs the loaded fit classes)";
     return BS_ERR_INVALID;
   }
-  if ((rc = resolve_groups(c))) return rc;
+  // findMaxPG's answer for the patched groups: taken if it has landed; guessed (last cycle's table) if it has not and the state is a
+  // steady one — the guess is checked when the results are first asked for (batch_settle)
+  c->spec_active = false;
+  if (c->info_pending && ((volatile int32_t*)c->h_info)[3] != c->info_tag && !c->no_spec && c->steady_prev >= 0 && c->n_uncaptured == 0 &&
+      c->n_nominres == 0 && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing == 0 && !c->collect_stats && c->nranks == 1 && !c->reduce_external &&
+      c->fd_iter == 0 && !c->groups_launch_pending) {
+    c->steady_table = c->steady_prev;
+    c->spec_active = true;
+    c->spec_table = c->steady_prev;
+    c->spec_stages = stages;
+    c->n_spec++;
+  } else if ((rc = resolve_groups(c))) {
+    return rc;
+  }
   if (!c->pairs_ready && (rc = build_pairs(c))) return rc;
   if (c->nranks > 1 && !c->owner_ready && P) {       // sharded: who owns what (balanced by pod count, whole groups)
     HIPCHK(c, c->d_own_start.reserve((size_t)P * 4));
@@ -2538,15 +2563,28 @@ static int fd_resolve(bs_ctx* c) {
   return BS_OK;
 }
 
-// Every reader of a batch's results comes through here first: wait for a BS_BATCH_FILTER_DENY batch and look at its flag words.
+// Every reader of a batch's results comes through here first.  A batch launched on a GUESSED table (see bs_ctx, speculation): wait
+// for it, take findMaxPG's real answer (long landed by then) and run the batch again if the guess was wrong.  A
+// BS_BATCH_FILTER_DENY batch: wait for it and look at its flag words (fd_resolve).
 static int fd_settle(bs_ctx* c) {
-  if (!c->fd_active) return BS_OK;
-  if (!c->batch_since_pods) { c->fd_active = false; return BS_OK; }      // the queue changed since: those results are history
+  if (!c->fd_active && !c->spec_active) return BS_OK;
+  if (!c->batch_since_pods) { c->fd_active = false; c->spec_active = false; return BS_OK; }      // the queue changed since: those results are history
+  int rc;
   if (c->last_host_out) {
-    int rc = wait_host_tag(c, 0, c->host_tag, reinterpret_cast<const int32_t*>(c->h_hout + c->off_htag));
-    if (rc) return rc;
+    if ((rc = wait_host_tag(c, 0, c->host_tag, reinterpret_cast<const int32_t*>(c->h_hout + c->off_htag)))) return rc;
   } else {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  if (c->spec_active) {
+    c->spec_active = false;
+    if ((rc = resolve_groups(c))) return rc;
+    if (c->steady_table != c->spec_table) {            // wrong guess: the batch again, on the real answer (nothing of a what-if batch sticks)
+      c->n_spec_miss++;
+      const bool fd = c->fd_active;
+      if ((rc = batch_run_inner(c, c->spec_stages))) return rc;
+      c->fd_active = fd;
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
   }
   return fd_resolve(c);
 }
@@ -3485,6 +3523,13 @@ int bs_timing_get(bs_ctx* c, bs_timing* out) {
   rc = timer_collect(c);
   *out = c->timing;
   return rc;
+}
+
+int bs_speculation_stats(const bs_ctx* c, uint64_t* launched, uint64_t* missed) {
+  if (!c || !launched || !missed) return BS_ERR_INVALID;
+  *launched = c->n_spec;
+  *missed = c->n_spec_miss;
+  return BS_OK;
 }
 
 int bs_filter_deny_stats(const bs_ctx* c, uint64_t* reruns) {

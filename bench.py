@@ -341,7 +341,11 @@ def resident_cycle(bsa, ctx, groups, pods, nodes, stages, darr, ndeltas, out, it
             for k, v in zip(("groups_apply", "pods_apply", "run", "read", "total"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)):
                 parts[k].append(v * 1e3)
     applies, rederives = ctx.apply_stats()
+    launched, missed = ctx.speculation_stats()
     r = {k: {"p50_ms": pct(v, 50), "p95_ms": pct(v, 95)} for k, v in parts.items()}
+    r["speculation"] = {"batches_launched_on_a_guess_so_far": launched, "wrong_guesses_re_run": missed,
+                        "note": "the chain is launched on the previous cycle's findMaxPG answer while this cycle's is still being computed on the device; "
+                                "checked when the results are asked for (bs_speculation_stats)"}
     r["queue_churn_per_cycle"] = {"removed": churn // 2, "appended": churn // 2, "of": pods.p}
     r["applies"], r["rederives"] = applies, rederives
     return r

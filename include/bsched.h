@@ -658,6 +658,13 @@ int bs_pods_apply_stats(const bs_ctx* ctx, uint64_t* applies, uint64_t* rederive
 /* BS_BATCH_FILTER_DENY batches that had to be run again so far (see bs_batch_run: a pod turned away by a failing Filter's deny
  * entry was needed by somebody else; the batch is then settled by fixed-point iteration when its results are first asked for). */
 int bs_filter_deny_stats(const bs_ctx* ctx, uint64_t* reruns);
+/* Batches launched on a GUESSED findMaxPG answer, and how many of the guesses were wrong.  After a group patch (bs_groups_apply)
+ * findMaxPG runs again on the device; bs_batch_run would have to wait for its answer (which running-sum table the batch uses) before
+ * it could launch anything.  When the loaded state is a steady one (every group has its pod and MinResources) and the answer has not
+ * landed yet, the chain is launched on the previous cycle's answer instead and checked when the results are first asked for
+ * (bs_batch_sync / read / map): a wrong guess re-runs the batch there — results are never taken from a wrong guess.  Never for a
+ * committing batch.  BS_NO_SPECULATE=1 turns it off. */
+int bs_speculation_stats(const bs_ctx* ctx, uint64_t* launched, uint64_t* missed);
 
 #ifdef __cplusplus
 }
