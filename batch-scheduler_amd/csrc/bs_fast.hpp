@@ -36,6 +36,11 @@
 
 #include "bs_kernels.hpp"
 
+#ifdef BS_NT_TABLES
+#define BS_TBL_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define BS_TBL_STORE(p, v) (*(p) = (v))
+#endif
 namespace bs {
 
 __device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i, uint32_t nthreads);
@@ -267,10 +272,10 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
         tot += x;
       }
       incl[j] += off;
-      if (valid) T[(size_t)k * LP + j] = (int64_t)incl[j];
+      if (valid) BS_TBL_STORE(&T[(size_t)k * LP + j], (int64_t)incl[j]);
       if (threadIdx.x == 0) b.chunk_tot[(size_t)chunk * 16 + j] = tot;
     } else if (j < LP && valid) {
-      T[(size_t)k * LP + j] = INT64_MAX;
+      BS_TBL_STORE(&T[(size_t)k * LP + j], (int64_t)INT64_MAX);
     }
   }
   // per 64-row group: max of the local sums per resource lane; the scan bounds the group's FINAL sums with max + chunk

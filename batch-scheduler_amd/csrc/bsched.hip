@@ -123,6 +123,9 @@ struct bs_ctx {
   uint32_t spec_stages = 0;
   uint32_t no_spec = 0;              // BS_NO_SPECULATE=1
   uint64_t n_spec = 0, n_spec_miss = 0;
+  // BS_HOST_PROBE=1: where bs_batch_run's host time goes (ns, accumulated; printed at bs_destroy)
+  uint32_t host_probe = 0;
+  uint64_t hp_ns[6] = {0, 0, 0, 0, 0, 0}, hp_n = 0, hp_t0 = 0, hp_t1 = 0;
   uint64_t early_filter_min = 200000000ull;   // pod x node pairs from which Filter overlaps the scan
   hipStream_t stream3 = nullptr;    // early Filter: runs beside the node scan when no capture can occur
   hipEvent_t ev_query = nullptr, ev_filter = nullptr;
@@ -1109,6 +1112,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_SPECULATE")) c->no_spec = std::atoi(e) ? 1u : 0u;
+  if (const char* e = std::getenv("BS_HOST_PROBE")) c->host_probe = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_SLOT_BITS")) { const int hb = std::atoi(e); c->slot_keep = hb >= 32 ? 0xFFFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_HASH_BITS")) { const int hb = std::atoi(e); c->hash_keep = hb >= 31 ? 0x7FFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) { c->early_filter_min = std::strtoull(e, nullptr, 10); c->early_forced = 1; }
@@ -1123,6 +1127,10 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
 
 int bs_destroy(bs_ctx* c) {
   if (!c) return BS_OK;
+  if (c->host_probe && c->hp_n)
+    std::fprintf(stderr, "[bs host probe] %llu fast-chain batches: to chain choice %.2f us | to launch A %.2f | launch A call %.2f | to launch B %.2f | launch B call %.2f | rest %.2f\n",
+                 (unsigned long long)c->hp_n, c->hp_ns[0] / 1e3 / c->hp_n, c->hp_ns[1] / 1e3 / c->hp_n, c->hp_ns[2] / 1e3 / c->hp_n, c->hp_ns[3] / 1e3 / c->hp_n,
+                 c->hp_ns[4] / 1e3 / c->hp_n, c->hp_ns[5] / 1e3 / c->hp_n);
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); }
   for (auto& e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1984,6 +1992,11 @@ static int launch_filter_deny_marks(bs_ctx* c, const BatchDev& b, BatchParams pr
   return BS_OK;
 }
 
+static inline uint64_t host_ns() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
 // The steady-state chain (bs_fast.hpp): three launches, nothing reset, no wait.
 static int run_fast(bs_ctx* c, uint32_t stages) {
   int rc;
@@ -2023,6 +2036,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   // kernels need not fetch it in front of everything else
   if (c->kinfo_pending && ((volatile int32_t*)c->h_info)[5] == c->kinfo_tag && (rc = resolve_pods(c))) return rc;
   prm.k_host = c->kinfo_pending ? 0u : c->h_K;
+  const uint64_t hp1 = c->host_probe ? host_ns() : 0;
   // ---- launch A: per-pod decisions, scan / Filter slots | chunk-local running sums of the table
   TIMED(c, BS_KERNEL_QUERY, {
     const uint32_t qb = cdiv(P, kTblChunk);
@@ -2036,7 +2050,9 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<-1>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
     }
   });
+  const uint64_t hp2 = c->host_probe ? host_ns() : 0;
   bool fused = false;
+  uint64_t hp3 = 0;
   // ---- launch B: node scan over the class slots | Filter evaluation over the Filter slots
   // The work loops size themselves on the device (the class count lives there); the grid only has to be large enough.
   const uint32_t k_est = std::min<uint32_t>(P, c->kinfo_pending ? std::max<uint32_t>(2 * c->h_K, 1024) : std::max<uint32_t>(c->h_K, 1));
@@ -2055,6 +2071,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     fused = tiles <= 16 && !c->no_fuse_final && (int)(scan_grid(4u) + fblocks + cdiv(P, 256)) <= fused_residency(c);
     prm.scan_nsub = fused ? 4u : 1u;
     const uint32_t scan_blocks = scan_grid(prm.scan_nsub);
+    hp3 = c->host_probe ? host_ns() : 0;
     if (fused) {
       // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
       const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
@@ -2063,6 +2080,11 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       launch_fast_b(c, dim3(scan_blocks + fblocks), pd, nd, bt, prm, 64u, scan_blocks);
     }
   });
+  if (c->host_probe) {
+    const uint64_t hp4 = host_ns();
+    c->hp_ns[0] += c->hp_t1 - c->hp_t0; c->hp_ns[1] += hp1 - c->hp_t1; c->hp_ns[2] += hp2 - hp1; c->hp_ns[3] += hp3 - hp2; c->hp_ns[4] += hp4 - hp3;
+    c->hp_n++;
+  }
   c->launches = 2;
   if (!fused) {                                      // the throughput regime (or a grid the chip cannot hold at once): launch C on its own
     TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
@@ -2217,6 +2239,7 @@ static int run_epoch(bs_ctx* c, uint32_t stages, bool* taken) {
 
 static int batch_run_inner(bs_ctx* c, uint32_t stages) {
   int rc = BS_OK;
+  if (c->host_probe) c->hp_t0 = host_ns();
   c->fd_on = (stages & BS_BATCH_FILTER_DENY) != 0;
   if (c->fd_on) {
     const size_t g1 = std::max<uint32_t>(c->G, 1);
@@ -2236,7 +2259,7 @@ static int batch_run_inner(bs_ctx* c, uint32_t stages) {
   c->spec_active = false;
   if (c->info_pending && ((volatile int32_t*)c->h_info)[3] != c->info_tag && !c->no_spec && c->steady_prev >= 0 && c->n_uncaptured == 0 &&
       c->n_nominres == 0 && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing == 0 && !c->collect_stats && c->nranks == 1 && !c->reduce_external &&
-      c->fd_iter == 0 && !c->groups_launch_pending) {
+      c->fd_iter == 0 && !c->groups_launch_pending && !c->ext_admit) {
     c->steady_table = c->steady_prev;
     c->spec_active = true;
     c->spec_table = c->steady_prev;
@@ -2292,6 +2315,7 @@ static int batch_run_inner(bs_ctx* c, uint32_t stages) {
   c->last_fast = use_classes && inline_tables && !early_filter && N && !c->no_fast && !c->no_fuse_filter;
   c->last_chain = c->last_fast ? 1u : 0u;
   if (c->last_fast) {
+    if (c->host_probe) c->hp_t1 = host_ns();
     rc = run_fast(c, stages);
     advance_batch_seq(c);
     return rc;
