@@ -10,6 +10,7 @@
  *   runBatch        bs_pods_load_flat, bs_batch_run(BS_STAGE_ALL), bs_filter_rows_count, bs_batch_read_flat   (bsched_batch.go: runBatch)
  *   clusterFits     bs_cluster_fits for the first pods of the queue              (bsched_cgo.go: clusterFits, core.go:595-632)
  *   next cycle      bs_groups_apply (patchGroups), bs_pods_apply_flat, bs_batch_run(| BS_BATCH_HOST_RESULTS), bs_batch_map
+ *   Filter on       bs_batch_run(| BS_BATCH_FILTER_DENY), bs_batch_read_flat, bs_filter_deny_stats, bs_speculation_stats
  *   close           bs_destroy
  * The struct-taking entry points are reached through their *_flat forms only, exactly as the Go files do (cgo pointer rule: no
  * Go-allocated struct of Go pointers crosses by pointer) — so the forms the shim binds are compiled, linked and run here.
@@ -190,6 +191,17 @@ int main(int argc, char** argv) {
   wr(o, v.pf_code, P); wr(o, v.pf_first_k, (size_t)P * 4); wr(o, v.pf_leader, (size_t)P * 4); wr(o, v.fl_code, P); wr(o, v.fl_feasible, (size_t)P * 4);
   wr(o, v.group_admit, (size_t)G * 4); wr(o, v.group_ready, G);
   wr(o, fits, nq); wr(o, fk, (size_t)nq * 4);
+
+  /* ---- a Filter-on deployment (runBatch in bsched_batch.go): BS_BATCH_FILTER_DENY replays the deny entry a failing Filter writes
+   * (core.go:183-185) inside the batch, on the device; results copied out through the flat read */
+  CHECK(bs_batch_run(ctx, BS_STAGE_ALL | BS_BATCH_FILTER_DENY));
+  CHECK(bs_batch_read_flat(ctx, pf_code, pf_first_k, pf_leader, fl_code, fl_feasible, NULL, admit, ready, NULL, NULL, NULL, 0, NULL));
+  wr(o, pf_code, P); wr(o, pf_first_k, (size_t)P * 4); wr(o, pf_leader, (size_t)P * 4); wr(o, fl_code, P); wr(o, fl_feasible, (size_t)P * 4);
+  wr(o, admit, (size_t)G * 4); wr(o, ready, G);
+  uint64_t reruns = 0, guessed = 0, missed = 0;
+  CHECK(bs_filter_deny_stats(ctx, &reruns));
+  CHECK(bs_speculation_stats(ctx, &guessed, &missed));
+  if (missed > guessed) return 8;
   fclose(o);
   CHECK(bs_destroy(ctx));
   printf("shim_client: ok (%" PRIu32 " pods, %" PRIu32 " groups, %" PRIu32 " nodes, %" PRIu32 " filter rows)\n", P, G, N, rows_n);

@@ -219,3 +219,17 @@ func (g *gpuCore) clusterFits(class uint32, req *nodeinfo.Resource, percent floa
 	g.mu.Unlock()
 	return rc == C.BS_OK && fits != 0
 }
+
+// cycleCounters: how often the library had to run a batch twice (metrics for the shim's dashboards; both stay at or near zero
+// in a steady state).  reruns: BS_BATCH_FILTER_DENY batches settled by fixed-point re-runs (a pod let through on its
+// lastPermittedPod entry failed Filter in front of its group's first eligible pod or of the batch's first findMaxPG call).
+// guessed / missed: batches launched on the previous cycle's findMaxPG answer, and wrong guesses that were run again.
+func (g *gpuCore) cycleCounters() (reruns, guessed, missed uint64) {
+	var r, a, m C.uint64_t
+	g.mu.Lock()
+	defer g.mu.Unlock()
+	if C.bs_filter_deny_stats(g.ctx, &r) != C.BS_OK || C.bs_speculation_stats(g.ctx, &a, &m) != C.BS_OK {
+		return 0, 0, 0
+	}
+	return uint64(r), uint64(a), uint64(m)
+}

@@ -129,3 +129,9 @@ def test_c11_client_runs_the_shim_cycle(config, scenario, tmp_path, bsa, soa, or
     for i in range(nq):
         ok, k = snap.compare_cluster(int(pods.cls[i]), pods.req[:, i], int(pods.req_present[i]), 1.0)[:2]
         assert bool(fits[i]) == bool(ok) and (not ok or int(fk[i]) == int(k)), f"clusterFits pod {i}"
+    # cycle 3: the same queue with Filter's deny entry replayed inside the batch (BS_BATCH_FILTER_DENY)
+    off += nq + 4 * nq
+    exp3 = orc.Sop(snap, groups).batch(pods2, soa.STAGE_ALL | soa.BATCH_FILTER_DENY)
+    got3, off = read_cycle(buf, off, pods.p, groups.g)
+    for k, v in got3.items():
+        assert np.array_equal(v, getattr(exp3, k)), f"cycle 3 (Filter's deny entry on the device): {k}"

@@ -10,6 +10,17 @@ cd /tmp && export TMPDIR=/tmp
 # 2. kernel trace + PMC of the batched step (as in earlier rounds)
 BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-pmc"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/step_pmc_sq -o pmc -- $BENCH > $OUT/step_pmc_sq.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/step_pmc_fetch -o pmc -- $BENCH > $OUT/step_pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/step_pmc_write -o pmc -- $BENCH > $OUT/step_pmc_write.log 2>&1
+# 2b. the throughput regime (every request distinct): kernel trace + SQ counters of the scan / Filter kernel
+DIST="python $R/tools/step_time.py cfg3 tail --distinct"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/distinct_trace -o trace -- $DIST > $OUT/distinct_trace.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/distinct_pmc_sq -o pmc -- $DIST > $OUT/distinct_pmc_sq.log 2>&1
+( cd $R && for a in "cfg3 tail" "cfg3 cold" "cfg4 tail" "cfg3 tail --distinct" "cfg4 tail --distinct"; do timeout 200 python tools/step_time.py $a 2>&1 | tail -1; done ) > $OUT/step_times.txt
+# 2c. the resident cycle: host-side anatomy (speculating / not), leader ladders
+( cd $R && BS_HOST_PROBE=1 timeout 200 python tools/cycle_probe.py cfg3 2>&1 | tail -2; echo "--- BS_NO_SPECULATE=1"; BS_NO_SPECULATE=1 BS_HOST_PROBE=1 timeout 200 python tools/cycle_probe.py cfg3 2>&1 | tail -2 ) > $OUT/cycle_probe.txt
+( cd $R && timeout 200 python tools/ladder_time.py 2>&1 | tail -10 ) > $OUT/ladder_time.txt
 # 3. the sequential pass: kernel trace, then counters in passes of their own
 SEQ="python $R/tools/seq_bench.py cfg3 tail"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/seq_trace -o trace -- $SEQ > $OUT/seq_trace.log 2>&1
@@ -21,3 +32,8 @@ for a in "cfg3 cold" "cfg3 tail --filter" "cfg2 tail" "cfg4 tail"; do ( cd $R &&
 # 4. launch-chain floor numbers (profiles/r03_launch_chain_ubench.txt was committed empty)
 ( cd $R/tools/ubench && hipcc --offload-arch=gfx950 -O3 -o launch_chain launch_chain.hip 2> $OUT/launch_chain_build.log && timeout 120 ./launch_chain > $OUT/launch_chain_ubench.txt 2>&1 )
 find $OUT -name "*stats*.csv" | head
+# 5. summaries on the box (gpurun copies at most 64 MiB back: the sqlite outputs stay behind)
+( cd $R && python tools/prof_db_summary.py $OUT k_fast k_seq_pass k_epoch k_pods_apply k_fd > $OUT/profile_summary.txt 2>&1 )
+find $OUT -name "*.db" -delete
+find $OUT -type d -empty -delete
+du -sh $OUT
