@@ -93,3 +93,64 @@ def test_oracle_batch_with_filter_deny_equals_the_sequential_replay_everywhere(s
         corner += int(((raw.pf_code == soa.PF_PASS_LAST_PERMITTED) & (raw.fl_code == soa.FL_EVALUATED) & (raw.fl_feasible < nodes.n)).any())
         bites += int(not np.array_equal(raw.pf_code, out.pf_code))
     assert corner >= 20 and bites >= 30, (corner, bites)
+
+
+def mechanical_pass_and_needed_pods(raw, pods, groups, n_nodes, sop_leader0=-1):
+    """What the device does behind a chain (csrc/bs_fdeny.hpp k_fd_apply), restated with numpy loops: per group the first pod whose
+    Filter fails on a node; every later pod of the group that reaches the deny check is turned away; and the test for "a pod that is
+    turned away was needed by somebody else" (the batch then goes to the fixed-point re-runs): (1) it got to findMaxPG and its
+    stale-leader value differs from its predecessor's, (2) it was its group's first eligible pod and the group lacked its pod or
+    its MinResources."""
+    import copy
+    out = copy.copy(raw)
+    out.pf_code, out.pf_first_k = raw.pf_code.copy(), raw.pf_first_k.copy()
+    out.fl_code, out.fl_feasible = raw.fl_code.copy(), raw.fl_feasible.copy()
+    event, first_np, needed = {}, {}, False
+    for i in range(pods.p):
+        g = int(pods.group[i])
+        if 0 <= g < groups.g and not (pods.flags[i] & nv.soa.POD_LAST_PERMITTED):
+            first_np.setdefault(g, i)
+        if 0 <= g < groups.g and raw.fl_code[i] == nv.soa.FL_EVALUATED and raw.fl_feasible[i] < n_nodes:
+            event.setdefault(g, i)
+    for i in range(pods.p):
+        g, code = int(pods.group[i]), int(raw.pf_code[i])
+        at_check = 0 <= g < groups.g and code not in (nv.soa.PF_PASS_NOT_GROUPED, nv.soa.PF_PASS_LAST_PERMITTED, nv.soa.PF_ERR_PG_NOT_FOUND)
+        if not (at_check and g in event and event[g] < i and code != nv.soa.PF_ERR_DENIED):
+            continue
+        if code != nv.soa.PF_ERR_OCCUPIED and int(raw.pf_leader[i]) != (int(raw.pf_leader[i - 1]) if i else sop_leader0):
+            needed = True
+        both = nv.soa.GROUP_HAS_POD | nv.soa.GROUP_HAS_MINRES
+        if first_np.get(g) == i and (int(groups.flags[g]) & both) != both:
+            needed = True
+        out.pf_code[i], out.pf_first_k[i], out.fl_code[i], out.fl_feasible[i] = nv.soa.PF_ERR_DENIED, 0xFFFFFFFE, nv.soa.FL_NOT_RUN, 0
+    return out, needed
+
+
+def test_the_needed_pod_rule_flags_every_scene_the_mechanical_pass_gets_wrong(bsa, soa, orc):
+    """CPU pin of the device algorithm's detection rule (the rule was checked this way before the kernel was written): on 800 random
+    scenes, whenever the rule does NOT fire, the what-if batch + the mechanical pass equals the oracle's batch with the flag in
+    every output (stale leader and first_k included); it fires in a few per cent of the scenes (30 of 800; 7 of those really differ: a
+    re-run that was not needed costs one batch, a missed one would cost exactness)."""
+    from test_gpu_parity import _force_class_mode
+    flagged = wrong_when_flagged = 0
+    for steady in (False, True):
+        for seed in range(7000, 7400):
+            sc = random_objects(seed, n_nodes=6 + seed % 40, n_groups=7, n_pods=60, n_scalars=seed % 3, n_classes=3)
+            if seed % 4 == 1:
+                sc["permitted"] = set()
+            nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"], denied=sc["denied"], permitted=sc["permitted"])
+            if steady:
+                rng = np.random.default_rng(seed)
+                _force_class_mode(groups, rng, sc["n_classes"])
+                groups.matched[:] = rng.integers(1, 4, groups.g)
+            raw = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL, bitmap=False)
+            exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL | soa.BATCH_FILTER_DENY, bitmap=False)
+            got, needed = mechanical_pass_and_needed_pods(raw, pods, groups, nodes.n)
+            same = all(np.array_equal(getattr(got, n), getattr(exp, n)) for n in ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible"))
+            if needed:
+                flagged += 1
+                wrong_when_flagged += int(not same)
+            else:
+                assert same, f"seed {seed} steady {steady}: the rule did not fire and the mechanical pass is wrong"
+    assert 10 <= flagged <= 80, flagged
+    assert wrong_when_flagged >= 3, (flagged, wrong_when_flagged)                   # conservative (30 flagged, 7 of them really differ), not idle
