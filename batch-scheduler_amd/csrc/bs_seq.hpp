@@ -50,7 +50,10 @@ constexpr int kSeqWaves = kSeqBlock / 64;
 constexpr uint32_t kSeqKeysLds = 8192;     // groups whose findMaxPG keys fit the LDS window (64 KB)
 constexpr uint32_t kSeqPruneTiles = 1024;  // 64-node tiles whose first-fit bounds fit the LDS window (65 536 nodes)
 constexpr uint32_t kSeqWaitList = 512;     // waiting pods of the current gang kept in LDS
-constexpr uint32_t kSeqCacheSlots = 4;     // table summaries (fit class x percent) kept in LDS at most
+#ifndef BS_SEQ_CACHE_MAX
+#define BS_SEQ_CACHE_MAX 4
+#endif
+constexpr uint32_t kSeqCacheSlots = BS_SEQ_CACHE_MAX;     // table summaries (fit class x percent) kept in LDS at most
 
 struct SeqDev {
   // resident state the pass mutates

@@ -22,6 +22,8 @@ def main():
     if "--probe" in sys.argv:            # the -DBS_SEQ_PROBE build: cycles per phase go to stderr
         bsa.capi.LIB_PATH = os.environ.get("BS_SEQ_PROBE_LIB") or os.path.join(ROOT, "tools", "ubench", "libbsched_seqprobe.so")
         os.environ["BS_SEQ_PROBE_PRINT"] = "1"
+    if os.environ.get("BS_AB_LIB"):        # A/B runs of build variants
+        bsa.capi.LIB_PATH = os.path.abspath(os.environ["BS_AB_LIB"])
     nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
     pods = pods.take(np.argsort(pods.group, kind="stable"))           # Compare order
     runs = []
