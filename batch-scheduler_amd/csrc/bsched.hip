@@ -2258,7 +2258,7 @@ static int batch_run_inner(bs_ctx* c, uint32_t stages) {
   // steady one — the guess is checked when the results are first asked for (batch_settle)
   c->spec_active = false;
   if (c->info_pending && ((volatile int32_t*)c->h_info)[3] != c->info_tag && !c->no_spec && c->steady_prev >= 0 && c->n_uncaptured == 0 &&
-      c->n_nominres == 0 && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing == 0 && !c->collect_stats && c->nranks == 1 && !c->reduce_external &&
+      c->n_nominres == 0 && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing < 2 && !c->collect_stats && c->nranks == 1 && !c->reduce_external &&
       c->fd_iter == 0 && !c->groups_launch_pending && !c->ext_admit) {
     c->steady_table = c->steady_prev;
     c->spec_active = true;
