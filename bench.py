@@ -229,6 +229,9 @@ def drain_section(bsa, nodes, fit, groups, pods, args):
     lat = (s["ready_ns"] - s["first_ns"]) / 1e6
     res["_cpu_sequential_pass"] = {"kind": "port (C restatement of the Go path, 1 core)", "gangs_released": s["n_released"],
                                    "pods_released": int((s["pod_node"] >= 0).sum()), "total_ms": s["total_ns"] / 1e6,
+                                   "of_which_node_choice_ms": s["pick_ns"] / 1e6,
+                                   "node_choice_note": "the first-fit node pick is UPSTREAM's work, not the plugin's: the plugin-only share of the CPU pass is total_ms - of_which_node_choice_ms "
+                                                       "(bs_seq_run does the pick as well; the comparison is whole pass against whole pass)",
                                    "gangs_per_s": s["n_released"] / max(s["total_ns"] * 1e-9, 1e-12), "reference_loop_iterations": s["iters"],
                                    "gang_admit_latency_ms_p50": pct(lat, 50), "gang_admit_latency_ms_p95": pct(lat, 95),
                                    "time_since_pass_start_ms_p50": pct(s["ready_ns"] / 1e6, 50),

@@ -39,6 +39,8 @@ typedef struct orc_seq_io {
   int64_t total_ns;
   uint32_t* pf_first_k;      /* [p] optional: first_k of the pod's node scan (as bs_batch_out.pf_first_k)                 */
   int32_t* pf_leader;        /* [p] optional: sop.maxFinishedPG as the pod's PreFilter left it (-1 none)                  */
+  int64_t pick_ns;           /* out: of total_ns, the time spent in the node-choice loop (UPSTREAM's work, not the plugin's; with the FILTER stage it
+                              * contains the plugin's Filter calls on the nodes tried) */
 } orc_seq_io;
 
 static int64_t mono_ns(void) {
@@ -81,6 +83,7 @@ void orc_seq_replay(orc_seq_io* io) {
   for (uint32_t g = 0; g < G; ++g) { t_first[g] = -1; head[g] = -1; slot_of[g] = 0xFFFFFFFFu; }
   for (uint32_t i = 0; i < P; ++i) io->pod_node[i] = -1;
   io->n_released = 0;
+  io->pick_ns = 0;
   const int64_t t0 = mono_ns();
   for (uint32_t i = 0; i < P; ++i) {
     const int32_t gi = pods->group[i];
@@ -97,6 +100,7 @@ void orc_seq_replay(orc_seq_io* io) {
     for (uint32_t j = 0; j < L; ++j) req[j] = pods->req[(size_t)j * P + i];
     const uint32_t pres = pods->req_present[i], cls = pods->cls[i];
     int32_t at = -1;
+    const int64_t t_pick = mono_ns();
     for (uint32_t k = 0; k < N && at < 0; ++k) {
       if (s->nodes.flags[k]) continue;
       if (cls >= s->n_classes || !((s->fit[(size_t)cls * fw + (k >> 5)] >> (k & 31u)) & 1u)) continue;
@@ -108,6 +112,7 @@ void orc_seq_replay(orc_seq_io* io) {
       if (!holds(s, k, req, pres)) continue;
       at = (int32_t)k;
     }
+    io->pick_ns += mono_ns() - t_pick;
     if (at < 0) continue;                                       /* unschedulable this pass: holds nothing */
     for (uint32_t j = 0; j < 3; ++j) requested[(size_t)j * N + at] += req[j];
     requested[(size_t)3 * N + at] += 1;

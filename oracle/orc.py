@@ -64,7 +64,7 @@ class SeqIO(C.Structure):
                 ("pf_code", C.POINTER(C.c_uint8)), ("pod_node", C.POINTER(C.c_int32)), ("cap", C.c_uint32),
                 ("released_group", C.POINTER(C.c_uint32)), ("released_pods", C.POINTER(C.c_uint32)),
                 ("first_ns", C.POINTER(C.c_int64)), ("ready_ns", C.POINTER(C.c_int64)), ("n_released", C.c_uint32), ("total_ns", C.c_int64),
-                ("pf_first_k", C.POINTER(C.c_uint32)), ("pf_leader", C.POINTER(C.c_int32))]
+                ("pf_first_k", C.POINTER(C.c_uint32)), ("pf_leader", C.POINTER(C.c_int32)), ("pick_ns", C.c_int64)]
 
 
 _lib = None
@@ -308,7 +308,7 @@ def seq_replay(nodes, fit, groups, pods, stages: int = soa.STAGE_PREFILTER | soa
     lib().orc_seq_replay(C.byref(io))
     k = min(int(io.n_released), cap)
     return dict(released_group=rg[:k].copy(), released_pods=rp[:k].copy(), first_ns=t_first[:k].copy(), ready_ns=t_ready[:k].copy(),
-                pod_node=pod_node[: pods.p].copy(), pf_code=pf[: pods.p].copy(), pf_first_k=fk[: pods.p].copy(), pf_leader=ld[: pods.p].copy(), n_released=int(io.n_released), total_ns=int(io.total_ns),
+                pod_node=pod_node[: pods.p].copy(), pf_code=pf[: pods.p].copy(), pf_first_k=fk[: pods.p].copy(), pf_leader=ld[: pods.p].copy(), n_released=int(io.n_released), total_ns=int(io.total_ns), pick_ns=int(io.pick_ns),
                 nodes=nodes, groups=sop.groups, iters=sop.iters)
 
 
