@@ -4,7 +4,7 @@
 // A batch (bs_batch_run) takes one of three chains:
 //   steady state   bs_fast.hpp    two launches (three dependency levels); every gang has its pod and MinResources, the leader has matched pods
 //   positional     bs_epoch.hpp   three launches; first-pod captures / MinResources defaults / leader without matched pods
-//   general        this file      what is left: more than four leader runs in one batch, early Filter, BS_NO_FAST / BS_NO_EPOCH
+//   general        this file      what is left: more than sixteen leader runs in one batch, early Filter, BS_NO_FAST / BS_NO_EPOCH
 // The steady-state and positional chains use scan_core / scan_loop / filter_item / filter_loop / filter_params_for / tables_local_* from here.
 //
 // General chain, one stream:

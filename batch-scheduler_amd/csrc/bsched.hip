@@ -1157,6 +1157,7 @@ int bs_destroy(bs_ctx* c) {
 int bs_nodes_load(bs_ctx* c, const bs_nodes_soa* nodes) {
   if (!c || !nodes) return BS_ERR_INVALID;
   int rc = use_device(c);
+  if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
   const uint32_t N = nodes->n, L = c->L;
   if (N && (!nodes->allocatable || !nodes->requested || !nodes->allocatable_present || !nodes->requested_present || !nodes->flags))
@@ -1182,6 +1183,7 @@ int bs_fit_load(bs_ctx* c, uint32_t n_classes, const uint32_t* fit_bits) {
   if (!c || n_classes == 0 || !fit_bits) return BS_ERR_INVALID;
   if (!c->have_nodes) { c->last_error = "bs_fit_load before bs_nodes_load"; return BS_ERR_STATE; }
   int rc = use_device(c);
+  if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
   c->C = n_classes;
   c->fit_words = cdiv(c->N, 32);
@@ -1196,6 +1198,7 @@ int bs_fit_build(bs_ctx* c, const bs_node_labels* nl, const bs_fit_templates* tp
   if (!c->have_nodes) { c->last_error = "bs_fit_build before bs_nodes_load"; return BS_ERR_STATE; }
   if (nl->n != c->N) { c->last_error = "bs_fit_build: label table size differs from the snapshot"; return BS_ERR_INVALID; }
   int rc = use_device(c);
+  if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
   const uint32_t N = c->N, C = tp->c;
   const uint32_t nlab = N ? nl->label_off[N] : 0, ntaint = N ? nl->taint_off[N] : 0;
@@ -1317,6 +1320,7 @@ int bs_fit_read(bs_ctx* c, uint32_t* out) {
 int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   if (!c || !g) return BS_ERR_INVALID;
   int rc = use_device(c);
+  if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
   const uint32_t G = g->g, L = c->L;
   if (G && (!g->min_member || !g->status_scheduled || !g->matched || !g->flags || !g->cls || !g->min_resources || !g->min_resources_present ||
@@ -2257,7 +2261,7 @@ static int batch_run_inner(bs_ctx* c, uint32_t stages) {
   // findMaxPG's answer for the patched groups: taken if it has landed; guessed (last cycle's table) if it has not and the state is a
   // steady one — the guess is checked when the results are first asked for (batch_settle)
   c->spec_active = false;
-  if (c->info_pending && ((volatile int32_t*)c->h_info)[3] != c->info_tag && !c->no_spec && c->steady_prev >= 0 && c->n_uncaptured == 0 &&
+  if (c->info_pending && ((volatile int32_t*)c->h_info)[3] != c->info_tag && !c->no_spec && c->steady_prev >= 0 && (uint32_t)c->steady_prev < 2 * c->C && c->n_uncaptured == 0 &&
       c->n_nominres == 0 && !(stages & BS_BATCH_COMMIT) && c->cfg.enable_timing < 2 && !c->collect_stats && c->nranks == 1 && !c->reduce_external &&
       c->fd_iter == 0 && !c->groups_launch_pending && !c->ext_admit) {
     c->steady_table = c->steady_prev;

@@ -256,7 +256,7 @@ typedef struct bs_batch_out {
    *                                   : fl_code[pod] < 16        (every node / no node)
    * so the Go plugin's Filter is a bit test with no cgo crossing.  Pods with equal derived requests share
    * a row: (request class, leader seen) in steady state, (leader run, request class) while first-pod captures
-   * or MinResources defaults can still happen in the batch; on the general chain (more than four leader
+   * or MinResources defaults can still happen in the batch; on the general chain (more than sixteen leader
    * changes in one batch) a row is the pod itself (fl_slot[pod] == pod).
    * Rows no pod of the batch refers to are unspecified.  bs_filter_rows_count never exceeds 2 x the request classes the
    * library knows (<= 2 x (pods at the last bs_pods_load + pods inserted since): classes keep their number between two
