@@ -50,6 +50,8 @@ constexpr int kSeqWaves = kSeqBlock / 64;
 constexpr uint32_t kSeqKeysLds = 8192;     // groups whose findMaxPG keys fit the LDS window (64 KB)
 constexpr uint32_t kSeqPruneTiles = 1024;  // 64-node tiles whose first-fit bounds fit the LDS window (65 536 nodes)
 constexpr uint32_t kSeqWaitList = 512;     // waiting pods of the current gang kept in LDS
+constexpr uint32_t kSeqCursorBits = 9;     // first-fit cursors in LDS: 512 direct-mapped entries (12 bytes each)
+constexpr uint32_t kSeqCursors = 1u << kSeqCursorBits;
 #ifndef BS_SEQ_CACHE_MAX
 #define BS_SEQ_CACHE_MAX 4
 #endif
@@ -69,6 +71,7 @@ struct SeqDev {
   uint32_t* nwait;               // [G]
   uint32_t* slot_of;             // [G] release record of a gang that is through
   unsigned long long* t_first;   // [G] clock when the gang's first pod entered PreFilter, ~0 = not yet
+  const uint32_t* pclass;        // [P] request class of the pod (equal request lanes + present bits <=> equal class; derived at the pod load)
   // results
   uint8_t* pf_code; int32_t* pod_node; uint32_t* pf_first_k; int32_t* pf_leader;
   uint32_t* released_group; uint32_t* released_pods; unsigned long long* first_tick; unsigned long long* ready_tick;
@@ -99,6 +102,7 @@ struct SeqParams {
   uint32_t keys_in_lds, prune;
   uint32_t cache_slots;          // table summaries kept in LDS (0: every scan walks the node list in rounds)
   uint32_t cache_off;            // byte offset of the summary area in dynamic LDS (behind the key window)
+  uint32_t use_cursor;           // first-fit cursors per request class (SeqShared::cur_kn, see k_seq_pass's node choice)
 };
 
 // ---- wave-uniform loads of state this kernel itself writes: vector loads, value moved to SGPRs ---------------------
@@ -224,6 +228,12 @@ struct SeqShared {
                                                          // between the two words, so that a word is re-armed a whole search (a barrier) before its next use
   uint32_t wl_pod[kSeqWaitList], wl_node[kSeqWaitList];  // waiting pods of the CURRENT gang (released in parallel; the chain in global memory is the fallback)
   uint32_t asm_ap[2][kSeqWaves], asm_rp[2][kSeqWaves], asm_fit[2][kSeqWaves];   // first fit: keys / fit bits of each wave's node (see SeqAssumed)
+  // first-fit cursors, direct-mapped by (request class, fit class): (request class + 1) << 32 | node the class's last search ended at
+  // (nodes: nothing fits any more), and the fit class that search ran under.  In LDS, not in global memory: thread 0 writes a cursor
+  // behind the search, the next pod's top barrier (LDS-only) orders it for every wave — all waves read the SAME cursor, which the
+  // barriers inside the search rely on.  An entry that was evicted only costs the next search of that class its head start.
+  unsigned long long cur_kn[kSeqCursors];
+  uint32_t cur_fc[kSeqCursors];
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -617,7 +627,7 @@ struct SeqAssumed { uint32_t ap, rp, fitbits; };     // of the chosen node: allo
 template <int TS>
 __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& sq, const SeqParams& prm, SeqShared& sh_, const SeqPick& q,
                                              const uint32_t (&slot_key)[kSeqCacheSlots], bool drained, uint32_t& hit_par, SeqAssumed& out,
-                                             unsigned long long& tiles_looked) {
+                                             unsigned long long& tiles_looked, uint32_t start_tile) {
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L(), S = sh.S();
   const int lane = lane_id(), w = (int)uni32((uint32_t)wave_id());
@@ -636,9 +646,11 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
 #pragma unroll
   for (uint32_t j = 0; j < BS_MAX_LANES; ++j) { al[j] = 0; rq[j] = 0; l07[j] = 0; l10[j] = 0; }
   uint32_t ap = 0, rp = 0, fbits = 0, meta = 0;
-  for (uint32_t chunk = 0; chunk < ntiles && mine == BS_INF; chunk += kSeqBlock) {
+  // start_tile: the first-fit cursor of the pod's request class — an identical request, with the same fit class, last ended its search
+  // there; while requests only ADD to the nodes nothing in front of it can have started to fit (k_seq_pass keeps that invariant)
+  for (uint32_t chunk = (start_tile / kSeqBlock) * kSeqBlock; chunk < ntiles && mine == BS_INF; chunk += kSeqBlock) {
     const uint32_t t = chunk + threadIdx.x;
-    bool cand = t < ntiles;
+    bool cand = t < ntiles && t >= start_tile;
     if (cand && prm.prune) {
       cand = !(q.preq[0] > 0 && sh_.pmax[0][t] < q.preq[0]) && !(q.preq[1] > 0 && sh_.pmax[1][t] < q.preq[1]);
       if (q.preq[0] > 0 && q.preq[1] > 0) cand = cand && !(sh_.pmax[2][t] < seq_joint(q.preq[0], q.preq[1]));
@@ -906,7 +918,9 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
   uint32_t slot_key[kSeqCacheSlots], slot_age[kSeqCacheSlots], age_ctr = 0;
 #pragma unroll
   for (uint32_t c = 0; c < kSeqCacheSlots; ++c) { slot_key[c] = BS_INF; slot_age[c] = 0; }
+  for (uint32_t e = threadIdx.x; e < kSeqCursors; e += kSeqBlock) { sh_.cur_kn[e] = 0ull; sh_.cur_fc[e] = 0u; }   // (ordered by the barrier in front of the loop)
   uint32_t hit_par = 0;                                      // which of the two early-stop words the next search uses
+  bool mono = true;                                          // no assumed request has freed capacity so far: the first-fit cursors hold
   bool stores_pending = true;                                // an assume step (or the prologue) stored node state nobody has waited for yet
   int32_t sop_leader = prm.sop_leader0;                      // sop.maxFinishedPG / maxPGStatus (core.go:58-59), stale between calls
   uint32_t n_released = 0;
@@ -1158,8 +1172,33 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
 #pragma unroll
       for (uint32_t j = 0; j < BS_MAX_LANES; ++j) q.preq[j] = j < L ? pods.req[(size_t)j * P + i] : 0;
       SeqAssumed as;
-      at = seq_pick<TS>(nd, sq, prm, sh_, q, slot_key, drained || !stores_pending, hit_par, as, n_tiles);
-      if (!drained) stores_pending = false;                  // (the search drained them itself)
+      // first-fit cursor of the pod's request class (pods of a gang share a template: the search of the next one starts where this
+      // one's ended).  Exact while (a) no assumed request has a negative lane — then free capacity only shrinks and a node that
+      // could not hold this request cannot hold it later —, (b) the plugin's Filter does not gate the choice (its verdict moves
+      // with the leader), (c) the cursor was left by the same fit class.
+      const bool cur_ok = prm.use_cursor && mono && q.fl < 16u && q.fl != BS_FL_EVALUATED && q.pcls < nd.n_classes;
+      uint32_t pc = 0, ce = 0, start = 0;
+      if (cur_ok) {
+        pc = sq.pclass[i];
+        ce = ((pc * 2654435761u) ^ (q.pcls * 40503u)) >> (32 - kSeqCursorBits);
+        const unsigned long long cv = sh_.cur_kn[ce];
+        if ((uint32_t)(cv >> 32) == pc + 1u && sh_.cur_fc[ce] == q.pcls) start = (uint32_t)cv;
+      }
+      if (cur_ok && start >= nd.n) {
+        at = BS_INF;                                         // an identical request found no node before, and nothing has been freed since
+      } else {
+        at = seq_pick<TS>(nd, sq, prm, sh_, q, slot_key, drained || !stores_pending, hit_par, as, n_tiles, start >> 6);
+        if (!drained) stores_pending = false;                // (the search drained them itself)
+        if (cur_ok && t0) {                                  // (every wave read the entry before the search's barrier)
+          sh_.cur_kn[ce] = ((unsigned long long)(pc + 1u) << 32) | (at != BS_INF ? at : nd.n);
+          sh_.cur_fc[ce] = q.pcls;
+        }
+      }
+      if (at != BS_INF) {
+#pragma unroll
+        for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+          if (j < L && j != 3 && q.preq[j] < 0 && (j < 3 || ((q.ppres >> (j - 4)) & 1u))) mono = false;   // capacity was FREED: cursors are history
+      }
       n_pick++;
       if (at != BS_INF) {
         stores_pending = true;

@@ -3273,6 +3273,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   sq.nwait = reinterpret_cast<uint32_t*>(base + o_nwait);
   sq.slot_of = reinterpret_cast<uint32_t*>(base + o_slot);
   sq.t_first = reinterpret_cast<unsigned long long*>(base + o_tfirst);
+  sq.pclass = pclass_dev(c);
   sq.pf_code = base + o_code;
   sq.pod_node = reinterpret_cast<int32_t*>(base + o_node);
   sq.pf_first_k = reinterpret_cast<uint32_t*>(base + o_fk);
@@ -3303,6 +3304,8 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
     prm.cache_off = (uint32_t)lds;
     if (K) lds += align256(K * per_slot + query + 64);
   }
+  // first-fit cursors per request class (bs_seq.hpp, seq_pick): BS_SEQ_NO_CURSOR=1 = every search starts at the head of the list
+  prm.use_cursor = (P && sq.pclass && !(std::getenv("BS_SEQ_NO_CURSOR") && std::atoi(std::getenv("BS_SEQ_NO_CURSOR")))) ? 1u : 0u;
   HIPCHK(c, hipMemsetAsync(base + o_info, 0, 256, c->stream));
   const PodsDev pd = pods_dev(c);
   const NodesDev nd = nodes_dev(c);

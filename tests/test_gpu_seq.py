@@ -245,3 +245,72 @@ def test_seq_pass_scan_variants_cfg3(slots, bsa, soa, orc, monkeypatch):
     s = oracle_pass(orc, nodes, fit, groups, pods, soa.STAGE_PREFILTER)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
         check_pass(ctx, s, soa, f"cfg3/cold slots {slots}")
+
+
+def template_scene(soa, seed, negative_at=None, N=200, G=60, per=6):
+    """gangs stamped from a few pod templates on a nearly full cluster: the searches of a template walk down the node list until
+    nothing fits any more (what the first-fit cursors of k_seq_pass shorten); `negative_at`: an ungrouped pod with a negative scalar
+    request in the middle of the queue (its assume step FREES capacity: a node in front of a cursor can fit again)"""
+    rng = np.random.default_rng(seed)
+    lanes = 5
+    alloc = np.zeros((lanes, N), np.int64)
+    alloc[0], alloc[1], alloc[2], alloc[3], alloc[4] = 8000, 32 << 30, 200 << 30, 110, 8
+    reqd = np.zeros((lanes, N), np.int64)
+    reqd[0] = rng.integers(2000, 7500, N)
+    reqd[1] = rng.integers(4, 28, N) << 30
+    reqd[3] = rng.integers(0, 100, N)
+    reqd[4] = rng.integers(5, 9, N)
+    ap = np.ones(N, np.uint32)
+    rp = (rng.random(N) < 0.8).astype(np.uint32)
+    reqd[4] *= rp
+    nodes = soa.Nodes(alloc, reqd, ap, rp, np.zeros(N, np.uint8))
+    fit = soa.FitMasks.from_bool(rng.random((2, N)) < 0.7)
+    groups = soa.Groups.empty(G, lanes)
+    groups.min_member[:] = per - 1
+    P = G * per
+    tpl = rng.integers(0, 4, G)                               # the gang's template
+    req = np.zeros((lanes, P), np.int64)
+    req[0] = np.repeat(np.array([500, 1000, 2000, 3500])[tpl], per)
+    req[1] = np.repeat(np.array([1, 2, 4, 8])[tpl], per) << 30
+    want_gpu = np.repeat(tpl % 2 == 1, per)
+    req[4] = want_gpu * 1
+    pres = want_gpu.astype(np.uint32)
+    cls = np.repeat(rng.integers(0, 2, G), per).astype(np.uint32)   # same request under two fit classes: two cursors
+    group = np.repeat(np.arange(G, dtype=np.int32), per)
+    if negative_at is not None:
+        group[negative_at] = soa.POD_NOT_GROUPED
+        req[:, negative_at] = 0
+        req[4, negative_at] = -3
+        pres[negative_at] = 1
+    pods = soa.Pods(group, req, pres, cls, np.zeros(P, np.uint64), np.zeros(P, np.uint8))
+    return nodes, fit, groups, pods
+
+
+@pytest.mark.parametrize("cursor", ["on", "off"])
+@pytest.mark.parametrize("negative", [False, True], ids=["adds-only", "a-request-frees-capacity"])
+@pytest.mark.parametrize("seed", range(4400, 4406))
+def test_seq_pass_first_fit_cursors(seed, negative, cursor, bsa, soa, orc, monkeypatch):
+    """the per-template first-fit cursors (csrc/bs_seq.hpp, node choice) never change a decision: with them, without them
+    (BS_SEQ_NO_CURSOR=1), across a request that frees capacity, and with Filter gating the choice — all == the oracle's pass"""
+    if cursor == "off":
+        monkeypatch.setenv("BS_SEQ_NO_CURSOR", "1")
+    nodes, fit, groups, pods = template_scene(soa, seed, negative_at=(150 + seed % 40) if negative else None)
+    for st in (soa.STAGE_PREFILTER, soa.STAGE_PREFILTER | soa.STAGE_FILTER):
+        s = oracle_pass(orc, nodes, fit, groups, pods, st)
+        with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+            r = check_pass(ctx, s, soa, f"templates seed {seed} stages {st} cursor {cursor}")
+        if st == soa.STAGE_PREFILTER and not negative:
+            placed = int((s["pod_node"] >= 0).sum())
+            assert 0 < placed < pods.p, "the scene is meant to run the cluster full"
+
+
+def test_seq_pass_cursors_survive_a_queue_patch(bsa, soa, orc):
+    """request classes of pods that arrived through bs_pods_apply (ids handed out by the insert wave) key the cursors as well"""
+    nodes, fit, groups, pods = template_scene(soa, 4410)
+    keep = np.arange(0, pods.p, 2)
+    with load_ctx(bsa, nodes, fit, groups, pods.take(keep)) as ctx:
+        late = np.arange(1, pods.p, 2)
+        ctx.apply_pods(remove=np.zeros(0, np.uint32), insert=pods.take(late))
+        queue = pods.take(np.concatenate([keep, late]))
+        s = oracle_pass(orc, nodes, fit, groups, queue, soa.STAGE_PREFILTER)
+        check_pass(ctx, s, soa, "patched queue")
