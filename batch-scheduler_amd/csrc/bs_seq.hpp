@@ -89,6 +89,13 @@ struct SeqDev {
 #define BS_SEQ_T(k) ((void)0)
 #endif
 
+// ... and a finer split (thread 0's clock, kept in LDS so that it costs the kernel no registers): info[32 + k]
+#ifdef BS_SEQ_PROBE
+#define BS_SEQ_P(k) do { if (threadIdx.x == 0) { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); sh_.ph2[k] += _t - sh_.tl2; sh_.tl2 = _t; } } while (0)
+#else
+#define BS_SEQ_P(k) ((void)0)
+#endif
+
 #ifdef BS_SEQ_PROBE
 __device__ unsigned long long g_seq_scan_ph[8];
 #define BS_SCAN_T(k) do { if (threadIdx.x == 0) { const unsigned long long _t = (unsigned long long)__builtin_readcyclecounter(); g_seq_scan_ph[k] += _t - stl; stl = _t; } } while (0)
@@ -234,6 +241,9 @@ struct SeqShared {
   // barriers inside the search rely on.  An entry that was evicted only costs the next search of that class its head start.
   unsigned long long cur_kn[kSeqCursors];
   uint32_t cur_fc[kSeqCursors];
+#ifdef BS_SEQ_PROBE
+  unsigned long long ph2[32], tl2;
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -569,6 +579,7 @@ __device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const Se
       }
     }
     unsigned long long cm = __ballot(cand);
+    BS_SEQ_P(5);
     // ---- this wave's candidate tiles of the chunk, in list order, until one holds a covering row
     while (cm && mine == BS_INF) {
       const uint32_t tile = chunk + ((uint32_t)w << 6) + (uint32_t)(__ffsll((long long)cm) - 1);
@@ -601,10 +612,13 @@ __device__ __forceinline__ uint32_t seq_scan_cached(const NodesDev& nd, const Se
       } else seq_cache_put<TS>(prm, ch, slot, tile, x, row, pres, false);      // looked at in vain: the tile's maxima become exact
     }
   }
+  BS_SEQ_P(6);
   if (lane == 0) sh_.fk[0][w] = mine;
   lds_barrier();
   if (threadIdx.x == 0) sh_.hit_w[hp] = BS_INF;               // (re-armed behind the barrier; the NEXT search uses the other word)
-  return seq_row_min_u32(lane < kSeqWaves ? sh_.fk[0][lane] : BS_INF);
+  const uint32_t fk_all = seq_row_min_u32(lane < kSeqWaves ? sh_.fk[0][lane] : BS_INF);
+  BS_SEQ_P(7);
+  return fk_all;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -641,6 +655,7 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
   const uint32_t pb = 0, hp = hit_par;
   hit_par ^= 1u;
   if (!drained) __syncthreads();                                            // the assume steps of earlier pods have landed before a tile is read
+  BS_SEQ_P(10);
   uint32_t mine = BS_INF;
   int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES], l07[BS_MAX_LANES], l10[BS_MAX_LANES];
 #pragma unroll
@@ -720,6 +735,7 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
       }
     }
   }
+  BS_SEQ_P(11);
   {
     const bool owner = mine != BS_INF && (uint32_t)lane == (mine & 63u);
     if (owner) { sh_.pick[pb][w] = mine; sh_.asm_ap[pb][w] = ap; sh_.asm_rp[pb][w] = rp; sh_.asm_fit[pb][w] = fbits; }
@@ -733,6 +749,7 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
       out.ap = sh_.asm_ap[pb][ww]; out.rp = sh_.asm_rp[pb][ww]; out.fitbits = sh_.asm_fit[pb][ww];
     }
     if (threadIdx.x == 0) sh_.hit_w[hp] = BS_INF;             // (re-armed behind the barrier; the NEXT search uses the other word)
+    BS_SEQ_P(12);
     if (found != BS_INF && owner && mine == found) {
       // ---- assume (NodeInfo.AddPod): requested += request, pods lane + 1; the left arrays and the meta word follow
       const uint32_t at = found;
@@ -775,6 +792,7 @@ __device__ __forceinline__ uint32_t seq_pick(const NodesDev& nd, const SeqDev& s
       }
     }
   }
+  BS_SEQ_P(13);
   return found;
 }
 
@@ -941,6 +959,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
   BS_SEQ_FULL_BARRIER();
 #ifdef BS_SEQ_PROBE
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = (unsigned long long)__builtin_readcyclecounter();
+  if (t0) { for (int k = 0; k < 32; ++k) sh_.ph2[k] = 0; sh_.tl2 = tl; }
 #endif
 
   int32_t gi_next = P ? pods.group[0] : BS_POD_NOT_GROUPED;
@@ -948,6 +967,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
   for (uint32_t i = 0; i < P; ++i) {
     lds_barrier();                                           // keys / bounds / wait list as the previous pod left them
     BS_SEQ_T(6);
+    BS_SEQ_P(0);
     const int32_t gi = gi_next;
     const uint32_t pflags = pflags_next;
     {                                                        // the next pod's first fields are on their way while this one is decided
@@ -985,6 +1005,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       own.seen = true;
     }
     BS_SEQ_T(0);
+    BS_SEQ_P(1);
     uint32_t gflags = grouped ? own.flags : 0u;              // of the pod's own group, as this PreFilter call leaves them
     const uint32_t gmatched = grouped ? own.matched : 0u, gsc = grouped ? own.sc : 0u;
 
@@ -1122,10 +1143,12 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
 
     // ---- the node scan of this PreFilter call
     BS_SEQ_T(0);
+    BS_SEQ_P(2);
     bool drained = false;                                    // this pod has already waited for the stores of earlier assume steps
     if (scan) {
       uint32_t first_k;
       if (stores_pending) { __syncthreads(); stores_pending = false; }
+      BS_SEQ_P(3);
       drained = true;
       if (prm.cache_slots) {
         const uint32_t key = (tcls << 1) | (pct07 ? 1u : 0u);
@@ -1152,6 +1175,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
 #pragma unroll
         for (uint32_t c = 0; c < kSeqCacheSlots; ++c)
           if (c == sel) slot_age[c] = age_ctr;
+        BS_SEQ_P(4);
         first_k = seq_scan_cached<TS>(nd, sq, prm, sh_, ch, sel, tcls, pct07, R, hit_par, n_rounds);
       } else {
         first_k = seq_scan<TS>(nd, sq, prm, sh_, tcls, pct07, R, n_rounds);
@@ -1165,6 +1189,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     }
     // ---- node choice + assume (WRITE PHASE from here on)
     BS_SEQ_T(3);
+    BS_SEQ_P(8);
     uint32_t at = BS_INF;
     if (BS_PF_IS_PASS(code)) {
       q.pcls = pods.cls[i];
@@ -1184,6 +1209,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
         const unsigned long long cv = sh_.cur_kn[ce];
         if ((uint32_t)(cv >> 32) == pc + 1u && sh_.cur_fc[ce] == q.pcls) start = (uint32_t)cv;
       }
+      BS_SEQ_P(9);
       if (cur_ok && start >= nd.n) {
         at = BS_INF;                                         // an identical request found no node before, and nothing has been freed since
       } else {
@@ -1243,6 +1269,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       }
     }
     BS_SEQ_T(4);
+    BS_SEQ_P(14);
     if (deny) { gflags |= BS_GROUP_DENIED; own.flags = gflags; }
     if (t0) {
       sq.pf_code[i] = (uint8_t)code;
@@ -1250,6 +1277,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       if (sq.pf_leader) sq.pf_leader[i] = sop_leader;
       if (deny) sq.g_flags[gi] = (uint8_t)gflags;
     }
+    BS_SEQ_P(15);
     if (at != BS_INF && !grouped) {                          // core.go:269-272: Permit lets it through at once
       if (t0) sq.pod_node[i] = (int32_t)at;
     } else if (at != BS_INF) {
@@ -1330,6 +1358,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       ldr.head = h;
     }
     BS_SEQ_T(5);
+    BS_SEQ_P(16);
   }
   BS_SEQ_FULL_BARRIER();
   if (t0) {
@@ -1344,6 +1373,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
 #ifdef BS_SEQ_PROBE
     for (int k = 0; k < 8; ++k) sq.info[8 + k] = ph[k];
     for (int k = 0; k < 8; ++k) { sq.info[16 + k] = g_seq_scan_ph[k]; g_seq_scan_ph[k] = 0; }
+    for (int k = 0; k < 32; ++k) sq.info[32 + k] = sh_.ph2[k];
 #endif
   }
 }

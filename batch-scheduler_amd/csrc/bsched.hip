@@ -3250,7 +3250,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   const size_t o_rp = o; o = align256(o + cap * 4);
   const size_t o_ft = o; o = align256(o + cap * 8);
   const size_t o_rt = o; o = align256(o + cap * 8);
-  const size_t o_info = o; o = align256(o + 256);
+  const size_t o_info = o; o = align256(o + 512);
   HIPCHK(c, c->d_seq.reserve(o));
   uint8_t* base = c->d_seq.as<uint8_t>();
   GroupsDev gr = groups_dev(c);
@@ -3306,7 +3306,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   }
   // first-fit cursors per request class (bs_seq.hpp, seq_pick): BS_SEQ_NO_CURSOR=1 = every search starts at the head of the list
   prm.use_cursor = (P && sq.pclass && !(std::getenv("BS_SEQ_NO_CURSOR") && std::atoi(std::getenv("BS_SEQ_NO_CURSOR")))) ? 1u : 0u;
-  HIPCHK(c, hipMemsetAsync(base + o_info, 0, 256, c->stream));
+  HIPCHK(c, hipMemsetAsync(base + o_info, 0, 512, c->stream));
   const PodsDev pd = pods_dev(c);
   const NodesDev nd = nodes_dev(c);
   switch (c->S <= 4 ? (int)c->S : -1) {
@@ -3340,6 +3340,13 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
                                    info[10], info[11], info[12], info[13], info[14]);
     if (std::atoi(e)) std::fprintf(stderr, "  scan rounds (thread 0): issue-next-loads %llu select %llu wave-scans %llu lds-writes %llu barrier %llu fk-check %llu offsets+compare %llu tail %llu\n",
                                    info[16], info[17], info[18], info[19], info[20], info[21], info[22], info[23]);
+    if (std::atoi(e)) {                                      // the finer split of thread 0's time (BS_SEQ_P in bs_seq.hpp)
+      static const char* nm[17] = {"top-barrier", "group-loads", "control", "scan:drain", "scan:slot", "scan:candidates", "scan:tiles", "scan:barrier+min", "scan:tail",
+                                   "pick:request", "pick:drain", "pick:tiles", "pick:barrier+min", "pick:assume", "summaries", "result-stores", "permit"};
+      std::fprintf(stderr, "  thread 0, cycles:");
+      for (int k2 = 0; k2 < 17; ++k2) std::fprintf(stderr, " %s %llu |", nm[k2], info[32 + k2]);
+      std::fprintf(stderr, "\n");
+    }
   }
   if (P) {
     if (out->pf_code) std::memcpy(out->pf_code, rb + o_code, P);

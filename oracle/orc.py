@@ -242,6 +242,12 @@ class Sop:
     def leader(self) -> int:
         return int(self.struct.max_finished_pg) if self.struct.has_max_status else -1
 
+    def carry(self, leader: int):
+        """sop.maxFinishedPG / maxPGStatus as an earlier call on another Sop left them (the fields outlive a PreFilter call)"""
+        self.struct.max_finished_pg = int(leader) if leader >= 0 else -1
+        self.struct.has_max_status = 1 if leader >= 0 else 0
+        return self
+
     def prefilter(self, pods, i: int):
         ps = pods.as_struct()
         fk = C.c_uint32(0)
@@ -288,12 +294,14 @@ def batch_threads(snap: Snapshot, groups, subsets, stages: int, bitmap: bool = F
     return ns * 1e-9, sum(s.iters for s in sops), list(zip(sops, outs))
 
 
-def seq_replay(nodes, fit, groups, pods, stages: int = soa.STAGE_PREFILTER | soa.STAGE_TALLY) -> dict:
+def seq_replay(nodes, fit, groups, pods, stages: int = soa.STAGE_PREFILTER | soa.STAGE_TALLY, leader: int = -1) -> dict:
     """One sequential scheduling pass over the queue, pod by pod (bs_oracle_seq.c): PreFilter, first-fit node choice, assume,
-    Permit, release at the quorum.  Works on COPIES of nodes / groups; returns them with the per-gang release records."""
+    Permit, release at the quorum.  Works on COPIES of nodes / groups; returns them with the per-gang release records.
+    `leader`: sop.maxFinishedPG / maxPGStatus (core.go:58-59) as an earlier call left them (-1: none yet)."""
     nodes, groups = nodes.copy(), groups.copy()
     snap = Snapshot(nodes, fit)
     sop = Sop(snap, groups)                     # (Sop copies the groups once more: sop.groups is the mutated state)
+    sop.carry(leader)
     cap = max(groups.g, 1)
     pf = np.zeros(max(pods.p, 1), np.uint8)
     pod_node = np.full(max(pods.p, 1), -1, np.int32)
@@ -309,7 +317,7 @@ def seq_replay(nodes, fit, groups, pods, stages: int = soa.STAGE_PREFILTER | soa
     k = min(int(io.n_released), cap)
     return dict(released_group=rg[:k].copy(), released_pods=rp[:k].copy(), first_ns=t_first[:k].copy(), ready_ns=t_ready[:k].copy(),
                 pod_node=pod_node[: pods.p].copy(), pf_code=pf[: pods.p].copy(), pf_first_k=fk[: pods.p].copy(), pf_leader=ld[: pods.p].copy(), n_released=int(io.n_released), total_ns=int(io.total_ns), pick_ns=int(io.pick_ns),
-                nodes=nodes, groups=sop.groups, iters=sop.iters)
+                nodes=nodes, groups=sop.groups, iters=sop.iters, leader=sop.leader)
 
 
 class TTL:

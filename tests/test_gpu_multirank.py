@@ -87,3 +87,31 @@ def test_ranks_meet_in_a_collective(mode, world, bsa, soa, orc):
         pytest.skip(f"RCCL with {world} ranks on one GPU: {status}")
     assert all(s == "ok" for s in status), status
     _check(res, mode, bsa, soa, orc, config, scenario, seed, pods, groups, exp)
+
+
+@pytest.mark.parametrize("scenario", ["tail", "cold"], ids=["partitioned", "replicated"])
+def test_bench_under_the_drivers_launcher_with_the_collective_path(scenario):
+    """bench.py the way the driver launches it for N > 1 (python -m torch.distributed.run, one rank per GPU, RCCL through
+    torch.distributed), at the world size this box has — 1 — with BS_FORCE_DIST=1 so that everything a multi-GPU run executes is
+    executed: process group on `nccl`, ownership, the bound admit buffer, the all-reduce stream-ordered on the library's stream,
+    bs_batch_finish, the max-over-ranks clock.  Its decisions must be the plain single-GPU run's."""
+    import json
+    root = os.path.dirname(HERE)
+    common = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--config", "cfg2", "--scenario", scenario, "--no-extras", "--no-cpu-baseline", "--no-pmc"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    port = 29600 + os.getpid() % 300
+    forced = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                             os.path.join(root, "bench.py"), *common], capture_output=True, text=True, timeout=600, cwd=root, env=dict(env, BS_FORCE_DIST="1"))
+    assert forced.returncode == 0, (forced.stdout[-2000:], forced.stderr[-3000:])
+    line = lambda r: json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    a, b = line(plain), line(forced)
+    assert b["ranks"]["rccl_world_size"] == 1 and b["ranks"]["backend"] == "nccl" and b["ranks"]["mode"] == scenario_mode(scenario)
+    assert b["ranks"]["owned_pods_per_rank"] == [1000] and "all-reduce" in b["config"]["parallelism"]
+    assert b["config"]["decisions"] == a["config"]["decisions"] and b["config"]["groups_ready"] == a["config"]["groups_ready"]
+    assert b["n_gpus"] == 1 and b["value"] > 10e6 and b["roofline"] is not None and b["cpu_baseline"] is None
+
+
+def scenario_mode(scenario):
+    return "partitioned" if scenario != "cold" else "replicated"
