@@ -9,15 +9,30 @@ import pytest
 
 from fullsize import ChurnStream
 from test_gpu_parity import assert_batch_equal, load_ctx
+import naive_ref as nv
+from scenarios import random_objects
+from test_gpu_parity import _force_class_mode
 from test_gpu_queue import random_delta, scene
 from test_gpu_seq import assert_groups_equal
 
 pytestmark = pytest.mark.gpu
+EXTRA = int(__import__("os").environ.get("BS_FUZZ_EXTRA", "0"))      # a longer one-off hunt: BS_FUZZ_EXTRA=3000 pytest tests/test_gpu_fuzz_cycle.py
 NAMES = ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible", "group_admit", "group_ready")
 
 
-def run_sequence(seed, steady, bsa, soa, orc, rounds=16):
-    rng, nodes, fit, groups, pods = scene(seed, bsa, soa, steady)
+def big_scene(seed, soa, steady):
+    """several blocks of pods, several tiles of nodes, more groups than a wave: the hand-overs between blocks are in play"""
+    rng = np.random.default_rng(seed)
+    sc = random_objects(seed, n_nodes=200 + seed % 150, n_groups=70, n_pods=900, n_scalars=seed % 3, n_classes=3)
+    nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"], denied=sc["denied"], permitted=sc["permitted"])
+    if steady:
+        _force_class_mode(groups, rng, 3)
+        groups.matched[:] = rng.integers(1, 4, groups.g)
+    return rng, nodes, fit, groups, pods
+
+
+def run_sequence(seed, steady, bsa, soa, orc, rounds=16, big=False):
+    rng, nodes, fit, groups, pods = big_scene(seed, soa, steady) if big else scene(seed, bsa, soa, steady)
     nodes, groups, cur = nodes.copy(), groups.copy(), pods
     leader = -1                                                # sop.maxFinishedPG as the context carries it
     log = []
@@ -99,6 +114,12 @@ def run_sequence(seed, steady, bsa, soa, orc, rounds=16):
 
 
 @pytest.mark.parametrize("steady", [True, False], ids=["steady", "positional"])
-@pytest.mark.parametrize("seed", range(9500, 9600))
+@pytest.mark.parametrize("seed", range(9500, 9600 + EXTRA))
 def test_random_cycle_sequences(seed, steady, bsa, soa, orc):
     run_sequence(seed, steady, bsa, soa, orc, rounds=20)
+
+
+@pytest.mark.parametrize("steady", [True, False], ids=["steady", "positional"])
+@pytest.mark.parametrize("seed", range(9700 + 100000, 9720 + 100000 + EXTRA // 10))
+def test_random_cycle_sequences_on_larger_scenes(seed, steady, bsa, soa, orc):
+    run_sequence(seed, steady, bsa, soa, orc, rounds=12, big=True)
