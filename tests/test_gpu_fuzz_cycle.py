@@ -123,3 +123,46 @@ def test_random_cycle_sequences(seed, steady, bsa, soa, orc):
 @pytest.mark.parametrize("seed", range(9700 + 100000, 9720 + 100000 + EXTRA // 10))
 def test_random_cycle_sequences_on_larger_scenes(seed, steady, bsa, soa, orc):
     run_sequence(seed, steady, bsa, soa, orc, rounds=12, big=True)
+
+
+def test_two_contexts_on_two_threads(bsa, soa, orc):
+    """include/bsched.h: calls on ONE context are serialised by the caller — two contexts are independent.  Two threads, each driving
+    its own context through batches, queue patches and passes at the same time (ctypes drops the GIL inside every call), must each see
+    exactly what a lone context sees: nothing in the library is shared between contexts."""
+    import threading
+    plans = []
+    for seed in (9801, 9802):
+        rng, nodes, fit, groups, pods = big_scene(seed, soa, steady=(seed % 2 == 1))
+        steps, cur = [], pods
+        for rnd in range(10):
+            d = random_delta(rng, cur, soa, novel_base=30 * rnd)
+            cur = cur.patched(**d)
+            exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(cur, soa.STAGE_ALL, bitmap=False)
+            seq = orc.seq_replay(nodes, fit, groups, cur, soa.STAGE_PREFILTER) if rnd == 9 else None
+            steps.append((d, exp, seq))
+        plans.append((nodes, fit, groups, pods, steps))
+    errors = []
+
+    def drive(plan, tag):
+        try:
+            nodes, fit, groups, pods, steps = plan
+            with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+                for rnd, (d, exp, seq) in enumerate(steps):
+                    ctx.apply_pods(**d)
+                    ctx.run(soa.STAGE_ALL | (soa.BATCH_HOST_RESULTS if rnd % 2 else 0))
+                    assert_batch_equal(ctx.read(bitmap=False, rows=False), exp, f"thread {tag} round {rnd}", bitmap=False)
+                    if seq is not None:
+                        r = ctx.seq_run(soa.STAGE_PREFILTER)
+                        for name in ("pf_code", "pf_first_k", "pf_leader", "pod_node"):
+                            assert np.array_equal(r[name], seq[name]), f"thread {tag}: pass: {name}"
+        except BaseException as e:                           # noqa: BLE001 — handed to the main thread
+            errors.append((tag, e))
+
+    threads = [threading.Thread(target=drive, args=(p, k)) for k, p in enumerate(plans)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a thread is stuck"
+    if errors:
+        raise errors[0][1]
