@@ -17,7 +17,7 @@ LIB_DIR = os.environ.get("BS_LIB_DIR") or HERE
 PREBUILT_ONLY = bool(os.environ.get("BS_LIB_DIR"))
 LIB_PATH = os.path.join(LIB_DIR, "libbsched.so")
 SOURCES = ["bsched.hip"]
-HEADERS = ["bs_common.hpp", "bs_kernels.hpp", "bs_fast.hpp", "bs_epoch.hpp", "bs_queue.hpp", "bs_fdeny.hpp", "bs_seq.hpp", "bs_sort.hpp", "bs_fit.hpp", os.path.join("..", "..", "include", "bsched.h")]
+HEADERS = ["bs_common.hpp", "bs_kernels.hpp", "bs_fast.hpp", "bs_filter_t.hpp", "bs_epoch.hpp", "bs_queue.hpp", "bs_fdeny.hpp", "bs_seq.hpp", "bs_sort.hpp", "bs_fit.hpp", os.path.join("..", "..", "include", "bsched.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

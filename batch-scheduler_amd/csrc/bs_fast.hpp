@@ -35,6 +35,7 @@
 #pragma once
 
 #include "bs_kernels.hpp"
+#include "bs_filter_t.hpp"
 
 #ifdef BS_NT_TABLES
 #define BS_TBL_STORE(p, v) __builtin_nontemporal_store((v), (p))
@@ -767,6 +768,28 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter(PodsDev pods, NodesDev
     scan_loop<S, true, 1>(bt, prm, m, jcap, 0u, 0u, 1u, blockIdx.x, scan_blocks, s_rows[wave_id()]);
   else
     filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - scan_blocks, gridDim.x - scan_blocks, prm.stamp, 2u * prm.k_host);
+}
+// ... and the two roles of that launch as launches of their own (BS_TP_FILTER=1..4, see run_fast): one kernel's register footprint is
+// the maximum over its roles — the scan's 137 VGPRs (S = 1) hold the Filter loop, the role that does the work when thousands of
+// requests are distinct, at three waves per SIMD.  On its own the Filter loop needs 109 VGPRs as written for the latency regime
+// (four requests per step, node blocks double-buffered: 4 waves), 93 with two requests per step (5), 75 without the double buffer (6),
+// 72 when the compiler is asked for seven waves (k_fast_filter_w7); none of them touches scratch (tools/kernel_resources.py).
+template <int S>
+__global__ __launch_bounds__(256) void k_fast_scan(BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap) {
+  __shared__ int64_t s_rows[4][64][4 + S];
+  scan_loop<S, true, 1>(bt, prm, m, jcap, 0u, 0u, 1u, blockIdx.x, gridDim.x, s_rows[wave_id()]);
+}
+template <int PU, bool DB>
+__global__ __launch_bounds__(256) void k_fast_filter(PodsDev pods, NodesDev nd, BatchDev bt, BatchParams prm, uint32_t filter_waves, uint32_t ustride) {
+  filter_loop<2, PU, DB>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x, gridDim.x, prm.stamp, 2u * prm.k_host);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_fast_filter_w7(PodsDev pods, NodesDev nd, BatchDev bt, BatchParams prm, uint32_t filter_waves,
+                                                                                                uint32_t ustride) {
+  filter_loop<2, 2, false>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x, gridDim.x, prm.stamp, 2u * prm.k_host);
+}
+// BS_TP_FILTER=5: the transposed item (bs_filter_t.hpp): lanes are request slots, nodes come through the scalar cache
+__global__ __launch_bounds__(256) void k_fast_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t filter_waves, uint32_t ustride) {
+  filter_loop_t(nd, bt, filter_waves, ustride, prm.collect_stats, blockIdx.x, gridDim.x, prm.stamp, 2u * prm.k_host);
 }
 __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
   fast_final_block(pods, gr, nd, b, prm, query_blocks, blockIdx.x, gridDim.x, 0u);

@@ -1,0 +1,259 @@
+// bs_filter_t.hpp — the TRANSPOSED Filter item (computeResourceSatisfied, core.go:514-564), for the throughput regime.
+//
+// filter_item (bs_kernels.hpp) is written for the latency regime: lanes are NODES while it compares, a slot's request is the
+// wave-uniform operand (broadcast from LDS), the compare's EXEC mask is dropped into the slot's lane with two v_writelane, and
+// what counts is the length of one item's load chain.  With thousands of distinct requests in a batch (bench.py
+// scenarios.all_distinct_requests; 10^8 .. 10^9 pod x node pairs really evaluated) every resident wave has compares to do, and
+// what counts is VALU instructions per pair and waves per SIMD.  Here lanes are REQUEST SLOTS for the whole item: a lane keeps
+// its request R (4 x int64) in VGPRs, and the NODE is the wave-uniform operand — a node's `left` (getLeftResource, core.go:436-475)
+// comes through the scalar cache (one s_load_dwordx8 = four nodes of one resource lane; the waves of a node run read the same
+// few KB) and sits in SGPRs:
+//     s_mov_b64 exec, em ; k x v_cmpx_ge_i64 vcc, left[j] (SGPR), R[j] (VGPR) ; v_or_b32 word, bit, word ; s_lshl_b32 bit, bit, 1
+// EXEC behind the chain = the slots this node can hold (case 2, core.go:551-555), and the OR under that EXEC sets the node's bit
+// in exactly those lanes' words: (k + 1) VALU per node and 64 slots — filter_item: (k + 2) VALU + 4 wait states per slot and 64
+// nodes —, no LDS, no v_writelane, no transposition at the end (a lane already owns its slot's word), and a register footprint
+// that lets eight waves share a SIMD.
+// The pod-independent masks of a node block (in range, evaluable, case 3 for the tile's common leader: core.go:558-563) still
+// want lanes = NODES: one vector load of the block + ballots, as in filter_item; a tile whose slots name different leaders (it
+// straddles the two leader halves of the slot array) gets case 3 from a second pass of the same chain against the lane's own M.
+// Scalar loads run up to the end of the last 64-node block: left4 carries 64 entries of padding behind its fourth lane
+// (upload_nodes), a block's tail beyond n reads the next lane's row or the padding, and those nodes are masked by `okmask`.
+// Results are bit-identical to filter_item's (tests/test_gpu_throughput.py runs every form against the oracle).
+#pragma once
+
+#include "bs_kernels.hpp"
+
+namespace bs {
+
+typedef const __attribute__((address_space(4))) int64_t* cnode_t;
+
+// four consecutive nodes (a[u], bq[u], cq[u], d[u] = node u's left on resource lane 0..3) against the lanes' requests R;
+// em = lanes to evaluate; w = the word half the nodes belong to; sb = bit of the first node (shifted on the way)
+template <int MASK>
+__device__ __forceinline__ void filter_node4(unsigned long long em, const int64_t (&R)[4], const int64_t (&a)[4], const int64_t (&bq)[4],
+                                             const int64_t (&cq)[4], const int64_t (&d)[4], uint32_t& w, uint32_t& sb);
+#define BS_FN4_NODE(f0, f1, f2, f3, u)                                                                                   \
+  "s_mov_b64 exec, %[em]\n\t"                                                                                            \
+  BS_OPT(f0, "v_cmpx_ge_i64 vcc, %[a" #u "], %[R0]\n\t") BS_OPT(f1, "v_cmpx_ge_i64 vcc, %[b" #u "], %[R1]\n\t")            \
+  BS_OPT(f2, "v_cmpx_ge_i64 vcc, %[c" #u "], %[R2]\n\t") BS_OPT(f3, "v_cmpx_ge_i64 vcc, %[d" #u "], %[R3]\n\t")            \
+  "v_or_b32 %[w], %[sb], %[w]\n\t"                                                                                       \
+  "s_lshl_b32 %[sb], %[sb], 1\n\t"
+#define BS_DEF_FILTER_NODE4(MASK, f0, f1, f2, f3)                                                                        \
+  template <>                                                                                                            \
+  __device__ __forceinline__ void filter_node4<MASK>(unsigned long long em, const int64_t (&R)[4], const int64_t (&a)[4], \
+                                                     const int64_t (&bq)[4], const int64_t (&cq)[4], const int64_t (&d)[4], \
+                                                     uint32_t& w, uint32_t& sb) {                                         \
+    asm volatile(BS_FN4_NODE(f0, f1, f2, f3, 0) BS_FN4_NODE(f0, f1, f2, f3, 1) BS_FN4_NODE(f0, f1, f2, f3, 2)              \
+                 BS_FN4_NODE(f0, f1, f2, f3, 3) "s_mov_b64 exec, -1"                                                     \
+                 : [w] "+v"(w), [sb] "+s"(sb)                                                                            \
+                 : [em] "s"(em), [R0] "v"(R[0]), [R1] "v"(R[1]), [R2] "v"(R[2]), [R3] "v"(R[3]), [a0] "s"(a[0]),         \
+                   [a1] "s"(a[1]), [a2] "s"(a[2]), [a3] "s"(a[3]), [b0] "s"(bq[0]), [b1] "s"(bq[1]), [b2] "s"(bq[2]),    \
+                   [b3] "s"(bq[3]), [c0] "s"(cq[0]), [c1] "s"(cq[1]), [c2] "s"(cq[2]), [c3] "s"(cq[3]), [d0] "s"(d[0]),  \
+                   [d1] "s"(d[1]), [d2] "s"(d[2]), [d3] "s"(d[3])                                                        \
+                 : "vcc", "scc");                                                                                        \
+  }
+BS_DEF_FILTER_NODE4(1, 1, 0, 0, 0)
+BS_DEF_FILTER_NODE4(2, 0, 1, 0, 0)
+BS_DEF_FILTER_NODE4(3, 1, 1, 0, 0)
+BS_DEF_FILTER_NODE4(4, 0, 0, 1, 0)
+BS_DEF_FILTER_NODE4(5, 1, 0, 1, 0)
+BS_DEF_FILTER_NODE4(6, 0, 1, 1, 0)
+BS_DEF_FILTER_NODE4(7, 1, 1, 1, 0)
+BS_DEF_FILTER_NODE4(8, 0, 0, 0, 1)
+BS_DEF_FILTER_NODE4(9, 1, 0, 0, 1)
+BS_DEF_FILTER_NODE4(10, 0, 1, 0, 1)
+BS_DEF_FILTER_NODE4(11, 1, 1, 0, 1)
+BS_DEF_FILTER_NODE4(12, 0, 0, 1, 1)
+BS_DEF_FILTER_NODE4(13, 1, 0, 1, 1)
+BS_DEF_FILTER_NODE4(14, 0, 1, 1, 1)
+BS_DEF_FILTER_NODE4(15, 1, 1, 1, 1)
+
+// one 64-node block (first node n0, a multiple of 64) against the lanes in `em`: per lane the 64 bits "left >= R on every
+// compared resource lane".  Bits of lanes outside `em` stay 0.
+// The scalar loads of the NEXT four nodes are issued before the compares of the current four (their results are already in
+// SGPRs: `filter_sgprs_ready` makes the compiler wait for them BEFORE it issues the next loads — scalar loads return out of
+// order, so a wait behind the issue would wait for both).
+__device__ __forceinline__ void filter_sgprs_ready(const int64_t (&s)[4][4]) {
+  asm volatile("" ::"s"(s[0][0]), "s"(s[0][1]), "s"(s[0][2]), "s"(s[0][3]), "s"(s[1][0]), "s"(s[1][1]), "s"(s[1][2]), "s"(s[1][3]), "s"(s[2][0]),
+               "s"(s[2][1]), "s"(s[2][2]), "s"(s[2][3]), "s"(s[3][0]), "s"(s[3][1]), "s"(s[3][2]), "s"(s[3][3]));
+}
+template <int MASK>
+__device__ __forceinline__ void filter_block_t(cnode_t L4, uint32_t stride, uint32_t n0, unsigned long long em, const int64_t (&R)[4],
+                                               uint32_t (&wd)[2]) {
+  auto load4 = [&](uint32_t nn, int64_t (&s)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[j][u] = ((MASK >> j) & 1) ? L4[(size_t)j * stride + nn + (uint32_t)u] : 0;
+  };
+  int64_t cur[4][4], nxt[4][4];
+  load4(n0, cur);
+  uint32_t w = 0, sb = 1u;
+#pragma unroll
+  for (uint32_t g = 0; g < 16u; ++g) {
+    filter_sgprs_ready(cur);
+    if (g + 1u < 16u) load4(n0 + (g + 1u) * 4u, nxt);
+    filter_node4<MASK>(em, R, cur[0], cur[1], cur[2], cur[3], w, sb);
+    if (g == 7u) { wd[0] = w; w = 0; sb = 1u; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cur[j][u] = nxt[j][u];
+  }
+  wd[1] = w;
+}
+__device__ __forceinline__ void filter_block_any(uint32_t lane_mask, cnode_t L4, uint32_t stride, uint32_t n0, unsigned long long em,
+                                                 const int64_t (&R)[4], uint32_t (&wd)[2]) {
+  switch (lane_mask) {
+    case 1: filter_block_t<1>(L4, stride, n0, em, R, wd); break;
+    case 2: filter_block_t<2>(L4, stride, n0, em, R, wd); break;
+    case 3: filter_block_t<3>(L4, stride, n0, em, R, wd); break;
+    case 4: filter_block_t<4>(L4, stride, n0, em, R, wd); break;
+    case 5: filter_block_t<5>(L4, stride, n0, em, R, wd); break;
+    case 6: filter_block_t<6>(L4, stride, n0, em, R, wd); break;
+    case 7: filter_block_t<7>(L4, stride, n0, em, R, wd); break;
+    case 8: filter_block_t<8>(L4, stride, n0, em, R, wd); break;
+    case 9: filter_block_t<9>(L4, stride, n0, em, R, wd); break;
+    case 10: filter_block_t<10>(L4, stride, n0, em, R, wd); break;
+    case 11: filter_block_t<11>(L4, stride, n0, em, R, wd); break;
+    case 12: filter_block_t<12>(L4, stride, n0, em, R, wd); break;
+    case 13: filter_block_t<13>(L4, stride, n0, em, R, wd); break;
+    case 14: filter_block_t<14>(L4, stride, n0, em, R, wd); break;
+    default: filter_block_t<15>(L4, stride, n0, em, R, wd); break;
+  }
+}
+
+// One item = (tile of 64 request slots, node blocks [w0, w1)); same contract and same outputs as filter_item.
+__device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ustride, uint32_t ptile, uint32_t w0,
+                                              uint32_t w1, uint32_t stamp) {
+  const int lane = lane_id();
+  const uint32_t p0 = ptile * 64u;
+  const uint32_t np = min(64u, U - p0);
+  const bool mine = (uint32_t)lane < np;
+  const uint32_t src = p0 + (uint32_t)lane;
+  // one round trip: the slot's flags word, its request R and leader request M, the cluster-wide bounds, the first node block
+  uint32_t myff = mine ? b.uflags[src] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  int64_t M[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
+  if (mine) {
+    const int64_t* rs = b.uparams + (size_t)src * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { R[j] = rs[j]; M[j] = rs[4 + j]; }
+  }
+  int64_t gl[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gl[j] = nd.lglob[j];
+  int64_t l[4], ln[4];                              // lanes = nodes: the block's left values, for the pod-independent masks only
+  uint8_t nfl, nfln = 0xFF;
+  auto load_block = [&](uint32_t w, int64_t (&dst)[4], uint8_t& fl) {
+    const uint32_t n = w * 64u + (uint32_t)lane;
+    fl = 0xFF;                                      // invalid
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j] = INT64_MIN;
+    if (w < w1 && n < nd.n) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[j] = nd.left4[(size_t)j * nd.stride + n];
+      fl = nd.flags[n];
+    }
+  };
+  load_block(w0, l, nfl);
+  if (stamp) myff = (myff >> 16) == stamp ? (myff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
+  const uint32_t myfl = myff >> 8;
+  const bool ev = myfl == BS_FL_EVALUATED;
+  if (!ev) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) M[j] = 0;
+  }
+  const unsigned long long evmask = __ballot(ev);
+  if (!evmask) return;                              // no slot of this tile is in use
+  // which resource lanes can decide anything for this tile (nd.lglob: cluster-wide min[4] / max[4] of left over the nodes Filter
+  // can evaluate): a lane is free when even the smallest left covers every request of the tile; the tile fails everywhere when
+  // the largest left of some lane is below every request
+  const bool c2pod = ev && !(myff & 1u);
+  const unsigned long long c2mask = __ballot(c2pod);
+  uint32_t lane_mask = 0;
+  bool tile_allfail = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (__ballot(c2pod && !(gl[j] >= R[j]))) lane_mask |= 1u << j;
+    if (c2mask && !__ballot(c2pod && gl[4 + j] >= R[j])) tile_allfail = true;
+  }
+  // is the leader's single-member request M the same for every evaluated slot of the tile?
+  int64_t M0[4];
+  bool same = true;
+  const int first = __ffsll((long long)evmask) - 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    M0[j] = __shfl(M[j], first);
+    same = same && (M[j] == M0[j]);
+  }
+  const uint32_t lb0 = (uint32_t)__shfl((int)(myff & 2u), first);
+  same = same && ((myff & 2u) == lb0);
+  const bool uniformM = __ballot(ev && !same) == 0;
+  const unsigned long long lfmask = __ballot(ev && !(myff & 2u));     // lanes whose case 3 depends on the node (own M)
+
+  const cnode_t L4 = (cnode_t)(uintptr_t)nd.left4;
+  uint32_t cnt = 0;
+  for (uint32_t w = w0; w < w1; ++w) {
+    load_block(w + 1u, ln, nfln);                   // (in flight during this block's compare loop; invalid behind w1)
+    const bool nvalid = nfl != 0xFF;
+    const bool node_ok = nvalid && !(nfl & (BS_NODE_NIL | BS_NODE_NO_NODE));     // core.go:442-449
+    const unsigned long long in_range = __ballot(nvalid), okmask = __ballot(node_ok);
+    // case 2 per (slot, node)
+    uint32_t c2w[2] = {0u, 0u};
+    if (c2mask && !tile_allfail) {
+      if (lane_mask == 0u) { c2w[0] = (uint32_t)okmask; c2w[1] = (uint32_t)(okmask >> 32); }     // every lane is free
+      else filter_block_any(lane_mask, L4, nd.stride, w * 64u, c2mask, R, c2w);
+    }
+    unsigned long long c2 = (((unsigned long long)c2w[1] << 32) | c2w[0]) & okmask;
+    if (!c2pod) c2 = 0;
+    // case 3: nodes that cannot hold one leader member pass
+    unsigned long long lf;
+    if (uniformM) {
+      lf = 0;
+      if (!lb0) lf = __ballot(l[0] >= M0[0]) & __ballot(l[1] >= M0[1]) & __ballot(l[2] >= M0[2]) & __ballot(l[3] >= M0[3]);
+    } else {
+      uint32_t lfw[2] = {0u, 0u};
+      if (lfmask) filter_block_t<15>(L4, nd.stride, w * 64u, lfmask, M, lfw);
+      lf = ((unsigned long long)lfw[1] << 32) | lfw[0];
+      if (myff & 2u) lf = 0;
+    }
+    unsigned long long word;
+    if (ev) word = okmask & (c2 | ~lf);
+    else word = myfl < 16u ? in_range : 0ull;       // nil before any node lookup / error
+    if (mine) {
+      cnt += (uint32_t)__popcll(word);
+      b.fu_bitmap[(size_t)w * ustride + p0 + lane] = word;
+      if (b.h_rows && p0 + (uint32_t)lane < b.hstride) b.h_rows[(size_t)w * b.hstride + p0 + lane] = word;   // latency mode: the row goes home as well
+    }
+    nfl = nfln;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) l[j] = ln[j];
+  }
+  if (mine && cnt) atomicAdd(&b.fu_feas[p0 + lane], cnt);
+}
+
+// filter_loop's split of the work (tiles x node runs), items taken by filter_item_t
+__device__ __forceinline__ void filter_loop_t(const NodesDev& nd, const BatchDev& b, uint32_t target_waves, uint32_t ustride, uint32_t collect_stats,
+                                              uint32_t bx, uint32_t nblocks, uint32_t stamp, uint32_t slots) {
+  const uint32_t U = slots ? slots : 2u * __builtin_amdgcn_readfirstlane(*b.kclass);
+  const uint32_t W = (nd.n + 63u) / 64u;
+  if (!U || !W) return;
+  const uint32_t tiles = (U + 63u) / 64u;
+  uint32_t nsplit = max(1u, target_waves / tiles);
+  nsplit = min(nsplit, max((W + 1u) / 2u, 1u));
+  const uint32_t bpw = max(2u, (((W + nsplit - 1u) / nsplit + 1u) / 2u) * 2u);
+  const uint32_t nchunk = (W + bpw - 1u) / bpw;
+  const uint32_t items = tiles * nchunk;
+  for (uint32_t it = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()); it < items; it += nblocks * 4u) {
+    const uint32_t chunk = it / tiles, tile = it - chunk * tiles;                   // neighbours share the node run
+    if (collect_stats && chunk == 0) {
+      const uint32_t sl = tile * 64u + (uint32_t)lane_id();
+      const uint32_t uf = sl < U ? b.uflags[sl] : 0u;
+      const unsigned long long evs = __ballot(sl < U && ((uf >> 8) & 0xFFu) == BS_FL_EVALUATED && (!stamp || (uf >> 16) == stamp));
+      if (lane_id() == 0 && evs) atomicAdd((unsigned long long*)&b.stats[3], (unsigned long long)__popcll(evs));
+    }
+    filter_item_t(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), stamp);
+  }
+}
+
+}  // namespace bs

@@ -1804,25 +1804,29 @@ BS_DEF_FILTER_POD2(14, 0, 1, 1, 1)
 BS_DEF_FILTER_POD2(15, 1, 1, 1, 1)
 
 // the 64-pod loop of one step for a given lane subset; requests come from this wave's LDS slice
-template <int MASK>
+// PU = pods per step (their LDS reads are issued together): 4 everywhere except in the lean throughput-regime kernel (k_fast_filter),
+// where the registers of two more requests are worth less than another resident wave
+template <int MASK, int PU = 4>
 __device__ __forceinline__ void filter_pod_loop(uint32_t np, const int64_t (*sR)[4], const unsigned long long (&okmask)[2],
                                                 const int64_t (&l)[2][4], uint32_t (&vlo)[2], uint32_t (&vhi)[2]) {
-  for (uint32_t pp = 0; pp < np; pp += 4) {
-    int64_t R[4][4];
+  for (uint32_t pp = 0; pp < np; pp += PU) {
+    int64_t R[PU][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PU; ++u) {
       const uint32_t pu = min(pp + (uint32_t)u, np - 1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) R[u][j] = ((MASK >> j) & 1) ? sR[pu][j] : 0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < PU; ++u)
       filter_pod2<MASK>(min(pp + (uint32_t)u, np - 1), R[u], okmask[0], okmask[1], l[0], l[1], vlo[0], vhi[0], vlo[1], vhi[1]);
   }
 }
 
 // stamp != 0 (fast path): a slot is in use iff the stamp in bits 16.. of its flags word is this batch's.
-template <int NB>
+// DB: the node blocks of step w+NB are loaded during the pod loop of step w (double-buffered, 18 VGPRs); !DB: behind it (the lean
+// throughput-regime kernel: other resident waves cover the round trip)
+template <int NB, int PU = 4, bool DB = true>
 __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ustride, uint32_t ptile,
                                             uint32_t w0, uint32_t w1, uint32_t stamp = 0) {
   static_assert(NB == 2, "the inner statement handles two node blocks");
@@ -1916,7 +1920,9 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
   cflag_t FF = (cflag_t)(uintptr_t)b.uflags;
   uint32_t cnt = 0;
   for (uint32_t w = w0; w < w1; w += NB) {
-    if (w + NB < w1) load_blocks(w + NB, ln, nfln);
+    if constexpr (DB) {
+      if (w + NB < w1) load_blocks(w + NB, ln, nfln);
+    }
     unsigned long long okmask[NB], in_range[NB], nlf[NB];
     uint32_t vlo[NB], vhi[NB];
 #pragma unroll
@@ -1945,21 +1951,21 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) { vlo[nb] = (uint32_t)okmask[nb]; vhi[nb] = (uint32_t)(okmask[nb] >> 32); }
             break;
-          case 1: filter_pod_loop<1>(np, sR, okmask, l, vlo, vhi); break;
-          case 2: filter_pod_loop<2>(np, sR, okmask, l, vlo, vhi); break;
-          case 3: filter_pod_loop<3>(np, sR, okmask, l, vlo, vhi); break;
-          case 4: filter_pod_loop<4>(np, sR, okmask, l, vlo, vhi); break;
-          case 5: filter_pod_loop<5>(np, sR, okmask, l, vlo, vhi); break;
-          case 6: filter_pod_loop<6>(np, sR, okmask, l, vlo, vhi); break;
-          case 7: filter_pod_loop<7>(np, sR, okmask, l, vlo, vhi); break;
-          case 8: filter_pod_loop<8>(np, sR, okmask, l, vlo, vhi); break;
-          case 9: filter_pod_loop<9>(np, sR, okmask, l, vlo, vhi); break;
-          case 10: filter_pod_loop<10>(np, sR, okmask, l, vlo, vhi); break;
-          case 11: filter_pod_loop<11>(np, sR, okmask, l, vlo, vhi); break;
-          case 12: filter_pod_loop<12>(np, sR, okmask, l, vlo, vhi); break;
-          case 13: filter_pod_loop<13>(np, sR, okmask, l, vlo, vhi); break;
-          case 14: filter_pod_loop<14>(np, sR, okmask, l, vlo, vhi); break;
-          default: filter_pod_loop<15>(np, sR, okmask, l, vlo, vhi); break;
+          case 1: filter_pod_loop<1, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 2: filter_pod_loop<2, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 3: filter_pod_loop<3, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 4: filter_pod_loop<4, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 5: filter_pod_loop<5, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 6: filter_pod_loop<6, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 7: filter_pod_loop<7, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 8: filter_pod_loop<8, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 9: filter_pod_loop<9, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 10: filter_pod_loop<10, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 11: filter_pod_loop<11, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 12: filter_pod_loop<12, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 13: filter_pod_loop<13, PU>(np, sR, okmask, l, vlo, vhi); break;
+          case 14: filter_pod_loop<14, PU>(np, sR, okmask, l, vlo, vhi); break;
+          default: filter_pod_loop<15, PU>(np, sR, okmask, l, vlo, vhi); break;
         }
       }
       // lanes are pods now: finish the word
@@ -2006,11 +2012,15 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
         if (b.h_rows && p0 + (uint32_t)lane < b.hstride) b.h_rows[(size_t)(w + nb) * b.hstride + p0 + lane] = word;   // latency mode: the row goes home as well
       }
     }
+    if constexpr (DB) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      nfl[nb] = nfln[nb];
+      for (int nb = 0; nb < NB; ++nb) {
+        nfl[nb] = nfln[nb];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) l[nb][j] = ln[nb][j];
+        for (int j = 0; j < 4; ++j) l[nb][j] = ln[nb][j];
+      }
+    } else {
+      if (w + NB < w1) load_blocks(w + NB, l, nfl);
     }
   }
   if (mine && cnt) atomicAdd(&b.fu_feas[p0 + lane], cnt);
@@ -2019,7 +2029,7 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
 // Work loop over (tile of 64 request slots, run of node blocks).  The slot count is only known on the
 // device, so the grid is fixed and every wave derives the split itself: as many node runs as it takes to
 // give the whole grid something to do.  ustride = row stride of fu_bitmap (slot capacity).
-template <int NB>
+template <int NB, int PU = 4, bool DB = true>
 __device__ __forceinline__ void filter_loop(const PodsDev& pods, const NodesDev& nd, const BatchDev& b, uint32_t target_waves, uint32_t use_classes,
                                             uint32_t ustride, uint32_t collect_stats, uint32_t bx, uint32_t nblocks, uint32_t stamp = 0,
                                             uint32_t slots = 0) {
@@ -2040,7 +2050,7 @@ __device__ __forceinline__ void filter_loop(const PodsDev& pods, const NodesDev&
       const unsigned long long evs = __ballot(sl < U && ((uf >> 8) & 0xFFu) == BS_FL_EVALUATED && (!stamp || (uf >> 16) == stamp));
       if (lane_id() == 0 && evs) atomicAdd((unsigned long long*)&b.stats[3], (unsigned long long)__popcll(evs));
     }
-    filter_item<NB>(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), stamp);
+    filter_item<NB, PU, DB>(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), stamp);
   }
 }
 template <int NB>

@@ -235,6 +235,10 @@ struct bs_ctx {
   bool groups_launch_pending = false; // bs_groups_apply left its (inline) deltas + findMaxPG for the next launch: k_pods_apply takes them along, anything else flushes
   DeltaPack pending_dp{};
   uint32_t no_fuse_final = 0;        // BS_NO_FUSE_FINAL: launches B and C always as separate launches
+  uint32_t tp_filter = 0;            // BS_TP_FILTER (throughput regime = more than 16 tiles of class slots): 0 = scan and Filter roles in one launch,
+                                     // 1..4 = k_fast_scan, then k_fast_filter<4,DB> / <2,DB> / <2,!DB> / k_fast_filter_w7 (109 / 93 / 75 / 72 VGPRs),
+                                     // 5 = k_fast_scan, then k_fast_filter_t (the transposed item, bs_filter_t.hpp: 63 VGPRs)
+  uint32_t tp_share = 64;            // BS_TP_SHARE: scan shares per tile of class slots in that regime (at most)
   int fused_blocks_resident = -1;    // whole-chip residency of k_fast_scan_filter_final (blocks), -1 = not asked yet
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   uint32_t general_waves = 4096;     // scan grid cap of the general chain (tools/cold_sweep.py)
@@ -533,7 +537,7 @@ int upload_nodes(bs_ctx* c, uint32_t lo = 0) {
   HIPCHK(c, c->d_alloc.reserve(cap * L * 8));
   if (c->d_alloc.cap != old_cap_bytes) lo = 0;     // (re)allocated: nothing resident yet
   HIPCHK(c, c->d_nreq.reserve(cap * L * 8));
-  HIPCHK(c, c->d_left4.reserve(cap * 4 * 8));
+  HIPCHK(c, c->d_left4.reserve(cap * 4 * 8 + 64 * 8));   // + one node block of padding: k_fast_filter_t's scalar loads run to the end of the last 64-node block
   HIPCHK(c, c->d_lglob.reserve(64));
   HIPCHK(c, c->d_apres.reserve(cap * 4));
   HIPCHK(c, c->d_rpres.reserve(cap * 4));
@@ -686,6 +690,36 @@ static void launch_fast_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDe
     case 10: launch_fast_b_s<10>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
     case 11: launch_fast_b_s<11>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
     default: launch_fast_b_s<12>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
+  }
+}
+template <int S>
+static void launch_fast_scan_s(bs_ctx* c, dim3 grid, const BatchDev& bt, const BatchParams& prm, uint32_t nseg) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan<S>), grid, dim3(256), 0, c->stream, bt, prm, c->M, nseg);
+}
+static void launch_fast_scan(bs_ctx* c, dim3 grid, const BatchDev& bt, const BatchParams& prm, uint32_t nseg) {
+  switch (c->S) {
+    case 0: launch_fast_scan_s<0>(c, grid, bt, prm, nseg); break;
+    case 1: launch_fast_scan_s<1>(c, grid, bt, prm, nseg); break;
+    case 2: launch_fast_scan_s<2>(c, grid, bt, prm, nseg); break;
+    case 3: launch_fast_scan_s<3>(c, grid, bt, prm, nseg); break;
+    case 4: launch_fast_scan_s<4>(c, grid, bt, prm, nseg); break;
+    case 5: launch_fast_scan_s<5>(c, grid, bt, prm, nseg); break;
+    case 6: launch_fast_scan_s<6>(c, grid, bt, prm, nseg); break;
+    case 7: launch_fast_scan_s<7>(c, grid, bt, prm, nseg); break;
+    case 8: launch_fast_scan_s<8>(c, grid, bt, prm, nseg); break;
+    case 9: launch_fast_scan_s<9>(c, grid, bt, prm, nseg); break;
+    case 10: launch_fast_scan_s<10>(c, grid, bt, prm, nseg); break;
+    case 11: launch_fast_scan_s<11>(c, grid, bt, prm, nseg); break;
+    default: launch_fast_scan_s<12>(c, grid, bt, prm, nseg); break;
+  }
+}
+static void launch_fast_filter(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm) {
+  switch (c->tp_filter) {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_filter<4, true>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_filter<2, true>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_filter<2, false>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
+    case 4: hipLaunchKernelGGL(k_fast_filter_w7, grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
+    default: hipLaunchKernelGGL(k_fast_filter_t, grid, dim3(256), 0, c->stream, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
   }
 }
 // How many blocks of the fused launch the chip holds at once (occupancy API, minus one block per CU: the API can be one high,
@@ -1111,6 +1145,8 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_EPOCH")) c->no_epoch = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
+  if (const char* e = std::getenv("BS_TP_FILTER")) c->tp_filter = (uint32_t)std::min(5, std::max(0, std::atoi(e)));
+  if (const char* e = std::getenv("BS_TP_SHARE")) c->tp_share = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_NO_SPECULATE")) c->no_spec = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HOST_PROBE")) c->host_probe = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_SLOT_BITS")) { const int hb = std::atoi(e); c->slot_keep = hb >= 32 ? 0xFFFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
@@ -2055,7 +2091,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     }
   });
   const uint64_t hp2 = c->host_probe ? host_ns() : 0;
-  bool fused = false;
+  bool fused = false, tp_split = false;
   uint64_t hp3 = 0;
   // ---- launch B: node scan over the class slots | Filter evaluation over the Filter slots
   // The work loops size themselves on the device (the class count lives there); the grid only has to be large enough.
@@ -2067,7 +2103,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     const uint32_t tiles = cdiv(k_est, 64);
     const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * k_est, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
     auto scan_grid = [&](uint32_t nsub) {
-      const uint32_t items = tiles * std::min<uint32_t>(nsub == 4u ? nseg : 64u, cdiv(c->M, 64));
+      const uint32_t items = tiles * std::min<uint32_t>(nsub == 4u ? nseg : c->tp_share, cdiv(c->M, 64));
       return std::max<uint32_t>(1, std::min<uint32_t>(cdiv(c->target_waves, 4), nsub == 4u ? items : cdiv(items, 4)));
     };
     // the fused form (final blocks wait for the producers INSIDE the launch) only in the latency regime, and only when every block
@@ -2080,8 +2116,15 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
       const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
       launch_fast_bc(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
+    } else if (c->tp_filter && fblocks && tiles > 16) {
+      // the throughput regime with the two roles as launches of their own: the scan at its register footprint, the Filter loop at a
+      // leaner one (more resident waves); same stream, the scan first — its items are dependent-load chains that would otherwise sit
+      // in the wave slots the Filter loop can fill
+      launch_fast_scan(c, dim3(scan_blocks), bt, prm, c->tp_share);
+      launch_fast_filter(c, dim3(fblocks), pd, nd, bt, prm);
+      tp_split = true;
     } else {
-      launch_fast_b(c, dim3(scan_blocks + fblocks), pd, nd, bt, prm, 64u, scan_blocks);
+      launch_fast_b(c, dim3(scan_blocks + fblocks), pd, nd, bt, prm, c->tp_share, scan_blocks);
     }
   });
   if (c->host_probe) {
@@ -2092,7 +2135,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   c->launches = 2;
   if (!fused) {                                      // the throughput regime (or a grid the chip cannot hold at once): launch C on its own
     TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
-    c->launches = 3;
+    c->launches = tp_split ? 4 : 3;
   }
   if (prm.filter_deny && (rc = launch_filter_deny(c, pd, gr, nd, b, prm, true))) return rc;
   if (commit) {
