@@ -1,0 +1,88 @@
+"""The throughput regime of the steady-state chain (every pod its own request: bench.py scenarios.all_distinct_requests), every form
+of launch B behind BS_TP_FILTER (0: scan + Filter roles in one launch; 1..4: k_fast_scan + a lean Filter kernel; 5: k_fast_scan +
+the transposed item, csrc/bs_filter_t.hpp) x BS_TP_SHARE (scan shares per tile), in ONE process: the scene is built once, every
+combination gets its own context (the switches are read when a context is created).  Per combination: us per resident step (best
+and median of REPS x 300 steps back to back), the step's per-kernel device times (bs_batch timing, when --kernels), and a digest of
+every output array — all forms must agree with form 0 bit for bit (the line says so).  GPU only; no oracle, no test imports.
+
+usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms 0,1,3,5] [--shares 64,16,4] [--kernels] [--plain]
+  --plain: the scene as synthesised (requests shared within a gang) instead of all-distinct"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+bsa = importlib.import_module("batch-scheduler_amd")
+soa = bsa.soa
+REPS = 3
+
+
+def arg(name, default):
+    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
+
+
+def digest(out):
+    h = hashlib.sha256()
+    for name in ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible", "group_admit", "group_ready"):
+        h.update(np.ascontiguousarray(getattr(out, name)).tobytes())
+    ev = out.fl_code == soa.FL_EVALUATED
+    if out.fl_rows is not None and ev.any():                      # the rows of the evaluated pods, in pod order (slot numbering is the library's business)
+        rows = np.ascontiguousarray(out.fl_rows[:, out.fl_slot[ev]])
+        h.update(rows.tobytes())
+    return h.hexdigest()[:16]
+
+
+def main():
+    pos = [a for a in sys.argv[1:] if not a.startswith("--") and not a[0].isdigit()]
+    cfg = pos[0] if pos else "cfg3"
+    scen = pos[1] if len(pos) > 1 else "tail"
+    forms = [int(x) for x in arg("--forms", "0,1,2,3,4,5").split(",")]
+    shares = [int(x) for x in arg("--shares", "64,16,4").split(",")]
+    nodes, fit, groups, pods, _ = bsa.synth.make(cfg, scen)
+    if "--plain" not in sys.argv:
+        pods = pods.copy()
+        pods.req[0, :] += np.arange(pods.p, dtype=np.int64)
+    ref = None
+    for form in forms:
+        for share in shares:
+            os.environ["BS_TP_FILTER"] = str(form)
+            os.environ["BS_TP_SHARE"] = str(share)
+            with bsa.Context(scalar_lanes=nodes.lanes - 4, enable_timing=1 if "--kernels" in sys.argv else 0) as ctx:
+                ctx.load_nodes(nodes, fit)
+                ctx.load_groups(groups)
+                ctx.load_pods(pods)
+                out = ctx.batch(soa.STAGE_ALL, bitmap=False)
+                d = digest(out)
+                if ref is None:
+                    ref = d
+                res = []
+                for _ in range(REPS):
+                    for _ in range(20):
+                        ctx.run(soa.STAGE_ALL)
+                    ctx.sync()
+                    t = time.perf_counter()
+                    for _ in range(300):
+                        ctx.run(soa.STAGE_ALL)
+                    ctx.sync()
+                    res.append((time.perf_counter() - t) / 300 * 1e6)
+                line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share,
+                        "us_per_step_best": round(min(res), 2), "us_per_step_median": round(sorted(res)[len(res) // 2], 2), "digest": d,
+                        "same_as_first": d == ref}
+                if "--kernels" in sys.argv:
+                    ctx.timing_reset()
+                    for _ in range(50):
+                        ctx.run(soa.STAGE_ALL)
+                    ctx.sync()
+                    line["kernel_us"] = {k: round(v[0] * 1000 / max(v[1], 1), 2) for k, v in ctx.timing().items() if v[1] > 0}      # mean per launch group
+                st = ctx.stats(soa.STAGE_ALL)
+                line.update({k: st[k] for k in ("chain", "launches", "filter_evals_executed", "scan_evals_executed", "filter_distinct")})
+                print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
