@@ -116,6 +116,7 @@ def test_latency_mode_and_filter_deny_in_the_throughput_regime(form, bsa, soa, o
             assert np.array_equal(out.bitmap_from_rows(), exp.fl_bitmap)
         ctx.run(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
         assert_batch_equal(ctx.read(), exp, "bitmap after latency mode")
-        if hasattr(soa, "BATCH_FILTER_DENY"):
-            exp_fd = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL | soa.BATCH_FILTER_DENY)
-            assert_batch_equal(ctx.batch(soa.STAGE_ALL | soa.BATCH_FILTER_DENY), exp_fd, f"Filter's deny entry, form {form}")
+        exp_fd = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL | soa.BATCH_FILTER_DENY, bitmap=False)
+        ctx.run(soa.STAGE_ALL | soa.BATCH_FILTER_DENY)
+        assert_batch_equal(ctx.read(bitmap=False, rows=False), exp_fd, f"Filter's deny entry, form {form}", bitmap=False)
+        assert not np.array_equal(exp_fd.pf_code, exp.pf_code), "the scene lost its Filter-deny events"
