@@ -791,6 +791,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k
 __global__ __launch_bounds__(256) void k_fast_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t filter_waves, uint32_t ustride) {
   filter_loop_t(nd, bt, filter_waves, ustride, prm.collect_stats, blockIdx.x, gridDim.x, prm.stamp, 2u * prm.k_host);
 }
+// BS_TP_FILTER=6 / 7: both roles in ONE launch again (the scan's dependent-load chains and the Filter loop's compares overlap), the
+// Filter role taken by the transposed item; 7: the Filter blocks carry the LOW block indices (dispatched first)
+template <int S>
+__global__ __launch_bounds__(256) void k_fast_scan_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t scan_blocks,
+                                                            uint32_t filter_waves, uint32_t ustride, uint32_t filter_first) {
+  __shared__ int64_t s_rows[4][64][4 + S];
+  const uint32_t filter_blocks = gridDim.x - scan_blocks;
+  const bool is_scan = filter_first ? blockIdx.x >= filter_blocks : blockIdx.x < scan_blocks;
+  if (is_scan)
+    scan_loop<S, true, 1>(bt, prm, m, jcap, 0u, 0u, 1u, filter_first ? blockIdx.x - filter_blocks : blockIdx.x, scan_blocks, s_rows[wave_id()]);
+  else
+    filter_loop_t(nd, bt, filter_waves, ustride, prm.collect_stats, filter_first ? blockIdx.x : blockIdx.x - scan_blocks, filter_blocks, prm.stamp, 2u * prm.k_host);
+}
 __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
   fast_final_block(pods, gr, nd, b, prm, query_blocks, blockIdx.x, gridDim.x, 0u);
 }

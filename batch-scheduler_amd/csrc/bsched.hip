@@ -237,7 +237,8 @@ struct bs_ctx {
   uint32_t no_fuse_final = 0;        // BS_NO_FUSE_FINAL: launches B and C always as separate launches
   uint32_t tp_filter = 0;            // BS_TP_FILTER (throughput regime = more than 16 tiles of class slots): 0 = scan and Filter roles in one launch,
                                      // 1..4 = k_fast_scan, then k_fast_filter<4,DB> / <2,DB> / <2,!DB> / k_fast_filter_w7 (109 / 93 / 75 / 72 VGPRs),
-                                     // 5 = k_fast_scan, then k_fast_filter_t (the transposed item, bs_filter_t.hpp: 63 VGPRs)
+                                     // 5 = k_fast_scan, then k_fast_filter_t (the transposed item, bs_filter_t.hpp: 64 VGPRs),
+                                     // 6 / 7 = one launch, Filter role by the transposed item (7: the Filter blocks first)
   uint32_t tp_share = 64;            // BS_TP_SHARE: scan shares per tile of class slots in that regime (at most)
   int fused_blocks_resident = -1;    // whole-chip residency of k_fast_scan_filter_final (blocks), -1 = not asked yet
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
@@ -713,6 +714,28 @@ static void launch_fast_scan(bs_ctx* c, dim3 grid, const BatchDev& bt, const Bat
     default: launch_fast_scan_s<12>(c, grid, bt, prm, nseg); break;
   }
 }
+template <int S>
+static void launch_fast_bt_s(bs_ctx* c, dim3 grid, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter_t<S>), grid, dim3(256), 0, c->stream, nd, bt, prm, c->M, nseg, scan_blocks, c->filter_waves,
+                     c->filter_slots_cap, c->tp_filter == 7u ? 1u : 0u);
+}
+static void launch_fast_bt(bs_ctx* c, dim3 grid, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks) {
+  switch (c->S) {
+    case 0: launch_fast_bt_s<0>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 1: launch_fast_bt_s<1>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 2: launch_fast_bt_s<2>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 3: launch_fast_bt_s<3>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 4: launch_fast_bt_s<4>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 5: launch_fast_bt_s<5>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 6: launch_fast_bt_s<6>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 7: launch_fast_bt_s<7>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 8: launch_fast_bt_s<8>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 9: launch_fast_bt_s<9>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 10: launch_fast_bt_s<10>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    case 11: launch_fast_bt_s<11>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    default: launch_fast_bt_s<12>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+  }
+}
 static void launch_fast_filter(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm) {
   switch (c->tp_filter) {
     case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_filter<4, true>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
@@ -1145,7 +1168,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_EPOCH")) c->no_epoch = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
-  if (const char* e = std::getenv("BS_TP_FILTER")) c->tp_filter = (uint32_t)std::min(5, std::max(0, std::atoi(e)));
+  if (const char* e = std::getenv("BS_TP_FILTER")) c->tp_filter = (uint32_t)std::min(7, std::max(0, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_SHARE")) c->tp_share = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_NO_SPECULATE")) c->no_spec = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HOST_PROBE")) c->host_probe = std::atoi(e) ? 1u : 0u;
@@ -2116,6 +2139,9 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
       const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
       launch_fast_bc(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
+    } else if (c->tp_filter >= 6u && fblocks && tiles > 16) {
+      // both roles in one launch, the Filter role by the transposed item
+      launch_fast_bt(c, dim3(scan_blocks + fblocks), nd, bt, prm, c->tp_share, scan_blocks);
     } else if (c->tp_filter && fblocks && tiles > 16) {
       // the throughput regime with the two roles as launches of their own: the scan at its register footprint, the Filter loop at a
       // leaner one (more resident waves); same stream, the scan first — its items are dependent-load chains that would otherwise sit

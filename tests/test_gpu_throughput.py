@@ -1,7 +1,8 @@
 """GPU parity in the THROUGHPUT regime of the steady-state chain: more than 16 tiles of class slots in a batch (thousands of
 distinct requests), where launch B's two roles run one scan item per wave and — with BS_TP_FILTER — as launches of their own:
 k_fast_scan, then a lean Filter kernel (1..4: filter_item at 109 / 93 / 75 / 72 VGPRs; 5: the transposed item of
-csrc/bs_filter_t.hpp — lanes are request slots, nodes come through the scalar cache).  BS_TP_SHARE bounds the scan shares per tile.
+csrc/bs_filter_t.hpp — lanes are request slots, nodes come through the scalar cache; 6 / 7: one launch again, the Filter role taken
+by the transposed item).  BS_TP_SHARE bounds the scan shares per tile.
 Every form against the oracle, bit for bit: codes, first_k, leaders, Filter codes, feasible counts, slot rows, expanded bitmap,
 admit / ready.  Scenes: all-distinct requests on synthetic clusters (S = 0, 1, 2), random object scenes with nil / unschedulable
 nodes and a STALE leader (both leader halves of the slot array in use; the tile across their boundary names two leaders),
@@ -17,7 +18,8 @@ from test_gpu_parity import assert_batch_equal, load_ctx, _force_class_mode
 
 pytestmark = pytest.mark.gpu
 
-FORMS = [0, 1, 2, 3, 4, 5]
+FORMS = [0, 1, 2, 3, 4, 5, 6, 7]
+ONE_LAUNCH = (0, 6, 7)          # forms that keep both roles of launch B in one launch
 
 
 def _distinct(bsa, config, scenario, **over):
@@ -28,7 +30,7 @@ def _distinct(bsa, config, scenario, **over):
 
 def _check_split(st, form):
     assert st["chain"] == 1 and st["class_mode"] == 1
-    assert st["launches"] == (3 if form == 0 else 4), "the batch did not take the throughput-regime launches"
+    assert st["launches"] == (3 if form in ONE_LAUNCH else 4), "the batch did not take the throughput-regime launches"
 
 
 @pytest.mark.parametrize("form", FORMS)
@@ -49,7 +51,7 @@ def test_all_distinct_requests_every_form(form, config, scenario, over, bsa, soa
 
 
 @pytest.mark.parametrize("share", [1, 4, 16])
-@pytest.mark.parametrize("form", [0, 3, 5])
+@pytest.mark.parametrize("form", [0, 3, 5, 6, 7])
 def test_scan_shares_in_the_throughput_regime(form, share, bsa, soa, orc, monkeypatch):
     nodes, fit, groups, pods = _distinct(bsa, "cfg3", "tail", pods=2600, groups=450, nodes=1100, classes=16)
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
@@ -95,10 +97,10 @@ def test_random_scenes_with_stale_leader_every_form(seed, form, bsa, soa, orc, m
         assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp_b, f"batch B, form {form}")
         st = ctx.stats(soa.STAGE_ALL)
         assert st["chain"] == 1, "batch B left the steady-state chain"
-        assert st["launches"] == (3 if form == 0 else 4)
+        assert st["launches"] == (3 if form in ONE_LAUNCH else 4)
 
 
-@pytest.mark.parametrize("form", [0, 2, 4, 5])
+@pytest.mark.parametrize("form", [0, 2, 4, 5, 6, 7])
 def test_latency_mode_and_filter_deny_in_the_throughput_regime(form, bsa, soa, orc, monkeypatch):
     nodes, fit, groups, pods = _distinct(bsa, "cfg3", "tail", pods=2400, groups=400, nodes=900, classes=8)
     sop = orc.Sop(orc.Snapshot(nodes, fit), groups)

@@ -1,11 +1,11 @@
 """The throughput regime of the steady-state chain (every pod its own request: bench.py scenarios.all_distinct_requests), every form
 of launch B behind BS_TP_FILTER (0: scan + Filter roles in one launch; 1..4: k_fast_scan + a lean Filter kernel; 5: k_fast_scan +
-the transposed item, csrc/bs_filter_t.hpp) x BS_TP_SHARE (scan shares per tile), in ONE process: the scene is built once, every
+the transposed item, csrc/bs_filter_t.hpp; 6 / 7: one launch, Filter role by the transposed item) x BS_TP_SHARE (scan shares per tile), in ONE process: the scene is built once, every
 combination gets its own context (the switches are read when a context is created).  Per combination: us per resident step (best
 and median of REPS x 300 steps back to back), the step's per-kernel device times (bs_batch timing, when --kernels), and a digest of
 every output array — all forms must agree with form 0 bit for bit (the line says so).  GPU only; no oracle, no test imports.
 
-usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms 0,1,3,5] [--shares 64,16,4] [--kernels] [--plain]
+usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms 0,1,3,5] [--shares 64,16,4] [--fwaves 8192,4096] [--kernels] [--plain]
   --plain: the scene as synthesised (requests shared within a gang) instead of all-distinct"""
 import hashlib
 import importlib
@@ -43,15 +43,17 @@ def main():
     scen = pos[1] if len(pos) > 1 else "tail"
     forms = [int(x) for x in arg("--forms", "0,1,2,3,4,5").split(",")]
     shares = [int(x) for x in arg("--shares", "64,16,4").split(",")]
+    fwaves = [int(x) for x in arg("--fwaves", "8192").split(",")]          # BS_FILTER_WAVES: waves the Filter work is cut for (8192 = the default)
     nodes, fit, groups, pods, _ = bsa.synth.make(cfg, scen)
     if "--plain" not in sys.argv:
         pods = pods.copy()
         pods.req[0, :] += np.arange(pods.p, dtype=np.int64)
     ref = None
-    for form in forms:
-        for share in shares:
+    for form, share, fw in [(f, s, w) for f in forms for s in shares for w in fwaves]:
+        if True:
             os.environ["BS_TP_FILTER"] = str(form)
             os.environ["BS_TP_SHARE"] = str(share)
+            os.environ["BS_FILTER_WAVES"] = str(fw)
             with bsa.Context(scalar_lanes=nodes.lanes - 4, enable_timing=1 if "--kernels" in sys.argv else 0) as ctx:
                 ctx.load_nodes(nodes, fit)
                 ctx.load_groups(groups)
@@ -70,7 +72,7 @@ def main():
                         ctx.run(soa.STAGE_ALL)
                     ctx.sync()
                     res.append((time.perf_counter() - t) / 300 * 1e6)
-                line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share,
+                line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share, "filter_waves": fw,
                         "us_per_step_best": round(min(res), 2), "us_per_step_median": round(sorted(res)[len(res) // 2], 2), "digest": d,
                         "same_as_first": d == ref}
                 if "--kernels" in sys.argv:
