@@ -70,35 +70,57 @@ BS_DEF_FILTER_NODE4(15, 1, 1, 1, 1)
 
 // one 64-node block (first node n0, a multiple of 64) against the lanes in `em`: per lane the 64 bits "left >= R on every
 // compared resource lane".  Bits of lanes outside `em` stay 0.
-// The scalar loads of the NEXT four nodes are issued before the compares of the current four (their results are already in
-// SGPRs: `filter_sgprs_ready` makes the compiler wait for them BEFORE it issues the next loads — scalar loads return out of
-// order, so a wait behind the issue would wait for both).
-__device__ __forceinline__ void filter_sgprs_ready(const int64_t (&s)[4][4]) {
-  asm volatile("" ::"s"(s[0][0]), "s"(s[0][1]), "s"(s[0][2]), "s"(s[0][3]), "s"(s[1][0]), "s"(s[1][1]), "s"(s[1][2]), "s"(s[1][3]), "s"(s[2][0]),
-               "s"(s[2][1]), "s"(s[2][2]), "s"(s[2][3]), "s"(s[3][0]), "s"(s[3][1]), "s"(s[3][2]), "s"(s[3][3]));
+// The nodes travel in GROUPS, double-buffered in SGPRs: the scalar loads of the NEXT group are issued before the compares of the
+// current one (whose values are already there: `filter_sgprs_ready` makes the compiler wait for them BEFORE it issues the next
+// loads — scalar loads return out of order, the only wait there is waits for everything outstanding, so a wait behind the issue
+// would wait for both).  The co-resident waves of a CU sit in different node runs, most of these loads miss the 16 KB scalar cache
+// and come from L2: what hides that round trip is the compare time of one group times the waves per SIMD, so a group is as many
+// nodes as the SGPR budget allows — 16 nodes (two s_load_dwordx16) when one resource lane is compared, 8 with two, 4 with three or
+// four (first measured with groups of 4 throughout: cfg4 all-distinct, one lane binding, 174 us in the launch against 61 us of
+// compare issue; profiles/r04c_*).
+__device__ __forceinline__ void filter_sgprs_ready4(const int64_t& a, const int64_t& b, const int64_t& c, const int64_t& d) {
+  asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d));
 }
 template <int MASK>
 __device__ __forceinline__ void filter_block_t(cnode_t L4, uint32_t stride, uint32_t n0, unsigned long long em, const int64_t (&R)[4],
                                                uint32_t (&wd)[2]) {
-  auto load4 = [&](uint32_t nn, int64_t (&s)[4][4]) {
+  constexpr int K = ((MASK >> 0) & 1) + ((MASK >> 1) & 1) + ((MASK >> 2) & 1) + ((MASK >> 3) & 1);
+  constexpr int GN = K == 1 ? 16 : (K == 2 ? 8 : 4);                 // nodes per group
+  constexpr int NG = 64 / GN;
+  constexpr int J0 = (MASK & 1) ? 0 : ((MASK & 2) ? 1 : ((MASK & 4) ? 2 : 3));      // a compared lane: stands in for the lanes that are not
+  auto load = [&](uint32_t nn, int64_t (&s)[4][GN]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s[j][u] = ((MASK >> j) & 1) ? L4[(size_t)j * stride + nn + (uint32_t)u] : 0;
+      for (int u = 0; u < GN; ++u)
+        if ((MASK >> j) & 1) s[j][u] = L4[(size_t)j * stride + nn + (uint32_t)u];
   };
-  int64_t cur[4][4], nxt[4][4];
-  load4(n0, cur);
+  int64_t cur[4][GN], nxt[4][GN];
+  load(n0, cur);
   uint32_t w = 0, sb = 1u;
 #pragma unroll
-  for (uint32_t g = 0; g < 16u; ++g) {
-    filter_sgprs_ready(cur);
-    if (g + 1u < 16u) load4(n0 + (g + 1u) * 4u, nxt);
-    filter_node4<MASK>(em, R, cur[0], cur[1], cur[2], cur[3], w, sb);
-    if (g == 7u) { wd[0] = w; w = 0; sb = 1u; }
+  for (int g = 0; g < NG; ++g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) cur[j][u] = nxt[j][u];
+      for (int c = 0; c < GN; c += 4)
+        if ((MASK >> j) & 1) filter_sgprs_ready4(cur[j][c], cur[j][c + 1], cur[j][c + 2], cur[j][c + 3]);
+    if (g + 1 < NG) load(n0 + (uint32_t)(g + 1) * GN, nxt);
+#pragma unroll
+    for (int c = 0; c < GN; c += 4) {
+      if (g * GN + c == 32) { wd[0] = w; w = 0; sb = 1u; }
+      int64_t t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[j][u] = cur[((MASK >> j) & 1) ? j : J0][c + u];
+      filter_node4<MASK>(em, R, t[0], t[1], t[2], t[3], w, sb);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int u = 0; u < GN; ++u)
+        if ((MASK >> j) & 1) cur[j][u] = nxt[j][u];
   }
   wd[1] = w;
 }
