@@ -235,11 +235,15 @@ struct bs_ctx {
   bool groups_launch_pending = false; // bs_groups_apply left its (inline) deltas + findMaxPG for the next launch: k_pods_apply takes them along, anything else flushes
   DeltaPack pending_dp{};
   uint32_t no_fuse_final = 0;        // BS_NO_FUSE_FINAL: launches B and C always as separate launches
-  uint32_t tp_filter = 0;            // BS_TP_FILTER (throughput regime = more than 16 tiles of class slots): 0 = scan and Filter roles in one launch,
+  uint32_t tp_filter = 6;            // BS_TP_FILTER (throughput regime = more than 16 tiles of class slots): 0 = scan and Filter roles in one launch (k_fast_scan_filter: rounds 2-4),
                                      // 1..4 = k_fast_scan, then k_fast_filter<4,DB> / <2,DB> / <2,!DB> / k_fast_filter_w7 (109 / 93 / 75 / 72 VGPRs),
                                      // 5 = k_fast_scan, then k_fast_filter_t (the transposed item, bs_filter_t.hpp: 64 VGPRs),
                                      // 6 / 7 = one launch, Filter role by the transposed item (7: the Filter blocks first)
-  uint32_t tp_share = 64;            // BS_TP_SHARE: scan shares per tile of class slots in that regime (at most)
+  uint32_t tp_share = 0;             // BS_TP_SHARE: scan shares per tile of class slots when launch B is not the fused form (at most);
+                                     // 0 = 2 in the throughput regime, 64 otherwise (what the sweeps of profiles/r04c_* say)
+  uint32_t tp_fwaves = 0;            // BS_TP_FWAVES: waves the Filter work of that regime is cut for; 0 = 16384 from 65 536 (tile, two node
+                                     // blocks) units on, filter_waves below; an explicit BS_FILTER_WAVES rules
+  bool filter_waves_env = false;
   int fused_blocks_resident = -1;    // whole-chip residency of k_fast_scan_filter_final (blocks), -1 = not asked yet
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   uint32_t general_waves = 4096;     // scan grid cap of the general chain (tools/cold_sweep.py)
@@ -1170,6 +1174,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_TP_FILTER")) c->tp_filter = (uint32_t)std::min(7, std::max(0, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_SHARE")) c->tp_share = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
+  if (const char* e = std::getenv("BS_TP_FWAVES")) c->tp_fwaves = (uint32_t)std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_NO_SPECULATE")) c->no_spec = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HOST_PROBE")) c->host_probe = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_SLOT_BITS")) { const int hb = std::atoi(e); c->slot_keep = hb >= 32 ? 0xFFFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
@@ -1177,7 +1182,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_EARLY_FILTER_MIN")) { c->early_filter_min = std::strtoull(e, nullptr, 10); c->early_forced = 1; }
   if (const char* e = std::getenv("BS_SCAN_SHARE")) c->scan_share_override = (uint32_t)std::max(0, std::atoi(e));
   if (const char* e = std::getenv("BS_TARGET_WAVES")) { c->target_waves = std::max(1, std::atoi(e)); c->general_waves = c->target_waves; }
-  if (const char* e = std::getenv("BS_FILTER_WAVES")) c->filter_waves = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BS_FILTER_WAVES")) { c->filter_waves = std::max(1, std::atoi(e)); c->filter_waves_env = true; }
   if (const char* e = std::getenv("BS_SERIAL_INSERT_MAX")) c->serial_insert_max = (uint32_t)std::max(0, std::atoi(e));
   if (const char* e = std::getenv("BS_ID_ROOM")) c->id_room = (uint32_t)std::max(1, std::atoi(e));   // tests: a tiny id space forces re-derivations
   *out = c;
@@ -2124,9 +2129,19 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     // few tiles (the latency regime): one scan item (tile of 64 class slots x share) per BLOCK, its four waves take a quarter of
     // every group's rows each; many tiles (thousands of distinct requests): one item per wave, 4 per block
     const uint32_t tiles = cdiv(k_est, 64);
+    const bool throughput = tiles > 16;
+    // scan shares per tile when an item is one wave's: thousands of tiles are parallelism enough, and every item pays the table's
+    // first fetch (cfg3 all-distinct 48.5 -> 38.5 us, cfg4 with the transposed Filter role 220 -> 192 us from 64 / 8 shares to 2)
+    const uint32_t share_b = c->tp_share ? c->tp_share : (throughput ? 2u : 64u);
+    // the Filter work of the transposed item is cut for twice the waves from 65 536 (tile, two node blocks) units on (half of the
+    // slot tiles belong to the carried leader and are usually idle: 8192 items leave half of the wave slots without work there)
+    struct FwGuard { bs_ctx* c; uint32_t saved; ~FwGuard() { c->filter_waves = saved; } } fw_guard{c, c->filter_waves};
+    if (throughput && c->tp_filter >= 5u && !c->filter_waves_env)
+      c->filter_waves = c->tp_fwaves ? c->tp_fwaves
+                                     : ((uint64_t)cdiv(2 * k_est, 64) * std::max<uint32_t>(1, cdiv(W, 2)) >= 65536u ? std::max<uint32_t>(c->filter_waves, 16384u) : c->filter_waves);
     const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * k_est, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
     auto scan_grid = [&](uint32_t nsub) {
-      const uint32_t items = tiles * std::min<uint32_t>(nsub == 4u ? nseg : c->tp_share, cdiv(c->M, 64));
+      const uint32_t items = tiles * std::min<uint32_t>(nsub == 4u ? nseg : share_b, cdiv(c->M, 64));
       return std::max<uint32_t>(1, std::min<uint32_t>(cdiv(c->target_waves, 4), nsub == 4u ? items : cdiv(items, 4)));
     };
     // the fused form (final blocks wait for the producers INSIDE the launch) only in the latency regime, and only when every block
@@ -2139,18 +2154,18 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
       const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
       launch_fast_bc(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
-    } else if (c->tp_filter >= 6u && fblocks && tiles > 16) {
-      // both roles in one launch, the Filter role by the transposed item
-      launch_fast_bt(c, dim3(scan_blocks + fblocks), nd, bt, prm, c->tp_share, scan_blocks);
-    } else if (c->tp_filter && fblocks && tiles > 16) {
+    } else if (c->tp_filter >= 6u && fblocks && throughput) {
+      // both roles in one launch, the Filter role by the transposed item (the default of the throughput regime)
+      launch_fast_bt(c, dim3(scan_blocks + fblocks), nd, bt, prm, share_b, scan_blocks);
+    } else if (c->tp_filter && fblocks && throughput) {
       // the throughput regime with the two roles as launches of their own: the scan at its register footprint, the Filter loop at a
       // leaner one (more resident waves); same stream, the scan first — its items are dependent-load chains that would otherwise sit
       // in the wave slots the Filter loop can fill
-      launch_fast_scan(c, dim3(scan_blocks), bt, prm, c->tp_share);
+      launch_fast_scan(c, dim3(scan_blocks), bt, prm, share_b);
       launch_fast_filter(c, dim3(fblocks), pd, nd, bt, prm);
       tp_split = true;
     } else {
-      launch_fast_b(c, dim3(scan_blocks + fblocks), pd, nd, bt, prm, c->tp_share, scan_blocks);
+      launch_fast_b(c, dim3(scan_blocks + fblocks), pd, nd, bt, prm, share_b, scan_blocks);
     }
   });
   if (c->host_probe) {

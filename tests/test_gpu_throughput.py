@@ -50,6 +50,25 @@ def test_all_distinct_requests_every_form(form, config, scenario, over, bsa, soa
         assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"form {form}, again (stamps)")
 
 
+@pytest.mark.parametrize("config,scenario,over", [
+    ("cfg2", "tail", dict(pods=2300, groups=300, nodes=700)),
+    ("cfg3", "tail", dict(pods=3000, groups=500, nodes=1300, classes=16)),
+    ("cfg3", "warm", dict(pods=2000, groups=400, nodes=1000, classes=8, scalars=2)),
+])
+def test_all_distinct_requests_library_defaults(config, scenario, over, bsa, soa, orc, monkeypatch):
+    """No switch set: the throughput regime takes one launch for both roles of launch B (the Filter role by the transposed item)."""
+    for k in ("BS_TP_FILTER", "BS_TP_SHARE", "BS_TP_FWAVES", "BS_FILTER_WAVES"):
+        monkeypatch.delenv(k, raising=False)
+    nodes, fit, groups, pods = _distinct(bsa, config, scenario, **over)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "defaults")
+        st = ctx.stats(soa.STAGE_ALL)
+        assert st["chain"] == 1 and st["class_mode"] == 1 and st["launches"] == 3
+        ctx.run(soa.STAGE_ALL | soa.BATCH_HOST_RESULTS)
+        assert_batch_equal(ctx.read(), exp, "defaults, latency mode")
+
+
 @pytest.mark.parametrize("share", [1, 4, 16])
 @pytest.mark.parametrize("form", [0, 3, 5, 6, 7])
 def test_scan_shares_in_the_throughput_regime(form, share, bsa, soa, orc, monkeypatch):

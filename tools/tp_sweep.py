@@ -5,7 +5,7 @@ combination gets its own context (the switches are read when a context is create
 and median of REPS x 300 steps back to back), the step's per-kernel device times (bs_batch timing, when --kernels), and a digest of
 every output array — all forms must agree with form 0 bit for bit (the line says so).  GPU only; no oracle, no test imports.
 
-usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms 0,1,3,5] [--shares 64,16,4] [--fwaves 8192,4096] [--kernels] [--plain]
+usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms -1,0,1,3,5  (-1 = the library's defaults)] [--shares 64,16,4] [--fwaves 8192,4096] [--kernels] [--plain]
   --plain: the scene as synthesised (requests shared within a gang) instead of all-distinct"""
 import hashlib
 import importlib
@@ -38,7 +38,7 @@ def digest(out):
 
 
 def main():
-    pos = [a for a in sys.argv[1:] if not a.startswith("--") and not a[0].isdigit()]
+    pos = [a for a in sys.argv[1:] if not a.startswith("--") and not a[0].isdigit() and not a[0] == "-"]
     cfg = pos[0] if pos else "cfg3"
     scen = pos[1] if len(pos) > 1 else "tail"
     forms = [int(x) for x in arg("--forms", "0,1,2,3,4,5").split(",")]
@@ -51,9 +51,12 @@ def main():
     ref = None
     for form, share, fw in [(f, s, w) for f in forms for s in shares for w in fwaves]:
         if True:
-            os.environ["BS_TP_FILTER"] = str(form)
-            os.environ["BS_TP_SHARE"] = str(share)
-            os.environ["BS_FILTER_WAVES"] = str(fw)
+            for k in ("BS_TP_FILTER", "BS_TP_SHARE", "BS_FILTER_WAVES"):
+                os.environ.pop(k, None)
+            if form >= 0:                                          # form -1: the library's defaults (no switch set)
+                os.environ["BS_TP_FILTER"] = str(form)
+                os.environ["BS_TP_SHARE"] = str(share)
+                os.environ["BS_FILTER_WAVES"] = str(fw)
             with bsa.Context(scalar_lanes=nodes.lanes - 4, enable_timing=1 if "--kernels" in sys.argv else 0) as ctx:
                 ctx.load_nodes(nodes, fit)
                 ctx.load_groups(groups)
