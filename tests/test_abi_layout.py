@@ -66,3 +66,19 @@ def test_ctypes_structures_match_the_header(tmp_path):
         for fname in py_fields:
             d = getattr(ct, fname)
             assert (d.offset, d.size) == want[fname], f"{cname}.{fname}: ctypes (offset, size) {(d.offset, d.size)} != header {want[fname]}"
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """Every `getenv("BS_...")` in the library's sources appears in INTEGRATION.md's table of diagnostic switches (none of them is needed
+    in production; a switch nobody can find is a behaviour nobody can explain)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for pat in ("batch-scheduler_amd/csrc/*", "batch-scheduler_amd/host/*"):
+        for f in glob.glob(os.path.join(root, pat)):
+            names |= set(re.findall(r'getenv\("(BS_[A-Z0-9_]+)"\)', open(f).read()))
+    assert len(names) >= 20, names
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, f"undocumented switches: {missing}"
