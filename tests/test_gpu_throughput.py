@@ -141,3 +141,33 @@ def test_latency_mode_and_filter_deny_in_the_throughput_regime(form, bsa, soa, o
         ctx.run(soa.STAGE_ALL | soa.BATCH_FILTER_DENY)
         assert_batch_equal(ctx.read(bitmap=False, rows=False), exp_fd, f"Filter's deny entry, form {form}", bitmap=False)
         assert not np.array_equal(exp_fd.pf_code, exp.pf_code), "the scene lost its Filter-deny events"
+
+
+@pytest.mark.parametrize("form", [0, 6])
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_shards_in_the_throughput_regime(nranks, form, bsa, soa, orc, monkeypatch):
+    """Pod-axis shard (bs_shard_set, the whole queue on every rank): only the pods a rank owns stamp their class / Filter slots, so a
+    rank's launch B evaluates the slots of ITS pods — with distinct requests that is 1 / nranks of the work.  Every rank's owned pods
+    == the single batch's, the union of the admit counters == the single batch's."""
+    nodes, fit, groups, pods = _distinct(bsa, "cfg3", "tail", pods=3000, groups=500, nodes=1300, classes=16)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    monkeypatch.setenv("BS_TP_FILTER", str(form))
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        admit = np.zeros(groups.g, np.uint32)
+        owned = np.zeros(pods.p, np.uint32)
+        for r in range(nranks):
+            ctx.set_shard(r, nranks)
+            ctx.run(soa.STAGE_ALL)
+            part = ctx.read()
+            mine = part.pf_code != 0xFF
+            owned += mine
+            for name in ("pf_code", "pf_first_k", "fl_code", "fl_feasible"):
+                assert np.array_equal(getattr(part, name)[mine], getattr(exp, name)[mine]), (name, r)
+            assert np.array_equal(part.fl_bitmap[:, mine], exp.fl_bitmap[:, mine]), r
+            admit += part.group_admit
+            st = ctx.stats(soa.STAGE_ALL)
+            assert st["chain"] == 1
+            assert st["filter_evals_executed"] < 0.75 * int((exp.fl_code == soa.FL_EVALUATED).sum()) * nodes.n, "a rank evaluated (almost) every slot"
+        assert np.array_equal(owned, np.ones(pods.p, np.uint32)), "every pod is owned by exactly one rank"
+        assert np.array_equal(admit, exp.group_admit)
+        ctx.set_shard(0, 1)

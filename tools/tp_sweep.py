@@ -5,7 +5,8 @@ combination gets its own context (the switches are read when a context is create
 and median of REPS x 300 steps back to back), the step's per-kernel device times (bs_batch timing, when --kernels), and a digest of
 every output array — all forms must agree with form 0 bit for bit (the line says so).  GPU only; no oracle, no test imports.
 
-usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms -1,0,1,3,5  (-1 = the library's defaults)] [--shares 64,16,4] [--fwaves 8192,4096] [--kernels] [--plain]
+usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms -1,0,1,3,5  (-1 = the library's defaults)] [--shares 64,16,4] [--fwaves 8192,4096] [--kernels] [--plain] [--shard r/n[,r/n...]]
+  --shard r/n: the step of rank r of n (pod-axis shard on this one context, no collective): what a rank's launches cost
   --plain: the scene as synthesised (requests shared within a gang) instead of all-distinct"""
 import hashlib
 import importlib
@@ -48,8 +49,9 @@ def main():
     if "--plain" not in sys.argv:
         pods = pods.copy()
         pods.req[0, :] += np.arange(pods.p, dtype=np.int64)
+    shards = [[int(x) for x in sh.split("/")] for sh in arg("--shard", "").split(",")] if "--shard" in sys.argv else [None]      # "--shard 0/2,0/8,7/8"
     ref = None
-    for form, share, fw in [(f, s, w) for f in forms for s in shares for w in fwaves]:
+    for form, share, fw, shard in [(f, s, w, sh) for f in forms for s in shares for w in fwaves for sh in shards]:
         if True:
             for k in ("BS_TP_FILTER", "BS_TP_SHARE", "BS_FILTER_WAVES"):
                 os.environ.pop(k, None)
@@ -61,9 +63,11 @@ def main():
                 ctx.load_nodes(nodes, fit)
                 ctx.load_groups(groups)
                 ctx.load_pods(pods)
+                if shard:                                          # rank r of n on this one context (bs_shard_set: the whole queue resident, ownership on the device)
+                    ctx.set_shard(shard[0], shard[1])
                 out = ctx.batch(soa.STAGE_ALL, bitmap=False)
                 d = digest(out)
-                if ref is None:
+                if ref is None or shard:                           # (a rank's outputs are its own: no comparison across shards)
                     ref = d
                 res = []
                 for _ in range(REPS):
@@ -75,7 +79,7 @@ def main():
                         ctx.run(soa.STAGE_ALL)
                     ctx.sync()
                     res.append((time.perf_counter() - t) / 300 * 1e6)
-                line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share, "filter_waves": fw,
+                line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share, "filter_waves": fw, "shard": shard,
                         "us_per_step_best": round(min(res), 2), "us_per_step_median": round(sorted(res)[len(res) // 2], 2), "digest": d,
                         "same_as_first": d == ref}
                 if "--kernels" in sys.argv:
