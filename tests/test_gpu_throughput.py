@@ -171,3 +171,29 @@ def test_shards_in_the_throughput_regime(nranks, form, bsa, soa, orc, monkeypatc
         assert np.array_equal(owned, np.ones(pods.p, np.uint32)), "every pod is owned by exactly one rank"
         assert np.array_equal(admit, exp.group_admit)
         ctx.set_shard(0, 1)
+
+
+def _golden():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "throughput_digests.json")))
+
+
+@pytest.mark.parametrize("config,scenario", [("cfg3", "tail"), ("cfg3", "busy"), ("cfg4", "tail")])
+def test_full_size_all_distinct_equals_the_oracles_digest(config, scenario, bsa, soa):
+    """BASELINE's full sizes with every request distinct (10k x 5k: 4.8e7 evaluated pod x node pairs per batch; 50k x 20k: 9.6e8) against
+    the digest of the ORACLE's batch committed under tests/golden/ (make_throughput_golden.py; the oracle needs ~3 minutes for cfg4)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_throughput_golden as mk
+    want = _golden().get(f"{config}/{scenario}/distinct")
+    if want is None:
+        pytest.skip("no golden digest for this scene")
+    nodes, fit, groups, pods = mk.scene(bsa, config, scenario)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        got = ctx.batch(soa.STAGE_ALL, bitmap=False)
+        assert mk.digest(got) == want["digest"], f"{config}/{scenario} all-distinct: the device's result arrays differ from the oracle's"
+        assert int((got.fl_code == soa.FL_EVALUATED).sum()) == want["evaluated_pods"] and int(got.group_ready.sum()) == want["groups_ready"]
+        st = ctx.stats(soa.STAGE_ALL)
+        assert st["chain"] == 1 and st["launches"] == 3
