@@ -52,45 +52,44 @@ def main():
     shards = [[int(x) for x in sh.split("/")] for sh in arg("--shard", "").split(",")] if "--shard" in sys.argv else [None]      # "--shard 0/2,0/8,7/8"
     ref = None
     for form, share, fw, shard in [(f, s, w, sh) for f in forms for s in shares for w in fwaves for sh in shards]:
-        if True:
-            for k in ("BS_TP_FILTER", "BS_TP_SHARE", "BS_FILTER_WAVES"):
-                os.environ.pop(k, None)
-            if form >= 0:                                          # form -1: the library's defaults (no switch set)
-                os.environ["BS_TP_FILTER"] = str(form)
-                os.environ["BS_TP_SHARE"] = str(share)
-                os.environ["BS_FILTER_WAVES"] = str(fw)
-            with bsa.Context(scalar_lanes=nodes.lanes - 4, enable_timing=1 if "--kernels" in sys.argv else 0) as ctx:
-                ctx.load_nodes(nodes, fit)
-                ctx.load_groups(groups)
-                ctx.load_pods(pods)
-                if shard:                                          # rank r of n on this one context (bs_shard_set: the whole queue resident, ownership on the device)
-                    ctx.set_shard(shard[0], shard[1])
-                out = ctx.batch(soa.STAGE_ALL, bitmap=False)
-                d = digest(out)
-                if ref is None or shard:                           # (a rank's outputs are its own: no comparison across shards)
-                    ref = d
-                res = []
-                for _ in range(REPS):
-                    for _ in range(20):
-                        ctx.run(soa.STAGE_ALL)
-                    ctx.sync()
-                    t = time.perf_counter()
-                    for _ in range(300):
-                        ctx.run(soa.STAGE_ALL)
-                    ctx.sync()
-                    res.append((time.perf_counter() - t) / 300 * 1e6)
-                line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share, "filter_waves": fw, "shard": shard,
-                        "us_per_step_best": round(min(res), 2), "us_per_step_median": round(sorted(res)[len(res) // 2], 2), "digest": d,
-                        "same_as_first": d == ref}
-                if "--kernels" in sys.argv:
-                    ctx.timing_reset()
-                    for _ in range(50):
-                        ctx.run(soa.STAGE_ALL)
-                    ctx.sync()
-                    line["kernel_us"] = {k: round(v[0] * 1000 / max(v[1], 1), 2) for k, v in ctx.timing().items() if v[1] > 0}      # mean per launch group
-                st = ctx.stats(soa.STAGE_ALL)
-                line.update({k: st[k] for k in ("chain", "launches", "filter_evals_executed", "scan_evals_executed", "filter_distinct")})
-                print(json.dumps(line), flush=True)
+        for k in ("BS_TP_FILTER", "BS_TP_SHARE", "BS_FILTER_WAVES"):
+            os.environ.pop(k, None)
+        if form >= 0:                                          # form -1: the library's defaults (no switch set)
+            os.environ["BS_TP_FILTER"] = str(form)
+            os.environ["BS_TP_SHARE"] = str(share)
+            os.environ["BS_FILTER_WAVES"] = str(fw)
+        with bsa.Context(scalar_lanes=nodes.lanes - 4, enable_timing=1 if "--kernels" in sys.argv else 0) as ctx:
+            ctx.load_nodes(nodes, fit)
+            ctx.load_groups(groups)
+            ctx.load_pods(pods)
+            if shard:                                          # rank r of n on this one context (bs_shard_set: the whole queue resident, ownership on the device)
+                ctx.set_shard(shard[0], shard[1])
+            out = ctx.batch(soa.STAGE_ALL, bitmap=False)
+            d = digest(out)
+            if ref is None or shard:                           # (a rank's outputs are its own: no comparison across shards)
+                ref = d
+            res = []
+            for _ in range(REPS):
+                for _ in range(20):
+                    ctx.run(soa.STAGE_ALL)
+                ctx.sync()
+                t = time.perf_counter()
+                for _ in range(300):
+                    ctx.run(soa.STAGE_ALL)
+                ctx.sync()
+                res.append((time.perf_counter() - t) / 300 * 1e6)
+            line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share, "filter_waves": fw, "shard": shard,
+                    "us_per_step_best": round(min(res), 2), "us_per_step_median": round(sorted(res)[len(res) // 2], 2), "digest": d,
+                    "same_as_first": d == ref}
+            if "--kernels" in sys.argv:
+                ctx.timing_reset()
+                for _ in range(50):
+                    ctx.run(soa.STAGE_ALL)
+                ctx.sync()
+                line["kernel_us"] = {k: round(v[0] * 1000 / max(v[1], 1), 2) for k, v in ctx.timing().items() if v[1] > 0}      # mean per launch group
+            st = ctx.stats(soa.STAGE_ALL)
+            line.update({k: st[k] for k in ("chain", "launches", "filter_evals_executed", "scan_evals_executed", "filter_distinct")})
+            print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
