@@ -626,7 +626,8 @@ def main():
                                                "filter_distinct_requests": st["filter_distinct"], "scan_queries_distinct": st["scan_queries"],
                                                "evals_executed_per_step": ev3, "issue_rate_frac": ev3 / (ms * 1e-3) / VOPC_EVALS_PER_S,
                                                "issue_rate_note": "executed pod x node compares / WHOLE step time / the measured 64-bit v_cmp issue rate "
-                                                                  "(tools/ubench/cmp_rate.hip): the utilisation figure when there is real work to do"}
+                                                                  "(tools/ubench/cmp_rate.hip): the utilisation figure when there is real work to do.  The reference rate prices an eval as a chain of "
+                                                                  "five 64-bit compares; a batch whose tiles leave one resource lane to compare (the lane mask of the Filter item) can exceed 1"}
             ms, st = resident_ms(bsa, nodes, fit, groups, all_pods, soa.STAGE_PREFILTER | soa.STAGE_TALLY, 100)
             extras["prefilter_only"] = {"ms_per_step": ms, "evals_per_s": logical / (ms * 1e-3)}
             extras["filter_increment_ms"] = ms_per_step - ms if args.stages == "all" else None
