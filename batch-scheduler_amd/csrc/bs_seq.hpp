@@ -50,6 +50,7 @@ constexpr int kSeqWaves = kSeqBlock / 64;
 constexpr uint32_t kSeqKeysLds = 8192;     // groups whose findMaxPG keys fit the LDS window (64 KB)
 constexpr uint32_t kSeqPruneTiles = 1024;  // 64-node tiles whose first-fit bounds fit the LDS window (65 536 nodes)
 constexpr uint32_t kSeqWaitList = 512;     // waiting pods of the current gang kept in LDS
+constexpr uint32_t kSeqHasRecord = 0x80000000u;   // in nwait[g]: the gang has been released in this pass (it has a release record)
 constexpr uint32_t kSeqCursorBits = 9;     // first-fit cursors in LDS: 512 direct-mapped entries (12 bytes each)
 constexpr uint32_t kSeqCursors = 1u << kSeqCursorBits;
 #ifndef BS_SEQ_CACHE_MAX
@@ -995,7 +996,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
           else seq_group_load(sq, G, (uint32_t)gi, sh, own);
           own_of = gi;
           wl_cnt = 0;
-          wl_ok = own.nwait == 0;
+          wl_ok = (own.nwait & ~kSeqHasRecord) == 0;
         }
         if (miss_ldr) { seq_group_load(sq, G, (uint32_t)sop_leader, sh, ldr); ldr_of = sop_leader; }
       }
@@ -1191,7 +1192,8 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     BS_SEQ_T(3);
     BS_SEQ_P(8);
     uint32_t at = BS_INF;
-    if (BS_PF_IS_PASS(code)) {
+    if (BS_PF_IS_PASS(code) && (grouped || gi == BS_POD_NOT_GROUPED)) {   // (a labelled pod of an unknown group, here on its lastPermittedPod entry:
+      //                                                                   Permit answers "can not found pod group", core.go:275-278, and the framework forgets it)
       q.pcls = pods.cls[i];
       q.ppres = pods.pres[i];
 #pragma unroll
@@ -1285,30 +1287,37 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       const uint32_t mm = gr.min_member[gi];
       const uint32_t m1 = gmatched + 1u;                                                             // :290
       const bool ready = m1 >= (uint32_t)(mm - gsc);                                                 // :303
-      const bool first_time = ready && !(gflags & BS_GROUP_SCHEDULED_LATCH);
-      const uint32_t prev = own.head, k = own.nwait + 1u;
-      own.matched = m1;
-      if (!ready) {
+      // sendStartScheduleSignal -> StartBatchSchedule (batchscheduler.go:254-344) releases — unless the phase is none of PreScheduling /
+      // Scheduling (:258-261): then the latch is all that happens and the pod waits on like any other
+      const bool release = ready && !(gflags & BS_GROUP_PHASE_CLOSED);
+      const uint32_t has_rec = own.nwait & kSeqHasRecord, nw = own.nwait & ~kSeqHasRecord;
+      const uint32_t prev = own.head, k = nw + 1u;
+      if (ready) gflags |= BS_GROUP_SCHEDULED_LATCH;                                                 // :305
+      if (!release) {
         if (t0) {
           sq.g_matched[gi] = m1;
+          if (gflags != own.flags) sq.g_flags[gi] = (uint8_t)gflags;
           sq.wait_rec[i] = ((unsigned long long)prev << 32) | at;
           sq.head[gi] = i + 1u;
-          sq.nwait[gi] = k;
+          sq.nwait[gi] = k | has_rec;
           if (wl_ok && wl_cnt < kSeqWaitList) { sh_.wl_pod[wl_cnt] = i; sh_.wl_node[wl_cnt] = at; }
         }
+        own.matched = m1;
+        own.flags = gflags;
         own.head = i + 1u;
-        own.nwait = k;
+        own.nwait = k | has_rec;
         if (wl_cnt < kSeqWaitList) wl_cnt++; else wl_ok = false;
       } else {
-        // the waiting pods of the gang bind (batchscheduler.go:254-344): in parallel from the LDS list when it holds them all
-        const bool from_list = wl_ok && wl_cnt == own.nwait;
+        // EVERY entry of MatchedPodNodes is allowed (:292,:301-333), deleted (:326) and counted by PostBind (core.go:327): the pods this
+        // pass placed — they bind in parallel from the LDS list when it holds them all — and the m1 - k that were waiting when it began
+        const bool from_list = wl_ok && wl_cnt == nw;
         if (from_list) {
           for (uint32_t e = threadIdx.x; e < wl_cnt; e += kSeqBlock) sq.pod_node[sh_.wl_pod[e]] = (int32_t)sh_.wl_node[e];
         }
-        gflags |= BS_GROUP_SCHEDULED_LATCH;                                                          // :305
-        const uint32_t scn = gsc + k;                                                                // PostBind, core.go:327
+        const uint32_t scn = gsc + m1;                                                               // PostBind, core.go:327 (uint32)
+        if (scn >= mm) gflags |= BS_GROUP_PHASE_CLOSED;                                              // core.go:329-330 phase Scheduled
         if (t0) {
-          sq.g_matched[gi] = m1;
+          sq.g_matched[gi] = 0;
           sq.pod_node[i] = (int32_t)at;
           if (!from_list)
             for (uint32_t wv = prev; wv != 0u;) {
@@ -1317,33 +1326,34 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
               wv = (uint32_t)(rec >> 32);
             }
           sq.head[gi] = 0;
-          sq.nwait[gi] = 0;
+          sq.nwait[gi] = kSeqHasRecord;
           sq.g_sc[gi] = scn;
           sq.g_flags[gi] = (uint8_t)gflags;
-          if (first_time) {
+          if (!has_rec) {
             if (n_released < sq.cap) {
               sq.released_group[n_released] = (uint32_t)gi;
-              sq.released_pods[n_released] = k;
+              sq.released_pods[n_released] = m1;
               sq.first_tick[n_released] = sq.t_first[gi];
               sq.ready_tick[n_released] = (unsigned long long)wall_clock64() - clk0;
               sq.slot_of[gi] = n_released;
             }
           } else if (sq.slot_of[gi] != BS_INF) {
-            sq.released_pods[sq.slot_of[gi]] += k;           // a late member of a gang that is already through
+            sq.released_pods[sq.slot_of[gi]] += m1;          // a second release of the gang (Status.Scheduled still below MinMember: only through uint32 wrap)
           }
         }
+        own.matched = 0;
         own.head = 0;
-        own.nwait = 0;
+        own.nwait = kSeqHasRecord;
         own.sc = scn;
         own.flags = gflags;
         wl_cnt = 0;
         wl_ok = true;
-        if (first_time) n_released++;
+        if (!has_rec) n_released++;
       }
       {
         // matched moved: the group's progress changed.  findMaxPG's answer stands unless this key now beats the winner's, or the
         // winner itself fell back (released: no candidate any more).
-        const unsigned long long key = seq_key((uint32_t)gi, own.flags, mm, own.sc, m1);
+        const unsigned long long key = seq_key((uint32_t)gi, own.flags, mm, own.sc, own.matched);
         if (t0) { if (prm.keys_in_lds) s_keys[gi] = key; else sq.keys[gi] = key; }
         if (fold_valid) {
           if (fold_top == 0ull || fold_panic) fold_valid = false;

@@ -60,7 +60,7 @@ typedef struct bsh_drain_io {
   /* results */
   uint32_t cap;                /* capacity of the three per-gang arrays                                              */
   uint32_t* admitted_group;    /* [cap] gang released k-th                                                            */
-  uint32_t* admitted_pods;     /* [cap] pods released with it                                                         */
+  uint32_t* admitted_pods;     /* [cap] pods released with it (its members placed in that cycle + the pods that were waiting) */
   int64_t* admitted_ns;        /* [cap] time since the drain began when it was released                               */
   int64_t* cycle_ns;           /* [cap] duration of the cycle that decided it (score + read + place + patch)          */
   int32_t* pod_node;           /* [pods.p] node each pod of the ORIGINAL queue was assumed on, -1 = still pending     */
@@ -202,7 +202,7 @@ int bsh_drain(bsh_drain_io* io) {
     };
     std::vector<uint32_t> gone, gone_node;                  // queue positions leaving in this cycle (ascending), and their nodes
     int32_t gang = -1;
-    uint32_t gang_pods = 0;
+    uint32_t gang_pods = 0, gang_released = 0;   // members placed this cycle; pods released with the gang (members + the ones already waiting)
     journal.clear();
     // undo of everything this cycle placed, should a device call fail
     auto undo_cycle = [&]() {
@@ -217,6 +217,7 @@ int bsh_drain(bsh_drain_io* io) {
         continue;
       }
       if (gi < 0 || (uint32_t)gi >= G || !ready[gi] || stuck[gi] || !passes(i0)) continue;
+      if (io->group_flags[gi] & BS_GROUP_PHASE_CLOSED) continue;   // batchscheduler.go:258-261: StartBatchSchedule releases nobody in this phase
       members.clear();
       placed_node.clear();
       const size_t mark = journal.size();
@@ -255,8 +256,13 @@ int bsh_drain(bsh_drain_io* io) {
       }
       gone.swap(all);
       gone_node.swap(alln);
-      gd = bs_group_delta{(uint32_t)gang, io->matched[gang] + gang_pods, io->status_scheduled[gang] + gang_pods,
-                          (uint32_t)(io->group_flags[gang] | BS_GROUP_SCHEDULED_LATCH)};
+      // StartBatchSchedule allows EVERY entry of MatchedPodNodes — the members placed now and the pods that were already waiting
+      // (io->matched) —, deletes each entry (batchscheduler.go:292-333) and PostBind counts each into Status.Scheduled (core.go:327);
+      // the phase turns Scheduled at MinMember (core.go:329-330)
+      const uint32_t bound = io->matched[gang] + gang_pods, scn = io->status_scheduled[gang] + bound;
+      gang_released = bound;
+      gd = bs_group_delta{(uint32_t)gang, 0u, scn,
+                          (uint32_t)(io->group_flags[gang] | BS_GROUP_SCHEDULED_LATCH | (scn >= io->min_member[gang] ? BS_GROUP_PHASE_CLOSED : 0u))};
     }
     {
       std::vector<uint32_t> touched(gone_node);
@@ -295,7 +301,7 @@ int bsh_drain(bsh_drain_io* io) {
       const int64_t t = now_ns();
       if (io->n_admitted < io->cap) {
         io->admitted_group[io->n_admitted] = (uint32_t)gang;
-        io->admitted_pods[io->n_admitted] = gang_pods;
+        io->admitted_pods[io->n_admitted] = gang_released;
         io->admitted_ns[io->n_admitted] = t - t_begin;
         io->cycle_ns[io->n_admitted] = t - t_cycle;
       }

@@ -23,7 +23,7 @@ LANE_CPU, LANE_MEM, LANE_EPH, LANE_PODS = 0, 1, 2, 3
 
 NODE_NIL, NODE_NO_NODE, NODE_UNSCHEDULABLE, NODE_TAINT_ERR = 0x01, 0x02, 0x04, 0x08
 NODE_SKIP_MASK = 0x07
-GROUP_SCHEDULED_LATCH, GROUP_HAS_POD, GROUP_HAS_MINRES, GROUP_DENIED = 0x01, 0x02, 0x04, 0x08
+GROUP_SCHEDULED_LATCH, GROUP_HAS_POD, GROUP_HAS_MINRES, GROUP_DENIED, GROUP_PHASE_CLOSED = 0x01, 0x02, 0x04, 0x08, 0x10
 POD_LAST_PERMITTED = 0x01
 POD_NOT_GROUPED, POD_GROUP_MISSING = -1, -2
 

@@ -73,6 +73,9 @@ typedef enum bs_status {
 #define BS_GROUP_HAS_POD         0x02u /* pgs.Pod != nil (first pod seen, core.go:486-488) */
 #define BS_GROUP_HAS_MINRES      0x04u /* Spec.MinResources != nil (core.go:489-493)      */
 #define BS_GROUP_DENIED          0x08u /* live entry in lastDeniedPG (core.go:105-110)    */
+#define BS_GROUP_PHASE_CLOSED    0x10u /* Status.Phase is none of Pending / PreScheduling / Scheduling: StartBatchSchedule returns without
+                                        * releasing anybody (batchscheduler.go:258-261).  Read and written by bs_seq_run only (set when PostBind
+                                        * turns the phase to Scheduled, core.go:329-330); the batch entry points ignore it */
 
 /* ---- pod flags / group sentinels -------------------------------------------------- */
 #define BS_POD_LAST_PERMITTED 0x01u   /* live entry in lastPermittedPod (core.go:95-98) */

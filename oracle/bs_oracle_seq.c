@@ -3,15 +3,23 @@
  *
  * One pass of the reference over the pending queue, pod by pod, the way upstream's scheduleOne drives the plugin:
  *   PreFilter            core.go:88-167    (orc_prefilter: deny entries, first-pod capture, findMaxPG and the node scan)
- *   [Filter              core.go:170-191,  :514-564 — only when the FILTER stage is on; the shipped config leaves it off]
+ *   [Filter              core.go:170-191,  :514-564 — only when the FILTER stage is on; the shipped config leaves it off.  It gates the
+ *                        node choice; with BS_BATCH_FILTER_DENY its TTL writes happen as well (:183-185 deny entry, :188 lastPermittedPod),
+ *                        under the offer rule "every node"]
  *   node choice + assume upstream (NodeResourcesFit / priorities / cache.AssumePod -> NodeInfo.AddPod), NOT plugin code, not
  *                        vendored: restated as the rule host/bs_drain.cpp states — FIRST FIT in list order over nodes without
  *                        a BS_NODE_* flag whose checkFit bit is set for the pod's class and that hold the request (lane j in
  *                        {cpu, mem, eph} binds when request > 0; pods lane: requested + 1 <= allocatable; a requested scalar
  *                        needs the allocatable key); assume = requested += request, pods lane + 1.  Stated, unpinned.
  *   Permit               core.go:268-309   matched + 1 (:290), quorum :303, latch :305
- *   release + PostBind   batchscheduler.go:254-344, core.go:312-362: when the quorum turns true every waiting pod of the gang
- *                        binds and counts into Status.Scheduled (:327)
+ *   release + PostBind   batchscheduler.go:254-344, core.go:312-362: when the quorum turns true StartBatchSchedule allows EVERY entry of
+ *                        MatchedPodNodes (:292,:301-333) — the pods this pass placed and the ones that were already waiting when it
+ *                        began (groups.matched on entry) —, deletes each entry (:326) and PostBind counts each into Status.Scheduled
+ *                        (core.go:327); the phase turns Scheduled when Status.Scheduled >= MinMember (core.go:329-330), after which
+ *                        StartBatchSchedule releases nobody any more (batchscheduler.go:258-261: BS_GROUP_PHASE_CLOSED): a late
+ *                        member of such a gang is assumed, counted by Permit and waits for its Permit timeout.
+ *                        Pinned against the object-level replay oracle/naive_seq.py (real TTL maps, start_batch, postbind):
+ *                        tests/test_seq_oracle_pin.py.
  * It records, per released gang, when its FIRST pod entered PreFilter and when the quorum turned true — SURVEY 8(d)(2)'s
  * gang-admit latency of the sequential path — and is the timed CPU baseline beside the batched drain (bench.py).
  * Pods that pass PreFilter but find no node stay pending and keep nothing; pods of a gang that never reaches its quorum keep
@@ -39,6 +47,8 @@ typedef struct orc_seq_io {
   int64_t total_ns;
   uint32_t* pf_first_k;      /* [p] optional: first_k of the pod's node scan (as bs_batch_out.pf_first_k)                 */
   int32_t* pf_leader;        /* [p] optional: sop.maxFinishedPG as the pod's PreFilter left it (-1 none)                  */
+  uint8_t* last_permitted;   /* [p] optional, with BS_STAGE_FILTER | BS_BATCH_FILTER_DENY: 1 = a Filter call of the pod passed, i.e. the pass
+                              * left a lastPermittedPod entry for it (core.go:188) — its next PreFilter within 2 s returns at :95-98 */
   int64_t pick_ns;           /* out: of total_ns, the time spent in the node-choice loop (UPSTREAM's work, not the plugin's; with the FILTER stage it
                               * contains the plugin's Filter calls on the nodes tried) */
 } orc_seq_io;
@@ -74,7 +84,6 @@ void orc_seq_replay(orc_seq_io* io) {
   int64_t* requested = (int64_t*)s->nodes.requested;            /* mutable by contract */
   uint32_t* rpres = (uint32_t*)s->nodes.requested_present;
   int64_t* t_first = (int64_t*)malloc(sizeof(int64_t) * (G ? G : 1));
-  uint32_t* nwait = (uint32_t*)calloc(G ? G : 1, sizeof(uint32_t));
   uint32_t* slot_of = (uint32_t*)malloc(sizeof(uint32_t) * (G ? G : 1));   /* release record of a latched group */
   /* waiting pods per group as linked lists through next_wait */
   int32_t* head = (int32_t*)malloc(sizeof(int32_t) * (G ? G : 1));
@@ -96,6 +105,26 @@ void orc_seq_replay(orc_seq_io* io) {
     if (io->pf_first_k) io->pf_first_k[i] = fk;
     if (io->pf_leader) io->pf_leader[i] = leader;
     if (!BS_PF_IS_PASS(code)) continue;
+    if (gi != BS_POD_NOT_GROUPED && !grouped) continue;         /* a labelled pod whose group is unknown only gets here on its lastPermittedPod
+                                                                 * entry (core.go:95-98); Permit answers "can not found pod group" (core.go:275-278)
+                                                                 * -> Unschedulable (batchscheduler.go:192-193) and the framework forgets the
+                                                                 * assumed pod: it holds nothing and is not released */
+    if (io->last_permitted) io->last_permitted[i] = 0;
+    if ((io->stages & BS_STAGE_FILTER) && (io->stages & BS_BATCH_FILTER_DENY) && grouped) {
+      /* Filter (core.go:170-191) with its TTL writes.  Which nodes the framework offers to Filter is upstream's business
+       * (percentageOfNodesToScore, parallel fan-out); the rule is the batch form's (bs_batch_run, BS_BATCH_FILTER_DENY): EVERY node of
+       * the list, with the node requests as the pods before this one left them.  A failing call deny-lists the group (:183-185 ->
+       * :105-110 for the gang's later pods), a passing one enters lastPermittedPod (:188).  The pod itself goes on to the node choice. */
+      int failed = 0, passed = 0;
+      uint8_t fl = 0;
+      for (uint32_t k = 0; k < N; ++k) {
+        uint8_t fn = 0;
+        fl = orc_filter_node(sop, pods, i, leader, k, &fn);
+        if ((fl < 16u) && (fl != BS_FL_EVALUATED || fn < 16u)) passed = 1; else failed = 1;
+      }
+      if (N && fl == BS_FL_EVALUATED && failed) sop->groups.flags[gi] |= BS_GROUP_DENIED;
+      if (passed && io->last_permitted) io->last_permitted[i] = 1;
+    }
     int64_t req[BS_MAX_LANES];
     for (uint32_t j = 0; j < L; ++j) req[j] = pods->req[(size_t)j * P + i];
     const uint32_t pres = pods->req_present[i], cls = pods->cls[i];
@@ -123,21 +152,25 @@ void orc_seq_replay(orc_seq_io* io) {
         rpres[at] |= 1u << sc;
       }
     assumed_on[i] = at;
-    if (!grouped) { io->pod_node[i] = at; continue; }           /* core.go:269-272: Permit lets it through at once */
+    if (!grouped) { io->pod_node[i] = at; continue; }           /* no label, core.go:269-272: Permit lets it through at once */
     bs_groups_soa* gr = &sop->groups;
-    gr->matched[gi] += 1;                                       /* :290 */
+    gr->matched[gi] += 1;                                       /* :290 MatchedPodNodes.Set */
     next_wait[i] = head[gi];
     head[gi] = (int32_t)i;
-    nwait[gi]++;
     if (!orc_permit_ready(gr->matched[gi], gr->min_member[gi], gr->status_scheduled[gi])) continue;   /* :303 */
-    const int first_time = !(gr->flags[gi] & BS_GROUP_SCHEDULED_LATCH);
     gr->flags[gi] |= BS_GROUP_SCHEDULED_LATCH;                  /* :305 */
-    const uint32_t k = nwait[gi];
-    for (int32_t w = head[gi]; w >= 0; w = next_wait[w]) io->pod_node[w] = assumed_on[w];
+    /* sendStartScheduleSignal -> StartBatchSchedule, batchscheduler.go:254-344 */
+    if (gr->flags[gi] & BS_GROUP_PHASE_CLOSED) continue;        /* :258-261 phase is neither PreScheduling nor Scheduling: nobody is
+                                                                 * released, the pod waits on (a late member of a gang in phase Scheduled) */
+    const uint32_t k = gr->matched[gi];                         /* :292,:301 EVERY entry of MatchedPodNodes: the pods of this pass and the
+                                                                 * ones that were waiting when it began (they have no queue index here) */
+    for (int32_t w = head[gi]; w >= 0; w = next_wait[w]) io->pod_node[w] = assumed_on[w];   /* :324 Allow */
     head[gi] = -1;
-    nwait[gi] = 0;
-    gr->status_scheduled[gi] += k;                              /* PostBind per released pod, :327 */
-    if (first_time) {
+    gr->matched[gi] = 0;                                        /* :326 pendingPods.Delete(uid), every entry */
+    gr->status_scheduled[gi] += k;                              /* PostBind once per released pod, core.go:327 (uint32) */
+    if (gr->status_scheduled[gi] >= gr->min_member[gi]) gr->flags[gi] |= BS_GROUP_PHASE_CLOSED;   /* core.go:329-330 phase Scheduled
+                                                                 * (else Scheduling, :331-336: still open) */
+    if (slot_of[gi] == 0xFFFFFFFFu) {
       if (io->n_released < io->cap) {
         io->released_group[io->n_released] = (uint32_t)gi;
         io->released_pods[io->n_released] = k;
@@ -146,12 +179,12 @@ void orc_seq_replay(orc_seq_io* io) {
         slot_of[gi] = io->n_released;
       }
       io->n_released++;
-    } else if (slot_of[gi] != 0xFFFFFFFFu) {
-      io->released_pods[slot_of[gi]] += k;                      /* a late member of a gang that is already through */
+    } else {
+      io->released_pods[slot_of[gi]] += k;                      /* a second release of the same gang (only when Status.Scheduled stays below MinMember: uint32 wrap) */
     }
   }
   io->total_ns = mono_ns() - t0;
-  free(t_first); free(nwait); free(slot_of); free(head); free(next_wait); free(assumed_on);
+  free(t_first); free(slot_of); free(head); free(next_wait); free(assumed_on);
 }
 
 

@@ -64,7 +64,7 @@ class SeqIO(C.Structure):
                 ("pf_code", C.POINTER(C.c_uint8)), ("pod_node", C.POINTER(C.c_int32)), ("cap", C.c_uint32),
                 ("released_group", C.POINTER(C.c_uint32)), ("released_pods", C.POINTER(C.c_uint32)),
                 ("first_ns", C.POINTER(C.c_int64)), ("ready_ns", C.POINTER(C.c_int64)), ("n_released", C.c_uint32), ("total_ns", C.c_int64),
-                ("pf_first_k", C.POINTER(C.c_uint32)), ("pf_leader", C.POINTER(C.c_int32)), ("pick_ns", C.c_int64)]
+                ("pf_first_k", C.POINTER(C.c_uint32)), ("pf_leader", C.POINTER(C.c_int32)), ("last_permitted", C.POINTER(C.c_uint8)), ("pick_ns", C.c_int64)]
 
 
 _lib = None
@@ -308,15 +308,16 @@ def seq_replay(nodes, fit, groups, pods, stages: int = soa.STAGE_PREFILTER | soa
     rg, rp = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
     t_first, t_ready = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
     fk, ld = np.zeros(max(pods.p, 1), np.uint32), np.zeros(max(pods.p, 1), np.int32)
+    lp = np.zeros(max(pods.p, 1), np.uint8)
     ps = pods.as_struct()
     io = SeqIO(C.pointer(sop.struct), C.pointer(ps), stages, pf.ctypes.data_as(C.POINTER(C.c_uint8)), pod_node.ctypes.data_as(C.POINTER(C.c_int32)), cap,
                rg.ctypes.data_as(C.POINTER(C.c_uint32)), rp.ctypes.data_as(C.POINTER(C.c_uint32)),
                t_first.ctypes.data_as(C.POINTER(C.c_int64)), t_ready.ctypes.data_as(C.POINTER(C.c_int64)), 0, 0,
-               fk.ctypes.data_as(C.POINTER(C.c_uint32)), ld.ctypes.data_as(C.POINTER(C.c_int32)))
+               fk.ctypes.data_as(C.POINTER(C.c_uint32)), ld.ctypes.data_as(C.POINTER(C.c_int32)), lp.ctypes.data_as(C.POINTER(C.c_uint8)))
     lib().orc_seq_replay(C.byref(io))
     k = min(int(io.n_released), cap)
     return dict(released_group=rg[:k].copy(), released_pods=rp[:k].copy(), first_ns=t_first[:k].copy(), ready_ns=t_ready[:k].copy(),
-                pod_node=pod_node[: pods.p].copy(), pf_code=pf[: pods.p].copy(), pf_first_k=fk[: pods.p].copy(), pf_leader=ld[: pods.p].copy(), n_released=int(io.n_released), total_ns=int(io.total_ns), pick_ns=int(io.pick_ns),
+                pod_node=pod_node[: pods.p].copy(), pf_code=pf[: pods.p].copy(), pf_first_k=fk[: pods.p].copy(), pf_leader=ld[: pods.p].copy(), last_permitted=lp[: pods.p].copy(), n_released=int(io.n_released), total_ns=int(io.total_ns), pick_ns=int(io.pick_ns),
                 nodes=nodes, groups=sop.groups, iters=sop.iters, leader=sop.leader)
 
 

@@ -75,6 +75,8 @@ def drain(orc, nodes, fit, groups, pods, stages, max_cycles=0):
                 continue
             if g < 0 or g >= groups.g or not out.group_ready[g] or g in stuck or not passes[i0]:
                 continue
+            if groups.flags[g] & soa.GROUP_PHASE_CLOSED:        # batchscheduler.go:258-261
+                continue
             members = [i for i in range(i0, cur.p) if cur.group[i] == g and passes[i]]
             attempt = trial.copy()
             placed = []
@@ -87,7 +89,7 @@ def drain(orc, nodes, fit, groups, pods, stages, max_cycles=0):
                 stuck.add(g)
                 continue
             trial = attempt
-            gang = (g, len(members))
+            gang = (g, len(members) + int(groups.matched[g]))      # every entry of MatchedPodNodes binds (batchscheduler.go:292-333)
             gone += members
             gone_node += placed
             break
@@ -96,9 +98,11 @@ def drain(orc, nodes, fit, groups, pods, stages, max_cycles=0):
         nodes = trial
         if gang is not None:
             g, k = gang
-            groups.matched[g] += k
+            groups.matched[g] = 0                               # pendingPods.Delete(uid), every entry (batchscheduler.go:326)
             groups.flags[g] |= soa.GROUP_SCHEDULED_LATCH
-            groups.status_scheduled[g] += k
+            groups.status_scheduled[g] += np.uint32(k)          # PostBind per released pod (core.go:327)
+            if groups.status_scheduled[g] >= groups.min_member[g]:
+                groups.flags[g] |= soa.GROUP_PHASE_CLOSED       # phase Scheduled (core.go:329-330)
             admitted.append(gang)
         for i, at in zip(gone, gone_node):
             pod_node[orig[i]] = at

@@ -63,6 +63,8 @@ def gang_scene(seed, soa, n_nodes=48, n_groups=10, n_pods=140, filter_on=False):
         nodes.requested[3] = np.minimum(nodes.requested[3], np.maximum(nodes.allocatable[3] - rng.integers(1, 30, nodes.n), 0))
     if seed % 3 == 0:
         pods = compare_order(pods)
+    if seed % 2:                                            # some gangs in a phase StartBatchSchedule does not release (batchscheduler.go:258-261)
+        groups.flags[rng.random(groups.g) < 0.2] |= soa.GROUP_PHASE_CLOSED
     return nodes, fit, groups, pods
 
 
@@ -86,6 +88,21 @@ def test_seq_pass_raw_edge_scenes(seed, bsa, soa, orc):
         s = oracle_pass(orc, nodes, fit, groups, pods, st)
         with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
             check_pass(ctx, s, soa, f"seed {seed} stages {st}")
+
+
+def test_seq_pass_release_kat(bsa, soa, orc):
+    """VERDICT r4's reproducer (tests/test_seq_oracle_pin.py::_kat_scene): the quorum releases the two pods that were ALREADY waiting with
+    the one that completes it (batchscheduler.go:292-343, core.go:327) -> matched 0, Scheduled 3, phase Scheduled, and the next pod of the
+    gang asks for nothing (core.go:136-147 with notFinished 0): PASS_FIRST_FITS, no deny entry"""
+    from test_seq_oracle_pin import _kat_scene
+    sc = _kat_scene()
+    nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"])
+    s = oracle_pass(orc, nodes, fit, groups, pods, soa.STAGE_PREFILTER)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        r = check_pass(ctx, s, soa, "release KAT")
+        g = ctx.read_groups()
+    assert r["pf_code"].tolist() == [soa.PF_PASS_IS_MAX, soa.PF_PASS_FIRST_FITS] and r["released_pods"].tolist() == [3]
+    assert int(g.matched[0]) == 0 and int(g.status_scheduled[0]) == 3 and g.flags[0] & soa.GROUP_PHASE_CLOSED and not g.flags[0] & soa.GROUP_DENIED
 
 
 def test_seq_pass_readme_race_scene(bsa, soa, orc):
