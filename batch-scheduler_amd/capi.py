@@ -78,7 +78,8 @@ class SeqOut(C.Structure):
                 ("pod_node", C.POINTER(C.c_int32)), ("cap", C.c_uint32), ("released_group", C.POINTER(C.c_uint32)),
                 ("released_pods", C.POINTER(C.c_uint32)), ("first_ns", C.POINTER(C.c_int64)), ("ready_ns", C.POINTER(C.c_int64)),
                 ("n_released", C.c_uint32), ("total_ns", C.c_int64), ("node_picks", C.c_uint64), ("node_scans", C.c_uint64),
-                ("scan_rounds", C.c_uint64), ("pick_rounds", C.c_uint64), ("leader_folds", C.c_uint64), ("table_builds", C.c_uint64)]
+                ("scan_rounds", C.c_uint64), ("pick_rounds", C.c_uint64), ("leader_folds", C.c_uint64), ("table_builds", C.c_uint64),
+                ("last_permitted", C.POINTER(C.c_uint8))]
 
 
 _lib = None
@@ -475,11 +476,12 @@ class Context:
         ld, node = np.zeros(n, np.int32), np.full(n, -1, np.int32)
         rg, rp = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
         t0, t1 = np.zeros(cap, np.int64), np.zeros(cap, np.int64)
+        lp = np.zeros(n, np.uint8)
         o = SeqOut(pf.ctypes.data_as(C.POINTER(C.c_uint8)), _u32p(fk), ld.ctypes.data_as(C.POINTER(C.c_int32)), node.ctypes.data_as(C.POINTER(C.c_int32)),
-                   cap, _u32p(rg), _u32p(rp), _i64p(t0), _i64p(t1), 0, 0, 0, 0, 0, 0, 0, 0)
+                   cap, _u32p(rg), _u32p(rp), _i64p(t0), _i64p(t1), 0, 0, 0, 0, 0, 0, 0, 0, lp.ctypes.data_as(C.POINTER(C.c_uint8)))
         self._chk(self._lib.bs_seq_run(self._h, stages, C.byref(o)), "bs_seq_run")
         k = min(int(o.n_released), cap)
-        return dict(pf_code=pf[:p], pf_first_k=fk[:p], pf_leader=ld[:p], pod_node=node[:p], released_group=rg[:k], released_pods=rp[:k],
+        return dict(pf_code=pf[:p], pf_first_k=fk[:p], pf_leader=ld[:p], pod_node=node[:p], last_permitted=lp[:p], released_group=rg[:k], released_pods=rp[:k],
                     first_ns=t0[:k], ready_ns=t1[:k], n_released=int(o.n_released), total_ns=int(o.total_ns), node_picks=int(o.node_picks),
                     node_scans=int(o.node_scans), scan_rounds=int(o.scan_rounds), pick_rounds=int(o.pick_rounds), leader_folds=int(o.leader_folds), table_builds=int(o.table_builds))
 

@@ -75,6 +75,7 @@ struct SeqDev {
   const uint32_t* pclass;        // [P] request class of the pod (equal request lanes + present bits <=> equal class; derived at the pod load)
   // results
   uint8_t* pf_code; int32_t* pod_node; uint32_t* pf_first_k; int32_t* pf_leader;
+  uint8_t* last_permitted;       // [P] prm.filter_deny: 1 = the pass left a lastPermittedPod entry for the pod (core.go:188)
   uint32_t* released_group; uint32_t* released_pods; unsigned long long* first_tick; unsigned long long* ready_tick;
   uint32_t cap;
   unsigned long long* info;      // [0] gangs released [1] clock ticks of the pass [2] first-fit searches [3] node scans [4] sop leader at the end + 1
@@ -111,6 +112,7 @@ struct SeqParams {
   uint32_t cache_slots;          // table summaries kept in LDS (0: every scan walks the node list in rounds)
   uint32_t cache_off;            // byte offset of the summary area in dynamic LDS (behind the key window)
   uint32_t use_cursor;           // first-fit cursors per request class (SeqShared::cur_kn, see k_seq_pass's node choice)
+  uint32_t filter_deny;          // BS_BATCH_FILTER_DENY: Filter's TTL writes (core.go:183-188) happen inside the pass, every node offered
 };
 
 // ---- wave-uniform loads of state this kernel itself writes: vector loads, value moved to SGPRs ---------------------
@@ -225,6 +227,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64_all(unsigned long lon
 struct SeqShared {
   unsigned long long kmax[kSeqWaves];
   uint32_t red[kSeqWaves];
+  uint32_t fdw[2][kSeqWaves];                            // Filter's TTL writes: per wave, bit 0 = a node's Filter failed, bit 1 = a node's Filter passed (parity per use)
   unsigned long long tot[2][BS_MAX_LANES][kSeqWaves];   // per round parity: tile totals, lane-major so that lanes 0..15 read one row
   uint32_t wpres[2][kSeqWaves];
   uint32_t fk[2][kSeqWaves];
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     sq.slot_of[g] = BS_INF;
     sq.t_first[g] = ~0ull;
   }
-  for (uint32_t i = threadIdx.x; i < P; i += kSeqBlock) sq.pod_node[i] = -1;
+  for (uint32_t i = threadIdx.x; i < P; i += kSeqBlock) { sq.pod_node[i] = -1; if (prm.filter_deny) sq.last_permitted[i] = 0; }
   if (t0) { sh_.hit_w[0] = BS_INF; sh_.hit_w[1] = BS_INF; }
   if (threadIdx.x < kSeqPruneTiles / 32) sh_.tight[threadIdx.x] = 0;
   for (uint32_t base = 0; base < N; base += kSeqBlock) {
@@ -1198,6 +1201,40 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       q.ppres = pods.pres[i];
 #pragma unroll
       for (uint32_t j = 0; j < BS_MAX_LANES; ++j) q.preq[j] = j < L ? pods.req[(size_t)j * P + i] : 0;
+      if (prm.filter_deny && grouped) {
+        // ---- Filter's TTL writes (core.go:170-191), every node of the list offered (the batch form's rule, bs_batch_run): a node whose
+        // Filter fails — getLeftResource nil (:545-548) or neither case 2 nor case 3 (:562-563) — deny-lists the group (:183-185) for the
+        // gang's later pods; a node whose Filter passes leaves the pod's lastPermittedPod entry (:188).  The pod itself goes on.
+        bool failed = false, passed = false;
+        if (q.fl == BS_FL_EVALUATED) {
+          if (!drained && stores_pending) { __syncthreads(); stores_pending = false; }      // the assume steps of earlier pods have landed
+          drained = true;
+          for (uint32_t n = threadIdx.x; n < N; n += kSeqBlock) {
+            bool c2 = !(q.ff & 1u), c3h = !(q.ff & 2u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int64_t left = wsub(nd.alloc[(size_t)j * nd.stride + n], sq.nreq[(size_t)j * nd.stride + n]);   // getLeftResource :460-463
+              c2 = c2 && left >= q.FR[j];
+              c3h = c3h && left >= q.FM[j];
+            }
+            const bool ok = !(nd.flags[n] & (BS_NODE_NIL | BS_NODE_NO_NODE)) && (c2 || !c3h);
+            failed = failed || !ok;
+            passed = passed || ok;
+          }
+          const uint32_t par = hit_par & 1u;
+          const uint32_t wbits = (__ballot(failed) ? 1u : 0u) | (__ballot(passed) ? 2u : 0u);
+          if (lane_id() == 0) sh_.fdw[par][wave_id()] = wbits;
+          lds_barrier();
+          uint32_t all = 0;
+#pragma unroll
+          for (int ww = 0; ww < kSeqWaves; ++ww) all |= sh_.fdw[par][ww];
+          all = uni32(all);
+          failed = all & 1u;
+          passed = all & 2u;
+        } else if (q.fl < 16u) passed = N != 0u;                                             // case 1 / no MinResources: nil on every node
+        if (failed) deny = true;                                                             // (written out with PreFilter's own entries below)
+        if (passed && t0) sq.last_permitted[i] = 1;
+      }
       SeqAssumed as;
       // first-fit cursor of the pod's request class (pods of a gang share a template: the search of the next one starts where this
       // one's ended).  Exact while (a) no assumed request has a negative lane — then free capacity only shrinks and a node that

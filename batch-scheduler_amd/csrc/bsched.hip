@@ -264,6 +264,7 @@ struct bs_ctx {
   DevBuf d_fd_event, d_fd_in, d_fd_flag;
   bool fd_on = false;                // the run being launched replays Filter's deny entry
   bool fd_active = false;            // the last batch did, and nobody has looked at its flag words yet (fd_settle)
+  bool fd_unsynced = false;          // a BS_BATCH_FILTER_DENY batch was launched and the stream has not been waited for since
   bool fd_in_live = false;           // a fixed-point re-run: the chains honour d_fd_in
   uint32_t fd_iter = 0, fd_stages = 0, fd_seq_inv = 0;
   uint64_t n_fd_reruns = 0;          // fixed-point re-runs so far (bs_batch_stats_get)
@@ -1106,6 +1107,12 @@ int resolve_epochs(bs_ctx* c) {
 // =================================================================================================
 extern "C" {
 
+// A batch launched on a guessed table (speculation) or with BS_BATCH_FILTER_DENY is only final once fd_settle has looked at it — it may
+// have to run again.  Every call that changes what a batch reads (nodes, fit, groups) or that runs over the state itself (bs_seq_run)
+// settles it FIRST, against the state it was launched on; its results stay readable afterwards.
+static int fd_settle(bs_ctx* c);
+static int settle_pending(bs_ctx* c) { return (c->fd_active || c->spec_active) ? fd_settle(c) : BS_OK; }
+
 uint32_t bs_abi_version(void) { return BS_ABI_VERSION; }
 
 const char* bs_strerror(int status) {
@@ -1223,6 +1230,7 @@ int bs_nodes_load(bs_ctx* c, const bs_nodes_soa* nodes) {
   int rc = use_device(c);
   if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
+  if ((rc = settle_pending(c))) return rc;
   const uint32_t N = nodes->n, L = c->L;
   if (N && (!nodes->allocatable || !nodes->requested || !nodes->allocatable_present || !nodes->requested_present || !nodes->flags))
     return BS_ERR_INVALID;
@@ -1249,6 +1257,7 @@ int bs_fit_load(bs_ctx* c, uint32_t n_classes, const uint32_t* fit_bits) {
   int rc = use_device(c);
   if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
+  if ((rc = settle_pending(c))) return rc;
   c->C = n_classes;
   c->fit_words = cdiv(c->N, 32);
   c->h_fit.assign(fit_bits, fit_bits + (size_t)n_classes * c->fit_words);
@@ -1264,6 +1273,7 @@ int bs_fit_build(bs_ctx* c, const bs_node_labels* nl, const bs_fit_templates* tp
   int rc = use_device(c);
   if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
+  if ((rc = settle_pending(c))) return rc;
   const uint32_t N = c->N, C = tp->c;
   const uint32_t nlab = N ? nl->label_off[N] : 0, ntaint = N ? nl->taint_off[N] : 0;
   const uint32_t nsel = tp->sel_off[C], nterm = tp->term_off[C], ntol = tp->tol_off[C];
@@ -1386,6 +1396,7 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   int rc = use_device(c);
   if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
+  if ((rc = settle_pending(c))) return rc;
   const uint32_t G = g->g, L = c->L;
   if (G && (!g->min_member || !g->status_scheduled || !g->matched || !g->flags || !g->cls || !g->min_resources || !g->min_resources_present ||
             !g->occupied_by))
@@ -1450,6 +1461,7 @@ int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
   if (!c->have_groups) { c->last_error = "bs_groups_apply before bs_groups_load"; return BS_ERR_STATE; }
   int rc = use_device(c);
   if (rc) return rc;
+  if ((rc = settle_pending(c))) return rc;
   if (!count) return BS_OK;
   const uint8_t keep = BS_GROUP_HAS_POD | BS_GROUP_HAS_MINRES;
   for (uint32_t d = 0; d < count; ++d) {            // validate everything before touching anything
@@ -2642,9 +2654,19 @@ static int batch_run_inner(bs_ctx* c, uint32_t stages) {
 // exactly the events it was given.  A verdict only depends on events in FRONT of the pod, so positions settle in queue order;
 // P + 2 runs is the bound nobody gets near (two runs in practice: one that finds, one that confirms).  A committing batch's
 // commit kernels are gated on the device by the same flag word: only the run that is the fixed point commits.
+// The results of a run that is thrown away (a wrong guess, a superseded fixed-point iteration) take their hand-over error word with them:
+// the re-run reports its own.  The lesson is kept: separate launches from now on.
+static void discard_handover(bs_ctx* c) {
+  if (c->h_info && ((volatile int32_t*)c->h_info)[12]) {
+    ((volatile int32_t*)c->h_info)[12] = 0;
+    c->no_fuse_final = 1;
+  }
+}
+
 static int fd_resolve(bs_ctx* c) {
   if (!c->fd_active) return BS_OK;
   c->fd_active = false;
+  c->fd_unsynced = false;                            // (every caller has waited for the batch)
   volatile int32_t* hf = c->h_info + 14;
   if (!hf[0]) return BS_OK;
   int rc = BS_OK;
@@ -2660,6 +2682,7 @@ static int fd_resolve(bs_ctx* c) {
     c->fd_in_live = true;
     c->fd_iter = iter;
     c->epochs_ready = false;                         // the positional analysis depends on fd_in
+    discard_handover(c);
     rc = batch_run_inner(c, stages);
     if (rc == BS_OK) rc = hipStreamSynchronize(c->stream) == hipSuccess ? BS_OK : BS_ERR_HIP;
     c->n_fd_reruns++;
@@ -2693,6 +2716,7 @@ static int fd_settle(bs_ctx* c) {
     if (c->steady_table != c->spec_table) {            // wrong guess: the batch again, on the real answer (nothing of a what-if batch sticks)
       c->n_spec_miss++;
       const bool fd = c->fd_active;
+      discard_handover(c);
       if ((rc = batch_run_inner(c, c->spec_stages))) return rc;
       c->fd_active = fd;
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2715,10 +2739,17 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   }
   int rc = use_device(c);
   if (rc) return rc;
+  if ((stages & BS_BATCH_FILTER_DENY) && c->fd_unsynced) {
+    // the verdict words of a BS_BATCH_FILTER_DENY batch are pinned and untagged: an earlier such batch nobody has waited for may still
+    // store into them (k_fd_apply) after batch_run_inner has reset them from the host — wait for it first
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->fd_unsynced = false;
+  }
   c->fd_active = false;
   c->fd_iter = 0;
   c->fd_in_live = false;
   rc = batch_run_inner(c, stages);
+  if (rc == BS_OK && (stages & BS_BATCH_FILTER_DENY) && c->P) c->fd_unsynced = true;
   if (rc == BS_OK && (stages & BS_BATCH_FILTER_DENY) && c->P) {
     c->fd_active = true;
     c->fd_stages = stages;
@@ -3164,6 +3195,7 @@ int bs_nodes_apply(bs_ctx* c, const bs_node_delta* deltas, uint32_t count) {
   if (!c->have_nodes || !c->have_fit) return BS_ERR_STATE;
   int rc = use_device(c);
   if (rc) return rc;
+  if ((rc = settle_pending(c))) return rc;
   const uint32_t L = c->L, C = c->C;
   // unpack fit bits to one byte vector per class for easy insert/erase
   uint32_t N = c->N;
@@ -3239,6 +3271,7 @@ int bs_nodes_assume(bs_ctx* c, const bs_node_request* reqs, uint32_t count) {
   if (!c->have_nodes) { c->last_error = "bs_nodes_assume before bs_nodes_load"; return BS_ERR_STATE; }
   int rc = use_device(c);
   if (rc) return rc;
+  if ((rc = settle_pending(c))) return rc;
   if (!count) return BS_OK;
   const uint32_t N = c->N, L = c->L;
   {
@@ -3301,15 +3334,23 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
     return BS_ERR_STATE;
   }
   if (!(stages & BS_STAGE_PREFILTER)) { c->last_error = "PREFILTER stage is mandatory"; return BS_ERR_INVALID; }
+  if ((stages & BS_BATCH_FILTER_DENY) && !(stages & BS_STAGE_FILTER)) { c->last_error = "BS_BATCH_FILTER_DENY needs BS_STAGE_FILTER"; return BS_ERR_INVALID; }
   if (c->nranks > 1 || c->reduce_external) { c->last_error = "bs_seq_run is single-rank only (a sequential pass does not shard)"; return BS_ERR_STATE; }
   int rc = use_device(c);
   if (rc) return rc;
+  if ((rc = settle_pending(c))) return rc;
   const uint32_t P = c->P, G = c->G, N = c->N, C = c->C, L = c->L;
   if ((G > c->n_uncaptured && c->max_group_cls >= C) || (P && c->max_pod_cls >= C)) {
     c->last_error = "fit class index out of range (groups.cls / pods.cls vs the loaded fit classes)";
     return BS_ERR_INVALID;
   }
   if (G > 0x7FFFFFF0u) return BS_ERR_CAPACITY;
+  // the first-fit cursors are keyed by the resident queue's request classes: a queue patch whose insert wave ran out of class ids
+  // (h_info[13], set by the device) left them unusable until the queue is re-derived — check_handover does that
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  discard_handover(c);                                      // (an unread batch's hand-over timeout is not this call's business)
+  if ((rc = check_handover(c)) && rc != BS_ERR_STATE) return rc;
+  if (rc == BS_ERR_STATE && (rc = check_handover(c))) return rc;
   out->n_released = 0;
   out->total_ns = 0;
   out->node_picks = out->node_scans = out->scan_rounds = out->pick_rounds = out->leader_folds = out->table_builds = 0;
@@ -3330,6 +3371,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   const size_t o_node = o; o = align256(o + nP * 4);
   const size_t o_fk = o; o = align256(o + nP * 4);
   const size_t o_leader = o; o = align256(o + nP * 4);
+  const size_t o_lperm = o; o = align256(o + nP);
   const size_t o_rg = o; o = align256(o + cap * 4);
   const size_t o_rp = o; o = align256(o + cap * 4);
   const size_t o_ft = o; o = align256(o + cap * 8);
@@ -3362,6 +3404,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   sq.pod_node = reinterpret_cast<int32_t*>(base + o_node);
   sq.pf_first_k = reinterpret_cast<uint32_t*>(base + o_fk);
   sq.pf_leader = reinterpret_cast<int32_t*>(base + o_leader);
+  sq.last_permitted = base + o_lperm;
   sq.released_group = reinterpret_cast<uint32_t*>(base + o_rg);
   sq.released_pods = reinterpret_cast<uint32_t*>(base + o_rp);
   sq.first_tick = reinterpret_cast<unsigned long long*>(base + o_ft);
@@ -3372,6 +3415,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   prm.S = c->S;
   prm.eph_gate = c->cfg.eph_gate;
   prm.run_filter = (stages & BS_STAGE_FILTER) ? 1u : 0u;
+  prm.filter_deny = (stages & BS_BATCH_FILTER_DENY) ? 1u : 0u;
   prm.C = C;
   prm.sop_leader0 = c->sop_leader0;
   prm.keys_in_lds = G <= kSeqKeysLds ? 1u : 0u;
@@ -3437,6 +3481,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
     if (out->pod_node) std::memcpy(out->pod_node, rb + o_node, (size_t)P * 4);
     if (out->pf_first_k) std::memcpy(out->pf_first_k, rb + o_fk, (size_t)P * 4);
     if (out->pf_leader) std::memcpy(out->pf_leader, rb + o_leader, (size_t)P * 4);
+    if (out->last_permitted) { if (prm.filter_deny) std::memcpy(out->last_permitted, rb + o_lperm, P); else std::memset(out->last_permitted, 0, P); }
     c->sop_leader0 = (int32_t)(uint32_t)info[4] - 1;         // sop.maxFinishedPG as the pass left it
   }
   const uint32_t k = std::min(out->n_released, out->cap);
@@ -3536,8 +3581,10 @@ int bs_batch_read_flat(bs_ctx* c, uint8_t* pf_code, uint32_t* pf_first_k, int32_
   return bs_batch_read(c, &o);
 }
 int bs_seq_run_flat(bs_ctx* c, uint32_t stages, uint8_t* pf_code, uint32_t* pf_first_k, int32_t* pf_leader, int32_t* pod_node, uint32_t cap,
-                    uint32_t* released_group, uint32_t* released_pods, int64_t* first_ns, int64_t* ready_ns, int64_t* scalars_out) {
+                    uint32_t* released_group, uint32_t* released_pods, int64_t* first_ns, int64_t* ready_ns, int64_t* scalars_out,
+                    uint8_t* last_permitted) {
   bs_seq_out o{};
+  o.last_permitted = last_permitted;
   o.pf_code = pf_code; o.pf_first_k = pf_first_k; o.pf_leader = pf_leader; o.pod_node = pod_node; o.cap = cap; o.released_group = released_group;
   o.released_pods = released_pods; o.first_ns = first_ns; o.ready_ns = ready_ns;
   const int rc = bs_seq_run(c, stages, &o);

@@ -153,7 +153,11 @@ func (g *gpuCore) runBatch(queue []*corev1.Pod, groupIndex map[string]uint32, pe
 	}
 	// Filter is on in this form: BS_BATCH_FILTER_DENY replays the deny entry a failing Filter writes (core.go:183-185) inside the
 	// batch, on the device — the codes are those of PreFilter + Filter-on-every-node, pod by pod (round 3 did that in a Go pass here)
-	if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, C.BS_STAGE_ALL|C.BS_BATCH_FILTER_DENY)); err != nil {
+	stages := C.uint32_t(C.BS_STAGE_ALL)
+	if g.ranks <= 1 { // the deny replay is single-rank (bs_batch_run answers BS_ERR_STATE on sharded / externally reduced contexts)
+		stages |= C.BS_BATCH_FILTER_DENY
+	}
+	if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, stages)); err != nil {
 		return nil, err
 	}
 	var rowsNeeded C.uint32_t
@@ -187,13 +191,26 @@ type queueDelta struct {
 // cycleView: the results of a latency-mode batch, read IN PLACE from the pinned memory the last launch wrote (bs_batch_map):
 // no device-to-host copy, no stream wait, no host-side copy.  Valid until the next cycle runs.
 type cycleView struct {
-	v C.bs_batch_view
+	v    C.bs_batch_view
+	copy *cycleCopy // set when bs_batch_map declined (BS_ERR_STATE): the results were copied out with bs_batch_read_flat instead
+}
+
+// cycleCopy: the cycle's results in Go memory (the fall-back of runCycle)
+type cycleCopy struct {
+	pfCode []C.uint8_t
+	ready  []C.uint8_t
 }
 
 func (c *cycleView) pfCode(i int) uint8 {
+	if c.copy != nil {
+		return uint8(c.copy.pfCode[i])
+	}
 	return uint8(*(*C.uint8_t)(unsafe.Pointer(uintptr(unsafe.Pointer(c.v.pf_code)) + uintptr(i))))
 }
 func (c *cycleView) groupReady(g int) bool {
+	if c.copy != nil {
+		return c.copy.ready[g] != 0
+	}
 	return *(*C.uint8_t)(unsafe.Pointer(uintptr(unsafe.Pointer(c.v.group_ready)) + uintptr(g))) != 0
 }
 func (c *cycleView) filterPasses(i, k int) bool { // Filter(pod i, node k), core.go:170-191, as a bit test in the mapped rows
@@ -256,8 +273,21 @@ func (g *gpuCore) runCycle(d *queueDelta, groupIndex map[string]uint32, permitte
 		return nil, err
 	}
 	res := &cycleView{}
-	if err := g.check("bs_batch_map", C.bs_batch_map(g.ctx, &res.v)); err != nil {
-		return nil, err // BS_ERR_STATE: the batch took the general chain (more than sixteen leader runs): read it with bs_batch_read
+	if rc := C.bs_batch_map(g.ctx, &res.v); rc == C.BS_ERR_STATE {
+		// not a failed cycle: the batch left the three-launch chains (more than sixteen leader runs, or a re-run behind a wrong
+		// table guess ended on the general chain), which write no host results — the results are valid, copy them out
+		var pc C.uint32_t
+		if err := g.check("bs_pods_count", C.bs_pods_count(g.ctx, &pc)); err != nil {
+			return nil, err
+		}
+		P := int(pc)
+		res.copy = &cycleCopy{pfCode: make([]C.uint8_t, P+1), ready: make([]C.uint8_t, g.groups+1)}
+		if err := g.check("bs_batch_read_flat", C.bs_batch_read_flat(g.ctx, &res.copy.pfCode[0], nil, nil, nil, nil, nil, nil, &res.copy.ready[0],
+			nil, nil, nil, 0, nil)); err != nil {
+			return nil, err
+		}
+	} else if err := g.check("bs_batch_map", rc); err != nil {
+		return nil, err
 	}
 	return res, nil
 }
@@ -271,23 +301,24 @@ type seqResult struct {
 	releasedGroup []C.uint32_t
 	releasedPods  []C.uint32_t
 	readyNs       []C.int64_t
+	lastPermitted []C.uint8_t // withFilter: 1 = Filter passed somewhere -> the plugin adds the pod to lastPermittedPod (core.go:188, 2 s TTL)
 	nReleased     int
 }
 
 func (g *gpuCore) seqPass(P int, withFilter bool) (*seqResult, error) {
 	cap := g.groups + 1
 	r := &seqResult{pfCode: make([]C.uint8_t, P+1), podNode: make([]C.int32_t, P+1), releasedGroup: make([]C.uint32_t, cap),
-		releasedPods: make([]C.uint32_t, cap), readyNs: make([]C.int64_t, cap)}
+		releasedPods: make([]C.uint32_t, cap), readyNs: make([]C.int64_t, cap), lastPermitted: make([]C.uint8_t, P+1)}
 	firstNs := make([]C.int64_t, cap)
 	var scalars [8]C.int64_t
 	stages := C.uint32_t(C.BS_STAGE_PREFILTER)
-	if withFilter {
-		stages |= C.BS_STAGE_FILTER
+	if withFilter { // Filter as the reference runs it: it gates the node choice AND writes its deny / lastPermittedPod entries (core.go:183-188)
+		stages |= C.BS_STAGE_FILTER | C.BS_BATCH_FILTER_DENY
 	}
 	g.mu.Lock()
 	defer g.mu.Unlock()
 	if err := g.check("bs_seq_run_flat", C.bs_seq_run_flat(g.ctx, stages, &r.pfCode[0], nil, nil, &r.podNode[0], C.uint32_t(cap),
-		&r.releasedGroup[0], &r.releasedPods[0], &firstNs[0], &r.readyNs[0], &scalars[0])); err != nil {
+		&r.releasedGroup[0], &r.releasedPods[0], &firstNs[0], &r.readyNs[0], &scalars[0], &r.lastPermitted[0])); err != nil {
 		return nil, err
 	}
 	r.nReleased = int(scalars[0])

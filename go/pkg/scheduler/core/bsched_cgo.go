@@ -1,4 +1,4 @@
-// Package core — cgo binding of libbsched.so (include/bsched.h, ABI v4) for tenstack/batch-scheduler.
+// Package core — cgo binding of libbsched.so (include/bsched.h, ABI v6) for tenstack/batch-scheduler.
 //
 // SOURCE ONLY.  The image this library is developed in has no Go toolchain and k8s.io/kubernetes v1.17.5 is
 // not vendored, so this file has been through neither `go build` nor `go vet`; it is kept as a real file
@@ -50,6 +50,7 @@ type gpuCore struct {
 	nodeIdx  map[string]int        // node name -> list index of the loaded snapshot (Filter's bit test)
 	fitRows  int                   // fit classes the device holds rows for (len(reps) at the last bs_fit_load)
 	groups   int                   // groups of the last bs_groups_load (sizes admit / ready)
+	ranks    int                   // ranks the context was sharded over (bs_shard_set; 0 / 1 = a single-rank context)
 }
 
 func newGPUCore(device int, scalars []corev1.ResourceName) (*gpuCore, error) {

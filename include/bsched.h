@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BS_ABI_VERSION 5u
+#define BS_ABI_VERSION 6u
 
 enum {
   BS_LANE_CPU = 0,       /* Resource.MilliCPU          */
@@ -497,7 +497,16 @@ int bs_filter_rows_count(bs_ctx* ctx, uint32_t* rows);
  * eph} binds when the pod asks for it; pods lane: requested + 1 <= allocatable; a requested scalar needs the allocatable
  * key).  Assume: requested += request, pods lane + 1.  A pod that passes PreFilter but finds no node holds nothing; pods of
  * a gang that never reaches its quorum keep what they assumed (as the reference does until the Permit timeout).
- * `stages`: BS_STAGE_PREFILTER (mandatory) [| BS_STAGE_FILTER].  Single-rank contexts only.
+ * `stages`: BS_STAGE_PREFILTER (mandatory) [| BS_STAGE_FILTER [| BS_BATCH_FILTER_DENY]].  Single-rank contexts only.
+ * With BS_STAGE_FILTER the plugin's Filter gates the node choice (a what-if: no TTL write).  With BS_BATCH_FILTER_DENY as well, Filter's
+ * own TTL writes happen inside the pass under the batch form's offer rule — Filter is called on EVERY node of the list, with the node
+ * requests as the pods before this one left them: a node whose Filter fails deny-lists the pod's group (core.go:183-185; the gang's
+ * later pods are turned away at :105-110, BS_GROUP_DENIED is set in the group state), a node whose Filter passes leaves the pod's
+ * lastPermittedPod entry (:188, reported in `last_permitted`).  The pod itself goes on to the node choice among the passing nodes.
+ * The release step is the reference's: at the quorum EVERY entry of MatchedPodNodes binds — the pods this pass placed and the
+ * groups.matched pods that were already waiting (they have no queue index: they count in released_pods and in Status.Scheduled and get
+ * no pod_node) —, matched returns to 0 (batchscheduler.go:292-333, core.go:327), and once Status.Scheduled >= MinMember the phase is
+ * Scheduled (BS_GROUP_PHASE_CLOSED is set) and later members of the gang wait without being released (batchscheduler.go:258-261).
  * On return the context's node requests, group counters / flags / MinResources / OccupiedBy ARE the state the pass left
  * (bs_groups_read, bs_nodes_read; later batches and passes start from it); the queue itself is unchanged (remove the released
  * pods with bs_pods_apply).  Results are bit-identical to the reference's sequential pass on the same inputs
@@ -509,7 +518,7 @@ typedef struct bs_seq_out {
   int32_t*  pod_node;        /* [p] node of every RELEASED pod (its gang reached the quorum, or it has no gang), else -1 (NULL ok) */
   uint32_t  cap;             /* capacity of the four per-gang arrays below                                             */
   uint32_t* released_group;  /* [cap] gangs in the order their quorum turned true                                      */
-  uint32_t* released_pods;   /* [cap] pods released with each (late members of a gang that is through are added)       */
+  uint32_t* released_pods;   /* [cap] pods released with each: every MatchedPodNodes entry, the earlier cycles' waiting pods included */
   int64_t*  first_ns;        /* [cap] device clock, ns since the pass began: the gang's first pod entered PreFilter    */
   int64_t*  ready_ns;        /* [cap] ... the quorum of core.go:303 turned true (NULL ok for all four)                 */
   uint32_t  n_released;      /* out: gangs released (may exceed cap: the first cap are recorded)                       */
@@ -521,6 +530,8 @@ typedef struct bs_seq_out {
    * usually needs none. */
   uint64_t  node_picks, node_scans, scan_rounds, pick_rounds, leader_folds;
   uint64_t  table_builds;    /* out: (fit class, percent) tables whose tile summaries were taken from scratch (LDS cache misses) */
+  uint8_t*  last_permitted;  /* [p] BS_STAGE_FILTER | BS_BATCH_FILTER_DENY passes: 1 = a Filter call of the pod passed, i.e. the pass left a
+                              * lastPermittedPod entry for it (core.go:188; the 2 s clock stays with the caller); NULL ok (ABI v6)     */
 } bs_seq_out;
 int bs_seq_run(bs_ctx* ctx, uint32_t stages, bs_seq_out* out);
 /* The node requests as the context holds them (after bs_nodes_load / bs_nodes_apply / bs_nodes_assume / bs_seq_run):
@@ -611,7 +622,8 @@ int bs_batch_read_flat(bs_ctx* ctx, uint8_t* pf_code, uint32_t* pf_first_k, int3
 /* bs_seq_run: the five scalar results come back through `scalars_out` = {n_released, total_ns, node_picks, node_scans, scan_rounds,
  * pick_rounds, leader_folds, table_builds} (int64[8], NULL ok) */
 int bs_seq_run_flat(bs_ctx* ctx, uint32_t stages, uint8_t* pf_code, uint32_t* pf_first_k, int32_t* pf_leader, int32_t* pod_node, uint32_t cap,
-                    uint32_t* released_group, uint32_t* released_pods, int64_t* first_ns, int64_t* ready_ns, int64_t* scalars_out);
+                    uint32_t* released_group, uint32_t* released_pods, int64_t* first_ns, int64_t* ready_ns, int64_t* scalars_out,
+                    uint8_t* last_permitted);
 /* bs_fit_build: node tables, then the template tables; `ex_*` = bs_fit_templates.exprs, `fd_*` = bs_fit_templates.fields */
 int bs_fit_build_flat(bs_ctx* ctx, uint32_t n, const uint32_t* name, const uint32_t* label_off, const uint32_t* label_key, const uint32_t* label_val,
                       const int64_t* label_int, const uint8_t* label_int_ok, const uint32_t* taint_off, const uint32_t* taint_key,

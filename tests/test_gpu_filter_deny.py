@@ -166,3 +166,36 @@ def test_flag_needs_filter_and_one_rank(bsa, soa):
         with pytest.raises(bsa.capi.BsError) as e:
             ctx.run(flags(soa))
         assert e.value.status == -4            # BS_ERR_STATE
+
+
+def test_back_to_back_batches_without_a_read_in_between(bsa, soa, orc):
+    """the verdict words of a BS_BATCH_FILTER_DENY batch are pinned and untagged.  An unread batch that found events,
+    followed at once by a committing batch on the same stream: the second one's answer and the committed state must be its own."""
+    hit = 0
+    for seed in range(7000, 7080):
+        nodes, fit, groups, pods = scene(seed, steady=False)
+        first = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL, bitmap=False)
+        with_deny = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, flags(soa), bitmap=False)
+        hit += int(not np.array_equal(first.pf_code, with_deny.pf_code))
+        sop = orc.Sop(orc.Snapshot(nodes, fit), groups)
+        exp = sop.batch(pods, flags(soa), bitmap=False)            # (the oracle's batch mutates sop.groups: that is the committed state)
+        with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+            ctx.run(flags(soa))                                    # found events or not: nobody looks
+            ctx.run(flags(soa) | soa.BATCH_COMMIT)
+            got = ctx.read(bitmap=False, rows=False)
+            assert_batch_equal(got, exp, f"seed {seed}", bitmap=False)
+            assert ctx.read_groups().state_equal(sop.groups), f"seed {seed}: committed group state"
+    assert hit >= 20
+
+
+def test_a_group_patch_between_run_and_read_settles_the_batch_first(bsa, soa, orc):
+    """speculative and Filter-deny batches are settled when their results are first asked for; a state-mutating call in
+    between (bs_groups_apply here) settles them FIRST, against the state they were launched on."""
+    for seed in range(7100, 7140):
+        nodes, fit, groups, pods = scene(seed, steady=bool(seed % 2))
+        exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, flags(soa), bitmap=False)
+        with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+            ctx.run(flags(soa))
+            g = int(seed % groups.g)
+            ctx.apply_group_deltas([(g, int(groups.matched[g]) + 1, int(groups.status_scheduled[g]), int(groups.flags[g]))])
+            assert_batch_equal(ctx.read(bitmap=False, rows=False), exp, f"seed {seed}", bitmap=False)

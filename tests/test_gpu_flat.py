@@ -68,7 +68,7 @@ def test_flat_forms_equal_struct_forms(bsa, soa, orc):
         i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
         u32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
         chk(lib.bs_seq_run_flat(ctx._h, soa.STAGE_PREFILTER, pf.ctypes.data_as(C.POINTER(C.c_uint8)), None, None, node.ctypes.data_as(C.POINTER(C.c_int32)), cap,
-                                u32(rg), u32(rp), i64(t0), i64(t1), i64(sc)), "bs_seq_run_flat")
+                                u32(rg), u32(rp), i64(t0), i64(t1), i64(sc), None), "bs_seq_run_flat")
         r = ref.seq_run(soa.STAGE_PREFILTER)
         k = r["n_released"]
         assert sc[0] == k > 0 and np.array_equal(pf, r["pf_code"]) and np.array_equal(node, r["pod_node"]) and np.array_equal(rg[:k], r["released_group"])

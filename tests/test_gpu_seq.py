@@ -29,7 +29,9 @@ def assert_groups_equal(got, exp, soa, where=""):
 
 def check_pass(ctx, s, soa, where=""):
     """one bs_seq_run on `ctx` against the oracle's record `s` of the same pass"""
-    r = ctx.seq_run(soa.STAGE_PREFILTER | (s["stages"] & soa.STAGE_FILTER))
+    r = ctx.seq_run(soa.STAGE_PREFILTER | (s["stages"] & (soa.STAGE_FILTER | soa.BATCH_FILTER_DENY)))
+    if s["stages"] & soa.BATCH_FILTER_DENY:
+        assert np.array_equal(r["last_permitted"], s["last_permitted"]), f"{where}: lastPermittedPod entries the pass leaves (core.go:188)"
     bad = np.nonzero(r["pf_code"] != s["pf_code"])[0]
     assert bad.size == 0, f"{where}: pf_code differs first at pod {bad[0]}: {r['pf_code'][bad[0]]} vs {s['pf_code'][bad[0]]}"
     assert np.array_equal(r["pf_first_k"], s["pf_first_k"]), f"{where}: first_k"
@@ -68,10 +70,10 @@ def gang_scene(seed, soa, n_nodes=48, n_groups=10, n_pods=140, filter_on=False):
     return nodes, fit, groups, pods
 
 
-@pytest.mark.parametrize("filter_on", [False, True], ids=["prefilter", "prefilter+filter"])
+@pytest.mark.parametrize("filter_on", [0, 1, 2], ids=["prefilter", "prefilter+filter", "prefilter+filter+ttl-writes"])
 @pytest.mark.parametrize("seed", range(4200, 4260))
 def test_seq_pass_random_object_scenes(seed, filter_on, bsa, soa, orc):
-    st = soa.STAGE_PREFILTER | soa.STAGE_TALLY | (soa.STAGE_FILTER if filter_on else 0)
+    st = soa.STAGE_PREFILTER | soa.STAGE_TALLY | (soa.STAGE_FILTER if filter_on else 0) | (soa.BATCH_FILTER_DENY if filter_on == 2 else 0)
     nodes, fit, groups, pods = gang_scene(seed, soa)
     s = oracle_pass(orc, nodes, fit, groups, pods, st)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
@@ -84,7 +86,7 @@ def test_seq_pass_raw_edge_scenes(seed, bsa, soa, orc):
     division of core.go:716-717), fully scheduled leaders (the tie rule :729-731), negative scalar requests"""
     sc = random_objects(seed)
     nodes, fit, groups, pods, _ = nv.to_soa(sc["nodes"], sc["cache"], sc["pods"], sc["names"], sc["n_classes"], denied=sc["denied"], permitted=sc["permitted"])
-    for st in (soa.STAGE_PREFILTER, soa.STAGE_PREFILTER | soa.STAGE_FILTER):
+    for st in (soa.STAGE_PREFILTER, soa.STAGE_PREFILTER | soa.STAGE_FILTER, soa.STAGE_PREFILTER | soa.STAGE_FILTER | soa.BATCH_FILTER_DENY):
         s = oracle_pass(orc, nodes, fit, groups, pods, st)
         with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
             check_pass(ctx, s, soa, f"seed {seed} stages {st}")
@@ -120,9 +122,9 @@ def test_seq_pass_readme_race_scene(bsa, soa, orc):
 @pytest.mark.parametrize("config,scenario", [("tiny", "cold"), ("tiny", "warm"), ("tiny", "tail"), ("tiny", "busy"),
                                              ("cfg2", "cold"), ("cfg2", "warm"), ("cfg2", "tail"), ("cfg2", "busy")])
 @pytest.mark.parametrize("order", ["as-is", "compare"])
-@pytest.mark.parametrize("filter_on", [False, True], ids=["prefilter", "prefilter+filter"])
+@pytest.mark.parametrize("filter_on", [0, 1, 2], ids=["prefilter", "prefilter+filter", "prefilter+filter+ttl-writes"])
 def test_seq_pass_synthetic_configs(config, scenario, order, filter_on, bsa, soa, orc):
-    st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if filter_on else 0)
+    st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if filter_on else 0) | (soa.BATCH_FILTER_DENY if filter_on == 2 else 0)
     nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
     if order == "compare":
         pods = compare_order(pods)
@@ -133,16 +135,19 @@ def test_seq_pass_synthetic_configs(config, scenario, order, filter_on, bsa, soa
         assert r["n_released"] > 0
 
 
-@pytest.mark.parametrize("scenario,filter_on", [("tail", False), ("cold", False), ("tail", True)])
+@pytest.mark.parametrize("scenario,filter_on", [("tail", 0), ("cold", 0), ("tail", 1), ("tail", 2), ("warm", 2)])
 def test_seq_pass_cfg3_full_size(scenario, filter_on, bsa, soa, orc):
     """BASELINE config 3 (10k pods / 2k groups / 5k nodes, 5 lanes), the whole pass against the oracle's"""
-    st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if filter_on else 0)
+    st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if filter_on else 0) | (soa.BATCH_FILTER_DENY if filter_on == 2 else 0)
     nodes, fit, groups, pods, _ = bsa.synth.make("cfg3", scenario)
     pods = compare_order(pods)
     s = oracle_pass(orc, nodes, fit, groups, pods, st)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
         r = check_pass(ctx, s, soa, f"cfg3/{scenario}")
-    assert r["n_released"] > 100
+    if filter_on == 2:                                      # every node offered: some node fails Filter for nearly every pod, the gangs are deny-listed
+        assert np.count_nonzero(r["pf_code"] == soa.PF_ERR_DENIED) > 1000
+    else:
+        assert r["n_released"] > 100
 
 
 def test_state_after_a_pass_feeds_batches_and_the_next_pass(bsa, soa, orc):
