@@ -16,9 +16,17 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.environ.get("BS_LIB_DIR") or HERE
 PREBUILT_ONLY = bool(os.environ.get("BS_LIB_DIR"))
 LIB_PATH = os.path.join(LIB_DIR, "libbsched.so")
-SOURCES = ["bsched.hip"]
-HEADERS = ["bs_common.hpp", "bs_kernels.hpp", "bs_fast.hpp", "bs_filter_t.hpp", "bs_epoch.hpp", "bs_queue.hpp", "bs_fdeny.hpp", "bs_seq.hpp", "bs_sort.hpp", "bs_fit.hpp", os.path.join("..", "..", "include", "bsched.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+# translation units -> the headers each one depends on (bs_launch.hpp is the interface between them; DESIGN.md section 4 "Build")
+_COMMON = ["bs_common.hpp", "bs_kernels.hpp", "bs_launch.hpp", os.path.join("..", "..", "include", "bsched.h")]
+UNITS = {
+    "bsched.hip": _COMMON + ["bs_fast.hpp", "bs_filter_t.hpp", "bs_epoch.hpp", "bs_queue.hpp", "bs_fdeny.hpp", "bs_seq.hpp", "bs_sort.hpp", "bs_fit.hpp"],
+    "tu_fast.hip": _COMMON + ["bs_fast.hpp", "bs_filter_t.hpp"],
+    "tu_seq.hip": _COMMON + ["bs_seq.hpp"],
+}
+SOURCES = list(UNITS)
+HEADERS = sorted({h for hs in UNITS.values() for h in hs})
+OBJ_DIR = os.path.join(HERE, "build")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
@@ -61,21 +69,68 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+def _obj(src: str) -> str:
+    return os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+
+
+def _unit_stale(src: str) -> bool:
+    o = _obj(src)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in [src] + UNITS[src])
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None, unity: bool = False) -> str:
+    """Compiles the translation units that are out of date (in parallel) and links libbsched.so.  extra_flags (probe / experiment builds)
+    always rebuild everything; unity=True compiles bsched.hip alone with -DBS_UNITY (it then includes the other units: the probe builds
+    need their __device__ probe arrays in ONE translation unit)."""
     if PREBUILT_ONLY:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"BS_LIB_DIR is set but {LIB_PATH} does not exist")
         return LIB_PATH
-    if not force and not is_stale():
+    if not force and not extra_flags and not is_stale():
         return LIB_PATH
-    cmd = [hipcc(), *FLAGS, *(extra_flags or []), "-o", LIB_PATH, *[os.path.join(CSRC, s) for s in SOURCES], "-ldl"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if unity:
+        cmd = [hipcc(), *FLAGS, "-shared", "-DBS_UNITY", *(extra_flags or []), "-o", LIB_PATH, os.path.join(CSRC, "bsched.hip"), "-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        for src in SOURCES:                                   # the objects no longer match the library
+            if os.path.exists(_obj(src)):
+                os.remove(_obj(src))
+        return LIB_PATH
+    todo = [src for src in SOURCES if force or extra_flags or _unit_stale(src)]
+    procs = []
+    for src in todo:
+        cmd = [hipcc(), *FLAGS, *(extra_flags or []), "-c", "-o", _obj(src), os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = []
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            failed.append(f"{src}:\n{out}")
+        elif verbose and out:
+            print(out)
+    if failed:
+        for src, _ in procs:                                  # never leave a half-built set that looks fresh
+            if os.path.exists(_obj(src)) and any(f.startswith(src) for f in failed):
+                os.remove(_obj(src))
+        raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *[_obj(src) for src in SOURCES], "-ldl"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    if verbose and res.stderr:
-        print(res.stderr)
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+    if extra_flags:
+        for src in SOURCES:                                   # objects of an experiment build must not be taken for the shipped ones
+            os.remove(_obj(src))
     return LIB_PATH
 
 

@@ -9,6 +9,20 @@
 
 #include "../../include/bsched.h"
 
+// Which translation unit emits the NON-template kernels of the shared headers (a template kernel is emitted where it is instantiated):
+// bsched.hip (BS_TU_MAIN) everything but the two Filter kernels tu_fast.hip launches; tu_fast.hip (BS_TU_FAST) those two; tu_seq.hip
+// (BS_TU_SEQ) none; a unity build (-DBS_UNITY: none of the three macros) all of them.
+#if defined(BS_TU_FAST) || defined(BS_TU_SEQ)
+#define BS_EMIT_MAIN 0
+#else
+#define BS_EMIT_MAIN 1
+#endif
+#if defined(BS_TU_MAIN) || defined(BS_TU_SEQ)
+#define BS_EMIT_FAST 0
+#else
+#define BS_EMIT_FAST 1
+#endif
+
 #define BS_INF 0xFFFFFFFFu
 
 namespace bs {

@@ -52,6 +52,7 @@ __device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b
 //   gstat[2][g] first such pod with OwnerReferences              gstat[3][g] head of the group's pair chain
 // A pair = (group, request class); its id is the index of its representative pod.
 // ------------------------------------------------------------------------------------------------
+#if BS_EMIT_MAIN
 __global__ void k_pods_prep(unsigned long long* tables, uint32_t ntab, uint32_t* gstat, uint32_t ngstat, uint32_t* kcount, uint32_t* gcount, uint32_t G) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
   for (uint32_t i = t; i < ntab; i += nt) tables[i] = 0ull;
@@ -59,10 +60,12 @@ __global__ void k_pods_prep(unsigned long long* tables, uint32_t ntab, uint32_t*
   for (uint32_t i = t; i < ngstat; i += nt) gstat[i] = BS_INF;     // [3][G] minima + [G] 64-bit chain heads = 5 G words, all ones
   if (t == 0 && kcount) *kcount = 0;
 }
+#endif
 
 // Second half of the class builder (every pod takes its representative's dense id) fused with the per-group
 // minima and the pair table.  `hinfo` = pinned host memory: K is handed to the host without a copy or an event
 // (value, then the tag with system-scope release; the host only looks when it needs the row count).
+#if BS_EMIT_MAIN
 __global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* rep, const uint32_t* id, uint32_t* pclass, unsigned long long* slots, uint32_t mask,
                             uint32_t hash_keep, uint32_t* gstat, uint32_t* ppair, unsigned long long* pair_next, const uint32_t* kcount, int32_t tag,
                             int32_t* hinfo, uint32_t* gcount) {
@@ -97,6 +100,7 @@ __global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* rep, const
     pair_next[i] = atomicExch(head, ((unsigned long long)c << 32) | i);
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // bs_groups_load / bs_groups_apply: findMaxPG for the loaded state + what the host wants to know about it
@@ -105,6 +109,7 @@ __global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* rep, const
 // ------------------------------------------------------------------------------------------------
 struct GroupDelta { uint32_t index, matched, status_scheduled, flags; };
 
+#if BS_EMIT_MAIN
 __global__ void k_groups_apply(const GroupDelta* d, uint32_t n, uint32_t* matched, uint32_t* status_scheduled, uint8_t* flags) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
@@ -113,6 +118,7 @@ __global__ void k_groups_apply(const GroupDelta* d, uint32_t n, uint32_t* matche
   status_scheduled[x.index] = x.status_scheduled;
   flags[x.index] = (uint8_t)x.flags;
 }
+#endif
 
 constexpr int kInlineDeltas = 48;                  // group deltas that ride in the kernel arguments (no H2D, no staging)
 struct DeltaPack { uint32_t n; GroupDelta d[kInlineDeltas]; };
@@ -215,10 +221,12 @@ __device__ __forceinline__ void leader_info_block(const GroupsDev& gr, const Bat
   }
 }
 
+#if BS_EMIT_MAIN
 __global__ __launch_bounds__(kLeaderBlock) void k_leader_info(GroupsDev gr, BatchDev b, uint32_t C, int32_t tag, int32_t* info, DeltaPack dp,
                                                               uint32_t* matched, uint32_t* status_scheduled, uint8_t* flags) {
   leader_info_block(gr, b, C, tag, info, dp, matched, status_scheduled, flags);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // launch A, table part: chunk-local running sums (core.go:602,621 restarted at every 256-row chunk), chunk
@@ -783,30 +791,35 @@ template <int PU, bool DB>
 __global__ __launch_bounds__(256) void k_fast_filter(PodsDev pods, NodesDev nd, BatchDev bt, BatchParams prm, uint32_t filter_waves, uint32_t ustride) {
   filter_loop<2, PU, DB>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x, gridDim.x, prm.stamp, 2u * prm.k_host);
 }
+#if BS_EMIT_FAST
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k_fast_filter_w7(PodsDev pods, NodesDev nd, BatchDev bt, BatchParams prm, uint32_t filter_waves,
                                                                                                 uint32_t ustride) {
   filter_loop<2, 2, false>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x, gridDim.x, prm.stamp, 2u * prm.k_host);
 }
+#endif
 // BS_TP_FILTER=5: the transposed item (bs_filter_t.hpp): lanes are request slots, nodes come through the scalar cache
+#if BS_EMIT_FAST
 __global__ __launch_bounds__(256) void k_fast_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t filter_waves, uint32_t ustride) {
   filter_loop_t(nd, bt, filter_waves, ustride, prm.collect_stats, blockIdx.x, gridDim.x, prm.stamp, 2u * prm.k_host);
 }
+#endif
 // BS_TP_FILTER=6 / 7: both roles in ONE launch again (the scan's dependent-load chains and the Filter loop's compares overlap), the
 // Filter role taken by the transposed item; 7: the Filter blocks carry the LOW block indices (dispatched first)
 template <int S>
 __global__ __launch_bounds__(256) void k_fast_scan_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t scan_blocks,
                                                             uint32_t filter_waves, uint32_t ustride, uint32_t filter_first) {
-  __shared__ int64_t s_rows[4][64][4 + S];
   const uint32_t filter_blocks = gridDim.x - scan_blocks;
   const bool is_scan = filter_first ? blockIdx.x >= filter_blocks : blockIdx.x < scan_blocks;
   if (is_scan)
-    scan_loop<S, true, 1>(bt, prm, m, jcap, 0u, 0u, 1u, filter_first ? blockIdx.x - filter_blocks : blockIdx.x, scan_blocks, s_rows[wave_id()]);
+    scan_loop<S, true, 3>(bt, prm, m, jcap, 0u, 0u, 1u, filter_first ? blockIdx.x - filter_blocks : blockIdx.x, scan_blocks, nullptr);   // (rows from the scalar cache: no LDS)
   else
     filter_loop_t(nd, bt, filter_waves, ustride, prm.collect_stats, filter_first ? blockIdx.x : blockIdx.x - scan_blocks, filter_blocks, prm.stamp, 2u * prm.k_host);
 }
+#if BS_EMIT_MAIN
 __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {
   fast_final_block(pods, gr, nd, b, prm, query_blocks, blockIdx.x, gridDim.x, 0u);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // launches B and C as ONE launch: [0, scan_blocks) node scan | [.., + filter_blocks) Filter evaluation | the rest: final
@@ -867,6 +880,7 @@ __global__ __launch_bounds__(kTblChunk) void k_tables_local_nofix(NodesDev nd, B
 // (leader_block) afterwards.  A uint32 divide by zero (:716-717) at some epoch panics every later epoch too.
 // key = (F + 1) << 31 | (0x7FFFFFFF - group): larger F wins, then the smaller group index; 0 = no candidate.
 // ------------------------------------------------------------------------------------------------
+#if BS_EMIT_MAIN
 __global__ __launch_bounds__(kLeaderBlock) void k_leader_scan(GroupsDev gr, BatchDev b) {
   __shared__ unsigned long long s_w[kLeaderBlock / 64];
   __shared__ uint32_t s_p[kLeaderBlock / 64];
@@ -941,10 +955,12 @@ __global__ __launch_bounds__(kLeaderBlock) void k_leader_scan(GroupsDev gr, Batc
     for (uint32_t x = 0; x < nex; ++x) { __syncthreads(); leader_block(gr, b, s_exact[x]); }
   }
 }
+#endif
 
 // BS_BATCH_COMMIT on the fast path: every group has its pod and MinResources already, so what sequential
 // PreFilter calls would leave behind is OccupiedBy (core.go:494-500) and the deny entries (:142,:163).
 // gate: BS_BATCH_FILTER_DENY's flag word — a run that is not the fixed point (bs_fdeny.hpp) commits nothing
+#if BS_EMIT_MAIN
 __global__ void k_fast_commit(PodsDev pods, BatchDev b, uint8_t* gflags, uint64_t* gocc, uint32_t G, const uint32_t* gate) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G || (gate && *gate)) return;
@@ -958,5 +974,6 @@ __global__ void k_fast_commit(PodsDev pods, BatchDev b, uint8_t* gflags, uint64_
   if (fr != BS_INF) fl |= BS_GROUP_DENIED;
   gflags[g] = fl;
 }
+#endif
 
 }  // namespace bs

@@ -1,0 +1,31 @@
+// bs_launch.hpp — the launch wrappers that live in translation units of their own (tu_fast.hip, tu_seq.hip), so that the library builds
+// in parallel and a change to one kernel family recompiles that family only.  Kernels in the shared headers are `inline __global__`:
+// each translation unit emits exactly the kernels it launches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bs_kernels.hpp"
+
+namespace bs {
+
+// what the wrappers of the steady-state chain's second launch need from the context
+struct FastLaunch {
+  hipStream_t stream;
+  uint32_t S, M, P, filter_waves, filter_slots_cap, tp_filter;
+  int device;
+};
+void launch_fast_bc(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
+                    const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks, uint32_t filter_blocks);
+void launch_fast_b(const FastLaunch& c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg,
+                   uint32_t scan_blocks);
+void launch_fast_scan(const FastLaunch& c, dim3 grid, const BatchDev& bt, const BatchParams& prm, uint32_t nseg);
+void launch_fast_bt(const FastLaunch& c, dim3 grid, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks);
+void launch_fast_filter(const FastLaunch& c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm);
+int fused_residency_query(const FastLaunch& c);      // blocks of k_fast_scan_filter_final<S> the chip holds at once (0 = unknown)
+
+struct SeqDev;
+struct SeqParams;
+void launch_seq(hipStream_t stream, uint32_t S, size_t lds, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const SeqDev& sq, const SeqParams& prm);
+
+}  // namespace bs

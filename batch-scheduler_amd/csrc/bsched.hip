@@ -15,6 +15,9 @@
 #include <string>
 #include <vector>
 
+#ifndef BS_UNITY
+#define BS_TU_MAIN
+#endif
 #include "bs_kernels.hpp"
 #include "bs_fast.hpp"
 #include "bs_epoch.hpp"
@@ -23,6 +26,11 @@
 #include "bs_queue.hpp"
 #include "bs_fdeny.hpp"
 #include "bs_seq.hpp"
+#include "bs_launch.hpp"
+#ifdef BS_UNITY   // one translation unit (the probe builds: g_probe / g_seq_scan_ph are per translation unit)
+#include "tu_fast.hip"
+#include "tu_seq.hip"
+#endif
 
 using namespace bs;
 
@@ -668,131 +676,13 @@ void launch_tables_nofix(bs_ctx* c, dim3 grid, const NodesDev& nd, const BatchDe
   }
 }
 
-template <int S>
-static void launch_fast_bc_s(bs_ctx* c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
-                             const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks, uint32_t filter_blocks) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter_final<S>), grid, dim3(256), 0, c->stream, pd, gr, nd, b, bt, prm, c->M, nseg, scan_blocks, filter_blocks,
-                     c->filter_waves, c->filter_slots_cap, cdiv(c->P, kTblChunk));
-}
-template <int S>
-static void launch_fast_b_s(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg,
-                            uint32_t scan_blocks) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter<S>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->M, nseg, scan_blocks, c->filter_waves,
-                     c->filter_slots_cap);
-}
-static void launch_fast_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg,
-                          uint32_t scan_blocks) {
-  switch (c->S) {
-    case 0: launch_fast_b_s<0>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 1: launch_fast_b_s<1>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 2: launch_fast_b_s<2>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 3: launch_fast_b_s<3>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 4: launch_fast_b_s<4>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 5: launch_fast_b_s<5>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 6: launch_fast_b_s<6>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 7: launch_fast_b_s<7>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 8: launch_fast_b_s<8>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 9: launch_fast_b_s<9>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 10: launch_fast_b_s<10>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    case 11: launch_fast_b_s<11>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-    default: launch_fast_b_s<12>(c, grid, pd, nd, bt, prm, nseg, scan_blocks); break;
-  }
-}
-template <int S>
-static void launch_fast_scan_s(bs_ctx* c, dim3 grid, const BatchDev& bt, const BatchParams& prm, uint32_t nseg) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan<S>), grid, dim3(256), 0, c->stream, bt, prm, c->M, nseg);
-}
-static void launch_fast_scan(bs_ctx* c, dim3 grid, const BatchDev& bt, const BatchParams& prm, uint32_t nseg) {
-  switch (c->S) {
-    case 0: launch_fast_scan_s<0>(c, grid, bt, prm, nseg); break;
-    case 1: launch_fast_scan_s<1>(c, grid, bt, prm, nseg); break;
-    case 2: launch_fast_scan_s<2>(c, grid, bt, prm, nseg); break;
-    case 3: launch_fast_scan_s<3>(c, grid, bt, prm, nseg); break;
-    case 4: launch_fast_scan_s<4>(c, grid, bt, prm, nseg); break;
-    case 5: launch_fast_scan_s<5>(c, grid, bt, prm, nseg); break;
-    case 6: launch_fast_scan_s<6>(c, grid, bt, prm, nseg); break;
-    case 7: launch_fast_scan_s<7>(c, grid, bt, prm, nseg); break;
-    case 8: launch_fast_scan_s<8>(c, grid, bt, prm, nseg); break;
-    case 9: launch_fast_scan_s<9>(c, grid, bt, prm, nseg); break;
-    case 10: launch_fast_scan_s<10>(c, grid, bt, prm, nseg); break;
-    case 11: launch_fast_scan_s<11>(c, grid, bt, prm, nseg); break;
-    default: launch_fast_scan_s<12>(c, grid, bt, prm, nseg); break;
-  }
-}
-template <int S>
-static void launch_fast_bt_s(bs_ctx* c, dim3 grid, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter_t<S>), grid, dim3(256), 0, c->stream, nd, bt, prm, c->M, nseg, scan_blocks, c->filter_waves,
-                     c->filter_slots_cap, c->tp_filter == 7u ? 1u : 0u);
-}
-static void launch_fast_bt(bs_ctx* c, dim3 grid, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks) {
-  switch (c->S) {
-    case 0: launch_fast_bt_s<0>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 1: launch_fast_bt_s<1>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 2: launch_fast_bt_s<2>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 3: launch_fast_bt_s<3>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 4: launch_fast_bt_s<4>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 5: launch_fast_bt_s<5>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 6: launch_fast_bt_s<6>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 7: launch_fast_bt_s<7>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 8: launch_fast_bt_s<8>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 9: launch_fast_bt_s<9>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 10: launch_fast_bt_s<10>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 11: launch_fast_bt_s<11>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    default: launch_fast_bt_s<12>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-  }
-}
-static void launch_fast_filter(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm) {
-  switch (c->tp_filter) {
-    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_filter<4, true>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_filter<2, true>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
-    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_filter<2, false>), grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
-    case 4: hipLaunchKernelGGL(k_fast_filter_w7, grid, dim3(256), 0, c->stream, pd, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
-    default: hipLaunchKernelGGL(k_fast_filter_t, grid, dim3(256), 0, c->stream, nd, bt, prm, c->filter_waves, c->filter_slots_cap); break;
-  }
-}
-// How many blocks of the fused launch the chip holds at once (occupancy API, minus one block per CU: the API can be one high,
-// MI355X_MICROARCH.md "Residency").  The fused launch is only taken when its whole grid fits: then no producer block can be
-// waiting for a slot that a spinning final block occupies, whatever order the dispatcher hands blocks out in.
-template <int S>
-static int fused_residency_s(bs_ctx* c) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fast_scan_filter_final<S>, 256, 0) != hipSuccess || per_cu <= 0) return 0;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, c->cfg.device) != hipSuccess) return 0;
-  return std::max(0, per_cu - 1) * prop.multiProcessorCount;
+static FastLaunch fast_launch(const bs_ctx* c) {
+  return FastLaunch{c->stream, c->S, c->M, c->P, c->filter_waves, c->filter_slots_cap, c->tp_filter, c->cfg.device};
 }
 static int fused_residency(bs_ctx* c) {
-  if (c->fused_blocks_resident >= 0) return c->fused_blocks_resident;
-  int r = 0;
-  switch (c->S) {
-    case 0: r = fused_residency_s<0>(c); break;   case 1: r = fused_residency_s<1>(c); break;   case 2: r = fused_residency_s<2>(c); break;
-    case 3: r = fused_residency_s<3>(c); break;   case 4: r = fused_residency_s<4>(c); break;   case 5: r = fused_residency_s<5>(c); break;
-    case 6: r = fused_residency_s<6>(c); break;   case 7: r = fused_residency_s<7>(c); break;   case 8: r = fused_residency_s<8>(c); break;
-    case 9: r = fused_residency_s<9>(c); break;   case 10: r = fused_residency_s<10>(c); break; case 11: r = fused_residency_s<11>(c); break;
-    default: r = fused_residency_s<12>(c); break;
-  }
-  c->fused_blocks_resident = r;
-  return r;
+  if (c->fused_blocks_resident < 0) c->fused_blocks_resident = fused_residency_query(fast_launch(c));
+  return c->fused_blocks_resident;
 }
-static void launch_fast_bc(bs_ctx* c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
-                           const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks, uint32_t filter_blocks) {
-  switch (c->S) {
-    case 0: launch_fast_bc_s<0>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 1: launch_fast_bc_s<1>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 2: launch_fast_bc_s<2>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 3: launch_fast_bc_s<3>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 4: launch_fast_bc_s<4>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 5: launch_fast_bc_s<5>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 6: launch_fast_bc_s<6>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 7: launch_fast_bc_s<7>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 8: launch_fast_bc_s<8>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 9: launch_fast_bc_s<9>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 10: launch_fast_bc_s<10>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    case 11: launch_fast_bc_s<11>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-    default: launch_fast_bc_s<12>(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, filter_blocks); break;
-  }
-}
-
 // Filter: the distinct requests (slots) against every node; fixed grid, the kernel splits the work itself.
 void launch_filter(bs_ctx* c, hipStream_t st, const PodsDev& pd, const NodesDev& nd, const BatchDev& b, bool use_classes) {
   const uint32_t W = cdiv(c->N, 64), ptiles = cdiv(c->P, 64);
@@ -1083,13 +973,6 @@ void launch_epoch_b(bs_ctx* c, dim3 grid, const PodsDev& pd, const NodesDev& nd,
                            uint32_t nseg, uint32_t scan_blocks, uint32_t filter_slots) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epoch_scan_filter<S>), grid, dim3(256), 0, c->stream, pd, nd, b, prm, ep, c->M, nseg, c->G, scan_blocks,
                      c->filter_waves, c->filter_slots_cap, filter_slots);
-}
-
-template <int TS>
-void launch_seq_s(bs_ctx* c, size_t lds, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const SeqDev& sq, const SeqParams& prm) {
-  // static LDS (first-fit bounds, reduction slots) + the key window can exceed the default 64 KB of dynamic LDS
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_pass<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seq_pass<TS>), dim3(1), dim3(kSeqBlock), lds, c->stream, pd, gr, nd, sq, prm);
 }
 
 int resolve_epochs(bs_ctx* c) {
@@ -2165,19 +2048,19 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     if (fused) {
       // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
       const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
-      launch_fast_bc(c, grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
+      launch_fast_bc(fast_launch(c), grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
     } else if (c->tp_filter >= 6u && fblocks && throughput) {
       // both roles in one launch, the Filter role by the transposed item (the default of the throughput regime)
-      launch_fast_bt(c, dim3(scan_blocks + fblocks), nd, bt, prm, share_b, scan_blocks);
+      launch_fast_bt(fast_launch(c), dim3(scan_blocks + fblocks), nd, bt, prm, share_b, scan_blocks);
     } else if (c->tp_filter && fblocks && throughput) {
       // the throughput regime with the two roles as launches of their own: the scan at its register footprint, the Filter loop at a
       // leaner one (more resident waves); same stream, the scan first — its items are dependent-load chains that would otherwise sit
       // in the wave slots the Filter loop can fill
-      launch_fast_scan(c, dim3(scan_blocks), bt, prm, share_b);
-      launch_fast_filter(c, dim3(fblocks), pd, nd, bt, prm);
+      launch_fast_scan(fast_launch(c), dim3(scan_blocks), bt, prm, share_b);
+      launch_fast_filter(fast_launch(c), dim3(fblocks), pd, nd, bt, prm);
       tp_split = true;
     } else {
-      launch_fast_b(c, dim3(scan_blocks + fblocks), pd, nd, bt, prm, share_b, scan_blocks);
+      launch_fast_b(fast_launch(c), dim3(scan_blocks + fblocks), pd, nd, bt, prm, share_b, scan_blocks);
     }
   });
   if (c->host_probe) {
@@ -3437,14 +3320,7 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   HIPCHK(c, hipMemsetAsync(base + o_info, 0, 512, c->stream));
   const PodsDev pd = pods_dev(c);
   const NodesDev nd = nodes_dev(c);
-  switch (c->S <= 4 ? (int)c->S : -1) {
-    case 0: launch_seq_s<0>(c, lds, pd, gr, nd, sq, prm); break;
-    case 1: launch_seq_s<1>(c, lds, pd, gr, nd, sq, prm); break;
-    case 2: launch_seq_s<2>(c, lds, pd, gr, nd, sq, prm); break;
-    case 3: launch_seq_s<3>(c, lds, pd, gr, nd, sq, prm); break;
-    case 4: launch_seq_s<4>(c, lds, pd, gr, nd, sq, prm); break;
-    default: launch_seq_s<-1>(c, lds, pd, gr, nd, sq, prm); break;
-  }
+  launch_seq(c->stream, c->S, lds, pd, gr, nd, sq, prm);
   LAUNCHCHK(c, BS_KERNEL_QUERY);
   // ---- results: one copy of the whole result block, then the caller's arrays
   std::vector<uint8_t> res(o - o_res);

@@ -11,7 +11,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$ROOT/tools/ubench/san}
 mkdir -p "$OUT"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -DBS_UNITY \
   -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize=vptr,function -D_GLIBCXX_ASSERTIONS \
   -o "$OUT/libbsched.so" "$ROOT/batch-scheduler_amd/csrc/bsched.hip" -ldl -L"$(dirname "$(gcc -print-file-name=libubsan.so)")" -lubsan
 g++ -O1 -g -std=c++17 -fPIC -shared -Wall -fsanitize=undefined -D_GLIBCXX_ASSERTIONS \

@@ -2,7 +2,7 @@
 """Where the microseconds of the latency-bound launches go: in-kernel clock stamps of the resident cycle / the resident step.
 
 Needs the PROBE build of the library (never the shipped one):
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -DBS_PROBE=1 \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -DBS_PROBE=1 -DBS_UNITY \
         -o tools/ubench/libbsched_probe.so batch-scheduler_amd/csrc/bsched.hip -ldl
   python tools/stamp_probe.py [cycle|step] [config=cfg3] [scenario=tail] [reps=40]
 
