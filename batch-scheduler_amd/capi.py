@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "bs_batch_run", "bs_batch_sync", "bs_batch_read", "bs_batch_map", "bs_filter_rows_count", "bs_queue_order_load", "bs_queue_sort",
     "bs_shard_set", "bs_reduce_external", "bs_group_admit_devptr", "bs_group_admit_bind", "bs_stream", "bs_comm_unique_id", "bs_comm_init", "bs_batch_finish",
     "bs_timing_reset", "bs_timing_get", "bs_kernel_name", "bs_batch_stats_get",
-    "bs_seq_run", "bs_nodes_read",
+    "bs_seq_run", "bs_nodes_read", "bs_first_reach_hint",
     "bs_nodes_load_flat", "bs_groups_load_flat", "bs_groups_read_flat", "bs_pods_load_flat", "bs_pods_apply_flat", "bs_pods_read_flat",
     "bs_batch_read_flat", "bs_seq_run_flat", "bs_fit_build_flat",
 ]
@@ -139,6 +139,7 @@ def load_library(path: str | None = None):
     L.bs_shard_set.argtypes = [vp, u32, u32]
     L.bs_group_admit_devptr.argtypes = [vp, P(vp), P(u32)]
     L.bs_reduce_external.argtypes = [vp, u32]
+    L.bs_first_reach_hint.argtypes = [vp, u32]
     L.bs_group_admit_bind.argtypes = [vp, vp]
     L.bs_stream.argtypes = [vp, P(vp)]
     L.bs_comm_unique_id.argtypes = [P(u8)]
@@ -498,6 +499,10 @@ class Context:
 
     def reduce_external(self, on: bool = True):
         self._chk(self._lib.bs_reduce_external(self._h, 1 if on else 0), "bs_reduce_external")
+
+    def first_reach_hint(self, local_index: int):
+        """bs_first_reach_hint: partitioned mode, this rank's pods in front of the job's first pod that reaches findMaxPG"""
+        self._chk(self._lib.bs_first_reach_hint(self._h, int(local_index) & 0xFFFFFFFF), "bs_first_reach_hint")
 
     def admit_devptr(self):
         p, n = C.c_void_p(), C.c_uint32(0)

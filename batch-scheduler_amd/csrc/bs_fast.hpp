@@ -695,7 +695,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
     uint8_t code = code0;
     const uint8_t st = st0;
     const int32_t gi = gi0;
-    const uint32_t first_reach = s_first_reach;
+    const uint32_t first_reach = min(s_first_reach, prm.first_reach_hint);     // (the hint never lies behind the local first reaching pod)
     uint32_t fk = BS_K_NOT_SCANNED;
     if (st & ST_OWNED) {
       bool denied = false;
@@ -808,10 +808,11 @@ __global__ __launch_bounds__(256) void k_fast_filter_t(NodesDev nd, BatchDev bt,
 template <int S>
 __global__ __launch_bounds__(256) void k_fast_scan_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t scan_blocks,
                                                             uint32_t filter_waves, uint32_t ustride, uint32_t filter_first) {
+  __shared__ int64_t s_rows[4][64][4 + S];
   const uint32_t filter_blocks = gridDim.x - scan_blocks;
   const bool is_scan = filter_first ? blockIdx.x >= filter_blocks : blockIdx.x < scan_blocks;
   if (is_scan)
-    scan_loop<S, true, 3>(bt, prm, m, jcap, 0u, 0u, 1u, filter_first ? blockIdx.x - filter_blocks : blockIdx.x, scan_blocks, nullptr);   // (rows from the scalar cache: no LDS)
+    scan_loop<S, true, 1>(bt, prm, m, jcap, 0u, 0u, 1u, filter_first ? blockIdx.x - filter_blocks : blockIdx.x, scan_blocks, s_rows[wave_id()]);
   else
     filter_loop_t(nd, bt, filter_waves, ustride, prm.collect_stats, filter_first ? blockIdx.x : blockIdx.x - scan_blocks, filter_blocks, prm.stamp, 2u * prm.k_host);
 }

@@ -192,6 +192,8 @@ struct BatchParams {
   uint32_t k_host;             // request classes, when the host already knows the count (0: read *kclass — a dependent load in front of the first round trip)
   uint32_t filter_deny;        // BS_BATCH_FILTER_DENY: the chain's last launch leaves tally and completion word to k_fd_apply
   uint32_t fd_iter;            // > 0: a fixed-point re-run (fd_in holds the events of the run before)
+  uint32_t first_reach_hint;   // partitioned mode (bs_first_reach_hint): first LOCAL queue index at or behind the whole job's first pod that reaches
+                               // findMaxPG (core.go:118); BS_INF = none (the local queue is the whole queue)
 };
 
 // BS_BATCH_FILTER_DENY re-runs: the pod stands behind the position at which its group was deny-listed by a failing Filter
@@ -1152,63 +1154,6 @@ __device__ __forceinline__ void row_all(const unsigned long long (&nf)[Q], uint3
   else row_step<L>(nf[0], myk[0], k, a, r[0]);
 }
 
-// ---- candidate rows (the throughput regime's scan role: thousands of tiles, every wave has groups to walk) ----
-// The LDS form below parks a live 64-row group and reads it back row by row with broadcast ds_reads: 64 lanes x 8 bytes move for every
-// value, so the CU's LDS pipe is what eight scan waves per CU queue up on (~165 cycles per row; profiles/r04c_trace_cfg4_rank0of8.txt).
-// Round 5 first tried the rows through the scalar cache (s_load per row, compared from SGPRs): slower — every row is a cache line of
-// its own and two rows in flight do not cover an L2 round trip (profiles/r05_tp_srow_v1.jsonl: cfg3 51.9 vs 41.1 us per step).
-// What is here instead: the group stays in the VGPRs it was loaded into (lane = row), the rows that can serve ANY slot of the tile are
-// found at once — row[j] >= the tile's smallest request on every lane, five compares for 64 rows; a necessary condition, since a
-// passing (slot, row) pair has row[j] >= r[j] >= rmin[j] on every lane the chain compares — and only those rows are broadcast
-// (v_readlane -> SGPR pair) and compared against the 64 slots (`v_cmpx_ge_i64 vcc, s[row_j], v[r_j]`).  No LDS; the next live
-// group's rows are in flight while the current one is looked at.
-#define BS_SOPS4 [a0] "s"(a[0]), [r0] "v"(r[0]), [a1] "s"(a[1]), [r1] "v"(r[1]), [a2] "s"(a[2]), [r2] "v"(r[2]), [a3] "s"(a[3]), [r3] "v"(r[3])
-template <int L>
-__device__ __forceinline__ void row_step_s(unsigned long long nf, uint32_t& myk, uint32_t k, const int64_t (&a)[L], const int64_t (&r)[L]) {
-  if constexpr (L == 4) {
-    asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_ROW_TAIL
-                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_SOPS4 : "vcc");
-  } else if constexpr (L == 5) {
-    asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_ROW_TAIL
-                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_SOPS4, [a4] "s"(a[4]), [r4] "v"(r[4]) : "vcc");
-  } else if constexpr (L == 6) {
-    asm volatile(BS_ROW_HEAD BS_CX(0) BS_CX(1) BS_CX(2) BS_CX(3) BS_CX(4) BS_CX(5) BS_ROW_TAIL
-                 : [myk] "+v"(myk) : [nf] "s"(nf), [k] "s"(k), BS_SOPS4, [a4] "s"(a[4]), [r4] "v"(r[4]), [a5] "s"(a[5]), [r5] "v"(r[5]) : "vcc");
-  } else {
-    // wider rows: one statement per resource lane, the surviving-lane mask travels in an SGPR pair
-    unsigned long long m = nf;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      asm volatile("s_mov_b64 exec, %[m]\n\tv_cmpx_ge_i64 vcc, %[a], %[r]\n\ts_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
-                   : [m] "+s"(m) : [a] "s"(a[j]), [r] "v"(r[j]) : "vcc");
-    }
-    asm volatile("s_mov_b64 exec, %[m]\n\tv_min_u32 %[myk], %[k], %[myk]\n\ts_mov_b64 exec, -1"
-                 : [myk] "+v"(myk) : [k] "s"(k), [m] "s"(m));
-  }
-}
-// the same chain, answering WHICH lanes pass (no row recorded): the joint test of a group's per-lane maxima against every slot
-template <int L>
-__device__ __forceinline__ unsigned long long row_mask_s(unsigned long long nf, const int64_t (&a)[L], const int64_t (&r)[L]) {
-  unsigned long long m = nf;
-#pragma unroll
-  for (int j0 = 0; j0 < L; j0 += 4) {
-    if (j0 + 4 <= L) {
-      asm volatile("s_mov_b64 exec, %[m]\n\tv_cmpx_ge_i64 vcc, %[a0], %[r0]\n\tv_cmpx_ge_i64 vcc, %[a1], %[r1]\n\tv_cmpx_ge_i64 vcc, %[a2], %[r2]\n\t"
-                   "v_cmpx_ge_i64 vcc, %[a3], %[r3]\n\ts_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
-                   : [m] "+s"(m)
-                   : [a0] "s"(a[j0]), [r0] "v"(r[j0]), [a1] "s"(a[j0 + 1]), [r1] "v"(r[j0 + 1]), [a2] "s"(a[j0 + 2]), [r2] "v"(r[j0 + 2]), [a3] "s"(a[j0 + 3]),
-                     [r3] "v"(r[j0 + 3])
-                   : "vcc");
-    } else {
-#pragma unroll
-      for (int j = j0; j < L; ++j)
-        asm volatile("s_mov_b64 exec, %[m]\n\tv_cmpx_ge_i64 vcc, %[a], %[r]\n\ts_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
-                     : [m] "+s"(m) : [a] "s"(a[j]), [r] "v"(r[j]) : "vcc");
-    }
-  }
-  return m;
-}
-
 // One wave's share of one tile of 64 request slots, for the slots of the tile that use table `slot`
 // (`valid` lanes).  The 64-row groups of the table that are LIVE for them (on every fixed lane the group's
 // largest running sum reaches the smallest request) are dealt round-robin over the J waves of the tile:
@@ -1296,7 +1241,7 @@ __device__ __forceinline__ void local_pre_load(const BatchDev& b, const BatchPar
   local_pre_finish<S>(b, prm, m, slot, raw, pre);
 }
 
-template <int S, bool LOCAL = false, bool HAVE_PRE = false, bool SROW = false>
+template <int S, bool LOCAL = false, bool HAVE_PRE = false>
 __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t slot, uint32_t pos, bool valid,
                                           const int64_t (&r)[1][4 + S], uint32_t qf, uint32_t share, uint32_t J, int64_t (*rows)[4 + S],
                                           const LocalPre<S>& given, uint32_t sub = 0, uint32_t nsub = 1) {
@@ -1362,14 +1307,6 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   };
 
   BS_STAMP(2, 2);
-  uint32_t groups_skipped = 0;
-  auto kp_or_inf = [&](int s2) -> uint32_t {     // first row of scalar key s2 in the running sum (not known before the first group: no bound)
-    uint32_t v = BS_INF;
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-      if (s == s2) v = (LOCAL || loaded) ? kp[s] : BS_INF;
-    return v;
-  };
   int64_t gm[L];
 #pragma unroll
   for (int j = 0; j < L; ++j) gm[j] = gmw[0][j];
@@ -1377,9 +1314,6 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
     // live mask of groups c0 .. c0+63 (lane l <-> group c0+l)
     bool dead = true;
     const uint32_t g = c0 + (uint32_t)lane;
-    int64_t jb[L];                                 // SROW: upper bound of every row of group g on lane j (INT64_MAX = no bound), for the joint test
-#pragma unroll
-    for (int j = 0; j < L; ++j) jb[j] = INT64_MAX;
     if constexpr (LOCAL) {
       ensure_window(c0 >> 8);                      // groups c0 .. c0+63 = chunks (c0 >> 2) .. +15: inside one window
       unsigned long long og[L];
@@ -1401,10 +1335,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 #pragma unroll
         for (int j = 0; j < L; ++j) {
           const long long o = (long long)og[j];
-          if (gm[j] != INT64_MAX && o > -kSafe && o < kSafe) {                                    // |max|, |off| < 2^62: no wrap, exact bound
-            if (gm[j] + o < rmin[j]) dead = true;
-            if constexpr (SROW) jb[j] = gm[j] + o;
-          }
+          if (gm[j] != INT64_MAX && o > -kSafe && o < kSafe && gm[j] + o < rmin[j]) dead = true;   // |max|, |off| < 2^62: no wrap, exact bound
         }
       }
     } else if (g < ngroups) {
@@ -1414,104 +1345,6 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
       for (int j = 0; j < L; ++j) dead = dead || gm[j] < rmin[j];
     }
     unsigned long long live = __ballot(!dead);
-    if constexpr (SROW) {
-      // this wave's live groups of the window, in row order; the NEXT one's rows are asked for before the current one is looked at
-      auto pop_mine = [&]() -> uint32_t {
-        while (live) {
-          const uint32_t bit = (uint32_t)__ffsll((long long)live) - 1u;
-          live &= live - 1ull;
-          const bool mine = turn == share;
-          turn = turn + 1u == J ? 0u : turn + 1u;
-          if (!mine) continue;
-          // Joint test: the group's per-lane maxima as ONE row against every slot.  No slot passes it -> no row of the group can
-          // serve anybody (a passing (slot, row) pair has r[j] <= row[j] <= max[j] on every lane): the group is not even fetched.
-          // rmin only says "on every lane SOME slot asks for less than the maximum" — with thousands of distinct requests that is
-          // true of nearly every group behind the point where the sums first get large enough (18 live groups per tile at cfg4 for a
-          // first row that is the same for all of them), while no single slot is satisfied on all its lanes at once.
-          // A scalar lane only counts when its key is in the running sum for the whole group (core.go:686-697: before that row the
-          // compare means something else).
-          int64_t top[L];
-#pragma unroll
-          for (int j = 0; j < L; ++j) {
-            top[j] = (int64_t)bcast64((uint64_t)jb[j], (int)bit);
-            if (j >= 4) { if (kp_or_inf(j - 4) > ((c0 + bit) << 6)) top[j] = INT64_MAX; }
-          }
-          if ((row_mask_s<L>(nf, top, r[0]) & nf) == 0ull) { groups_skipped++; continue; }
-          return bit;
-        }
-        return 64u;
-      };
-      auto fetch = [&](uint32_t bit, int64_t (&dst)[L]) {
-        const uint32_t g0 = (c0 + bit) << 6;
-        const uint32_t row = min(g0 + (uint32_t)lane, m - 1u);
-        const int64_t* src = T + (size_t)row * LP;
-#pragma unroll
-        for (int j = 0; j < L; ++j) dst[j] = src[j];
-      };
-      int64_t rowA[L], rowB[L];
-#pragma unroll
-      for (int j = 0; j < L; ++j) { rowA[j] = 0; rowB[j] = 0; }
-      uint32_t cur = pop_mine();
-      if (cur < 64u) fetch(cur, rowA);
-      bool stop = false;
-      while (cur < 64u) {
-        const uint32_t nxt = pop_mine();
-        if (nxt < 64u) fetch(nxt, rowB);
-        const uint32_t g0 = (c0 + cur) << 6;
-        const uint32_t gend = min(m, g0 + 64u);
-        if (!loaded || (LOCAL && J > 2u)) {      // first live group of this wave; with many shares per tile, every group: what another wave found since
-          seen = valid ? __hip_atomic_load(&b.first_row[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        }
-        if (!loaded) {
-          loaded = true;
-#pragma unroll
-          for (int s = 0; s < S; ++s) {
-            if constexpr (!LOCAL) kp[s] = __builtin_amdgcn_readfirstlane(b.kp[slot * 16 + s]);
-            absok[s] = __ballot((qf >> (16 + s)) & 1u);
-          }
-        }
-        // rows that can serve some slot of the tile: on every lane the (final) running sum reaches the tile's smallest request
-        bool can = g0 + (uint32_t)lane < gend;
-        int64_t fin[L];
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-          fin[j] = rowA[j];
-          if constexpr (LOCAL) fin[j] = (int64_t)((unsigned long long)fin[j] + bcast64(offl[j], (int)((g0 / kTblChunk) & 63u)));   // (the window of this group's chunk is the current one)
-          can = can && fin[j] >= rmin[j];
-        }
-        unsigned long long cm = __ballot(can);
-        // lanes another wave already served with an earlier row need nothing from this group — nor from any later one
-        nf &= __ballot(seen >= g0);
-        if (nf == 0) { stop = true; break; }
-        unsigned long long want = nf;
-        rows_done += (uint32_t)__popcll(cm);
-        while (cm) {
-          const uint32_t rb = (uint32_t)__ffsll((long long)cm) - 1u;
-          cm &= cm - 1ull;
-          const uint32_t k = g0 + rb;
-          unsigned long long el = ~0ull;           // lanes that can pass while key s is absent from the running sum (core.go:688-692)
-#pragma unroll
-          for (int s = 0; s < S; ++s)
-            if (kp[s] > k) el &= absok[s];
-          const unsigned long long act = want & el;
-          if (!act) continue;
-          int64_t one[L];
-#pragma unroll
-          for (int j = 0; j < L; ++j) one[j] = (int64_t)bcast64((uint64_t)fin[j], (int)rb);
-          row_step_s<L>(act, myk[0], k, one, r[0]);
-          want &= __ballot(myk[0] == BS_INF);
-          if (want == 0) break;
-        }
-        // found lanes are done for good (this wave walks its groups in increasing row order)
-        nf &= __ballot(myk[0] == BS_INF);
-        if (nf == 0) { stop = true; break; }
-#pragma unroll
-        for (int j = 0; j < L; ++j) rowA[j] = rowB[j];
-        cur = nxt;
-      }
-      if (stop) { c0 = ngroups; break; }
-      continue;
-    }
     while (live) {
       const uint32_t bit = (uint32_t)__ffsll((long long)live) - 1u;
       live &= live - 1ull;
@@ -1596,14 +1429,12 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
         if (want == 0) break;
         a = e;
       }
-      
       // found lanes are done for good (this wave walks its groups in increasing row order)
       nf &= __ballot(myk[0] == BS_INF);
       if (nf == 0) { c0 = ngroups; break; }
     }
   }
   BS_STAMP(2, 4);
-  (void)groups_skipped;
   if (!loaded) return;
   if (myk[0] != BS_INF) atomicMin(&b.first_row[pos], myk[0]);
   if (prm.collect_stats && lane == 0) {
@@ -1617,8 +1448,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
 // table are scanned together (steady state: one table for everything); consecutive waves take different
 // tiles with the same share.  The grid is fixed; the slot count is read on the device.
 // MODE 0: an item's table is whatever its slots ask for (general chain); 1: steady state, one table for every item, an item per wave;
-// 2: steady state, an item per BLOCK (its four waves share the first fetch and take a quarter of every group's rows each);
-// 3: as 1, rows through the scalar cache (scan_rows_s; `rows` is not used)
+// 2: steady state, an item per BLOCK (its four waves share the first fetch and take a quarter of every group's rows each)
 template <int S, bool LOCAL = false, int MODE = 0>
 __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& prm, uint32_t m, uint32_t jcap, uint32_t nslots_fixed,
                                           uint32_t ngroups_g, uint32_t tsplit, uint32_t bx, uint32_t nblocks, int64_t (*rows)[4 + S]) {
@@ -1741,7 +1571,7 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
     while (todo) {
       const int32_t t0 = __builtin_amdgcn_readlane(tab, __ffsll((long long)todo) - 1);
       const bool member = tab == t0;
-      if (turn == ts) scan_core<S, LOCAL, uni, MODE == 3>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows, pre, sub, nsub);
+      if (turn == ts) scan_core<S, LOCAL, uni>(b, prm, m, (uint32_t)t0, pos, member, r, qf, share, J, rows, pre, sub, nsub);
       turn = turn + 1u == tsplit ? 0u : turn + 1u;
       todo &= ~__ballot(member);
     }

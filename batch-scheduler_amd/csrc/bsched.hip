@@ -272,6 +272,7 @@ struct bs_ctx {
   DevBuf d_fd_event, d_fd_in, d_fd_flag;
   bool fd_on = false;                // the run being launched replays Filter's deny entry
   bool fd_active = false;            // the last batch did, and nobody has looked at its flag words yet (fd_settle)
+  uint32_t first_reach_hint = 0xFFFFFFFFu;   // bs_first_reach_hint (partitioned mode), reset by every queue load / patch
   bool fd_unsynced = false;          // a BS_BATCH_FILTER_DENY batch was launched and the stream has not been waited for since
   bool fd_in_live = false;           // a fixed-point re-run: the chains honour d_fd_in
   uint32_t fd_iter = 0, fd_stages = 0, fd_seq_inv = 0;
@@ -505,6 +506,7 @@ BatchParams batch_params(const bs_ctx* c) {
   p.mcap = c->table_mcap;
   p.filter_deny = c->fd_on ? 1u : 0u;
   p.fd_iter = c->fd_iter;
+  p.first_reach_hint = c->reduce_external ? c->first_reach_hint : BS_INF;
   return p;
 }
 
@@ -1475,6 +1477,7 @@ int bs_pods_load(bs_ctx* c, const bs_pods_soa* pods) {
   c->pairs_ready = false;
   c->epochs_ready = false;
   c->batch_since_pods = false;
+  c->first_reach_hint = 0xFFFFFFFFu;
   c->max_pod_cls = 0;
   for (uint32_t i = 0; i < P; ++i)
     if (pods->group[i] >= 0) c->max_pod_cls = std::max(c->max_pod_cls, pods->cls[i]);
@@ -1733,6 +1736,7 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
   c->rep_valid = false;                                              // the queue was compacted: pod indices of the derivation are history
   c->epochs_ready = false;
   c->batch_since_pods = false;
+  c->first_reach_hint = 0xFFFFFFFFu;
   c->bitmap_valid = false;
   if (derive) {
     c->gstat_cur ^= 1u;
@@ -1803,6 +1807,13 @@ int bs_stream(bs_ctx* c, void** stream) {
 int bs_reduce_external(bs_ctx* c, uint32_t on) {
   if (!c) return BS_ERR_INVALID;
   c->reduce_external = on != 0;
+  return BS_OK;
+}
+
+int bs_first_reach_hint(bs_ctx* c, uint32_t local_index) {
+  if (!c) return BS_ERR_INVALID;
+  if (!c->have_pods) { c->last_error = "bs_first_reach_hint before bs_pods_load"; return BS_ERR_STATE; }
+  c->first_reach_hint = local_index;
   return BS_OK;
 }
 
@@ -2049,7 +2060,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
       const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
       launch_fast_bc(fast_launch(c), grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
-    } else if (c->tp_filter >= 6u && fblocks && throughput) {
+    } else if (c->tp_filter >= 6u && fblocks && throughput && c->S <= 4u) {
       // both roles in one launch, the Filter role by the transposed item (the default of the throughput regime)
       launch_fast_bt(fast_launch(c), dim3(scan_blocks + fblocks), nd, bt, prm, share_b, scan_blocks);
     } else if (c->tp_filter && fblocks && throughput) {

@@ -71,20 +71,14 @@ void launch_fast_bt_s(const FastLaunch& c, dim3 grid, const NodesDev& nd, const 
                      c.filter_slots_cap, c.tp_filter == 7u ? 1u : 0u);
 }
 void launch_fast_bt(const FastLaunch& c, dim3 grid, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks) {
+  // S <= 4 only (run_fast sends wider contexts through k_fast_scan + k_fast_filter_t): beyond that the two roles in one kernel run out
+  // of SGPRs and the instantiation reserves scratch memory (36 bytes at S = 5, tools/kernel_resources.py), which every launch pays for
   switch (c.S) {
     case 0: launch_fast_bt_s<0>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
     case 1: launch_fast_bt_s<1>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
     case 2: launch_fast_bt_s<2>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
     case 3: launch_fast_bt_s<3>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 4: launch_fast_bt_s<4>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 5: launch_fast_bt_s<5>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 6: launch_fast_bt_s<6>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 7: launch_fast_bt_s<7>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 8: launch_fast_bt_s<8>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 9: launch_fast_bt_s<9>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 10: launch_fast_bt_s<10>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    case 11: launch_fast_bt_s<11>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
-    default: launch_fast_bt_s<12>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
+    default: launch_fast_bt_s<4>(c, grid, nd, bt, prm, nseg, scan_blocks); break;
   }
 }
 void launch_fast_filter(const FastLaunch& c, dim3 grid, const PodsDev& pd, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm) {

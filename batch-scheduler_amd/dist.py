@@ -41,3 +41,39 @@ def all_reduce_admit(counts, dist_module=None):
         import torch.distributed as dist_module
     dist_module.all_reduce(counts)
     return counts
+
+
+def first_reach_thresholds(pods, groups, ranks: np.ndarray, nranks: int) -> list:
+    """Partitioned mode: for every rank the argument of bs_first_reach_hint — how many of ITS pods stand in front of the whole queue's
+    first pod that reaches findMaxPG (core.go:118-123).  The reaching rule of a batch in which no first-pod capture can occur (the
+    steady state; k_fast_query_tables states the same): labelled with a known group (:100-103), no lastPermittedPod entry (:95-98), no deny
+    entry (:105-110), OccupiedBy agrees (:494-511: against the group's entry, or — the group has none yet — against the first pod of the
+    group that brings owner references), and findMaxPG does not hit the uint32 division by zero of :716-717 (then nobody reaches).
+    `ranks` = owner_ranks(...) of the whole queue; returns 0xFFFFFFFF for every rank when no pod reaches."""
+    from . import soa
+    p = pods.p
+    group = np.asarray(pods.group)
+    idx = np.arange(p, dtype=np.int64)
+    G = groups.g
+    grouped = (group >= 0) & (group < G)
+    g = np.where(grouped, group, 0)
+    cand = ((groups.flags & soa.GROUP_SCHEDULED_LATCH) == 0) & ((groups.flags & soa.GROUP_HAS_POD) != 0)
+    panic = bool(np.any(cand & (groups.min_member == 0) & (groups.status_scheduled != 0)))
+    none = [0xFFFFFFFF] * nranks
+    if panic or p == 0 or G == 0:
+        return none
+    notperm = (pods.flags & soa.POD_LAST_PERMITTED) == 0
+    denied = (groups.flags[g] & soa.GROUP_DENIED) != 0
+    occ0 = groups.occupied_by[g]
+    own = np.asarray(pods.owner)
+    fo = np.full(G, p, dtype=np.int64)                     # first pod of the group (without a lastPermittedPod entry) that has owner references
+    brings = grouped & notperm & (own != 0)
+    np.minimum.at(fo, g[brings], idx[brings])
+    fog = fo[g]
+    need_fo = (occ0 == 0) & (fog < p) & (idx > fog)
+    occ_err = np.where(occ0 != 0, (own == 0) | (own != occ0), need_fo & ((own == 0) | (own != own[np.minimum(fog, p - 1)])))
+    reach = grouped & notperm & ~denied & ~occ_err
+    if not reach.any():
+        return none
+    first = int(np.argmax(reach))
+    return [int(np.count_nonzero(np.asarray(ranks)[:first] == r)) for r in range(nranks)]

@@ -570,6 +570,16 @@ int bs_group_admit_devptr(bs_ctx* ctx, void** dptr, uint32_t* count);
  * occur in the batch (every group already has its pod): then no pod's decision depends on a pod of
  * another group.  Otherwise use bs_shard_set (whole batch on every rank). */
 int bs_reduce_external(bs_ctx* ctx, uint32_t on);
+/* Partitioned mode, the one thing a rank cannot know from its own pods: where in ITS queue the whole job's first pod that reaches
+ * findMaxPG (core.go:118-123) stands.  A pod that returns before that line (lastPermittedPod, no label, unknown group, deny entry,
+ * OccupiedBy) leaves sop.maxFinishedPG as the latest reaching pod IN FRONT OF IT left it — on the whole queue, not on the rank's part
+ * of it; pf_leader and the Filter result of a BS_POD_LAST_PERMITTED pod hang on that.  `local_index` = number of this rank's pods
+ * that stand in front of the job's first reaching pod (the caller partitions the queue, so it has the queue:
+ * batch-scheduler_amd/dist.py first_reach_thresholds is the host rule, the Go shim's partitioner does the same); 0xFFFFFFFF = none.
+ * Valid for the loaded queue (every bs_pods_load / bs_pods_apply resets it); honoured by the steady-state chain, which is the chain
+ * partitioned mode is exact on (no first-pod capture possible).  With it every output of a partitioned batch equals the single
+ * context's (tests/test_gpu_multirank.py: plain equality). */
+int bs_first_reach_hint(bs_ctx* ctx, uint32_t local_index);
 /* The three multi-rank modes (one process per GPU; node / group / fit state replicated on every rank):
  *   replicated   bs_shard_set(rank, nranks) [or bs_comm_init]: the whole queue on every rank, ownership decided on the device.
  *   partitioned  bs_reduce_external(1): each rank holds only the pods of the groups it owns; with bs_comm_init the library
@@ -579,9 +589,9 @@ int bs_reduce_external(bs_ctx* ctx, uint32_t on);
  * Exactness under sharding: decisions (pf_code, pf_first_k, Filter results, admit, ready) of owned pods equal the
  * single-context batch.  pf_leader — the stale shared field sop.maxFinishedPG a pod leaves behind when it returns before
  * core.go:120 — and with it the Filter result of BS_POD_LAST_PERMITTED pods is exact in replicated mode whenever no
- * first-pod capture can occur in the batch; in partitioned mode (and in replicated mode with captures) such a pod sees the
- * leader left by the latest reaching pod OF ITS OWN RANK'S view.  Nothing else is affected (tests/test_gpu_multirank.py
- * asserts that set). */
+ * first-pod capture can occur in the batch, and in partitioned mode with bs_first_reach_hint (round 5; without the hint such a pod
+ * sees the leader left by the latest reaching pod OF ITS OWN RANK'S view).  In replicated mode WITH captures the own-rank view
+ * remains (tests/test_gpu_multirank.py). */
 /* Use caller-owned device memory (uint32[g], e.g. a torch tensor's data_ptr) for the admit counters,
  * so that a framework collective can reduce it in place.  NULL restores the internal buffer. */
 int bs_group_admit_bind(bs_ctx* ctx, void* dptr);

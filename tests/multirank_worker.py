@@ -16,6 +16,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def with_early_returners(pods, soa, seed):
+    """pods that return from PreFilter BEFORE findMaxPG (core.go:89-98: no label / a lastPermittedPod entry), sprinkled over the queue —
+    front included: they leave the stale sop.maxFinishedPG of whoever reached :118 in front of them on the WHOLE queue, which is what a
+    rank of a partitioned batch cannot see (bs_first_reach_hint)"""
+    rng = np.random.default_rng(seed + 4711)
+    pods = pods.copy()
+    pods.flags[rng.random(pods.p) < 0.06] |= soa.POD_LAST_PERMITTED
+    pods.group[rng.random(pods.p) < 0.03] = soa.POD_NOT_GROUPED
+    pods.flags[:3] |= soa.POD_LAST_PERMITTED                  # the head of the queue does not reach
+    return pods
+
+
 def main():
     mode, rank, world, work, config, scenario, seed = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6], int(sys.argv[7])
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
@@ -25,9 +37,13 @@ def main():
     bdist = importlib.import_module("batch-scheduler_amd.dist")
     soa = bsa.soa
     nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario, seed=seed)
+    pods = with_early_returners(pods, soa, seed)
     idx = np.arange(pods.p)
+    hint = None
     if mode.endswith("partitioned"):
-        idx = np.nonzero(bdist.owner_ranks(pods.group, groups.g, world) == rank)[0]
+        own = bdist.owner_ranks(pods.group, groups.g, world)
+        idx = np.nonzero(own == rank)[0]
+        hint = bdist.first_reach_thresholds(pods, groups, own, world)[rank]
     mine = pods.take(idx)
     device = 0
     if mode.startswith("native"):
@@ -36,6 +52,8 @@ def main():
     ctx.load_nodes(nodes, fit)
     ctx.load_groups(groups)
     ctx.load_pods(mine)
+    if hint is not None:
+        ctx.first_reach_hint(hint)                          # the one thing a rank cannot know from its own pods (bsched.h)
     status = "ok"
     try:
         if mode.startswith("native"):

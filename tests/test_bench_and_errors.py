@@ -28,7 +28,14 @@ def test_bench_json_contract():
     # the step is two latency-bound launches; HBM stays the nominal roofline the bytes are priced against
     assert r["bound"] == "latency" and r["nominal_bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["frac_per_eval_logical"] - d["value"] * r["bytes_per_eval"] / 8e12) < 1e-9 * r["frac_per_eval_logical"]
-    assert abs(r["frac_per_eval_executed"] - d["value_executed"] * r["bytes_per_eval"] / 8e12) < 1e-9 * max(r["frac_per_eval_executed"], 1e-30)
+    # executed work at SURVEY 8(d)'s bytes — scan evals x (16 L + 2) + Filter evals x 65.125 — over the DOMINANT kernel's time
+    wa, L = d["work_avoided"], 4
+    exp_frac = (wa["prefilter_evals_executed"] * (16 * L + 2) + wa["filter_evals_executed"] * 65.125) / (r["avg_launch_us"] * 1e-6) / 8e12
+    assert abs(r["frac_per_eval_executed"] - exp_frac) < 1e-6 * max(exp_frac, 1e-30) and r["frac_per_eval_executed"] <= 1.0
+    rt = d["roofline_throughput"]                           # the real-work figure: launch B of the all-distinct step against its VALU issue bound
+    assert rt["bound"] == "valu-issue" and rt["k_compared_lanes"] == 1 and rt["kernel_us"] > 0 and 0 < rt["frac"] <= 1.0
+    assert abs(rt["frac"] - rt["evals_executed_per_launch"] / (rt["kernel_us"] * 1e-6) / rt["peak_evals_per_s"]) < 1e-9
+    assert rt["frac_of_whole_step"] <= rt["frac"] * 1.05
     assert 0 < d["value_executed"] <= d["value"]
     assert "traffic" in r and "kernel" in r and r["avg_launch_us"] > 0
     for e in d["roofline_launches"]:                      # compulsory bytes / kernel-only time: nothing can exceed the roofline

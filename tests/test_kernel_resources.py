@@ -17,10 +17,8 @@ HOT = ("k_fast_query_tables", "k_fast_scan_filter_final", "k_fast_scan_filter", 
        "k_fd_apply", "k_fd_events", "k_nodes_derive", "k_filter_expand")
 # kernel (demangled prefix) -> bytes of scratch it is known to use, and why that is tolerated
 KNOWN = {
-    "k_seq_pass": "one persistent launch per pass (20 bytes; the generic-lane instantiation 1488): the set-up is paid once per 45 ms",
+    "k_seq_pass": "one persistent launch per pass (20 bytes; the generic-lane instantiation 1492): the set-up is paid once per pass (tens of ms)",
     "k_commit": "general chain's commit pass only (144 bytes)",
-    "k_fast_scan_filter_t<3>": "36 bytes in the S = 3 instantiation only (9 spilled dwords when the whole library is one translation unit; "
-                               "the same kernel compiled alone has none): noted in DESIGN.md section 9",
 }
 
 
