@@ -326,6 +326,17 @@ __device__ __forceinline__ void tables_local_fast(const NodesDev& nd, const Batc
 // Status.Scheduled, matched.  Wave-uniform addresses; loaded by every thread at the very top, together with the pod's own
 // fields, so that nothing the pod derives later waits for another round trip.
 struct LeaderPre { Res mr; bool have_mr; int64_t min_member, status_scheduled, matched; };
+// stores a consumer block of the SAME launch reads after a ticket (k_fast_step_a): write-through, agent scope (sc1) — a plain store
+// stays in this XCD's L2 and another XCD's reader would see the previous batch's value (MI355X_MICROARCH.md, inter-workgroup visibility)
+template <bool PUB, typename T>
+__device__ __forceinline__ void st_pub(T* p, T v) {
+  if constexpr (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent64(const void* p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int TS>
 __device__ __forceinline__ void leader_pre_load(const GroupsDev& gr, int32_t leader, Shape<TS> sh, LeaderPre& o) {
   const uint32_t l = leader >= 0 ? (uint32_t)leader : 0u;           // (clamped: the values are only used when leader >= 0)
@@ -354,7 +365,7 @@ __device__ __forceinline__ void pre_allocated_from(const LeaderPre& lp, Shape<TS
   if (out.v[BS_LANE_PODS] == 0) out.v[BS_LANE_PODS] = mm + 1;
 }
 // the Filter slot of (class of `cur`, leader `lp`): computeResourceSatisfied's R = pod + maxSingle, M = maxSingle (core.go:526-552)
-template <int TS>
+template <int TS, bool PUB = false>
 __device__ __forceinline__ void filter_slot_from(const BatchDev& b, const BatchParams& prm, const Res& cur_in, const LeaderPre& lp, Shape<TS> sh, uint32_t gate,
                                                  uint32_t slot) {
   if (!lp.have_mr) return;                                           // PASS_NO_MINRES (core.go:542-544): no slot to evaluate
@@ -370,18 +381,18 @@ __device__ __forceinline__ void filter_slot_from(const BatchDev& b, const BatchP
       if ((ms.present & (1u << s)) && ms.v[4 + s] != 0) ff |= 2u;    // node "cannot hold" a leader member
     }
   }
-  b.uflags[slot] = ff | ((uint32_t)BS_FL_EVALUATED << 8) | (prm.stamp << 16);
-  b.fu_feas[slot] = 0;
+  st_pub<PUB>(&b.fu_feas[slot], 0u);
   int64_t* dst2 = b.uparams + (size_t)slot * 8;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { dst2[j] = cur.v[j]; dst2[4 + j] = ms.v[j]; }
+  for (int j = 0; j < 4; ++j) { st_pub<PUB>(&dst2[j], cur.v[j]); st_pub<PUB>(&dst2[4 + j], ms.v[j]); }
+  st_pub<PUB>(&b.uflags[slot], ff | ((uint32_t)BS_FL_EVALUATED << 8) | (prm.stamp << 16));      // (the stamp goes last)
 }
 
 // Three rounds of loads, issued as early as their addresses are known, then arithmetic, then stores:
 //   round 1   the pod's own fields (group, flags, owner, request, class, pair) | the batch's leader and panic flag
 //   round 2   the pod's group (flags, OccupiedBy, first owner, first pod) | both leaders' resources (uniform)
 //   round 3   the owner of the group's first owning pod (only where OccupiedBy is still empty)
-template <int TS>
+template <int TS, bool PUB = false>
 __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i,
                                                   uint32_t nthreads) {
   const Shape<TS> sh(prm.S);
@@ -471,14 +482,34 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
   // class that may pass and is not in the leader's own group derives the same slot contents: one lane per (wave, class)
   // is elected to fill it (tens of thousands of identical stores to a few hundred cache lines were a measurable part
   // of this launch; electing ONE writer per batch with an atomic swap of the stamp was worse: a hot-spot of returning atomics).
+  const uint32_t qslot = has_q ? pc : 0u;
+  bool fill = wave_elect_by_key(qslot, has_q);         // one writer per (wave, class): ~10x fewer identical stores, no atomics
+  bool w1 = false, w2 = false;
   if (prm.run_filter) {
     const bool may = valid && (st & ST_OWNED) && BS_PF_IS_PASS(code) && grouped;
-    if (wave_elect_by_key(pc, may && leader0 >= 0 && leader0 != gi)) filter_slot_from(b, prm, cur, lp0, sh, gate, pc);
-    if (wave_elect_by_key(pc, may && prm.sop_leader0 >= 0 && prm.sop_leader0 != gi)) filter_slot_from(b, prm, cur, lp1, sh, gate, pc + K);
+    w1 = wave_elect_by_key(pc, may && leader0 >= 0 && leader0 != gi);
+    w2 = wave_elect_by_key(pc, may && prm.sop_leader0 >= 0 && prm.sop_leader0 != gi);
   }
+  if constexpr (PUB) {
+    // k_fast_step_a: the slots are read by other blocks of THIS launch, so they go out write-through (st_pub) — one fabric write per
+    // store, and ~2 400 (wave, class) writers x 18 stores kept the pod blocks draining for 30 us (profiles/r05_stamps_step_a.txt; a
+    // look at the stamp first does not help: every wave looks before anybody's stamp has landed).  One writer per slot and batch: the
+    // elected lanes CLAIM their slots with a swap of the stamp word, all three swaps in flight together; whoever finds the batch's
+    // stamp already there leaves the slot to the claimant (whose block finishes its stores before it takes the ticket the readers
+    // wait for).
+    uint32_t o1 = 0, o2 = 0, o3 = 0;
+    // (claim words of their own for the Filter slots: a swap and a write-through store of DIFFERENT values to one word were seen to
+    // land in either order — the readers found the claim, not the flags; the scan slot's stamp word takes the same value both times)
+    if (w1) o1 = __hip_atomic_exchange(&b.uclaim[pc], prm.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w2) o2 = __hip_atomic_exchange(&b.uclaim[pc + K], prm.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fill) o3 = __hip_atomic_exchange(&b.qstamp_s[qslot], prm.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w1 && o1 == prm.stamp) w1 = false;
+    if (w2 && o2 == prm.stamp) w2 = false;
+    if (fill && o3 == prm.stamp) fill = false;
+  }
+  if (w1) filter_slot_from<TS, PUB>(b, prm, cur, lp0, sh, gate, pc);
+  if (w2) filter_slot_from<TS, PUB>(b, prm, cur, lp1, sh, gate, pc + K);
   BS_STAMP(1, 3);
-  const uint32_t qslot = has_q ? pc : 0u;
-  const bool fill = wave_elect_by_key(qslot, has_q);   // one writer per (wave, class): ~10x fewer identical stores, no atomics
   if (has_q) {
     b.qpos[i] = qslot;
     atomicMin(&b.pair_firstq[pp], ((unsigned long long)prm.seq_inv << 32) | i);
@@ -497,11 +528,11 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
     int64_t* dst = b.qreq_s + (size_t)slot * prm.LP;
 #pragma unroll
     for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-      if (j < prm.LP) dst[j] = j < sh.L() ? q.v[j] : INT64_MIN;
-    b.qflags_s[slot] = q.present | (absok << 16);
-    b.qtab_s[slot] = 0;
-    b.first_row[slot] = BS_INF;                               // every writer stores the same; launch B takes minima
-    b.qstamp_s[slot] = prm.stamp;
+      if (j < prm.LP) st_pub<PUB>(&dst[j], j < sh.L() ? q.v[j] : (int64_t)INT64_MIN);
+    st_pub<PUB>(&b.qflags_s[slot], q.present | (absok << 16));
+    st_pub<PUB>(&b.qtab_s[slot], (int32_t)0);
+    st_pub<PUB>(&b.first_row[slot], BS_INF);                  // every writer stores the same; launch B takes minima
+    st_pub<PUB>(&b.qstamp_s[slot], prm.stamp);
   }
   if (prm.collect_stats) {
     const unsigned long long hq = __ballot(has_q);
@@ -516,6 +547,251 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_query_tables(PodsDev pods, G
   BS_STAMP(1, 0);
   if (blockIdx.x < query_blocks) fast_query_thread<TS>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
   else tables_local_fast<TS>(nd, bt, prm, forced, blockIdx.x - query_blocks);
+  BS_STAMP(1, 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: launch A and the scan / Filter roles of launch B as ONE launch — k_fast_step_a — followed by k_fast_final.
+//
+// The three-level step (tables -> scan -> final) spends most of its 21 us on what sits BETWEEN the levels (stamps,
+// profiles/r03_stamps_step.txt): launch A's drain, the boundary, the scan blocks' first fetches of what A wrote (slots, chunk totals,
+// group maxima, then the table rows of a live group), 944 KB of table rows that go out through L2 and come back.  Here the block that
+// BUILDS chunk c of the table keeps its 256 rows in registers (thread = row) and scans them itself:
+//   pod blocks    [0, qb)                    fast_query_thread, slot stores write-through (st_pub), then ticket[8] += 1
+//   table blocks  qb + c * SS + q            chunk c (built by each of its SS blocks: a few us of arithmetic on L2-resident node lanes),
+//                                            publishes the chunk's totals / first key rows (q == 0), ticket[9] += 1; waits for BOTH
+//                                            tickets; chunk offset = exclusive prefix of the totals (<= 64 chunks: one lane each);
+//                                            then share q of the class slots against its rows: lanes are ROWS, a slot's request is the
+//                                            uniform operand (LDS copy of the block's slots), first row per slot -> atomicMin(first_row)
+//   filter blocks the rest                   wait for ticket[8], agent acquire, filter_loop<2> as in launch B
+// No table row, group maximum or chunk key row is written at all.  A slot's first row is the minimum over the chunks of the first row
+// inside each chunk: the same answer as the legacy scan's early exit.  Tickets are never reset: the host passes the counter values
+// this launch starts from (wrap-safe differences).  Every block of the grid must be resident at once (the waiting blocks spin):
+// run_fast asks the occupancy API and takes the legacy chain otherwise; spins are bounded and raise the context's error word.
+// ------------------------------------------------------------------------------------------------
+// lanes whose row covers the request on every resource lane: compareResourceAndRequire (core.go:672-699) as an EXEC chain, row and
+// request both per-lane operands (rows in the lanes, the slot's request broadcast from LDS)
+template <int NL>
+__device__ __forceinline__ unsigned long long rows_cover(unsigned long long m, const int64_t (&a)[BS_MAX_LANES], const int64_t (&r)[BS_MAX_LANES]) {
+  asm volatile("s_mov_b64 exec, %[m]\n\tv_cmpx_ge_i64 vcc, %[a0], %[r0]\n\tv_cmpx_ge_i64 vcc, %[a1], %[r1]\n\tv_cmpx_ge_i64 vcc, %[a2], %[r2]\n\t"
+               "v_cmpx_ge_i64 vcc, %[a3], %[r3]\n\ts_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1"
+               : [m] "+s"(m)
+               : [a0] "v"(a[0]), [r0] "v"(r[0]), [a1] "v"(a[1]), [r1] "v"(r[1]), [a2] "v"(a[2]), [r2] "v"(r[2]), [a3] "v"(a[3]), [r3] "v"(r[3])
+               : "vcc");
+#pragma unroll
+  for (int j = 4; j < NL; ++j)
+    asm volatile("s_mov_b64 exec, %[m]\n\tv_cmpx_ge_i64 vcc, %[a], %[r]\n\ts_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1" : [m] "+s"(m) : [a] "v"(a[j]), [r] "v"(r[j]) : "vcc");
+  return m;
+}
+constexpr uint32_t kStepSlotsMax = 256;        // class slots the one-launch form handles (the latency regime: K <= 256)
+__device__ __forceinline__ bool step_wait(const uint32_t* word, uint32_t base, uint32_t need, int32_t* h_err) {
+  uint32_t spins = 0;
+  while ((uint32_t)(ld_agent(word) - base) < need) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 24)) { if (h_err) __hip_atomic_store(h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+  }
+  return true;
+}
+template <int TS>
+__device__ __forceinline__ void table_scan_block(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk, uint32_t nchunks,
+                                                 uint32_t share, uint32_t nshares, uint32_t pod_blocks, uint32_t tk_pods0, uint32_t tk_tab0) {
+  __shared__ unsigned long long s_wtot[BS_MAX_LANES][4];
+  __shared__ uint32_t s_kp[BS_MAX_SCALARS];
+  __shared__ unsigned long long s_off[BS_MAX_LANES];
+  __shared__ uint32_t s_kpg[BS_MAX_SCALARS];
+  __shared__ int64_t s_req[kStepSlotsMax][BS_MAX_LANES];
+  __shared__ uint32_t s_qf[kStepSlotsMax];
+  __shared__ uint32_t s_first[kStepSlotsMax];
+  BS_STAMP(2, 0);
+  const Shape<TS> sh(prm.S);
+  const uint32_t L = sh.L(), S = sh.S(), LP = prm.LP;
+  const uint32_t k = chunk * kTblChunk + threadIdx.x;
+  const bool valid = k < nd.m;
+  const uint32_t n = valid ? nd.kmap[k] : 0u;
+  const TableDesc d = *forced;
+  const uint32_t fw = nd.fit[(size_t)d.cls * nd.fit_words + (n >> 5)];
+  const uint8_t fl = nd.flags[n];
+  const uint32_t ap = nd.apres[n], rp = nd.rpres[n];
+  int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES];
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    if (j < L) {
+      al[j] = nd.alloc[(size_t)j * nd.stride + n];
+      rq[j] = nd.req[(size_t)j * nd.stride + n];
+    }
+  }
+  const bool fit = valid && ((fw >> (n & 31u)) & 1u) && !(fl & BS_NODE_TAINT_ERR);
+  const uint32_t pres = fit ? (ap & rp) : 0u;
+  if (threadIdx.x < BS_MAX_SCALARS) s_kp[threadIdx.x] = BS_INF;
+  for (uint32_t t = threadIdx.x; t < kStepSlotsMax; t += kTblChunk) s_first[t] = BS_INF;
+  unsigned long long incl[BS_MAX_LANES];
+  const int w = wave_id();
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    incl[j] = 0;
+    if (j < L) {
+      const bool live = fit && (j < 4 || (pres & (1u << (j - 4)))) && !(j == BS_LANE_EPH && !prm.eph_gate);
+      const unsigned long long left = live ? (unsigned long long)wsub(scale_f32(al[j], d.pct), rq[j]) : 0ull;
+      incl[j] = wave_incl_scan_add_u64(left);
+      if (lane_id() == 63) s_wtot[j][w] = incl[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
+    if (s2 < S) {
+      const unsigned long long mk = __ballot(valid && (pres & (1u << s2)));
+      if (mk && lane_id() == 0) atomicMin(&s_kp[s2], chunk * kTblChunk + (uint32_t)(threadIdx.x & ~63u) + (uint32_t)(__ffsll((long long)mk) - 1));
+    }
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    if (j < L) {
+      unsigned long long off = 0, tot = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned long long x = s_wtot[j][i];
+        if (i < w) off += x;
+        tot += x;
+      }
+      incl[j] += off;
+      if (threadIdx.x == 0 && share == 0) st_pub<true>(&b.chunk_tot[(size_t)chunk * 16 + j], tot);
+    }
+  }
+  __syncthreads();
+  if (share == 0 && threadIdx.x < 16) st_pub<true>(&b.chunk_kp[(size_t)chunk * 16 + threadIdx.x], threadIdx.x < BS_MAX_SCALARS ? s_kp[threadIdx.x] : BS_INF);
+  // ---- publish (share 0 of every chunk), then wait for every chunk's totals and for every pod block's slots
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  BS_STAMP(2, 1);
+  __shared__ uint32_t s_ok;
+  if (threadIdx.x == 0) {
+    if (share == 0) (void)__hip_atomic_fetch_add(&b.ticket[9], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ok = (step_wait(&b.ticket[9], tk_tab0, nchunks, b.h_err) && step_wait(&b.ticket[8], tk_pods0, pod_blocks, b.h_err)) ? 1u : 0u;
+  }
+  __syncthreads();
+  BS_STAMP(2, 2);
+  if (!s_ok) return;
+  // ---- this block's slots -> LDS; the chunk's offset and the table's first key rows (wave 0: lane <-> chunk)
+  const uint32_t K = prm.k_host;
+  const uint32_t per = (K + nshares - 1u) / nshares, s_lo = share * per, s_hi = min(K, s_lo + per);
+  {
+    // one round trip for everything: wave 0's lanes take the chunk totals / key rows (lane <-> chunk), every thread a slot of the share
+    const uint32_t ch = (uint32_t)lane_id();
+    unsigned long long cv[BS_MAX_LANES];
+    uint32_t ckp[BS_MAX_SCALARS];
+    if (w == 0) {
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) cv[j] = (j < L && ch < nchunks) ? ld_agent64(&b.chunk_tot[(size_t)ch * 16 + j]) : 0ull;
+#pragma unroll
+      for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) ckp[s2] = (s2 < S && ch < nchunks) ? ld_agent(&b.chunk_kp[(size_t)ch * 16 + s2]) : BS_INF;
+    }
+    const uint32_t t = s_lo + threadIdx.x;
+    uint32_t stp = 0, qf = 0x80000000u;
+    int32_t tab = -1;
+    unsigned long long rv[BS_MAX_LANES];
+    if (t < s_hi) {
+      stp = ld_agent(&b.qstamp_s[t]);
+      tab = (int32_t)ld_agent(reinterpret_cast<const uint32_t*>(&b.qtab_s[t]));
+      qf = ld_agent(&b.qflags_s[t]);
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) rv[j] = j < L ? ld_agent64(&b.qreq_s[(size_t)t * LP + j]) : 0ull;
+    }
+    if (w == 0) {
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+        if (j < L) {
+          const unsigned long long incl_c = wave_incl_scan_add_u64(cv[j]);
+          const unsigned long long mine = bcast64(incl_c - cv[j], (int)(chunk & 63u));
+          if (ch == 0) s_off[j] = mine;
+        }
+      }
+#pragma unroll
+      for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
+        if (s2 < S) {
+          const uint32_t mn = wave_min_u32(ckp[s2]);
+          if (ch == 0) s_kpg[s2] = mn;
+        }
+      }
+    }
+    if (t < s_hi) {                                          // (per <= 256: one slot per thread)
+      if (stp != prm.stamp || tab != 0) qf = 0x80000000u;    // not written by a pod of THIS batch: no query
+      s_qf[threadIdx.x] = qf;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+        if (j < L) s_req[threadIdx.x][j] = (int64_t)rv[j];
+    }
+  }
+  __syncthreads();
+  int64_t fin[BS_MAX_LANES];
+  uint32_t keyrow = 0;                                         // bit s: key s is in the running sum at this row (core.go:686-697)
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+    fin[j] = 0;
+    if (j < L) fin[j] = (int64_t)(incl[j] + s_off[j]);
+  }
+#pragma unroll
+  for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2)
+    if (s2 < S && k >= s_kpg[s2]) keyrow |= 1u << s2;
+  BS_STAMP(2, 3);
+  // ---- the scan: lanes are rows, the slot's request is the uniform operand
+  const uint32_t nmine = s_hi > s_lo ? s_hi - s_lo : 0u;
+  const uint32_t smask = S ? ((1u << S) - 1u) : 0u;
+  const uint32_t row0 = chunk * kTblChunk + ((uint32_t)w << 6);
+  for (uint32_t t0 = 0; t0 < nmine; t0 += 4u) {            // four slots per step: their LDS reads travel together
+    uint32_t qf[4];
+    int64_t r[4][BS_MAX_LANES];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t t = min(t0 + u, nmine - 1u);
+      qf[u] = t0 + u < nmine ? s_qf[t] : 0x80000000u;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) r[u][j] = j < L ? s_req[t][j] : 0;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      // a scalar key that is not in the running sum yet at this row: only a slot that asks for nothing of it can pass (core.go:686-697)
+      const uint32_t nab = ~(qf[u] >> 16) & smask;
+      unsigned long long m = (qf[u] & 0x80000000u) ? 0ull : __ballot(valid && (nab & ~keyrow) == 0u);
+      static_assert(TS >= 0 && TS <= 4, "k_fast_step_a is instantiated for 0..4 scalar lanes (run_fast: step_a_possible)");
+      m = rows_cover<4 + TS>(m, fin, r[u]);
+      if (m && lane_id() == 0) atomicMin(&s_first[t0 + u], row0 + (uint32_t)(__ffsll((long long)m) - 1));
+    }
+  }
+  __syncthreads();
+  BS_STAMP(2, 4);
+  for (uint32_t t = threadIdx.x; t < nmine; t += kTblChunk)
+    if (s_first[t] != BS_INF) atomicMin(&b.first_row[s_lo + t], s_first[t]);
+  BS_STAMP(2, 7);
+}
+
+// block layout: [0, qb) pods | qb + c * nshares + q: chunk c, slot share q | the rest: Filter
+template <int TS>
+__global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm, const TableDesc* forced,
+                                                           uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks, uint32_t filter_waves,
+                                                           uint32_t ustride, uint32_t tk_pods0, uint32_t tk_tab0) {
+  BS_STAMP(1, 0);
+  const uint32_t tb = nchunks * nshares;
+  if (blockIdx.x < query_blocks) {
+    fast_query_thread<TS, true>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
+    BS_STAMP(1, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // slots, Filter parameters, first-reach word: out before the ticket
+    __syncthreads();
+    BS_STAMP(1, 5);
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (blockIdx.x < query_blocks + tb) {
+    const uint32_t x = blockIdx.x - query_blocks;
+    table_scan_block<TS>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, query_blocks, tk_pods0, tk_tab0);
+  } else {
+    __shared__ uint32_t s_go;
+    if (threadIdx.x == 0) {
+      s_go = step_wait(&b.ticket[8], tk_pods0, query_blocks, b.h_err) ? 1u : 0u;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the Filter loop reads the slots with plain loads (one lane's acquire + the barrier)
+    }
+    __syncthreads();
+    if (!s_go) return;
+    filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - query_blocks - tb, filter_blocks, prm.stamp, 2u * prm.k_host);
+  }
   BS_STAMP(1, 7);
 }
 
@@ -622,7 +898,6 @@ __device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& 
 // ------------------------------------------------------------------------------------------------
 // what launch B left behind, read by a block of the SAME launch: performed at the coherence point (its writers used agent-scope
 // atomics), not looked up in this XCD's L2
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // block `bx` of `nblocks` final blocks; producers > 0: they run in this very launch (k_fast_scan_filter_final) and count themselves
 // into ticket[1] when their results are out — everything that does not depend on them is fetched first

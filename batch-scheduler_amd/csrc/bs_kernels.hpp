@@ -132,6 +132,7 @@ struct BatchDev {
   uint32_t* fu_slot;        // [P] Filter slot of the pod
   int64_t* uparams;         // [filter slots][8] R[4] = pod + maxSingle, M[4] = maxSingle (fixed lanes)
   uint32_t* uflags;         // [filter slots] as fflags; fl_code NOT_RUN = slot unused
+  uint32_t* uclaim;         // [filter slots] k_fast_step_a: stamp of the batch whose (one) writer claimed the slot
   uint64_t* fu_bitmap;      // [W][filter slots] rows of the slots
   uint32_t* fu_feas;        // [filter slots] feasible-node counts of the slots
   // ---- steady-state fast path (bs_fast.hpp): nothing here is reset per batch

@@ -191,7 +191,7 @@ struct bs_ctx {
   bool side_ready = false;      // desc[] of the steady-state table is in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
   // request slots (see BatchDev): classes of the loaded pods + per-batch slot arrays
-  DevBuf d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_fu_bitmap, d_fu_feas;
+  DevBuf d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_uclaim, d_fu_bitmap, d_fu_feas;
   uint32_t slot_keep = 0xFFFFFFFFu;   // BS_HASH_SLOT_BITS (tests): directory probes start at hash & slot_keep
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
   DevBuf d_fl_bitmap, d_admit, d_ready, d_gcount, d_admit64, d_own_start;
@@ -253,6 +253,12 @@ struct bs_ctx {
                                      // blocks) units on, filter_waves below; an explicit BS_FILTER_WAVES rules
   bool filter_waves_env = false;
   int fused_blocks_resident = -1;    // whole-chip residency of k_fast_scan_filter_final (blocks), -1 = not asked yet
+  int step_a_resident = -1;          // ... of k_fast_step_a
+  bool step_a_on = false;            // BS_STEP_A=1: take the one-launch form of launch A + scan / Filter roles where it applies (measured SLOWER
+                                     // than the two launches: 32 vs 20.7 us at cfg3/tail, DESIGN.md section 4 — kept as a tested experiment, off by default)
+  uint32_t step_shares = 4;          // BS_STEP_SHARES: blocks that share one table chunk's class slots
+  uint32_t tk_pods = 0, tk_tab = 0;  // values of ticket[8] / ticket[9] the next k_fast_step_a starts from (never reset: wrap-safe differences)
+  bool last_step_a = false;
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   uint32_t general_waves = 4096;     // scan grid cap of the general chain (tools/cold_sweep.py)
   bs_batch_stats stats{};
@@ -457,6 +463,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.qtab_s = c->d_qtab_s.as<int32_t>();
   b.uparams = c->d_uparams.as<int64_t>();
   b.uflags = c->d_uflags.as<uint32_t>();
+  b.uclaim = c->d_uclaim.as<uint32_t>();
   b.fu_bitmap = c->d_fu_bitmap.as<uint64_t>();
   // per-slot feasible counts sit right behind the last row of the slot bitmap: one 2-D copy returns rows + counts
   b.fu_feas = reinterpret_cast<uint32_t*>(at(c->d_fu_bitmap.as<uint64_t>(), (size_t)cdiv(c->N, 64) * c->filter_slots_cap));
@@ -1065,6 +1072,8 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_TP_FILTER")) c->tp_filter = (uint32_t)std::min(7, std::max(0, std::atoi(e)));
+  if (const char* e = std::getenv("BS_STEP_A")) c->step_a_on = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BS_STEP_SHARES")) c->step_shares = (uint32_t)std::min(32, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_SHARE")) c->tp_share = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_FWAVES")) c->tp_fwaves = (uint32_t)std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_NO_SPECULATE")) c->no_spec = std::atoi(e) ? 1u : 0u;
@@ -1877,6 +1886,7 @@ static int reserve_slots(bs_ctx* c, bool run_filter) {
     HIPCHK(c, c->d_fu_bitmap.reserve((size_t)(cdiv(c->N, 64) + 1) * filter_cap * 8));      // slot rows, then the per-slot feasible counts
     HIPCHK(c, c->d_uparams.reserve((size_t)filter_cap * 64));
     if ((rc = reserve_filled(c, c->d_uflags, (size_t)filter_cap * 4, 0))) return rc;
+    if ((rc = reserve_filled(c, c->d_uclaim, (size_t)filter_cap * 4, 0))) return rc;
   }
   c->scan_slots_cap = scan_cap;
   c->filter_slots_cap = filter_cap;
@@ -1971,6 +1981,18 @@ static inline uint64_t host_ns() {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
+// k_fast_step_a (bs_fast.hpp): the one-launch form of launch A + the scan / Filter roles — the latency regime only (K known on the
+// host and <= 256 class slots, <= 64 table chunks), no instrumentation that needs the legacy launches (work counters, per-launch stamps),
+// and a context that has not seen an in-launch hand-over time out.  OFF unless BS_STEP_A=1 (it is correct and slower, see bs_ctx::step_a_on).
+static bool step_a_possible(const bs_ctx* c, uint32_t stages, const BatchParams& prm, uint32_t nchunks) {
+  return c->step_a_on && !c->no_fuse_final && prm.k_host > 0 && prm.k_host <= kStepSlotsMax && nchunks <= 64 && c->M > 0 && c->P > 0 && !c->collect_stats &&
+         c->cfg.enable_timing < 2 && c->S <= 4;
+}
+static int step_a_residency(bs_ctx* c) {
+  if (c->step_a_resident < 0) c->step_a_resident = step_a_residency_query(fast_launch(c));
+  return c->step_a_resident;
+}
+
 // The steady-state chain (bs_fast.hpp): three launches, nothing reset, no wait.
 static int run_fast(bs_ctx* c, uint32_t stages) {
   int rc;
@@ -2011,6 +2033,39 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   if (c->kinfo_pending && ((volatile int32_t*)c->h_info)[5] == c->kinfo_tag && (rc = resolve_pods(c))) return rc;
   prm.k_host = c->kinfo_pending ? 0u : c->h_K;
   const uint64_t hp1 = c->host_probe ? host_ns() : 0;
+  // ---- round 5: launch A and the scan / Filter roles of launch B as ONE launch (k_fast_step_a), then k_fast_final
+  if (step_a_possible(c, stages, prm, nchunks)) {
+    const uint32_t qb = cdiv(P, kTblChunk);
+    const uint32_t K = prm.k_host;
+    const uint32_t nshares = std::max<uint32_t>(1, std::min<uint32_t>(c->step_shares, cdiv(K, 8)));
+    const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * K, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
+    const uint32_t grid = qb + nchunks * nshares + fblocks;
+    if ((int)grid <= step_a_residency(c)) {
+      TIMED(c, BS_KERNEL_QUERY, {
+        launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks, qb, nshares, fblocks, c->tk_pods, c->tk_tab);
+      });
+      c->tk_pods += qb;
+      c->tk_tab += nchunks;
+      TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
+      c->launches = 2;
+      c->last_step_a = true;
+      if (prm.filter_deny && (rc = launch_filter_deny(c, pd, gr, nd, b, prm, true))) return rc;
+      if (commit) {
+        if (prm.filter_deny && (rc = launch_filter_deny_marks(c, b, prm, b.fast_reject))) return rc;
+        if (G) hipLaunchKernelGGL(k_fast_commit, dim3(cdiv(G, 256)), dim3(256), 0, c->stream, pd, b, const_cast<uint8_t*>(gr.flags),
+                                  const_cast<uint64_t*>(gr.occupied), G, prm.filter_deny ? b.fd_flag : nullptr);
+        LAUNCHCHK(c, BS_KERNEL_RESOLVE);
+        int32_t last = -1;
+        HIPCHK(c, hipMemcpyAsync(&last, b.pf_leader + (P - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        if (G) HIPCHK(c, hipMemcpyAsync(c->h_gflags.data(), gr.flags, G, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!fd_commit_gated(c)) c->sop_leader0 = last;
+        c->launches++;
+      }
+      return batch_collective(c, stages, gr, b);
+    }
+  }
+  c->last_step_a = false;
   // ---- launch A: per-pod decisions, scan / Filter slots | chunk-local running sums of the table
   TIMED(c, BS_KERNEL_QUERY, {
     const uint32_t qb = cdiv(P, kTblChunk);
@@ -2279,6 +2334,7 @@ static int batch_run_inner(bs_ctx* c, uint32_t stages) {
   if (c->stamp_ctr == 0) {
     if (c->d_qstamp_s.p) HIPCHK(c, hipMemsetAsync(c->d_qstamp_s.p, 0, c->d_qstamp_s.cap, c->stream));
     if (c->d_uflags.p) HIPCHK(c, hipMemsetAsync(c->d_uflags.p, 0, c->d_uflags.cap, c->stream));
+    if (c->d_uclaim.p) HIPCHK(c, hipMemsetAsync(c->d_uclaim.p, 0, c->d_uclaim.cap, c->stream));
   }
   // the key sequence ran out: every keyed 64-bit minimum goes back to 'none' before ~key_seq starts over
   if (c->rekey_pending) {

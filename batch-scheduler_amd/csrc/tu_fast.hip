@@ -132,4 +132,40 @@ void launch_fast_bc(const FastLaunch& c, dim3 grid, const PodsDev& pd, const Gro
 }
 
 
+template <int TS>
+static void launch_fast_step_a_s(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
+                                 const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
+                                 uint32_t tk_pods0, uint32_t tk_tab0) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_step_a<TS>), grid, dim3(kTblChunk), 0, c.stream, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks,
+                     c.filter_waves, c.filter_slots_cap, tk_pods0, tk_tab0);
+}
+void launch_fast_step_a(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
+                        const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
+                        uint32_t tk_pods0, uint32_t tk_tab0) {
+  switch (c.S) {
+    case 0: launch_fast_step_a_s<0>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0); break;
+    case 1: launch_fast_step_a_s<1>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0); break;
+    case 2: launch_fast_step_a_s<2>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0); break;
+    case 3: launch_fast_step_a_s<3>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0); break;
+    default: launch_fast_step_a_s<4>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0); break;
+  }
+}
+template <int TS>
+static int step_a_residency_s(const FastLaunch& c) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fast_step_a<TS>, (int)kTblChunk, 0) != hipSuccess || per_cu <= 0) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) return 0;
+  return std::max(0, per_cu - 1) * prop.multiProcessorCount;      // (minus one block per CU: the API can be one high, see fused_residency_query)
+}
+int step_a_residency_query(const FastLaunch& c) {
+  switch (c.S) {
+    case 0: return step_a_residency_s<0>(c);
+    case 1: return step_a_residency_s<1>(c);
+    case 2: return step_a_residency_s<2>(c);
+    case 3: return step_a_residency_s<3>(c);
+    default: return step_a_residency_s<4>(c);
+  }
+}
+
 }  // namespace bs

@@ -236,3 +236,23 @@ def test_unfused_final_launch_is_selectable_and_equal(config, scenario, bsa, soa
         ctx.load_groups(groups)
         ctx.load_pods(pods)
         assert ctx.stats(soa.STAGE_ALL)["launches"] == 2          # the fused form: the whole grid is resident on this chip
+
+
+@pytest.mark.parametrize("config,scenario", [("cfg2", "warm"), ("cfg2", "tail"), ("cfg3", "tail"), ("tiny", "busy")])
+def test_one_launch_form_of_the_step_equals_the_oracle(config, scenario, monkeypatch, bsa, soa, orc):
+    """BS_STEP_A=1 (round 5's experiment, off by default because it measured slower): launch A and the scan / Filter roles of launch B as
+    ONE launch — the block that builds a table chunk keeps its rows in registers and scans them itself, slots handed over inside the
+    launch (k_fast_step_a) — then k_fast_final.  Same answers, batch after batch, with a queue patch in between."""
+    monkeypatch.setenv("BS_STEP_A", "1")
+    nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        for _ in range(4):
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"{config}/{scenario} one-launch step")
+        assert ctx.stats(soa.STAGE_ALL)["launches"] == 2
+        rem = np.arange(0, pods.p, 7, dtype=np.uint32)
+        ctx.apply_pods(remove=rem)
+        left = pods.take(np.setdiff1d(np.arange(pods.p), rem))
+        exp2 = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(left, soa.STAGE_ALL)
+        for _ in range(2):
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp2, f"{config}/{scenario} one-launch step after a queue patch")

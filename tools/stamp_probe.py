@@ -25,7 +25,7 @@ import bench  # noqa: E402
 
 bsa = importlib.import_module("batch-scheduler_amd")
 soa = bsa.soa
-NAMES = {0: "k_pods_apply", 1: "A k_fast_query_tables", 2: "B producer blocks of k_fast_scan_filter_final", 3: "C final blocks of k_fast_scan_filter_final"}
+NAMES = {0: "k_pods_apply", 1: "A k_fast_query_tables / pod blocks of k_fast_step_a", 2: "B producer blocks of k_fast_scan_filter_final / table blocks of k_fast_step_a", 3: "C final blocks"}
 
 
 def main():
