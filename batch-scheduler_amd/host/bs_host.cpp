@@ -123,7 +123,8 @@ struct bsh_sop {
     for (uint32_t g = 0; g < G; ++g) {
       const Group& x = groups[g];
       mm[g] = x.min_member; sc[g] = x.status_scheduled; ma[g] = x.matched.Count(now); cl[g] = x.cls; mp[g] = x.minres_present; oc[g] = x.occupied_by;
-      fl[g] = (x.scheduled_latch ? BS_GROUP_SCHEDULED_LATCH : 0) | (x.has_pod ? BS_GROUP_HAS_POD : 0) | (x.has_minres ? BS_GROUP_HAS_MINRES : 0);
+      fl[g] = (x.scheduled_latch ? BS_GROUP_SCHEDULED_LATCH : 0) | (x.has_pod ? BS_GROUP_HAS_POD : 0) | (x.has_minres ? BS_GROUP_HAS_MINRES : 0) |
+              ((x.phase != Pending && x.phase != PreScheduling && x.phase != Scheduling) ? BS_GROUP_PHASE_CLOSED : 0);   // batchscheduler.go:258-261
       for (uint32_t j = 0; j < L; ++j) mr[(size_t)j * G + g] = x.minres[j];
     }
     bs_groups_soa s{G, mm.data(), sc.data(), ma.data(), fl.data(), cl.data(), mr.data(), mp.data(), oc.data()};

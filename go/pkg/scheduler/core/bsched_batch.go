@@ -16,6 +16,7 @@ import (
 	"k8s.io/apimachinery/pkg/types"
 	"k8s.io/kubernetes/pkg/scheduler/nodeinfo"
 
+	pgv1 "github.com/tenstack/batch-scheduler/pkg/apis/podgroup/v1"
 	"github.com/tenstack/batch-scheduler/pkg/scheduler/cache"
 	"github.com/tenstack/batch-scheduler/pkg/util"
 )
@@ -71,6 +72,13 @@ func (g *gpuCore) groupFlags(name string, pgs *cache.PodGroupMatchStatus, denied
 	}
 	if denied(name) { // live lastDeniedPG entry, core.go:105
 		f |= C.BS_GROUP_DENIED
+	}
+	// StartBatchSchedule releases only in phase PreScheduling / Scheduling (batchscheduler.go:258-261; Permit turns Pending into
+	// PreScheduling first, core.go:279-281): every other phase is "closed" for the pod-by-pod pass (bs_seq_run)
+	switch pgs.PodGroup.Status.Phase {
+	case pgv1.PodGroupPending, pgv1.PodGroupPreScheduling, pgv1.PodGroupScheduling, "":
+	default:
+		f |= C.BS_GROUP_PHASE_CLOSED
 	}
 	return f
 }

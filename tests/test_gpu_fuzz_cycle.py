@@ -51,7 +51,7 @@ def run_sequence(seed, steady, bsa, soa, orc, rounds=16, big=False):
                 for i in rng.choice(groups.g, min(4, groups.g), replace=False):
                     groups.matched[i] = rng.integers(0, groups.min_member[i] + 2)
                     groups.status_scheduled[i] = rng.integers(0, 3)
-                    groups.flags[i] = (groups.flags[i] & 0x6) | int(rng.integers(0, 2)) | (8 * int(rng.integers(0, 2)))
+                    groups.flags[i] = (groups.flags[i] & 0x6) | int(rng.integers(0, 2)) | (8 * int(rng.integers(0, 2))) | (soa.GROUP_PHASE_CLOSED if rng.random() < 0.15 else 0)
                     deltas.append((i, groups.matched[i], groups.status_scheduled[i], groups.flags[i]))
                 ctx.apply_group_deltas(deltas)
             elif op == "assume":
@@ -77,10 +77,12 @@ def run_sequence(seed, steady, bsa, soa, orc, rounds=16, big=False):
                 else:
                     ctx.load_nodes(nodes, fit)
             elif op == "seq":
-                st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if rng.random() < 0.4 else 0)
+                st = soa.STAGE_PREFILTER | (soa.STAGE_FILTER if rng.random() < 0.5 else 0)
+                if (st & soa.STAGE_FILTER) and rng.random() < 0.5:
+                    st |= soa.BATCH_FILTER_DENY                # Filter's TTL writes inside the pass (core.go:183-188)
                 s = orc.seq_replay(nodes, fit, groups, cur, st, leader=leader)
                 r = ctx.seq_run(st)
-                for name in ("pf_code", "pf_first_k", "pf_leader", "pod_node"):
+                for name in ("pf_code", "pf_first_k", "pf_leader", "pod_node") + (("last_permitted",) if st & soa.BATCH_FILTER_DENY else ()):
                     assert np.array_equal(r[name], s[name]), f"{where}: {name}"
                 assert r["released_group"].tolist() == s["released_group"].tolist() and r["released_pods"].tolist() == s["released_pods"].tolist(), where
                 nodes, groups, leader = s["nodes"], s["groups"], s["leader"]
@@ -96,6 +98,10 @@ def run_sequence(seed, steady, bsa, soa, orc, rounds=16, big=False):
                 sop = orc.Sop(orc.Snapshot(nodes, fit), groups).carry(leader)
                 exp = sop.batch(cur, st, bitmap=False)
                 ctx.run(st | (soa.BATCH_COMMIT if commit else 0) | (soa.BATCH_HOST_RESULTS if host else 0))
+                if not commit and rng.random() < 0.2:          # a patch BETWEEN run and read: the batch is settled first, against the state it ran on
+                    i = int(rng.integers(0, groups.g))
+                    groups.matched[i] = rng.integers(0, groups.min_member[i] + 2)
+                    ctx.apply_group_deltas([(i, groups.matched[i], groups.status_scheduled[i], groups.flags[i])])
                 view = None
                 if host and rng.random() < 0.6:
                     try:

@@ -197,3 +197,43 @@ def test_full_size_all_distinct_equals_the_oracles_digest(config, scenario, bsa,
         assert int((got.fl_code == soa.FL_EVALUATED).sum()) == want["evaluated_pods"] and int(got.group_ready.sum()) == want["groups_ready"]
         st = ctx.stats(soa.STAGE_ALL)
         assert st["chain"] == 1 and st["launches"] == 3
+
+
+@pytest.mark.parametrize("scalars", [5, 7])
+def test_wide_contexts_take_the_split_launches(scalars, bsa, soa, orc):
+    """More than four scalar lanes: the combined transposed kernel is not instantiated (it ran out of SGPRs there and reserved scratch
+    memory, tools/kernel_resources.py); run_fast sends such contexts through k_fast_scan + k_fast_filter_t.  Same answers."""
+    nodes, fit, groups, pods = _distinct(bsa, "cfg3", "busy", pods=2000, groups=400, nodes=1000, classes=8, scalars=scalars)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"{scalars} scalar lanes, default form")
+        st = ctx.stats(soa.STAGE_ALL)
+        assert st["chain"] == 1 and st["launches"] == 4, st          # query+tables | scan | transposed Filter | final
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_full_size_shards_equal_the_single_batch(nranks, bsa, soa):
+    """BASELINE configs[3] (50k pods / 5k groups / 20k nodes) with every request distinct, pod-axis shard on ONE context: every rank's
+    owned pods == the single batch's (which tests/golden/throughput_digests.json pins on the oracle), every pod owned exactly once, the
+    union of the admit counters == the single batch's.  (2 / 4 / 8 ranks.)"""
+    nodes, fit, groups, pods = _distinct(bsa, "cfg4", "tail")
+    with bsa.Context(scalar_lanes=nodes.lanes - 4) as ctx:
+        ctx.load_nodes(nodes, fit)
+        ctx.load_groups(groups)
+        ctx.load_pods(pods)
+        full = ctx.batch(soa.STAGE_ALL, bitmap=False, rows=True)
+        owned = np.zeros(pods.p, np.uint32)
+        admit = np.zeros(groups.g, np.uint32)
+        for r in range(nranks):
+            ctx.set_shard(r, nranks)
+            part = ctx.batch(soa.STAGE_ALL, bitmap=False, rows=True)
+            mine = part.pf_code != 0xFF
+            owned += mine
+            admit += part.group_admit
+            for name in ("pf_code", "pf_first_k", "pf_leader", "fl_code", "fl_feasible"):
+                assert np.array_equal(getattr(part, name)[mine], getattr(full, name)[mine]), (name, r)
+            ev = mine & (part.fl_code == soa.FL_EVALUATED)
+            if ev.any():                                            # the Filter rows of the owned, evaluated pods (slot numbering is the rank's own)
+                assert np.array_equal(part.fl_rows[:, part.fl_slot[ev]], full.fl_rows[:, full.fl_slot[ev]]), r
+        assert np.array_equal(owned, np.ones(pods.p, np.uint32)) and np.array_equal(admit, full.group_admit)
+        ctx.set_shard(0, 1)
