@@ -668,6 +668,20 @@ def main():
                                        "VGPRs; the launch's HBM-side duty is its OUTPUT, the Filter rows (distinct requests x nodes / 8 bytes)",
                            "output_bytes_per_launch": st["filter_distinct"] * ((nodes.n + 63) // 64) * 8,
                            "output_GBps": (st["filter_distinct"] * ((nodes.n + 63) // 64) * 8 / (b_us * 1e-6) / 1e9) if b_us else None}
+            if args.config == "cfg3":
+                # ... and the same at BASELINE configs[3]'s size (50k pods x 20k nodes: 9.6e8 pairs really evaluated per step), where the launch is
+                # long enough for the compares to show: the regime's figure at cfg3 is mostly the launch's own latency
+                n4, f4, g4, p4, _ = synth.make("cfg4", args.scenario, seed=args.seed)
+                p4 = p4.copy()
+                p4.req[0, :] += np.arange(p4.p, dtype=np.int64)
+                ms4, st4 = resident_ms(bsa, n4, f4, g4, p4, stages, 30, warmup=5)
+                t4 = launch_times(bsa, n4, f4, g4, p4, stages, 20).get("scan")
+                ev4 = st4["scan_evals_executed"] + st4["filter_evals_executed"]
+                roofline_tp["at_cfg4"] = {"workload": f"cfg4/{args.scenario}, every pod its own request ({st4['filter_distinct']} distinct Filter requests)", "kernel_us": t4,
+                                          "evals_executed_per_launch": ev4, "achieved_evals_per_s": ev4 / (t4 * 1e-6) if t4 else None, "frac": (ev4 / (t4 * 1e-6) / bound) if t4 else None,
+                                          "whole_step_ms": ms4, "frac_of_whole_step": ev4 / (ms4 * 1e-3) / bound,
+                                          "output_bytes_per_launch": st4["filter_distinct"] * ((n4.n + 63) // 64) * 8,
+                                          "output_GBps": (st4["filter_distinct"] * ((n4.n + 63) // 64) * 8 / (t4 * 1e-6) / 1e9) if t4 else None}
             ms, st = resident_ms(bsa, nodes, fit, groups, all_pods, soa.STAGE_PREFILTER | soa.STAGE_TALLY, 100)
             extras["prefilter_only"] = {"ms_per_step": ms, "evals_per_s": logical / (ms * 1e-3)}
             extras["filter_increment_ms"] = ms_per_step - ms if args.stages == "all" else None
