@@ -1291,6 +1291,7 @@ int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
   if ((rc = settle_pending(c))) return rc;
+  c->first_reach_hint = 0xFFFFFFFFu;                // (which pod reaches findMaxPG first depends on the groups' deny entries and OccupiedBy)
   const uint32_t G = g->g, L = c->L;
   if (G && (!g->min_member || !g->status_scheduled || !g->matched || !g->flags || !g->cls || !g->min_resources || !g->min_resources_present ||
             !g->occupied_by))
@@ -1356,6 +1357,7 @@ int bs_groups_apply(bs_ctx* c, const bs_group_delta* deltas, uint32_t count) {
   int rc = use_device(c);
   if (rc) return rc;
   if ((rc = settle_pending(c))) return rc;
+  c->first_reach_hint = 0xFFFFFFFFu;                // (which pod reaches findMaxPG first depends on the groups' deny entries and OccupiedBy)
   if (!count) return BS_OK;
   const uint8_t keep = BS_GROUP_HAS_POD | BS_GROUP_HAS_MINRES;
   for (uint32_t d = 0; d < count; ++d) {            // validate everything before touching anything

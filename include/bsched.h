@@ -576,7 +576,8 @@ int bs_reduce_external(bs_ctx* ctx, uint32_t on);
  * of it; pf_leader and the Filter result of a BS_POD_LAST_PERMITTED pod hang on that.  `local_index` = number of this rank's pods
  * that stand in front of the job's first reaching pod (the caller partitions the queue, so it has the queue:
  * batch-scheduler_amd/dist.py first_reach_thresholds is the host rule, the Go shim's partitioner does the same); 0xFFFFFFFF = none.
- * Valid for the loaded queue (every bs_pods_load / bs_pods_apply resets it); honoured by the steady-state chain, which is the chain
+ * Valid for the loaded queue AND group state (every bs_pods_load / bs_pods_apply / bs_groups_load / bs_groups_apply resets it: a deny entry or
+ * an OccupiedBy change moves the first reaching pod — set it again behind them); honoured by the steady-state chain, which is the chain
  * partitioned mode is exact on (no first-pod capture possible).  With it every output of a partitioned batch equals the single
  * context's (tests/test_gpu_multirank.py: plain equality). */
 int bs_first_reach_hint(bs_ctx* ctx, uint32_t local_index);
