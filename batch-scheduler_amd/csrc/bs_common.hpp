@@ -42,9 +42,15 @@ __device__ __forceinline__ void probe_stamp(int k, int s, uint32_t blk) {
     g_probe[k][blk][s] = t;
   }
 }
+// a COUNT in a stamp slot: shown by tools/stamp_probe.py as `v` microseconds behind the block's entry stamp (100 ticks = 1 us)
+__device__ __forceinline__ void probe_count(int k, int s, uint32_t blk, uint32_t v) {
+  if (threadIdx.x == 0 && blk < (uint32_t)kProbeBlocks) g_probe[k][blk][s] = g_probe[k][blk][0] + 100ull * v;
+}
 #define BS_STAMP(k, s) probe_stamp((k), (s), blockIdx.x)
+#define BS_COUNT(k, s, v) probe_count((k), (s), blockIdx.x, (v))
 #else
 #define BS_STAMP(k, s) ((void)0)
+#define BS_COUNT(k, s, v) ((void)0)
 #endif
 constexpr int kScanBlock = 1024;   // single-block sequential-chunk scans
 

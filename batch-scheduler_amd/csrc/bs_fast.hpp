@@ -1074,22 +1074,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) void k
 #endif
 // BS_TP_FILTER=5: the transposed item (bs_filter_t.hpp): lanes are request slots, nodes come through the scalar cache
 #if BS_EMIT_FAST
-__global__ __launch_bounds__(256) void k_fast_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t filter_waves, uint32_t ustride) {
-  filter_loop_t(nd, bt, filter_waves, ustride, prm.collect_stats, blockIdx.x, gridDim.x, prm.stamp, 2u * prm.k_host);
+__global__ __launch_bounds__(256) void k_fast_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t filter_waves, uint32_t ustride, uint32_t by_tile) {
+  filter_loop_t<false>(nd, bt, filter_waves, ustride, prm.collect_stats, blockIdx.x, gridDim.x, prm.stamp, 2u * prm.k_host, by_tile);   // (no look-ahead: 64 VGPRs, eight waves)
 }
 #endif
 // BS_TP_FILTER=6 / 7: both roles in ONE launch again (the scan's dependent-load chains and the Filter loop's compares overlap), the
 // Filter role taken by the transposed item; 7: the Filter blocks carry the LOW block indices (dispatched first)
 template <int S>
 __global__ __launch_bounds__(256) void k_fast_scan_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t scan_blocks,
-                                                            uint32_t filter_waves, uint32_t ustride, uint32_t filter_first) {
+                                                            uint32_t filter_waves, uint32_t ustride, uint32_t form) {
   __shared__ int64_t s_rows[4][64][4 + S];
+  const uint32_t filter_first = form & 1u, by_tile = form & 2u;      // (bit 0: BS_TP_FILTER=7; bit 1: the Filter items' order, filter_loop_t)
   const uint32_t filter_blocks = gridDim.x - scan_blocks;
   const bool is_scan = filter_first ? blockIdx.x >= filter_blocks : blockIdx.x < scan_blocks;
+  BS_STAMP(2, 0);                                   // (probe builds: the first 128 blocks = scan blocks, or Filter blocks with BS_TP_FILTER=7)
   if (is_scan)
     scan_loop<S, true, 1>(bt, prm, m, jcap, 0u, 0u, 1u, filter_first ? blockIdx.x - filter_blocks : blockIdx.x, scan_blocks, s_rows[wave_id()]);
   else
-    filter_loop_t(nd, bt, filter_waves, ustride, prm.collect_stats, filter_first ? blockIdx.x : blockIdx.x - scan_blocks, filter_blocks, prm.stamp, 2u * prm.k_host);
+    filter_loop_t<true>(nd, bt, filter_waves, ustride, prm.collect_stats, filter_first ? blockIdx.x : blockIdx.x - scan_blocks, filter_blocks, prm.stamp, 2u * prm.k_host, by_tile);
+  BS_STAMP(2, 7);
 }
 #if BS_EMIT_MAIN
 __global__ __launch_bounds__(256) void k_fast_final(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchParams prm, uint32_t query_blocks) {

@@ -8,11 +8,11 @@
 // its request R (4 x int64) in VGPRs, and the NODE is the wave-uniform operand — a node's `left` (getLeftResource, core.go:436-475)
 // comes through the scalar cache (one s_load_dwordx8 = four nodes of one resource lane; the waves of a node run read the same
 // few KB) and sits in SGPRs:
-//     s_mov_b64 exec, em ; k x v_cmpx_ge_i64 vcc, left[j] (SGPR), R[j] (VGPR) ; v_or_b32 word, bit, word ; s_lshl_b32 bit, bit, 1
-// EXEC behind the chain = the slots this node can hold (case 2, core.go:551-555), and the OR under that EXEC sets the node's bit
-// in exactly those lanes' words: (k + 1) VALU per node and 64 slots — filter_item: (k + 2) VALU + 4 wait states per slot and 64
-// nodes —, no LDS, no v_writelane, no transposition at the end (a lane already owns its slot's word), and a register footprint
-// that lets eight waves share a SIMD.
+//     k x v_cmp_ge_i64 mask, left[j] (SGPR), R[j] (VGPR)  [masks of the lanes ANDed on the scalar unit] ; v_addc_co_u32 word, word, word, mask
+// mask = the slots this node can hold (case 2, core.go:551-555); the add-with-carry shifts the lane's word and drops the lane's
+// mask bit into it: (k + 1) VALU per node and 64 slots — filter_item: (k + 2) VALU + 4 wait states per slot and 64
+// nodes —, no LDS, no v_writelane, no EXEC write, no transposition at the end (a lane already owns its slot's word), and a
+// register footprint that lets eight waves share a SIMD.
 // The pod-independent masks of a node block (in range, evaluable, case 3 for the tile's common leader: core.go:558-563) still
 // want lanes = NODES: one vector load of the block + ballots, as in filter_item; a tile whose slots name different leaders (it
 // straddles the two leader halves of the slot array) gets case 3 from a second pass of the same chain against the lane's own M.
@@ -27,46 +27,58 @@ namespace bs {
 
 typedef const __attribute__((address_space(4))) int64_t* cnode_t;
 
-// four consecutive nodes (a[u], bq[u], cq[u], d[u] = node u's left on resource lane 0..3) against the lanes' requests R;
-// em = lanes to evaluate; w = the word half the nodes belong to; sb = bit of the first node (shifted on the way)
+// four consecutive nodes (a[u], bq[u], cq[u], d[u] = node u's left on resource lane 0..3) against the lanes' requests R; w = the word
+// half the nodes belong to, shifted left by four with the nodes' verdicts in its low bits, FIRST node highest (the caller reverses a
+// finished half: v_bfrev_b32).
+// Per node: one v_cmp_ge_i64 per compared lane into an SGPR pair (the first straight into the node's mask, the others through VCC and
+// s_and_b64 on the scalar unit), then ONE v_addc_co_u32 w, w, w, mask — w = 2 w + (this lane's mask bit): the shift and the insertion
+// of the lane's verdict in one VALU instruction, no EXEC write anywhere.  Rounds 3-5 ran the compares as an EXEC chain
+// (s_mov exec · k x v_cmpx · v_or under that EXEC · s_lshl): the same k + 1 VALU instructions, but every one of them waits for the
+// EXEC the previous one wrote, and at the three waves per SIMD the one-launch form runs at (the scan role's 137 VGPRs) nothing hides
+// that chain — 21 cycles per node and SIMD against the 8-10 the sequence needs (tools/ubench/node_loop).  Here the four nodes of a
+// group are independent until their addc, and the masks are read three instructions after they were written (a VALU-written SGPR
+// read as a carry needs two wait states on gfx950; the compiler puts s_nop 1 there, this sequence needs none).
+// Lanes that are not to be evaluated get verdicts too; the callers drop them (c2pod / the (myff & 2) test).
 template <int MASK>
-__device__ __forceinline__ void filter_node4(unsigned long long em, const int64_t (&R)[4], const int64_t (&a)[4], const int64_t (&bq)[4],
-                                             const int64_t (&cq)[4], const int64_t (&d)[4], uint32_t& w, uint32_t& sb);
-#define BS_FN4_NODE(f0, f1, f2, f3, u)                                                                                   \
-  "s_mov_b64 exec, %[em]\n\t"                                                                                            \
-  BS_OPT(f0, "v_cmpx_ge_i64 vcc, %[a" #u "], %[R0]\n\t") BS_OPT(f1, "v_cmpx_ge_i64 vcc, %[b" #u "], %[R1]\n\t")            \
-  BS_OPT(f2, "v_cmpx_ge_i64 vcc, %[c" #u "], %[R2]\n\t") BS_OPT(f3, "v_cmpx_ge_i64 vcc, %[d" #u "], %[R3]\n\t")            \
-  "v_or_b32 %[w], %[sb], %[w]\n\t"                                                                                       \
-  "s_lshl_b32 %[sb], %[sb], 1\n\t"
-#define BS_DEF_FILTER_NODE4(MASK, f0, f1, f2, f3)                                                                        \
+__device__ __forceinline__ void filter_node4(const int64_t (&R)[4], const int64_t (&a)[4], const int64_t (&bq)[4], const int64_t (&cq)[4],
+                                             const int64_t (&d)[4], uint32_t& w);
+#define BS_FN4_NODE(g0, g1, g2, g3, h0, h1, h2, h3, u)                                                                   \
+  BS_OPT(g0, "v_cmp_ge_i64_e64 %[m" #u "], %[a" #u "], %[R0]\n\t") BS_OPT(g1, "v_cmp_ge_i64_e64 %[m" #u "], %[b" #u "], %[R1]\n\t") \
+  BS_OPT(g2, "v_cmp_ge_i64_e64 %[m" #u "], %[c" #u "], %[R2]\n\t") BS_OPT(g3, "v_cmp_ge_i64_e64 %[m" #u "], %[d" #u "], %[R3]\n\t") \
+  BS_OPT(h1, "v_cmp_ge_i64_e32 vcc, %[b" #u "], %[R1]\n\ts_and_b64 %[m" #u "], %[m" #u "], vcc\n\t")                      \
+  BS_OPT(h2, "v_cmp_ge_i64_e32 vcc, %[c" #u "], %[R2]\n\ts_and_b64 %[m" #u "], %[m" #u "], vcc\n\t")                      \
+  BS_OPT(h3, "v_cmp_ge_i64_e32 vcc, %[d" #u "], %[R3]\n\ts_and_b64 %[m" #u "], %[m" #u "], vcc\n\t")
+#define BS_FN4_ADDC(u) "v_addc_co_u32_e64 %[w], %[m" #u "], %[w], %[w], %[m" #u "]\n\t"
+#define BS_DEF_FILTER_NODE4(MASK, g0, g1, g2, g3, h0, h1, h2, h3)                                                        \
   template <>                                                                                                            \
-  __device__ __forceinline__ void filter_node4<MASK>(unsigned long long em, const int64_t (&R)[4], const int64_t (&a)[4], \
-                                                     const int64_t (&bq)[4], const int64_t (&cq)[4], const int64_t (&d)[4], \
-                                                     uint32_t& w, uint32_t& sb) {                                         \
-    asm volatile(BS_FN4_NODE(f0, f1, f2, f3, 0) BS_FN4_NODE(f0, f1, f2, f3, 1) BS_FN4_NODE(f0, f1, f2, f3, 2)              \
-                 BS_FN4_NODE(f0, f1, f2, f3, 3) "s_mov_b64 exec, -1"                                                     \
-                 : [w] "+v"(w), [sb] "+s"(sb)                                                                            \
-                 : [em] "s"(em), [R0] "v"(R[0]), [R1] "v"(R[1]), [R2] "v"(R[2]), [R3] "v"(R[3]), [a0] "s"(a[0]),         \
+  __device__ __forceinline__ void filter_node4<MASK>(const int64_t (&R)[4], const int64_t (&a)[4], const int64_t (&bq)[4], \
+                                                     const int64_t (&cq)[4], const int64_t (&d)[4], uint32_t& w) {         \
+    unsigned long long m0, m1, m2, m3;                                                                                   \
+    asm volatile(BS_FN4_NODE(g0, g1, g2, g3, h0, h1, h2, h3, 0) BS_FN4_NODE(g0, g1, g2, g3, h0, h1, h2, h3, 1)             \
+                 BS_FN4_NODE(g0, g1, g2, g3, h0, h1, h2, h3, 2) BS_FN4_NODE(g0, g1, g2, g3, h0, h1, h2, h3, 3)             \
+                 BS_FN4_ADDC(0) BS_FN4_ADDC(1) BS_FN4_ADDC(2) BS_FN4_ADDC(3)                                             \
+                 : [w] "+v"(w), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)                           \
+                 : [R0] "v"(R[0]), [R1] "v"(R[1]), [R2] "v"(R[2]), [R3] "v"(R[3]), [a0] "s"(a[0]),                       \
                    [a1] "s"(a[1]), [a2] "s"(a[2]), [a3] "s"(a[3]), [b0] "s"(bq[0]), [b1] "s"(bq[1]), [b2] "s"(bq[2]),    \
                    [b3] "s"(bq[3]), [c0] "s"(cq[0]), [c1] "s"(cq[1]), [c2] "s"(cq[2]), [c3] "s"(cq[3]), [d0] "s"(d[0]),  \
                    [d1] "s"(d[1]), [d2] "s"(d[2]), [d3] "s"(d[3])                                                        \
                  : "vcc", "scc");                                                                                        \
   }
-BS_DEF_FILTER_NODE4(1, 1, 0, 0, 0)
-BS_DEF_FILTER_NODE4(2, 0, 1, 0, 0)
-BS_DEF_FILTER_NODE4(3, 1, 1, 0, 0)
-BS_DEF_FILTER_NODE4(4, 0, 0, 1, 0)
-BS_DEF_FILTER_NODE4(5, 1, 0, 1, 0)
-BS_DEF_FILTER_NODE4(6, 0, 1, 1, 0)
-BS_DEF_FILTER_NODE4(7, 1, 1, 1, 0)
-BS_DEF_FILTER_NODE4(8, 0, 0, 0, 1)
-BS_DEF_FILTER_NODE4(9, 1, 0, 0, 1)
-BS_DEF_FILTER_NODE4(10, 0, 1, 0, 1)
-BS_DEF_FILTER_NODE4(11, 1, 1, 0, 1)
-BS_DEF_FILTER_NODE4(12, 0, 0, 1, 1)
-BS_DEF_FILTER_NODE4(13, 1, 0, 1, 1)
-BS_DEF_FILTER_NODE4(14, 0, 1, 1, 1)
-BS_DEF_FILTER_NODE4(15, 1, 1, 1, 1)
+BS_DEF_FILTER_NODE4(1, 1, 0, 0, 0, 0, 0, 0, 0)
+BS_DEF_FILTER_NODE4(2, 0, 1, 0, 0, 0, 0, 0, 0)
+BS_DEF_FILTER_NODE4(3, 1, 0, 0, 0, 0, 1, 0, 0)
+BS_DEF_FILTER_NODE4(4, 0, 0, 1, 0, 0, 0, 0, 0)
+BS_DEF_FILTER_NODE4(5, 1, 0, 0, 0, 0, 0, 1, 0)
+BS_DEF_FILTER_NODE4(6, 0, 1, 0, 0, 0, 0, 1, 0)
+BS_DEF_FILTER_NODE4(7, 1, 0, 0, 0, 0, 1, 1, 0)
+BS_DEF_FILTER_NODE4(8, 0, 0, 0, 1, 0, 0, 0, 0)
+BS_DEF_FILTER_NODE4(9, 1, 0, 0, 0, 0, 0, 0, 1)
+BS_DEF_FILTER_NODE4(10, 0, 1, 0, 0, 0, 0, 0, 1)
+BS_DEF_FILTER_NODE4(11, 1, 0, 0, 0, 0, 1, 0, 1)
+BS_DEF_FILTER_NODE4(12, 0, 0, 1, 0, 0, 0, 0, 1)
+BS_DEF_FILTER_NODE4(13, 1, 0, 0, 0, 0, 0, 1, 1)
+BS_DEF_FILTER_NODE4(14, 0, 1, 0, 0, 0, 0, 1, 1)
+BS_DEF_FILTER_NODE4(15, 1, 0, 0, 0, 0, 1, 1, 1)
 
 // one 64-node block (first node n0, a multiple of 64) against the lanes in `em`: per lane the 64 bits "left >= R on every
 // compared resource lane".  Bits of lanes outside `em` stay 0.
@@ -80,8 +92,7 @@ __device__ __forceinline__ void filter_sgprs_ready4(const int64_t& a, const int6
   asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d));
 }
 template <int MASK>
-__device__ __forceinline__ void filter_block_t(cnode_t L4, uint32_t stride, uint32_t n0, unsigned long long em, const int64_t (&R)[4],
-                                               uint32_t (&wd)[2]) {
+__device__ __forceinline__ void filter_block_t(cnode_t L4, uint32_t stride, uint32_t n0, const int64_t (&R)[4], uint32_t (&wd)[2]) {
   constexpr int K = ((MASK >> 0) & 1) + ((MASK >> 1) & 1) + ((MASK >> 2) & 1) + ((MASK >> 3) & 1);
 #ifdef BS_FT_BIG_GROUPS
   constexpr int GN = K == 1 ? 16 : (K == 2 ? 8 : 4);                 // nodes per group
@@ -100,7 +111,7 @@ __device__ __forceinline__ void filter_block_t(cnode_t L4, uint32_t stride, uint
   };
   int64_t cur[4][GN], nxt[4][GN];
   load(n0, cur);
-  uint32_t w = 0, sb = 1u;
+  uint32_t w = 0;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -111,13 +122,13 @@ __device__ __forceinline__ void filter_block_t(cnode_t L4, uint32_t stride, uint
     if (g + 1 < NG) load(n0 + (uint32_t)(g + 1) * GN, nxt);
 #pragma unroll
     for (int c = 0; c < GN; c += 4) {
-      if (g * GN + c == 32) { wd[0] = w; w = 0; sb = 1u; }
+      if (g * GN + c == 32) { wd[0] = __builtin_bitreverse32(w); w = 0; }
       int64_t t[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int u = 0; u < 4; ++u) t[j][u] = cur[((MASK >> j) & 1) ? j : J0][c + u];
-      filter_node4<MASK>(em, R, t[0], t[1], t[2], t[3], w, sb);
+      filter_node4<MASK>(R, t[0], t[1], t[2], t[3], w);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -125,39 +136,48 @@ __device__ __forceinline__ void filter_block_t(cnode_t L4, uint32_t stride, uint
       for (int u = 0; u < GN; ++u)
         if ((MASK >> j) & 1) cur[j][u] = nxt[j][u];
   }
-  wd[1] = w;
+  wd[1] = __builtin_bitreverse32(w);
 }
-__device__ __forceinline__ void filter_block_any(uint32_t lane_mask, cnode_t L4, uint32_t stride, uint32_t n0, unsigned long long em,
-                                                 const int64_t (&R)[4], uint32_t (&wd)[2]) {
+__device__ __forceinline__ void filter_block_any(uint32_t lane_mask, cnode_t L4, uint32_t stride, uint32_t n0, const int64_t (&R)[4],
+                                                 uint32_t (&wd)[2]) {
   switch (lane_mask) {
-    case 1: filter_block_t<1>(L4, stride, n0, em, R, wd); break;
-    case 2: filter_block_t<2>(L4, stride, n0, em, R, wd); break;
-    case 3: filter_block_t<3>(L4, stride, n0, em, R, wd); break;
-    case 4: filter_block_t<4>(L4, stride, n0, em, R, wd); break;
-    case 5: filter_block_t<5>(L4, stride, n0, em, R, wd); break;
-    case 6: filter_block_t<6>(L4, stride, n0, em, R, wd); break;
-    case 7: filter_block_t<7>(L4, stride, n0, em, R, wd); break;
-    case 8: filter_block_t<8>(L4, stride, n0, em, R, wd); break;
-    case 9: filter_block_t<9>(L4, stride, n0, em, R, wd); break;
-    case 10: filter_block_t<10>(L4, stride, n0, em, R, wd); break;
-    case 11: filter_block_t<11>(L4, stride, n0, em, R, wd); break;
-    case 12: filter_block_t<12>(L4, stride, n0, em, R, wd); break;
-    case 13: filter_block_t<13>(L4, stride, n0, em, R, wd); break;
-    case 14: filter_block_t<14>(L4, stride, n0, em, R, wd); break;
-    default: filter_block_t<15>(L4, stride, n0, em, R, wd); break;
+    case 1: filter_block_t<1>(L4, stride, n0, R, wd); break;
+    case 2: filter_block_t<2>(L4, stride, n0, R, wd); break;
+    case 3: filter_block_t<3>(L4, stride, n0, R, wd); break;
+    case 4: filter_block_t<4>(L4, stride, n0, R, wd); break;
+    case 5: filter_block_t<5>(L4, stride, n0, R, wd); break;
+    case 6: filter_block_t<6>(L4, stride, n0, R, wd); break;
+    case 7: filter_block_t<7>(L4, stride, n0, R, wd); break;
+    case 8: filter_block_t<8>(L4, stride, n0, R, wd); break;
+    case 9: filter_block_t<9>(L4, stride, n0, R, wd); break;
+    case 10: filter_block_t<10>(L4, stride, n0, R, wd); break;
+    case 11: filter_block_t<11>(L4, stride, n0, R, wd); break;
+    case 12: filter_block_t<12>(L4, stride, n0, R, wd); break;
+    case 13: filter_block_t<13>(L4, stride, n0, R, wd); break;
+    case 14: filter_block_t<14>(L4, stride, n0, R, wd); break;
+    default: filter_block_t<15>(L4, stride, n0, R, wd); break;
   }
 }
 
 // One item = (tile of 64 request slots, node blocks [w0, w1)); same contract and same outputs as filter_item.
+// ff = the lane's slot flags word (b.uflags[p0 + lane], fetched by filter_loop_t one item ahead): a tile without a slot in use — the
+// carried-leader half of the slot array in most batches, 7 tiles of 8 on a rank of 8 (class ids follow the queue, k_pod_class_ids) —
+// returns before it has issued another load (as written up to round 4 it had asked for its 4 KB of requests and 2.5 KB of nodes by
+// then: 118 895 items, 772 MB of dead fetches, when a rank of 8 cut its items as fine as its share of live tiles called for).
 __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ustride, uint32_t ptile, uint32_t w0,
-                                              uint32_t w1, uint32_t stamp) {
+                                              uint32_t w1, uint32_t stamp, uint32_t ff) {
   const int lane = lane_id();
   const uint32_t p0 = ptile * 64u;
   const uint32_t np = min(64u, U - p0);
   const bool mine = (uint32_t)lane < np;
   const uint32_t src = p0 + (uint32_t)lane;
-  // one round trip: the slot's flags word, its request R and leader request M, the cluster-wide bounds, the first node block
-  uint32_t myff = mine ? b.uflags[src] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  uint32_t myff = mine ? ff : ((uint32_t)BS_FL_NOT_RUN << 8);
+  if (stamp) myff = (myff >> 16) == stamp ? (myff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
+  const uint32_t myfl = myff >> 8;
+  const bool ev = myfl == BS_FL_EVALUATED;
+  const unsigned long long evmask = __ballot(ev);
+  if (!evmask) return;                              // no slot of this tile is in use
+  // one round trip: the slots' requests R and leader requests M, the cluster-wide bounds, the first node block
   int64_t M[4] = {0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
   if (mine) {
     const int64_t* rs = b.uparams + (size_t)src * 8;
@@ -181,15 +201,10 @@ __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev
     }
   };
   load_block(w0, l, nfl);
-  if (stamp) myff = (myff >> 16) == stamp ? (myff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
-  const uint32_t myfl = myff >> 8;
-  const bool ev = myfl == BS_FL_EVALUATED;
   if (!ev) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) M[j] = 0;
   }
-  const unsigned long long evmask = __ballot(ev);
-  if (!evmask) return;                              // no slot of this tile is in use
   // which resource lanes can decide anything for this tile (nd.lglob: cluster-wide min[4] / max[4] of left over the nodes Filter
   // can evaluate): a lane is free when even the smallest left covers every request of the tile; the tile fails everywhere when
   // the largest left of some lane is below every request
@@ -227,7 +242,7 @@ __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev
     uint32_t c2w[2] = {0u, 0u};
     if (c2mask && !tile_allfail) {
       if (lane_mask == 0u) { c2w[0] = (uint32_t)okmask; c2w[1] = (uint32_t)(okmask >> 32); }     // every lane is free
-      else filter_block_any(lane_mask, L4, nd.stride, w * 64u, c2mask, R, c2w);
+      else filter_block_any(lane_mask, L4, nd.stride, w * 64u, R, c2w);
     }
     unsigned long long c2 = (((unsigned long long)c2w[1] << 32) | c2w[0]) & okmask;
     if (!c2pod) c2 = 0;
@@ -238,7 +253,7 @@ __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev
       if (!lb0) lf = __ballot(l[0] >= M0[0]) & __ballot(l[1] >= M0[1]) & __ballot(l[2] >= M0[2]) & __ballot(l[3] >= M0[3]);
     } else {
       uint32_t lfw[2] = {0u, 0u};
-      if (lfmask) filter_block_t<15>(L4, nd.stride, w * 64u, lfmask, M, lfw);
+      if (lfmask) filter_block_t<15>(L4, nd.stride, w * 64u, M, lfw);
       lf = ((unsigned long long)lfw[1] << 32) | lfw[0];
       if (myff & 2u) lf = 0;
     }
@@ -257,9 +272,18 @@ __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev
   if (mine && cnt) atomicAdd(&b.fu_feas[p0 + lane], cnt);
 }
 
-// filter_loop's split of the work (tiles x node runs), items taken by filter_item_t
+// filter_loop's split of the work (tiles x node runs), items taken by filter_item_t.  AHEAD: the flags of the wave's next item are
+// fetched while the current one runs (one VGPR held across the item).
+// Item order.  by_tile == 0: chunk-major (item = chunk * tiles + tile) — with at most one item per wave the order only decides who
+// shares a node run.  by_tile != 0 (a rank of a sharded job: more items than waves, most of them idle): quads of four neighbouring
+// tiles, chunk by chunk (item = ((tile / 4) * nchunk + chunk) * 4 + tile % 4: the four waves of a block still share their node run).
+// A rank's live tiles are neighbours (class ids follow the queue), so its live items are CONSECUTIVE and the waves' strided walk deals
+// them out evenly; chunk-major, a wave's items fall on tiles (w + k * waves) mod tiles, live by chance — rank 0 of 8 on cfg4, 60 200
+// items on 16 384 waves: 7 % of the waves drew two live items, 0.7 % three, and the launch lasted as long as those (48 us of 16 us
+// items; tools/stamp_probe.py, profiles/r05_shard_scaling.md).
+template <bool AHEAD>
 __device__ __forceinline__ void filter_loop_t(const NodesDev& nd, const BatchDev& b, uint32_t target_waves, uint32_t ustride, uint32_t collect_stats,
-                                              uint32_t bx, uint32_t nblocks, uint32_t stamp, uint32_t slots) {
+                                              uint32_t bx, uint32_t nblocks, uint32_t stamp, uint32_t slots, uint32_t by_tile) {
   const uint32_t U = slots ? slots : 2u * __builtin_amdgcn_readfirstlane(*b.kclass);
   const uint32_t W = (nd.n + 63u) / 64u;
   if (!U || !W) return;
@@ -268,16 +292,39 @@ __device__ __forceinline__ void filter_loop_t(const NodesDev& nd, const BatchDev
   nsplit = min(nsplit, max((W + 1u) / 2u, 1u));
   const uint32_t bpw = max(2u, (((W + nsplit - 1u) / nsplit + 1u) / 2u) * 2u);
   const uint32_t nchunk = (W + bpw - 1u) / bpw;
-  const uint32_t items = tiles * nchunk;
-  for (uint32_t it = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()); it < items; it += nblocks * 4u) {
-    const uint32_t chunk = it / tiles, tile = it - chunk * tiles;                   // neighbours share the node run
+  const uint32_t items = by_tile ? ((tiles + 3u) / 4u) * nchunk * 4u : tiles * nchunk;
+  auto decode = [&](uint32_t it, uint32_t& tile, uint32_t& chunk) {
+    if (by_tile) {
+      const uint32_t q = it / (nchunk * 4u), rem = it - q * (nchunk * 4u);
+      chunk = rem >> 2;
+      tile = q * 4u + (rem & 3u);                                                   // (may lie behind the last tile: no slots, idle)
+    } else {
+      chunk = it / tiles;
+      tile = it - chunk * tiles;                                                    // neighbours share the node run
+    }
+  };
+  auto slot_flags = [&](uint32_t it) -> uint32_t {                                  // the item's tile: its lanes' flags words
+    uint32_t tile, chunk;
+    decode(it, tile, chunk);
+    const uint32_t sl = tile * 64u + (uint32_t)lane_id();
+    return (it < items && sl < U) ? b.uflags[sl] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  };
+  uint32_t it = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id());
+  uint32_t ff = AHEAD ? slot_flags(it) : 0u;
+  while (it < items) {
+    if (!AHEAD) ff = slot_flags(it);
+    const uint32_t nx = it + nblocks * 4u;
+    uint32_t ffn = 0;
+    if (AHEAD) ffn = slot_flags(nx);                                                // (in flight while this item runs)
+    uint32_t tile, chunk;
+    decode(it, tile, chunk);
     if (collect_stats && chunk == 0) {
-      const uint32_t sl = tile * 64u + (uint32_t)lane_id();
-      const uint32_t uf = sl < U ? b.uflags[sl] : 0u;
-      const unsigned long long evs = __ballot(sl < U && ((uf >> 8) & 0xFFu) == BS_FL_EVALUATED && (!stamp || (uf >> 16) == stamp));
+      const unsigned long long evs = __ballot(((ff >> 8) & 0xFFu) == BS_FL_EVALUATED && (!stamp || (ff >> 16) == stamp));
       if (lane_id() == 0 && evs) atomicAdd((unsigned long long*)&b.stats[3], (unsigned long long)__popcll(evs));
     }
-    filter_item_t(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), stamp);
+    if (tile < tiles) filter_item_t(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), stamp, ff);
+    it = nx;
+    ff = ffn;
   }
 }
 

@@ -332,25 +332,47 @@ __device__ __forceinline__ uint64_t bcast64(uint64_t v, int l) {
 }
 
 // Request classes of the loaded pods (bs_pods_load): equal (request lanes, present bits) <=> equal class.
-// k_pod_class_a: every pod looks its request up in the hash table; the first of a kind becomes the
-// representative and draws the class id.  k_pod_class_b: every pod takes its representative's id.
+// k_pod_class_a: every pod looks its request up in the hash table; the first of a kind becomes the representative (rep[i] == i);
+// each block leaves its count of representatives.  k_pod_class_ids: a representative's class id = its rank among the
+// representatives in QUEUE order (block counts + in-block scan), so class ids grow with the queue position of the class: the
+// pods of a contiguous piece of the queue — a rank's share under bs_shard_set, a gang — fall into neighbouring class slots, and
+// the tiles of 64 slots the throughput regime's Filter items and scan items work on are either a rank's or empty (ids drawn in
+// arrival order — one atomicAdd per class, rounds 1-4 — spread every rank's classes over all tiles: a rank's step cost as much
+// as the whole job's).  Classes drawn later by the resident queue (bs_queue.hpp) follow behind in arrival order, as before.
+// k_pod_class_b: every pod takes its representative's id.
 #if BS_EMIT_MAIN
-__global__ void k_pod_class_a(PodsDev pods, unsigned long long* slots, uint32_t mask, uint32_t hash_keep, uint32_t L, uint32_t* rep,
-                              uint32_t* id, uint32_t* kcount) {
+__global__ __launch_bounds__(256) void k_pod_class_a(PodsDev pods, unsigned long long* slots, uint32_t mask, uint32_t hash_keep, uint32_t L, uint32_t* rep,
+                                                     uint32_t* blk_count) {
+  __shared__ uint32_t lds[16];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= pods.p) return;
-  const uint32_t pres = pods.pres[i];
-  uint64_t h = mix64((uint64_t)pres + 0x9e3779b97f4a7c15ull);
-  for (uint32_t j = 0; j < L; ++j) h = mix64(h ^ (uint64_t)pods.req[(size_t)j * pods.p + i]);
-  bool winner;
-  const uint32_t r = dedupe_insert(slots, mask, hash_keep, h, i, [&](uint32_t o) {
-    if (o >= pods.p || pods.pres[o] != pres) return false;
-    for (uint32_t j = 0; j < L; ++j)
-      if (pods.req[(size_t)j * pods.p + o] != pods.req[(size_t)j * pods.p + i]) return false;
-    return true;
-  }, winner);
-  rep[i] = r;
-  if (winner) id[i] = atomicAdd(kcount, 1u);
+  bool winner = false;
+  if (i < pods.p) {
+    const uint32_t pres = pods.pres[i];
+    uint64_t h = mix64((uint64_t)pres + 0x9e3779b97f4a7c15ull);
+    for (uint32_t j = 0; j < L; ++j) h = mix64(h ^ (uint64_t)pods.req[(size_t)j * pods.p + i]);
+    rep[i] = dedupe_insert(slots, mask, hash_keep, h, i, [&](uint32_t o) {
+      if (o >= pods.p || pods.pres[o] != pres) return false;
+      for (uint32_t j = 0; j < L; ++j)
+        if (pods.req[(size_t)j * pods.p + o] != pods.req[(size_t)j * pods.p + i]) return false;
+      return true;
+    }, winner);
+  }
+  uint32_t total;
+  (void)block_incl_scan_add<uint32_t>(winner ? 1u : 0u, lds, total);
+  if (threadIdx.x == 0) blk_count[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void k_pod_class_ids(uint32_t p, const uint32_t* rep, const uint32_t* blk_count, uint32_t* id, uint32_t* kcount) {
+  __shared__ uint32_t lds[16];
+  uint32_t part = 0;
+  for (uint32_t j = threadIdx.x; j < blockIdx.x; j += blockDim.x) part += blk_count[j];
+  uint32_t prev;
+  (void)block_incl_scan_add<uint32_t>(part, lds, prev);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool is_rep = i < p && rep[i] == i;
+  uint32_t total;
+  const uint32_t incl = block_incl_scan_add<uint32_t>(is_rep ? 1u : 0u, lds, total);
+  if (is_rep) id[i] = prev + incl - 1u;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *kcount = prev + total;
 }
 #endif
 #if BS_EMIT_MAIN
@@ -1264,6 +1286,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
   const int64_t* T = b.tables + (size_t)slot * prm.mcap * LP;
   uint32_t rows_done = 0;
   uint32_t turn = 0;                             // rank of the next live group modulo J
+  [[maybe_unused]] uint32_t probe_groups = 0;    // (probe builds: groups this item fetched)
   // chunk-local tables: exclusive prefix of the chunk totals, window by window (forward only)
   const uint32_t nchunks = (m + kTblChunk - 1u) / kTblChunk, cstride = (prm.mcap + kTblChunk - 1u) / kTblChunk;
   unsigned long long offl[L], carry[L];
@@ -1353,6 +1376,8 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
       turn = turn + 1u == J ? 0u : turn + 1u;
       if (!mine) continue;
       // ---- this group is ours: rows [g0, gend)
+      if (!loaded) BS_STAMP(2, 5);
+      ++probe_groups;
       const uint32_t g0 = (c0 + bit) << 6;
       const uint32_t gend = min(m, g0 + 64u);
       int64_t mine_row[L];
@@ -1436,6 +1461,7 @@ __device__ __forceinline__ void scan_core(const BatchDev& b, const BatchParams& 
     }
   }
   BS_STAMP(2, 4);
+  BS_COUNT(2, 6, probe_groups);
   if (!loaded) return;
   if (myk[0] != BS_INF) atomicMin(&b.first_row[pos], myk[0]);
   if (prm.collect_stats && lane == 0) {
@@ -1497,9 +1523,23 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
   // wave: loads, then wave scans that wait for them): one round trip for both, not two in a row
   SlotLoad first;
   LocalPre<S> pre = {};
+  uint32_t w_live = w_first;                        // MODE 1: the first item of this wave that has work
   if constexpr (LOCAL) {
     if constexpr (uni && !split) {
-      if (w_first < items) { load_slots(w_first, first); local_pre_load<S>(b, prm, m, 0u, pre); }
+      // (throughput regime) the wave's first item with a slot in use: two words per lane are looked at before anything else is asked
+      // for.  A wave whose items are all idle — the tiles of other ranks' request classes under bs_shard_set: class ids follow the
+      // queue (k_pod_class_ids), so 7 tiles of 8 are idle on a rank of 8 — leaves without the first fetch (~60 KB), and a rank can
+      // cut its live tiles into as many shares as its part of the job allows (run_fast: share_b).
+      while (w_live < items) {
+        const uint32_t rest = w_live / ntl, tile = t_lo + (w_live - rest * ntl);
+        const uint32_t ps = tile * 64u + (uint32_t)lane;
+        const bool live = ps < nslots && b.qtab_s[ps] >= 0 && (!prm.stamp || b.qstamp_s[ps] == prm.stamp);
+        if (__ballot(live)) break;
+        w_live += nblocks * wpb;
+      }
+      if (w_live >= items) return;
+      load_slots(w_live, first);
+      local_pre_load<S>(b, prm, m, 0u, pre);
     } else if constexpr (split) {
       // The four waves of the block work on ONE item and need the SAME first fetch (the tile's slots, the table's chunk
       // totals / key rows, the maxima of its first 128 groups): 64 lanes x 64-byte strides, ~900 cache lines per wave — four
@@ -1546,12 +1586,12 @@ __device__ __forceinline__ void scan_loop(const BatchDev& b, const BatchParams& 
   } else if (w_first < items) {
     load_slots(w_first, first);
   }
-  for (uint32_t w = w_first; w < items; w += nblocks * wpb) {
+  for (uint32_t w = w_live; w < items; w += nblocks * wpb) {
     const uint32_t rest = w / ntl, tile = t_lo + (w - rest * ntl);
     const uint32_t share = rest / tsplit, ts = rest - share * tsplit;
     const uint32_t pos = tile * 64u + (uint32_t)lane;
     SlotLoad cur;
-    if (w == w_first) cur = first; else load_slots(w, cur);
+    if (w == w_live) cur = first; else load_slots(w, cur);
     int32_t tab = cur.tab;
     const uint32_t stp = cur.stp;
     int64_t r[1][L];

@@ -14,6 +14,7 @@ struct FastLaunch {
   hipStream_t stream;
   uint32_t S, M, P, filter_waves, filter_slots_cap, tp_filter;
   int device;
+  uint32_t filter_split = 0;   // waves the transposed Filter items are CUT for (0 = filter_waves, the grid): a rank of a sharded job cuts finer, see run_fast
 };
 void launch_fast_bc(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                     const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks, uint32_t filter_blocks);

@@ -252,6 +252,12 @@ struct bs_ctx {
   uint32_t tp_fwaves = 0;            // BS_TP_FWAVES: waves the Filter work of that regime is cut for; 0 = 16384 from 65 536 (tile, two node
                                      // blocks) units on, filter_waves below; an explicit BS_FILTER_WAVES rules
   bool filter_waves_env = false;
+  uint32_t tp_split = 0;             // BS_TP_SPLIT: the transposed Filter items are cut for tp_split x the launched waves and dealt out tile quad by
+                                     // tile quad (filter_loop_t, by_tile); 0 = 2 on a rank of a sharded context (bs_shard_set), 1 otherwise.
+                                     // Class ids follow the queue (k_pod_class_ids), so all but 1 / nranks of the slot tiles are idle on a rank and
+                                     // return at their first load; the live ones are cut finer so that they spread over more of the launched
+                                     // waves.  cfg4 all-distinct, rank 0 of 8 (profiles/r05_shard_scaling.md): 60 us at x2, 63 at x4, 74 at x8
+                                     // (an item's prologue — requests, bounds, first node block — is ~4 us whatever its length).
   int fused_blocks_resident = -1;    // whole-chip residency of k_fast_scan_filter_final (blocks), -1 = not asked yet
   int step_a_resident = -1;          // ... of k_fast_step_a
   bool step_a_on = false;            // BS_STEP_A=1: take the one-launch form of launch A + scan / Filter roles where it applies (measured SLOWER
@@ -686,7 +692,10 @@ void launch_tables_nofix(bs_ctx* c, dim3 grid, const NodesDev& nd, const BatchDe
 }
 
 static FastLaunch fast_launch(const bs_ctx* c) {
-  return FastLaunch{c->stream, c->S, c->M, c->P, c->filter_waves, c->filter_slots_cap, c->tp_filter, c->cfg.device};
+  FastLaunch f{c->stream, c->S, c->M, c->P, c->filter_waves, c->filter_slots_cap, c->tp_filter, c->cfg.device};
+  const uint32_t mul = c->tp_split ? c->tp_split : ((!c->reduce_external && c->nranks > 1u) ? 2u : 1u);
+  if (mul > 1u) f.filter_split = (uint32_t)std::min<uint64_t>((uint64_t)c->filter_waves * mul, 1u << 22);
+  return f;
 }
 static int fused_residency(bs_ctx* c) {
   if (c->fused_blocks_resident < 0) c->fused_blocks_resident = fused_residency_query(fast_launch(c));
@@ -845,7 +854,9 @@ int derive_pods(bs_ctx* c, bool pairs_only) {
     } else {
       hipLaunchKernelGGL(k_pods_prep, dim3(64), dim3(256), 0, c->stream, ctab, 2 * c->cls_cap, c->d_gstat.as<uint32_t>(), ngstat, kcount, gcount, gcn);
       hipLaunchKernelGGL(k_pod_class_a, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pods_dev(c), ctab, c->cls_cap - 1, c->hash_keep, L,
-                         c->d_cls_rep.as<uint32_t>(), c->d_cls_id.as<uint32_t>(), kcount);
+                         c->d_cls_rep.as<uint32_t>(), c->d_blk_scratch.as<uint32_t>());
+      hipLaunchKernelGGL(k_pod_class_ids, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, P, c->d_cls_rep.as<uint32_t>(), c->d_blk_scratch.as<uint32_t>(),
+                         c->d_cls_id.as<uint32_t>(), kcount);
     }
     LAUNCHCHK(c, BS_KERNEL_PREPASS);
   } else {
@@ -1076,6 +1087,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_STEP_SHARES")) c->step_shares = (uint32_t)std::min(32, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_SHARE")) c->tp_share = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_FWAVES")) c->tp_fwaves = (uint32_t)std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BS_TP_SPLIT")) c->tp_split = (uint32_t)std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_NO_SPECULATE")) c->no_spec = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HOST_PROBE")) c->host_probe = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_SLOT_BITS")) { const int hb = std::atoi(e); c->slot_keep = hb >= 32 ? 0xFFFFFFFFu : ((1u << std::max(0, hb)) - 1u); }

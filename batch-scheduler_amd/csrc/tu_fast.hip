@@ -67,8 +67,8 @@ void launch_fast_scan(const FastLaunch& c, dim3 grid, const BatchDev& bt, const 
 }
 template <int S>
 void launch_fast_bt_s(const FastLaunch& c, dim3 grid, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter_t<S>), grid, dim3(256), 0, c.stream, nd, bt, prm, c.M, nseg, scan_blocks, c.filter_waves,
-                     c.filter_slots_cap, c.tp_filter == 7u ? 1u : 0u);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_scan_filter_t<S>), grid, dim3(256), 0, c.stream, nd, bt, prm, c.M, nseg, scan_blocks, c.filter_split ? c.filter_split : c.filter_waves,
+                     c.filter_slots_cap, (c.tp_filter == 7u ? 1u : 0u) | (c.filter_split ? 2u : 0u));
 }
 void launch_fast_bt(const FastLaunch& c, dim3 grid, const NodesDev& nd, const BatchDev& bt, const BatchParams& prm, uint32_t nseg, uint32_t scan_blocks) {
   // S <= 4 only (run_fast sends wider contexts through k_fast_scan + k_fast_filter_t): beyond that the two roles in one kernel run out
@@ -87,7 +87,7 @@ void launch_fast_filter(const FastLaunch& c, dim3 grid, const PodsDev& pd, const
     case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_filter<2, true>), grid, dim3(256), 0, c.stream, pd, nd, bt, prm, c.filter_waves, c.filter_slots_cap); break;
     case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_filter<2, false>), grid, dim3(256), 0, c.stream, pd, nd, bt, prm, c.filter_waves, c.filter_slots_cap); break;
     case 4: hipLaunchKernelGGL(k_fast_filter_w7, grid, dim3(256), 0, c.stream, pd, nd, bt, prm, c.filter_waves, c.filter_slots_cap); break;
-    default: hipLaunchKernelGGL(k_fast_filter_t, grid, dim3(256), 0, c.stream, nd, bt, prm, c.filter_waves, c.filter_slots_cap); break;
+    default: hipLaunchKernelGGL(k_fast_filter_t, grid, dim3(256), 0, c.stream, nd, bt, prm, c.filter_split ? c.filter_split : c.filter_waves, c.filter_slots_cap, c.filter_split ? 1u : 0u); break;
   }
 }
 // How many blocks of the fused launch the chip holds at once (occupancy API, minus one block per CU: the API can be one high,

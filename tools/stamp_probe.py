@@ -38,12 +38,21 @@ def main():
     lib.bs_probe_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     stages = soa.STAGE_ALL if os.environ.get("PROBE_FILTER", "1") == "1" else (soa.STAGE_PREFILTER | soa.STAGE_TALLY)
     nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
+    if os.environ.get("PROBE_DISTINCT") == "1":             # every pod its own request: the throughput regime (k_fast_scan_filter_t)
+        pods = pods.copy()
+        pods.req[0, :] += np.arange(pods.p, dtype=np.int64)
+    if os.environ.get("PROBE_SHARD"):                       # "r/n": rank r of n on this one context
+        shard = [int(x) for x in os.environ["PROBE_SHARD"].split("/")]
+    else:
+        shard = None
     buf = np.zeros((8, 128, 8), np.uint64)
     recs = []
     with bsa.Context(scalar_lanes=nodes.lanes - 4) as ctx:
         ctx.load_nodes(nodes, fit)
         ctx.load_groups(groups)
         ctx.load_pods(pods)
+        if shard:
+            ctx.set_shard(shard[0], shard[1])
         ctx.run(stages)
         ctx.sync()
         idx = np.random.default_rng(1).choice(groups.g, min(32, groups.g), replace=False)

@@ -5,7 +5,8 @@ combination gets its own context (the switches are read when a context is create
 and median of REPS x 300 steps back to back), the step's per-kernel device times (bs_batch timing, when --kernels), and a digest of
 every output array — all forms must agree with form 0 bit for bit (the line says so).  GPU only; no oracle, no test imports.
 
-usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms -1,0,1,3,5  (-1 = the library's defaults)] [--shares 64,16,4] [--fwaves 8192,4096] [--kernels] [--plain] [--shard r/n[,r/n...]]
+usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms -1,0,1,3,5  (-1 = the library's defaults)] [--shares 64,16,4] [--fwaves 8192,4096] [--kernels] [--plain] [--shard r/n[,r/n...]] [--split 1,8]
+  --split m: BS_TP_SPLIT, the transposed Filter items are cut for m x the launched waves (0 / absent: the library's rule = the number of ranks)
   --shard r/n: the step of rank r of n (pod-axis shard on this one context, no collective): what a rank's launches cost
   --plain: the scene as synthesised (requests shared within a gang) instead of all-distinct"""
 import hashlib
@@ -51,9 +52,12 @@ def main():
         pods.req[0, :] += np.arange(pods.p, dtype=np.int64)
     shards = [[int(x) for x in sh.split("/")] for sh in arg("--shard", "").split(",")] if "--shard" in sys.argv else [None]      # "--shard 0/2,0/8,7/8"
     ref = None
-    for form, share, fw, shard in [(f, s, w, sh) for f in forms for s in shares for w in fwaves for sh in shards]:
-        for k in ("BS_TP_FILTER", "BS_TP_SHARE", "BS_FILTER_WAVES"):
+    splits = [int(x) for x in arg("--split", "0").split(",")]
+    for form, share, fw, shard, split in [(f, s, w, sh, sp) for f in forms for s in shares for w in fwaves for sh in shards for sp in splits]:
+        for k in ("BS_TP_FILTER", "BS_TP_SHARE", "BS_FILTER_WAVES", "BS_TP_SPLIT"):
             os.environ.pop(k, None)
+        if split:
+            os.environ["BS_TP_SPLIT"] = str(split)
         if form >= 0:                                          # form -1: the library's defaults (no switch set)
             os.environ["BS_TP_FILTER"] = str(form)
             os.environ["BS_TP_SHARE"] = str(share)
@@ -78,7 +82,7 @@ def main():
                     ctx.run(soa.STAGE_ALL)
                 ctx.sync()
                 res.append((time.perf_counter() - t) / 300 * 1e6)
-            line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share, "filter_waves": fw, "shard": shard,
+            line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share, "filter_waves": fw, "shard": shard, "split": split,
                     "us_per_step_best": round(min(res), 2), "us_per_step_median": round(sorted(res)[len(res) // 2], 2), "digest": d,
                     "same_as_first": d == ref}
             if "--kernels" in sys.argv:
