@@ -246,7 +246,8 @@ struct bs_ctx {
   uint32_t tp_filter = 6;            // BS_TP_FILTER (throughput regime = more than 16 tiles of class slots): 0 = scan and Filter roles in one launch (k_fast_scan_filter: rounds 2-4),
                                      // 1..4 = k_fast_scan, then k_fast_filter<4,DB> / <2,DB> / <2,!DB> / k_fast_filter_w7 (109 / 93 / 75 / 72 VGPRs),
                                      // 5 = k_fast_scan, then k_fast_filter_t (the transposed item, bs_filter_t.hpp: 64 VGPRs),
-                                     // 6 / 7 = one launch, Filter role by the transposed item (7: the Filter blocks first)
+                                     // 6 / 7 = one launch, Filter role by the transposed item (7: the Filter blocks first),
+                                     // 8 = as 5, the two launches side by side on two streams
   uint32_t tp_share = 0;             // BS_TP_SHARE: scan shares per tile of class slots when launch B is not the fused form (at most);
                                      // 0 = 2 in the throughput regime, 64 otherwise (what the sweeps of profiles/r04c_* say)
   uint32_t tp_fwaves = 0;            // BS_TP_FWAVES: waves the Filter work of that regime is cut for; 0 = 16384 from 65 536 (tile, two node
@@ -1082,7 +1083,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_EPOCH")) c->no_epoch = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
-  if (const char* e = std::getenv("BS_TP_FILTER")) c->tp_filter = (uint32_t)std::min(7, std::max(0, std::atoi(e)));
+  if (const char* e = std::getenv("BS_TP_FILTER")) c->tp_filter = (uint32_t)std::min(8, std::max(0, std::atoi(e)));
   if (const char* e = std::getenv("BS_STEP_A")) c->step_a_on = std::atoi(e) != 0;
   if (const char* e = std::getenv("BS_STEP_SHARES")) c->step_shares = (uint32_t)std::min(32, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_SHARE")) c->tp_share = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
@@ -2129,6 +2130,19 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       // ---- ... and launch C in the same launch: final codes, Filter code / slot / feasible count per pod, admit counts, quorum
       const dim3 grid(scan_blocks + fblocks + cdiv(P, 256));
       launch_fast_bc(fast_launch(c), grid, pd, gr, nd, b, bt, prm, nseg, scan_blocks, fblocks);
+    } else if (c->tp_filter == 8u && fblocks && throughput) {
+      // the two roles as launches of their own, SIDE BY SIDE: the scan on the side stream (its items are chains of dependent loads,
+      // its 130-odd VGPRs its own business), the transposed Filter item at seven waves per SIMD on the main one; both read what launch
+      // A wrote and write disjoint outputs for the final launch, which waits for both
+      FastLaunch side = fast_launch(c);
+      side.stream = c->stream3;
+      HIPCHK(c, hipEventRecord(c->ev_query, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_query, 0));
+      launch_fast_scan(side, dim3(scan_blocks), bt, prm, share_b);
+      HIPCHK(c, hipEventRecord(c->ev_filter, c->stream3));
+      launch_fast_filter(fast_launch(c), dim3(fblocks), pd, nd, bt, prm);
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_filter, 0));
+      tp_split = true;
     } else if (c->tp_filter >= 6u && fblocks && throughput && c->S <= 4u) {
       // both roles in one launch, the Filter role by the transposed item (the default of the throughput regime)
       launch_fast_bt(fast_launch(c), dim3(scan_blocks + fblocks), nd, bt, prm, share_b, scan_blocks);

@@ -18,7 +18,7 @@ from test_gpu_parity import assert_batch_equal, load_ctx, _force_class_mode
 
 pytestmark = pytest.mark.gpu
 
-FORMS = [0, 1, 2, 3, 4, 5, 6, 7]
+FORMS = [0, 1, 2, 3, 4, 5, 6, 7, 8]
 ONE_LAUNCH = (0, 6, 7)          # forms that keep both roles of launch B in one launch
 
 
