@@ -57,7 +57,7 @@ def test_all_distinct_requests_every_form(form, config, scenario, over, bsa, soa
 ])
 def test_all_distinct_requests_library_defaults(config, scenario, over, bsa, soa, orc, monkeypatch):
     """No switch set: the throughput regime takes one launch for both roles of launch B (the Filter role by the transposed item)."""
-    for k in ("BS_TP_FILTER", "BS_TP_SHARE", "BS_TP_FWAVES", "BS_FILTER_WAVES"):
+    for k in ("BS_TP_FILTER", "BS_TP_SHARE", "BS_TP_FWAVES", "BS_FILTER_WAVES", "BS_TP_SPLIT"):
         monkeypatch.delenv(k, raising=False)
     nodes, fit, groups, pods = _distinct(bsa, config, scenario, **over)
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
@@ -143,15 +143,34 @@ def test_latency_mode_and_filter_deny_in_the_throughput_regime(form, bsa, soa, o
         assert not np.array_equal(exp_fd.pf_code, exp.pf_code), "the scene lost its Filter-deny events"
 
 
-@pytest.mark.parametrize("form", [0, 6])
+@pytest.mark.parametrize("split", [2, 5])
+@pytest.mark.parametrize("form", [5, 6, 8])
+def test_item_order_by_tile_quads_on_one_context(form, split, bsa, soa, orc, monkeypatch):
+    """BS_TP_SPLIT on a single context: the transposed Filter items cut finer than the launched waves and numbered tile quad by tile
+    quad (a tile count that is not a multiple of four: the last quad has idle members)."""
+    nodes, fit, groups, pods = _distinct(bsa, "cfg3", "tail", pods=2950, groups=500, nodes=1300, classes=16)
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    monkeypatch.setenv("BS_TP_FILTER", str(form))
+    monkeypatch.setenv("BS_TP_SPLIT", str(split))
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, f"form {form}, split {split}")
+        assert ctx.stats(soa.STAGE_ALL)["chain"] == 1
+
+
+@pytest.mark.parametrize("split", [0, 1, 3, 8])       # BS_TP_SPLIT: a rank cuts its Filter items finer and deals them out tile quad by tile quad (0: the library's rule)
+@pytest.mark.parametrize("form", [0, 5, 6, 8])
 @pytest.mark.parametrize("nranks", [2, 3])
-def test_shards_in_the_throughput_regime(nranks, form, bsa, soa, orc, monkeypatch):
+def test_shards_in_the_throughput_regime(nranks, form, split, bsa, soa, orc, monkeypatch):
     """Pod-axis shard (bs_shard_set, the whole queue on every rank): only the pods a rank owns stamp their class / Filter slots, so a
     rank's launch B evaluates the slots of ITS pods — with distinct requests that is 1 / nranks of the work.  Every rank's owned pods
     == the single batch's, the union of the admit counters == the single batch's."""
     nodes, fit, groups, pods = _distinct(bsa, "cfg3", "tail", pods=3000, groups=500, nodes=1300, classes=16)
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
     monkeypatch.setenv("BS_TP_FILTER", str(form))
+    if split:
+        monkeypatch.setenv("BS_TP_SPLIT", str(split))
+    else:
+        monkeypatch.delenv("BS_TP_SPLIT", raising=False)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
         admit = np.zeros(groups.g, np.uint32)
         owned = np.zeros(pods.p, np.uint32)
