@@ -82,24 +82,28 @@ BS_DEF_FILTER_NODE4(15, 1, 0, 0, 0, 0, 1, 1, 1)
 
 // one 64-node block (first node n0, a multiple of 64) against the lanes in `em`: per lane the 64 bits "left >= R on every
 // compared resource lane".  Bits of lanes outside `em` stay 0.
-// The nodes travel in GROUPS of four (one s_load_dwordx8 per compared lane), double-buffered in SGPRs: the scalar loads of the NEXT
-// group are issued before the compares of the current one (whose values are already there: `filter_sgprs_ready4` makes the compiler
-// wait for them BEFORE it issues the next loads — scalar loads return out of order, the only wait there is waits for everything
-// outstanding, so a wait behind the issue would wait for both).  Larger groups when fewer lanes are compared (16 nodes with one
-// lane, 8 with two: BS_FT_BIG_GROUPS) were measured and bought nothing — cfg4 all-distinct, one lane binding: 203 us per step
-// against 192 us with groups of four (profiles/r04c_tp_sweep4_groups16.jsonl): the loads are not what the loop waits for.
+// The nodes travel in GROUPS (eight with one compared lane: one s_load_dwordx16; four otherwise: one s_load_dwordx8 per lane),
+// double-buffered in SGPRs: the scalar loads of the NEXT group are issued before the compares of the current one (whose values are
+// already there: `filter_sgprs_ready4` makes the compiler wait for them BEFORE it issues the next loads — scalar loads return out of
+// order, the only wait there is waits for everything outstanding, so a wait behind the issue would wait for both).
+// Group size, measured (cfg4 all-distinct, one lane binding).  Round 4, compares as an EXEC chain: 16 / 8 nodes per group 203 us per
+// step against 192 with four (profiles/r04c_tp_sweep4_groups16.jsonl) — at 56 cycles per node a group of four covered the load.
+// Round 5, v_cmp + v_addc (8 cycles per node): eight nodes 161.7 us against 169.2 with four, sixteen 172.3 (the SGPR file: 2 x 32 node
+// registers + 8 of masks); cfg3 32.9 / 34.0 / 33.2 (profiles/r05_tp_groups.txt; digests equal).
 __device__ __forceinline__ void filter_sgprs_ready4(const int64_t& a, const int64_t& b, const int64_t& c, const int64_t& d) {
   asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d));
 }
+#ifndef BS_FT_G1
+#define BS_FT_G1 8                 // nodes per group with ONE compared lane (s_load_dwordx16), BS_FT_G2 with two; four beyond that
+#endif
+#ifndef BS_FT_G2
+#define BS_FT_G2 4
+#endif
 template <int MASK>
 __device__ __forceinline__ void filter_block_t(cnode_t L4, uint32_t stride, uint32_t n0, const int64_t (&R)[4], uint32_t (&wd)[2]) {
   constexpr int K = ((MASK >> 0) & 1) + ((MASK >> 1) & 1) + ((MASK >> 2) & 1) + ((MASK >> 3) & 1);
-#ifdef BS_FT_BIG_GROUPS
-  constexpr int GN = K == 1 ? 16 : (K == 2 ? 8 : 4);                 // nodes per group
-#else
-  constexpr int GN = 4;
   static_assert(K >= 1 && K <= 4, "MASK names the compared lanes");
-#endif
+  constexpr int GN = K == 1 ? BS_FT_G1 : (K == 2 ? BS_FT_G2 : 4);    // nodes per group
   constexpr int NG = 64 / GN;
   constexpr int J0 = (MASK & 1) ? 0 : ((MASK & 2) ? 1 : ((MASK & 4) ? 2 : 3));      // a compared lane: stands in for the lanes that are not
   auto load = [&](uint32_t nn, int64_t (&s)[4][GN]) {

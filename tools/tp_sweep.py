@@ -46,6 +46,9 @@ def main():
     forms = [int(x) for x in arg("--forms", "0,1,2,3,4,5").split(",")]
     shares = [int(x) for x in arg("--shares", "64,16,4").split(",")]
     fwaves = [int(x) for x in arg("--fwaves", "8192").split(",")]          # BS_FILTER_WAVES: waves the Filter work is cut for (8192 = the default)
+    if "--lib" in sys.argv:                                      # an experiment build of the library (never the shipped one)
+        bsa.capi.LIB_PATH = os.path.abspath(arg("--lib", ""))
+        bsa.capi.load_library()
     nodes, fit, groups, pods, _ = bsa.synth.make(cfg, scen)
     if "--plain" not in sys.argv:
         pods = pods.copy()
