@@ -283,8 +283,8 @@ __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev
 // tiles, chunk by chunk (item = ((tile / 4) * nchunk + chunk) * 4 + tile % 4: the four waves of a block still share their node run).
 // A rank's live tiles are neighbours (class ids follow the queue), so its live items are CONSECUTIVE and the waves' strided walk deals
 // them out evenly; chunk-major, a wave's items fall on tiles (w + k * waves) mod tiles, live by chance — rank 0 of 8 on cfg4, 60 200
-// items on 16 384 waves: 7 % of the waves drew two live items, 0.7 % three, and the launch lasted as long as those (48 us of 16 us
-// items; tools/stamp_probe.py, profiles/r05_shard_scaling.md).
+// items on 16 384 waves: some waves drew two or three live items of 16 us each and the launch lasted as long as those, while the
+// stamped live blocks were done after 16 us (tools/stamp_probe.py, profiles/r05_shard_scaling.md: 72 -> 60 us per step).
 template <bool AHEAD>
 __device__ __forceinline__ void filter_loop_t(const NodesDev& nd, const BatchDev& b, uint32_t target_waves, uint32_t ustride, uint32_t collect_stats,
                                               uint32_t bx, uint32_t nblocks, uint32_t stamp, uint32_t slots, uint32_t by_tile) {
