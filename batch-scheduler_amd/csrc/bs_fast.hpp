@@ -540,13 +540,60 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
   }
 }
 
-// block layout: [0, query_blocks) pods | query_blocks + c: table chunk c
+// Node words (round 6): what computeResourceSatisfied (core.go:514-564) needs of a NODE that no pod has a say in, once per batch instead of once
+// per (tile of 64 request slots, 64-node block) in the Filter items of the throughput regime (filter_item_t, bs_filter_t.hpp).  Thread = node,
+// wave = 64-node block: the nodes Filter can evaluate (getLeftResource finds them: core.go:442-449) and, for each of the batch's two leaders
+// (findMaxPG's result, and sop.maxFinishedPG as it was carried into the batch), the nodes whose left covers one member of the leader's gang
+// (maxSingle = Resource{} + MinResources, core.go:526-527) — case 3 lets exactly the OTHER nodes pass (core.go:558-563).  The item then fetches two
+// words per block through the scalar cache where it loaded 33 bytes per node into the lanes, double-buffered, and took six ballots (PMC of round 5:
+// 3.6 VALU per node and wave against the 2.1 of the node loop, profiles/r05_distinct4_pmc_summary.txt).  The maxSingle the words were built from is
+// left beside them: an item whose slots carry another one (never in this chain today) keeps the old path.
+template <int TS>
+__device__ __forceinline__ void node_words_block(const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchParams& prm, uint32_t blk) {
+  const Shape<TS> sh(prm.S);
+  const uint32_t gate = prm.eph_gate;
+  const uint32_t n = blk * kTblChunk + threadIdx.x, w = n >> 6, stride = b.nodew_stride;
+  const int32_t leaders[2] = {b.leader_epoch[0], prm.sop_leader0};
+  int64_t l[4] = {INT64_MIN, INT64_MIN, INT64_MIN, INT64_MIN};
+  uint8_t fl = 0xFF;
+  if (n < nd.n) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) l[j] = nd.left4[(size_t)j * nd.stride + n];
+    fl = nd.flags[n];
+  }
+  const unsigned long long ok = __ballot(fl != 0xFF && !(fl & (BS_NODE_NIL | BS_NODE_NO_NODE)));
+  if (lane_id() == 0) b.nodew[w] = ok;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    LeaderPre lp{};
+    const bool have = gr.g != 0 && leaders[s] >= 0;
+    if (have) leader_pre_load(gr, leaders[s], sh, lp);
+    Res ms;
+    res_zero(ms, sh);
+    if (have && lp.have_mr) res_add(ms, lp.mr, sh, gate);               // core.go:526-527
+    uint32_t ff = (have && lp.have_mr) ? 1u : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < BS_MAX_SCALARS; ++q)
+      if (q < sh.S() && (ms.present & (1u << q)) && ms.v[4 + q] != 0) ff |= 2u;
+    const unsigned long long holds = __ballot(l[0] >= ms.v[0] && l[1] >= ms.v[1] && l[2] >= ms.v[2] && l[3] >= ms.v[3]);
+    if (lane_id() == 0) b.nodew[(size_t)(1 + s) * stride + w] = holds;
+    if (blk == 0 && threadIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b.nodew[(size_t)3 * stride + 4 * s + j] = (uint64_t)ms.v[j];
+      b.nodew[(size_t)3 * stride + 8 + s] = ff;
+    }
+  }
+}
+
+// block layout: [0, query_blocks) pods | query_blocks + c: table chunk c | behind the chunks: node words (only launched when launch B takes the
+// transposed Filter item)
 template <int TS>
 __global__ __launch_bounds__(kTblChunk) void k_fast_query_tables(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm,
                                                                  const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks) {
   BS_STAMP(1, 0);
   if (blockIdx.x < query_blocks) fast_query_thread<TS>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
-  else tables_local_fast<TS>(nd, bt, prm, forced, blockIdx.x - query_blocks);
+  else if (blockIdx.x < query_blocks + nchunks) tables_local_fast<TS>(nd, bt, prm, forced, blockIdx.x - query_blocks);
+  else node_words_block<TS>(gr, nd, b, prm, blockIdx.x - query_blocks - nchunks);
   BS_STAMP(1, 7);
 }
 

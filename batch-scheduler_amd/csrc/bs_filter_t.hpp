@@ -204,7 +204,6 @@ __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev
       fl = nd.flags[n];
     }
   };
-  load_block(w0, l, nfl);
   if (!ev) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) M[j] = 0;
@@ -237,6 +236,52 @@ __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev
 
   const cnode_t L4 = (cnode_t)(uintptr_t)nd.left4;
   uint32_t cnt = 0;
+  // Round 6: the pod-independent words of a node block come from the batch's node words (launch A, node_words_block) through the scalar
+  // cache when the tile's slots all name one of the batch's two leaders — every tile but the one that straddles the two halves of the
+  // slot array.  sel = which leader's words (2: the leader's MinResources names a scalar, no node holds a member: case 3 passes everywhere).
+  int sel = -1;
+  if (b.nodew && uniformM) {
+    if (lb0) sel = 2;
+    else {
+      const cnode_t ref = (cnode_t)(uintptr_t)(b.nodew + (size_t)3 * b.nodew_stride);
+#pragma unroll
+      for (int s2 = 1; s2 >= 0; --s2) {
+        const bool eq = (ref[8 + s2] & 3) == 1 && ref[4 * s2] == M0[0] && ref[4 * s2 + 1] == M0[1] && ref[4 * s2 + 2] == M0[2] && ref[4 * s2 + 3] == M0[3];
+        if (__ballot(eq) != 0) sel = s2;              // (M0 is the same in every lane)
+      }
+    }
+  }
+  if (sel >= 0) {
+    typedef const __attribute__((address_space(4))) unsigned long long* cword_t;
+    const cword_t OK = (cword_t)(uintptr_t)b.nodew;
+    const cword_t HOLD = (cword_t)(uintptr_t)(b.nodew + (size_t)(sel == 1 ? 2 : 1) * b.nodew_stride);
+    const bool c2run = c2mask && !tile_allfail;
+    const bool other = !ev && myfl < 16u;               // nil before any node lookup / error: every node in range
+    uint64_t* out = b.fu_bitmap + (size_t)w0 * ustride + p0 + lane;
+    for (uint32_t w = w0; w < w1; ++w, out += ustride) {
+      const unsigned long long okmask = OK[w];
+      const unsigned long long lf = sel == 2 ? 0ull : HOLD[w];
+      uint32_t c2w[2] = {0u, 0u};
+      if (c2run) {
+        if (lane_mask == 0u) { c2w[0] = (uint32_t)okmask; c2w[1] = (uint32_t)(okmask >> 32); }     // every lane is free
+        else filter_block_any(lane_mask, L4, nd.stride, w * 64u, R, c2w);
+      }
+      const uint32_t left = nd.n - w * 64u;
+      const unsigned long long in_range = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
+      unsigned long long c2 = ((unsigned long long)c2w[1] << 32) | c2w[0];
+      if (!c2pod) c2 = 0;
+      unsigned long long word = okmask & (c2 | ~lf);
+      if (!ev) word = other ? in_range : 0ull;
+      if (mine) {
+        cnt += (uint32_t)__popcll(word);
+        *out = word;
+        if (b.h_rows && p0 + (uint32_t)lane < b.hstride) b.h_rows[(size_t)w * b.hstride + p0 + lane] = word;
+      }
+    }
+    if (mine && cnt) atomicAdd(&b.fu_feas[p0 + lane], cnt);
+    return;
+  }
+  load_block(w0, l, nfl);
   for (uint32_t w = w0; w < w1; ++w) {
     load_block(w + 1u, ln, nfln);                   // (in flight during this block's compare loop; invalid behind w1)
     const bool nvalid = nfl != 0xFF;

@@ -192,6 +192,8 @@ struct bs_ctx {
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
   // request slots (see BatchDev): classes of the loaded pods + per-batch slot arrays
   DevBuf d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_uclaim, d_fu_bitmap, d_fu_feas;
+  DevBuf d_nodew;                    // node words of the batch (BatchDev::nodew): 3 x (W + 2) words + the two leaders' maxSingle
+  bool no_nodew = false;             // BS_NO_NODEW=1: the transposed Filter item derives the node-only masks of every block itself (rounds 4-5; A/B switch)
   uint32_t slot_keep = 0xFFFFFFFFu;   // BS_HASH_SLOT_BITS (tests): directory probes start at hash & slot_keep
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
   DevBuf d_fl_bitmap, d_admit, d_ready, d_gcount, d_admit64, d_own_start;
@@ -471,6 +473,8 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.uparams = c->d_uparams.as<int64_t>();
   b.uflags = c->d_uflags.as<uint32_t>();
   b.uclaim = c->d_uclaim.as<uint32_t>();
+  b.nodew = nullptr;                 // run_fast sets it for the batches whose launch A builds the node words
+  b.nodew_stride = 0;
   b.fu_bitmap = c->d_fu_bitmap.as<uint64_t>();
   // per-slot feasible counts sit right behind the last row of the slot bitmap: one 2-D copy returns rows + counts
   b.fu_feas = reinterpret_cast<uint32_t*>(at(c->d_fu_bitmap.as<uint64_t>(), (size_t)cdiv(c->N, 64) * c->filter_slots_cap));
@@ -1089,6 +1093,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_TP_SHARE")) c->tp_share = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_FWAVES")) c->tp_fwaves = (uint32_t)std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_TP_SPLIT")) c->tp_split = (uint32_t)std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("BS_NO_NODEW")) c->no_nodew = std::atoi(e) != 0;
   if (const char* e = std::getenv("BS_NO_SPECULATE")) c->no_spec = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HOST_PROBE")) c->host_probe = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_SLOT_BITS")) { const int hb = std::atoi(e); c->slot_keep = hb >= 32 ? 0xFFFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
@@ -1135,9 +1140,9 @@ int bs_destroy(bs_ctx* c) {
 int bs_nodes_load(bs_ctx* c, const bs_nodes_soa* nodes) {
   if (!c || !nodes) return BS_ERR_INVALID;
   int rc = use_device(c);
-  if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
   if ((rc = settle_pending(c))) return rc;
+  c->steady_prev = -1;                              // (a guess must name a table of the state that is being loaded, not of the one before; behind the settle, whose resolve_groups writes the field)
   const uint32_t N = nodes->n, L = c->L;
   if (N && (!nodes->allocatable || !nodes->requested || !nodes->allocatable_present || !nodes->requested_present || !nodes->flags))
     return BS_ERR_INVALID;
@@ -1162,9 +1167,9 @@ int bs_fit_load(bs_ctx* c, uint32_t n_classes, const uint32_t* fit_bits) {
   if (!c || n_classes == 0 || !fit_bits) return BS_ERR_INVALID;
   if (!c->have_nodes) { c->last_error = "bs_fit_load before bs_nodes_load"; return BS_ERR_STATE; }
   int rc = use_device(c);
-  if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
   if ((rc = settle_pending(c))) return rc;
+  c->steady_prev = -1;                              // (a guess must name a table of the state that is being loaded, not of the one before; behind the settle, whose resolve_groups writes the field)
   c->C = n_classes;
   c->fit_words = cdiv(c->N, 32);
   c->h_fit.assign(fit_bits, fit_bits + (size_t)n_classes * c->fit_words);
@@ -1178,9 +1183,9 @@ int bs_fit_build(bs_ctx* c, const bs_node_labels* nl, const bs_fit_templates* tp
   if (!c->have_nodes) { c->last_error = "bs_fit_build before bs_nodes_load"; return BS_ERR_STATE; }
   if (nl->n != c->N) { c->last_error = "bs_fit_build: label table size differs from the snapshot"; return BS_ERR_INVALID; }
   int rc = use_device(c);
-  if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
   if ((rc = settle_pending(c))) return rc;
+  c->steady_prev = -1;                              // (a guess must name a table of the state that is being loaded, not of the one before; behind the settle, whose resolve_groups writes the field)
   const uint32_t N = c->N, C = tp->c;
   const uint32_t nlab = N ? nl->label_off[N] : 0, ntaint = N ? nl->taint_off[N] : 0;
   const uint32_t nsel = tp->sel_off[C], nterm = tp->term_off[C], ntol = tp->tol_off[C];
@@ -1301,9 +1306,9 @@ int bs_fit_read(bs_ctx* c, uint32_t* out) {
 int bs_groups_load(bs_ctx* c, const bs_groups_soa* g) {
   if (!c || !g) return BS_ERR_INVALID;
   int rc = use_device(c);
-  if (c) c->steady_prev = -1;                       // (a guess must name a table of the state that is being loaded, not of the one before)
   if (rc) return rc;
   if ((rc = settle_pending(c))) return rc;
+  c->steady_prev = -1;                              // (a guess must name a table of the state that is being loaded, not of the one before; behind the settle, whose resolve_groups writes the field)
   c->first_reach_hint = 0xFFFFFFFFu;                // (which pod reaches findMaxPG first depends on the groups' deny entries and OccupiedBy)
   const uint32_t G = g->g, L = c->L;
   if (G && (!g->min_member || !g->status_scheduled || !g->matched || !g->flags || !g->cls || !g->min_resources || !g->min_resources_present ||
@@ -1902,6 +1907,7 @@ static int reserve_slots(bs_ctx* c, bool run_filter) {
     HIPCHK(c, c->d_uparams.reserve((size_t)filter_cap * 64));
     if ((rc = reserve_filled(c, c->d_uflags, (size_t)filter_cap * 4, 0))) return rc;
     if ((rc = reserve_filled(c, c->d_uclaim, (size_t)filter_cap * 4, 0))) return rc;
+    HIPCHK(c, c->d_nodew.reserve(((size_t)3 * (cdiv(c->N, 64) + 2) + 16) * 8));
   }
   c->scan_slots_cap = scan_cap;
   c->filter_slots_cap = filter_cap;
@@ -2081,10 +2087,18 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     }
   }
   c->last_step_a = false;
+  // the throughput regime (more than 16 tiles of class slots) is known before launch A: when launch B will take the transposed Filter item,
+  // launch A's grid carries the node-word blocks (node_words_block) behind the table chunks
+  const uint32_t k_est = std::min<uint32_t>(P, c->kinfo_pending ? std::max<uint32_t>(2 * c->h_K, 1024) : std::max<uint32_t>(c->h_K, 1));
+  const bool node_words = run_filter && cdiv(k_est, 64) > 16 && c->tp_filter >= 5u && !c->no_nodew && c->d_nodew.p;
+  if (node_words) {
+    b.nodew = bt.nodew = c->d_nodew.as<uint64_t>();
+    b.nodew_stride = bt.nodew_stride = W + 2;
+  }
   // ---- launch A: per-pod decisions, scan / Filter slots | chunk-local running sums of the table
   TIMED(c, BS_KERNEL_QUERY, {
     const uint32_t qb = cdiv(P, kTblChunk);
-    const dim3 qg(qb + nchunks), blk(kTblChunk);
+    const dim3 qg(qb + nchunks + (node_words ? cdiv(N, kTblChunk) : 0u)), blk(kTblChunk);
     switch (ts) {
       case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<0>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
       case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_query_tables<1>), qg, blk, 0, c->stream, pd, gr, nd, b, bt, prm, forced, nchunks, qb); break;
@@ -2099,7 +2113,6 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   uint64_t hp3 = 0;
   // ---- launch B: node scan over the class slots | Filter evaluation over the Filter slots
   // The work loops size themselves on the device (the class count lives there); the grid only has to be large enough.
-  const uint32_t k_est = std::min<uint32_t>(P, c->kinfo_pending ? std::max<uint32_t>(2 * c->h_K, 1024) : std::max<uint32_t>(c->h_K, 1));
   TIMED(c, BS_KERNEL_SCAN, {
     const uint32_t nseg = pick_scan_share(c);
     // few tiles (the latency regime): one scan item (tile of 64 class slots x share) per BLOCK, its four waves take a quarter of

@@ -315,3 +315,24 @@ def make_fit_scene(seed: int, n: int, classes: int, quirks: bool = True):
             tp["tolerations"].append(rnd.choice(tol_pool))
         templates.append(tp)
     return nodes, templates
+
+
+def all_distinct(pods, nodes, k_lanes: int = 1):
+    """The throughput regime's scenes (bench.py scenarios.all_distinct_*, tools/tp_sweep.py): every pod asks for something nobody else asks
+    for, on k_lanes of the four fixed lanes Filter compares (getLeftResource, core.go:436-475: cpu, memory, ephemeral storage, pods).
+    k_lanes = 1 is rounds 3-5's scene (cpu + queue index: memory / ephemeral / pods of every request stay below the cluster's smallest
+    left, so the Filter item's lane mask leaves ONE lane to compare).  For k_lanes > 1 the further lanes start just above the smallest left
+    of that lane over the nodes Filter can evaluate and rise with the queue index (1 MiB per pod; 1 per pod modulo 64 on the pods lane):
+    every tile of 64 requests then has to compare those lanes on every node, and no request exceeds the largest left (no tile fails outright)."""
+    p = pods.copy()
+    idx = np.arange(p.p, dtype=np.int64)
+    p.req[0, :] += idx
+    if k_lanes > 1:
+        ok = (nodes.flags & (soa.NODE_NIL | soa.NODE_NO_NODE)) == 0
+        left = (nodes.allocatable[:4] - nodes.requested[:4])[:, ok]
+        step = {1: 1 << 20, 2: 1 << 20, 3: 1}
+        for j in (1, 2, 3)[: k_lanes - 1]:
+            lo, hi = int(left[j].min()), int(left[j].max())
+            span = max(1, min(hi - lo - 1, step[j] * (p.p if j != 3 else 64)))
+            p.req[j, :] = lo + 1 + (idx * step[j]) % span
+    return p

@@ -8,7 +8,9 @@ every output array — all forms must agree with form 0 bit for bit (the line sa
 usage: python tools/tp_sweep.py cfg3|cfg4 [tail] [--forms -1,0,1,3,5  (-1 = the library's defaults)] [--shares 64,16,4] [--fwaves 8192,4096] [--kernels] [--plain] [--shard r/n[,r/n...]] [--split 1,8]
   --split m: BS_TP_SPLIT, the transposed Filter items are cut for m x the launched waves (0 / absent: the library's rule = the number of ranks)
   --shard r/n: the step of rank r of n (pod-axis shard on this one context, no collective): what a rank's launches cost
-  --plain: the scene as synthesised (requests shared within a gang) instead of all-distinct"""
+  --plain: the scene as synthesised (requests shared within a gang) instead of all-distinct
+  --lanes k: the requests differ on k of the four fixed lanes (1 = rounds 3-5's scene: cpu only; 4 = cpu, memory, ephemeral storage, pods all bind)
+  (BS_NO_NODEW=1 in the environment: round 5's item, without the batch's node words — the A/B switch of round 6)"""
 import hashlib
 import importlib
 import json
@@ -50,9 +52,9 @@ def main():
         bsa.capi.LIB_PATH = os.path.abspath(arg("--lib", ""))
         bsa.capi.load_library()
     nodes, fit, groups, pods, _ = bsa.synth.make(cfg, scen)
+    lanes = int(arg("--lanes", "1"))                             # --lanes k: every request distinct on k of the four lanes Filter compares (synth.all_distinct)
     if "--plain" not in sys.argv:
-        pods = pods.copy()
-        pods.req[0, :] += np.arange(pods.p, dtype=np.int64)
+        pods = bsa.synth.all_distinct(pods, nodes, lanes)
     shards = [[int(x) for x in sh.split("/")] for sh in arg("--shard", "").split(",")] if "--shard" in sys.argv else [None]      # "--shard 0/2,0/8,7/8"
     ref = None
     splits = [int(x) for x in arg("--split", "0").split(",")]
@@ -85,7 +87,7 @@ def main():
                     ctx.run(soa.STAGE_ALL)
                 ctx.sync()
                 res.append((time.perf_counter() - t) / 300 * 1e6)
-            line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "form": form, "share": share, "filter_waves": fw, "shard": shard, "split": split,
+            line = {"config": cfg, "scenario": scen, "distinct": "--plain" not in sys.argv, "lanes": lanes, "no_nodew": os.environ.get("BS_NO_NODEW", "0"), "form": form, "share": share, "filter_waves": fw, "shard": shard, "split": split,
                     "us_per_step_best": round(min(res), 2), "us_per_step_median": round(sorted(res)[len(res) // 2], 2), "digest": d,
                     "same_as_first": d == ref}
             if "--kernels" in sys.argv:
