@@ -39,7 +39,7 @@ def hipcc() -> str:
 
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libbsched_host.so")
 HOST_SRC = os.path.join(HERE, "host", "bs_host.cpp")
-HOST_SRCS = [HOST_SRC, os.path.join(HERE, "host", "bs_drain.cpp")]
+HOST_SRCS = [HOST_SRC, os.path.join(HERE, "host", "bs_drain.cpp"), os.path.join(HERE, "host", "bs_phase.cpp")]
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
@@ -47,7 +47,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     build()
     if PREBUILT_ONLY:
         return HOST_LIB_PATH
-    deps = [*HOST_SRCS, os.path.join(HERE, "..", "include", "bsched.h"), LIB_PATH]
+    deps = [*HOST_SRCS, os.path.join(HERE, "..", "include", "bsched.h"), os.path.join(HERE, "..", "include", "bsched_host.h"), LIB_PATH]
     if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
         return HOST_LIB_PATH
     cxx = shutil.which("g++") or "g++"

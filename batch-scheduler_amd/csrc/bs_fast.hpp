@@ -562,7 +562,10 @@ __device__ __forceinline__ void node_words_block(const GroupsDev& gr, const Node
     fl = nd.flags[n];
   }
   const unsigned long long ok = __ballot(fl != 0xFF && !(fl & (BS_NODE_NIL | BS_NODE_NO_NODE)));
-  if (lane_id() == 0) b.nodew[w] = ok;
+  if (lane_id() == 0) {                                                   // table 2: a leader no node can hold a member of (scalar MinResources)
+    b.nodew[((size_t)2 * stride + w) * 2] = ok;
+    b.nodew[((size_t)2 * stride + w) * 2 + 1] = ~0ull;
+  }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     LeaderPre lp{};
@@ -576,11 +579,14 @@ __device__ __forceinline__ void node_words_block(const GroupsDev& gr, const Node
     for (uint32_t q = 0; q < BS_MAX_SCALARS; ++q)
       if (q < sh.S() && (ms.present & (1u << q)) && ms.v[4 + q] != 0) ff |= 2u;
     const unsigned long long holds = __ballot(l[0] >= ms.v[0] && l[1] >= ms.v[1] && l[2] >= ms.v[2] && l[3] >= ms.v[3]);
-    if (lane_id() == 0) b.nodew[(size_t)(1 + s) * stride + w] = holds;
+    if (lane_id() == 0) {
+      b.nodew[((size_t)s * stride + w) * 2] = ok;
+      b.nodew[((size_t)s * stride + w) * 2 + 1] = ~holds;
+    }
     if (blk == 0 && threadIdx.x == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b.nodew[(size_t)3 * stride + 4 * s + j] = (uint64_t)ms.v[j];
-      b.nodew[(size_t)3 * stride + 8 + s] = ff;
+      for (int j = 0; j < 4; ++j) b.nodew[(size_t)6 * stride + 4 * s + j] = (uint64_t)ms.v[j];
+      b.nodew[(size_t)6 * stride + 8 + s] = ff;
     }
   }
 }

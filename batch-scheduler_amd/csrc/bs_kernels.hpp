@@ -135,12 +135,13 @@ struct BatchDev {
   uint32_t* uclaim;         // [filter slots] k_fast_step_a: stamp of the batch whose (one) writer claimed the slot
   uint64_t* fu_bitmap;      // [W][filter slots] rows of the slots
   uint32_t* fu_feas;        // [filter slots] feasible-node counts of the slots
-  // node words of the batch (round 6, node_words_block in bs_fast.hpp; null = not built for this batch): per 64-node block w
-  //   nodew[w]                      nodes Filter can evaluate (in range, neither nil nor without a Node object: core.go:442-449)
-  //   nodew[(1 + s) * stride + w]   nodes that CAN hold one member of leader s (s = 0: the batch's findMaxPG result, 1: the leader carried in):
-  //                                 left >= maxSingle on the four fixed lanes, i.e. the nodes case 3 (core.go:558-563) does NOT let pass
-  //   nodew[3 * stride + 4 s + j]   the maxSingle the words of leader s were built from (int64), [3 * stride + 8 + s] bit 0: built, bit 1: the leader's
-  //                                 MinResources names a scalar resource (no node can hold a member: getLeftResource has no scalars, Q4)
+  // node words of the batch (round 6, node_words_block in bs_fast.hpp; null = not built for this batch).  Three tables of [stride] word PAIRS, one
+  // pair per 64-node block w — one s_load_dwordx4 of the Filter item:
+  //   nodew[(t * stride + w) * 2]       nodes Filter can evaluate (in range, neither nil nor without a Node object: core.go:442-449)
+  //   nodew[(t * stride + w) * 2 + 1]   nodes that can NOT hold one member of the leader's gang (left < maxSingle on some fixed lane): the nodes
+  //                                     case 3 (core.go:558-563) lets pass.  t = 0: the batch's findMaxPG result, t = 1: the leader carried in,
+  //                                     t = 2: a leader whose MinResources names a scalar resource (no node holds a member: getLeftResource has no scalars, Q4)
+  //   nodew[6 * stride + 4 t + j]       the maxSingle the pairs of table t < 2 were built from (int64), [6 * stride + 8 + t] bit 0: built, bit 1: scalar MinResources
   uint64_t* nodew;
   uint32_t nodew_stride;
   // ---- steady-state fast path (bs_fast.hpp): nothing here is reset per batch

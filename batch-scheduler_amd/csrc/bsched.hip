@@ -192,7 +192,8 @@ struct bs_ctx {
   DevBuf d_tables, d_kp, d_stats, d_fparams, d_fflags, d_chunk_tot, d_blk_scratch, d_gmax, d_chunk_kp;
   // request slots (see BatchDev): classes of the loaded pods + per-batch slot arrays
   DevBuf d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_uclaim, d_fu_bitmap, d_fu_feas;
-  DevBuf d_nodew;                    // node words of the batch (BatchDev::nodew): 3 x (W + 2) words + the two leaders' maxSingle
+  DevBuf d_nodew;                    // node words of the batch (BatchDev::nodew): 3 tables x (W + 2) word pairs + the two leaders' maxSingle
+  bool batch_void = false;           // the last batch's results must not be handed out (check_handover); cleared by the next bs_batch_run
   bool no_nodew = false;             // BS_NO_NODEW=1: the transposed Filter item derives the node-only masks of every block itself (rounds 4-5; A/B switch)
   uint32_t slot_keep = 0xFFFFFFFFu;   // BS_HASH_SLOT_BITS (tests): directory probes start at hash & slot_keep
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
@@ -571,7 +572,7 @@ int upload_nodes(bs_ctx* c, uint32_t lo = 0) {
   HIPCHK(c, c->d_alloc.reserve(cap * L * 8));
   if (c->d_alloc.cap != old_cap_bytes) lo = 0;     // (re)allocated: nothing resident yet
   HIPCHK(c, c->d_nreq.reserve(cap * L * 8));
-  HIPCHK(c, c->d_left4.reserve(cap * 4 * 8 + 64 * 8));   // + one node block of padding: k_fast_filter_t's scalar loads run to the end of the last 64-node block
+  HIPCHK(c, c->d_left4.reserve(cap * 4 * 8 + 128 * 8));  // + two node blocks of padding: k_fast_filter_t's scalar loads run to the end of the last 64-node block, the lean loop one group (<= 16 nodes) further
   HIPCHK(c, c->d_lglob.reserve(64));
   HIPCHK(c, c->d_apres.reserve(cap * 4));
   HIPCHK(c, c->d_rpres.reserve(cap * 4));
@@ -1033,6 +1034,7 @@ const char* bs_strerror(int status) {
     case BS_ERR_CAPACITY: return "capacity exceeded";
     case BS_ERR_NOMEM: return "out of memory";
     case BS_ERR_COMM: return "RCCL error";
+    case BS_ERR_RETRY: return "the last batch's results are void and the cause is repaired: run the batch again";
     default: return "unknown status";
   }
 }
@@ -1907,7 +1909,7 @@ static int reserve_slots(bs_ctx* c, bool run_filter) {
     HIPCHK(c, c->d_uparams.reserve((size_t)filter_cap * 64));
     if ((rc = reserve_filled(c, c->d_uflags, (size_t)filter_cap * 4, 0))) return rc;
     if ((rc = reserve_filled(c, c->d_uclaim, (size_t)filter_cap * 4, 0))) return rc;
-    HIPCHK(c, c->d_nodew.reserve(((size_t)3 * (cdiv(c->N, 64) + 2) + 16) * 8));
+    HIPCHK(c, c->d_nodew.reserve(((size_t)6 * (cdiv(c->N, 64) + 2) + 16) * 8));
   }
   c->scan_slots_cap = scan_cap;
   c->filter_slots_cap = filter_cap;
@@ -2739,6 +2741,7 @@ int bs_batch_run(bs_ctx* c, uint32_t stages) {
   c->fd_active = false;
   c->fd_iter = 0;
   c->fd_in_live = false;
+  c->batch_void = false;                             // a new batch: the verdict on the one before is history
   rc = batch_run_inner(c, stages);
   if (rc == BS_OK && (stages & BS_BATCH_FILTER_DENY) && c->P) c->fd_unsynced = true;
   if (rc == BS_OK && (stages & BS_BATCH_FILTER_DENY) && c->P) {
@@ -2773,14 +2776,20 @@ static int check_handover(bs_ctx* c) {
     c->ids_used = c->pair_cap;
     const int rc2 = derive_pods(c, false);
     c->n_rederives++;
+    c->batch_void = true;                              // whatever ran over the overflowed queue is void until the next bs_batch_run
     c->last_error = "bs_pods_apply: class / pair id space overflowed on the device; the queue was re-derived, run the batch again";
-    return rc2 ? rc2 : BS_ERR_STATE;
+    return rc2 ? rc2 : BS_ERR_RETRY;
   }
   if (c->h_info && ((volatile int32_t*)c->h_info)[12]) {
     ((volatile int32_t*)c->h_info)[12] = 0;
     c->no_fuse_final = 1;                              // from now on: separate launches
-    c->last_error = "in-launch hand-over timed out (producer blocks not resident): batch refused, re-run it (the context now uses separate launches)";
-    return BS_ERR_HIP;
+    c->batch_void = true;
+    c->last_error = "in-launch hand-over timed out (producer blocks not resident): batch void, run it again (the context now uses separate launches)";
+    return BS_ERR_RETRY;
+  }
+  if (c->batch_void) {                                 // (the word was consumed by an earlier look — bs_seq_run's, or a reader's — and no batch has run since)
+    c->last_error = "the last batch's results are void (hand-over time-out or queue re-derivation, reported earlier): run the batch again";
+    return BS_ERR_RETRY;
   }
   return BS_OK;
 }
@@ -3339,9 +3348,11 @@ int bs_seq_run(bs_ctx* c, uint32_t stages, bs_seq_out* out) {
   // the first-fit cursors are keyed by the resident queue's request classes: a queue patch whose insert wave ran out of class ids
   // (h_info[13], set by the device) left them unusable until the queue is re-derived — check_handover does that
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  discard_handover(c);                                      // (an unread batch's hand-over timeout is not this call's business)
-  if ((rc = check_handover(c)) && rc != BS_ERR_STATE) return rc;
-  if (rc == BS_ERR_STATE && (rc = check_handover(c))) return rc;
+  // An unread batch's error words are looked at here (the id overflow concerns this pass: check_handover re-derives the queue) but they stay
+  // that batch's: batch_void keeps every later read of it failing with BS_ERR_RETRY until bs_batch_run starts a new one.  The pass itself
+  // reads no batch result and goes on.
+  if ((rc = check_handover(c)) && rc != BS_ERR_RETRY) return rc;
+  if (rc == BS_ERR_RETRY) c->last_error.clear();            // (nothing failed for THIS call)
   out->n_released = 0;
   out->total_ns = 0;
   out->node_picks = out->node_scans = out->scan_rounds = out->pick_rounds = out->leader_folds = out->table_builds = 0;

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/bsched.h"
+#include "../../include/bsched_host.h"
 
 namespace {
 
@@ -64,7 +65,9 @@ struct TtlCache {
   }
 };
 
-enum Phase : uint8_t { Pending = 0, PreScheduling, Scheduling, Scheduled, Running, Finished, Failed };   // types.go:28-56
+// PodGroupPhase, types.go:28-56: the values of include/bsched_host.h (the phase machine proper — syncHandler, the merge patch — is bs_phase.cpp)
+enum Phase : uint8_t { Pending = BSH_PHASE_PENDING, PreScheduling = BSH_PHASE_PRESCHEDULING, Scheduling = BSH_PHASE_SCHEDULING, Scheduled = BSH_PHASE_SCHEDULED,
+                       Running = BSH_PHASE_RUNNING, Finished = BSH_PHASE_FINISHED, Failed = BSH_PHASE_FAILED };
 
 struct Group {   // cache.PodGroupMatchStatus + PodGroup spec/status (cache.go:52-67, types.go:79-130)
   uint32_t min_member = 0, status_scheduled = 0;
@@ -124,7 +127,7 @@ struct bsh_sop {
       const Group& x = groups[g];
       mm[g] = x.min_member; sc[g] = x.status_scheduled; ma[g] = x.matched.Count(now); cl[g] = x.cls; mp[g] = x.minres_present; oc[g] = x.occupied_by;
       fl[g] = (x.scheduled_latch ? BS_GROUP_SCHEDULED_LATCH : 0) | (x.has_pod ? BS_GROUP_HAS_POD : 0) | (x.has_minres ? BS_GROUP_HAS_MINRES : 0) |
-              ((x.phase != Pending && x.phase != PreScheduling && x.phase != Scheduling) ? BS_GROUP_PHASE_CLOSED : 0);   // batchscheduler.go:258-261
+              (bsh_phase_closed(x.phase) ? BS_GROUP_PHASE_CLOSED : 0);   // batchscheduler.go:258-261 (bs_phase.cpp decides)
       for (uint32_t j = 0; j < L; ++j) mr[(size_t)j * G + g] = x.minres[j];
     }
     bs_groups_soa s{G, mm.data(), sc.data(), ma.data(), fl.data(), cl.data(), mr.data(), mp.data(), oc.data()};
@@ -231,7 +234,7 @@ struct bsh_sop {
     if (p.group == BS_POD_NOT_GROUPED) { *ready = true; return 2; }        // :269-272
     if (p.group < 0 || (size_t)p.group >= groups.size()) return 3;          // :274-277
     Group& pgs = groups[p.group];
-    if (pgs.phase == Pending) pgs.phase = PreScheduling;                   // :279-281
+    pgs.phase = (uint8_t)bsh_pg_permit(pgs.phase);                         // :279-281
     const int64_t wait = wait_time(pgs);                                   // :289
     pgs.matched.Set(p.uid, node, now, wait, p.name);                       // :290
     uint64_t old_uid = 0;

@@ -184,9 +184,14 @@ int main(int argc, char** argv) {
   uint32_t p2 = 0;
   CHECK(bs_pods_count(ctx, &p2));
   if (p2 != P) return 6;
-  CHECK(bs_batch_run(ctx, BS_STAGE_ALL | BS_BATCH_HOST_RESULTS));
   bs_batch_view v;
-  CHECK(bs_batch_map(ctx, &v));
+  for (int attempt = 0;; ++attempt) {   /* runCycle's loop: BS_ERR_RETRY (ABI v7) = results void, cause repaired, run the batch again */
+    CHECK(bs_batch_run(ctx, BS_STAGE_ALL | BS_BATCH_HOST_RESULTS));
+    const int mrc = bs_batch_map(ctx, &v);
+    if (mrc == BS_ERR_RETRY && attempt < 2) continue;
+    CHECK(mrc);
+    break;
+  }
   if (v.p != P || v.g != G) return 7;
   wr(o, v.pf_code, P); wr(o, v.pf_first_k, (size_t)P * 4); wr(o, v.pf_leader, (size_t)P * 4); wr(o, v.fl_code, P); wr(o, v.fl_feasible, (size_t)P * 4);
   wr(o, v.group_admit, (size_t)G * 4); wr(o, v.group_ready, G);

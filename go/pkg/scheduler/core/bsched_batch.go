@@ -203,10 +203,14 @@ type cycleView struct {
 	copy *cycleCopy // set when bs_batch_map declined (BS_ERR_STATE): the results were copied out with bs_batch_read_flat instead
 }
 
-// cycleCopy: the cycle's results in Go memory (the fall-back of runCycle)
+// cycleCopy: the cycle's results in Go memory (the fall-back of runCycle): everything the accessors below hand out
 type cycleCopy struct {
-	pfCode []C.uint8_t
-	ready  []C.uint8_t
+	pfCode  []C.uint8_t
+	ready   []C.uint8_t
+	flCode  []C.uint8_t
+	flSlot  []C.uint32_t
+	rows    []C.uint64_t // [W][rowsCap]
+	rowsCap int
 }
 
 func (c *cycleView) pfCode(i int) uint8 {
@@ -221,7 +225,15 @@ func (c *cycleView) groupReady(g int) bool {
 	}
 	return *(*C.uint8_t)(unsafe.Pointer(uintptr(unsafe.Pointer(c.v.group_ready)) + uintptr(g))) != 0
 }
-func (c *cycleView) filterPasses(i, k int) bool { // Filter(pod i, node k), core.go:170-191, as a bit test in the mapped rows
+func (c *cycleView) filterPasses(i, k int) bool { // Filter(pod i, node k), core.go:170-191, as a bit test in the rows (mapped, or copied out)
+	if c.copy != nil {
+		code := c.copy.flCode[i]
+		if code != C.BS_FL_EVALUATED {
+			return code < 16
+		}
+		word := c.copy.rows[(k>>6)*c.copy.rowsCap+int(c.copy.flSlot[i])]
+		return word>>(uint(k)&63)&1 == 1
+	}
 	code := *(*C.uint8_t)(unsafe.Pointer(uintptr(unsafe.Pointer(c.v.fl_code)) + uintptr(i)))
 	if code != C.BS_FL_EVALUATED {
 		return code < 16
@@ -277,27 +289,49 @@ func (g *gpuCore) runCycle(d *queueDelta, groupIndex map[string]uint32, permitte
 		C.uint32_t(I), &grp[0], &req[0], &pres[0], &cls[0], &owner[0], &flags[0], insertAt)); err != nil {
 		return nil, err
 	}
-	if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, C.BS_STAGE_PREFILTER|C.BS_STAGE_TALLY|C.BS_BATCH_HOST_RESULTS)); err != nil {
-		return nil, err
-	}
-	res := &cycleView{}
-	if rc := C.bs_batch_map(g.ctx, &res.v); rc == C.BS_ERR_STATE {
-		// not a failed cycle: the batch left the three-launch chains (more than sixteen leader runs, or a re-run behind a wrong
-		// table guess ended on the general chain), which write no host results — the results are valid, copy them out
-		var pc C.uint32_t
-		if err := g.check("bs_pods_count", C.bs_pods_count(g.ctx, &pc)); err != nil {
+	// BS_ERR_RETRY (ABI v7): the batch's results are void for a reason the library has repaired by the time it says so (the id space
+	// of the queue patch overflowed and the queue was re-derived; an in-launch hand-over timed out) — run the batch again, nothing of
+	// the caller's state is wrong.  BS_ERR_STATE from bs_batch_map is something else: a VALID batch that wrote no host results.
+	for attempt := 0; ; attempt++ {
+		if err := g.check("bs_batch_run", C.bs_batch_run(g.ctx, C.BS_STAGE_PREFILTER|C.BS_STAGE_TALLY|C.BS_BATCH_HOST_RESULTS)); err != nil {
 			return nil, err
 		}
-		P := int(pc)
-		res.copy = &cycleCopy{pfCode: make([]C.uint8_t, P+1), ready: make([]C.uint8_t, g.groups+1)}
-		if err := g.check("bs_batch_read_flat", C.bs_batch_read_flat(g.ctx, &res.copy.pfCode[0], nil, nil, nil, nil, nil, nil, &res.copy.ready[0],
-			nil, nil, nil, 0, nil)); err != nil {
+		res := &cycleView{}
+		rc := C.bs_batch_map(g.ctx, &res.v)
+		if rc == C.BS_ERR_RETRY && attempt < 2 {
+			continue
+		}
+		if rc == C.BS_ERR_STATE {
+			// not a failed cycle: the batch left the three-launch chains (more than sixteen leader runs, or a re-run behind a wrong
+			// table guess ended on the general chain), which write no host results — the results are valid, copy ALL of them out
+			// (every accessor of cycleView reads the copy then)
+			var pc, rowsNeeded, rowsN C.uint32_t
+			if err := g.check("bs_pods_count", C.bs_pods_count(g.ctx, &pc)); err != nil {
+				return nil, err
+			}
+			if err := g.check("bs_filter_rows_count", C.bs_filter_rows_count(g.ctx, &rowsNeeded)); err != nil {
+				return nil, err
+			}
+			P, W := int(pc), (g.nodes+63)/64
+			cp := &cycleCopy{pfCode: make([]C.uint8_t, P+1), ready: make([]C.uint8_t, g.groups+1), flCode: make([]C.uint8_t, P+1),
+				flSlot: make([]C.uint32_t, P+1), rowsCap: int(rowsNeeded) + 1}
+			cp.rows = make([]C.uint64_t, W*cp.rowsCap+1)
+			rc = C.bs_batch_read_flat(g.ctx, &cp.pfCode[0], nil, nil, &cp.flCode[0], nil, nil, nil, &cp.ready[0],
+				&cp.flSlot[0], &cp.rows[0], nil, C.uint32_t(cp.rowsCap), &rowsN)
+			if rc == C.BS_ERR_RETRY && attempt < 2 {
+				continue
+			}
+			if err := g.check("bs_batch_read_flat", rc); err != nil {
+				return nil, err
+			}
+			res.copy = cp
+			return res, nil
+		}
+		if err := g.check("bs_batch_map", rc); err != nil {
 			return nil, err
 		}
-	} else if err := g.check("bs_batch_map", rc); err != nil {
-		return nil, err
+		return res, nil
 	}
-	return res, nil
 }
 
 // seqPass: the reference's own order of events on the device (bs_seq_run): PreFilter -> node choice -> assume -> Permit -> release,

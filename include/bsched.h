@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BS_ABI_VERSION 6u
+#define BS_ABI_VERSION 7u
 
 enum {
   BS_LANE_CPU = 0,       /* Resource.MilliCPU          */
@@ -58,7 +58,11 @@ typedef enum bs_status {
   BS_ERR_STATE = -4,     /* call order: nodes / fit / groups / pods not loaded yet    */
   BS_ERR_CAPACITY = -5,  /* exceeds configured or addressable capacity                */
   BS_ERR_NOMEM = -6,
-  BS_ERR_COMM = -7       /* RCCL failure                                              */
+  BS_ERR_COMM = -7,      /* RCCL failure                                              */
+  BS_ERR_RETRY = -8      /* (ABI v7) the last batch's results are void for a reason the library has already repaired (the class / pair id
+                          * space of a queue patch overflowed and the queue was re-derived; an in-launch hand-over timed out and the context
+                          * went over to separate launches): nothing is wrong with the caller's state — run the batch again.  Distinct from
+                          * BS_ERR_STATE, which bs_batch_map answers for a VALID batch that merely wrote no host results               */
 } bs_status;
 
 /* ---- node flags (per NodeInfo in list order) -------------------------------------- */
@@ -575,7 +579,7 @@ int bs_reduce_external(bs_ctx* ctx, uint32_t on);
  * OccupiedBy) leaves sop.maxFinishedPG as the latest reaching pod IN FRONT OF IT left it — on the whole queue, not on the rank's part
  * of it; pf_leader and the Filter result of a BS_POD_LAST_PERMITTED pod hang on that.  `local_index` = number of this rank's pods
  * that stand in front of the job's first reaching pod (the caller partitions the queue, so it has the queue:
- * batch-scheduler_amd/dist.py first_reach_thresholds is the host rule, the Go shim's partitioner does the same); 0xFFFFFFFF = none.
+ * batch-scheduler_amd/dist.py first_reach_thresholds is the host rule; go/pkg/scheduler/core/bsched_shard.go firstReachThreshold restates it); 0xFFFFFFFF = none.
  * Valid for the loaded queue AND group state (every bs_pods_load / bs_pods_apply / bs_groups_load / bs_groups_apply resets it: a deny entry or
  * an OccupiedBy change moves the first reaching pod — set it again behind them); honoured by the steady-state chain, which is the chain
  * partitioned mode is exact on (no first-pod capture possible).  With it every output of a partitioned batch equals the single

@@ -22,7 +22,7 @@ def test_library_builds_and_exports_every_declared_symbol(bsa):
     for name in declared:
         assert hasattr(lib, name), f"libbsched.so does not export {name}"
     assert declared == set(bsa.capi.ABI_SYMBOLS), declared ^ set(bsa.capi.ABI_SYMBOLS)
-    assert lib.bs_abi_version() == 6
+    assert lib.bs_abi_version() == 7
     lib.bs_strerror.restype = ctypes.c_char_p
     assert lib.bs_strerror(-2) == b"no usable gfx950 device"
 

@@ -53,14 +53,13 @@ def test_hot_kernels_use_no_scratch(bsa):
 
 
 def test_throughput_regime_kernels_keep_their_footprint(bsa):
-    """The transposed Filter item on its own fits seven waves per SIMD (<= 72 VGPRs, no LDS); in one launch with the scan role the kernel is
-    at the scan's footprint, not above it."""
+    """The transposed Filter item on its own (BS_TP_FILTER=5): no LDS, no scratch, five waves per SIMD since round 6 (two tiles of request slots per
+    wave: two request sets, 2 k accumulators and two row pointers per lane — 100 VGPRs; 64-66 up to round 5 with one tile).  In one launch with the
+    scan role (the default) the kernel stays at the scan's footprint, which is what decides its waves per SIMD."""
     import kernel_resources as kr
     res = {_demangle(m): r for m, r in kr.resources(bsa.build.build()).items()}
     ft = res["k_fast_filter_t"]
-    # 64 VGPRs (eight waves) up to round 4; the item order of a sharded rank (filter_loop_t, by_tile) brought the SGPR file to its limit and
-    # two spill VGPRs with it: 66 = seven waves per SIMD.  72 is the seven-wave line.
-    assert ft["vgpr"] <= 72 and ft["lds"] == 0 and ft["scratch"] == 0, ft
+    assert ft["vgpr"] <= 102 and ft["lds"] == 0 and ft["scratch"] == 0, ft            # 102 = the five-wave line (512 / 5)
     for s in range(0, 5):
         both, scan = res[f"k_fast_scan_filter_t<{s}>"], res[f"k_fast_scan<{s}>"]
-        assert both["vgpr"] <= scan["vgpr"] + 2, (s, both, scan)
+        assert both["vgpr"] <= scan["vgpr"] + 3 and both["scratch"] == 0, (s, both, scan)
