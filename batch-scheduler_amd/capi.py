@@ -69,7 +69,7 @@ class BatchStats(C.Structure):
                 ("tables_built", C.c_uint64), ("logical_evals", C.c_uint64), ("filter_evals", C.c_uint64),
                 ("filter_distinct", C.c_uint64), ("filter_evals_executed", C.c_uint64),
                 ("scan_queries_logical", C.c_uint64), ("class_mode", C.c_uint64), ("fast_path", C.c_uint64), ("launches", C.c_uint64),
-                ("chain", C.c_uint64)]
+                ("chain", C.c_uint64), ("filter_lane_blocks", C.c_uint64), ("filter_tile_blocks", C.c_uint64)]
 
 
 class SeqOut(C.Structure):

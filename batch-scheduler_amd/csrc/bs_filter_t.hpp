@@ -429,13 +429,13 @@ __device__ __forceinline__ void lean_tile_head(const NodesDev& nd, const BatchDe
   other_o = myfl < 16u;
 }
 __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ustride, uint32_t ptile, uint32_t w0, uint32_t w1,
-                                              uint32_t stamp, uint32_t ff);
+                                              uint32_t stamp, uint32_t ff, uint32_t collect_stats);
 // One item = (T neighbouring tiles of 64 request slots, node blocks [w0, w1)).  When every tile that has slots in use can take the lean loop on
 // the same node-word table, they take it together; otherwise (the tile across the two leader halves of the slot array, latency-mode batches with
 // host rows, contexts without node words) tile by tile through filter_item_t.
 template <int T>
 __device__ __forceinline__ void filter_item_multi(const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ustride, uint32_t ptile0, uint32_t w0, uint32_t w1,
-                                                  uint32_t stamp, const uint32_t (&ff)[T]) {
+                                                  uint32_t stamp, const uint32_t (&ff)[T], uint32_t collect_stats) {
   const int lane = lane_id();
   int64_t gl[8];
 #pragma unroll
@@ -463,7 +463,7 @@ __device__ __forceinline__ void filter_item_multi(const NodesDev& nd, const Batc
   if (!together) {
 #pragma unroll
     for (int t = 0; t < T; ++t)
-      if (tsel[t] != -2) filter_item_t(nd, b, U, ustride, ptile0 + (uint32_t)t, w0, w1, stamp, ff[t]);
+      if (tsel[t] != -2) filter_item_t(nd, b, U, ustride, ptile0 + (uint32_t)t, w0, w1, stamp, ff[t], collect_stats);
     return;
   }
   const cnode_t L4 = (cnode_t)(uintptr_t)nd.left4;
@@ -472,6 +472,13 @@ __device__ __forceinline__ void filter_item_multi(const NodesDev& nd, const Batc
   for (int t = 0; t < T; ++t) {
     cnt[t] = 0u; live[t] = tsel[t] >= 0;
     out[t] = b.fu_bitmap + (size_t)w0 * ustride + (size_t)(ptile0 + (uint32_t)t) * 64u + lane;
+  }
+  if (collect_stats && lane == 0) {                  // the tiles of a pair are compared on the UNION of their lanes: that is what the launch executes
+    uint32_t nlive = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) nlive += live[t] ? 1u : 0u;
+    atomicAdd((unsigned long long*)&b.stats[5], (unsigned long long)__popc(mask) * nlive * (w1 - w0));
+    atomicAdd((unsigned long long*)&b.stats[6], (unsigned long long)nlive * (w1 - w0));
   }
   switch (mask) {
     case 0: filter_run_lean_t<0, T>(L4, nd.stride, NW, w0, w1, R, c2m, evm, live, out, ustride, cnt); break;
@@ -517,7 +524,7 @@ __device__ __forceinline__ void filter_item_multi(const NodesDev& nd, const Batc
 // returns before it has issued another load (as written up to round 4 it had asked for its 4 KB of requests and 2.5 KB of nodes by
 // then: 118 895 items, 772 MB of dead fetches, when a rank of 8 cut its items as fine as its share of live tiles called for).
 __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ustride, uint32_t ptile, uint32_t w0,
-                                              uint32_t w1, uint32_t stamp, uint32_t ff) {
+                                              uint32_t w1, uint32_t stamp, uint32_t ff, uint32_t collect_stats) {
   const int lane = lane_id();
   const uint32_t p0 = ptile * 64u;
   const uint32_t np = min(64u, U - p0);
@@ -567,6 +574,10 @@ __device__ __forceinline__ void filter_item_t(const NodesDev& nd, const BatchDev
   for (int j = 0; j < 4; ++j) {
     if (__ballot(c2pod && !(gl[j] >= R[j]))) lane_mask |= 1u << j;
     if (c2mask && !__ballot(c2pod && gl[4 + j] >= R[j])) tile_allfail = true;
+  }
+  if (collect_stats && lane == 0) {                  // compared lanes x node blocks | node blocks of this tile run (bs_batch_stats: filter_lane_blocks / filter_tile_blocks)
+    atomicAdd((unsigned long long*)&b.stats[5], (unsigned long long)((c2mask && !tile_allfail) ? __popc(lane_mask) : 0) * (w1 - w0));
+    atomicAdd((unsigned long long*)&b.stats[6], (unsigned long long)(w1 - w0));
   }
   // is the leader's single-member request M the same for every evaluated slot of the tile?
   int64_t M0[4];
@@ -741,8 +752,8 @@ __device__ __forceinline__ void filter_loop_tiles(const NodesDev& nd, const Batc
       }
     }
     if (tile < tiles) {
-      if constexpr (T == 1) filter_item_t(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), stamp, ff[0]);
-      else filter_item_multi<T>(nd, b, U, ustride, tile * (uint32_t)T, chunk * bpw, min(W, chunk * bpw + bpw), stamp, ff);
+      if constexpr (T == 1) filter_item_t(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), stamp, ff[0], collect_stats);
+      else filter_item_multi<T>(nd, b, U, ustride, tile * (uint32_t)T, chunk * bpw, min(W, chunk * bpw + bpw), stamp, ff, collect_stats);
     }
     it = nx;
 #pragma unroll
@@ -754,14 +765,13 @@ __device__ __forceinline__ void filter_loop_tiles(const NodesDev& nd, const Batc
 // one below that (cfg3 all-distinct, 303 tiles: pairs halve the items a launch of ~20 us has: 34.4 -> 36.8 us) and without node words
 // (BS_NO_NODEW=1: round 5's item, tile by tile).  Four tiles per item measured WORSE than two at cfg4 (195 / 279 / 344 us at one / two / four
 // lanes against 151 / 200 / 324: a tile's prologue is then spread over a quarter of the node blocks).
-#ifndef BS_FL_T_MIN_TILES
-#define BS_FL_T_MIN_TILES 768u
-#endif
+// The threshold travels with the batch (BatchDev::tiles2_min = BS_TP_TMIN, default 768, times the ranks of a sharded context: a rank's live
+// tiles are its share of them).
 template <bool AHEAD>
 __device__ __forceinline__ void filter_loop_t(const NodesDev& nd, const BatchDev& b, uint32_t target_waves, uint32_t ustride, uint32_t collect_stats,
                                               uint32_t bx, uint32_t nblocks, uint32_t stamp, uint32_t slots, uint32_t by_tile) {
   const uint32_t U = slots ? slots : 2u * __builtin_amdgcn_readfirstlane(*b.kclass);
-  if (BS_FL_T > 1 && b.nodew && !b.h_rows && (U + 63u) / 64u >= BS_FL_T_MIN_TILES)
+  if (BS_FL_T > 1 && b.nodew && !b.h_rows && (U + 63u) / 64u >= b.tiles2_min)
     filter_loop_tiles<AHEAD, BS_FL_T>(nd, b, target_waves, ustride, collect_stats, bx, nblocks, stamp, U, by_tile);
   else
     filter_loop_tiles<AHEAD, 1>(nd, b, target_waves, ustride, collect_stats, bx, nblocks, stamp, U, by_tile);

@@ -144,6 +144,7 @@ struct BatchDev {
   //   nodew[6 * stride + 4 t + j]       the maxSingle the pairs of table t < 2 were built from (int64), [6 * stride + 8 + t] bit 0: built, bit 1: scalar MinResources
   uint64_t* nodew;
   uint32_t nodew_stride;
+  uint32_t tiles2_min;      // the transposed Filter items take PAIRS of tiles from this many tiles of Filter slots on (filter_loop_t; run_fast: BS_TP_TMIN x ranks)
   // ---- steady-state fast path (bs_fast.hpp): nothing here is reset per batch
   uint32_t* qstamp_s;       // [scan slots] batch stamp of the slot's last writer (slot live iff == prm.stamp)
   const uint32_t* first_pod_s;    // [G] min pod index of the group                               } derived from the pods alone

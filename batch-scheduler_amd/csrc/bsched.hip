@@ -194,6 +194,7 @@ struct bs_ctx {
   DevBuf d_cls_slots, d_cls_rep, d_cls_id, d_qtab_s, d_fu_slot, d_uparams, d_uflags, d_uclaim, d_fu_bitmap, d_fu_feas;
   DevBuf d_nodew;                    // node words of the batch (BatchDev::nodew): 3 tables x (W + 2) word pairs + the two leaders' maxSingle
   bool batch_void = false;           // the last batch's results must not be handed out (check_handover); cleared by the next bs_batch_run
+  uint32_t tp_tmin = 768;            // BS_TP_TMIN: tiles of Filter slots from which the transposed items take pairs of tiles (x ranks on a sharded context)
   bool no_nodew = false;             // BS_NO_NODEW=1: the transposed Filter item derives the node-only masks of every block itself (rounds 4-5; A/B switch)
   uint32_t slot_keep = 0xFFFFFFFFu;   // BS_HASH_SLOT_BITS (tests): directory probes start at hash & slot_keep
   uint32_t cls_cap = 0, hash_keep = 0x7FFFFFFFu, n_nominres = 0, scan_slots_cap = 0, filter_slots_cap = 0;
@@ -476,6 +477,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.uclaim = c->d_uclaim.as<uint32_t>();
   b.nodew = nullptr;                 // run_fast sets it for the batches whose launch A builds the node words
   b.nodew_stride = 0;
+  b.tiles2_min = 0xFFFFFFFFu;
   b.fu_bitmap = c->d_fu_bitmap.as<uint64_t>();
   // per-slot feasible counts sit right behind the last row of the slot bitmap: one 2-D copy returns rows + counts
   b.fu_feas = reinterpret_cast<uint32_t*>(at(c->d_fu_bitmap.as<uint64_t>(), (size_t)cdiv(c->N, 64) * c->filter_slots_cap));
@@ -1096,6 +1098,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_TP_FWAVES")) c->tp_fwaves = (uint32_t)std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_TP_SPLIT")) c->tp_split = (uint32_t)std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_NO_NODEW")) c->no_nodew = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BS_TP_TMIN")) c->tp_tmin = (uint32_t)std::max(1, std::atoi(e));
   if (const char* e = std::getenv("BS_NO_SPECULATE")) c->no_spec = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HOST_PROBE")) c->host_probe = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_HASH_SLOT_BITS")) { const int hb = std::atoi(e); c->slot_keep = hb >= 32 ? 0xFFFFFFFFu : ((1u << std::max(0, hb)) - 1u); }
@@ -2096,6 +2099,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   if (node_words) {
     b.nodew = bt.nodew = c->d_nodew.as<uint64_t>();
     b.nodew_stride = bt.nodew_stride = W + 2;
+    b.tiles2_min = bt.tiles2_min = c->tp_tmin * std::max<uint32_t>(1u, c->nranks);
   }
   // ---- launch A: per-pod decisions, scan / Filter slots | chunk-local running sums of the table
   TIMED(c, BS_KERNEL_QUERY, {
@@ -3727,6 +3731,8 @@ int bs_batch_stats_get(bs_ctx* c, bs_batch_stats* out) {
   out->scan_evals_executed = raw[1];
   out->scan_queries = raw[4];
   out->scan_queries_logical = raw[2];
+  out->filter_lane_blocks = raw[5];
+  out->filter_tile_blocks = raw[6];
   out->class_mode = c->last_use_classes ? 1 : 0;
   out->fast_path = c->last_fast ? 1 : 0;
   out->chain = c->last_chain;

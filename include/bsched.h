@@ -680,6 +680,10 @@ typedef struct bs_batch_stats {
   uint64_t fast_path;               /* 1: the steady-state chain ran (two launches)                          */
   uint64_t launches;                /* kernel launches of the batch                                        */
   uint64_t chain;                   /* 0 general chain, 1 steady-state chain, 2 positional chain              */
+  uint64_t filter_lane_blocks;      /* (ABI v7) throughput regime, transposed Filter item: sum over (tile of 64 request slots, 64-node block) of the
+                                     * resource lanes the launch compared there (0..4: the item's lane mask; a pair of tiles is compared on the
+                                     * union of their masks) ...                                                                              */
+  uint64_t filter_tile_blocks;      /* ... and the number of such (tile, block) units: the ratio is the k of DESIGN.md's VALU-issue bound     */
 } bs_batch_stats;
 int bs_batch_stats_get(bs_ctx* ctx, bs_batch_stats* out);
 /* bs_pods_apply calls so far, and how many of them (plus later batches) had to re-derive classes and pairs from the
