@@ -392,7 +392,7 @@ __device__ __forceinline__ void filter_slot_from(const BatchDev& b, const BatchP
 //   round 1   the pod's own fields (group, flags, owner, request, class, pair) | the batch's leader and panic flag
 //   round 2   the pod's group (flags, OccupiedBy, first owner, first pod) | both leaders' resources (uniform)
 //   round 3   the owner of the group's first owning pod (only where OccupiedBy is still empty)
-template <int TS, bool PUB = false>
+template <int TS, bool PUB = false, bool SLOTS = true>
 __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i,
                                                   uint32_t nthreads) {
   const Shape<TS> sh(prm.S);
@@ -483,9 +483,11 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
   // is elected to fill it (tens of thousands of identical stores to a few hundred cache lines were a measurable part
   // of this launch; electing ONE writer per batch with an atomic swap of the stamp was worse: a hot-spot of returning atomics).
   const uint32_t qslot = has_q ? pc : 0u;
-  bool fill = wave_elect_by_key(qslot, has_q);         // one writer per (wave, class): ~10x fewer identical stores, no atomics
+  // (SLOTS == false, k_fast_step_a's class-slot form: the slots of EVERY class are written by class_slots_block of the same launch, from the
+  // class directory — nothing here may store into them: the scan blocks of that launch are already taking minima in first_row[])
+  bool fill = SLOTS && wave_elect_by_key(qslot, has_q);         // one writer per (wave, class): ~10x fewer identical stores, no atomics
   bool w1 = false, w2 = false;
-  if (prm.run_filter) {
+  if (SLOTS && prm.run_filter) {
     const bool may = valid && (st & ST_OWNED) && BS_PF_IS_PASS(code) && grouped;
     w1 = wave_elect_by_key(pc, may && leader0 >= 0 && leader0 != gi);
     w2 = wave_elect_by_key(pc, may && prm.sop_leader0 >= 0 && prm.sop_leader0 != gi);
@@ -818,32 +820,106 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
   BS_STAMP(2, 7);
 }
 
-// block layout: [0, qb) pods | qb + c * nshares + q: chunk c, slot share q | the rest: Filter
+// Round 6, the class-slot form of the one-launch step (BS_STEP_A=2).  What made round 5's form slow was WHO publishes the slots: every pod block
+// (40 blocks x 4 waves x a few classes each, write-through, a claim swap per slot) in front of the ticket every table / Filter block waits for.  But a
+// class slot's content does not depend on any pod of the batch: the scan query of class c is the leader's pre-allocation + the class's request
+// (core.go:157-159), its Filter parameters the class's request + the leader's MinResources (core.go:526-552, for the batch's leader and for the one
+// carried in) — class request = the class directory's key (ckeys / cpres, kept by bs_pods_load / bs_pods_apply), leaders = leader_epoch[0] and
+// prm.sop_leader0.  One thread per class id writes all three slots write-through; the ticket has as many producers as there are such blocks (one
+// per 256 classes), the pod blocks publish nothing and gate nobody (fast_query_thread<TS, false, false>), and a slot nobody asks about costs a scan /
+// Filter lane, not an answer.
+template <int TS>
+__device__ __forceinline__ void class_slots_block(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, const int64_t* ckeys, const uint32_t* cpres,
+                                                  uint32_t kcap, uint32_t blk) {
+  const Shape<TS> sh(prm.S);
+  const uint32_t gate = prm.eph_gate, K = prm.k_host;
+  const uint32_t c = blk * kTblChunk + threadIdx.x;
+  Res raw;                                                                                 // (the class's key: asked for before the leader chain, which is two dependent trips)
+  const uint32_t cc = c < K ? c : 0u;
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+    if (j < sh.L()) raw.v[j] = ckeys[(size_t)j * kcap + cc];
+  raw.present = cpres[cc];
+  const int32_t leader0 = b.leader_epoch[0];
+  const uint8_t panic0 = b.panic_epoch[0];
+  LeaderPre lp0{}, lp1{};
+  const bool two = prm.run_filter && prm.sop_leader0 >= 0 && prm.sop_leader0 != leader0;
+  if (gr.g) {
+    leader_pre_load(gr, leader0, sh, lp0);
+    if (two) leader_pre_load(gr, prm.sop_leader0, sh, lp1); else lp1 = lp0;
+  }
+  if (c < K) {
+    Res cur;                                                                               // pod_require (core.go:761-772) on the key: the raw lanes through Resource.Add's rule
+    res_zero(cur, sh);
+    res_add(cur, raw, sh, gate);
+    if (leader0 >= 0 && !panic0) {                                                       // core.go:157-166 for every class that could ask
+      Res q;
+      pre_allocated_from(lp0, sh, gate, q);
+      res_add(q, cur, sh, gate);
+      uint32_t absok = 0;
+#pragma unroll
+      for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
+        if (s2 < sh.S()) {
+          const bool pres = q.present & (1u << s2);
+          if (!pres || q.v[4 + s2] == 0) absok |= 1u << s2;       // core.go:688-692
+          if (!pres) q.v[4 + s2] = INT64_MIN;
+        }
+      }
+      int64_t* dst = b.qreq_s + (size_t)c * prm.LP;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+        if (j < prm.LP) st_pub<true>(&dst[j], j < sh.L() ? q.v[j] : (int64_t)INT64_MIN);
+      st_pub<true>(&b.qflags_s[c], q.present | (absok << 16));
+      st_pub<true>(&b.qtab_s[c], (int32_t)0);
+      st_pub<true>(&b.first_row[c], BS_INF);
+      st_pub<true>(&b.qstamp_s[c], prm.stamp);
+    }
+    if (prm.run_filter) {
+      if (leader0 >= 0) filter_slot_from<TS, true>(b, prm, cur, lp0, sh, gate, c);
+      if (prm.sop_leader0 >= 0) filter_slot_from<TS, true>(b, prm, cur, lp1, sh, gate, c + K);
+    }
+  }
+  BS_STAMP(1, 4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  BS_STAMP(1, 5);
+  if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// block layout: [0, qb) pods | (class-slot form: pb class-slot blocks) | then c * nshares + q: chunk c, slot share q | the rest: Filter
 template <int TS>
 __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm, const TableDesc* forced,
                                                            uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks, uint32_t filter_waves,
-                                                           uint32_t ustride, uint32_t tk_pods0, uint32_t tk_tab0) {
+                                                           uint32_t ustride, uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys,
+                                                           const uint32_t* cpres, uint32_t kcap) {
   BS_STAMP(1, 0);
   const uint32_t tb = nchunks * nshares;
+  const uint32_t producers = param_blocks ? param_blocks : query_blocks;      // blocks the slots' ticket waits for
   if (blockIdx.x < query_blocks) {
-    fast_query_thread<TS, true>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
-    BS_STAMP(1, 4);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // slots, Filter parameters, first-reach word: out before the ticket
-    __syncthreads();
-    BS_STAMP(1, 5);
-    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else if (blockIdx.x < query_blocks + tb) {
-    const uint32_t x = blockIdx.x - query_blocks;
-    table_scan_block<TS>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, query_blocks, tk_pods0, tk_tab0);
+    if (param_blocks) {
+      fast_query_thread<TS, false, false>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
+    } else {
+      fast_query_thread<TS, true>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
+      BS_STAMP(1, 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // slots, Filter parameters, first-reach word: out before the ticket
+      __syncthreads();
+      BS_STAMP(1, 5);
+      if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (blockIdx.x < query_blocks + param_blocks) {
+    class_slots_block<TS>(gr, b, prm, ckeys, cpres, kcap, blockIdx.x - query_blocks);
+  } else if (blockIdx.x < query_blocks + param_blocks + tb) {
+    const uint32_t x = blockIdx.x - query_blocks - param_blocks;
+    table_scan_block<TS>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0);
   } else {
     __shared__ uint32_t s_go;
     if (threadIdx.x == 0) {
-      s_go = step_wait(&b.ticket[8], tk_pods0, query_blocks, b.h_err) ? 1u : 0u;
+      s_go = step_wait(&b.ticket[8], tk_pods0, producers, b.h_err) ? 1u : 0u;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the Filter loop reads the slots with plain loads (one lane's acquire + the barrier)
     }
     __syncthreads();
     if (!s_go) return;
-    filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - query_blocks - tb, filter_blocks, prm.stamp, 2u * prm.k_host);
+    filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - query_blocks - param_blocks - tb, filter_blocks, prm.stamp, 2u * prm.k_host);
   }
   BS_STAMP(1, 7);
 }
@@ -1133,8 +1209,13 @@ __global__ __launch_bounds__(256) void k_fast_filter_t(NodesDev nd, BatchDev bt,
 #endif
 // BS_TP_FILTER=6 / 7: both roles in ONE launch again (the scan's dependent-load chains and the Filter loop's compares overlap), the
 // Filter role taken by the transposed item; 7: the Filter blocks carry the LOW block indices (dispatched first)
+// Compiled for FOUR waves per SIMD where that costs next to nothing (round 6): the kernel's footprint is the scan role's (112 VGPRs at S = 0, 136 at
+// S = 1, more beyond), and the Filter role of the throughput regime is bound by the scalar loads its waves keep in flight (bs_filter_t.hpp) — a
+// fourth wave per SIMD is a third more of them.  At S = 1 the limit of 128 VGPRs spills nine dwords to scratch (36 bytes: the ONE listed exception of
+// tests/test_kernel_resources.py; cfg4 all-distinct 140 -> 137 / 211 -> 199 / 325 -> 324 us at one / two / four compared lanes, cfg3 34.5 -> 35.0 /
+// 38.2 -> 37.4 / 50.5 -> 46.1, gpurun_out r06_g_W4 -> profiles/r06_waves4_ab.txt); from S = 2 on it would spill 116+ bytes: left at three.
 template <int S>
-__global__ __launch_bounds__(256) void k_fast_scan_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t scan_blocks,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S <= 1 ? 4 : 1))) void k_fast_scan_filter_t(NodesDev nd, BatchDev bt, BatchParams prm, uint32_t m, uint32_t jcap, uint32_t scan_blocks,
                                                             uint32_t filter_waves, uint32_t ustride, uint32_t form) {
   __shared__ int64_t s_rows[4][64][4 + S];
   const uint32_t filter_first = form & 1u, by_tile = form & 2u;      // (bit 0: BS_TP_FILTER=7; bit 1: the Filter items' order, filter_loop_t)

@@ -265,9 +265,13 @@ struct bs_ctx {
                                      // (an item's prologue — requests, bounds, first node block — is ~4 us whatever its length).
   int fused_blocks_resident = -1;    // whole-chip residency of k_fast_scan_filter_final (blocks), -1 = not asked yet
   int step_a_resident = -1;          // ... of k_fast_step_a
-  bool step_a_on = false;            // BS_STEP_A=1: take the one-launch form of launch A + scan / Filter roles where it applies (measured SLOWER
-                                     // than the two launches: 32 vs 20.7 us at cfg3/tail, DESIGN.md section 4 — kept as a tested experiment, off by default)
-  uint32_t step_shares = 4;          // BS_STEP_SHARES: blocks that share one table chunk's class slots
+  // The one-launch form of launch A + the scan / Filter roles (k_fast_step_a, then k_fast_final), where it applies (the latency regime: at most 256
+  // classes, 64 table chunks, 4 scalar lanes; the second batch over a queue onwards).  BS_STEP_A=2, the DEFAULT since round 6: the class-slot form —
+  // class_slots_block publishes every class's slots from the class directory, the pod blocks gate nobody: 19.05-19.35 us per cfg3/tail step against
+  // 20.5-20.7 for the two-launch chain.  BS_STEP_A=1: round 5's form (every pod block publishes: 32 us, kept as a tested experiment).  BS_STEP_A=0: off.
+  uint32_t step_a_form = 2;
+  bool step_a_on = true;
+  uint32_t step_shares = 8;          // BS_STEP_SHARES: blocks that share one table chunk's class slots (class-slot form, cfg3: 2 / 4 / 8 / 16 shares = 25.1 / 20.4 / 19.05 / 20.9 us per step)
   uint32_t tk_pods = 0, tk_tab = 0;  // values of ticket[8] / ticket[9] the next k_fast_step_a starts from (never reset: wrap-safe differences)
   bool last_step_a = false;
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
@@ -1092,7 +1096,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_TP_FILTER")) c->tp_filter = (uint32_t)std::min(8, std::max(0, std::atoi(e)));
-  if (const char* e = std::getenv("BS_STEP_A")) c->step_a_on = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BS_STEP_A")) { c->step_a_on = std::atoi(e) != 0; c->step_a_form = (uint32_t)std::atoi(e); }
   if (const char* e = std::getenv("BS_STEP_SHARES")) c->step_shares = (uint32_t)std::min(32, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_SHARE")) c->tp_share = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_FWAVES")) c->tp_fwaves = (uint32_t)std::max(1, std::atoi(e));
@@ -2009,7 +2013,7 @@ static inline uint64_t host_ns() {
 }
 // k_fast_step_a (bs_fast.hpp): the one-launch form of launch A + the scan / Filter roles — the latency regime only (K known on the
 // host and <= 256 class slots, <= 64 table chunks), no instrumentation that needs the legacy launches (work counters, per-launch stamps),
-// and a context that has not seen an in-launch hand-over time out.  OFF unless BS_STEP_A=1 (it is correct and slower, see bs_ctx::step_a_on).
+// and a context that has not seen an in-launch hand-over time out.  BS_STEP_A=0 switches it off (bs_ctx::step_a_form).
 static bool step_a_possible(const bs_ctx* c, uint32_t stages, const BatchParams& prm, uint32_t nchunks) {
   return c->step_a_on && !c->no_fuse_final && prm.k_host > 0 && prm.k_host <= kStepSlotsMax && nchunks <= 64 && c->M > 0 && c->P > 0 && !c->collect_stats &&
          c->cfg.enable_timing < 2 && c->S <= 4;
@@ -2059,18 +2063,26 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   if (c->kinfo_pending && ((volatile int32_t*)c->h_info)[5] == c->kinfo_tag && (rc = resolve_pods(c))) return rc;
   prm.k_host = c->kinfo_pending ? 0u : c->h_K;
   const uint64_t hp1 = c->host_probe ? host_ns() : 0;
-  // ---- round 5: launch A and the scan / Filter roles of launch B as ONE launch (k_fast_step_a), then k_fast_final
-  if (step_a_possible(c, stages, prm, nchunks)) {
+  // ---- launch A and the scan / Filter roles of launch B as ONE launch (k_fast_step_a; round 6: its class-slot form is the default), then k_fast_final
+  if (step_a_possible(c, stages, prm, nchunks) && (c->step_a_form == 1u || c->dirs_ready || (c->batch_since_pods && c->pairs_ready && c->rep_valid && c->have_groups))) {
     const uint32_t qb = cdiv(P, kTblChunk);
     const uint32_t K = prm.k_host;
     const uint32_t nshares = std::max<uint32_t>(1, std::min<uint32_t>(c->step_shares, cdiv(K, 8)));
     const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * K, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
-    const uint32_t grid = qb + nchunks * nshares + fblocks;
+    // the class-slot form needs the class directory (ckeys / cpres: class id -> request lanes).  It is built once per derivation of the queue — like bs_pods_apply's first call — and only for a queue that
+    // is scored a SECOND time (a caller that re-uploads its queue every cycle would pay a kernel and a stream wait per cycle for nothing).
+    uint32_t pb = 0;
+    if (c->step_a_form >= 2u) {
+      if (!c->dirs_ready && c->batch_since_pods && c->pairs_ready && c->rep_valid && c->have_groups && (rc = build_dirs(c))) return rc;
+      if (c->dirs_ready) pb = cdiv(K, kTblChunk);
+    }
+    const uint32_t grid = qb + pb + nchunks * nshares + fblocks;
     if ((int)grid <= step_a_residency(c)) {
       TIMED(c, BS_KERNEL_QUERY, {
-        launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks, qb, nshares, fblocks, c->tk_pods, c->tk_tab);
+        launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks, qb, nshares, fblocks, c->tk_pods, c->tk_tab, pb,
+                           c->d_ckeys.as<int64_t>(), c->d_cpres.as<uint32_t>(), c->pair_cap);
       });
-      c->tk_pods += qb;
+      c->tk_pods += pb ? pb : qb;
       c->tk_tab += nchunks;
       TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
       c->launches = 2;

@@ -238,12 +238,15 @@ def test_unfused_final_launch_is_selectable_and_equal(config, scenario, bsa, soa
         assert ctx.stats(soa.STAGE_ALL)["launches"] == 2          # the fused form: the whole grid is resident on this chip
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
 @pytest.mark.parametrize("config,scenario", [("cfg2", "warm"), ("cfg2", "tail"), ("cfg3", "tail"), ("tiny", "busy")])
-def test_one_launch_form_of_the_step_equals_the_oracle(config, scenario, monkeypatch, bsa, soa, orc):
+def test_one_launch_form_of_the_step_equals_the_oracle(config, scenario, form, monkeypatch, bsa, soa, orc):
     """BS_STEP_A=1 (round 5's experiment, off by default because it measured slower): launch A and the scan / Filter roles of launch B as
     ONE launch — the block that builds a table chunk keeps its rows in registers and scans them itself, slots handed over inside the
-    launch (k_fast_step_a) — then k_fast_final.  Same answers, batch after batch, with a queue patch in between."""
-    monkeypatch.setenv("BS_STEP_A", "1")
+    launch (k_fast_step_a) — then k_fast_final.  BS_STEP_A=2 (round 6): the slots come from the class directory (class_slots_block), the pod
+    blocks publish nothing.  Same answers, batch after batch, with queue patches in between (pods leaving; pods with NEW requests arriving:
+    class ids the directory learns from the insert wave)."""
+    monkeypatch.setenv("BS_STEP_A", form)
     nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
@@ -256,3 +259,10 @@ def test_one_launch_form_of_the_step_equals_the_oracle(config, scenario, monkeyp
         exp2 = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(left, soa.STAGE_ALL)
         for _ in range(2):
             assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp2, f"{config}/{scenario} one-launch step after a queue patch")
+        new = left.take(np.arange(min(6, left.p)))
+        new.req[0, :] += 13 + np.arange(new.p)                      # requests nobody had: new class ids
+        ctx.apply_pods(insert=new)
+        grown = left.patched(insert=new, insert_at=None)
+        exp3 = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(grown, soa.STAGE_ALL)
+        for _ in range(2):
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp3, f"{config}/{scenario} one-launch step after new classes arrived")

@@ -19,6 +19,9 @@ HOT = ("k_fast_query_tables", "k_fast_scan_filter_final", "k_fast_scan_filter", 
 KNOWN = {
     "k_seq_pass": "one persistent launch per pass (20 bytes; the generic-lane instantiation 1492): the set-up is paid once per pass (tens of ms)",
     "k_commit": "general chain's commit pass only (144 bytes)",
+    "k_fast_scan_filter_t<1>": "the throughput regime's one-launch form at one scalar lane, compiled for FOUR waves per SIMD (126 VGPRs, nine dwords spilled = 36 bytes): "
+                               "the launch lasts 20-300 us and is bound by what its waves keep in flight; measured faster with the fourth wave than without the spill "
+                               "(bs_fast.hpp, profiles/r06_waves4_ab.txt)",
 }
 
 
@@ -63,4 +66,4 @@ def test_throughput_regime_kernels_keep_their_footprint(bsa):
     for s in range(0, 5):
         both, scan = res[f"k_fast_scan_filter_t<{s}>"], res[f"k_fast_scan<{s}>"]
         waves = lambda v: 512 // (-(-v // 8) * 8)                                      # waves per SIMD the VGPR count admits (granule 8)
-        assert waves(both["vgpr"]) == waves(scan["vgpr"]) and both["vgpr"] <= scan["vgpr"] + 4 and both["scratch"] == 0, (s, both, scan)
+        assert waves(both["vgpr"]) >= waves(scan["vgpr"]) and both["vgpr"] <= scan["vgpr"] + 4 and (both["scratch"] == 0 or s == 1), (s, both, scan)
