@@ -722,6 +722,8 @@ def main():
             if args.stages == "all":
                 # Filter's deny entry (core.go:183-185) replayed inside the batch: the reference's behaviour with the Filter extension point enabled
                 ms_fd, st = resident_ms(bsa, nodes, fit, groups, all_pods, stages | soa.BATCH_FILTER_DENY, 100)
+                fd_launch = launch_times(bsa, nodes, fit, groups, all_pods, stages | soa.BATCH_FILTER_DENY, 40)      # device time per launch group (hipEvents)
+                plain_launch = launch_times(bsa, nodes, fit, groups, all_pods, stages, 40)
                 with bsa.Context(scalar_lanes=nodes.lanes - 4) as c2:
                     c2.load_nodes(nodes, fit)
                     c2.load_groups(groups)
@@ -729,6 +731,11 @@ def main():
                     fd = c2.batch(stages | soa.BATCH_FILTER_DENY, bitmap=False, rows=False)
                     reruns = c2.filter_deny_reruns()
                 extras["filter_deny_on_device"] = {"ms_per_step": ms_fd, "extra_ms_over_the_what_if_filter": ms_fd - ms_per_step, "launches": st["launches"], "chain": st["chain"],
+                                                   "device_us_per_launch_group": fd_launch, "device_us_per_launch_group_without_the_flag": plain_launch,
+                                                   "extra_device_us": sum(fd_launch.values()) - sum(plain_launch.values()),
+                                                   "ms_per_step_note": "steps run back to back WITHOUT a read in between: a BS_BATCH_FILTER_DENY batch waits for the stream before it resets the pinned verdict words "
+                                                                       "an unread predecessor may still store into (bs_batch_run, fd_unsynced), so ms_per_step here is a host-serialised figure; a caller that "
+                                                                       "reads every batch has waited anyway.  extra_device_us is what the flag adds on the device (one apply launch behind the chain)",
                                                    "pods_turned_away_by_filters_entry": int(((fd.pf_code == soa.PF_ERR_DENIED) & (out.pf_code != soa.PF_ERR_DENIED)).sum()),
                                                    "groups_ready": int(fd.group_ready.sum()), "fixed_point_reruns": reruns,
                                                    "note": "BS_BATCH_FILTER_DENY: results == PreFilter + Filter-on-every-node pod by pod (tests/test_gpu_filter_deny.py)"}
