@@ -44,6 +44,7 @@
 #endif
 namespace bs {
 
+template <bool INL = false>
 __device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i, uint32_t nthreads);
 
 // ------------------------------------------------------------------------------------------------
@@ -392,7 +393,7 @@ __device__ __forceinline__ void filter_slot_from(const BatchDev& b, const BatchP
 //   round 1   the pod's own fields (group, flags, owner, request, class, pair) | the batch's leader and panic flag
 //   round 2   the pod's group (flags, OccupiedBy, first owner, first pod) | both leaders' resources (uniform)
 //   round 3   the owner of the group's first owning pod (only where OccupiedBy is still empty)
-template <int TS, bool PUB = false, bool SLOTS = true>
+template <int TS, bool PUB = false, bool SLOTS = true, bool INL = false>
 __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i,
                                                   uint32_t nthreads) {
   const Shape<TS> sh(prm.S);
@@ -410,7 +411,7 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
   const uint32_t pp = pods.p ? b.ppair[ii] : BS_INF;
   Res cur;
   if (pods.p) pod_require(pods, ii, sh, gate, cur); else res_zero(cur, sh);
-  arm_tally(gr, b, prm, i, nthreads);                                  // consumed by launch C
+  arm_tally<INL>(gr, b, prm, i, nthreads);                             // consumed by launch C (INL: by the second half of this launch)
   if (i < 8 && prm.collect_stats) b.stats[i] = 0;
   // ---- round 2
   const bool grouped = valid && gi >= 0 && (uint32_t)gi < gr.g;
@@ -475,7 +476,7 @@ __device__ __forceinline__ void fast_query_thread(const PodsDev& pods, const Gro
     const unsigned long long rb = __ballot(valid && (st & ST_REACH6));
     if (rb && lane_id() == __ffsll((long long)rb) - 1) atomicMin(&s_reach, i);
     __syncthreads();
-    if (threadIdx.x == 0) b.first_reach64[blockIdx.x] = ((unsigned long long)prm.seq_inv << 32) | s_reach;
+    if (threadIdx.x == 0) st_pub<INL>(&b.first_reach64[blockIdx.x], ((unsigned long long)prm.seq_inv << 32) | s_reach);
   }
   BS_STAMP(1, 2);
   // Filter slots: class c with the batch's leader, class c + K with the leader carried into the batch.  Every pod of a
@@ -647,6 +648,27 @@ __device__ __forceinline__ bool step_wait(const uint32_t* word, uint32_t base, u
   }
   return true;
 }
+// Where the tickets of k_fast_step_a live (u32 indices into BatchDev::ticket; every word other blocks poll has a 64-byte line of its own: a poll and an
+// add to one line queue behind each other at the memory side, and with one line for everything the pod blocks' polling of the last counter slowed the
+// table blocks' wait for the first by 1.3 us, profiles/r06_stamps_whole_step.txt).  The two counters with hundreds of adds per launch are spread over
+// kTkWays lines: same-address agent-scope adds complete one after the other (~50 ns each: 200 producers = 10 us on one word).
+constexpr uint32_t kTkSlots = 32, kTkTab = 48, kTkP1 = 64, kTkDone = 64 + 16 * 16, kTkWays = 16, kTkWords = 64 + 2 * 16 * 16;
+__device__ __forceinline__ void spread_add(uint32_t* words, uint32_t who) {
+  (void)__hip_atomic_fetch_add(&words[16u * (who % kTkWays)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the whole of wave 0 calls this: lane l < kTkWays polls way l, the sum is the counter
+__device__ __forceinline__ bool spread_wait(const uint32_t* words, uint32_t base, uint32_t need, int32_t* h_err) {
+  uint32_t spins = 0;
+  for (;;) {
+    uint32_t v = lane_id() < (int)kTkWays ? ld_agent(&words[16u * (uint32_t)lane_id()]) : 0u;
+#pragma unroll
+    for (int o = 1; o < (int)kTkWays; o <<= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    if ((uint32_t)(v - base) >= need) return true;
+    __builtin_amdgcn_s_sleep(4);
+    if (++spins > (1u << 22)) { if (h_err && lane_id() == 0) __hip_atomic_store(h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+  }
+}
 template <int TS>
 __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk, uint32_t nchunks,
                                                  uint32_t share, uint32_t nshares, uint32_t pod_blocks, uint32_t tk_pods0, uint32_t tk_tab0) {
@@ -721,8 +743,8 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
   BS_STAMP(2, 1);
   __shared__ uint32_t s_ok;
   if (threadIdx.x == 0) {
-    if (share == 0) (void)__hip_atomic_fetch_add(&b.ticket[9], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_ok = (step_wait(&b.ticket[9], tk_tab0, nchunks, b.h_err) && step_wait(&b.ticket[8], tk_pods0, pod_blocks, b.h_err)) ? 1u : 0u;
+    if (share == 0) (void)__hip_atomic_fetch_add(&b.ticket[kTkTab], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ok = (step_wait(&b.ticket[kTkTab], tk_tab0, nchunks, b.h_err) && step_wait(&b.ticket[kTkSlots], tk_pods0, pod_blocks, b.h_err)) ? 1u : 0u;
   }
   __syncthreads();
   BS_STAMP(2, 2);
@@ -883,46 +905,9 @@ __device__ __forceinline__ void class_slots_block(const GroupsDev& gr, const Bat
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   BS_STAMP(1, 5);
-  if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[kTkSlots], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// block layout: [0, qb) pods | (class-slot form: pb class-slot blocks) | then c * nshares + q: chunk c, slot share q | the rest: Filter
-template <int TS>
-__global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm, const TableDesc* forced,
-                                                           uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks, uint32_t filter_waves,
-                                                           uint32_t ustride, uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys,
-                                                           const uint32_t* cpres, uint32_t kcap) {
-  BS_STAMP(1, 0);
-  const uint32_t tb = nchunks * nshares;
-  const uint32_t producers = param_blocks ? param_blocks : query_blocks;      // blocks the slots' ticket waits for
-  if (blockIdx.x < query_blocks) {
-    if (param_blocks) {
-      fast_query_thread<TS, false, false>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
-    } else {
-      fast_query_thread<TS, true>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
-      BS_STAMP(1, 4);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // slots, Filter parameters, first-reach word: out before the ticket
-      __syncthreads();
-      BS_STAMP(1, 5);
-      if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  } else if (blockIdx.x < query_blocks + param_blocks) {
-    class_slots_block<TS>(gr, b, prm, ckeys, cpres, kcap, blockIdx.x - query_blocks);
-  } else if (blockIdx.x < query_blocks + param_blocks + tb) {
-    const uint32_t x = blockIdx.x - query_blocks - param_blocks;
-    table_scan_block<TS>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0);
-  } else {
-    __shared__ uint32_t s_go;
-    if (threadIdx.x == 0) {
-      s_go = step_wait(&b.ticket[8], tk_pods0, producers, b.h_err) ? 1u : 0u;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the Filter loop reads the slots with plain loads (one lane's acquire + the barrier)
-    }
-    __syncthreads();
-    if (!s_go) return;
-    filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - query_blocks - param_blocks - tb, filter_blocks, prm.stamp, 2u * prm.k_host);
-  }
-  BS_STAMP(1, 7);
-}
 
 // ------------------------------------------------------------------------------------------------
 // The common ends of a steady-state / positional batch (final blocks of k_fast_scan_filter_final, k_fast_final, k_epoch_final;
@@ -936,12 +921,15 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsD
 //                Sharded / external reduction: fire-and-forget adds into admit[] (the collective and k_ready follow).
 //   final_tail   latency mode only: the LAST block to get here publishes the completion word the host polls.
 // ------------------------------------------------------------------------------------------------
+template <bool INL>
 __device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, uint32_t i, uint32_t nthreads) {
+  // INL (k_fast_step_a, whole step in one launch): the counters are added to and closed by blocks of THIS launch — the zeros go out write-through
+  // (a plain store parked in this XCD's L2 would be written back over the closing lane's value at the end of the launch)
   if (i == 0) __hip_atomic_store(&b.ticket[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // hand-over counter of the fused scan / final launch
   for (uint32_t g = i; g < gr.g; g += nthreads) {
-    b.admit[g] = 0;
+    st_pub<INL>(&b.admit[g], 0u);
     if (prm.do_ready) {
-      b.admit64[g] = 0ull;
+      st_pub<INL>(&b.admit64[g], 0ull);
       if (b.gcount[g] == 0u) {
         const uint8_t rd = gr.matched[g] >= (uint32_t)(gr.min_member[g] - gr.status_scheduled[g]) ? 1 : 0;
         b.ready[g] = rd;
@@ -1030,10 +1018,18 @@ __device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& 
 
 // block `bx` of `nblocks` final blocks; producers > 0: they run in this very launch (k_fast_scan_filter_final) and count themselves
 // into ticket[1] when their results are out — everything that does not depend on them is fetched first
+// INL (k_fast_step_a, the whole step in one launch): the block is a POD block of the same launch that has finished its own first half; what other pod
+// blocks left for it (first-reach words, the pairs' first querying pods, the armed counters) is read after their ticket (ticket[10], base tk_p1), with
+// agent-scope loads; the scan / Filter blocks count themselves into ticket[11] (base tk_done, `producers` of them).
+template <bool INL = false>
 __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchParams& prm,
-                                                 uint32_t query_blocks, uint32_t bx, uint32_t nblocks, uint32_t producers) {
+                                                 uint32_t query_blocks, uint32_t bx, uint32_t nblocks, uint32_t producers, uint32_t tk_p1 = 0, uint32_t tk_done = 0) {
   __shared__ uint32_t s_first_reach;
   BS_STAMP(3, 0);
+  if constexpr (INL) {
+    if (threadIdx.x < 64) (void)spread_wait(&b.ticket[kTkP1], tk_p1, query_blocks, b.h_err);
+    __syncthreads();
+  }
   const uint32_t i = bx * 256u + threadIdx.x;
   const bool valid = i < pods.p;
   // ---- round trip 1: the pod's own fields, and the block's look at the first reaching pod
@@ -1050,7 +1046,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
       const uint32_t bk = b0 + threadIdx.x;
       uint32_t v = BS_INF;
       if (bk < query_blocks) {
-        const unsigned long long w = b.first_reach64[bk];
+        const unsigned long long w = INL ? ld_agent64(&b.first_reach64[bk]) : b.first_reach64[bk];
         if ((uint32_t)(w >> 32) == prm.seq_inv) v = (uint32_t)w;
       }
       const unsigned long long any = __ballot(v != BS_INF);
@@ -1068,7 +1064,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
   unsigned long long head = ~0ull, own_fq = ~0ull, own_next = ~0ull;
   if (walk) {
     head = b.pair_head[gi0];
-    if (pair0 != BS_INF) { own_fq = b.pair_firstq[pair0]; own_next = b.pair_next[pair0]; }
+    if (pair0 != BS_INF) { own_fq = INL ? ld_agent64(&b.pair_firstq[pair0]) : b.pair_firstq[pair0]; own_next = b.pair_next[pair0]; }
   }
   if (producers) {                                   // the scan / Filter blocks of this launch have to be through
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (our own loads first: they overlap the producers, not the wait)
@@ -1080,7 +1076,9 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
     // can never be waiting for a slot a spinning final block holds; the spin is bounded all the same (CU masking, a profiler
     // serialising blocks): on time-out the block raises the context's error word and goes on — the batch is then refused by
     // bs_batch_sync / read / map instead of hanging the GPU.
-    if (threadIdx.x == 0) {
+    if constexpr (INL) {
+      if (threadIdx.x < 64) (void)spread_wait(&b.ticket[kTkDone], tk_done, producers, b.h_err);
+    } else if (threadIdx.x == 0) {
       uint32_t spins = 0;
       while (ld_agent(&b.ticket[1]) < producers) {
         __builtin_amdgcn_s_sleep(2);
@@ -1111,7 +1109,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
         } else {
           for (unsigned long long link = head; (uint32_t)link != BS_INF;) {
             const uint32_t r = (uint32_t)link, cls = (uint32_t)(link >> 32);
-            const unsigned long long pq = b.pair_firstq[r];              // } one round trip: the pair's first querying pod,
+            const unsigned long long pq = INL ? ld_agent64(&b.pair_firstq[r]) : b.pair_firstq[r];   // } one round trip: the pair's first querying pod,
             const uint32_t row = ld_agent(&b.first_row[cls]);            // } its class slot's scan result,
             link = b.pair_next[r];                                       // } the next link
             if ((uint32_t)(pq >> 32) != prm.seq_inv) continue;           // no pod of the pair had a query in this batch
@@ -1262,6 +1260,62 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter_final(PodsDev pods, Gr
     return;
   }
   fast_final_block(pods, gr, nd, b, prm, query_blocks, blockIdx.x - producers, gridDim.x - producers, producers);
+}
+
+// block layout: [0, qb) pods | (class-slot form: pb class-slot blocks) | then c * nshares + q: chunk c, slot share q | the rest: Filter
+template <int TS>
+__global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm, const TableDesc* forced,
+                                                           uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks, uint32_t filter_waves,
+                                                           uint32_t ustride, uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys,
+                                                           const uint32_t* cpres, uint32_t kcap, uint32_t whole, uint32_t tk_p1, uint32_t tk_done) {
+  BS_STAMP(1, 0);
+  const uint32_t tb = nchunks * nshares;
+  const uint32_t producers = param_blocks ? param_blocks : query_blocks;      // blocks the slots' ticket waits for
+  if (blockIdx.x < query_blocks) {
+    if (whole) {
+      // the whole step in this launch: the pod block goes on to its pods' final verdicts (fast_final_block<true>) once every pod block's first half
+      // and every scan / Filter block are through
+      fast_query_thread<TS, false, false, true>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first-reach word, armed counters, the pairs' minima: out before the ticket
+      __syncthreads();
+      if (threadIdx.x == 0) spread_add(&b.ticket[kTkP1], blockIdx.x);
+      fast_final_block<true>(pods, gr, nd, b, prm, query_blocks, blockIdx.x, query_blocks, tb + filter_blocks, tk_p1, tk_done);
+    } else if (param_blocks) {
+      fast_query_thread<TS, false, false>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
+    } else {
+      fast_query_thread<TS, true>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
+      BS_STAMP(1, 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // slots, Filter parameters, first-reach word: out before the ticket
+      __syncthreads();
+      BS_STAMP(1, 5);
+      if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[kTkSlots], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (blockIdx.x < query_blocks + param_blocks) {
+    class_slots_block<TS>(gr, b, prm, ckeys, cpres, kcap, blockIdx.x - query_blocks);
+  } else if (blockIdx.x < query_blocks + param_blocks + tb) {
+    const uint32_t x = blockIdx.x - query_blocks - param_blocks;
+    table_scan_block<TS>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0);
+    if (whole) {                                               // minima performed, then count this block in (a block that timed out never does: the pod blocks time out too)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) spread_add(&b.ticket[kTkDone], blockIdx.x);
+    }
+  } else {
+    __shared__ uint32_t s_go;
+    if (threadIdx.x == 0) {
+      s_go = step_wait(&b.ticket[kTkSlots], tk_pods0, producers, b.h_err) ? 1u : 0u;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the Filter loop reads the slots with plain loads (one lane's acquire + the barrier)
+    }
+    __syncthreads();
+    if (!s_go) return;
+    filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - query_blocks - param_blocks - tb, filter_blocks, prm.stamp, 2u * prm.k_host);
+    if (whole) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) spread_add(&b.ticket[kTkDone], blockIdx.x);
+    }
+  }
+  BS_STAMP(1, 7);
 }
 
 

@@ -27,7 +27,8 @@ int fused_residency_query(const FastLaunch& c);
 // round 5: launch A + the scan / Filter roles in one launch (k_fast_step_a<S>, S <= 4 or the generic-lane instantiation)
 void launch_fast_step_a(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                         const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
-                        uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap);
+                        uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap,
+                        uint32_t whole, uint32_t tk_p1, uint32_t tk_done);
 int step_a_residency_query(const FastLaunch& c);      // blocks of k_fast_scan_filter_final<S> the chip holds at once (0 = unknown)
 
 struct SeqDev;

@@ -273,6 +273,7 @@ struct bs_ctx {
   bool step_a_on = true;
   uint32_t step_shares = 8;          // BS_STEP_SHARES: blocks that share one table chunk's class slots (class-slot form, cfg3: 2 / 4 / 8 / 16 shares = 25.1 / 20.4 / 19.05 / 20.9 us per step)
   uint32_t tk_pods = 0, tk_tab = 0;  // values of ticket[8] / ticket[9] the next k_fast_step_a starts from (never reset: wrap-safe differences)
+  uint32_t tk_p1 = 0, tk_done = 0;   // ... of ticket[10] / ticket[11] (form 3: the pod blocks' first halves, the scan / Filter blocks)
   bool last_step_a = false;
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   uint32_t general_waves = 4096;     // scan grid cap of the general chain (tools/cold_sweep.py)
@@ -1075,8 +1076,8 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   }
   // small counters every load / batch path touches: owned by the context from the start, so no call order
   // between bs_pods_load and bs_groups_load is implied
-  if (c->d_nepochs.reserve(64) != hipSuccess || hipMemset(c->d_nepochs.p, 0, 64) != hipSuccess || c->d_ticket.reserve(64) != hipSuccess ||
-      hipMemset(c->d_ticket.p, 0, 64) != hipSuccess) {
+  if (c->d_nepochs.reserve(64) != hipSuccess || hipMemset(c->d_nepochs.p, 0, 64) != hipSuccess || c->d_ticket.reserve(kTkWords * 4) != hipSuccess ||
+      hipMemset(c->d_ticket.p, 0, kTkWords * 4) != hipSuccess) {
     delete c;
     return BS_ERR_NOMEM;
   }
@@ -2078,14 +2079,21 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     }
     const uint32_t grid = qb + pb + nchunks * nshares + fblocks;
     if ((int)grid <= step_a_residency(c)) {
+      // form 3: the pod blocks go on to the final verdicts inside the same launch (fast_final_block<true>) — one launch for the whole step
+      const uint32_t whole = (c->step_a_form >= 3u && pb) ? 1u : 0u;
       TIMED(c, BS_KERNEL_QUERY, {
         launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks, qb, nshares, fblocks, c->tk_pods, c->tk_tab, pb,
-                           c->d_ckeys.as<int64_t>(), c->d_cpres.as<uint32_t>(), c->pair_cap);
+                           c->d_ckeys.as<int64_t>(), c->d_cpres.as<uint32_t>(), c->pair_cap, whole, c->tk_p1, c->tk_done);
       });
       c->tk_pods += pb ? pb : qb;
       c->tk_tab += nchunks;
-      TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
-      c->launches = 2;
+      if (whole) {
+        c->tk_p1 += qb;
+        c->tk_done += nchunks * nshares + fblocks;
+      } else {
+        TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
+      }
+      c->launches = whole ? 1 : 2;
       c->last_step_a = true;
       if (prm.filter_deny && (rc = launch_filter_deny(c, pd, gr, nd, b, prm, true))) return rc;
       if (commit) {

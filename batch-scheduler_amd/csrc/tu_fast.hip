@@ -135,19 +135,21 @@ void launch_fast_bc(const FastLaunch& c, dim3 grid, const PodsDev& pd, const Gro
 template <int TS>
 static void launch_fast_step_a_s(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                                  const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
-                                 uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap) {
+                                 uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap,
+                        uint32_t whole, uint32_t tk_p1, uint32_t tk_done) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_step_a<TS>), grid, dim3(kTblChunk), 0, c.stream, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks,
-                     c.filter_waves, c.filter_slots_cap, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap);
+                     c.filter_waves, c.filter_slots_cap, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done);
 }
 void launch_fast_step_a(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                         const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
-                        uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap) {
+                        uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap,
+                        uint32_t whole, uint32_t tk_p1, uint32_t tk_done) {
   switch (c.S) {
-    case 0: launch_fast_step_a_s<0>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap); break;
-    case 1: launch_fast_step_a_s<1>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap); break;
-    case 2: launch_fast_step_a_s<2>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap); break;
-    case 3: launch_fast_step_a_s<3>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap); break;
-    default: launch_fast_step_a_s<4>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap); break;
+    case 0: launch_fast_step_a_s<0>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
+    case 1: launch_fast_step_a_s<1>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
+    case 2: launch_fast_step_a_s<2>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
+    case 3: launch_fast_step_a_s<3>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
+    default: launch_fast_step_a_s<4>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
   }
 }
 template <int TS>
