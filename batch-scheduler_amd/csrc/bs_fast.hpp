@@ -365,11 +365,10 @@ __device__ __forceinline__ void pre_allocated_from(const LeaderPre& lp, Shape<TS
   }
   if (out.v[BS_LANE_PODS] == 0) out.v[BS_LANE_PODS] = mm + 1;
 }
-// the Filter slot of (class of `cur`, leader `lp`): computeResourceSatisfied's R = pod + maxSingle, M = maxSingle (core.go:526-552)
-template <int TS, bool PUB = false>
-__device__ __forceinline__ void filter_slot_from(const BatchDev& b, const BatchParams& prm, const Res& cur_in, const LeaderPre& lp, Shape<TS> sh, uint32_t gate,
-                                                 uint32_t slot) {
-  if (!lp.have_mr) return;                                           // PASS_NO_MINRES (core.go:542-544): no slot to evaluate
+// the Filter slot of (class of `cur`, leader `lp`): computeResourceSatisfied's R = pod + maxSingle, M = maxSingle (core.go:526-552); ff bit 0: case 2 can
+// never hold, bit 1: every node "cannot hold" a leader member
+template <int TS>
+__device__ __forceinline__ uint32_t filter_slot_values(const Res& cur_in, const LeaderPre& lp, Shape<TS> sh, uint32_t gate, int64_t (&R)[4], int64_t (&M)[4]) {
   Res ms, cur = cur_in;
   res_zero(ms, sh);
   res_add(ms, lp.mr, sh, gate);                                      // :526-527
@@ -382,11 +381,38 @@ __device__ __forceinline__ void filter_slot_from(const BatchDev& b, const BatchP
       if ((ms.present & (1u << s)) && ms.v[4 + s] != 0) ff |= 2u;    // node "cannot hold" a leader member
     }
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { R[j] = cur.v[j]; M[j] = ms.v[j]; }
+  return ff;
+}
+template <int TS, bool PUB = false>
+__device__ __forceinline__ void filter_slot_from(const BatchDev& b, const BatchParams& prm, const Res& cur_in, const LeaderPre& lp, Shape<TS> sh, uint32_t gate,
+                                                 uint32_t slot) {
+  if (!lp.have_mr) return;                                           // PASS_NO_MINRES (core.go:542-544): no slot to evaluate
+  int64_t R[4], M[4];
+  const uint32_t ff = filter_slot_values(cur_in, lp, sh, gate, R, M);
   st_pub<PUB>(&b.fu_feas[slot], 0u);
   int64_t* dst2 = b.uparams + (size_t)slot * 8;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { st_pub<PUB>(&dst2[j], cur.v[j]); st_pub<PUB>(&dst2[4 + j], ms.v[j]); }
+  for (int j = 0; j < 4; ++j) { st_pub<PUB>(&dst2[j], R[j]); st_pub<PUB>(&dst2[4 + j], M[j]); }
   st_pub<PUB>(&b.uflags[slot], ff | ((uint32_t)BS_FL_EVALUATED << 8) | (prm.stamp << 16));      // (the stamp goes last)
+}
+// the scan query of a class against the batch's leader (core.go:157-159): pre-allocation + the class's request; returns the slot's flags word
+// (present | absok << 16), scalar keys nobody asks for become INT64_MIN (never constrain)
+template <int TS>
+__device__ __forceinline__ uint32_t class_scan_query(const Res& cur, const LeaderPre& lp0, Shape<TS> sh, uint32_t gate, Res& q) {
+  pre_allocated_from(lp0, sh, gate, q);
+  res_add(q, cur, sh, gate);
+  uint32_t absok = 0;
+#pragma unroll
+  for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
+    if (s2 < sh.S()) {
+      const bool pres = q.present & (1u << s2);
+      if (!pres || q.v[4 + s2] == 0) absok |= 1u << s2;       // core.go:688-692
+      if (!pres) q.v[4 + s2] = INT64_MIN;
+    }
+  }
+  return q.present | (absok << 16);
 }
 
 // Three rounds of loads, issued as early as their addresses are known, then arithmetic, then stores:
@@ -669,9 +695,13 @@ __device__ __forceinline__ bool spread_wait(const uint32_t* words, uint32_t base
     if (++spins > (1u << 22)) { if (h_err && lane_id() == 0) __hip_atomic_store(h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
   }
 }
-template <int TS>
+// REGS (the whole step in one launch, BS_STEP_A=3): the block derives its share's scan queries ITSELF from the class directory and the leader
+// (class_scan_query: what class_slots_block publishes) while it waits for the chunk totals — it waits for no slot ticket and fetches no slot; the first
+// rows go to first_row64[] as 64-bit minima keyed by ~batch_seq (never reset: the block that would reset them is not waited for either).
+template <int TS, bool REGS = false>
 __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk, uint32_t nchunks,
-                                                 uint32_t share, uint32_t nshares, uint32_t pod_blocks, uint32_t tk_pods0, uint32_t tk_tab0) {
+                                                 uint32_t share, uint32_t nshares, uint32_t pod_blocks, uint32_t tk_pods0, uint32_t tk_tab0, const GroupsDev& gr,
+                                                 const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap) {
   __shared__ unsigned long long s_wtot[BS_MAX_LANES][4];
   __shared__ uint32_t s_kp[BS_MAX_SCALARS];
   __shared__ unsigned long long s_off[BS_MAX_LANES];
@@ -696,6 +726,23 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
       al[j] = nd.alloc[(size_t)j * nd.stride + n];
       rq[j] = nd.req[(size_t)j * nd.stride + n];
     }
+  }
+  // REGS: the share's class keys and the leader, asked for together with the node lanes
+  const uint32_t K = prm.k_host;
+  const uint32_t per = (K + nshares - 1u) / nshares, s_lo = share * per, s_hi = min(K, s_lo + per);
+  Res raw;
+  int32_t leader0 = -1;
+  uint8_t panic0 = 0;
+  LeaderPre lp0{};
+  if constexpr (REGS) {
+    const uint32_t cc = s_lo + threadIdx.x < s_hi ? s_lo + threadIdx.x : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < L) raw.v[j] = ckeys[(size_t)j * kcap + cc];
+    raw.present = cpres[cc];
+    leader0 = b.leader_epoch[0];
+    panic0 = b.panic_epoch[0];
+    if (gr.g) leader_pre_load(gr, leader0, sh, lp0);
   }
   const bool fit = valid && ((fw >> (n & 31u)) & 1u) && !(fl & BS_NODE_TAINT_ERR);
   const uint32_t pres = fit ? (ap & rp) : 0u;
@@ -744,14 +791,32 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
   __shared__ uint32_t s_ok;
   if (threadIdx.x == 0) {
     if (share == 0) (void)__hip_atomic_fetch_add(&b.ticket[kTkTab], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_ok = (step_wait(&b.ticket[kTkTab], tk_tab0, nchunks, b.h_err) && step_wait(&b.ticket[kTkSlots], tk_pods0, pod_blocks, b.h_err)) ? 1u : 0u;
   }
+  if constexpr (REGS) {
+    // the share's scan queries -> LDS (one slot per thread), in the shadow of the other chunks' totals
+    const uint32_t t = s_lo + threadIdx.x;
+    if (t < s_hi) {
+      uint32_t qf = 0x80000000u;
+      Res q;
+      res_zero(q, sh);
+      if (leader0 >= 0 && !panic0) {                                                     // core.go:157-166 for every class that could ask
+        Res cur;
+        res_zero(cur, sh);
+        res_add(cur, raw, sh, prm.eph_gate);
+        qf = class_scan_query(cur, lp0, sh, prm.eph_gate, q);
+      }
+      s_qf[threadIdx.x] = qf;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+        if (j < L) s_req[threadIdx.x][j] = q.v[j];
+    }
+  }
+  if (threadIdx.x == 0)
+    s_ok = (step_wait(&b.ticket[kTkTab], tk_tab0, nchunks, b.h_err) && (REGS || step_wait(&b.ticket[kTkSlots], tk_pods0, pod_blocks, b.h_err))) ? 1u : 0u;
   __syncthreads();
   BS_STAMP(2, 2);
   if (!s_ok) return;
   // ---- this block's slots -> LDS; the chunk's offset and the table's first key rows (wave 0: lane <-> chunk)
-  const uint32_t K = prm.k_host;
-  const uint32_t per = (K + nshares - 1u) / nshares, s_lo = share * per, s_hi = min(K, s_lo + per);
   {
     // one round trip for everything: wave 0's lanes take the chunk totals / key rows (lane <-> chunk), every thread a slot of the share
     const uint32_t ch = (uint32_t)lane_id();
@@ -767,7 +832,7 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
     uint32_t stp = 0, qf = 0x80000000u;
     int32_t tab = -1;
     unsigned long long rv[BS_MAX_LANES];
-    if (t < s_hi) {
+    if (!REGS && t < s_hi) {
       stp = ld_agent(&b.qstamp_s[t]);
       tab = (int32_t)ld_agent(reinterpret_cast<const uint32_t*>(&b.qtab_s[t]));
       qf = ld_agent(&b.qflags_s[t]);
@@ -791,7 +856,7 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
         }
       }
     }
-    if (t < s_hi) {                                          // (per <= 256: one slot per thread)
+    if (!REGS && t < s_hi) {                                 // (per <= 256: one slot per thread)
       if (stp != prm.stamp || tab != 0) qf = 0x80000000u;    // not written by a pod of THIS batch: no query
       s_qf[threadIdx.x] = qf;
 #pragma unroll
@@ -837,9 +902,66 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
   }
   __syncthreads();
   BS_STAMP(2, 4);
-  for (uint32_t t = threadIdx.x; t < nmine; t += kTblChunk)
-    if (s_first[t] != BS_INF) atomicMin(&b.first_row[s_lo + t], s_first[t]);
+  for (uint32_t t = threadIdx.x; t < nmine; t += kTblChunk) {
+    if (s_first[t] == BS_INF) continue;
+    if constexpr (REGS) atomicMin(&b.first_row64[s_lo + t], ((unsigned long long)prm.seq_inv << 32) | s_first[t]);
+    else atomicMin(&b.first_row[s_lo + t], s_first[t]);
+  }
   BS_STAMP(2, 7);
+}
+
+// The Filter role of the whole-step launch: the work loop of filter_loop<2> (same item order, same split) with the tile's slots derived on the spot —
+// lane = slot: class c = slot mod K, leader = the batch's (slots [0, K)) or the one carried in (slots [K, 2K)); what class_slots_block writes into
+// uflags[] / uparams[] for that slot, computed from the class directory and the leader's MinResources (filter_slot_values), never read back.
+template <int TS>
+__device__ __forceinline__ void step_filter_block(const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const int64_t* ckeys,
+                                                  const uint32_t* cpres, uint32_t kcap, uint32_t target_waves, uint32_t ustride, uint32_t bx, uint32_t nblocks,
+                                                  uint32_t tk_slots0, uint32_t slot_producers) {
+  const Shape<TS> sh(prm.S);
+  const uint32_t gate = prm.eph_gate, K = prm.k_host, U = 2u * K;
+  const uint32_t W = (nd.n + 63u) / 64u;
+  if (!U || !W) return;
+  const uint32_t tiles = (U + 63u) / 64u;
+  uint32_t nsplit = max(1u, target_waves / tiles);
+  nsplit = min(nsplit, max((W + 1u) / 2u, 1u));
+  const uint32_t bpw = max(2u, (((W + nsplit - 1u) / nsplit + 1u) / 2u) * 2u);
+  const uint32_t nchunk = (W + bpw - 1u) / bpw;
+  const uint32_t items = tiles * nchunk;
+  const int32_t leader0 = b.leader_epoch[0];
+  LeaderPre lp0{}, lp1{};
+  const bool two = prm.sop_leader0 >= 0 && prm.sop_leader0 != leader0;
+  if (gr.g) {
+    leader_pre_load(gr, leader0, sh, lp0);
+    if (two) leader_pre_load(gr, prm.sop_leader0, sh, lp1); else lp1 = lp0;
+  }
+  bool waited = false;
+  for (uint32_t it = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()); it < items; it += nblocks * 4u) {
+    const uint32_t chunk = it / tiles, tile = it - chunk * tiles;
+    const uint32_t src = tile * 64u + (uint32_t)lane_id();
+    const bool second = src >= K;
+    const uint32_t c = src < U ? (second ? src - K : src) : 0u;
+    Res raw;
+#pragma unroll
+    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+      if (j < sh.L()) raw.v[j] = ckeys[(size_t)j * kcap + c];
+    raw.present = cpres[c];
+    Res cur;
+    res_zero(cur, sh);
+    res_add(cur, raw, sh, gate);
+    LeaderPre lp = lp0;
+    if (second) lp = lp1;
+    const bool on = src < U && (second ? prm.sop_leader0 >= 0 : leader0 >= 0) && lp.have_mr;      // class_slots_block / filter_slot_from: who gets a slot
+    int64_t R[4], M[4];
+    const uint32_t ff = filter_slot_values(cur, lp, sh, gate, R, M);
+    uint32_t cnt = 0;
+    filter_item<2, 4, true, true>(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), 0u,
+                                  on ? (ff | ((uint32_t)BS_FL_EVALUATED << 8)) : ((uint32_t)BS_FL_NOT_RUN << 8), R, M, &cnt);
+    if (!waited) {                                    // the counters were zeroed by the class-slot block: long through by now, one look
+      (void)step_wait(&b.ticket[kTkSlots], tk_slots0, slot_producers, b.h_err);
+      waited = true;
+    }
+    if (src < U && cnt) atomicAdd(&b.fu_feas[src], cnt);
+  }
 }
 
 // Round 6, the class-slot form of the one-launch step (BS_STEP_A=2).  What made round 5's form slow was WHO publishes the slots: every pod block
@@ -876,22 +998,12 @@ __device__ __forceinline__ void class_slots_block(const GroupsDev& gr, const Bat
     res_add(cur, raw, sh, gate);
     if (leader0 >= 0 && !panic0) {                                                       // core.go:157-166 for every class that could ask
       Res q;
-      pre_allocated_from(lp0, sh, gate, q);
-      res_add(q, cur, sh, gate);
-      uint32_t absok = 0;
-#pragma unroll
-      for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
-        if (s2 < sh.S()) {
-          const bool pres = q.present & (1u << s2);
-          if (!pres || q.v[4 + s2] == 0) absok |= 1u << s2;       // core.go:688-692
-          if (!pres) q.v[4 + s2] = INT64_MIN;
-        }
-      }
+      const uint32_t qfw = class_scan_query(cur, lp0, sh, gate, q);
       int64_t* dst = b.qreq_s + (size_t)c * prm.LP;
 #pragma unroll
       for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
         if (j < prm.LP) st_pub<true>(&dst[j], j < sh.L() ? q.v[j] : (int64_t)INT64_MIN);
-      st_pub<true>(&b.qflags_s[c], q.present | (absok << 16));
+      st_pub<true>(&b.qflags_s[c], qfw);
       st_pub<true>(&b.qtab_s[c], (int32_t)0);
       st_pub<true>(&b.first_row[c], BS_INF);
       st_pub<true>(&b.qstamp_s[c], prm.stamp);
@@ -1089,8 +1201,12 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
   __syncthreads();
   BS_STAMP(3, 1);
   // ---- round trip 2b: the pod's scan slot's result, both Filter slots' feasible counts
-  if (owned && (st0 & ST_QUERY)) row_q = ld_agent(&b.first_row[qpos0]);
-  if (walk) row_c = ld_agent(&b.first_row[pclass0]);
+  auto keyed_row = [&](uint32_t slot) -> uint32_t {                 // INL: first_row64[], a 64-bit minimum keyed by ~batch_seq
+    const unsigned long long w = ld_agent64(&b.first_row64[slot]);
+    return (uint32_t)(w >> 32) == prm.seq_inv ? (uint32_t)w : BS_INF;
+  };
+  if (owned && (st0 & ST_QUERY)) row_q = INL ? keyed_row(qpos0) : ld_agent(&b.first_row[qpos0]);
+  if (walk) row_c = INL ? keyed_row(pclass0) : ld_agent(&b.first_row[pclass0]);
   if (valid && prm.run_filter && grouped) { feas0 = ld_agent(&b.fu_feas[pclass0]); feas1 = ld_agent(&b.fu_feas[pclass0 + K]); }
   bool admit = false;
   if (valid) {
@@ -1110,7 +1226,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
           for (unsigned long long link = head; (uint32_t)link != BS_INF;) {
             const uint32_t r = (uint32_t)link, cls = (uint32_t)(link >> 32);
             const unsigned long long pq = INL ? ld_agent64(&b.pair_firstq[r]) : b.pair_firstq[r];   // } one round trip: the pair's first querying pod,
-            const uint32_t row = ld_agent(&b.first_row[cls]);            // } its class slot's scan result,
+            const uint32_t row = INL ? keyed_row(cls) : ld_agent(&b.first_row[cls]);   // } its class slot's scan result,
             link = b.pair_next[r];                                       // } the next link
             if ((uint32_t)(pq >> 32) != prm.seq_inv) continue;           // no pod of the pair had a query in this batch
             const uint32_t fq = (uint32_t)pq;
@@ -1263,18 +1379,24 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter_final(PodsDev pods, Gr
 }
 
 // block layout: [0, qb) pods | (class-slot form: pb class-slot blocks) | then c * nshares + q: chunk c, slot share q | the rest: Filter
-template <int TS>
+// WHOLE (BS_STEP_A=3, needs the class-slot form): the whole step in this launch.
+//   pod blocks    first half as before (publishing nothing but their first-reach word and the armed counters, write-through), ticket kTkP1; then the
+//                 block goes on to its pods' final verdicts (fast_final_block<true>) once every pod block's first half and every table / Filter block
+//                 (ticket kTkDone) are through
+//   table blocks  derive their share's scan queries themselves (table_scan_block<TS, true>): they wait for the chunk totals only
+//   Filter blocks derive their tile's slots themselves (class directory + leaders -> filter_slot_values), run the item on registers, and only their
+//                 closing add to fu_feas[] waits for the class-slot block (which still publishes every slot for whoever reads them after the launch,
+//                 and zeroes those counters)
+template <int TS, bool WHOLE>
 __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm, const TableDesc* forced,
                                                            uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks, uint32_t filter_waves,
                                                            uint32_t ustride, uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys,
-                                                           const uint32_t* cpres, uint32_t kcap, uint32_t whole, uint32_t tk_p1, uint32_t tk_done) {
+                                                           const uint32_t* cpres, uint32_t kcap, uint32_t tk_p1, uint32_t tk_done) {
   BS_STAMP(1, 0);
   const uint32_t tb = nchunks * nshares;
   const uint32_t producers = param_blocks ? param_blocks : query_blocks;      // blocks the slots' ticket waits for
   if (blockIdx.x < query_blocks) {
-    if (whole) {
-      // the whole step in this launch: the pod block goes on to its pods' final verdicts (fast_final_block<true>) once every pod block's first half
-      // and every scan / Filter block are through
+    if constexpr (WHOLE) {
       fast_query_thread<TS, false, false, true>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first-reach word, armed counters, the pairs' minima: out before the ticket
       __syncthreads();
@@ -1294,12 +1416,17 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsD
     class_slots_block<TS>(gr, b, prm, ckeys, cpres, kcap, blockIdx.x - query_blocks);
   } else if (blockIdx.x < query_blocks + param_blocks + tb) {
     const uint32_t x = blockIdx.x - query_blocks - param_blocks;
-    table_scan_block<TS>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0);
-    if (whole) {                                               // minima performed, then count this block in (a block that timed out never does: the pod blocks time out too)
+    table_scan_block<TS, WHOLE>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0, gr, ckeys, cpres, kcap);
+    if constexpr (WHOLE) {                                     // minima performed, then count this block in (a block that timed out never does: the pod blocks time out too)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0) spread_add(&b.ticket[kTkDone], blockIdx.x);
     }
+  } else if constexpr (WHOLE) {
+    step_filter_block<TS>(gr, nd, bt, prm, ckeys, cpres, kcap, filter_waves, ustride, blockIdx.x - query_blocks - param_blocks - tb, filter_blocks, tk_pods0, producers);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) spread_add(&b.ticket[kTkDone], blockIdx.x);
   } else {
     __shared__ uint32_t s_go;
     if (threadIdx.x == 0) {
@@ -1309,11 +1436,6 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsD
     __syncthreads();
     if (!s_go) return;
     filter_loop<2>(pods, nd, bt, filter_waves, 1u, ustride, prm.collect_stats, blockIdx.x - query_blocks - param_blocks - tb, filter_blocks, prm.stamp, 2u * prm.k_host);
-    if (whole) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (threadIdx.x == 0) spread_add(&b.ticket[kTkDone], blockIdx.x);
-    }
   }
   BS_STAMP(1, 7);
 }

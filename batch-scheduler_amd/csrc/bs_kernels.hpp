@@ -99,6 +99,7 @@ struct BatchDev {
   uint8_t* stage;
   int32_t* leader_raw;      // leader findMaxPG returned for this pod (valid iff ST_REACH6)
   uint32_t* first_row;      // [scan slots] min table row satisfying the slot's request (INF none)
+  unsigned long long* first_row64;  // [scan slots] the same as a 64-bit minimum keyed by ~batch_seq (k_fast_step_a's whole-step form: never reset)
   int64_t* qreq_s;          // [scan slots][LP] effective request (absent scalar -> INT64_MIN)
   uint32_t* qflags_s;       // [scan slots] bits 0..11 request key present, bits 16..27 "zero/absent" (passes w/o left key)
   uint32_t* qpos;           // [P] pod -> scan slot (valid iff ST_QUERY)
@@ -1903,9 +1904,13 @@ __device__ __forceinline__ void filter_pod_loop(uint32_t np, const int64_t (*sR)
 // stamp != 0 (fast path): a slot is in use iff the stamp in bits 16.. of its flags word is this batch's.
 // DB: the node blocks of step w+NB are loaded during the pod loop of step w (double-buffered, 18 VGPRs); !DB: behind it (the lean
 // throughput-regime kernel: other resident waves cover the round trip)
-template <int NB, int PU = 4, bool DB = true>
+// REGS (k_fast_step_a's whole-step form): the lane's slot — flags word (stamp already resolved), R, M — comes in registers from the caller, nothing of
+// the slot arrays is read, and the slot's feasible count is handed back (*cnt_out) instead of being added to fu_feas[] (the caller adds it once the
+// block that zeroes the counters is through).
+template <int NB, int PU = 4, bool DB = true, bool REGS = false>
 __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& b, uint32_t U, uint32_t ustride, uint32_t ptile,
-                                            uint32_t w0, uint32_t w1, uint32_t stamp = 0) {
+                                            uint32_t w0, uint32_t w1, uint32_t stamp = 0, uint32_t ff_in = 0, const int64_t* R_in = nullptr,
+                                            const int64_t* M_in = nullptr, uint32_t* cnt_out = nullptr) {
   static_assert(NB == 2, "the inner statement handles two node blocks");
   typedef const __attribute__((address_space(4))) uint32_t* cflag_t;
   const int lane = lane_id();
@@ -1919,9 +1924,16 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
   // Everything this item needs from memory before it can compare is issued in ONE round trip: the slot's flags word, its
   // request R and leader request M, the cluster-wide bounds, and the first two node blocks (they do not depend on the
   // slots; a tile without a live slot has loaded them for nothing, which costs less than a second trip costs the rest).
-  uint32_t myff = mine ? b.uflags[src] : ((uint32_t)BS_FL_NOT_RUN << 8);
+  uint32_t myff = (uint32_t)BS_FL_NOT_RUN << 8;
   int64_t M[4] = {0, 0, 0, 0}, myR[4] = {0, 0, 0, 0};
-  if (mine) {
+  if constexpr (REGS) {
+    if (mine) {
+      myff = ff_in;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { myR[j] = R_in[j]; M[j] = M_in[j]; }
+    }
+  } else if (mine) {
+    myff = b.uflags[src];
     const int64_t* rs = b.uparams + (size_t)src * 8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { myR[j] = rs[j]; M[j] = rs[4 + j]; }
@@ -1948,7 +1960,7 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
     }
   };
   load_blocks(w0, l, nfl);
-  if (stamp) myff = (myff >> 16) == stamp ? (myff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
+  if (!REGS && stamp) myff = (myff >> 16) == stamp ? (myff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
   const uint32_t myfl = myff >> 8;
   const bool ev = myfl == BS_FL_EVALUATED;
   if (!ev) {
@@ -2059,18 +2071,26 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
       // generic path: per-pod leader request (tile straddles a capture); plain ballots
       for (uint32_t pp = 0; pp < np; ++pp) {
         const uint32_t p = p0 + pp;
-        uint32_t ff = FF[p];
-        if (stamp) ff = (ff >> 16) == stamp ? (ff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
+        uint32_t ff;
+        int64_t fp[8];
+        if constexpr (REGS) {                          // the slot of lane pp, broadcast (pp is uniform)
+          ff = (uint32_t)__shfl((int)myff, (int)pp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { fp[j] = __shfl(myR[j], (int)pp); fp[4 + j] = __shfl(M[j], (int)pp); }
+        } else {
+          ff = FF[p];
+          if (stamp) ff = (ff >> 16) == stamp ? (ff & 0xFFFFu) : ((uint32_t)BS_FL_NOT_RUN << 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) fp[j] = FP[(size_t)p * 8 + j];
+        }
         const uint32_t fl = ff >> 8;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           unsigned long long word;
           if (fl == BS_FL_EVALUATED) {
             unsigned long long c2 = 0, lf = 0;
-            if (!(ff & 1u)) c2 = __ballot(l[nb][0] >= FP[(size_t)p * 8 + 0]) & __ballot(l[nb][1] >= FP[(size_t)p * 8 + 1]) &
-                                 __ballot(l[nb][2] >= FP[(size_t)p * 8 + 2]) & __ballot(l[nb][3] >= FP[(size_t)p * 8 + 3]);
-            if (!(ff & 2u)) lf = __ballot(l[nb][0] >= FP[(size_t)p * 8 + 4]) & __ballot(l[nb][1] >= FP[(size_t)p * 8 + 5]) &
-                                 __ballot(l[nb][2] >= FP[(size_t)p * 8 + 6]) & __ballot(l[nb][3] >= FP[(size_t)p * 8 + 7]);
+            if (!(ff & 1u)) c2 = __ballot(l[nb][0] >= fp[0]) & __ballot(l[nb][1] >= fp[1]) & __ballot(l[nb][2] >= fp[2]) & __ballot(l[nb][3] >= fp[3]);
+            if (!(ff & 2u)) lf = __ballot(l[nb][0] >= fp[4]) & __ballot(l[nb][1] >= fp[5]) & __ballot(l[nb][2] >= fp[6]) & __ballot(l[nb][3] >= fp[7]);
             word = okmask[nb] & (c2 | ~lf);
           } else {
             word = fl < 16u ? in_range[nb] : 0ull;
@@ -2100,7 +2120,8 @@ __device__ __forceinline__ void filter_item(const NodesDev& nd, const BatchDev& 
       if (w + NB < w1) load_blocks(w + NB, l, nfl);
     }
   }
-  if (mine && cnt) atomicAdd(&b.fu_feas[p0 + lane], cnt);
+  if constexpr (REGS) *cnt_out = mine ? cnt : 0u;
+  else if (mine && cnt) atomicAdd(&b.fu_feas[p0 + lane], cnt);
 }
 
 // Work loop over (tile of 64 request slots, run of node blocks).  The slot count is only known on the

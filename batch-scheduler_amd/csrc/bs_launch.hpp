@@ -29,7 +29,7 @@ void launch_fast_step_a(const FastLaunch& c, dim3 grid, const PodsDev& pd, const
                         const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
                         uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap,
                         uint32_t whole, uint32_t tk_p1, uint32_t tk_done);
-int step_a_residency_query(const FastLaunch& c);      // blocks of k_fast_scan_filter_final<S> the chip holds at once (0 = unknown)
+int step_a_residency_query(const FastLaunch& c, bool whole);      // blocks of k_fast_scan_filter_final<S> the chip holds at once (0 = unknown)
 
 struct SeqDev;
 struct SeqParams;

@@ -185,7 +185,7 @@ struct bs_ctx {
   // ---- batch scratch / outputs
   DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
   DevBuf d_epoch, d_nepochs, d_leader_epoch, d_panic_epoch;
-  DevBuf d_tcode, d_stage, d_leader_raw, d_first_row, d_qreq_s, d_qflags_s, d_qpos;
+  DevBuf d_tcode, d_stage, d_leader_raw, d_first_row, d_first_row64, d_qreq_s, d_qflags_s, d_qpos;
   DevBuf d_needed, d_qcount, d_ticket, d_desc;
   bool scratch_armed = false;
   bool side_ready = false;      // desc[] of the steady-state table is in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
@@ -264,7 +264,7 @@ struct bs_ctx {
                                      // waves.  cfg4 all-distinct, rank 0 of 8 (profiles/r05_shard_scaling.md): 60 us at x2, 63 at x4, 74 at x8
                                      // (an item's prologue — requests, bounds, first node block — is ~4 us whatever its length).
   int fused_blocks_resident = -1;    // whole-chip residency of k_fast_scan_filter_final (blocks), -1 = not asked yet
-  int step_a_resident = -1;          // ... of k_fast_step_a
+  int step_a_resident[2] = {-1, -1};          // ... of k_fast_step_a
   // The one-launch form of launch A + the scan / Filter roles (k_fast_step_a, then k_fast_final), where it applies (the latency regime: at most 256
   // classes, 64 table chunks, 4 scalar lanes; the second batch over a queue onwards).  BS_STEP_A=2, the DEFAULT since round 6: the class-slot form —
   // class_slots_block publishes every class's slots from the class directory, the pod blocks gate nobody: 19.05-19.35 us per cfg3/tail step against
@@ -453,6 +453,7 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.stage = c->d_stage.as<uint8_t>();
   b.leader_raw = c->d_leader_raw.as<int32_t>();
   b.first_row = c->d_first_row.as<uint32_t>();
+  b.first_row64 = c->d_first_row64.as<unsigned long long>();
   b.qreq_s = c->d_qreq_s.as<int64_t>();
   b.qflags_s = c->d_qflags_s.as<uint32_t>();
   b.qpos = c->d_qpos.as<uint32_t>();
@@ -1908,6 +1909,7 @@ static int reserve_slots(bs_ctx* c, bool run_filter) {
     filter_cap += filter_cap / 2;
   int rc;
   HIPCHK(c, c->d_first_row.reserve((size_t)scan_cap * 4));
+  if ((rc = reserve_filled(c, c->d_first_row64, (size_t)scan_cap * 8, 0xFF))) return rc;      // 64-bit minima keyed by ~batch_seq: born as "none", never reset
   HIPCHK(c, c->d_qreq_s.reserve((size_t)scan_cap * c->LP * 8));
   HIPCHK(c, c->d_qflags_s.reserve((size_t)scan_cap * 4));
   HIPCHK(c, c->d_qtab_s.reserve((size_t)scan_cap * 4));
@@ -2019,9 +2021,10 @@ static bool step_a_possible(const bs_ctx* c, uint32_t stages, const BatchParams&
   return c->step_a_on && !c->no_fuse_final && prm.k_host > 0 && prm.k_host <= kStepSlotsMax && nchunks <= 64 && c->M > 0 && c->P > 0 && !c->collect_stats &&
          c->cfg.enable_timing < 2 && c->S <= 4;
 }
-static int step_a_residency(bs_ctx* c) {
-  if (c->step_a_resident < 0) c->step_a_resident = step_a_residency_query(fast_launch(c));
-  return c->step_a_resident;
+static int step_a_residency(bs_ctx* c, bool whole) {
+  int& r = c->step_a_resident[whole ? 1 : 0];
+  if (r < 0) r = step_a_residency_query(fast_launch(c), whole);
+  return r;
 }
 
 // The steady-state chain (bs_fast.hpp): three launches, nothing reset, no wait.
@@ -2078,9 +2081,9 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       if (c->dirs_ready) pb = cdiv(K, kTblChunk);
     }
     const uint32_t grid = qb + pb + nchunks * nshares + fblocks;
-    if ((int)grid <= step_a_residency(c)) {
-      // form 3: the pod blocks go on to the final verdicts inside the same launch (fast_final_block<true>) — one launch for the whole step
-      const uint32_t whole = (c->step_a_form >= 3u && pb) ? 1u : 0u;
+    // form 3: the pod blocks go on to the final verdicts inside the same launch (fast_final_block<true>) — one launch for the whole step
+    const uint32_t whole = (c->step_a_form >= 3u && pb && c->d_first_row64.p) ? 1u : 0u;
+    if ((int)grid <= step_a_residency(c, whole != 0)) {
       TIMED(c, BS_KERNEL_QUERY, {
         launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks, qb, nshares, fblocks, c->tk_pods, c->tk_tab, pb,
                            c->d_ckeys.as<int64_t>(), c->d_cpres.as<uint32_t>(), c->pair_cap, whole, c->tk_p1, c->tk_done);
@@ -2407,6 +2410,7 @@ static int batch_run_inner(bs_ctx* c, uint32_t stages) {
   if (c->rekey_pending) {
     if (c->d_pair_firstq.p) HIPCHK(c, hipMemsetAsync(c->d_pair_firstq.p, 0xFF, c->d_pair_firstq.cap, c->stream));
     if (c->d_first_reach.p) HIPCHK(c, hipMemsetAsync(c->d_first_reach.p, 0xFF, c->d_first_reach.cap, c->stream));
+    if (c->d_first_row64.p) HIPCHK(c, hipMemsetAsync(c->d_first_row64.p, 0xFF, c->d_first_row64.cap, c->stream));
     if (c->d_gfirstq.p) HIPCHK(c, hipMemsetAsync(c->d_gfirstq.p, 0xFF, c->d_gfirstq.cap, c->stream));
     if (c->d_fd_event.p) HIPCHK(c, hipMemsetAsync(c->d_fd_event.p, 0xFF, c->d_fd_event.cap, c->stream));
     c->rekey_pending = false;

@@ -132,41 +132,53 @@ void launch_fast_bc(const FastLaunch& c, dim3 grid, const PodsDev& pd, const Gro
 }
 
 
-template <int TS>
+template <int TS, bool WHOLE>
 static void launch_fast_step_a_s(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                                  const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
                                  uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap,
-                        uint32_t whole, uint32_t tk_p1, uint32_t tk_done) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_step_a<TS>), grid, dim3(kTblChunk), 0, c.stream, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks,
-                     c.filter_waves, c.filter_slots_cap, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done);
+                                 uint32_t tk_p1, uint32_t tk_done) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_step_a<TS, WHOLE>), grid, dim3(kTblChunk), 0, c.stream, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks,
+                     c.filter_waves, c.filter_slots_cap, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, tk_p1, tk_done);
 }
+#define BS_STEP_A_ARGS c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, tk_p1, tk_done
 void launch_fast_step_a(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                         const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
                         uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap,
                         uint32_t whole, uint32_t tk_p1, uint32_t tk_done) {
-  switch (c.S) {
-    case 0: launch_fast_step_a_s<0>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
-    case 1: launch_fast_step_a_s<1>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
-    case 2: launch_fast_step_a_s<2>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
-    case 3: launch_fast_step_a_s<3>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
-    default: launch_fast_step_a_s<4>(c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, whole, tk_p1, tk_done); break;
+  switch (c.S * 2u + (whole ? 1u : 0u)) {
+    case 0: launch_fast_step_a_s<0, false>(BS_STEP_A_ARGS); break;
+    case 1: launch_fast_step_a_s<0, true>(BS_STEP_A_ARGS); break;
+    case 2: launch_fast_step_a_s<1, false>(BS_STEP_A_ARGS); break;
+    case 3: launch_fast_step_a_s<1, true>(BS_STEP_A_ARGS); break;
+    case 4: launch_fast_step_a_s<2, false>(BS_STEP_A_ARGS); break;
+    case 5: launch_fast_step_a_s<2, true>(BS_STEP_A_ARGS); break;
+    case 6: launch_fast_step_a_s<3, false>(BS_STEP_A_ARGS); break;
+    case 7: launch_fast_step_a_s<3, true>(BS_STEP_A_ARGS); break;
+    case 8: launch_fast_step_a_s<4, false>(BS_STEP_A_ARGS); break;
+    default: launch_fast_step_a_s<4, true>(BS_STEP_A_ARGS); break;
   }
 }
-template <int TS>
+#undef BS_STEP_A_ARGS
+template <int TS, bool WHOLE>
 static int step_a_residency_s(const FastLaunch& c) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fast_step_a<TS>, (int)kTblChunk, 0) != hipSuccess || per_cu <= 0) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fast_step_a<TS, WHOLE>, (int)kTblChunk, 0) != hipSuccess || per_cu <= 0) return 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) return 0;
   return std::max(0, per_cu - 1) * prop.multiProcessorCount;      // (minus one block per CU: the API can be one high, see fused_residency_query)
 }
-int step_a_residency_query(const FastLaunch& c) {
-  switch (c.S) {
-    case 0: return step_a_residency_s<0>(c);
-    case 1: return step_a_residency_s<1>(c);
-    case 2: return step_a_residency_s<2>(c);
-    case 3: return step_a_residency_s<3>(c);
-    default: return step_a_residency_s<4>(c);
+int step_a_residency_query(const FastLaunch& c, bool whole) {
+  switch (c.S * 2u + (whole ? 1u : 0u)) {
+    case 0: return step_a_residency_s<0, false>(c);
+    case 1: return step_a_residency_s<0, true>(c);
+    case 2: return step_a_residency_s<1, false>(c);
+    case 3: return step_a_residency_s<1, true>(c);
+    case 4: return step_a_residency_s<2, false>(c);
+    case 5: return step_a_residency_s<2, true>(c);
+    case 6: return step_a_residency_s<3, false>(c);
+    case 7: return step_a_residency_s<3, true>(c);
+    case 8: return step_a_residency_s<4, false>(c);
+    default: return step_a_residency_s<4, true>(c);
   }
 }
 
