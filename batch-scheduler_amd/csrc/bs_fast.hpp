@@ -728,7 +728,7 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
     }
   }
   // REGS: the share's class keys and the leader, asked for together with the node lanes
-  const uint32_t K = prm.k_host;
+  const uint32_t K = prm.k_host ? prm.k_host : *b.kclass;
   const uint32_t per = (K + nshares - 1u) / nshares, s_lo = share * per, s_hi = min(K, s_lo + per);
   Res raw;
   int32_t leader0 = -1;
@@ -918,7 +918,7 @@ __device__ __forceinline__ void step_filter_block(const GroupsDev& gr, const Nod
                                                   const uint32_t* cpres, uint32_t kcap, uint32_t target_waves, uint32_t ustride, uint32_t bx, uint32_t nblocks,
                                                   uint32_t tk_slots0, uint32_t slot_producers) {
   const Shape<TS> sh(prm.S);
-  const uint32_t gate = prm.eph_gate, K = prm.k_host, U = 2u * K;
+  const uint32_t gate = prm.eph_gate, K = prm.k_host ? prm.k_host : (uint32_t)__builtin_amdgcn_readfirstlane((int)*b.kclass), U = 2u * K;
   const uint32_t W = (nd.n + 63u) / 64u;
   if (!U || !W) return;
   const uint32_t tiles = (U + 63u) / 64u;
@@ -976,7 +976,7 @@ template <int TS>
 __device__ __forceinline__ void class_slots_block(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, const int64_t* ckeys, const uint32_t* cpres,
                                                   uint32_t kcap, uint32_t blk) {
   const Shape<TS> sh(prm.S);
-  const uint32_t gate = prm.eph_gate, K = prm.k_host;
+  const uint32_t gate = prm.eph_gate, K = prm.k_host ? prm.k_host : *b.kclass;        // (K not on the host yet: the grid was sized for a bound, see run_fast)
   const uint32_t c = blk * kTblChunk + threadIdx.x;
   Res raw;                                                                                 // (the class's key: asked for before the leader chain, which is two dependent trips)
   const uint32_t cc = c < K ? c : 0u;

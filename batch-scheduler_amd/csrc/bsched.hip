@@ -150,6 +150,7 @@ struct bs_ctx {
   bool info_pending = false, kinfo_pending = false;
   uint32_t max_group_cls = 0, max_pod_cls = 0;   // largest fit class any HAS_POD group / grouped pod names (checked against C per batch)
   uint32_t h_K = 0;                  // request classes of the loaded pods (valid after resolve_pods)
+  uint32_t k_bound = 0;              // while kinfo_pending: an upper bound of the class count the device holds (last known K + pods inserted since)
 
   // ---- pods
   uint32_t P = 0;
@@ -269,7 +270,7 @@ struct bs_ctx {
   // classes, 64 table chunks, 4 scalar lanes; the second batch over a queue onwards).  BS_STEP_A=2, the DEFAULT since round 6: the class-slot form —
   // class_slots_block publishes every class's slots from the class directory, the pod blocks gate nobody: 19.05-19.35 us per cfg3/tail step against
   // 20.5-20.7 for the two-launch chain.  BS_STEP_A=1: round 5's form (every pod block publishes: 32 us, kept as a tested experiment).  BS_STEP_A=0: off.
-  uint32_t step_a_form = 2;
+  uint32_t step_a_form = 3;
   bool step_a_on = true;
   uint32_t step_shares = 8;          // BS_STEP_SHARES: blocks that share one table chunk's class slots (class-slot form, cfg3: 2 / 4 / 8 / 16 shares = 25.1 / 20.4 / 19.05 / 20.9 us per step)
   uint32_t tk_pods = 0, tk_tab = 0;  // values of ticket[8] / ticket[9] the next k_fast_step_a starts from (never reset: wrap-safe differences)
@@ -832,6 +833,7 @@ int resolve_pods(bs_ctx* c) {
   if (rc) return rc;
   c->kinfo_pending = false;
   c->h_K = (uint32_t)c->h_info[4];
+  c->k_bound = c->h_K;
   return BS_OK;
 }
 
@@ -883,6 +885,7 @@ int derive_pods(bs_ctx* c, bool pairs_only) {
                      ppair_dev(c), c->d_pair_next.as<unsigned long long>(), kcount, c->kinfo_tag, c->h_info, gcount);
   LAUNCHCHK(c, BS_KERNEL_PREPASS);
   c->kinfo_pending = true;
+  c->k_bound = P;                                                    // a fresh derivation: no more classes than pods
   c->pairs_ready = c->have_groups;
   c->owner_ready = false;
   c->epochs_ready = false;
@@ -1782,6 +1785,7 @@ int bs_pods_apply(bs_ctx* c, const bs_pods_delta* d) {
     c->gstat_cur ^= 1u;
     c->ids_used += I;
     c->kinfo_pending = true;
+    c->k_bound += I;                                                 // every inserted pod may bring a request nobody had
   } else {
     c->n_rederives++;
     if ((rc = derive_pods(c, false))) return rc;
@@ -2017,8 +2021,8 @@ static inline uint64_t host_ns() {
 // k_fast_step_a (bs_fast.hpp): the one-launch form of launch A + the scan / Filter roles — the latency regime only (K known on the
 // host and <= 256 class slots, <= 64 table chunks), no instrumentation that needs the legacy launches (work counters, per-launch stamps),
 // and a context that has not seen an in-launch hand-over time out.  BS_STEP_A=0 switches it off (bs_ctx::step_a_form).
-static bool step_a_possible(const bs_ctx* c, uint32_t stages, const BatchParams& prm, uint32_t nchunks) {
-  return c->step_a_on && !c->no_fuse_final && prm.k_host > 0 && prm.k_host <= kStepSlotsMax && nchunks <= 64 && c->M > 0 && c->P > 0 && !c->collect_stats &&
+static bool step_a_possible(const bs_ctx* c, uint32_t stages, uint32_t k, uint32_t nchunks) {
+  return c->step_a_on && !c->no_fuse_final && k > 0 && k <= kStepSlotsMax && nchunks <= 64 && c->M > 0 && c->P > 0 && !c->collect_stats &&
          c->cfg.enable_timing < 2 && c->S <= 4;
 }
 static int step_a_residency(bs_ctx* c, bool whole) {
@@ -2068,9 +2072,13 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
   prm.k_host = c->kinfo_pending ? 0u : c->h_K;
   const uint64_t hp1 = c->host_probe ? host_ns() : 0;
   // ---- launch A and the scan / Filter roles of launch B as ONE launch (k_fast_step_a; round 6: its class-slot form is the default), then k_fast_final
-  if (step_a_possible(c, stages, prm, nchunks) && (c->step_a_form == 1u || c->dirs_ready || (c->batch_since_pods && c->pairs_ready && c->rep_valid && c->have_groups))) {
+  // K not on the host yet (the queue was patched a moment ago and nobody has waited for the patch's word): the whole-step form sizes its grid for a
+  // BOUND of the class count (last known K + pods inserted since) and its blocks read K on the device; the other forms want it known
+  const bool k_known = !c->kinfo_pending;
+  const uint32_t k_step = k_known ? prm.k_host : ((c->step_a_form >= 3u && c->dirs_ready) ? c->k_bound : 0u);
+  if (step_a_possible(c, stages, k_step, nchunks) && (c->step_a_form == 1u || c->dirs_ready || (c->batch_since_pods && c->pairs_ready && c->rep_valid && c->have_groups))) {
     const uint32_t qb = cdiv(P, kTblChunk);
-    const uint32_t K = prm.k_host;
+    const uint32_t K = k_step;
     const uint32_t nshares = std::max<uint32_t>(1, std::min<uint32_t>(c->step_shares, cdiv(K, 8)));
     const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * K, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
     // the class-slot form needs the class directory (ckeys / cpres: class id -> request lanes).  It is built once per derivation of the queue — like bs_pods_apply's first call — and only for a queue that
@@ -2083,7 +2091,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     const uint32_t grid = qb + pb + nchunks * nshares + fblocks;
     // form 3: the pod blocks go on to the final verdicts inside the same launch (fast_final_block<true>) — one launch for the whole step
     const uint32_t whole = (c->step_a_form >= 3u && pb && c->d_first_row64.p) ? 1u : 0u;
-    if ((int)grid <= step_a_residency(c, whole != 0)) {
+    if ((k_known || whole) && (int)grid <= step_a_residency(c, whole != 0)) {
       TIMED(c, BS_KERNEL_QUERY, {
         launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks, qb, nshares, fblocks, c->tk_pods, c->tk_tab, pb,
                            c->d_ckeys.as<int64_t>(), c->d_cpres.as<uint32_t>(), c->pair_cap, whole, c->tk_p1, c->tk_done);

@@ -49,6 +49,7 @@ TIMED_REGIONS = 5           # the K-step timed region is run this many times (ea
 # the steady-state step's launches by the library's timing group -> kernel name in a rocprofv3 trace.  Two forms: the one-launch
 # form of launch A + the scan / Filter roles followed by the final launch (the default where it applies, round 6), or launches A and B+C
 LAUNCH_KERNELS_ONE = {"query": "k_fast_step_a", "resolve": "k_fast_final"}
+LAUNCH_KERNELS_WHOLE = {"query": "k_fast_step_a"}     # round 6, the whole step in one launch (BS_STEP_A=3, the default where it applies)
 LAUNCH_KERNELS_TWO = {"query": "k_fast_query_tables", "scan": "k_fast_scan_filter_final"}
 LAUNCH_KERNELS = dict(LAUNCH_KERNELS_TWO)            # (set by main() once it knows which form the timed steps took)
 
@@ -583,10 +584,17 @@ def main():
         W = (nodes.n + 63) // 64
         rows = max(1, stats["filter_distinct"])
         # which form did the timed steps take?  (the one-launch form has no "scan" group: its first launch is timed as "query", k_fast_final as "resolve")
-        one_launch = bool(stats["fast_path"]) and not (timing.get("scan", (0.0, 0))[1]) and bool(timing.get("resolve", (0.0, 0))[1])
+        no_scan = bool(stats["fast_path"]) and not (timing.get("scan", (0.0, 0))[1]) and bool(timing.get("query", (0.0, 0))[1])
+        one_launch = no_scan and bool(timing.get("resolve", (0.0, 0))[1])
+        whole_step = no_scan and not one_launch                 # no k_fast_final either: the pod blocks of k_fast_step_a finish their own pods
         LAUNCH_KERNELS.clear()
-        LAUNCH_KERNELS.update(LAUNCH_KERNELS_ONE if one_launch else LAUNCH_KERNELS_TWO)
-        if one_launch:
+        LAUNCH_KERNELS.update(LAUNCH_KERNELS_WHOLE if whole_step else LAUNCH_KERNELS_ONE if one_launch else LAUNCH_KERNELS_TWO)
+        if whole_step:
+            # everything once: pods + nodes + the class directory in; decisions, first rows, Filter rows, admit / ready out (neither table rows nor per-pod
+            # scratch have to leave the chip: the block that derives a pod's scratch finishes the pod)
+            alg = {"query": pods.p * (8 * L + 21) + nodes.n * (16 * L + 6) + nodes.n * 33 + stats["scan_queries"] * (8 * L + 4) + stats["scan_queries"] * 8
+                            + rows * (W * 8 + 4) + pods.p * 18 + groups.g * 21}
+        elif one_launch:
             # A' = pods + nodes + the class directory in; per-pod scratch, first rows, Filter rows out — the table rows are never written (the block that
             # builds a chunk scans it from its registers);  C = per-pod scratch + group counters in, decisions + admit / ready out
             alg = {
@@ -604,7 +612,7 @@ def main():
         if single and not args.no_pmc and stats["fast_path"]:
             prof, prof_src = profile_passes(args)
         launches = []
-        for key in (("query", "resolve") if one_launch else ("query", "scan")):
+        for key in (("query",) if whole_step else ("query", "resolve") if one_launch else ("query", "scan")):
             ms, n = timing.get(key, (0.0, 0))
             pk = (prof or {}).get(key, {})
             kernel_us = pk.get("kernel_us")
@@ -618,7 +626,7 @@ def main():
                  "hip_event_us": event_us, "algorithmic_bytes_per_launch": alg[key], "achieved": alg[key] / (t_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                  "unit": "GB/s", "frac": alg[key] / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tb,
                  "physical_frac": (tb / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if tb else None}
-            if key == ("query" if one_launch else "scan"):
+            if key == ("query" if (one_launch or whole_step) else "scan"):
                 e["evals_executed_per_launch"] = stats["scan_evals_executed"] + stats["filter_evals_executed"]
             launches.append(e)
         roofline = None
@@ -635,8 +643,11 @@ def main():
                              "frac_note": "SURVEY 8(d)'s formula on the LOGICAL rate: evals/s x (PreFilter + Filter bytes per eval) / 8 TB/s (> 1: the step does not do "
                                           "per-eval work - request classes and pruning, see work_avoided); on the EXECUTED work: (scan evals x (16 L + 2) + Filter evals x "
                                           "65.125 bytes) / the dominant kernel's time / 8 TB/s; `frac` above is compulsory bytes / kernel time / 8 TB/s",
-                             "limiter": "launch latency and dependent-load chains (the step is two small launches, three dependency levels; see frac)",
-                             "step_form": "one-launch form of launch A + scan / Filter roles (k_fast_step_a, class slots from the class directory), then k_fast_final" if one_launch
+                             "limiter": "dependent-load chains and in-launch hand-overs (one small launch, three dependency levels; see frac)" if whole_step else
+                                        "launch latency and dependent-load chains (the step is two small launches, three dependency levels; see frac)",
+                             "step_form": "the whole step in ONE launch (k_fast_step_a<S, true>: pod blocks | class-slot block | table blocks | Filter blocks; the pod blocks "
+                                          "finish their own pods after an in-launch hand-over)" if whole_step
+                                          else "one-launch form of launch A + scan / Filter roles (k_fast_step_a, class slots from the class directory), then k_fast_final" if one_launch
                                           else "launch A (k_fast_query_tables), then scan / Filter / final blocks in one launch (k_fast_scan_filter_final)",
                              "source": prof_src, "sum_of_launch_us": ksum, "ms_per_step_us": ms_per_step * 1e3,
                              "note": "the step's longest launch (by kernel-only time).  achieved = compulsory algorithmic bytes of the launch (every input once, "

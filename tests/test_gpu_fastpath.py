@@ -238,13 +238,14 @@ def test_unfused_final_launch_is_selectable_and_equal(config, scenario, bsa, soa
         assert ctx.stats(soa.STAGE_ALL)["launches"] == 2          # the fused form: the whole grid is resident on this chip
 
 
-@pytest.mark.parametrize("form", ["1", "2"])
+@pytest.mark.parametrize("form", ["1", "2", "3"])
 @pytest.mark.parametrize("config,scenario", [("cfg2", "warm"), ("cfg2", "tail"), ("cfg3", "tail"), ("tiny", "busy")])
 def test_one_launch_form_of_the_step_equals_the_oracle(config, scenario, form, monkeypatch, bsa, soa, orc):
     """BS_STEP_A=1 (round 5's experiment, off by default because it measured slower): launch A and the scan / Filter roles of launch B as
     ONE launch — the block that builds a table chunk keeps its rows in registers and scans them itself, slots handed over inside the
     launch (k_fast_step_a) — then k_fast_final.  BS_STEP_A=2 (round 6): the slots come from the class directory (class_slots_block), the pod
-    blocks publish nothing.  Same answers, batch after batch, with queue patches in between (pods leaving; pods with NEW requests arriving:
+    blocks publish nothing.  BS_STEP_A=3 (the default): the whole step in that one launch — table and Filter blocks derive their slots themselves, the
+    pod blocks finish their own pods after an in-launch hand-over, no k_fast_final.  Same answers, batch after batch, with queue patches in between (pods leaving; pods with NEW requests arriving:
     class ids the directory learns from the insert wave)."""
     monkeypatch.setenv("BS_STEP_A", form)
     nodes, fit, groups, pods, _ = bsa.synth.make(config, scenario)

@@ -6,7 +6,7 @@ mkdir -p $OUT $R/tools/ubench
 cd $R
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -DBS_PROBE=1 -DBS_UNITY -o tools/ubench/libbsched_probe.so batch-scheduler_amd/csrc/bsched.hip -ldl > $OUT/build.log 2>&1
 tail -n 3 $OUT/build.log
-for F in 2 3; do
+for F in 3; do
   echo "=== BS_STEP_A=$F" >> $OUT/stamps_step.txt
   BS_STEP_A=$F timeout 200 python tools/stamp_probe.py step cfg3 tail 40 >> $OUT/stamps_step.txt 2>> $OUT/err.txt
 done
