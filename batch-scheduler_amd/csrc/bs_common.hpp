@@ -48,7 +48,11 @@ __device__ __forceinline__ void probe_count(int k, int s, uint32_t blk, uint32_t
 }
 #define BS_STAMP(k, s) probe_stamp((k), (s), blockIdx.x)
 #define BS_COUNT(k, s, v) probe_count((k), (s), blockIdx.x, (v))
+#define BS_STAMP_AT(k, s, blk) probe_stamp((k), (s), (blk))
+#define BS_COUNT_AT(k, s, blk, v) probe_count((k), (s), (blk), (v))
 #else
+#define BS_STAMP_AT(k, s, blk) ((void)0)
+#define BS_COUNT_AT(k, s, blk, v) ((void)0)
 #define BS_STAMP(k, s) ((void)0)
 #define BS_COUNT(k, s, v) ((void)0)
 #endif

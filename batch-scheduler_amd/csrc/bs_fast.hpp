@@ -677,7 +677,15 @@ __device__ __forceinline__ bool step_wait(const uint32_t* word, uint32_t base, u
 // Where the tickets of k_fast_step_a live (u32 indices into BatchDev::ticket; every word other blocks poll has a 64-byte line of its own: a poll and an
 // add to one line queue behind each other at the memory side, and with one line for everything the pod blocks' polling of the last counter slowed the
 // table blocks' wait for the first by 1.3 us, profiles/r06_stamps_whole_step.txt).  The two counters with hundreds of adds per launch are spread over
-// kTkWays lines: same-address agent-scope adds complete one after the other (~50 ns each: 200 producers = 10 us on one word).
+// kTkWays lines: same-address agent-scope adds complete one after the other (~50 ns each: 200 producers = 10 us on one word).  kTkDone: the scan / Filter blocks of a large queue (more than
+// kGatherDirectBlocks pod blocks), counted in after their atomics have drained; a small queue's results are tagged words (scan_rec / feas_rec), no counter.
+constexpr uint32_t kScanRecChunks = 64;  // BatchDev::scan_rec[chunk][slot]: tag << 32 | the slot's first row inside the chunk (BS_INF: none) — one writer per word
+constexpr uint32_t kFeasRecGroups = 32;  // BatchDev::feas_rec[group of 4 node runs][slot]: tag << 32 | feasible nodes of the slot in those runs — one writer per word
+#ifndef BS_GATHER_DIRECT
+#define BS_GATHER_DIRECT 8
+#endif
+constexpr uint32_t kGatherDirectBlocks = BS_GATHER_DIRECT;   // up to this many pod blocks poll the result words directly (fast_final_block<true>)
+constexpr uint32_t kRecStride = 32;      // 64-bit words per chunk record (BatchDev::chunk_rec): [2 j], [2 j + 1] = tag << 32 | low / high half of lane j's total; [16 + s] = tag << 32 | first row of key s
 constexpr uint32_t kTkSlots = 32, kTkTab = 48, kTkP1 = 64, kTkDone = 64 + 16 * 16, kTkWays = 16, kTkWords = 64 + 2 * 16 * 16;
 __device__ __forceinline__ void spread_add(uint32_t* words, uint32_t who) {
   (void)__hip_atomic_fetch_add(&words[16u * (who % kTkWays)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -697,11 +705,11 @@ __device__ __forceinline__ bool spread_wait(const uint32_t* words, uint32_t base
 }
 // REGS (the whole step in one launch, BS_STEP_A=3): the block derives its share's scan queries ITSELF from the class directory and the leader
 // (class_scan_query: what class_slots_block publishes) while it waits for the chunk totals — it waits for no slot ticket and fetches no slot; the first
-// rows go to first_row64[] as 64-bit minima keyed by ~batch_seq (never reset: the block that would reset them is not waited for either).
+// row of every slot of the share inside this chunk goes to scan_rec[chunk][slot] as a tagged word.
 template <int TS, bool REGS = false>
 __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk, uint32_t nchunks,
                                                  uint32_t share, uint32_t nshares, uint32_t pod_blocks, uint32_t tk_pods0, uint32_t tk_tab0, const GroupsDev& gr,
-                                                 const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap) {
+                                                 const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap, bool direct = false) {
   __shared__ unsigned long long s_wtot[BS_MAX_LANES][4];
   __shared__ uint32_t s_kp[BS_MAX_SCALARS];
   __shared__ unsigned long long s_off[BS_MAX_LANES];
@@ -779,18 +787,31 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
         tot += x;
       }
       incl[j] += off;
-      if (threadIdx.x == 0 && share == 0) st_pub<true>(&b.chunk_tot[(size_t)chunk * 16 + j], tot);
+      if (threadIdx.x == 0 && share == 0) {
+        if constexpr (REGS) {
+          // tagged record (see kRecStride): each half of the total travels in a 64-bit word of its own beside the batch's tag — a reader that finds
+          // the tag in both words has both halves of THIS batch's total, whatever order the words landed in: no drain, no ticket, no second fetch
+          const unsigned long long tag = (unsigned long long)prm.seq_inv << 32;
+          st_pub<true>(&b.chunk_rec[(size_t)chunk * kRecStride + 2u * j], tag | (uint32_t)tot);
+          st_pub<true>(&b.chunk_rec[(size_t)chunk * kRecStride + 2u * j + 1u], tag | (uint32_t)(tot >> 32));
+        } else {
+          st_pub<true>(&b.chunk_tot[(size_t)chunk * 16 + j], tot);
+        }
+      }
     }
   }
   __syncthreads();
-  if (share == 0 && threadIdx.x < 16) st_pub<true>(&b.chunk_kp[(size_t)chunk * 16 + threadIdx.x], threadIdx.x < BS_MAX_SCALARS ? s_kp[threadIdx.x] : BS_INF);
-  // ---- publish (share 0 of every chunk), then wait for every chunk's totals and for every pod block's slots
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  BS_STAMP(2, 1);
   __shared__ uint32_t s_ok;
-  if (threadIdx.x == 0) {
-    if (share == 0) (void)__hip_atomic_fetch_add(&b.ticket[kTkTab], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if constexpr (REGS) {
+    if (share == 0 && threadIdx.x < S) st_pub<true>(&b.chunk_rec[(size_t)chunk * kRecStride + 16u + threadIdx.x], ((unsigned long long)prm.seq_inv << 32) | s_kp[threadIdx.x]);
+    BS_STAMP(2, 1);
+  } else {
+    if (share == 0 && threadIdx.x < 16) st_pub<true>(&b.chunk_kp[(size_t)chunk * 16 + threadIdx.x], threadIdx.x < BS_MAX_SCALARS ? s_kp[threadIdx.x] : BS_INF);
+    // ---- publish (share 0 of every chunk), then wait for every chunk's totals and for every pod block's slots
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    BS_STAMP(2, 1);
+    if (threadIdx.x == 0 && share == 0) (void)__hip_atomic_fetch_add(&b.ticket[kTkTab], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (REGS) {
     // the share's scan queries -> LDS (one slot per thread), in the shadow of the other chunks' totals
@@ -811,18 +832,60 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
         if (j < L) s_req[threadIdx.x][j] = q.v[j];
     }
   }
-  if (threadIdx.x == 0)
-    s_ok = (step_wait(&b.ticket[kTkTab], tk_tab0, nchunks, b.h_err) && (REGS || step_wait(&b.ticket[kTkSlots], tk_pods0, pod_blocks, b.h_err))) ? 1u : 0u;
-  __syncthreads();
-  BS_STAMP(2, 2);
-  if (!s_ok) return;
+  if constexpr (!REGS) {
+    if (threadIdx.x == 0) s_ok = (step_wait(&b.ticket[kTkTab], tk_tab0, nchunks, b.h_err) && step_wait(&b.ticket[kTkSlots], tk_pods0, pod_blocks, b.h_err)) ? 1u : 0u;
+    __syncthreads();
+    BS_STAMP(2, 2);
+    if (!s_ok) return;
+  }
   // ---- this block's slots -> LDS; the chunk's offset and the table's first key rows (wave 0: lane <-> chunk)
   {
     // one round trip for everything: wave 0's lanes take the chunk totals / key rows (lane <-> chunk), every thread a slot of the share
     const uint32_t ch = (uint32_t)lane_id();
     unsigned long long cv[BS_MAX_LANES];
     uint32_t ckp[BS_MAX_SCALARS];
-    if (w == 0) {
+    if constexpr (REGS) {
+      // wave 0 polls the records themselves: lane <-> chunk, every word of the record in one round trip, again until every chunk's words carry the tag
+      if (w == 0) {
+        const uint32_t tagw = prm.seq_inv;
+        const unsigned long long* rec = b.chunk_rec + (size_t)(ch < nchunks ? ch : 0u) * kRecStride;
+        bool ok = false;
+        for (uint32_t spins = 0;; ++spins) {
+          unsigned long long lo[BS_MAX_LANES], hi[BS_MAX_LANES], kw[BS_MAX_SCALARS];
+#pragma unroll
+          for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+            if (j < L) { lo[j] = ld_agent64(&rec[2u * j]); hi[j] = ld_agent64(&rec[2u * j + 1u]); }
+#pragma unroll
+          for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2)
+            if (s2 < S) kw[s2] = ld_agent64(&rec[16u + s2]);
+          bool mine_ok = true;
+#pragma unroll
+          for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
+            cv[j] = 0ull;
+            if (j < L) {
+              mine_ok = mine_ok && (uint32_t)(lo[j] >> 32) == tagw && (uint32_t)(hi[j] >> 32) == tagw;
+              cv[j] = (hi[j] << 32) | (uint32_t)lo[j];
+            }
+          }
+#pragma unroll
+          for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) {
+            ckp[s2] = BS_INF;
+            if (s2 < S) { mine_ok = mine_ok && (uint32_t)(kw[s2] >> 32) == tagw; ckp[s2] = (uint32_t)kw[s2]; }
+          }
+          if (__ballot(!(mine_ok || ch >= nchunks)) == 0ull) { ok = true; break; }
+          if (spins > (1u << 22)) { if (b.h_err && ch == 0) __hip_atomic_store(b.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (ch >= nchunks) {
+#pragma unroll
+          for (uint32_t j = 0; j < BS_MAX_LANES; ++j) cv[j] = 0ull;
+#pragma unroll
+          for (uint32_t s2 = 0; s2 < BS_MAX_SCALARS; ++s2) ckp[s2] = BS_INF;
+        }
+        if (ch == 0) s_ok = ok ? 1u : 0u;
+      }
+      BS_STAMP(2, 2);
+    } else if (w == 0) {
 #pragma unroll
       for (uint32_t j = 0; j < BS_MAX_LANES; ++j) cv[j] = (j < L && ch < nchunks) ? ld_agent64(&b.chunk_tot[(size_t)ch * 16 + j]) : 0ull;
 #pragma unroll
@@ -865,6 +928,9 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
     }
   }
   __syncthreads();
+  if constexpr (REGS) {
+    if (!s_ok) return;
+  }
   int64_t fin[BS_MAX_LANES];
   uint32_t keyrow = 0;                                         // bit s: key s is in the running sum at this row (core.go:686-697)
 #pragma unroll
@@ -902,31 +968,56 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
   }
   __syncthreads();
   BS_STAMP(2, 4);
+  if constexpr (REGS) {
+    // a small queue: every (slot of the share, this chunk) word is written, found or not — the pod blocks know a slot is complete when all its chunks'
+    // words carry the batch's tag: no counter to add to, no drain in front of it, and their poll IS their fetch
+    if (direct) {
+      for (uint32_t t = threadIdx.x; t < nmine; t += kTblChunk)
+        st_pub<true>(&b.scan_rec[(size_t)chunk * kStepSlotsMax + s_lo + t], ((unsigned long long)prm.seq_inv << 32) | s_first[t]);
+    } else {
+      // a large queue (see kGatherDirectBlocks): one 64-bit minimum per slot, keyed by ~batch_seq (never reset), behind the kTkDone counter
+      for (uint32_t t = threadIdx.x; t < nmine; t += kTblChunk)
+        if (s_first[t] != BS_INF) atomicMin(&b.first_row64[s_lo + t], ((unsigned long long)prm.seq_inv << 32) | s_first[t]);
+    }
+    BS_STAMP(2, 7);
+    return;
+  }
   for (uint32_t t = threadIdx.x; t < nmine; t += kTblChunk) {
     if (s_first[t] == BS_INF) continue;
-    if constexpr (REGS) atomicMin(&b.first_row64[s_lo + t], ((unsigned long long)prm.seq_inv << 32) | s_first[t]);
-    else atomicMin(&b.first_row[s_lo + t], s_first[t]);
+    atomicMin(&b.first_row[s_lo + t], s_first[t]);
   }
   BS_STAMP(2, 7);
 }
 
-// The Filter role of the whole-step launch: the work loop of filter_loop<2> (same item order, same split) with the tile's slots derived on the spot —
-// lane = slot: class c = slot mod K, leader = the batch's (slots [0, K)) or the one carried in (slots [K, 2K)); what class_slots_block writes into
-// uflags[] / uparams[] for that slot, computed from the class directory and the leader's MinResources (filter_slot_values), never read back.
+// The Filter role of the whole-step launch: filter_loop<2>'s split into (tile of 64 slots, run of node blocks) items, with the tile's slots derived on the
+// spot — lane = slot: class c = slot mod K, leader = the batch's (slots [0, K)) or the one carried in (slots [K, 2K)); what class_slots_block writes into
+// uflags[] / uparams[] for that slot, computed from the class directory and the leader's MinResources (filter_slot_values), never read back.  A block takes
+// FOUR node runs of ONE tile (a wave each); a small queue's block leaves the slots' feasible counts over those runs in feas_rec[group][slot] as tagged
+// words (nothing is added to, nothing has to be zeroed first, nobody is waited for), a large queue's adds them to fu_feas[].
+__device__ __forceinline__ void step_filter_split(uint32_t K, uint32_t W, uint32_t target_waves, uint32_t& tiles, uint32_t& bpw, uint32_t& nchunk) {
+  tiles = (2u * K + 63u) / 64u;
+  uint32_t nsplit = max(1u, target_waves / max(tiles, 1u));
+  nsplit = min(nsplit, max((W + 1u) / 2u, 1u));
+  bpw = max(2u, (((W + nsplit - 1u) / nsplit + 1u) / 2u) * 2u);
+  nchunk = (W + bpw - 1u) / bpw;
+  if ((nchunk + 3u) / 4u > kFeasRecGroups) {                       // (never with <= 64 table chunks; keeps the record within its row whatever the caller passes)
+    bpw = ((W + 4u * kFeasRecGroups - 1u) / (4u * kFeasRecGroups) + 1u) / 2u * 2u;
+    nchunk = (W + bpw - 1u) / bpw;
+  }
+}
 template <int TS>
 __device__ __forceinline__ void step_filter_block(const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const int64_t* ckeys,
                                                   const uint32_t* cpres, uint32_t kcap, uint32_t target_waves, uint32_t ustride, uint32_t bx, uint32_t nblocks,
-                                                  uint32_t tk_slots0, uint32_t slot_producers) {
+                                                  bool direct, uint32_t tk_slots0, uint32_t slot_producers) {
+  __shared__ uint32_t s_cnt[4][64];
+  BS_STAMP_AT(4, 0, bx);
   const Shape<TS> sh(prm.S);
   const uint32_t gate = prm.eph_gate, K = prm.k_host ? prm.k_host : (uint32_t)__builtin_amdgcn_readfirstlane((int)*b.kclass), U = 2u * K;
   const uint32_t W = (nd.n + 63u) / 64u;
   if (!U || !W) return;
-  const uint32_t tiles = (U + 63u) / 64u;
-  uint32_t nsplit = max(1u, target_waves / tiles);
-  nsplit = min(nsplit, max((W + 1u) / 2u, 1u));
-  const uint32_t bpw = max(2u, (((W + nsplit - 1u) / nsplit + 1u) / 2u) * 2u);
-  const uint32_t nchunk = (W + bpw - 1u) / bpw;
-  const uint32_t items = tiles * nchunk;
+  uint32_t tiles, bpw, nchunk;
+  step_filter_split(K, W, target_waves, tiles, bpw, nchunk);
+  const uint32_t groups = (nchunk + 3u) / 4u;
   const int32_t leader0 = b.leader_epoch[0];
   LeaderPre lp0{}, lp1{};
   const bool two = prm.sop_leader0 >= 0 && prm.sop_leader0 != leader0;
@@ -935,33 +1026,46 @@ __device__ __forceinline__ void step_filter_block(const GroupsDev& gr, const Nod
     if (two) leader_pre_load(gr, prm.sop_leader0, sh, lp1); else lp1 = lp0;
   }
   bool waited = false;
-  for (uint32_t it = __builtin_amdgcn_readfirstlane(bx * 4u + (uint32_t)wave_id()); it < items; it += nblocks * 4u) {
-    const uint32_t chunk = it / tiles, tile = it - chunk * tiles;
+  for (uint32_t bi = bx; bi < tiles * groups; bi += nblocks) {
+    const uint32_t tile = bi % tiles, group = bi / tiles, chunk = group * 4u + (uint32_t)wave_id();
     const uint32_t src = tile * 64u + (uint32_t)lane_id();
     const bool second = src >= K;
     const uint32_t c = src < U ? (second ? src - K : src) : 0u;
-    Res raw;
-#pragma unroll
-    for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
-      if (j < sh.L()) raw.v[j] = ckeys[(size_t)j * kcap + c];
-    raw.present = cpres[c];
-    Res cur;
-    res_zero(cur, sh);
-    res_add(cur, raw, sh, gate);
-    LeaderPre lp = lp0;
-    if (second) lp = lp1;
-    const bool on = src < U && (second ? prm.sop_leader0 >= 0 : leader0 >= 0) && lp.have_mr;      // class_slots_block / filter_slot_from: who gets a slot
-    int64_t R[4], M[4];
-    const uint32_t ff = filter_slot_values(cur, lp, sh, gate, R, M);
     uint32_t cnt = 0;
-    filter_item<2, 4, true, true>(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), 0u,
-                                  on ? (ff | ((uint32_t)BS_FL_EVALUATED << 8)) : ((uint32_t)BS_FL_NOT_RUN << 8), R, M, &cnt);
-    if (!waited) {                                    // the counters were zeroed by the class-slot block: long through by now, one look
-      (void)step_wait(&b.ticket[kTkSlots], tk_slots0, slot_producers, b.h_err);
-      waited = true;
+    if (chunk < nchunk) {
+      Res raw;
+#pragma unroll
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+        if (j < sh.L()) raw.v[j] = ckeys[(size_t)j * kcap + c];
+      raw.present = cpres[c];
+      Res cur;
+      res_zero(cur, sh);
+      res_add(cur, raw, sh, gate);
+      LeaderPre lp = lp0;
+      if (second) lp = lp1;
+      const bool on = src < U && (second ? prm.sop_leader0 >= 0 : leader0 >= 0) && lp.have_mr;      // class_slots_block / filter_slot_from: who gets a slot
+      int64_t R[4], M[4];
+      const uint32_t ff = filter_slot_values(cur, lp, sh, gate, R, M);
+      filter_item<2, 4, true, true>(nd, b, U, ustride, tile, chunk * bpw, min(W, chunk * bpw + bpw), 0u,
+                                    on ? (ff | ((uint32_t)BS_FL_EVALUATED << 8)) : ((uint32_t)BS_FL_NOT_RUN << 8), R, M, &cnt);
     }
-    if (src < U && cnt) atomicAdd(&b.fu_feas[src], cnt);
+    s_cnt[wave_id()][lane_id()] = cnt;
+    BS_STAMP_AT(4, 1, bx);
+    __syncthreads();
+    BS_STAMP_AT(4, 2, bx);
+    if (wave_id() == 0 && src < U) {
+      const uint32_t sum = s_cnt[0][lane_id()] + s_cnt[1][lane_id()] + s_cnt[2][lane_id()] + s_cnt[3][lane_id()];
+      if (direct) {
+        st_pub<true>(&b.feas_rec[(size_t)group * (2u * kStepSlotsMax) + src], ((unsigned long long)prm.seq_inv << 32) | sum);
+      } else {
+        // a large queue: the counts are added to fu_feas[], which the class-slot block zeroed (long through by now: one look)
+        if (!waited) { (void)step_wait(&b.ticket[kTkSlots], tk_slots0, slot_producers, b.h_err); waited = true; }
+        if (sum) atomicAdd(&b.fu_feas[src], sum);
+      }
+    }
+    __syncthreads();
   }
+  BS_STAMP_AT(4, 7, bx);
 }
 
 // Round 6, the class-slot form of the one-launch step (BS_STEP_A=2).  What made round 5's form slow was WHO publishes the slots: every pod block
@@ -1132,11 +1236,15 @@ __device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& 
 // into ticket[1] when their results are out — everything that does not depend on them is fetched first
 // INL (k_fast_step_a, the whole step in one launch): the block is a POD block of the same launch that has finished its own first half; what other pod
 // blocks left for it (first-reach words, the pairs' first querying pods, the armed counters) is read after their ticket (ticket[10], base tk_p1), with
-// agent-scope loads; the scan / Filter blocks count themselves into ticket[11] (base tk_done, `producers` of them).
+// agent-scope loads.  The scan / Filter blocks leave their results as tagged words, one writer each (scan_rec[chunk][slot], feas_rec[group][slot]): the
+// block gathers every class's first row (minimum over the `producers` = table chunks) and every Filter slot's feasible count (sum over the groups of
+// node runs; `aux` = the Filter split's target waves) into LDS, again until every word carries the batch's tag — the poll is the fetch, no counter.
 template <bool INL = false>
 __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchParams& prm,
-                                                 uint32_t query_blocks, uint32_t bx, uint32_t nblocks, uint32_t producers, uint32_t tk_p1 = 0, uint32_t tk_done = 0) {
+                                                 uint32_t query_blocks, uint32_t bx, uint32_t nblocks, uint32_t producers, uint32_t tk_p1 = 0, uint32_t aux = 0,
+                                                 uint32_t tk_done = 0, uint32_t hint_blocks = 0) {
   __shared__ uint32_t s_first_reach;
+  __shared__ uint32_t s_rowk[INL ? kStepSlotsMax : 1u], s_feask[INL ? 2u * kStepSlotsMax : 1u];
   BS_STAMP(3, 0);
   if constexpr (INL) {
     if (threadIdx.x < 64) (void)spread_wait(&b.ticket[kTkP1], tk_p1, query_blocks, b.h_err);
@@ -1189,7 +1297,59 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
     // serialising blocks): on time-out the block raises the context's error word and goes on — the batch is then refused by
     // bs_batch_sync / read / map instead of hanging the GPU.
     if constexpr (INL) {
-      if (threadIdx.x < 64) (void)spread_wait(&b.ticket[kTkDone], tk_done, producers, b.h_err);
+      const uint32_t tagw = prm.seq_inv, U = prm.run_filter ? 2u * K : 0u;
+      uint32_t groups = 0;
+      if (prm.run_filter) {
+        uint32_t tiles, bpw, nchunk;
+        step_filter_split(K, (nd.n + 63u) / 64u, aux, tiles, bpw, nchunk);
+        groups = (nchunk + 3u) / 4u;
+      }
+      const unsigned long long none = ((unsigned long long)tagw << 32) | BS_INF, zero = (unsigned long long)tagw << 32;
+      BS_STAMP(3, 4);
+      if (query_blocks > kGatherDirectBlocks) {
+        // a large queue: the producers' counter, then every pod fetches its own words (below)
+        if (threadIdx.x < 64) (void)spread_wait(&b.ticket[kTkDone], tk_done, hint_blocks, b.h_err);
+      } else
+      // thread = slot: the class's words of every chunk (minimum), the Filter slots' words of every group (sum); eight loads in flight at a time.  (A
+      // version that spread the words evenly over the block's threads and reduced them with LDS atomics measured slower at both BASELINE sizes.)
+      for (uint32_t spins = 0;; ++spins) {
+        uint32_t andt = tagw, ort = tagw, row = BS_INF, fs[2] = {0u, 0u};
+        if (threadIdx.x < K) {
+          const unsigned long long* rec = b.scan_rec + threadIdx.x;             // [chunk][slot]: a wave's lanes read neighbouring words
+          for (uint32_t c0 = 0; c0 < producers; c0 += 8u) {
+            unsigned long long w[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) w[u] = c0 + u < producers ? ld_agent64(&rec[(size_t)(c0 + u) * kStepSlotsMax]) : none;
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) { andt &= (uint32_t)(w[u] >> 32); ort |= (uint32_t)(w[u] >> 32); row = min(row, (uint32_t)w[u]); }
+          }
+        }
+#pragma unroll
+        for (uint32_t h = 0; h < 2u; ++h) {
+          const uint32_t slot = threadIdx.x + 256u * h;
+          if (slot < U) {
+            const unsigned long long* rec = b.feas_rec + slot;                  // [group][slot]
+            for (uint32_t g0 = 0; g0 < groups; g0 += 8u) {
+              unsigned long long w[8];
+#pragma unroll
+              for (uint32_t u = 0; u < 8u; ++u) w[u] = g0 + u < groups ? ld_agent64(&rec[(size_t)(g0 + u) * (2u * kStepSlotsMax)]) : zero;
+#pragma unroll
+              for (uint32_t u = 0; u < 8u; ++u) { andt &= (uint32_t)(w[u] >> 32); ort |= (uint32_t)(w[u] >> 32); fs[h] += (uint32_t)w[u]; }
+            }
+          }
+        }
+        const bool timed_out = spins > (1u << 20);
+        if (__syncthreads_and((andt == tagw && ort == tagw) || timed_out)) {
+          if (threadIdx.x < K) s_rowk[threadIdx.x] = row;
+#pragma unroll
+          for (uint32_t h = 0; h < 2u; ++h)
+            if (threadIdx.x + 256u * h < U) s_feask[threadIdx.x + 256u * h] = fs[h];
+          if (timed_out && threadIdx.x == 0 && b.h_err) __hip_atomic_store(b.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          BS_COUNT(3, 5, spins + 1u);                    // (probe build: gather rounds, shown as microseconds)
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
     } else if (threadIdx.x == 0) {
       uint32_t spins = 0;
       while (ld_agent(&b.ticket[1]) < producers) {
@@ -1200,14 +1360,19 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
   }
   __syncthreads();
   BS_STAMP(3, 1);
-  // ---- round trip 2b: the pod's scan slot's result, both Filter slots' feasible counts
-  auto keyed_row = [&](uint32_t slot) -> uint32_t {                 // INL: first_row64[], a 64-bit minimum keyed by ~batch_seq
+  // ---- round trip 2b: the pod's scan slot's result, both Filter slots' feasible counts (INL: they are in LDS already)
+  const bool gathered = INL && query_blocks <= kGatherDirectBlocks;
+  auto keyed_row = [&](uint32_t slot) -> uint32_t {                 // INL: from LDS (gathered), or first_row64[], a 64-bit minimum keyed by ~batch_seq
+    if (gathered) return s_rowk[INL ? slot : 0u];
     const unsigned long long w = ld_agent64(&b.first_row64[slot]);
     return (uint32_t)(w >> 32) == prm.seq_inv ? (uint32_t)w : BS_INF;
   };
   if (owned && (st0 & ST_QUERY)) row_q = INL ? keyed_row(qpos0) : ld_agent(&b.first_row[qpos0]);
   if (walk) row_c = INL ? keyed_row(pclass0) : ld_agent(&b.first_row[pclass0]);
-  if (valid && prm.run_filter && grouped) { feas0 = ld_agent(&b.fu_feas[pclass0]); feas1 = ld_agent(&b.fu_feas[pclass0 + K]); }
+  if (valid && prm.run_filter && grouped) {
+    if (gathered) { feas0 = s_feask[INL ? pclass0 : 0u]; feas1 = s_feask[INL ? pclass0 + K : 0u]; }
+    else { feas0 = ld_agent(&b.fu_feas[pclass0]); feas1 = ld_agent(&b.fu_feas[pclass0 + K]); }
+  }
   bool admit = false;
   if (valid) {
     uint8_t code = code0;
@@ -1274,9 +1439,13 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
     // BS_BATCH_FILTER_DENY: Filter fails on some node -> the group's first such pod (k_fd_apply takes it from here, bs_fdeny.hpp)
     if (prm.filter_deny && fl == BS_FL_EVALUATED && feasible < nd.n) atomicMin(&b.fd_event[gi], ((unsigned long long)prm.seq_inv << 32) | i);
   }
+  if (gathered) {                                    // the slots' counts, for whoever reads fu_feas[] after the launch (bs_fdeny.hpp, bs_batch_read)
+    if (prm.run_filter)
+      for (uint32_t k = i; k < 2u * K; k += nblocks * 256u) b.fu_feas[k] = s_feask[INL ? k : 0u];
+  }
   if (prm.host_tag && prm.run_filter) {             // per-row feasible counts of the slots in use
     const uint32_t U = min(2u * K, b.hstride);
-    for (uint32_t k = i; k < U; k += nblocks * 256u) b.h_feas[k] = ld_agent(&b.fu_feas[k]);
+    for (uint32_t k = i; k < U; k += nblocks * 256u) b.h_feas[k] = gathered ? s_feask[INL ? k : 0u] : ld_agent(&b.fu_feas[k]);
   }
   BS_STAMP(3, 2);
   if (!prm.filter_deny) tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi0 : 0u, admit, nblocks);      // (else: k_fd_apply, bs_fdeny.hpp)
@@ -1395,13 +1564,18 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsD
   BS_STAMP(1, 0);
   const uint32_t tb = nchunks * nshares;
   const uint32_t producers = param_blocks ? param_blocks : query_blocks;      // blocks the slots' ticket waits for
+  // WHOLE: how the scan / Filter results reach the pod blocks.  A few pod blocks (<= kGatherDirectBlocks) poll the result words themselves (tagged, one
+  // writer each: no counter, no drain, the poll is the fetch — cfg2: 13.1 -> 12.0 us per step); with forty of them polling the same 40 KB at the memory
+  // side everybody slowed down, and gathering after a hint counter measured no better than the compact form (cfg3: +0.5 us): a large queue's producers
+  // reduce with atomics (first_row64[], fu_feas[]), drain, count themselves into kTkDone, and every pod fetches its own three words after that
+  const bool direct = query_blocks <= kGatherDirectBlocks;
   if (blockIdx.x < query_blocks) {
     if constexpr (WHOLE) {
       fast_query_thread<TS, false, false, true>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first-reach word, armed counters, the pairs' minima: out before the ticket
       __syncthreads();
       if (threadIdx.x == 0) spread_add(&b.ticket[kTkP1], blockIdx.x);
-      fast_final_block<true>(pods, gr, nd, b, prm, query_blocks, blockIdx.x, query_blocks, tb + filter_blocks, tk_p1, tk_done);
+      fast_final_block<true>(pods, gr, nd, b, prm, query_blocks, blockIdx.x, query_blocks, nchunks, tk_p1, filter_waves, tk_done, tb + filter_blocks);
     } else if (param_blocks) {
       fast_query_thread<TS, false, false>(pods, gr, b, prm, blockIdx.x * kTblChunk + threadIdx.x, query_blocks * kTblChunk);
     } else {
@@ -1416,17 +1590,21 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsD
     class_slots_block<TS>(gr, b, prm, ckeys, cpres, kcap, blockIdx.x - query_blocks);
   } else if (blockIdx.x < query_blocks + param_blocks + tb) {
     const uint32_t x = blockIdx.x - query_blocks - param_blocks;
-    table_scan_block<TS, WHOLE>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0, gr, ckeys, cpres, kcap);
-    if constexpr (WHOLE) {                                     // minima performed, then count this block in (a block that timed out never does: the pod blocks time out too)
+    table_scan_block<TS, WHOLE>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0, gr, ckeys, cpres, kcap, direct);
+    if constexpr (WHOLE) {
+      if (!direct) {                                           // minima performed, then count this block in
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) spread_add(&b.ticket[kTkDone], blockIdx.x);
+      }
+    }
+  } else if constexpr (WHOLE) {
+    step_filter_block<TS>(gr, nd, bt, prm, ckeys, cpres, kcap, filter_waves, ustride, blockIdx.x - query_blocks - param_blocks - tb, filter_blocks, direct, tk_pods0, producers);
+    if (!direct) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0) spread_add(&b.ticket[kTkDone], blockIdx.x);
     }
-  } else if constexpr (WHOLE) {
-    step_filter_block<TS>(gr, nd, bt, prm, ckeys, cpres, kcap, filter_waves, ustride, blockIdx.x - query_blocks - param_blocks - tb, filter_blocks, tk_pods0, producers);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) spread_add(&b.ticket[kTkDone], blockIdx.x);
   } else {
     __shared__ uint32_t s_go;
     if (threadIdx.x == 0) {

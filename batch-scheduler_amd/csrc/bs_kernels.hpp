@@ -99,7 +99,10 @@ struct BatchDev {
   uint8_t* stage;
   int32_t* leader_raw;      // leader findMaxPG returned for this pod (valid iff ST_REACH6)
   uint32_t* first_row;      // [scan slots] min table row satisfying the slot's request (INF none)
-  unsigned long long* first_row64;  // [scan slots] the same as a 64-bit minimum keyed by ~batch_seq (k_fast_step_a's whole-step form: never reset)
+  unsigned long long* chunk_rec;    // [64 chunks][kRecStride] k_fast_step_a's whole-step form: the chunks' totals / first key rows as tagged 64-bit words (bs_fast.hpp)
+  unsigned long long* first_row64;  // [scan slots] whole-step form, large queues: first_row[] as a 64-bit minimum keyed by ~batch_seq (never reset)
+  unsigned long long* scan_rec;     // [256 class slots][kScanRecChunks] whole-step form: tag << 32 | first row of the slot inside the chunk
+  unsigned long long* feas_rec;     // [512 Filter slots][kFeasRecGroups] whole-step form: tag << 32 | feasible nodes of the slot in a group of node runs
   int64_t* qreq_s;          // [scan slots][LP] effective request (absent scalar -> INT64_MIN)
   uint32_t* qflags_s;       // [scan slots] bits 0..11 request key present, bits 16..27 "zero/absent" (passes w/o left key)
   uint32_t* qpos;           // [P] pod -> scan slot (valid iff ST_QUERY)

@@ -186,7 +186,7 @@ struct bs_ctx {
   // ---- batch scratch / outputs
   DevBuf d_first_elig, d_first_owner, d_first_reject, d_first_pod, d_cap_epoch;
   DevBuf d_epoch, d_nepochs, d_leader_epoch, d_panic_epoch;
-  DevBuf d_tcode, d_stage, d_leader_raw, d_first_row, d_first_row64, d_qreq_s, d_qflags_s, d_qpos;
+  DevBuf d_tcode, d_stage, d_leader_raw, d_first_row, d_first_row64, d_scan_rec, d_feas_rec, d_chunk_rec, d_qreq_s, d_qflags_s, d_qpos;
   DevBuf d_needed, d_qcount, d_ticket, d_desc;
   bool scratch_armed = false;
   bool side_ready = false;      // desc[] of the steady-state table is in place for the next batch   // per-group minima are INF (k_init ran, or the previous batch's k_tally re-armed them)
@@ -274,7 +274,7 @@ struct bs_ctx {
   bool step_a_on = true;
   uint32_t step_shares = 8;          // BS_STEP_SHARES: blocks that share one table chunk's class slots (class-slot form, cfg3: 2 / 4 / 8 / 16 shares = 25.1 / 20.4 / 19.05 / 20.9 us per step)
   uint32_t tk_pods = 0, tk_tab = 0;  // values of ticket[8] / ticket[9] the next k_fast_step_a starts from (never reset: wrap-safe differences)
-  uint32_t tk_p1 = 0, tk_done = 0;   // ... of ticket[10] / ticket[11] (form 3: the pod blocks' first halves, the scan / Filter blocks)
+  uint32_t tk_p1 = 0, tk_done = 0;   // ... of the spread counter at kTkP1 (form 3: the pod blocks' first halves); tk_done: of the counter at kTkDone (large queues: every table / Filter block adds once)
   bool last_step_a = false;
   uint32_t scan_share_override = 0, no_fuse_filter = 0, early_forced = 0, target_waves = 8192, filter_waves = 8192, collect_stats = 0;
   uint32_t general_waves = 4096;     // scan grid cap of the general chain (tools/cold_sweep.py)
@@ -455,6 +455,9 @@ BatchDev batch_dev(const bs_ctx* c) {
   b.leader_raw = c->d_leader_raw.as<int32_t>();
   b.first_row = c->d_first_row.as<uint32_t>();
   b.first_row64 = c->d_first_row64.as<unsigned long long>();
+  b.scan_rec = c->d_scan_rec.as<unsigned long long>();
+  b.feas_rec = c->d_feas_rec.as<unsigned long long>();
+  b.chunk_rec = c->d_chunk_rec.as<unsigned long long>();
   b.qreq_s = c->d_qreq_s.as<int64_t>();
   b.qflags_s = c->d_qflags_s.as<uint32_t>();
   b.qpos = c->d_qpos.as<uint32_t>();
@@ -1914,6 +1917,9 @@ static int reserve_slots(bs_ctx* c, bool run_filter) {
   int rc;
   HIPCHK(c, c->d_first_row.reserve((size_t)scan_cap * 4));
   if ((rc = reserve_filled(c, c->d_first_row64, (size_t)scan_cap * 8, 0xFF))) return rc;      // 64-bit minima keyed by ~batch_seq: born as "none", never reset
+  if ((rc = reserve_filled(c, c->d_scan_rec, (size_t)kStepSlotsMax * kScanRecChunks * 8, 0))) return rc;       // } tagged result words of the whole-step launch
+  if ((rc = reserve_filled(c, c->d_feas_rec, (size_t)2 * kStepSlotsMax * kFeasRecGroups * 8, 0))) return rc;   // } (tag = ~batch_seq, never 0)
+  if ((rc = reserve_filled(c, c->d_chunk_rec, (size_t)64 * kRecStride * 8, 0))) return rc;    // tagged words (tag = ~batch_seq, never 0)
   HIPCHK(c, c->d_qreq_s.reserve((size_t)scan_cap * c->LP * 8));
   HIPCHK(c, c->d_qflags_s.reserve((size_t)scan_cap * 4));
   HIPCHK(c, c->d_qtab_s.reserve((size_t)scan_cap * 4));
@@ -2090,17 +2096,17 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     }
     const uint32_t grid = qb + pb + nchunks * nshares + fblocks;
     // form 3: the pod blocks go on to the final verdicts inside the same launch (fast_final_block<true>) — one launch for the whole step
-    const uint32_t whole = (c->step_a_form >= 3u && pb && c->d_first_row64.p) ? 1u : 0u;
+    const uint32_t whole = (c->step_a_form >= 3u && pb && c->d_first_row64.p && c->d_scan_rec.p && c->d_feas_rec.p && c->d_chunk_rec.p) ? 1u : 0u;
     if ((k_known || whole) && (int)grid <= step_a_residency(c, whole != 0)) {
       TIMED(c, BS_KERNEL_QUERY, {
         launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks, qb, nshares, fblocks, c->tk_pods, c->tk_tab, pb,
                            c->d_ckeys.as<int64_t>(), c->d_cpres.as<uint32_t>(), c->pair_cap, whole, c->tk_p1, c->tk_done);
       });
       c->tk_pods += pb ? pb : qb;
-      c->tk_tab += nchunks;
+      if (!whole) c->tk_tab += nchunks;                              // (the whole-step form hands the chunk totals over as tagged words: no ticket)
       if (whole) {
         c->tk_p1 += qb;
-        c->tk_done += nchunks * nshares + fblocks;
+        if (qb > kGatherDirectBlocks) c->tk_done += nchunks * nshares + fblocks;   // (a small queue's producers leave tagged words, no counter)
       } else {
         TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
       }
@@ -2419,6 +2425,9 @@ static int batch_run_inner(bs_ctx* c, uint32_t stages) {
     if (c->d_pair_firstq.p) HIPCHK(c, hipMemsetAsync(c->d_pair_firstq.p, 0xFF, c->d_pair_firstq.cap, c->stream));
     if (c->d_first_reach.p) HIPCHK(c, hipMemsetAsync(c->d_first_reach.p, 0xFF, c->d_first_reach.cap, c->stream));
     if (c->d_first_row64.p) HIPCHK(c, hipMemsetAsync(c->d_first_row64.p, 0xFF, c->d_first_row64.cap, c->stream));
+    if (c->d_scan_rec.p) HIPCHK(c, hipMemsetAsync(c->d_scan_rec.p, 0, c->d_scan_rec.cap, c->stream));
+    if (c->d_feas_rec.p) HIPCHK(c, hipMemsetAsync(c->d_feas_rec.p, 0, c->d_feas_rec.cap, c->stream));
+    if (c->d_chunk_rec.p) HIPCHK(c, hipMemsetAsync(c->d_chunk_rec.p, 0, c->d_chunk_rec.cap, c->stream));
     if (c->d_gfirstq.p) HIPCHK(c, hipMemsetAsync(c->d_gfirstq.p, 0xFF, c->d_gfirstq.cap, c->stream));
     if (c->d_fd_event.p) HIPCHK(c, hipMemsetAsync(c->d_fd_event.p, 0xFF, c->d_fd_event.cap, c->stream));
     c->rekey_pending = false;

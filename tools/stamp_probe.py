@@ -25,7 +25,7 @@ import bench  # noqa: E402
 
 bsa = importlib.import_module("batch-scheduler_amd")
 soa = bsa.soa
-NAMES = {0: "k_pods_apply", 1: "A k_fast_query_tables / pod blocks of k_fast_step_a", 2: "B producer blocks of k_fast_scan_filter_final / table blocks of k_fast_step_a", 3: "C final blocks"}
+NAMES = {0: "k_pods_apply", 1: "A k_fast_query_tables / pod blocks of k_fast_step_a", 2: "B producer blocks of k_fast_scan_filter_final / table blocks of k_fast_step_a", 3: "C final blocks", 4: "F Filter blocks of the whole-step launch"}
 
 
 def main():
@@ -73,7 +73,7 @@ def main():
             if it >= 10:
                 recs.append(buf.copy())
     out = {}
-    kernels = [k for k in range(4) if any(r[k, :, 0].any() for r in recs)]
+    kernels = [k for k in range(5) if any(r[k, :, 0].any() for r in recs)]
     per = {k: [] for k in kernels}
     for r in recs:
         t0 = min(int(r[k, :, 0][r[k, :, 0] > 0].min()) for k in kernels)
