@@ -334,6 +334,21 @@ __device__ __forceinline__ void st_pub(T* p, T v) {
   if constexpr (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
 }
+// Host mirrors (pinned memory the host reads when the completion word arrives, latency mode).  BS_HOME_WT=1 (an experiment, off): stored write-through at
+// system scope, so that a block's "all my mirrors are out" would be s_waitcnt vmcnt(0) instead of final_tail's system-scope release fence.  Measured
+// (profiles/r06_home_wt_ab.txt): the resident cycle's wait goes from 31 to 95 us at cfg3 — system-scope stores cross PCIe lane by lane (60 000 small writes
+// instead of a few thousand combined ones).  What the fence's ~7 us are is the mirrors' own way home: 340 KB (per-pod arrays + Filter rows) at PCIe rate.
+#ifndef BS_HOME_WT
+#define BS_HOME_WT 0
+#endif
+template <typename T>
+__device__ __forceinline__ void st_home(T* p, T v) {
+#if BS_HOME_WT
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+  *p = v;
+#endif
+}
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ld_agent64(const void* p) {
   return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1051,6 +1066,8 @@ __device__ __forceinline__ void step_filter_block(const GroupsDev& gr, const Nod
     }
     s_cnt[wave_id()][lane_id()] = cnt;
     BS_STAMP_AT(4, 1, bx);
+    // latency mode, small queue: the rows this wave sent home must be out before the tagged word says the slot is complete (nobody drains for us here)
+    if (direct && b.h_rows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     BS_STAMP_AT(4, 2, bx);
     if (wave_id() == 0 && src < U) {
@@ -1149,12 +1166,14 @@ __device__ __forceinline__ void arm_tally(const GroupsDev& gr, const BatchDev& b
       if (b.gcount[g] == 0u) {
         const uint8_t rd = gr.matched[g] >= (uint32_t)(gr.min_member[g] - gr.status_scheduled[g]) ? 1 : 0;
         b.ready[g] = rd;
-        if (prm.host_tag) { b.h_admit[g] = 0; b.h_ready[g] = rd; }
+        if (prm.host_tag) { st_home(&b.h_admit[g], 0u); st_home(&b.h_ready[g], rd); }
       }
     }
   }
 }
 
+// WT: every mirror the calling kernel's blocks wrote went out through st_home (fast_final_block); otherwise the fence
+template <bool WT = false>
 __device__ __forceinline__ void final_tail(const BatchDev& b, const BatchParams& prm, uint32_t nblocks) {
   __shared__ uint32_t s_last;
   if (!prm.host_tag) return;
@@ -1164,18 +1183,22 @@ __device__ __forceinline__ void final_tail(const BatchDev& b, const BatchParams&
   // leave through eight XCDs' separate paths, the counter only says they left the CU, and the completion word of the last block
   // could overtake another XCD's mirrors — a host that copied the results out at once (bs_batch_read) saw the previous cycle's
   // values in a few of them, one run in three (tests/test_gpu_speculate.py::test_latency_mode_results_are_complete_when_the_word_arrives).  The release fence costs the latency mode about a microsecond.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  // (BS_HOME_WT=1, the experiment above: mirrors written through at system scope, "out" = s_waitcnt vmcnt(0), the word a relaxed system-scope store.)
+  if constexpr (WT && BS_HOME_WT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __syncthreads();
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&b.ticket[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1 ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&b.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(b.h_tag, prm.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if constexpr (WT && BS_HOME_WT) __hip_atomic_store(b.h_tag, prm.host_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(b.h_tag, prm.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 // grouped: the pod names a group of the loaded state (g valid); admit: it passes PreFilter and, if Filter ran, has a feasible node
+template <bool WT = false>
 __device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, bool grouped, uint32_t g, bool admit,
                                            uint32_t nblocks) {
   if (prm.do_tally && prm.do_ready) {
@@ -1211,13 +1234,13 @@ __device__ __forceinline__ void tally_tail(const GroupsDev& gr, const BatchDev& 
         const uint8_t rd = (ma + ad) >= (uint32_t)(mm - sc) ? 1 : 0;
         b.admit[g] = ad;
         b.ready[g] = rd;
-        if (prm.host_tag) { b.h_admit[g] = ad; b.h_ready[g] = rd; }
+        if (prm.host_tag) { st_home(&b.h_admit[g], ad); st_home(&b.h_ready[g], rd); }
       }
     }
   } else if (prm.do_tally) {
     wave_aggregated_add(b.admit, g, grouped && admit);
   }
-  final_tail(b, prm, nblocks);
+  final_tail<WT>(b, prm, nblocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1414,7 +1437,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
     const bool reached = i >= first_reach;
     const int32_t leader = reached ? leader_now : prm.sop_leader0;
     b.pf_leader[i] = leader;
-    if (prm.host_tag) { b.h_pf_code[i] = code; b.h_pf_first_k[i] = fk; b.h_pf_leader[i] = leader; }
+    if (prm.host_tag) { st_home(&b.h_pf_code[i], code); st_home(&b.h_pf_first_k[i], fk); st_home(&b.h_pf_leader[i], leader); }
     const bool pass = code != BS_PF_NOT_OWNED && BS_PF_IS_PASS(code);
     uint32_t feasible = 1u, slot = 0;
     uint8_t fl = BS_FL_NOT_RUN;
@@ -1434,7 +1457,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
     }
     b.fl_code[i] = fl;
     b.fflags[i] = (uint32_t)fl << 8;
-    if (prm.host_tag) { b.h_fl_code[i] = fl; b.h_fl_feasible[i] = prm.run_filter ? feasible : 0u; b.h_fl_slot[i] = slot; }
+    if (prm.host_tag) { st_home(&b.h_fl_code[i], fl); st_home(&b.h_fl_feasible[i], prm.run_filter ? feasible : 0u); st_home(&b.h_fl_slot[i], slot); }
     if (gi >= 0 && (uint32_t)gi < gr.g && pass && feasible > 0) admit = true;
     // BS_BATCH_FILTER_DENY: Filter fails on some node -> the group's first such pod (k_fd_apply takes it from here, bs_fdeny.hpp)
     if (prm.filter_deny && fl == BS_FL_EVALUATED && feasible < nd.n) atomicMin(&b.fd_event[gi], ((unsigned long long)prm.seq_inv << 32) | i);
@@ -1445,10 +1468,10 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
   }
   if (prm.host_tag && prm.run_filter) {             // per-row feasible counts of the slots in use
     const uint32_t U = min(2u * K, b.hstride);
-    for (uint32_t k = i; k < U; k += nblocks * 256u) b.h_feas[k] = gathered ? s_feask[INL ? k : 0u] : ld_agent(&b.fu_feas[k]);
+    for (uint32_t k = i; k < U; k += nblocks * 256u) st_home(&b.h_feas[k], gathered ? s_feask[INL ? k : 0u] : ld_agent(&b.fu_feas[k]));
   }
   BS_STAMP(3, 2);
-  if (!prm.filter_deny) tally_tail(gr, b, prm, grouped, grouped ? (uint32_t)gi0 : 0u, admit, nblocks);      // (else: k_fd_apply, bs_fdeny.hpp)
+  if (!prm.filter_deny) tally_tail<true>(gr, b, prm, grouped, grouped ? (uint32_t)gi0 : 0u, admit, nblocks);      // (else: k_fd_apply, bs_fdeny.hpp)
   BS_STAMP(3, 7);
 }
 

@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/..")
 bsa = importlib.import_module("batch-scheduler_amd")
 soa = bsa.soa
+if os.environ.get("BS_AB_LIB"):                      # A/B runs of build variants (tools/ubench/*.so)
+    bsa.capi.LIB_PATH = os.path.abspath(os.environ["BS_AB_LIB"])
 import bench  # noqa: E402  (make_pod_deltas: the same queue deltas the bench's resident cycle uses)
 
 
