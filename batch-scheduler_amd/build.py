@@ -51,13 +51,15 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(HOST_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB_PATH) for d in deps):
         return HOST_LIB_PATH
     cxx = shutil.which("g++") or "g++"
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB_PATH, *HOST_SRCS, "-L" + HERE, "-lbsched",
+    tmp = f"{HOST_LIB_PATH}.{os.getpid()}.tmp"          # linked beside the target, then renamed: another process (pytest -n) never loads half a file
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", tmp, *HOST_SRCS, "-L" + HERE, "-lbsched",
            "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("g++ failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, HOST_LIB_PATH)
     return HOST_LIB_PATH
 
 
@@ -122,12 +124,14 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
             if os.path.exists(_obj(src)) and any(f.startswith(src) for f in failed):
                 os.remove(_obj(src))
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *[_obj(src) for src in SOURCES], "-ldl"]
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *[_obj(src) for src in SOURCES], "-ldl"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
     if extra_flags:
         for src in SOURCES:                                   # objects of an experiment build must not be taken for the shipped ones
             os.remove(_obj(src))
