@@ -72,8 +72,7 @@ __global__ void k_pod_pairs(PodsDev pods, uint32_t G, const uint32_t* rep, const
                             int32_t* hinfo, uint32_t* gcount) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && hinfo) {
-    hinfo[4] = (int32_t)*kcount;
-    __hip_atomic_store(&hinfo[5], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&hinfo[4]), ((unsigned long long)(uint32_t)tag << 32) | *kcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // K + its tag in one store
   }
   {
     const int32_t gq = i < pods.p ? pods.group[i] : -1;
