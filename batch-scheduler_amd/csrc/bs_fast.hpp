@@ -735,11 +735,15 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
   const Shape<TS> sh(prm.S);
   const uint32_t L = sh.L(), S = sh.S(), LP = prm.LP;
   const uint32_t k = chunk * kTblChunk + threadIdx.x;
-  const bool valid = k < nd.m;
-  const uint32_t n = valid ? nd.kmap[k] : 0u;
+  // REGS (whole-step form): the table's rows are the NODES in list order, a node compareClusterResourceAndRequire skips (core.go:606-617) is a row that adds
+  // nothing and can never be the first covering row — the same running sums and the same first node as over the compacted rows (kmap), without the
+  // dependent trip through kmap here and without the one back from row to node in the pod blocks: a "row" of this form IS the node's list index
+  const bool in_range = REGS ? k < nd.n : k < nd.m;
+  const uint32_t n = REGS ? (in_range ? k : 0u) : (in_range ? nd.kmap[k] : 0u);
   const TableDesc d = *forced;
   const uint32_t fw = nd.fit[(size_t)d.cls * nd.fit_words + (n >> 5)];
   const uint8_t fl = nd.flags[n];
+  const bool valid = in_range && (!REGS || !(fl & BS_NODE_SKIP_MASK));
   const uint32_t ap = nd.apres[n], rp = nd.rpres[n];
   int64_t al[BS_MAX_LANES], rq[BS_MAX_LANES];
 #pragma unroll
@@ -1426,7 +1430,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
       if (denied) code = BS_PF_ERR_DENIED;
       else if (st & ST_QUERY) {
         if (row_q == BS_INF) { code = BS_PF_REJECT_RESERVE; fk = BS_K_NONE; }                // core.go:161-165
-        else fk = nd.kmap[row_q];
+        else fk = INL ? row_q : nd.kmap[row_q];          // (INL: the whole-step form's rows are node list indices already)
       }
     } else {
       code = BS_PF_NOT_OWNED;

@@ -2094,19 +2094,22 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       if (!c->dirs_ready && c->batch_since_pods && c->pairs_ready && c->rep_valid && c->have_groups && (rc = build_dirs(c))) return rc;
       if (c->dirs_ready) pb = cdiv(K, kTblChunk);
     }
-    const uint32_t grid = qb + pb + nchunks * nshares + fblocks;
-    // form 3: the pod blocks go on to the final verdicts inside the same launch (fast_final_block<true>) — one launch for the whole step
-    const uint32_t whole = (c->step_a_form >= 3u && pb && c->d_first_row64.p && c->d_scan_rec.p && c->d_feas_rec.p && c->d_chunk_rec.p) ? 1u : 0u;
+    // form 3: the pod blocks go on to the final verdicts inside the same launch (fast_final_block<true>) — one launch for the whole step; its table rows
+    // are the nodes in list order (skipped nodes are rows that add nothing), not the compacted rows
+    const uint32_t nch_nodes = std::max<uint32_t>(1, cdiv(N, 256));
+    const uint32_t whole = (c->step_a_form >= 3u && pb && nch_nodes <= 64 && c->d_first_row64.p && c->d_scan_rec.p && c->d_feas_rec.p && c->d_chunk_rec.p) ? 1u : 0u;
+    const uint32_t nchunks_s = whole ? nch_nodes : nchunks;
+    const uint32_t grid = qb + pb + nchunks_s * nshares + fblocks;
     if ((k_known || whole) && (int)grid <= step_a_residency(c, whole != 0)) {
       TIMED(c, BS_KERNEL_QUERY, {
-        launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks, qb, nshares, fblocks, c->tk_pods, c->tk_tab, pb,
+        launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks_s, qb, nshares, fblocks, c->tk_pods, c->tk_tab, pb,
                            c->d_ckeys.as<int64_t>(), c->d_cpres.as<uint32_t>(), c->pair_cap, whole, c->tk_p1, c->tk_done);
       });
       c->tk_pods += pb ? pb : qb;
-      if (!whole) c->tk_tab += nchunks;                              // (the whole-step form hands the chunk totals over as tagged words: no ticket)
+      if (!whole) c->tk_tab += nchunks_s;                              // (the whole-step form hands the chunk totals over as tagged words: no ticket)
       if (whole) {
         c->tk_p1 += qb;
-        if (qb > kGatherDirectBlocks) c->tk_done += nchunks * nshares + fblocks;   // (a small queue's producers leave tagged words, no counter)
+        if (qb > kGatherDirectBlocks) c->tk_done += nchunks_s * nshares + fblocks;   // (a small queue's producers leave tagged words, no counter)
       } else {
         TIMED(c, BS_KERNEL_RESOLVE, hipLaunchKernelGGL(k_fast_final, dim3(cdiv(P, 256)), dim3(256), 0, c->stream, pd, gr, nd, b, prm, cdiv(P, kTblChunk)));
       }

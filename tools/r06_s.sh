@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B of the resident step: tools/ubench/libbsched_prev.so (the previous commit, unity build) against the in-tree library, alternating
+# A/B of the resident step: tools/ubench/libbsched_fence.so (the previous commit, unity build) against the in-tree library, alternating
 R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p gpurun_out/r06_s
 for i in 1 2 3; do
   for A in "cfg3 tail" "cfg2 tail"; do
-    BS_AB_LIB=tools/ubench/libbsched_prev.so timeout 200 python tools/step_time.py $A 2>&1 | tail -1 | cut -c1-120
+    BS_AB_LIB=tools/ubench/libbsched_fence.so timeout 200 python tools/step_time.py $A 2>&1 | tail -1 | cut -c1-120
     timeout 200 python tools/step_time.py $A 2>&1 | tail -1 | cut -c1-90
   done
 done | tee gpurun_out/r06_s/step_times.txt
