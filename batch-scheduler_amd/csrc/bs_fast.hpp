@@ -679,12 +679,18 @@ __device__ __forceinline__ unsigned long long rows_cover(unsigned long long m, c
     asm volatile("s_mov_b64 exec, %[m]\n\tv_cmpx_ge_i64 vcc, %[a], %[r]\n\ts_mov_b64 %[m], exec\n\ts_mov_b64 exec, -1" : [m] "+s"(m) : [a] "v"(a[j]), [r] "v"(r[j]) : "vcc");
   return m;
 }
+#ifndef BS_SCAN_BALLOT
+#define BS_SCAN_BALLOT 1
+#endif
+// In-launch waits are bounded: kSpinBound looks (each an agent-scope load, about a microsecond) — a quarter of a second where a wait that goes well takes
+// tens of microseconds; then the context's error word is raised, the batch is void (BS_ERR_RETRY) and the context goes back to separate launches.
+constexpr uint32_t kSpinBound = 1u << 18;
 constexpr uint32_t kStepSlotsMax = 256;        // class slots the one-launch form handles (the latency regime: K <= 256)
 __device__ __forceinline__ bool step_wait(const uint32_t* word, uint32_t base, uint32_t need, int32_t* h_err) {
   uint32_t spins = 0;
   while ((uint32_t)(ld_agent(word) - base) < need) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1u << 24)) { if (h_err) __hip_atomic_store(h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+    if (++spins > kSpinBound) { if (h_err) __hip_atomic_store(h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
   }
   return true;
 }
@@ -714,7 +720,7 @@ __device__ __forceinline__ bool spread_wait(const uint32_t* words, uint32_t base
     v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     if ((uint32_t)(v - base) >= need) return true;
     __builtin_amdgcn_s_sleep(4);
-    if (++spins > (1u << 22)) { if (h_err && lane_id() == 0) __hip_atomic_store(h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+    if (++spins > kSpinBound) { if (h_err && lane_id() == 0) __hip_atomic_store(h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
   }
 }
 // REGS (the whole step in one launch, BS_STEP_A=3): the block derives its share's scan queries ITSELF from the class directory and the leader
@@ -723,7 +729,7 @@ __device__ __forceinline__ bool spread_wait(const uint32_t* words, uint32_t base
 template <int TS, bool REGS = false>
 __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const BatchDev& b, const BatchParams& prm, const TableDesc* forced, uint32_t chunk, uint32_t nchunks,
                                                  uint32_t share, uint32_t nshares, uint32_t pod_blocks, uint32_t tk_pods0, uint32_t tk_tab0, const GroupsDev& gr,
-                                                 const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap, bool direct = false) {
+                                                 const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap, bool direct = false, uint32_t forced_cls = 0) {
   __shared__ unsigned long long s_wtot[BS_MAX_LANES][4];
   __shared__ uint32_t s_kp[BS_MAX_SCALARS];
   __shared__ unsigned long long s_off[BS_MAX_LANES];
@@ -740,7 +746,9 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
   // dependent trip through kmap here and without the one back from row to node in the pod blocks: a "row" of this form IS the node's list index
   const bool in_range = REGS ? k < nd.n : k < nd.m;
   const uint32_t n = REGS ? (in_range ? k : 0u) : (in_range ? nd.kmap[k] : 0u);
-  const TableDesc d = *forced;
+  // (REGS: the steady table's descriptor is a function of its slot — fit class = slot - C, 70 % (leader_publish, core.go:161) — and the host knows the
+  // slot: it comes in the kernel arguments, not through a load the fit word would have to wait for)
+  const TableDesc d = REGS ? TableDesc{forced_cls, 0.7f} : *forced;
   const uint32_t fw = nd.fit[(size_t)d.cls * nd.fit_words + (n >> 5)];
   const uint8_t fl = nd.flags[n];
   const bool valid = in_range && (!REGS || !(fl & BS_NODE_SKIP_MASK));
@@ -891,7 +899,7 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
             if (s2 < S) { mine_ok = mine_ok && (uint32_t)(kw[s2] >> 32) == tagw; ckp[s2] = (uint32_t)kw[s2]; }
           }
           if (__ballot(!(mine_ok || ch >= nchunks)) == 0ull) { ok = true; break; }
-          if (spins > (1u << 22)) { if (b.h_err && ch == 0) __hip_atomic_store(b.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+          if (spins > kSpinBound) { if (b.h_err && ch == 0) __hip_atomic_store(b.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
           __builtin_amdgcn_s_sleep(2);
         }
         if (ch >= nchunks) {
@@ -980,7 +988,13 @@ __device__ __forceinline__ void table_scan_block(const NodesDev& nd, const Batch
       const uint32_t nab = ~(qf[u] >> 16) & smask;
       unsigned long long m = (qf[u] & 0x80000000u) ? 0ull : __ballot(valid && (nab & ~keyrow) == 0u);
       static_assert(TS >= 0 && TS <= 4, "k_fast_step_a is instantiated for 0..4 scalar lanes (run_fast: step_a_possible)");
+#if BS_SCAN_BALLOT
+      // one v_cmp_ge_i64 -> SGPR mask per resource lane, ANDed: no EXEC write, the four slots' compares are independent of each other
+#pragma unroll
+      for (uint32_t j = 0; j < 4u + (uint32_t)TS; ++j) m &= __ballot(fin[j] >= r[u][j]);
+#else
       m = rows_cover<4 + TS>(m, fin, r[u]);
+#endif
       if (m && lane_id() == 0) atomicMin(&s_first[t0 + u], row0 + (uint32_t)(__ffsll((long long)m) - 1));
     }
   }
@@ -1364,7 +1378,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
             }
           }
         }
-        const bool timed_out = spins > (1u << 20);
+        const bool timed_out = spins > kSpinBound / 2u;
         if (__syncthreads_and((andt == tagw && ort == tagw) || timed_out)) {
           if (threadIdx.x < K) s_rowk[threadIdx.x] = row;
 #pragma unroll
@@ -1380,7 +1394,7 @@ __device__ __forceinline__ void fast_final_block(const PodsDev& pods, const Grou
       uint32_t spins = 0;
       while (ld_agent(&b.ticket[1]) < producers) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24)) { if (b.h_err) __hip_atomic_store(b.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        if (++spins > kSpinBound) { if (b.h_err) __hip_atomic_store(b.h_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
       }
     }
   }
@@ -1586,7 +1600,7 @@ template <int TS, bool WHOLE>
 __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm, const TableDesc* forced,
                                                            uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks, uint32_t filter_waves,
                                                            uint32_t ustride, uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys,
-                                                           const uint32_t* cpres, uint32_t kcap, uint32_t tk_p1, uint32_t tk_done) {
+                                                           const uint32_t* cpres, uint32_t kcap, uint32_t tk_p1, uint32_t tk_done, uint32_t forced_cls) {
   BS_STAMP(1, 0);
   const uint32_t tb = nchunks * nshares;
   const uint32_t producers = param_blocks ? param_blocks : query_blocks;      // blocks the slots' ticket waits for
@@ -1616,7 +1630,7 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsD
     class_slots_block<TS>(gr, b, prm, ckeys, cpres, kcap, blockIdx.x - query_blocks);
   } else if (blockIdx.x < query_blocks + param_blocks + tb) {
     const uint32_t x = blockIdx.x - query_blocks - param_blocks;
-    table_scan_block<TS, WHOLE>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0, gr, ckeys, cpres, kcap, direct);
+    table_scan_block<TS, WHOLE>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0, gr, ckeys, cpres, kcap, direct, forced_cls);
     if constexpr (WHOLE) {
       if (!direct) {                                           // minima performed, then count this block in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

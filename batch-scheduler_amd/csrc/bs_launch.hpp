@@ -28,7 +28,7 @@ int fused_residency_query(const FastLaunch& c);
 void launch_fast_step_a(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                         const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
                         uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap,
-                        uint32_t whole, uint32_t tk_p1, uint32_t tk_done);
+                        uint32_t whole, uint32_t tk_p1, uint32_t tk_done, uint32_t forced_cls);
 int step_a_residency_query(const FastLaunch& c, bool whole);      // blocks of k_fast_scan_filter_final<S> the chip holds at once (0 = unknown)
 
 struct SeqDev;

@@ -273,6 +273,7 @@ struct bs_ctx {
   uint32_t step_a_form = 3;
   bool step_a_on = true;
   uint32_t step_shares = 8;          // BS_STEP_SHARES: blocks that share one table chunk's class slots (class-slot form, cfg3: 2 / 4 / 8 / 16 shares = 25.1 / 20.4 / 19.05 / 20.9 us per step)
+  uint32_t test_timeout_after = 0;   // BS_TEST_HANDOVER_TIMEOUT=n (test hook): the n-th one-launch step reports a timed-out hand-over as the device would
   uint32_t tk_pods = 0, tk_tab = 0;  // values of ticket[8] / ticket[9] the next k_fast_step_a starts from (never reset: wrap-safe differences)
   uint32_t tk_p1 = 0, tk_done = 0;   // ... of the spread counter at kTkP1 (form 3: the pod blocks' first halves); tk_done: of the counter at kTkDone (large queues: every table / Filter block adds once)
   bool last_step_a = false;
@@ -1104,6 +1105,7 @@ int bs_create(const bs_config* cfg, bs_ctx** out) {
   if (const char* e = std::getenv("BS_NO_FUSE_FILTER")) c->no_fuse_filter = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_NO_FUSE_FINAL")) c->no_fuse_final = std::atoi(e) ? 1u : 0u;
   if (const char* e = std::getenv("BS_TP_FILTER")) c->tp_filter = (uint32_t)std::min(8, std::max(0, std::atoi(e)));
+  if (const char* e = std::getenv("BS_TEST_HANDOVER_TIMEOUT")) c->test_timeout_after = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("BS_STEP_A")) { c->step_a_on = std::atoi(e) != 0; c->step_a_form = (uint32_t)std::atoi(e); }
   if (const char* e = std::getenv("BS_STEP_SHARES")) c->step_shares = (uint32_t)std::min(32, std::max(1, std::atoi(e)));
   if (const char* e = std::getenv("BS_TP_SHARE")) c->tp_share = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
@@ -2103,7 +2105,7 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     if ((k_known || whole) && (int)grid <= step_a_residency(c, whole != 0)) {
       TIMED(c, BS_KERNEL_QUERY, {
         launch_fast_step_a(fast_launch(c), dim3(grid), pd, gr, nd, b, bt, prm, forced, nchunks_s, qb, nshares, fblocks, c->tk_pods, c->tk_tab, pb,
-                           c->d_ckeys.as<int64_t>(), c->d_cpres.as<uint32_t>(), c->pair_cap, whole, c->tk_p1, c->tk_done);
+                           c->d_ckeys.as<int64_t>(), c->d_cpres.as<uint32_t>(), c->pair_cap, whole, c->tk_p1, c->tk_done, side_slot - c->C);
       });
       c->tk_pods += pb ? pb : qb;
       if (!whole) c->tk_tab += nchunks_s;                              // (the whole-step form hands the chunk totals over as tagged words: no ticket)
@@ -2115,6 +2117,10 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
       }
       c->launches = whole ? 1 : 2;
       c->last_step_a = true;
+      if (c->test_timeout_after && --c->test_timeout_after == 0 && c->h_info) {      // test hook: what a block whose wait ran out does (bs_fast.hpp, kSpinBound)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        ((volatile int32_t*)c->h_info)[12] = 1;
+      }
       if (prm.filter_deny && (rc = launch_filter_deny(c, pd, gr, nd, b, prm, true))) return rc;
       if (commit) {
         if (prm.filter_deny && (rc = launch_filter_deny_marks(c, b, prm, b.fast_reject))) return rc;

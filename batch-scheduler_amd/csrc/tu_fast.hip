@@ -136,15 +136,15 @@ template <int TS, bool WHOLE>
 static void launch_fast_step_a_s(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                                  const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
                                  uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap,
-                                 uint32_t tk_p1, uint32_t tk_done) {
+                                 uint32_t tk_p1, uint32_t tk_done, uint32_t forced_cls) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fast_step_a<TS, WHOLE>), grid, dim3(kTblChunk), 0, c.stream, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks,
-                     c.filter_waves, c.filter_slots_cap, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, tk_p1, tk_done);
+                     c.filter_waves, c.filter_slots_cap, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, tk_p1, tk_done, forced_cls);
 }
-#define BS_STEP_A_ARGS c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, tk_p1, tk_done
+#define BS_STEP_A_ARGS c, grid, pd, gr, nd, b, bt, prm, forced, nchunks, query_blocks, nshares, filter_blocks, tk_pods0, tk_tab0, param_blocks, ckeys, cpres, kcap, tk_p1, tk_done, forced_cls
 void launch_fast_step_a(const FastLaunch& c, dim3 grid, const PodsDev& pd, const GroupsDev& gr, const NodesDev& nd, const BatchDev& b, const BatchDev& bt,
                         const BatchParams& prm, const TableDesc* forced, uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks,
                         uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys, const uint32_t* cpres, uint32_t kcap,
-                        uint32_t whole, uint32_t tk_p1, uint32_t tk_done) {
+                        uint32_t whole, uint32_t tk_p1, uint32_t tk_done, uint32_t forced_cls) {
   switch (c.S * 2u + (whole ? 1u : 0u)) {
     case 0: launch_fast_step_a_s<0, false>(BS_STEP_A_ARGS); break;
     case 1: launch_fast_step_a_s<0, true>(BS_STEP_A_ARGS); break;

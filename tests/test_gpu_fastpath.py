@@ -267,3 +267,21 @@ def test_one_launch_form_of_the_step_equals_the_oracle(config, scenario, form, m
         exp3 = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(grown, soa.STAGE_ALL)
         for _ in range(2):
             assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp3, f"{config}/{scenario} one-launch step after new classes arrived")
+
+
+@pytest.mark.gpu
+def test_a_timed_out_hand_over_voids_the_batch_and_the_context_goes_back_to_separate_launches(monkeypatch, bsa, soa, orc):
+    """The in-launch waits of the one-launch step are bounded (bs_fast.hpp, kSpinBound): a block whose wait runs out raises the context's error word.  The
+    host's side of that, with the word raised by a test hook instead of a stuck GPU: the batch is void (BS_ERR_RETRY from the call that would have handed
+    its results out), the next bs_batch_run answers like the oracle again, and the context no longer takes the one-launch forms."""
+    monkeypatch.setenv("BS_TEST_HANDOVER_TIMEOUT", "2")            # the second one-launch step "times out"
+    nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "tail")
+    exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "first batch (two-launch chain)")
+        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "second batch (first one-launch step)")
+        with pytest.raises(bsa.capi.BsError) as e:
+            ctx.batch(soa.STAGE_ALL)                                # third batch = second one-launch step: void
+        assert e.value.status == -8                               # BS_ERR_RETRY (include/bsched.h)
+        for _ in range(3):
+            assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "after the time-out")
