@@ -11,6 +11,17 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# Property tests (hypothesis) draw the SAME examples on every run unless BS_HYPOTHESIS_RANDOM=1: a suite that is green here is green in the driver's run;
+# the random mode is for looking for new counter-examples (found ones are pinned with @example).
+try:
+    from hypothesis import settings as _hs
+    _hs.register_profile("fixed", derandomize=True, database=None)
+    _hs.register_profile("random", database=None)
+    _hs.load_profile("random" if os.environ.get("BS_HYPOTHESIS_RANDOM") == "1" else "fixed")
+except ImportError:                                   # (the tests that need it skip themselves)
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
 
