@@ -53,6 +53,7 @@ constexpr uint32_t kSeqWaitList = 512;     // waiting pods of the current gang k
 constexpr uint32_t kSeqHasRecord = 0x80000000u;   // in nwait[g]: the gang has been released in this pass (it has a release record)
 constexpr uint32_t kSeqCursorBits = 9;     // first-fit cursors in LDS: 512 direct-mapped entries (12 bytes each)
 constexpr uint32_t kSeqCursors = 1u << kSeqCursorBits;
+constexpr uint32_t kSeqPodWin = 32;        // pods whose (immutable) input fields are staged in LDS ahead of their turn
 #ifndef BS_SEQ_CACHE_MAX
 #define BS_SEQ_CACHE_MAX 4
 #endif
@@ -245,6 +246,12 @@ struct SeqShared {
   // barriers inside the search rely on.  An entry that was evicted only costs the next search of that class its head start.
   unsigned long long cur_kn[kSeqCursors];
   uint32_t cur_fc[kSeqCursors];
+  // the next kSeqPodWin pods' input fields (nothing the pass writes): one bulk fetch per window instead of half a dozen dependent
+  // trips to memory per pod — group, flags, fit class, present bits, request class, owner hash, the group's MinMember, request lanes
+  int64_t pw_req[BS_MAX_LANES][kSeqPodWin];
+  uint64_t pw_owner[kSeqPodWin];
+  int32_t pw_group[kSeqPodWin];
+  uint32_t pw_flags[kSeqPodWin], pw_cls[kSeqPodWin], pw_pres[kSeqPodWin], pw_pclass[kSeqPodWin], pw_mm[kSeqPodWin];
 #ifdef BS_SEQ_PROBE
   unsigned long long ph2[32], tl2;
 #endif
@@ -851,17 +858,52 @@ __device__ __forceinline__ void seq_find_max(const GroupsDev& gr, const SeqDev& 
   leader = (int32_t)cur;
 }
 
+// The input fields of pods i0 .. i0 + kSeqPodWin - 1 into LDS (the caller brackets it with barriers).  MinMember of the pod's group
+// rides along (one more dependent trip per WINDOW, not per pod); nothing here is written by the pass.
+template <int TS>
+__device__ __forceinline__ void seq_stage_pods(const PodsDev& pods, const GroupsDev& gr, const SeqDev& sq, SeqShared& sh_, uint32_t i0, Shape<TS> sh) {
+  const uint32_t P = pods.p, L = sh.L();
+  for (uint32_t e = threadIdx.x; e < kSeqPodWin * L; e += kSeqBlock) {
+    const uint32_t j = e / kSeqPodWin, w = e % kSeqPodWin, p = min(i0 + w, P - 1u);
+    sh_.pw_req[j][w] = pods.req[(size_t)j * P + p];
+  }
+  if (threadIdx.x < kSeqPodWin) {
+    const uint32_t w = threadIdx.x, p = min(i0 + w, P - 1u);
+    const int32_t g = pods.group[p];
+    sh_.pw_group[w] = g;
+    sh_.pw_flags[w] = pods.flags[p];
+    sh_.pw_cls[w] = pods.cls[p];
+    sh_.pw_pres[w] = pods.pres[p];
+    sh_.pw_owner[w] = pods.owner[p];
+    sh_.pw_pclass[w] = sq.pclass ? sq.pclass[p] : 0u;
+    sh_.pw_mm[w] = (g >= 0 && (uint32_t)g < gr.g) ? gr.min_member[g] : 0u;
+  }
+}
+// getPodResourceRequire(pod) from the staged fields (pod_require's rule: the lanes normalised through Add)
+template <int TS>
+__device__ __forceinline__ void seq_pod_require(const SeqShared& sh_, uint32_t w, Shape<TS> sh, uint32_t gate, Res& out) {
+  Res raw;
+#pragma unroll
+  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+    if (j < sh.L()) raw.v[j] = (int64_t)uni64((uint64_t)sh_.pw_req[j][w]);
+  raw.present = uni32(sh_.pw_pres[w]);
+  res_zero(out, sh);
+  res_add(out, raw, sh, gate);
+}
+
 // Everything the pass reads from one group, loaded in ONE round trip.  The state of the pod's own group and of the leader
 // then stays in registers (wave-uniform, every wave applies the same updates): consecutive pods of a gang, and pods that
 // reserve for the same leader, read nothing from global memory.
 struct SeqGroup {
   uint32_t flags, matched, sc, cls, head, nwait;
+  uint32_t mm;                   // Spec.MinMember (never written by the pass; fetched in the same trip)
   bool seen;                     // a pod of the gang has entered PreFilter in this pass (t_first is set)
   uint64_t occ;
   Res mr;
 };
 template <int TS>
-__device__ __forceinline__ void seq_group_load(const SeqDev& sq, uint32_t G, uint32_t g, Shape<TS> sh, SeqGroup& o) {
+__device__ __forceinline__ void seq_group_load(const SeqDev& sq, const GroupsDev& gr, uint32_t G, uint32_t g, Shape<TS> sh, SeqGroup& o) {
+  const uint32_t gmm = gr.min_member[g];
   const uint32_t f = seq_raw8(&sq.g_flags[g]), m = seq_raw32(&sq.g_matched[g]), s = seq_raw32(&sq.g_sc[g]), c = seq_raw32(&sq.g_cls[g]),
                  p = seq_raw32(&sq.g_mrpres[g]), h = seq_raw32(&sq.head[g]), nw = seq_raw32(&sq.nwait[g]);
   const uint64_t oc = seq_raw64(&sq.g_occ[g]), tf = seq_raw64(&sq.t_first[g]);
@@ -870,6 +912,7 @@ __device__ __forceinline__ void seq_group_load(const SeqDev& sq, uint32_t G, uin
   for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
     if (j < sh.L()) mr[j] = seq_raw64(&sq.g_minres[(size_t)j * G + g]);
   o.flags = uni32(f); o.matched = uni32(m); o.sc = uni32(s); o.cls = uni32(c); o.head = uni32(h); o.nwait = uni32(nw);
+  o.mm = uni32(gmm);
   o.occ = uni64(oc);
   o.seen = uni64(tf) != ~0ull;
 #pragma unroll
@@ -879,7 +922,7 @@ __device__ __forceinline__ void seq_group_load(const SeqDev& sq, uint32_t G, uin
 }
 template <int TS>
 __device__ __forceinline__ void seq_group_zero(SeqGroup& o, Shape<TS> sh) {
-  o.flags = o.matched = o.sc = o.cls = o.head = o.nwait = 0;
+  o.flags = o.matched = o.sc = o.cls = o.head = o.nwait = o.mm = 0;
   o.seen = false;
   o.occ = 0;
   res_zero(o.mr, sh);
@@ -966,19 +1009,18 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
   if (t0) { for (int k = 0; k < 32; ++k) sh_.ph2[k] = 0; sh_.tl2 = tl; }
 #endif
 
-  int32_t gi_next = P ? pods.group[0] : BS_POD_NOT_GROUPED;
-  uint32_t pflags_next = P ? pods.flags[0] : 0u;
   for (uint32_t i = 0; i < P; ++i) {
+    const uint32_t pw = i % kSeqPodWin;
+    if (pw == 0u) {                                          // the next window of pod fields (every wave is through with the last one)
+      if (i) lds_barrier();
+      seq_stage_pods(pods, gr, sq, sh_, i, sh);
+    }
     lds_barrier();                                           // keys / bounds / wait list as the previous pod left them
     BS_SEQ_T(6);
     BS_SEQ_P(0);
-    const int32_t gi = gi_next;
-    const uint32_t pflags = pflags_next;
-    {                                                        // the next pod's first fields are on their way while this one is decided
-      const uint32_t i1 = i + 1 < P ? i + 1 : i;
-      gi_next = pods.group[i1];
-      pflags_next = pods.flags[i1];
-    }
+    const int32_t gi = (int32_t)uni32((uint32_t)sh_.pw_group[pw]);
+    const uint32_t pflags = uni32(sh_.pw_flags[pw]);
+    const uint32_t pod_mm = uni32(sh_.pw_mm[pw]);            // MinMember of the pod's group (0 if it has none)
     const bool grouped = gi >= 0 && (uint32_t)gi < G;
     uint32_t code;
     uint32_t fk = BS_K_NOT_SCANNED;
@@ -996,12 +1038,12 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
         if (miss_own) {
           if (gi == ldr_of) { const uint32_t h = seq_raw32(&sq.head[gi]), nw = seq_raw32(&sq.nwait[gi]); const uint64_t tf = seq_raw64(&sq.t_first[gi]);
                               own = ldr; own.head = uni32(h); own.nwait = uni32(nw); own.seen = uni64(tf) != ~0ull; }
-          else seq_group_load(sq, G, (uint32_t)gi, sh, own);
+          else seq_group_load(sq, gr, G, (uint32_t)gi, sh, own);
           own_of = gi;
           wl_cnt = 0;
           wl_ok = (own.nwait & ~kSeqHasRecord) == 0;
         }
-        if (miss_ldr) { seq_group_load(sq, G, (uint32_t)sop_leader, sh, ldr); ldr_of = sop_leader; }
+        if (miss_ldr) { seq_group_load(sq, gr, G, (uint32_t)sop_leader, sh, ldr); ldr_of = sop_leader; }
       }
     }
     if (grouped && !own.seen) {
@@ -1019,11 +1061,11 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     else if (gflags & BS_GROUP_DENIED) code = BS_PF_ERR_DENIED;                                     // :105-110
     else {
       // fillOccupiedObj, core.go:477-512
-      const uint32_t mm = gr.min_member[gi];
+      const uint32_t mm = pod_mm;
       uint32_t nf = gflags;
-      if (!(gflags & BS_GROUP_HAS_POD)) { nf |= BS_GROUP_HAS_POD; own.cls = pods.cls[i]; }           // :486-488
-      if (!(gflags & BS_GROUP_HAS_MINRES)) { nf |= BS_GROUP_HAS_MINRES; pod_require(pods, i, sh, gate, own.mr); }   // :489-493
-      const uint64_t occ = own.occ, refs = pods.owner[i];
+      if (!(gflags & BS_GROUP_HAS_POD)) { nf |= BS_GROUP_HAS_POD; own.cls = uni32(sh_.pw_cls[pw]); }           // :486-488
+      if (!(gflags & BS_GROUP_HAS_MINRES)) { nf |= BS_GROUP_HAS_MINRES; seq_pod_require(sh_, pw, sh, gate, own.mr); }   // :489-493
+      const uint64_t occ = own.occ, refs = uni64(sh_.pw_owner[pw]);
       const bool take_owner = occ == 0 && refs != 0;                                                 // :494-501
       const bool occupied = occ != 0 && (refs == 0 || refs != occ);                                  // :503-510
       if (nf != gflags || take_owner) {
@@ -1065,7 +1107,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
           else {
             if (leader != gi && leader != ldr_of) {          // (the leader changed: one more round trip)
               BS_SEQ_FULL_BARRIER();
-              seq_group_load(sq, G, (uint32_t)leader, sh, ldr);
+              seq_group_load(sq, gr, G, (uint32_t)leader, sh, ldr);
               ldr_of = leader;
             }
             const uint32_t lmatched = leader == gi ? gmatched : ldr.matched;                         // :132-135
@@ -1087,7 +1129,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
               code = BS_PF_PASS_FIRST_FITS;
             } else if (leader == gi) code = BS_PF_PASS_IS_MAX;                                       // :150-155
             else {                                                                                   // :157-166
-              const uint32_t lmm = gr.min_member[leader];
+              const uint32_t lmm = ldr.mm;
               const int64_t nfin = (int64_t)lmm - (int64_t)lmatched;                                 // matched != 0: :778-779
               if (nfin > 0 && (ldr.flags & BS_GROUP_HAS_MINRES)) {
                 Res times;
@@ -1099,7 +1141,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
               }
               if (R.v[BS_LANE_PODS] == 0) R.v[BS_LANE_PODS] = (int64_t)lmm + 1;
               Res cur;
-              pod_require(pods, i, sh, gate, cur);                                                   // :158
+              seq_pod_require(sh_, pw, sh, gate, cur);                                               // :158
               res_add(R, cur, sh, gate);                                                             // :159
               scan = true;
               tcls = ldr.cls;
@@ -1129,7 +1171,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
           Res ms, cur;
           res_zero(ms, sh);
           res_add(ms, ldr.mr, sh, gate);                                                             // :526-527
-          pod_require(pods, i, sh, gate, cur);                                                       // :551
+          seq_pod_require(sh_, pw, sh, gate, cur);                                                   // :551
           res_add(cur, ms, sh, gate);                                                                // :552
           q.fl = BS_FL_EVALUATED;
 #pragma unroll
@@ -1197,10 +1239,10 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     uint32_t at = BS_INF;
     if (BS_PF_IS_PASS(code) && (grouped || gi == BS_POD_NOT_GROUPED)) {   // (a labelled pod of an unknown group, here on its lastPermittedPod entry:
       //                                                                   Permit answers "can not found pod group", core.go:275-278, and the framework forgets it)
-      q.pcls = pods.cls[i];
-      q.ppres = pods.pres[i];
+      q.pcls = uni32(sh_.pw_cls[pw]);
+      q.ppres = uni32(sh_.pw_pres[pw]);
 #pragma unroll
-      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) q.preq[j] = j < L ? pods.req[(size_t)j * P + i] : 0;
+      for (uint32_t j = 0; j < BS_MAX_LANES; ++j) q.preq[j] = j < L ? (int64_t)uni64((uint64_t)sh_.pw_req[j][pw]) : 0;
       if (prm.filter_deny && grouped) {
         // ---- Filter's TTL writes (core.go:170-191), every node of the list offered (the batch form's rule, bs_batch_run): a node whose
         // Filter fails — getLeftResource nil (:545-548) or neither case 2 nor case 3 (:562-563) — deny-lists the group (:183-185) for the
@@ -1243,7 +1285,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       const bool cur_ok = prm.use_cursor && mono && q.fl < 16u && q.fl != BS_FL_EVALUATED && q.pcls < nd.n_classes;
       uint32_t pc = 0, ce = 0, start = 0;
       if (cur_ok) {
-        pc = sq.pclass[i];
+        pc = uni32(sh_.pw_pclass[pw]);
         ce = ((pc * 2654435761u) ^ (q.pcls * 40503u)) >> (32 - kSeqCursorBits);
         const unsigned long long cv = sh_.cur_kn[ce];
         if ((uint32_t)(cv >> 32) == pc + 1u && sh_.cur_fc[ce] == q.pcls) start = (uint32_t)cv;
@@ -1321,7 +1363,7 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
       if (t0) sq.pod_node[i] = (int32_t)at;
     } else if (at != BS_INF) {
       // ---- Permit, core.go:268-309.  Every wave applies the update to its copy of the group; thread 0 writes it out.
-      const uint32_t mm = gr.min_member[gi];
+      const uint32_t mm = pod_mm;
       const uint32_t m1 = gmatched + 1u;                                                             // :290
       const bool ready = m1 >= (uint32_t)(mm - gsc);                                                 // :303
       // sendStartScheduleSignal -> StartBatchSchedule (batchscheduler.go:254-344) releases — unless the phase is none of PreScheduling /
