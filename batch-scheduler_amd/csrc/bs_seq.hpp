@@ -53,6 +53,7 @@ constexpr uint32_t kSeqWaitList = 512;     // waiting pods of the current gang k
 constexpr uint32_t kSeqHasRecord = 0x80000000u;   // in nwait[g]: the gang has been released in this pass (it has a release record)
 constexpr uint32_t kSeqCursorBits = 9;     // first-fit cursors in LDS: 512 direct-mapped entries (12 bytes each)
 constexpr uint32_t kSeqCursors = 1u << kSeqCursorBits;
+constexpr uint32_t kSeqResultThread = kSeqWaves > 1 ? 64u : 0u;   // the thread that writes a pod's PreFilter results
 constexpr uint32_t kSeqPodWin = 32;        // pods whose (immutable) input fields are staged in LDS ahead of their turn
 #ifndef BS_SEQ_CACHE_MAX
 #define BS_SEQ_CACHE_MAX 4
@@ -897,7 +898,7 @@ __device__ __forceinline__ void seq_pod_require(const SeqShared& sh_, uint32_t w
 struct SeqGroup {
   uint32_t flags, matched, sc, cls, head, nwait;
   uint32_t mm;                   // Spec.MinMember (never written by the pass; fetched in the same trip)
-  bool seen;                     // a pod of the gang has entered PreFilter in this pass (t_first is set)
+  uint32_t seen;                 // a pod of the gang has entered PreFilter in this pass (t_first is set); a word, not a bool: no padding to copy
   uint64_t occ;
   Res mr;
 };
@@ -1335,13 +1336,14 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
               if (drop) slot_key[c] = BS_INF;                // summarised afresh at its next use
               else {
                 for (uint32_t t = ta + threadIdx.x; t < ch.T; t += kSeqBlock) {       // the node's tile (its total) and every tile behind it (their offsets)
+                  unsigned long long* pb = (t == ta ? ch.tt : ch.off) + (size_t)c * L * ch.T + t;
+                  unsigned long long cur[BS_MAX_LANES];      // every lane's word fetched before the first is written back (one LDS latency, not L)
 #pragma unroll
-                  for (uint32_t j = 0; j < BS_MAX_LANES; ++j) {
-                    if (j < L && dlt[j] != 0) {
-                      unsigned long long* pw = (t == ta ? ch.tt : ch.off) + ((size_t)c * L + j) * ch.T + t;
-                      *pw -= (unsigned long long)dlt[j];
-                    }
-                  }
+                  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+                    if (j < L) cur[j] = pb[(size_t)j * ch.T];
+#pragma unroll
+                  for (uint32_t j = 0; j < BS_MAX_LANES; ++j)
+                    if (j < L) pb[(size_t)j * ch.T] = cur[j] - (unsigned long long)dlt[j];
                 }
               }
             }
@@ -1352,12 +1354,12 @@ __global__ __launch_bounds__(kSeqBlock, 1) void k_seq_pass(PodsDev pods, GroupsD
     BS_SEQ_T(4);
     BS_SEQ_P(14);
     if (deny) { gflags |= BS_GROUP_DENIED; own.flags = gflags; }
-    if (t0) {
+    if (threadIdx.x == kSeqResultThread) {                  // write-only results: not wave 0, whose thread 0 has the group and node bookkeeping to do
       sq.pf_code[i] = (uint8_t)code;
       if (sq.pf_first_k) sq.pf_first_k[i] = fk;
       if (sq.pf_leader) sq.pf_leader[i] = sop_leader;
-      if (deny) sq.g_flags[gi] = (uint8_t)gflags;
     }
+    if (t0 && deny) sq.g_flags[gi] = (uint8_t)gflags;
     BS_SEQ_P(15);
     if (at != BS_INF && !grouped) {                          // core.go:269-272: Permit lets it through at once
       if (t0) sq.pod_node[i] = (int32_t)at;
