@@ -54,7 +54,10 @@ constexpr uint32_t kSeqHasRecord = 0x80000000u;   // in nwait[g]: the gang has b
 constexpr uint32_t kSeqCursorBits = 9;     // first-fit cursors in LDS: 512 direct-mapped entries (12 bytes each)
 constexpr uint32_t kSeqCursors = 1u << kSeqCursorBits;
 constexpr uint32_t kSeqResultThread = kSeqWaves > 1 ? 64u : 0u;   // the thread that writes a pod's PreFilter results
-constexpr uint32_t kSeqPodWin = 32;        // pods whose (immutable) input fields are staged in LDS ahead of their turn
+#ifndef BS_SEQ_POD_WIN
+#define BS_SEQ_POD_WIN 64
+#endif
+constexpr uint32_t kSeqPodWin = BS_SEQ_POD_WIN;        // pods whose (immutable) input fields are staged in LDS ahead of their turn
 #ifndef BS_SEQ_CACHE_MAX
 #define BS_SEQ_CACHE_MAX 4
 #endif
