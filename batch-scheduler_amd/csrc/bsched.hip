@@ -2089,8 +2089,9 @@ static int run_fast(bs_ctx* c, uint32_t stages) {
     const uint32_t K = k_step;
     const uint32_t nshares = std::max<uint32_t>(1, std::min<uint32_t>(c->step_shares, cdiv(K, 8)));
     const uint32_t fblocks = run_filter ? cdiv(std::min<uint32_t>(c->filter_waves, cdiv(2 * K, 64) * std::max<uint32_t>(1, cdiv(W, 2))), 4) : 0u;
-    // the class-slot form needs the class directory (ckeys / cpres: class id -> request lanes).  It is built once per derivation of the queue — like bs_pods_apply's first call — and only for a queue that
-    // is scored a SECOND time (a caller that re-uploads its queue every cycle would pay a kernel and a stream wait per cycle for nothing).
+    // the class-slot form needs the class directory (ckeys / cpres: class id -> request lanes).  It is built once per derivation of the queue — like bs_pods_apply's first call — and only when the
+    // queue's classes and pairs are already resolved on the host (pairs_ready / rep_valid: the pod load's class count has landed; never waited for here): a caller that re-uploads its queue and
+    // scores it at once takes the two-launch chain and pays neither the directory kernel nor a stream wait.  So the FIRST batch over a fresh queue is of either form (both equal the oracle).
     uint32_t pb = 0;
     if (c->step_a_form >= 2u) {
       if (!c->dirs_ready && c->batch_since_pods && c->pairs_ready && c->rep_valid && c->have_groups && (rc = build_dirs(c))) return rc;

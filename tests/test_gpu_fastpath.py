@@ -278,10 +278,18 @@ def test_a_timed_out_hand_over_voids_the_batch_and_the_context_goes_back_to_sepa
     nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "tail")
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
-        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "first batch (two-launch chain)")
-        assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "second batch (first one-launch step)")
-        with pytest.raises(bsa.capi.BsError) as e:
-            ctx.batch(soa.STAGE_ALL)                                # third batch = second one-launch step: void
-        assert e.value.status == -8                               # BS_ERR_RETRY (include/bsched.h)
+        # Which batch is the second one-launch step depends on a race the library leaves open on purpose: the FIRST batch over a fresh queue takes the
+        # one-launch form only if the pod load's class count has already landed on the host (it never waits for it) — so the void batch is the second
+        # or the third.  Every batch in front of it answers like the oracle.
+        void_at = None
+        for k in range(3):
+            try:
+                got = ctx.batch(soa.STAGE_ALL)
+            except bsa.capi.BsError as e:
+                assert e.status == -8                               # BS_ERR_RETRY (include/bsched.h)
+                void_at = k
+                break
+            assert_batch_equal(got, exp, f"batch {k} (in front of the time-out)")
+        assert void_at in (1, 2), void_at
         for _ in range(3):
             assert_batch_equal(ctx.batch(soa.STAGE_ALL), exp, "after the time-out")
