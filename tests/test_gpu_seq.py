@@ -80,6 +80,19 @@ def test_seq_pass_random_object_scenes(seed, filter_on, bsa, soa, orc):
         check_pass(ctx, s, soa, f"seed {seed}")
 
 
+@pytest.mark.parametrize("n_pods", [1, 2, 63, 64, 65, 127, 128, 129])
+@pytest.mark.parametrize("seed", [4201, 4202, 4206])
+def test_seq_pass_queue_lengths_around_the_staging_window(seed, n_pods, bsa, soa, orc):
+    """k_seq_pass stages the input fields of 64 pods at a time in LDS (bs_seq.hpp, kSeqPodWin): queues that end in front of, at and just behind a window
+    boundary (the last window is ragged: its tail slots repeat the last pod and are never read)"""
+    st = soa.STAGE_PREFILTER | soa.STAGE_TALLY | soa.STAGE_FILTER
+    nodes, fit, groups, pods = gang_scene(seed, soa)
+    pods = pods.take(np.arange(min(n_pods, pods.p)))
+    s = oracle_pass(orc, nodes, fit, groups, pods, st)
+    with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
+        check_pass(ctx, s, soa, f"seed {seed}, {n_pods} pods")
+
+
 @pytest.mark.parametrize("seed", range(4300, 4330))
 def test_seq_pass_raw_edge_scenes(seed, bsa, soa, orc):
     """the unshaped scenes: nil / unschedulable / taint-error nodes, missing groups, permitted pods, MinMember 0 (the uint32
