@@ -401,11 +401,13 @@ __device__ __forceinline__ uint32_t filter_slot_values(const Res& cur_in, const 
 }
 template <int TS, bool PUB = false>
 __device__ __forceinline__ void filter_slot_from(const BatchDev& b, const BatchParams& prm, const Res& cur_in, const LeaderPre& lp, Shape<TS> sh, uint32_t gate,
-                                                 uint32_t slot) {
+                                                 uint32_t slot, bool zero_feas = true) {
   if (!lp.have_mr) return;                                           // PASS_NO_MINRES (core.go:542-544): no slot to evaluate
   int64_t R[4], M[4];
   const uint32_t ff = filter_slot_values(cur_in, lp, sh, gate, R, M);
-  st_pub<PUB>(&b.fu_feas[slot], 0u);
+  // zero_feas = false: the whole-step launch of a small queue — its pod blocks STORE every slot's count at their end and wait for nobody, so a zero
+  // written here by a block that happened to run late would be the value that stays (k_fd_apply and bs_batch_read read fu_feas[] behind the launch)
+  if (zero_feas) st_pub<PUB>(&b.fu_feas[slot], 0u);
   int64_t* dst2 = b.uparams + (size_t)slot * 8;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { st_pub<PUB>(&dst2[j], R[j]); st_pub<PUB>(&dst2[4 + j], M[j]); }
@@ -1112,8 +1114,14 @@ __device__ __forceinline__ void step_filter_block(const GroupsDev& gr, const Nod
 // Filter lane, not an answer.
 template <int TS>
 __device__ __forceinline__ void class_slots_block(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, const int64_t* ckeys, const uint32_t* cpres,
-                                                  uint32_t kcap, uint32_t blk) {
+                                                  uint32_t kcap, uint32_t blk, bool zero_feas) {
   const Shape<TS> sh(prm.S);
+#ifdef BS_TEST_LATE_CLASS_SLOTS   // experiment builds only (tools/r06_flaky2.sh): this block runs as late as a busy GPU could make it
+  for (int spin = 0; spin < BS_TEST_LATE_CLASS_SLOTS; ++spin) __builtin_amdgcn_s_sleep(127);
+#ifdef BS_TEST_OLD_ZERO
+  zero_feas = true;
+#endif
+#endif
   const uint32_t gate = prm.eph_gate, K = prm.k_host ? prm.k_host : *b.kclass;        // (K not on the host yet: the grid was sized for a bound, see run_fast)
   const uint32_t c = blk * kTblChunk + threadIdx.x;
   Res raw;                                                                                 // (the class's key: asked for before the leader chain, which is two dependent trips)
@@ -1147,8 +1155,8 @@ __device__ __forceinline__ void class_slots_block(const GroupsDev& gr, const Bat
       st_pub<true>(&b.qstamp_s[c], prm.stamp);
     }
     if (prm.run_filter) {
-      if (leader0 >= 0) filter_slot_from<TS, true>(b, prm, cur, lp0, sh, gate, c);
-      if (prm.sop_leader0 >= 0) filter_slot_from<TS, true>(b, prm, cur, lp1, sh, gate, c + K);
+      if (leader0 >= 0) filter_slot_from<TS, true>(b, prm, cur, lp0, sh, gate, c, zero_feas);
+      if (prm.sop_leader0 >= 0) filter_slot_from<TS, true>(b, prm, cur, lp1, sh, gate, c + K, zero_feas);
     }
   }
   BS_STAMP(1, 4);
@@ -1627,7 +1635,7 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsD
       if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&b.ticket[kTkSlots], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else if (blockIdx.x < query_blocks + param_blocks) {
-    class_slots_block<TS>(gr, b, prm, ckeys, cpres, kcap, blockIdx.x - query_blocks);
+    class_slots_block<TS>(gr, b, prm, ckeys, cpres, kcap, blockIdx.x - query_blocks, !(WHOLE && direct));
   } else if (blockIdx.x < query_blocks + param_blocks + tb) {
     const uint32_t x = blockIdx.x - query_blocks - param_blocks;
     table_scan_block<TS, WHOLE>(nd, bt, prm, forced, x / nshares, nchunks, x % nshares, nshares, producers, tk_pods0, tk_tab0, gr, ckeys, cpres, kcap, direct, forced_cls);

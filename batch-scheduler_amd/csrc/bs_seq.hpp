@@ -53,7 +53,10 @@ constexpr uint32_t kSeqWaitList = 512;     // waiting pods of the current gang k
 constexpr uint32_t kSeqHasRecord = 0x80000000u;   // in nwait[g]: the gang has been released in this pass (it has a release record)
 constexpr uint32_t kSeqCursorBits = 9;     // first-fit cursors in LDS: 512 direct-mapped entries (12 bytes each)
 constexpr uint32_t kSeqCursors = 1u << kSeqCursorBits;
-constexpr uint32_t kSeqResultThread = kSeqWaves > 1 ? 64u : 0u;   // the thread that writes a pod's PreFilter results
+#ifndef BS_SEQ_RESULT_WAVE
+#define BS_SEQ_RESULT_WAVE 1
+#endif
+constexpr uint32_t kSeqResultThread = kSeqWaves > BS_SEQ_RESULT_WAVE ? 64u * BS_SEQ_RESULT_WAVE : 0u;   // the thread that writes a pod's PreFilter results
 #ifndef BS_SEQ_POD_WIN
 #define BS_SEQ_POD_WIN 64
 #endif
