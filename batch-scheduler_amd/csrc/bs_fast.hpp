@@ -1116,11 +1116,8 @@ template <int TS>
 __device__ __forceinline__ void class_slots_block(const GroupsDev& gr, const BatchDev& b, const BatchParams& prm, const int64_t* ckeys, const uint32_t* cpres,
                                                   uint32_t kcap, uint32_t blk, bool zero_feas) {
   const Shape<TS> sh(prm.S);
-#ifdef BS_TEST_LATE_CLASS_SLOTS   // experiment builds only (tools/r06_flaky2.sh): this block runs as late as a busy GPU could make it
-  for (int spin = 0; spin < BS_TEST_LATE_CLASS_SLOTS; ++spin) __builtin_amdgcn_s_sleep(127);
-#ifdef BS_TEST_OLD_ZERO
+#ifdef BS_TEST_OLD_ZERO            // experiment builds only (tools/r06_flaky2.sh): the behaviour before the fix described at filter_slot_from
   zero_feas = true;
-#endif
 #endif
   const uint32_t gate = prm.eph_gate, K = prm.k_host ? prm.k_host : *b.kclass;        // (K not on the host yet: the grid was sized for a bound, see run_fast)
   const uint32_t c = blk * kTblChunk + threadIdx.x;
@@ -1611,6 +1608,12 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsD
                                                            const uint32_t* cpres, uint32_t kcap, uint32_t tk_p1, uint32_t tk_done, uint32_t forced_cls) {
   BS_STAMP(1, 0);
   const uint32_t tb = nchunks * nshares;
+#ifdef BS_TEST_LATE_ROLE             // experiment builds only (tools/r06_flaky2.sh, profiles/r06_late_class_slots_race.txt): the blocks of ONE role — 0 pod blocks, 1 class-slot
+  {                                  // block, 2 table blocks, 3 Filter blocks — start ~70 us late, as a busy GPU could make them: every hand-over has to hold, only the time may change
+    const int role = blockIdx.x < query_blocks ? 0 : blockIdx.x < query_blocks + param_blocks ? 1 : blockIdx.x < query_blocks + param_blocks + tb ? 2 : 3;
+    if (role == BS_TEST_LATE_ROLE) for (int spin = 0; spin < 20; ++spin) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   const uint32_t producers = param_blocks ? param_blocks : query_blocks;      // blocks the slots' ticket waits for
   // WHOLE: how the scan / Filter results reach the pod blocks.  A few pod blocks (<= kGatherDirectBlocks) poll the result words themselves (tagged, one
   // writer each: no counter, no drain, the poll is the fetch — cfg2: 13.1 -> 12.0 us per step); with forty of them polling the same 40 KB at the memory
