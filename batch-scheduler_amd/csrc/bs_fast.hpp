@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter_final(PodsDev pods, Gr
 //   table blocks  derive their share's scan queries themselves (table_scan_block<TS, true>): they wait for the chunk totals only
 //   Filter blocks derive their tile's slots themselves (class directory + leaders -> filter_slot_values), run the item on registers, and only their
 //                 closing add to fu_feas[] waits for the class-slot block (which still publishes every slot for whoever reads them after the launch,
-//                 and zeroes those counters)
+//                 and zeroes those counters — for a large queue only: a small queue's pod blocks store the counts themselves, see filter_slot_from)
 template <int TS, bool WHOLE>
 __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsDev gr, NodesDev nd, BatchDev b, BatchDev bt, BatchParams prm, const TableDesc* forced,
                                                            uint32_t nchunks, uint32_t query_blocks, uint32_t nshares, uint32_t filter_blocks, uint32_t filter_waves,

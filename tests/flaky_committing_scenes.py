@@ -1,5 +1,5 @@
-"""Round 6 debugging aid: tests/test_gpu_filter_deny.py::test_committing_batches[steady], a few seeds many times over; prints which rounds differ from the
-oracle and in what (run from the repo root on the GPU box)."""
+"""Round 6 debugging aid (test infrastructure: it uses the oracle, so it lives under tests/): tests/test_gpu_filter_deny.py::test_committing_batches[steady], a few seeds
+many times over, optionally against a build variant (BS_AB_LIB); prints which rounds differ from the oracle and in what.  Driven by tools/r06_flaky2.sh on the GPU box."""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -9,5 +9,5 @@
 cd $GRAFT_REPO_ROOT
 S=$(python -c "print(','.join(str(s) for s in range(7000,7100)))")
 for lib in tools/ubench/ab/libbsched_late_old.so tools/ubench/ab/libbsched_late_new.so ""; do
-  echo "lib=${lib:-shipped}: $(BS_AB_LIB=$lib timeout 600 python tools/r06_flaky2.py 2 $S 2>&1 | grep -v "^info" | tail -4 | cut -c1-330)"
+  echo "lib=${lib:-shipped}: $(BS_AB_LIB=$lib timeout 600 python tests/flaky_committing_scenes.py 2 $S 2>&1 | grep -v "^info" | tail -4 | cut -c1-330)"
 done
