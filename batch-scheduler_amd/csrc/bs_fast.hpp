@@ -1576,6 +1576,12 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter_final(PodsDev pods, Gr
                                                                 uint32_t ustride, uint32_t query_blocks) {
   __shared__ int64_t s_rows[4][64][4 + S];
   const uint32_t producers = scan_blocks + filter_blocks;
+#ifdef BS_TEST_LATE_ROLE_B           // experiment builds only (see BS_TEST_LATE_ROLE at k_fast_step_a): 0 scan blocks, 1 Filter blocks, 2 final blocks start ~70 us late
+  {
+    const int role = blockIdx.x < scan_blocks ? 0 : blockIdx.x < producers ? 1 : 2;
+    if (role == BS_TEST_LATE_ROLE_B) for (int spin = 0; spin < 20; ++spin) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   if (blockIdx.x < producers) {
     BS_STAMP(2, 0);
     if (blockIdx.x < scan_blocks)

@@ -275,6 +275,7 @@ def test_a_timed_out_hand_over_voids_the_batch_and_the_context_goes_back_to_sepa
     host's side of that, with the word raised by a test hook instead of a stuck GPU: the batch is void (BS_ERR_RETRY from the call that would have handed
     its results out), the next bs_batch_run answers like the oracle again, and the context no longer takes the one-launch forms."""
     monkeypatch.setenv("BS_TEST_HANDOVER_TIMEOUT", "2")            # the second one-launch step "times out"
+    monkeypatch.delenv("BS_STEP_A", raising=False)                  # (the library's default forms: a suite run under BS_STEP_A=0 has no one-launch step to time out)
     nodes, fit, groups, pods, _ = bsa.synth.make("cfg2", "tail")
     exp = orc.Sop(orc.Snapshot(nodes, fit), groups).batch(pods, soa.STAGE_ALL)
     with load_ctx(bsa, nodes, fit, groups, pods) as ctx:
