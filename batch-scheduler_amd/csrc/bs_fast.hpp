@@ -687,6 +687,15 @@ __device__ __forceinline__ unsigned long long rows_cover(unsigned long long m, c
 // In-launch waits are bounded: kSpinBound looks (each an agent-scope load, about a microsecond) — a quarter of a second where a wait that goes well takes
 // tens of microseconds; then the context's error word is raised, the batch is void (BS_ERR_RETRY) and the context goes back to separate launches.
 constexpr uint32_t kSpinBound = 1u << 18;
+// Experiment builds only (-DBS_TEST_CHAOS, profiles/r06_late_class_slots_race.txt): every block of the kernels that hand data over inside a launch starts 0 .. ~50 us
+// late, a different amount per block and launch — what a busy GPU can do to block order.  Results must not change; only the time may.
+__device__ __forceinline__ void test_chaos_delay() {
+#ifdef BS_TEST_CHAOS
+  uint32_t h = (blockIdx.x + 1u) * 2654435761u ^ (uint32_t)wall_clock64() * 40503u;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  for (uint32_t s = 0; s < (h & 15u); ++s) __builtin_amdgcn_s_sleep(127);
+#endif
+}
 constexpr uint32_t kStepSlotsMax = 256;        // class slots the one-launch form handles (the latency regime: K <= 256)
 __device__ __forceinline__ bool step_wait(const uint32_t* word, uint32_t base, uint32_t need, int32_t* h_err) {
   uint32_t spins = 0;
@@ -1576,6 +1585,7 @@ __global__ __launch_bounds__(256) void k_fast_scan_filter_final(PodsDev pods, Gr
                                                                 uint32_t ustride, uint32_t query_blocks) {
   __shared__ int64_t s_rows[4][64][4 + S];
   const uint32_t producers = scan_blocks + filter_blocks;
+  test_chaos_delay();
 #ifdef BS_TEST_LATE_ROLE_B           // experiment builds only (see BS_TEST_LATE_ROLE at k_fast_step_a): 0 scan blocks, 1 Filter blocks, 2 final blocks start ~70 us late
   {
     const int role = blockIdx.x < scan_blocks ? 0 : blockIdx.x < producers ? 1 : 2;
@@ -1613,6 +1623,7 @@ __global__ __launch_bounds__(kTblChunk) void k_fast_step_a(PodsDev pods, GroupsD
                                                            uint32_t ustride, uint32_t tk_pods0, uint32_t tk_tab0, uint32_t param_blocks, const int64_t* ckeys,
                                                            const uint32_t* cpres, uint32_t kcap, uint32_t tk_p1, uint32_t tk_done, uint32_t forced_cls) {
   BS_STAMP(1, 0);
+  test_chaos_delay();
   const uint32_t tb = nchunks * nshares;
 #ifdef BS_TEST_LATE_ROLE             // experiment builds only (tools/r06_flaky2.sh, profiles/r06_late_class_slots_race.txt): the blocks of ONE role — 0 pod blocks, 1 class-slot
   {                                  // block, 2 table blocks, 3 Filter blocks — start ~70 us late, as a busy GPU could make them: every hand-over has to hold, only the time may change
